@@ -1,0 +1,497 @@
+"""CPU oracle for the TuneMPC convexify() hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the numpy restatement of the reference algorithm
+(`/root/reference/tunempc/convexifier.py`) that the HIP path is checked against.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it.  The product (`tunempc_amd`) never does.
+
+PARITY STATUS: **parity unpinned** against the reference stack.  The reference
+hands its SDP to PICOS -> CVXOPT/MOSEK (`convexifier.py:29,363`), which are
+un-vendored third-party packages (picos==1.2.0.post32, `setup.py:52`; Mosek 9.0.98,
+`README.md:34`) that are not installed here, and the reference's own tests hold no
+golden vector for this path.  What *is* pinned:
+  * the problem definition (`convexifier.py:213-357`), scaling (`:374-401`),
+    un-scaling and supplement reconstruction (`:403-435`, `:165-211`), the status
+    rule (`:437-456`), the step/exception logic (`:36-163`) -- restated 1:1 below;
+  * the literals of `examples/convex_lqr.py:40-46` and their eigenvalues / LQR gain;
+  * solver-independent invariants (see `check_invariants`).
+The interior-point method itself (any correct fp64 IPM solves the same SDP) is the
+build's own: an infeasible-start primal-dual path-following method (HKM direction,
+Mehrotra predictor-corrector) that finishes with pure centering steps on the central
+path at a fixed barrier parameter, so that the returned point is a *mathematically
+defined* object (the central-path point at mu_target) and CPU/GPU parity does not
+depend on iteration history.
+
+Notation: per stage k=0..p-1: A_k (nx x nx), B_k (nx x mb),
+H_k = [[Q,N],[N',R]] (n x n, n = nx+mb), V_k = [A_k B_k], E = [I 0].
+    calH_k(P) = V_k' P_{k+1 mod p} V_k - E' P_k E            (convexifier.py:335-343)
+    M_k = s*alpha*H_k + calH_k(Pbar)                          (:325, :357; Pbar = s*dP)
+    I <= M_k <= tau I,  tau = sbeta*beta,  alpha >= 1e-8      (:245, :305-306)
+    min beta                                                  (:276, :287)
+"""
+import numpy as np
+import scipy.linalg as sla
+
+ALPHA_MIN = 1e-8          # convexifier.py:245
+STATUS_OPTIMAL, STATUS_FEASIBLE, STATUS_INFEASIBLE = 0, 1, 2
+STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
+
+DEFAULT_OPTS = dict(tol=1e-6, max_iter=50, center_iter=12, center_tol=1e-9)
+
+
+# --------------------------------------------------------------------------- helpers
+def symmetrize(S):
+    """mtools.py:33-36"""
+    return (S + np.swapaxes(S, -1, -2)) / 2.0
+
+
+def build_hessian(Q, R, N):
+    """mtools.py:38-41  [[Q,N],[N',R]]"""
+    return np.vstack((np.hstack((Q, N)), np.hstack((N.T, R))))
+
+
+def input_checks(arg):
+    """preprocessing.py:157-185 (same assertion messages)."""
+    msg1 = "Input arguments should be of same type!"
+    assert all(type(a) == type(arg['A']) for a in arg.values()), msg1
+    if type(arg['A']) == list:
+        msg2 = "Input data lists should have same length!"
+        assert all(len(a) == len(arg['A']) for a in arg.values()), msg2
+    else:
+        for key in list(arg.keys()):
+            arg[key] = [arg[key]]
+    msg3 = "Data matrices should have same size along trajectory."
+    for key, a in arg.items():
+        if key != 'C':
+            assert all(np.shape(m) == np.shape(a[0]) for m in a), msg3
+    return arg
+
+
+def auto_scaling(H):
+    """convexifier.py:374-401.  H: [p,n,n].  Returns (s, sbeta) = (1/min|eig|, max|eig|/min|eig|),
+    exact zeros excluded (:387-388).  Symmetric eigensolver on real symmetric input (the
+    reference calls the general `eigvals`; identical on symmetric matrices up to rounding)."""
+    ev = np.abs(np.linalg.eigvalsh(H)).ravel()
+    ev = ev[ev != 0.0]
+    mn = min(1e10, ev.min())       # :383 initial value 1e10
+    mx = max(0.0, ev.max())
+    return 1.0 / mn, mx / mn
+
+
+def calH(A, B, P):
+    """Supplement map, convexifier.py:191-194 / :339-343.  A [p,nx,nx], B [p,nx,mb], P [p,nx,nx] -> [p,n,n]."""
+    p, nx, _ = A.shape
+    V = np.concatenate([A, B], axis=2)
+    Pn = np.roll(P, -1, axis=0)
+    out = np.swapaxes(V, 1, 2) @ Pn @ V
+    out[:, :nx, :nx] -= P
+    return out
+
+
+def calH_adj(A, B, G):
+    """Adjoint of calH:  (calH*(G))_j = V_{j-1} G_{j-1} V_{j-1}' - E G_j E'.   G [p,n,n] -> [p,nx,nx]."""
+    p, nx, _ = A.shape
+    V = np.concatenate([A, B], axis=2)
+    W = V @ G @ np.swapaxes(V, 1, 2)
+    return np.roll(W, 1, axis=0) - G[:, :nx, :nx]
+
+
+def convex_hessian_suppl(A, B, P):
+    """convexifier.py:165-211 without G/C/T terms: dHc_k = sym(calH_k(P)); slices dQ,dR,dN."""
+    nx = A.shape[1]
+    dH = symmetrize(calH(A, B, P))
+    return dH, dH[:, :nx, :nx], dH[:, nx:, nx:], dH[:, :nx, nx:]
+
+
+# ------------------------------------------------------------ svec coordinates on S^nx
+def _tri_idx(nx):
+    ia, ib = np.triu_indices(nx)
+    return ia, ib
+
+
+def _svec_grad(G, ia, ib):
+    """<E_ab, G> for the basis E_ab = e_a e_b' + e_b e_a' (a<b), e_a e_a' (a=b); G symmetric [.., nx, nx]."""
+    w = np.where(ia == ib, 1.0, 2.0)
+    return G[..., ia, ib] * w
+
+
+def _smat(v, nx, ia, ib):
+    P = np.zeros(v.shape[:-1] + (nx, nx))
+    P[..., ia, ib] = v
+    P[..., ib, ia] = v
+    return P
+
+
+def _T(L, R, ia, ib):
+    """T(L,R)[..,(ab),(cd)] = <E_ab, L E_cd R'>  (d x d), L,R: [..., nx, nx] (not nec. symmetric)."""
+    def g(M, r, c):
+        return M[..., r[:, None], c[None, :]]
+    wc = np.where(ia == ib, 0.5, 1.0)[None, :]
+    wr = np.where(ia == ib, 0.5, 1.0)[:, None]
+    # (L E_cd R')_ab = L_ac R_bd + L_ad R_bc ; plus (a<->b)
+    return ((g(L, ia, ia) * g(R, ib, ib) + g(L, ia, ib) * g(R, ib, ia))
+            + (g(L, ib, ia) * g(R, ia, ib) + g(L, ib, ib) * g(R, ia, ia))) * (wc * wr)
+
+
+def _hkm_block(Lx, Ls, ia, ib):
+    """0.5*(T(Lx,Ls)+T(Ls,Lx)): the d x d HKM Schur block(s) generated by the nx x nx pair(s) (Lx, Ls)."""
+    return 0.5 * (_T(Lx, Ls, ia, ib) + _T(Ls, Lx, ia, ib))
+
+
+# ------------------------------------------------------------ block-cyclic-tridiagonal solve
+class _CyclicBlockChol:
+    """Cholesky of the SPD block-cyclic-tridiagonal matrix with diagonal blocks D[k] (d x d),
+    coupling blocks C[k] = T[P_k, P_{k+1 mod p}] (d x d).  p>=3 uses the structured factorisation,
+    p<=2 a dense one.  `shift`: relative diagonal shift added on breakdown (Cholesky-with-shift)."""
+
+    def __init__(self, D, C):
+        p, d, _ = D.shape
+        self.p, self.d = p, d
+        self.shift = 0.0
+        sh = 0.0
+        while True:
+            try:
+                self._factor(D, C, sh)
+                break
+            except np.linalg.LinAlgError:
+                sh = 1e-13 if sh == 0.0 else sh * 100.0
+                if sh > 1e-2:
+                    raise
+        self.shift = sh
+
+    def _factor(self, D, C, sh):
+        p, d = self.p, self.d
+        if p <= 2:
+            T = np.zeros((p * d, p * d))
+            for k in range(p):
+                T[k*d:(k+1)*d, k*d:(k+1)*d] += D[k]
+                kn = (k + 1) % p
+                if kn == k:
+                    T[k*d:(k+1)*d, k*d:(k+1)*d] += C[k] + C[k].T
+                else:
+                    T[k*d:(k+1)*d, kn*d:(kn+1)*d] += C[k]
+                    T[kn*d:(kn+1)*d, k*d:(k+1)*d] += C[k].T
+            if sh:
+                T = T + sh * np.diag(np.diag(T))
+            self.Ld = np.linalg.cholesky(T)
+            return
+        Lkk = np.zeros((p, d, d)); O = np.zeros((p, d, d)); F = np.zeros((p, d, d))
+        Dw = D.copy()
+        if sh:
+            for k in range(p):
+                Dw[k] = Dw[k] + sh * np.diag(np.diag(D[k]))
+        Fpre = C[p - 1].copy()                  # block [p-1, 0]
+        for k in range(p - 1):
+            Lkk[k] = np.linalg.cholesky(Dw[k])
+            sub = C[k].T.copy()                 # block [k+1, k]
+            if k == p - 2:
+                sub = sub + Fpre                # fill meets the sub-diagonal
+                O[k] = sla.solve_triangular(Lkk[k], sub.T, lower=True).T
+                Dw[p - 1] -= O[k] @ O[k].T
+            else:
+                O[k] = sla.solve_triangular(Lkk[k], sub.T, lower=True).T
+                F[k] = sla.solve_triangular(Lkk[k], Fpre.T, lower=True).T
+                Dw[k + 1] -= O[k] @ O[k].T
+                Dw[p - 1] -= F[k] @ F[k].T
+                Fpre = -F[k] @ O[k].T
+        Lkk[p - 1] = np.linalg.cholesky(Dw[p - 1])
+        self.Lkk, self.O, self.F = Lkk, O, F
+
+    def solve(self, R):
+        """R: [p, d, nrhs] -> solution same shape."""
+        p, d = self.p, self.d
+        if p <= 2:
+            r = R.reshape(p * d, -1)
+            z = sla.solve_triangular(self.Ld, r, lower=True)
+            z = sla.solve_triangular(self.Ld.T, z, lower=False)
+            return z.reshape(R.shape)
+        Lkk, O, F = self.Lkk, self.O, self.F
+        Z = R.copy()
+        # forward
+        for k in range(p - 1):
+            Z[k] = sla.solve_triangular(Lkk[k], Z[k], lower=True)
+            Z[k + 1] -= O[k] @ Z[k]
+            if k < p - 2:
+                Z[p - 1] -= F[k] @ Z[k]
+        Z[p - 1] = sla.solve_triangular(Lkk[p - 1], Z[p - 1], lower=True)
+        # backward
+        Z[p - 1] = sla.solve_triangular(Lkk[p - 1].T, Z[p - 1], lower=False)
+        for k in range(p - 2, -1, -1):
+            Z[k] -= O[k].T @ Z[k + 1]
+            if k < p - 2:
+                Z[k] -= F[k].T @ Z[p - 1]
+            Z[k] = sla.solve_triangular(Lkk[k].T, Z[k], lower=False)
+        return Z
+
+
+# ------------------------------------------------------------ small batched helpers
+def _chol_inv(S):
+    """S [p,n,n] SPD -> (L, Sinv)."""
+    L = np.linalg.cholesky(S)
+    n = S.shape[-1]
+    Li = np.linalg.solve(L, np.broadcast_to(np.eye(n), S.shape))   # L^-1
+    return L, np.swapaxes(Li, 1, 2) @ Li, Li
+
+
+def _max_step(Li, dX):
+    """largest theta with X + theta dX >= 0, X = L L', Li = L^-1.  [p,n,n] -> scalar."""
+    W = Li @ dX @ np.swapaxes(Li, 1, 2)
+    lm = np.linalg.eigvalsh(symmetrize(W))[:, 0].min()
+    return np.inf if lm >= 0 else -1.0 / lm
+
+
+# ------------------------------------------------------------ the SDP solve (Step 1)
+def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
+    """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
+    constr=False, force=False, G=None) for one tuning problem.  Returns dict with P (= dP of
+    convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags."""
+    o = dict(DEFAULT_OPTS)
+    if opts:
+        o.update(opts)
+    p, nx, _ = A.shape
+    n = H.shape[1]
+    mb = n - nx
+    d = nx * (nx + 1) // 2
+    ia, ib = _tri_idx(nx)
+    s, sbeta = auto_scaling(H)
+    Hb = s * H
+    V = np.concatenate([A, B], axis=2)
+    Vt = np.swapaxes(V, 1, 2)
+    I = np.eye(n)
+    N = 2 * p * n + 1
+    # ---- initial point (infeasible start)
+    tau = 2.0 * sbeta
+    alpha = 1.0
+    P = np.zeros((p, nx, nx))
+    S1 = np.broadcast_to(sbeta * I, (p, n, n)).copy()
+    S2 = tau * I - Hb                                  # feasible: eig(Hb) <= sbeta
+    X1 = np.broadcast_to(I / (p * n), (p, n, n)).copy()
+    X2 = X1.copy()
+    s0 = 1.0
+    x0 = 1.0 / (p * n)
+    mu_t = None
+    phase = 0
+    ncent = 0
+    status = 'max_iter'
+    it = 0
+    shift_used = 0.0
+    prev_stepn = None
+    stepn = np.inf
+    for it in range(o['max_iter'] + o['center_iter'] + 1):
+        M = alpha * Hb + calH(A, B, P)
+        Rd1 = (M - I) - S1
+        Rd2 = (tau * I - M) - S2
+        rd0 = (alpha - ALPHA_MIN) - s0
+        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0) / N
+        Y = X1 - X2
+        r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
+        r_alpha = -np.sum(Hb * Y) - x0
+        r_P = -calH_adj(A, B, Y)
+        pinf = np.sqrt(r_tau ** 2 + r_alpha ** 2 + np.sum(_svec_grad(r_P, ia, ib) ** 2)) / 2.0
+        dinf = np.sqrt(np.sum(Rd1 ** 2) + np.sum(Rd2 ** 2) + rd0 ** 2) / (1.0 + np.sqrt(np.sum(S1 ** 2) + np.sum(S2 ** 2)))
+        relgap = N * mu / max(1.0, abs(tau))
+        if verbose:
+            print(f"it {it:2d} ph{phase} tau={tau:.10f} alpha={alpha:.4e} mu={mu:.3e} pinf={pinf:.2e} dinf={dinf:.2e} relgap={relgap:.2e}")
+        if trace is not None:
+            trace.append(dict(it=it, tau=tau, mu=mu, pinf=pinf, dinf=dinf, phase=phase))
+        if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
+            mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau)) / N))
+        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < o['tol'] and pinf < max(o['tol'], 1e-6):
+            phase = 1
+        if phase == 0 and it >= o['max_iter']:
+            break
+        L1, S1i, L1i = _chol_inv(S1)
+        L2, S2i, L2i = _chol_inv(S2)
+        refactor = True
+        # ---- Schur complement pieces
+        # nx x nx Kronecker factors per LMI block
+        if refactor:
+          D = np.zeros((p, d, d)); C = np.zeros((p, d, d))
+          for (X, Si) in ((X1, S1i), (X2, S2i)):
+            Kx = V @ X @ Vt; Ks = V @ Si @ Vt            # V-side (P_{k+1})
+            Fx = X[:, :nx, :] @ Vt; Fs = Si[:, :nx, :] @ Vt   # cross  (E . V')
+            D += _hkm_block(X[:, :nx, :nx], Si[:, :nx, :nx], ia, ib)
+            D += np.roll(_hkm_block(Kx, Ks, ia, ib), 1, axis=0)
+            C -= _hkm_block(Fx, Fs, ia, ib)
+          # border columns (tau, alpha)
+          Psi = symmetrize(X2 @ S2i)                              # Phi2(I)
+          PhiH = symmetrize(X1 @ Hb @ S1i) + symmetrize(X2 @ Hb @ S2i)
+          u_tau = _svec_grad(-calH_adj(A, B, Psi), ia, ib)        # [p,d]
+          u_alpha = _svec_grad(calH_adj(A, B, PhiH), ia, ib)
+          b_tt = np.trace(Psi, axis1=1, axis2=2).sum()
+          b_ta = -np.trace(symmetrize(X2 @ Hb @ S2i), axis1=1, axis2=2).sum()
+          b_aa = np.sum(Hb * PhiH) + x0 / s0
+          chol = _CyclicBlockChol(D, C)
+          shift_used = max(shift_used, chol.shift)
+          U = np.stack([u_tau, u_alpha], axis=2)                  # [p,d,2]
+          TU = chol.solve(U)
+          Sb = np.array([[b_tt, b_ta], [b_ta, b_aa]]) - np.einsum('kdi,kdj->ij', U, TU)
+
+        def direction(sig_mu, corr1=None, corr2=None, corr0=0.0):
+            T1 = sig_mu * S1i - symmetrize(X1 @ Rd1 @ S1i)
+            T2 = sig_mu * S2i - symmetrize(X2 @ Rd2 @ S2i)
+            if corr1 is not None:
+                T1 = T1 - corr1; T2 = T2 - corr2
+            t0 = sig_mu / s0 - x0 * rd0 / s0 - corr0
+            rhs_tau = np.trace(T2, axis1=1, axis2=2).sum() - 1.0
+            rhs_alpha = np.sum(Hb * (T1 - T2)) + t0
+            rhs_P = _svec_grad(calH_adj(A, B, T1 - T2), ia, ib)      # [p,d]
+            z = chol.solve(rhs_P[:, :, None])[:, :, 0]
+            rb = np.array([rhs_tau, rhs_alpha]) - np.einsum('kdi,kd->i', U, z)
+            db = np.linalg.solve(Sb, rb)
+            dp = z - TU @ db
+            dtau, dalpha = db
+            dP = _smat(dp, nx, ia, ib)
+            dM = dalpha * Hb + calH(A, B, dP)
+            dS1 = dM + Rd1
+            dS2 = dtau * I - dM + Rd2
+            dX1 = sig_mu * S1i - X1 - symmetrize(X1 @ dS1 @ S1i)
+            dX2 = sig_mu * S2i - X2 - symmetrize(X2 @ dS2 @ S2i)
+            if corr1 is not None:
+                dX1 = dX1 - corr1; dX2 = dX2 - corr2
+            ds0 = dalpha + rd0
+            dx0 = sig_mu / s0 - x0 - x0 * ds0 / s0 - corr0
+            return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0
+
+        def steps(dS1, dS2, dX1, dX2, ds0, dx0):
+            LX1i = np.linalg.inv(np.linalg.cholesky(X1)); LX2i = np.linalg.inv(np.linalg.cholesky(X2))
+            ap = min(_max_step(LX1i, dX1), _max_step(LX2i, dX2))
+            ad = min(_max_step(L1i, dS1), _max_step(L2i, dS2))
+            if dx0 < 0: ap = min(ap, -x0 / dx0)
+            if ds0 < 0: ad = min(ad, -s0 / ds0)
+            return ap, ad
+
+        if phase == 0:
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(0.0)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            ap = min(1.0, ap); ad = min(1.0, ad)
+            mu_aff = (np.sum((X1 + ap * dX1) * (S1 + ad * dS1)) + np.sum((X2 + ap * dX2) * (S2 + ad * dS2))
+                      + (x0 + ap * dx0) * (s0 + ad * ds0)) / N
+            sigma = min(max((mu_aff / mu) ** 3, 1e-6), 1.0)
+            sig_mu = sigma * mu
+            if mu_t is not None:
+                sig_mu = max(sig_mu, mu_t)
+            corr1 = symmetrize(dX1 @ dS1 @ S1i); corr2 = symmetrize(dX2 @ dS2 @ S2i)
+            corr0 = dx0 * ds0 / s0
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(sig_mu, corr1, corr2, corr0)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            mn = min(ap, ad)
+            gam = 0.9 + 0.09 * min(mn, 1.0)
+            ap = min(1.0, gam * ap); ad = min(1.0, gam * ad)
+        else:
+            ncent += 1
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(mu_t)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            ap = min(1.0, 0.95 * ap); ad = min(1.0, 0.95 * ad)
+            stepn = np.sqrt(dtau ** 2 + dalpha ** 2 + np.sum(dP ** 2)) / (1.0 + np.sqrt(tau ** 2 + alpha ** 2 + np.sum(P ** 2)))
+            if verbose:
+                print(f"      center |dy|rel={stepn:.3e} ap={ap:.3f} ad={ad:.3f}")
+        X1 = symmetrize(X1 + ap * dX1); X2 = symmetrize(X2 + ap * dX2)
+        S1 = symmetrize(S1 + ad * dS1); S2 = symmetrize(S2 + ad * dS2)
+        x0 += ap * dx0; s0 += ad * ds0
+        tau += ad * dtau; alpha += ad * dalpha; P = P + ad * dP
+        if phase == 1:
+            # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation
+            # at the rounding floor, or on the iteration cap
+            full = (ap == 1.0 and ad == 1.0)
+            if full and stepn < o['center_tol']:
+                status = 'optimal'
+                break
+            if full and prev_stepn is not None and stepn > 0.5 * prev_stepn and stepn < 1e-6:
+                status = 'optimal'        # rounding floor reached
+                break
+            if ncent >= o['center_iter']:
+                status = 'optimal_inaccurate'
+                break
+            prev_stepn = stepn if full else None
+    Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
+    return dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
+                ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
+
+
+def check_convergence(A, B, H, P, ipm_status):
+    """convexifier.py:403-456 (status rule :442-451)."""
+    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P)
+    Hc = H + dHc
+    ev = np.linalg.eigvalsh(Hc)
+    min_eig = ev.min(); max_cond = (ev[:, -1] / ev[:, 0]).max() if min_eig > 0 else np.inf
+    if min_eig > 0.0:
+        st = STATUS_OPTIMAL if ipm_status == 'optimal' else STATUS_FEASIBLE
+    else:
+        st = STATUS_INFEASIBLE
+    return st, dHc, dQc, dRc, dNc, min_eig, max_cond
+
+
+def convexify_arrays(A, B, H, opts=None, verbose=False):
+    """Array-level restatement of convexifier.convexify (Step 1 only, no G/C):
+    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, dHc, Hc, P, alpha, beta, kappa, iters, early_exit)."""
+    A = np.asarray(A, float); B = np.asarray(B, float); H = symmetrize(np.asarray(H, float))
+    p, nx, _ = A.shape
+    n = H.shape[1]
+    # already convex?  convexifier.py:82-85
+    if np.linalg.eigvalsh(H)[:, 0].min() > 0:
+        return dict(status=STATUS_OPTIMAL, early_exit=True, dHc=np.zeros_like(H), Hc=H.copy(),
+                    P=np.zeros((p, nx, nx)), alpha=1.0, beta=0.0, kappa=0.0, iters=0)
+    r = sdp_step1(A, B, H, opts, verbose)
+    st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'])
+    r.update(status=st, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond)
+    return r
+
+
+def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
+    """Drop-in restatement of convexifier.convexify (convexifier.py:36-163) for Step 1."""
+    arg = dict(A=A, B=B, Q=Q, R=R, N=N)
+    if C is not None:
+        arg['C'] = C
+    if G is not None:
+        arg['G'] = G
+    arg = input_checks(arg)
+    if 'G' in arg or 'C' in arg:
+        raise NotImplementedError('oracle: Steps with G/C terms not restated yet')
+    nx = np.shape(arg['A'][0])[0]; nu = np.shape(arg['B'][0])[1]
+    Hs = np.stack([build_hessian(np.asarray(q, float), np.asarray(r, float), np.asarray(nn, float))
+                   for q, r, nn in zip(arg['Q'], arg['R'], arg['N'])])
+    As = np.stack([np.asarray(a, float) for a in arg['A']]); Bs = np.stack([np.asarray(b, float) for b in arg['B']])
+    res = convexify_arrays(As, Bs, Hs, opts)
+    if res['early_exit']:
+        return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))   # :85
+    if res['status'] == STATUS_INFEASIBLE:
+        raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
+    dH = res['dHc']
+    return ([dH[k] for k in range(len(dH))], [dH[k][:nx, :nx] for k in range(len(dH))],
+            [dH[k][nx:, nx:] for k in range(len(dH))], [dH[k][:nx, nx:] for k in range(len(dH))])
+
+
+# ------------------------------------------------------------ synthetic inputs
+def gen_problem(seed, p, nx, mb, sigP=1.0, identity=False):
+    """'random SPD-perturbed Hessian' generator: H_k = Hhat_k - calH_k(Phat), strictly feasible by construction."""
+    rng = np.random.default_rng(seed)
+    n = nx + mb
+    A = np.zeros((p, nx, nx)); B = np.zeros((p, nx, mb)); Phat = np.zeros((p, nx, nx)); Hhat = np.zeros((p, n, n))
+    for k in range(p):
+        a = rng.standard_normal((nx, nx)) / np.sqrt(nx)
+        rho = np.max(np.abs(np.linalg.eigvals(a)))
+        A[k] = a * (0.9 / rho)
+        B[k] = rng.standard_normal((nx, mb)) / np.sqrt(nx)
+        W, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.ones(n) if identity else 10.0 ** rng.uniform(0, 1, n)
+        Hhat[k] = (W * lam) @ W.T
+        pk = rng.standard_normal((nx, nx)); Phat[k] = sigP * (pk + pk.T) / 2
+    H = symmetrize(Hhat - calH(A, B, Phat))
+    return A, B, H, Phat, Hhat
+
+
+def gen_batch(base_seed, nb, p, nx, mb, **kw):
+    out = [gen_problem(base_seed + b, p, nx, mb, **kw) for b in range(nb)]
+    return tuple(np.stack([o[i] for o in out]) for i in range(3))
+
+
+def check_invariants(A, B, H, res, tol_struct=1e-10):
+    """Solver-independent checks.  Returns dict of measured quantities."""
+    Hc = res['Hc']; P = res['P']
+    ev = np.linalg.eigvalsh(Hc)
+    struct = np.linalg.norm(Hc - H - symmetrize(calH(A, B, P))) / max(1.0, np.linalg.norm(Hc))
+    out = dict(min_eig=ev.min(), max_cond=(ev[:, -1] / ev[:, 0]).max(), struct_err=struct)
+    if not res.get('early_exit'):
+        out['cond_bound'] = res['kappa']
+    return out
