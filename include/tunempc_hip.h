@@ -1,0 +1,110 @@
+/*
+ * tunempc_hip.h -- C ABI of the MI355X (gfx950) convexifier.
+ *
+ * Drop-in boundary for the hot path of TuneMPC, `tunempc/convexifier.py` in the reference:
+ * the per-problem SDP that turns the p indefinite stage Hessians H_k of a solved periodic OCP into
+ * positive-definite tracking-cost matrices  Hc_k = H_k + dHc_k.  The reference has no native boundary
+ * (everything is Python calling PICOS -> CVXOPT/MOSEK); the entry points below are what a ctypes
+ * binding of that path binds instead:
+ *
+ *   reference interface                                    replaced by
+ *   ------------------------------------------------------------------------------------------------
+ *   convexifier.convexify(A,B,Q,R,N,G,C,opts)               tmpc_convexify_batch_host / _device
+ *       (convexifier.py:36-163; Step 1: :98-114)              (B independent problems per call)
+ *   convexifier.autoScaling            (:374-401)           inside (k_init_*), reported via info[]
+ *   convexifier.setUpModelPicos+solveSDP (:213-308,:359-372) inside (structured primal-dual IPM)
+ *   convexifier.check_convergence      (:403-456)           status[] (0 Optimal,1 Feasible,2 Infeasible)
+ *   convexifier.convexHessianSuppl     (:165-211)           tmpc_supplement_batch_* and dHc output
+ *   opts = {'rho','solver','force'}    (:36)                tmpc_set_options (tol, iteration caps)
+ *   Tuner.convexify                    (tuner.py:134-160)   Python side: tunempc_amd.tuner
+ *
+ * Conventions: plain pointers + sizes, fp64, C (row-major) contiguous arrays:
+ *   A  [B][p][nx][nx]      B  [B][p][nx][mb]      H  [B][p][n][n]   (n = nx + mb, H = [[Q,N],[N',R]])
+ *   Hc, dHc [B][p][n][n]   P  [B][p][nx][nx]  (P = the reference's un-scaled dP_k, convexifier.py:406)
+ * The caller owns every buffer; the library never frees or keeps caller memory.  `_device` variants
+ * take device pointers and enqueue on `stream` (a hipStream_t passed as void*); they synchronise the
+ * stream internally once per interior-point iteration (a 4-byte "problems still active" read-back).
+ * All functions return 0 on success or a negative TMPC_E_* code; per-problem solver outcomes are in
+ * status[] so that one infeasible member does not abort a batch.
+ */
+#ifndef TUNEMPC_HIP_H
+#define TUNEMPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMPC_OK 0
+#define TMPC_E_ARG (-1)        /* bad argument (null pointer, non-positive size)            */
+#define TMPC_E_UNSUPPORTED (-2) /* n = nx+mb > 32 (one LDS tile per stage block) or p < 1   */
+#define TMPC_E_NOMEM (-3)      /* hipMalloc failed                                          */
+#define TMPC_E_HIP (-4)        /* HIP runtime error (see tmpc_last_error)                   */
+#define TMPC_E_NODEVICE (-5)   /* no gfx950 device visible                                  */
+
+#define TMPC_STATUS_OPTIMAL 0    /* convexifier.py:444 'Optimal'    */
+#define TMPC_STATUS_FEASIBLE 1   /* convexifier.py:446 'Feasible'   */
+#define TMPC_STATUS_INFEASIBLE 2 /* convexifier.py:451 'Infeasible' */
+
+#define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments instead of v_mfma_f64_16x16x4 */
+#define TMPC_FLAG_PROFILE 2      /* record hipEvent timings per phase (tmpc_get_profile)           */
+
+#define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
+/* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
+ *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter),
+ *                 11 #shifted pivots, 12 centering iterations, 13 early-exit flag (convexifier.py:83-85),
+ *                 14 last centering step norm, 15 reserved                                          */
+
+typedef struct tmpc_handle tmpc_handle;
+
+/* Number of HIP devices visible (0 if none / HIP not initialisable).  Never touches a device. */
+int tmpc_device_count(void);
+
+/* Device workspace needed for `chunk` problems of shape (p, nx, mb), in bytes (0 if unsupported). */
+uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
+
+/* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.
+ * Larger batches are processed in chunks.  chunk <= 0 selects a default that fits free HBM. */
+int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
+int tmpc_destroy(tmpc_handle* h);
+
+/* Solver options: tol = relative duality gap on kappa (max condition number), default 1e-6;
+ * center_tol = relative Newton step ending the final centering phase, default 1e-9;
+ * max_iter / center_iter = iteration caps (defaults 50 / 12); flags = TMPC_FLAG_*.  Values <= 0 keep
+ * the current setting (flags is always applied). */
+int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags);
+
+/* Step 1 of convexifier.convexify for `nb` independent problems.  Any output pointer may be NULL.
+ * status/iters are int32 [nb]; alpha/beta/kappa are double [nb]; info is double [nb][16]. */
+int tmpc_convexify_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H,
+                              double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
+                              int32_t* status, int32_t* iters, double* info);
+int tmpc_convexify_batch_device(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH,
+                                double* dHc_out, double* ddHc_out, double* dP_out, double* d_alpha, double* d_beta,
+                                double* d_kappa, int32_t* d_status, int32_t* d_iters, double* d_info, void* stream);
+
+/* convexHessianSuppl (convexifier.py:165-211) alone: dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E). */
+int tmpc_supplement_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, double* dHc);
+
+/* Stage-block eigen scan (pre-check convexifier.py:82, autoScaling :374-401, status check :438-440):
+ * out[b*p+k][0..3] = min eig, max eig, min |eig| (zeros excluded), max |eig| of sym(H[b][k]). */
+int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
+
+/* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set:
+ * out[0] stage_pre+ctrl, [1] schur assembly, [2] block factorisation (k_factor), [3] predictor pass,
+ * [4] corrector pass + update, [5] number of k_factor launches, [6] total ms of convexify calls,
+ * [7] IPM iterations (max over chunk, summed over chunks). */
+int tmpc_get_profile(tmpc_handle* h, double* out8);
+
+/* Debug / unit-test entry points (tests call the kernels' building blocks through the same library). */
+int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
+int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift);
+
+const char* tmpc_last_error(void);
+const char* tmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUNEMPC_HIP_H */

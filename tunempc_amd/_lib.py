@@ -1,0 +1,191 @@
+"""ctypes binding of the C ABI in include/tunempc_hip.h (libtunempc_hip.so, built in-tree by
+`__graft_entry__.build()` / `tunempc_amd/build.py`).  No torch types cross this boundary: plain pointers
+and sizes.  The loader fails loudly when the library is missing -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+INFO_STRIDE = 16
+FLAG_NO_MFMA = 1
+FLAG_PROFILE = 2
+STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
+
+# every symbol declared in include/tunempc_hip.h
+EXPORTS = [
+    'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_set_options',
+    'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
+    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve',
+    'tmpc_last_error', 'tmpc_version',
+]
+
+
+def library_path():
+    return os.path.join(_HERE, 'lib', 'libtunempc_hip.so')
+
+
+def load_library():
+    """Load libtunempc_hip.so (never initialises a device by itself)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"tunempc_amd: HIP library not built ({path}); run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " -- there is no CPU fallback for the convexify hot path")
+    lib = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    lib.tmpc_device_count.restype = C.c_int
+    lib.tmpc_workspace_bytes.restype = C.c_uint64
+    lib.tmpc_workspace_bytes.argtypes = [C.c_int] * 4
+    lib.tmpc_create.restype = C.c_int
+    lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_destroy.restype = C.c_int
+    lib.tmpc_destroy.argtypes = [vp]
+    lib.tmpc_set_options.restype = C.c_int
+    lib.tmpc_set_options.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_convexify_batch_host.restype = C.c_int
+    lib.tmpc_convexify_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
+    lib.tmpc_convexify_batch_device.restype = C.c_int
+    lib.tmpc_convexify_batch_device.argtypes = [vp, C.c_int] + [vp] * 12 + [vp]
+    lib.tmpc_supplement_batch_host.restype = C.c_int
+    lib.tmpc_supplement_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    lib.tmpc_eig_scan_host.restype = C.c_int
+    lib.tmpc_eig_scan_host.argtypes = [vp, C.c_int, dp, dp]
+    lib.tmpc_get_profile.restype = C.c_int
+    lib.tmpc_get_profile.argtypes = [vp, dp]
+    lib.tmpc_debug_gemm_nt.restype = C.c_int
+    lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_debug_block_solve.restype = C.c_int
+    lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
+    lib.tmpc_last_error.restype = C.c_char_p
+    lib.tmpc_version.restype = C.c_char_p
+    _LIB = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"tunempc_amd: {what} failed with code {rc}: {lib.tmpc_last_error().decode()}")
+
+
+class HipConvexifier:
+    """Handle for batched convexification of problems of one shape (p, nx, mb) on the current HIP device."""
+
+    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0):
+        self.lib = load_library()
+        if self.lib.tmpc_device_count() < 1:
+            raise RuntimeError("tunempc_amd: no HIP device visible; the convexify hot path has no CPU fallback")
+        self.p, self.nx, self.mb, self.n = int(p), int(nx), int(mb), int(nx) + int(mb)
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.tmpc_create(C.byref(self._h), int(chunk), self.p, self.nx, self.mb), 'tmpc_create')
+        self.flags = int(flags)
+        self.set_options(tol, center_tol, max_iter, center_iter, flags)
+
+    def set_options(self, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=None):
+        if flags is not None:
+            self.flags = int(flags)
+        _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
+                                                   int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self.lib.tmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ host-buffer entry
+    def convexify_batch(self, A, B, H):
+        """A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] (numpy, fp64) -> dict of numpy outputs."""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        nb = A.shape[0]
+        assert A.shape == (nb, self.p, self.nx, self.nx), A.shape
+        assert B.shape == (nb, self.p, self.nx, self.mb), B.shape
+        assert H.shape == (nb, self.p, self.n, self.n), H.shape
+        out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), alpha=np.empty(nb), beta=np.empty(nb),
+                   kappa=np.empty(nb), status=np.empty(nb, np.int32), iters=np.empty(nb, np.int32),
+                   info=np.empty((nb, INFO_STRIDE)))
+        rc = self.lib.tmpc_convexify_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(out['Hc']), _dptr(out['dHc']),
+                                                _dptr(out['P']), _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
+                                                _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
+        _check(self.lib, rc, 'tmpc_convexify_batch_host')
+        return out
+
+    # ------------------------------------------------------------------ device-resident entry (torch tensors)
+    def convexify_batch_device(self, A, B, H, out=None, stream=None):
+        """torch CUDA tensors (fp64, contiguous) in, torch tensors out; data stays in HBM."""
+        import torch
+        nb = A.shape[0]
+        for t in (A, B, H):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        dev = A.device
+        if out is None:
+            out = dict(Hc=torch.empty_like(H), dHc=torch.empty_like(H), P=torch.empty_like(A),
+                       alpha=torch.empty(nb, dtype=torch.float64, device=dev), beta=torch.empty(nb, dtype=torch.float64, device=dev),
+                       kappa=torch.empty(nb, dtype=torch.float64, device=dev), status=torch.empty(nb, dtype=torch.int32, device=dev),
+                       iters=torch.empty(nb, dtype=torch.int32, device=dev),
+                       info=torch.empty((nb, INFO_STRIDE), dtype=torch.float64, device=dev))
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.tmpc_convexify_batch_device(self._h, nb, ptr(A), ptr(B), ptr(H), ptr(out['Hc']), ptr(out['dHc']), ptr(out['P']),
+                                                  ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']),
+                                                  ptr(out['iters']), ptr(out['info']), C.c_void_p(st))
+        _check(self.lib, rc, 'tmpc_convexify_batch_device')
+        return out
+
+    def supplement_batch(self, A, B, P):
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        nb = A.shape[0]
+        dH = np.empty((nb, self.p, self.n, self.n))
+        _check(self.lib, self.lib.tmpc_supplement_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(P), _dptr(dH)), 'tmpc_supplement_batch_host')
+        return dH
+
+    def eig_scan(self, H):
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        nb = H.shape[0]
+        out = np.empty((nb, self.p, 4))
+        _check(self.lib, self.lib.tmpc_eig_scan_host(self._h, nb, _dptr(H), _dptr(out)), 'tmpc_eig_scan_host')
+        return out
+
+    def profile(self):
+        out = np.zeros(8)
+        _check(self.lib, self.lib.tmpc_get_profile(self._h, _dptr(out)), 'tmpc_get_profile')
+        keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters']
+        return dict(zip(keys, out.tolist()))
+
+    # ------------------------------------------------------------------ unit-test hooks
+    def debug_gemm_nt(self, Cm, A, B, mode=0, lower=False):
+        Cm = np.ascontiguousarray(Cm, dtype=np.float64).copy(); A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        M, N = Cm.shape; K = A.shape[1]
+        _check(self.lib, self.lib.tmpc_debug_gemm_nt(self._h, _dptr(Cm), _dptr(A), _dptr(B), M, N, K, int(mode), int(lower)), 'tmpc_debug_gemm_nt')
+        return Cm
+
+    def debug_block_solve(self, D, Ccpl, rhs):
+        D = np.ascontiguousarray(D, dtype=np.float64); Ccpl = np.ascontiguousarray(Ccpl, dtype=np.float64)
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        p, d, _ = D.shape
+        x = np.empty((p, d)); ns = np.zeros(1, np.int32)
+        _check(self.lib, self.lib.tmpc_debug_block_solve(self._h, p, d, _dptr(D), _dptr(Ccpl), _dptr(rhs), _dptr(x), _iptr(ns)), 'tmpc_debug_block_solve')
+        return x, int(ns[0])

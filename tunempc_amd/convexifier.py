@@ -1,0 +1,147 @@
+"""Convexification code -- MI355X-native drop-in for `tunempc/convexifier.py`.
+
+Same entry point, argument meaning, return structure, log lines and exceptions as the reference
+(`convexify`, convexifier.py:36-163); the SDP that the reference hands to PICOS -> CVXOPT/MOSEK
+(`setUpModelPicos` :213-308, `solveSDP` :359-372) is solved by the HIP kernels behind
+include/tunempc_hip.h.  `opts['solver']` selects the backend: 'hip' (default here; the reference's
+'mosek' / 'cvxopt' strings are accepted and mapped to 'hip' because those solvers do not exist on this
+stack).  There is no CPU path in this package.
+
+Scope of this round: Step 1 (eta_F = 0, eta_T = 0) without equality-constraint
+regularisation.  Problems that need Step 2 / Step 3 (active-constraint or forced regularisation,
+convexifier.py:116-157) raise NotImplementedError when G or C are supplied and Step 1 is infeasible.
+"""
+import numpy as np
+
+from . import mtools
+from . import preprocessing
+from .logger import Logger
+from ._lib import HipConvexifier, STATUS_NAMES
+
+_HANDLES = {}
+
+
+def _handle(p, nx, mb):
+    key = (p, nx, mb)
+    h = _HANDLES.get(key)
+    if h is None:
+        h = HipConvexifier(p, nx, mb)
+        _HANDLES[key] = h
+    return h
+
+
+def _to_array(m):
+    """numpy / np.matrix / CasADi DM (via .full()) -> 2-D float64 ndarray."""
+    if hasattr(m, 'full'):
+        m = m.full()
+    return np.atleast_2d(np.asarray(m, dtype=np.float64))
+
+
+def convexify_batch(A, B, H, tol=None, handle=None):
+    """Batched Step 1.  A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict with
+    Hc, dHc [nb,p,n,n], P [nb,p,nx,nx], alpha, beta, kappa [nb], status [nb] (0 Optimal, 1 Feasible,
+    2 Infeasible; convexifier.py:442-451), iters [nb], info [nb,16]."""
+    A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
+    nb, p, nx, _ = A.shape
+    mb = B.shape[3]
+    h = handle or _handle(p, nx, mb)
+    if tol is not None:
+        h.set_options(tol=tol)
+    return h.convexify_batch(A, B, H)
+
+
+def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip', 'force': False}):
+    """ Convexify the indefinite Hessian "H" of the system with the discrete time dynamics
+
+        x_{k+1} = A x_k + B u_k
+
+    so that the solution of the LQR problem based on the convexified Hessian "H + dH" yields the same
+    trajectory as the LQR-solution of the indefinite problem  (convexifier.py:36-58).
+
+    :param A: system matrix            :param B: input matrix
+    :param Q: weighting matrix Q (nx,nx)   :param R: (nu,nu)   :param N: (nx,nu)
+    :param C: jacobian of active constraints at steady state (nc, nx+nu)
+    :param G: jacobian of equality constraints at steady state (ng, nx+nu)
+    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91)
+    :return: Convexified Hessian supplement "dH": (dHc, dQc, dRc, dNc), lists of p arrays.
+    """
+    arg = {'A': A, 'B': B, 'Q': Q, 'R': R, 'N': N}
+    if C is None:
+        Logger.logger.info('Convexifier called w/o active constraints at steady state')
+    else:
+        arg['C'] = C
+    if G is not None:
+        arg['G'] = G
+
+    arg = preprocessing.input_checks(arg)
+    if 'G' in arg:
+        raise NotImplementedError('equality-constraint regularisation Fg (convexifier.py:249-255) is not built yet')
+    period = len(arg['A'])
+    Logger.logger.info('Convexify Hessians along {:d}-periodic steady state trajectory.'.format(period))
+
+    As = np.stack([_to_array(a) for a in arg['A']])
+    Bs = np.stack([_to_array(b) for b in arg['B']])
+    nx = As.shape[1]
+    nu = Bs.shape[2]
+    Hs = np.stack([mtools.buildHessian(_to_array(q), _to_array(r), _to_array(n_))
+                   for q, r, n_ in zip(arg['Q'], arg['R'], arg['N'])])
+
+    solver = (opts or {}).get('solver', 'hip')
+    if solver not in ('hip', 'mosek', 'cvxopt'):
+        raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))
+
+    Logger.logger.info('Construct SDP...')
+    Logger.logger.info('')
+    Logger.logger.info(50 * '*')
+    Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
+    Logger.logger.info('solving SDP...')
+    res = convexify_batch(As[None], Bs[None], Hs[None])
+
+    if res['info'][0, 13] != 0.0:      # already convex: convexifier.py:83-85 (bare zero arrays, as the reference)
+        Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')
+        return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))
+
+    status = STATUS_NAMES[int(res['status'][0])]
+    Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
+    Logger.logger.debug('beta: {}'.format(res['beta'][0]))
+    if status in ['Optimal', 'Feasible']:
+        Logger.logger.info('{} solution found.'.format(status))
+        Logger.logger.info('Maximum condition number: {}'.format(res['info'][0, 4]))
+        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+        Logger.logger.info('EQUIVALENCE TYPE A')
+        Logger.logger.info(50 * '*')
+    else:
+        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+        Logger.logger.info('!! Problem infeasible !!')
+        if 'C' in arg or 'G' in arg or (opts or {}).get('force', False):
+            raise NotImplementedError('Step 2/3 of the convexifier (convexifier.py:116-157) are not built yet')
+        Logger.logger.warning('!! Strict dissipativity does not hold locally !!')
+        Logger.logger.warning('!! The provided indefinite LQ MPC problem is not stabilising !!')
+        Logger.logger.warning(50 * '*')
+        Logger.logger.warning('Consider operating the system at another orbit of different period p')
+        Logger.logger.warning('Convexification and stabilization of the MPC scheme can be enforced by enabling "force"-flag.')
+        Logger.logger.warning('In this case there are no guarantees of (local, first-order) equivalence.')
+        raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
+
+    Logger.logger.info('')
+    Logger.logger.info('Hessians convexified.')
+    Logger.logger.info('')
+
+    dH = res['dHc'][0]
+    dHc = [dH[k].copy() for k in range(period)]
+    dQc = [d[:nx, :nx] for d in dHc]
+    dRc = [d[nx:, nx:] for d in dHc]
+    dNc = [d[:nx, nx:] for d in dHc]
+    return dHc, dQc, dRc, dNc
+
+
+def convexHessianSuppl(A, B, Q, R, N, dP, G=None, Fg=None, C=None, F=None, T=None):
+    """Construct the convexified Hessian supplement from dP (convexifier.py:165-211), on the GPU."""
+    if G or F or T:
+        raise NotImplementedError('G/F/T terms of convexHessianSuppl are not built yet')
+    As = np.stack([_to_array(a) for a in A]); Bs = np.stack([_to_array(b) for b in B])
+    Ps = np.stack([_to_array(p_) for p_ in dP])
+    period, nx, _ = As.shape
+    dH = _handle(period, nx, Bs.shape[2]).supplement_batch(As[None], Bs[None], Ps[None])[0]
+    dHc = [dH[k] for k in range(period)]
+    return dHc, [d[:nx, :nx] for d in dHc], [d[nx:, nx:] for d in dHc], [d[:nx, nx:] for d in dHc]

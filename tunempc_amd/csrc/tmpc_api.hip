@@ -1,0 +1,486 @@
+// Host side of the MI355X convexifier: workspace, launch sequence, C ABI (include/tunempc_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/tunempc_hip.h"
+#include "tmpc_common.h"
+#include "tmpc_small.h"
+#include "tmpc_stage.h"
+#include "tmpc_schur.h"
+#include "tmpc_factor.h"
+
+using namespace tmpc;
+
+static thread_local char g_err[512] = "";
+static int set_err(const char* what, hipError_t e, int line) {
+  snprintf(g_err, sizeof(g_err), "%s: %s (line %d)", what, hipGetErrorString(e), line);
+  return TMPC_E_HIP;
+}
+#define HIPCHK(x)                                            \
+  do {                                                       \
+    hipError_t e_ = (x);                                     \
+    if (e_ != hipSuccess) return set_err(#x, e_, __LINE__);  \
+  } while (0)
+
+struct tmpc_handle {
+  Dims dm;          // dm.B = chunk capacity
+  Opts opt;
+  int flags;
+  WS ws;
+  void* slab;
+  size_t slab_bytes;
+  // chunk-local copies of the user inputs when called with host pointers
+  double *dA, *dB, *dH;          // device staging for host API (chunk sized)
+  double* d_info;                // [chunk][16]
+  double* d_abk;                 // [chunk][3]
+  int32_t* d_si;                 // [chunk][2]
+  hipEvent_t ev[8];
+  double prof[8];
+};
+
+// ---------------------------------------------------------------------------------- sizes
+static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
+
+static Dims make_dims(int chunk, int p, int nx, int mb) {
+  Dims d;
+  d.B = chunk; d.p = p; d.nx = nx; d.mb = mb; d.n = nx + mb;
+  d.d = nx * (nx + 1) / 2;
+  d.dp = (d.d + 15) / 16 * 16;
+  d.nt = (d.dp + TB - 1) / TB;
+  d.flags = 0;
+  return d;
+}
+
+struct Carver {
+  char* base; size_t off;
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
+  Carver c{base, 0};
+  const size_t BP = (size_t)dm.B * dm.p, nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
+  const size_t bs = (size_t)dm.dp * dm.dp;
+  w.Hb = c.take<double>(BP * nn); w.V = c.take<double>(BP * dm.nx * dm.n);
+  w.P = c.take<double>(BP * nxx);
+  w.X1 = c.take<double>(BP * nn); w.X2 = c.take<double>(BP * nn); w.S1 = c.take<double>(BP * nn); w.S2 = c.take<double>(BP * nn);
+  w.S1i = c.take<double>(BP * nn); w.S2i = c.take<double>(BP * nn); w.L1i = c.take<double>(BP * nn); w.L2i = c.take<double>(BP * nn);
+  w.LX1i = c.take<double>(BP * nn); w.LX2i = c.take<double>(BP * nn);
+  w.Rd1 = c.take<double>(BP * nn); w.Rd2 = c.take<double>(BP * nn); w.T1 = c.take<double>(BP * nn); w.T2 = c.take<double>(BP * nn);
+  w.dS1 = c.take<double>(BP * nn); w.dS2 = c.take<double>(BP * nn); w.dX1 = c.take<double>(BP * nn); w.dX2 = c.take<double>(BP * nn);
+  w.c1 = c.take<double>(BP * nn); w.c2 = c.take<double>(BP * nn);
+  w.dP = c.take<double>(BP * nxx);
+  w.KF = c.take<double>(BP * 12 * nxx); w.adjV = c.take<double>(BP * NADJ * nxx); w.adjE = c.take<double>(BP * NADJ * nxx);
+  w.part = c.take<double>(BP * NPART); w.prob = c.take<double>((size_t)dm.B * PS); w.iprob = c.take<int>((size_t)dm.B * IS);
+  w.D = c.take<double>(BP * bs); w.O = c.take<double>(BP * bs); w.F = c.take<double>(BP * bs);
+  w.Linv = c.take<double>(BP * dm.nt * TB * TB); w.Ddiag = c.take<double>(BP * dm.dp);
+  w.W3 = c.take<double>(BP * dm.dp * 3); w.U = c.take<double>(BP * dm.dp * 2); w.TU = c.take<double>(BP * dm.dp * 2);
+  w.Z = c.take<double>(BP * dm.dp);
+  w.active = c.take<int>(64);
+  w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
+  if (h) {
+    h->dA = c.take<double>(BP * nxx); h->dB = c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); h->dH = c.take<double>(BP * nn);
+    h->d_info = c.take<double>((size_t)dm.B * TMPC_INFO_STRIDE); h->d_abk = c.take<double>((size_t)dm.B * 3);
+    h->d_si = c.take<int32_t>((size_t)dm.B * 2);
+  } else {
+    c.take<double>(BP * nxx); c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); c.take<double>(BP * nn);
+    c.take<double>((size_t)dm.B * TMPC_INFO_STRIDE); c.take<double>((size_t)dm.B * 3); c.take<int32_t>((size_t)dm.B * 2);
+  }
+  return (c.off + 255) & ~(size_t)255;
+}
+
+// ---------------------------------------------------------------------------------- small output kernels
+__global__ void k_output(WS w, Dims dm, double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters,
+                         double* info) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= dm.B) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (alpha) alpha[b] = pr[P_ALPHA_OUT];
+  if (beta) beta[b] = pr[P_BETA];
+  if (kappa) kappa[b] = pr[P_KAPPA];
+  if (status) status[b] = ip[I_STATUS];
+  if (iters) iters[b] = ip[I_ITERS];
+  if (info) {
+    double* o = info + (size_t)b * TMPC_INFO_STRIDE;
+    o[0] = pr[P_S]; o[1] = pr[P_SBETA]; o[2] = pr[P_MINEIG_H]; o[3] = pr[P_MINEIG_HC]; o[4] = pr[P_MAXCOND];
+    o[5] = pr[P_MU]; o[6] = pr[P_MUT]; o[7] = pr[P_PINF]; o[8] = pr[P_DINF]; o[9] = pr[P_RELGAP];
+    o[10] = (double)ip[I_IPMSTATUS]; o[11] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]); o[12] = (double)ip[I_NCENT];
+    o[13] = (double)ip[I_EARLY]; o[14] = pr[P_STEPN]; o[15] = 0.0;
+  }
+}
+
+// eig scan of arbitrary stage blocks (tmpc_eig_scan_host)
+__global__ void __launch_bounds__(64) k_eig_scan(const double* H, double* out, int n) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = blockIdx.x, lane = threadIdx.x;
+  double* sH = sm; double* cs = sm + MS;
+  const double* Hg = H + (size_t)sid * n * n;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; sH[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
+  wsync();
+  jacobi_eigvals(sH, n, cs, lane);
+  double lo = 1e300, hi = -1e300, amin = 1e300, amax = 0.0;
+  if (lane < n) { const double ev = sH[lane * LD + lane]; lo = ev; hi = ev; const double a = fabs(ev); if (a != 0.0) { amin = a; amax = a; } }
+  lo = wave_min(lo); hi = wave_max(hi); amin = wave_min(amin); amax = wave_max(amax);
+  if (lane == 0) { double* o = out + (size_t)sid * 4; o[0] = lo; o[1] = hi; o[2] = amin; o[3] = amax; }
+}
+
+// dHc = sym(V' P+ V - E' P E) for arbitrary P (tmpc_supplement_batch_host); uses ws.V built from A,B
+__global__ void __launch_bounds__(64) k_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int n = dm.n, nx = dm.nx, mb = dm.mb, nxx = nx * nx;
+  double* sV = sm; double* sM = sm + MS; double* t0 = sm + 2 * MS; double* t1 = sm + 3 * MS; double* sZ = sm + 4 * MS;
+  for (int e = lane; e < nx * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    sV[i * LD + j] = (j < nx) ? A[(size_t)sid * nxx + i * nx + j] : Bm[(size_t)sid * nx * mb + i * mb + (j - nx)];
+  }
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; sZ[i * LD + j] = 0.0; }
+  wsync();
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  build_M(sM, sV, t0, t1, sZ, P + (size_t)sid * nxx, P + (size_t)(b * dm.p + kn) * nxx, 0.0, n, nx, lane);
+  s2g_sym(dHc + (size_t)sid * n * n, sM, n, lane);
+}
+
+// ---------------------------------------------------------------------------------- debug kernels
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg_gemm_nt<USE_MFMA>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
+}
+__global__ void __launch_bounds__(256) k_debug_solve(WS w, Dims dm) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg_cyclic_solve<1>(w.Z, w.D, w.O, w.F, w.Linv, dm.p, dm.dp, dm.nt, lds);
+}
+
+// ---------------------------------------------------------------------------------- launch configuration
+static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
+static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
+static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
+static size_t solve_lds(const Dims& dm) { return (size_t)(3 * dm.dp * 3 + TB * 3 + 8 + 8) * sizeof(double); }
+
+static int set_lds_attrs() {
+  static bool done = false;
+  if (done) return TMPC_OK;
+  const int big = 160 * 1024;
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_final_stage, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  done = true;
+  return TMPC_OK;
+}
+
+// one chunk (dm.B = actual number of problems in this chunk, <= capacity); inputs already on device
+static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st) {
+  Dims dm = h->dm;
+  dm.B = nb;
+  dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
+  WS w = h->ws;
+  w.A = dA; w.Bm = dB; w.H = dH;
+  const Opts o = h->opt;
+  const int BP = nb * dm.p;
+  const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
+  HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_init_stage, dim3(BP), dim3(64), slots_bytes(2), st, w, dm);
+  hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, w, dm);
+  hipLaunchKernelGGL(k_init_state, dim3(BP), dim3(64), 0, st, w, dm);
+  int active = 0;
+  HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int cap = o.max_iter + o.center_iter + 2;
+  int it = 0;
+  while (active > 0 && it < cap) {
+    if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
+    hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
+    hipLaunchKernelGGL(k_ctrl_a, dim3(nb), dim3(64), 0, st, w, dm, o);
+    if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
+    hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
+    if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
+    if (dm.flags & 1) hipLaunchKernelGGL(k_factor<false>, dim3(nb), dim3(256), factor_lds(), st, w, dm);
+    else hipLaunchKernelGGL(k_factor<true>, dim3(nb), dim3(256), factor_lds(), st, w, dm);
+    if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
+    for (int pass = 1; pass <= 2; ++pass) {
+      hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
+      hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
+      hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
+      if (pass == 1) {
+        hipLaunchKernelGGL(k_ctrl_b, dim3(nb), dim3(64), 0, st, w, dm);
+        if (prof) HIPCHK(hipEventRecord(h->ev[4], st));
+      } else {
+        hipLaunchKernelGGL(k_ctrl_c, dim3(nb), dim3(64), 0, st, w, dm);
+      }
+    }
+    hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
+    HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
+    if (prof) HIPCHK(hipEventRecord(h->ev[5], st));
+    HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (prof) {
+      float ms;
+      for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1])); h->prof[i] += ms; }
+      h->prof[5] += 1.0;
+    }
+    ++it;
+  }
+  h->prof[7] += it;
+  hipLaunchKernelGGL(k_final_stage, dim3(BP), dim3(64), slots_bytes(FIN_SLOTS), st, w, dm);
+  hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, w, dm);
+  HIPCHK(hipGetLastError());
+  return TMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char* tmpc_last_error(void) { return g_err; }
+const char* tmpc_version(void) { return "tunempc_amd 0.1 (gfx950, fp64 MFMA)"; }
+
+int tmpc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) {
+  if (chunk < 1 || !dims_ok(p, nx, mb)) return 0;
+  WS w;
+  Dims dm = make_dims(chunk, p, nx, mb);
+  return (uint64_t)carve(w, dm, nullptr, nullptr);
+}
+
+int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) {
+  if (!out) return TMPC_E_ARG;
+  *out = nullptr;
+  if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }
+  if (chunk <= 0) {
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    const uint64_t per = tmpc_workspace_bytes(1, p, nx, mb);
+    uint64_t fit = (uint64_t)(0.6 * (double)fr) / std::max<uint64_t>(per, 1);
+    chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(512, fit));
+  }
+  tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
+  if (!h) return TMPC_E_NOMEM;
+  h->dm = make_dims(chunk, p, nx, mb);
+  h->opt.tol = 1e-6; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
+  h->flags = 0;
+  h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
+  if (hipMalloc(&h->slab, h->slab_bytes) != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "hipMalloc(%zu bytes) failed", h->slab_bytes);
+    free(h);
+    return TMPC_E_NOMEM;
+  }
+  carve(h->ws, h->dm, (char*)h->slab, h);
+  for (int i = 0; i < 8; ++i) { if (hipEventCreate(&h->ev[i]) != hipSuccess) { hipFree(h->slab); free(h); return TMPC_E_HIP; } }
+  int rc = set_lds_attrs();
+  if (rc != TMPC_OK) { hipFree(h->slab); free(h); return rc; }
+  *out = h;
+  return TMPC_OK;
+}
+
+int tmpc_destroy(tmpc_handle* h) {
+  if (!h) return TMPC_E_ARG;
+  for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
+  hipFree(h->slab);
+  free(h);
+  return TMPC_OK;
+}
+
+int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
+  if (!h) return TMPC_E_ARG;
+  if (tol > 0) h->opt.tol = tol;
+  if (center_tol > 0) h->opt.center_tol = center_tol;
+  if (max_iter > 0) h->opt.max_iter = max_iter;
+  if (center_iter > 0) h->opt.center_iter = center_iter;
+  h->flags = flags;
+  return TMPC_OK;
+}
+
+int tmpc_get_profile(tmpc_handle* h, double* out8) {
+  if (!h || !out8) return TMPC_E_ARG;
+  for (int i = 0; i < 8; ++i) { out8[i] = h->prof[i]; h->prof[i] = 0.0; }
+  return TMPC_OK;
+}
+
+static int copy_out(tmpc_handle* h, int nb, size_t off, double* Hc, double* dHc, double* P, double* alpha, double* beta,
+                    double* kappa, int32_t* status, int32_t* iters, double* info, hipMemcpyKind kind, hipStream_t st) {
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, BP = (size_t)nb * dm.p;
+  Dims d2 = dm; d2.B = nb;
+  hipLaunchKernelGGL(k_output, dim3((nb + 63) / 64), dim3(64), 0, st, h->ws, d2, h->d_abk, h->d_abk + nb, h->d_abk + 2 * nb,
+                     h->d_si, h->d_si + nb, h->d_info);
+  if (Hc) HIPCHK(hipMemcpyAsync(Hc + off * dm.p * nn, h->ws.Hc, BP * nn * sizeof(double), kind, st));
+  if (dHc) HIPCHK(hipMemcpyAsync(dHc + off * dm.p * nn, h->ws.dHc, BP * nn * sizeof(double), kind, st));
+  if (P) HIPCHK(hipMemcpyAsync(P + off * dm.p * nxx, h->ws.Pout, BP * nxx * sizeof(double), kind, st));
+  if (alpha) HIPCHK(hipMemcpyAsync(alpha + off, h->d_abk, nb * sizeof(double), kind, st));
+  if (beta) HIPCHK(hipMemcpyAsync(beta + off, h->d_abk + nb, nb * sizeof(double), kind, st));
+  if (kappa) HIPCHK(hipMemcpyAsync(kappa + off, h->d_abk + 2 * nb, nb * sizeof(double), kind, st));
+  if (status) HIPCHK(hipMemcpyAsync(status + off, h->d_si, nb * sizeof(int32_t), kind, st));
+  if (iters) HIPCHK(hipMemcpyAsync(iters + off, h->d_si + nb, nb * sizeof(int32_t), kind, st));
+  if (info) HIPCHK(hipMemcpyAsync(info + off * TMPC_INFO_STRIDE, h->d_info, (size_t)nb * TMPC_INFO_STRIDE * sizeof(double), kind, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return TMPC_OK;
+}
+
+int tmpc_convexify_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH,
+                                double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
+                                int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (!h || nbt < 1 || !dA || !dH || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
+  hipEvent_t e0 = h->ev[6], e1 = h->ev[7];
+  const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
+  if (prof) HIPCHK(hipEventRecord(e0, st));
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    int rc = run_chunk(h, nb, dA + (size_t)off * dm.p * nxx, dB ? dB + (size_t)off * dm.p * dm.nx * dm.mb : nullptr,
+                       dH + (size_t)off * dm.p * nn, st);
+    if (rc != TMPC_OK) return rc;
+    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToDevice, st);
+    if (rc != TMPC_OK) return rc;
+  }
+  if (prof) {
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); h->prof[6] += ms;
+  }
+  return TMPC_OK;
+}
+
+int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H,
+                              double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
+                              int32_t* status, int32_t* iters, double* info) {
+  if (!h || nbt < 1 || !A || !H || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  hipStream_t st = 0;
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t BP = (size_t)nb * dm.p;
+    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st);
+    if (rc != TMPC_OK) return rc;
+    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
+    if (rc != TMPC_OK) return rc;
+  }
+  return TMPC_OK;
+}
+
+int tmpc_supplement_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* P, double* dHc) {
+  if (!h || nbt < 1 || !A || !P || !dHc || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  hipStream_t st = 0;
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t BP = (size_t)nb * dm.p;
+    Dims d2 = dm; d2.B = nb;
+    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->ws.P, P + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2);
+    HIPCHK(hipMemcpyAsync(dHc + (size_t)off * dm.p * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return TMPC_OK;
+}
+
+int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
+  if (!h || nbt < 1 || !H || !out) return TMPC_E_ARG;
+  hipStream_t st = 0;
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t BP = (size_t)nb * dm.p;
+    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_eig_scan, dim3((unsigned)BP), dim3(64), slots_bytes(2), st, h->dH, h->ws.part, dm.n);
+    HIPCHK(hipMemcpyAsync(out + (size_t)off * dm.p * 4, h->ws.part, BP * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return TMPC_OK;
+}
+
+int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
+  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16) return TMPC_E_ARG;
+  double *dC, *dA, *dB;
+  HIPCHK(hipMalloc(&dC, (size_t)M * N * 8)); HIPCHK(hipMalloc(&dA, (size_t)M * K * 8)); HIPCHK(hipMalloc(&dB, (size_t)N * K * 8));
+  HIPCHK(hipMemcpy(dC, C, (size_t)M * N * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dB, B, (size_t)N * K * 8, hipMemcpyHostToDevice));
+  if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  else hipLaunchKernelGGL(k_debug_gemm<true>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(C, dC, (size_t)M * N * 8, hipMemcpyDeviceToHost));
+  hipFree(dC); hipFree(dA); hipFree(dB);
+  return TMPC_OK;
+}
+
+// Factor + solve one block-cyclic-tridiagonal system given dense blocks (unit test of k_factor / wg_cyclic_solve):
+// D [p][d][d] diagonal blocks, Ccpl [p][d][d] with Ccpl[k] = T[block k, block k+1 mod p], rhs/x [p][d].
+int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift) {
+  if (!h || p < 1 || d < 1 || !D || !Ccpl || !rhs || !x) return TMPC_E_ARG;
+  Dims dm; memset(&dm, 0, sizeof(dm));
+  dm.B = 1; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB; dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
+  const int dp = dm.dp;
+  const size_t bs = (size_t)dp * dp;
+  std::vector<double> hD(p * bs, 0.0), hO(p * bs, 0.0), hF(p * bs, 0.0), hdd((size_t)p * dp, 1.0), hz((size_t)p * dp, 0.0);
+  for (int k = 0; k < p; ++k) {
+    for (int i = 0; i < dp; ++i)
+      for (int j = 0; j < dp; ++j) {
+        double dv = (i == j) ? 1.0 : 0.0, cv = 0.0;
+        if (i < d && j < d) { dv = D[((size_t)k * d + i) * d + j]; cv = Ccpl[((size_t)k * d + i) * d + j]; }
+        hD[k * bs + (size_t)i * dp + j] = dv;
+        if (k == p - 1) hF[(size_t)i * dp + j] = cv; else hO[k * bs + (size_t)j * dp + i] = cv;
+      }
+    for (int i = 0; i < d; ++i) { hdd[(size_t)k * dp + i] = D[((size_t)k * d + i) * d + i]; hz[(size_t)k * dp + i] = rhs[(size_t)k * d + i]; }
+  }
+  WS w; memset(&w, 0, sizeof(w));
+  int hip_[IS]; memset(hip_, 0, sizeof(hip_));
+  HIPCHK(hipMalloc(&w.D, p * bs * 8)); HIPCHK(hipMalloc(&w.O, p * bs * 8)); HIPCHK(hipMalloc(&w.F, p * bs * 8));
+  HIPCHK(hipMalloc(&w.Linv, (size_t)p * dm.nt * TB * TB * 8)); HIPCHK(hipMalloc(&w.Ddiag, (size_t)p * dp * 8));
+  HIPCHK(hipMalloc(&w.Z, (size_t)p * dp * 8)); HIPCHK(hipMalloc(&w.iprob, sizeof(hip_)));
+  HIPCHK(hipMemcpy(w.D, hD.data(), p * bs * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w.O, hO.data(), p * bs * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w.F, hF.data(), p * bs * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w.Ddiag, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w.Z, hz.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(w.iprob, hip_, sizeof(hip_), hipMemcpyHostToDevice));
+  if (dm.flags & 1) hipLaunchKernelGGL(k_factor<false>, dim3(1), dim3(256), factor_lds(), 0, w, dm);
+  else hipLaunchKernelGGL(k_factor<true>, dim3(1), dim3(256), factor_lds(), 0, w, dm);
+  hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(256), solve_lds(dm), 0, w, dm);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(hz.data(), w.Z, (size_t)p * dp * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hip_, w.iprob, sizeof(hip_), hipMemcpyDeviceToHost));
+  for (int k = 0; k < p; ++k) for (int i = 0; i < d; ++i) x[(size_t)k * d + i] = hz[(size_t)k * dp + i];
+  if (nshift) *nshift = hip_[I_NSHIFT];
+  hipFree(w.D); hipFree(w.O); hipFree(w.F); hipFree(w.Linv); hipFree(w.Ddiag); hipFree(w.Z); hipFree(w.iprob);
+  return TMPC_OK;
+}
+
+}  // extern "C"

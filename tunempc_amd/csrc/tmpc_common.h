@@ -1,0 +1,96 @@
+// Shared definitions for the MI355X (gfx950) convexifier kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tmpc {
+
+constexpr double ALPHA_MIN = 1e-8;     // reference: convexifier.py:245  (alpha > 1e-8)
+constexpr int TB = 64;                 // tile size of the d x d block factorisation (potrf / trsm granularity)
+
+// ---- per-problem double scalars (prob[b*PS + idx])
+enum {
+  P_TAU = 0, P_ALPHA, P_S0, P_X0, P_MU, P_MUT, P_SIGMU, P_AP, P_AD, P_S, P_SBETA, P_PINF, P_DINF, P_RELGAP,
+  P_STEPN, P_PREVSTEPN, P_DTAU, P_DALPHA, P_DS0, P_DX0, P_RD0, P_CORR0, P_MINEIG_H, P_BTT, P_BTA, P_BAA,
+  P_SB00, P_SB01, P_SB11, P_RHS_TAU, P_RHS_ALPHA, P_SXS, P_MINEIG_HC, P_MAXCOND, P_KAPPA, P_BETA, P_ALPHA_OUT,
+  P_MAXEIG_HC, PS = 48
+};
+// ---- per-problem int scalars (iprob[b*IS + idx])
+enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, IS = 16 };
+// phases
+enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2 };
+// ipm status
+enum { IPM_OPTIMAL = 0, IPM_INACCURATE = 1, IPM_MAXITER = 2 };
+// reference status strings (convexifier.py:442-451)
+enum { ST_OPTIMAL = 0, ST_FEASIBLE = 1, ST_INFEASIBLE = 2 };
+
+// ---- per-stage partial scalars (part[(b*p+k)*NPART + idx])
+enum {
+  Q_XS = 0, Q_RD2, Q_S2, Q_TRX2, Q_HBY, Q_TRPSI, Q_TRPHI2, Q_HBPHI,   // stage_pre
+  Q_TRT2, Q_HBG,                                                       // stage_rhs
+  Q_MINX, Q_MINS, Q_DXS, Q_XDS, Q_DXDS, Q_DP2, Q_P2,                   // stage_dir
+  Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, NPART = 24
+};
+
+// Kronecker-factor slots per stage (KF[((b*p+k)*12 + slot) * nx*nx])
+enum { KF_XXX = 0, KF_SIXX, KF_KX, KF_KS, KF_FX, KF_FS, KF_PER_LMI = 6 };
+// adjoint slots per stage: 0: G = T1-T2 (rhs), 1: Psi (tau column), 2: PhiH (alpha column)
+enum { ADJ_G = 0, ADJ_PSI, ADJ_PHI, NADJ = 3 };
+
+struct Dims {
+  int B;        // problems in this chunk
+  int p;        // period (stages per problem)
+  int nx, mb;   // state / input(+slack) dims
+  int n;        // nx + mb
+  int d;        // nx(nx+1)/2
+  int dp;       // d padded to a multiple of 16
+  int nt;       // ceil(dp / TB)
+  int flags;    // bit0: debug - replace MFMA by scalar FMAs
+};
+
+struct Opts {
+  double tol;          // relative duality gap on kappa (max condition number)
+  double center_tol;   // relative Newton step that ends the centering phase
+  int max_iter;
+  int center_iter;
+};
+
+// Device workspace (all pointers device memory, fp64 row-major)
+struct WS {
+  // inputs (chunk views)
+  const double* A; const double* Bm; const double* H;
+  // scaled data
+  double* Hb;      // [B,p,n,n]   s * H
+  double* V;       // [B,p,nx,n]  [A B]
+  // iterate
+  double* P;       // [B,p,nx,nx] (scaled Pbar)
+  double* X1; double* X2; double* S1; double* S2;       // [B,p,n,n]
+  // per-iteration stage data
+  double* S1i; double* S2i; double* L1i; double* L2i; double* LX1i; double* LX2i;
+  double* Rd1; double* Rd2; double* T1; double* T2;
+  double* dS1; double* dS2; double* dX1; double* dX2; double* c1; double* c2;
+  double* dP;      // [B,p,nx,nx]
+  double* KF;      // [B,p,12,nx,nx]
+  double* adjV;    // [B,p,3,nx,nx]
+  double* adjE;    // [B,p,3,nx,nx]
+  double* part;    // [B,p,NPART]
+  double* prob;    // [B,PS]
+  int* iprob;      // [B,IS]
+  // Schur system
+  double* D;       // [B,p,dp,dp]   diagonal blocks -> Cholesky factors (diag tiles hold L_jj, inverse in Linv)
+  double* O;       // [B,p,dp,dp]   sub-diagonal blocks T[P_{k+1},P_k] -> O_k
+  double* F;       // [B,p,dp,dp]   cyclic fill row T[P_{p-1},P_k]    -> F_k
+  double* Linv;    // [B,p,nt,TB,TB] inverses of the diagonal tiles
+  double* Ddiag;   // [B,p,dp]      assembled diagonal of D (pivot reference for Cholesky-with-shift)
+  double* W3;      // [B,p,dp,3]    pass-1 right-hand sides [rhs | u_tau | u_alpha] -> solutions
+  double* U;       // [B,p,dp,2]    border columns (tau, alpha)
+  double* TU;      // [B,p,dp,2]    T^-1 U
+  double* Z;       // [B,p,dp]      rhs / solution
+  int* active;     // [1] number of problems still iterating
+  // outputs
+  double* Hc;      // [B,p,n,n]
+  double* dHc;     // [B,p,n,n]
+  double* Pout;    // [B,p,nx,nx]
+};
+
+}  // namespace tmpc

@@ -1,0 +1,475 @@
+// Block-cyclic-tridiagonal Cholesky of the HKM Schur matrix and the matching triangular solves.
+//
+// One 256-thread workgroup (4 wavefronts) per tuning problem walks the p stages sequentially (they are
+// chained through P_k / P_{k+1}); all the d x d block work is GEMM-shaped and runs on the fp64 matrix
+// cores: v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile
+// (2 x 2 MFMA tiles), K staged through LDS 16 columns at a time with register prefetch of the next slab.
+//
+// Storage per stage k (all dp x dp, row-major, dp = d rounded up to 16, padding = identity / zero):
+//   D[k]  diagonal block  -> L_k   (64 x 64 diagonal tiles hold L_jj; their inverses go to Linv)
+//   O[k]  T[P_{k+1},P_k]  -> O_k = T[..] L_k^-T
+//   F[k]  fill of the cyclic corner row T[P_{p-1},P_k] -> F_k
+#pragma once
+#include "tmpc_common.h"
+
+namespace tmpc {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GK = 16;             // K slab staged in LDS per step
+constexpr int GLD = GK + 1;        // LDS leading dim (doubles) of the A/B slabs
+constexpr int FACT_LDS_DOUBLES = 64 * 65 + 64 * 65 + 64 + 8;   // potrf tile + inverse + diag ref (+counter); the GEMM slabs (2*64*GLD) alias the front
+
+enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
+
+// C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
+// lower: skip 64x64 tiles strictly above the block diagonal (SYRK-style update of a symmetric block).
+// In-place use (C aliasing A with K == N-tile width) is safe: a C tile is stored only after all of its
+// A slabs have been loaded.
+template <bool USE_MFMA>
+__device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
+                                           const double* B, int ldb, int M, int N, int K, int mode, bool lower,
+                                           double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  double* As = lds;
+  double* Bs = lds + 64 * GLD;
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;     // slab loader: row, first k
+  const int nks = K / GK;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      if (lower && n0 > m0) continue;
+      double4_t acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      double ra[4], rb[4];
+      const bool arow_ok = (m0 + lrow) < M, brow_ok = (n0 + lrow) < N;
+      const double* ap = A + (size_t)(m0 + lrow) * lda + lk;
+      const double* bp = B + (size_t)(n0 + lrow) * ldb + lk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ra[q] = arow_ok ? ap[q] : 0.0; rb[q] = brow_ok ? bp[q] : 0.0; }
+      for (int ks = 0; ks < nks; ++ks) {
+        __syncthreads();                     // previous slab fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { As[lrow * GLD + lk + q] = ra[q]; Bs[lrow * GLD + lk + q] = rb[q]; }
+        __syncthreads();
+        if (ks + 1 < nks) {
+          const double* ap2 = ap + (size_t)(ks + 1) * GK;
+          const double* bp2 = bp + (size_t)(ks + 1) * GK;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { ra[q] = arow_ok ? ap2[q] : 0.0; rb[q] = brow_ok ? bp2[q] : 0.0; }
+        }
+        const int fr = lane & 15, fk = lane >> 4;
+        if (USE_MFMA) {
+#pragma unroll
+          for (int kk = 0; kk < GK / 4; ++kk) {
+            const double a0 = As[(wr * 32 + fr) * GLD + kk * 4 + fk];
+            const double a1 = As[(wr * 32 + 16 + fr) * GLD + kk * 4 + fk];
+            const double b0 = Bs[(wc * 32 + fr) * GLD + kk * 4 + fk];
+            const double b1 = Bs[(wc * 32 + 16 + fr) * GLD + kk * 4 + fk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+          }
+        } else {   // debug path: same fragment ownership, scalar FMAs
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = wr * 32 + i * 16 + fk + 4 * r, col = wc * 32 + j * 16 + fr;
+                double s = acc[i][j][r];
+                for (int kk = 0; kk < GK; ++kk) s = fma(As[row * GLD + kk], Bs[col * GLD + kk], s);
+                acc[i][j][r] = s;
+              }
+        }
+      }
+      // epilogue: C/D fragment of v_mfma_f64_16x16x4: reg r -> row (lane>>4) + 4r, col lane&15
+      const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wr * 32 + i * 16;
+        if (rbase >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wc * 32 + j * 16;
+          if (cbase >= N) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double* cp = C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;
+            const double v = acc[i][j][r];
+            if (mode == GM_SUB) *cp -= v; else if (mode == GM_SET) *cp = v; else *cp = -v;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
+// dref: assembled diagonal entries (pivot reference).  Returns number of shifted pivots (thread-uniform).
+__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds) {
+  const int tid = threadIdx.x;
+  double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
+  double* Si = S + 64 * 65;                // 64 x 65
+  double* dr = Si + 64 * 65;               // 64
+  int* s_badp = (int*)(dr + 64);
+  if (tid == 0) *s_badp = 0;
+  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * 65 + j] = T[(size_t)i * ldt + j]; }
+  if (tid < nb) dr[tid] = dref[tid];
+  __syncthreads();
+  const int row = tid & 63, cg = tid >> 6;
+  for (int j = 0; j < nb; ++j) {
+    double piv = S[j * 65 + j];
+    const double ref = fabs(dr[j]);
+    bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
+    if (bad) piv = (ref > 0.0 ? ref : 1.0) * 1e20;       // Cholesky-with-shift: freeze this direction
+    const double dj = sqrt(piv);
+    __syncthreads();
+    if (tid == 0) { S[j * 65 + j] = dj; if (bad) *s_badp += 1; }
+    if (cg == 0 && row > j && row < nb) S[row * 65 + j] /= dj;
+    __syncthreads();
+    if (row > j && row < nb) {
+      const double lij = S[row * 65 + j];
+      for (int c = j + 1 + cg; c <= row; c += 4) S[row * 65 + c] -= lij * S[c * 65 + j];
+    }
+    __syncthreads();
+  }
+  // inverse, one column per thread (threads 0..nb-1)
+  if (tid < nb) {
+    const int c = tid;
+    for (int i = 0; i < c; ++i) Si[i * 65 + c] = 0.0;
+    Si[c * 65 + c] = 1.0 / S[c * 65 + c];
+    for (int i = c + 1; i < nb; ++i) {
+      double acc = 0.0;
+      for (int k2 = c; k2 < i; ++k2) acc = fma(S[i * 65 + k2], Si[k2 * 65 + c], acc);
+      Si[i * 65 + c] = -acc / S[i * 65 + i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) T[(size_t)i * ldt + j] = S[i * 65 + j];
+    Ti[i * TB + j] = Si[i * 65 + j];
+  }
+  __syncthreads();
+  const int nb_bad = *s_badp;
+  __syncthreads();
+  return nb_bad;
+}
+
+// Left-looking blocked Cholesky of the block column headed by Dk, applied also to the rows of R1 (and R2):
+//   Dk = L L' ;  R1 <- R1 L^-T ;  R2 <- R2 L^-T        (R1/R2 may be null)
+template <bool USE_MFMA>
+__device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R2, double* Linv_k, const double* dref,
+                                               int dp, double* lds) {
+  int nbad = 0;
+  int jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    if (j0 > 0) {
+      wg_gemm_nt<USE_MFMA>(Dk + (size_t)j0 * dp + j0, dp, Dk + (size_t)j0 * dp, dp, Dk + (size_t)j0 * dp, dp, dp - j0, nb, j0, GM_SUB, false, lds);
+      if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+      if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+    }
+    double* Ti = Linv_k + (size_t)jt * TB * TB;
+    nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
+    // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
+    if (dp - j0 - nb > 0)
+      wg_gemm_nt<USE_MFMA>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
+    if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+    if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+  }
+  return nbad;
+}
+
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
+  const int b = blockIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int p = dm.p, dp = dm.dp, tid = threadIdx.x;
+  const size_t bs = (size_t)dp * dp;
+  double* D = w.D + (size_t)b * p * bs;
+  double* O = w.O + (size_t)b * p * bs;
+  double* F = w.F + (size_t)b * p * bs;
+  double* Li = w.Linv + (size_t)b * p * dm.nt * TB * TB;
+  const double* dref = w.Ddiag + (size_t)b * p * dp;
+  const size_t ls = (size_t)dm.nt * TB * TB;
+  int nbad = 0;
+  if (p == 1) {
+    // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'   (C stored in F[0])
+    for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += F[e] + F[(size_t)j * dp + i]; }
+    __syncthreads();
+    nbad += wg_block_column<USE_MFMA>(D, nullptr, nullptr, Li, dref, dp, lds);
+  } else {
+    for (int k = 0; k < p - 1; ++k) {
+      double* Dk = D + k * bs; double* Ok = O + k * bs; double* Fk = F + k * bs;
+      const bool last = (k == p - 2);
+      if (last) {   // the fill of the cyclic corner meets the sub-diagonal block
+        for (int e = tid; e < dp * dp; e += 256) Ok[e] += Fk[e];
+        __syncthreads();
+      }
+      nbad += wg_block_column<USE_MFMA>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
+      // Schur updates
+      wg_gemm_nt<USE_MFMA>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+      if (!last) {
+        wg_gemm_nt<USE_MFMA>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+        wg_gemm_nt<USE_MFMA>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+      }
+    }
+    nbad += wg_block_column<USE_MFMA>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds);
+  }
+  if (tid == 0 && nbad) ip[I_NSHIFT] += nbad;
+}
+
+// ------------------------------------------------------------------ triangular solves with the block factor
+// vectors: [p][dp][NC] (NC interleaved right-hand sides) in global memory, solved in place.
+
+// y[r0 + i] -= sum_c M[i][c] * x[c]   for i < rows, c < cols  (M row-major ldm); wave per row
+template <int NC>
+__device__ __forceinline__ void mv_sub(double* y, const double* M, int ldm, const double* x, int rows, int cols) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = wv; i < rows; i += 4) {
+    double acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+    const double* mr = M + (size_t)i * ldm;
+    for (int c = lane; c < cols; c += 64) {
+      const double m = mr[c];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[q] = fma(m, x[c * NC + q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      double v = acc[q];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) y[i * NC + q] -= v;
+    }
+  }
+}
+// y[c] -= sum_i M[i][c] * x[i]   (transposed product); thread per column
+template <int NC>
+__device__ __forceinline__ void mtv_sub(double* y, const double* M, int ldm, const double* x, int rows, int cols) {
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    double acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+    for (int i = 0; i < rows; ++i) {
+      const double m = M[(size_t)i * ldm + c];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[q] = fma(m, x[i * NC + q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) y[c * NC + q] -= acc[q];
+  }
+}
+
+// z <- L_k^-1 z   (z: dp x NC in LDS), using the inverted diagonal tiles
+template <int NC>
+__device__ __forceinline__ void blk_fwd(double* z, double* tmp, const double* Dk, const double* Lik, int dp) {
+  int jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    const double* Ti = Lik + (size_t)jt * TB * TB;
+    // tmp = Ti * z[j0..]
+    for (int e = threadIdx.x; e < nb * NC; e += 256) tmp[e] = 0.0;
+    __syncthreads();
+    {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int i = wv; i < nb; i += 4) {
+        double acc[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+        for (int c = lane; c <= i; c += 64) {
+          const double m = Ti[i * TB + c];
+#pragma unroll
+          for (int q = 0; q < NC; ++q) acc[q] = fma(m, z[(j0 + c) * NC + q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          double v = acc[q];
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          if (lane == 0) tmp[i * NC + q] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nb * NC; e += 256) z[j0 * NC + e] = tmp[e];
+    __syncthreads();
+    const int rem = dp - j0 - nb;
+    if (rem > 0) mv_sub<NC>(z + (size_t)(j0 + nb) * NC, Dk + (size_t)(j0 + nb) * dp + j0, dp, z + (size_t)j0 * NC, rem, nb);
+    __syncthreads();
+  }
+}
+// z <- L_k^-T z
+template <int NC>
+__device__ __forceinline__ void blk_bwd(double* z, double* tmp, const double* Dk, const double* Lik, int dp) {
+  const int nt = (dp + TB - 1) / TB;
+  for (int jt = nt - 1; jt >= 0; --jt) {
+    const int j0 = jt * TB;
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    const double* Ti = Lik + (size_t)jt * TB * TB;
+    // tmp = Ti' * z[j0..]
+    for (int c = threadIdx.x; c < nb; c += 256) {
+      double acc[NC];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+      for (int i = c; i < nb; ++i) {
+        const double m = Ti[i * TB + c];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = fma(m, z[(j0 + i) * NC + q], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q) tmp[c * NC + q] = acc[q];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nb * NC; e += 256) z[j0 * NC + e] = tmp[e];
+    __syncthreads();
+    if (j0 > 0) mtv_sub<NC>(z, Dk + (size_t)j0 * dp, dp, z + (size_t)j0 * NC, nb, j0);
+    __syncthreads();
+  }
+}
+
+// Solve T x = r for NC interleaved right-hand sides stored at R [p][dp][NC] (in place).
+template <int NC>
+__device__ __forceinline__ void wg_cyclic_solve(double* R, const double* D, const double* O, const double* F,
+                                                const double* Li, int p, int dp, int nt, double* lds) {
+  const size_t bs = (size_t)dp * dp, ls = (size_t)nt * TB * TB;
+  double* zc = lds;                   // current stage      dp*NC
+  double* zn = zc + dp * NC;          // next stage         dp*NC
+  double* zl = zn + dp * NC;          // last stage         dp*NC
+  double* tmp = zl + dp * NC;         // TB*NC
+  const int tid = threadIdx.x, len = dp * NC;
+  if (p == 1) {
+    for (int e = tid; e < len; e += 256) zc[e] = R[e];
+    __syncthreads();
+    blk_fwd<NC>(zc, tmp, D, Li, dp);
+    blk_bwd<NC>(zc, tmp, D, Li, dp);
+    for (int e = tid; e < len; e += 256) R[e] = zc[e];
+    __syncthreads();
+    return;
+  }
+  // ---- forward
+  for (int e = tid; e < len; e += 256) { zc[e] = R[e]; zl[e] = R[(size_t)(p - 1) * len + e]; }
+  __syncthreads();
+  for (int k = 0; k < p - 1; ++k) {
+    blk_fwd<NC>(zc, tmp, D + k * bs, Li + k * ls, dp);
+    for (int e = tid; e < len; e += 256) R[(size_t)k * len + e] = zc[e];
+    if (k + 1 < p - 1) { for (int e = tid; e < len; e += 256) zn[e] = R[(size_t)(k + 1) * len + e]; }
+    __syncthreads();
+    if (k + 1 < p - 1) {
+      mv_sub<NC>(zn, O + k * bs, dp, zc, dp, dp);
+      mv_sub<NC>(zl, F + k * bs, dp, zc, dp, dp);
+    } else {
+      mv_sub<NC>(zl, O + k * bs, dp, zc, dp, dp);      // k = p-2: O_k couples into the last block
+    }
+    __syncthreads();
+    if (k + 1 < p - 1) { for (int e = tid; e < len; e += 256) zc[e] = zn[e]; }
+    __syncthreads();
+  }
+  blk_fwd<NC>(zl, tmp, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp);
+  // ---- backward
+  blk_bwd<NC>(zl, tmp, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp);
+  for (int e = tid; e < len; e += 256) { R[(size_t)(p - 1) * len + e] = zl[e]; zn[e] = zl[e]; }
+  __syncthreads();
+  for (int k = p - 2; k >= 0; --k) {
+    for (int e = tid; e < len; e += 256) zc[e] = R[(size_t)k * len + e];
+    __syncthreads();
+    mtv_sub<NC>(zc, O + k * bs, dp, zn, dp, dp);          // O_k' x_{k+1}
+    __syncthreads();
+    if (k < p - 2) { mtv_sub<NC>(zc, F + k * bs, dp, zl, dp, dp); __syncthreads(); }
+    blk_bwd<NC>(zc, tmp, D + k * bs, Li + k * ls, dp);
+    for (int e = tid; e < len; e += 256) { R[(size_t)k * len + e] = zc[e]; zn[e] = zc[e]; }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double wg_reduce_sum(double v, double* red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  const double r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+// pass 1: solve [rhs | u_tau | u_alpha]; pass 2: solve rhs.  Then the 2x2 border system and dP.
+__global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
+  const int b = blockIdx.x;
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p, dp = dm.dp, nt = dm.nt, tid = threadIdx.x, nx = dm.nx;
+  const size_t bs = (size_t)dp * dp;
+  const double* D = w.D + (size_t)b * p * bs;
+  const double* O = w.O + (size_t)b * p * bs;
+  const double* F = w.F + (size_t)b * p * bs;
+  const double* Li = w.Linv + (size_t)b * p * nt * TB * TB;
+  const size_t vl = (size_t)p * dp;
+  double* W3 = w.W3 + (size_t)b * vl * 3;
+  double* Z = w.Z + (size_t)b * vl;
+  double* TU = w.TU + (size_t)b * vl * 2;
+  const double* U = w.U + (size_t)b * vl * 2;
+  double* red = lds + 3 * dp * 3 + TB * 3 + 8;
+  const bool have_rhs = (pass == 2) || (phase == PH_MAIN);
+  if (pass == 1) {
+    wg_cyclic_solve<3>(W3, D, O, F, Li, p, dp, nt, lds);
+    double s00 = 0.0, s01 = 0.0, s11 = 0.0;
+    for (size_t e = tid; e < vl; e += 256) {
+      const double t0 = W3[e * 3 + 1], t1 = W3[e * 3 + 2];
+      TU[e * 2] = t0; TU[e * 2 + 1] = t1;
+      Z[e] = W3[e * 3];
+      s00 = fma(U[e * 2], t0, s00); s01 = fma(U[e * 2], t1, s01); s11 = fma(U[e * 2 + 1], t1, s11);
+    }
+    s00 = wg_reduce_sum(s00, red); s01 = wg_reduce_sum(s01, red); s11 = wg_reduce_sum(s11, red);
+    if (tid == 0) { pr[P_SB00] = pr[P_BTT] - s00; pr[P_SB01] = pr[P_BTA] - s01; pr[P_SB11] = pr[P_BAA] - s11; }
+  } else {
+    wg_cyclic_solve<1>(Z, D, O, F, Li, p, dp, nt, lds);
+  }
+  __syncthreads();
+  if (!have_rhs) return;
+  // border:  rb = [rhs_tau, rhs_alpha] - U' z ;  db = Sb^-1 rb ;  dp = z - TU db
+  double u0 = 0.0, u1 = 0.0;
+  for (size_t e = tid; e < vl; e += 256) { const double z = Z[e]; u0 = fma(U[e * 2], z, u0); u1 = fma(U[e * 2 + 1], z, u1); }
+  u0 = wg_reduce_sum(u0, red); u1 = wg_reduce_sum(u1, red);
+  double trt2 = 0.0, hbg = 0.0;
+  for (int k = tid; k < p; k += 256) { const double* q = w.part + (size_t)(b * p + k) * NPART; trt2 += q[Q_TRT2]; hbg += q[Q_HBG]; }
+  trt2 = wg_reduce_sum(trt2, red); hbg = wg_reduce_sum(hbg, red);
+  const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
+  const double corr0 = (pass == 1) ? 0.0 : pr[P_CORR0];
+  const double s0 = pr[P_S0], x0 = pr[P_X0], rd0 = pr[P_RD0];
+  const double t0 = sig / s0 - x0 * rd0 / s0 - corr0;
+  const double rb0 = (trt2 - 1.0) - u0, rb1 = (hbg + t0) - u1;
+  const double a = pr[P_SB00], bb = pr[P_SB01], c = pr[P_SB11];
+  const double det = a * c - bb * bb;
+  const double dtau = (c * rb0 - bb * rb1) / det, dalpha = (a * rb1 - bb * rb0) / det;
+  __syncthreads();
+  if (tid == 0) { pr[P_DTAU] = dtau; pr[P_DALPHA] = dalpha; }
+  // dP_k = smat(z - TU db)
+  double* dPg = w.dP + (size_t)b * p * nx * nx;
+  const int d = dm.d;
+  for (int e = tid; e < p * d; e += 256) {
+    const int k = e / d, idx = e - k * d;
+    // idx -> (a,c), a <= c  (row-major upper triangle)
+    int a2 = 0, rem = idx;
+    while (rem >= nx - a2) { rem -= nx - a2; ++a2; }
+    const int c2 = a2 + rem;
+    const size_t vi = (size_t)k * dp + idx;
+    const double v = Z[vi] - TU[vi * 2] * dtau - TU[vi * 2 + 1] * dalpha;
+    dPg[(size_t)k * nx * nx + a2 * nx + c2] = v;
+    dPg[(size_t)k * nx * nx + c2 * nx + a2] = v;
+  }
+}
+
+}  // namespace tmpc

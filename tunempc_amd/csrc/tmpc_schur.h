@@ -1,0 +1,297 @@
+// Schur-complement assembly and per-problem control kernels.
+//
+// The HKM Schur matrix of the convexifier SDP is block-cyclic-tridiagonal in the stage index because
+// stage k touches only P_k and P_{k+1} (reference: convexifier.py:335-336).  Every d x d block is a
+// sum of symmetric Kronecker products of nx x nx matrices, so it is assembled in O(d^2) from the
+// Kronecker factors written by k_stage_pre (no PICOS-style symbolic model is ever materialised;
+// reference: convexifier.py:213-357).
+#pragma once
+#include "tmpc_common.h"
+#include "tmpc_small.h"
+
+namespace tmpc {
+
+// 0.5*(T(Lx,Ls)+T(Ls,Lx)) [(ab),(cd)],   T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>
+__device__ __forceinline__ double hkm_entry(const double* __restrict__ Lx, const double* __restrict__ Ls, int ldk,
+                                            int a, int b, int c, int d_) {
+  const double xac = Lx[a * ldk + c], xad = Lx[a * ldk + d_], xbc = Lx[b * ldk + c], xbd = Lx[b * ldk + d_];
+  const double sac = Ls[a * ldk + c], sad = Ls[a * ldk + d_], sbc = Ls[b * ldk + c], sbd = Ls[b * ldk + d_];
+  const double t = (xac * sbd + xad * sbc + xbc * sad + xbd * sac) + (sac * xbd + sad * xbc + sbc * xad + sbd * xac);
+  const double wr = (a == b) ? 0.5 : 1.0, wc = (c == d_) ? 0.5 : 1.0;
+  return 0.5 * wr * wc * t;
+}
+
+// One 256-thread workgroup per (problem, stage): D_k, and the coupling block C_k = T[P_k, P_{k+1}]
+// (stored transposed as the sub-diagonal block O_k = T[P_{k+1},P_k], or, for k = p-1, untransposed as the
+// cyclic corner F_0 = T[P_{p-1}, P_0]).
+__global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
+  const int sid = blockIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  const int tid = threadIdx.x;
+  const int nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
+  const int ldk = nx + 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  // 12 matrices: [r][0..5] = Xxx, Sixx (stage k), Kx, Ks (stage k-1), Fx, Fs (stage k)
+  double* mats = sm;
+  const int msz = nx * ldk;
+  short* ia = (short*)(sm + 12 * msz);
+  short* ib = ia + d;
+  const int km = (k == 0) ? dm.p - 1 : k - 1;
+  const double* kfk = w.KF + (size_t)sid * 12 * nxx;
+  const double* kfm = w.KF + (size_t)(b * dm.p + km) * 12 * nxx;
+  for (int e = tid; e < 12 * nxx; e += 256) {
+    const int m = e / nxx, r = e - m * nxx;
+    const int slot = m % KF_PER_LMI;
+    const double v = (slot == KF_KX || slot == KF_KS) ? kfm[e] : kfk[e];
+    const int i = r / nx, j = r - i * nx;
+    mats[m * msz + i * ldk + j] = v;
+  }
+  if (tid == 0) {
+    int e = 0;
+    for (int a = 0; a < nx; ++a)
+      for (int c = a; c < nx; ++c) { ia[e] = (short)a; ib[e] = (short)c; ++e; }
+  }
+  __syncthreads();
+  double* Dg = w.D + (size_t)sid * dp * dp;
+  const bool corner = (k == dm.p - 1);
+  double* Cg = corner ? (w.F + (size_t)(b * dm.p) * dp * dp) : (w.O + (size_t)sid * dp * dp);
+  double* dd = w.Ddiag + (size_t)sid * dp;
+  const int tot = dp * dp;
+  for (int e = tid; e < tot; e += 256) {
+    const int row = e / dp, col = e - row * dp;
+    if (row >= d || col >= d) {
+      Dg[e] = (row == col) ? 1.0 : 0.0;
+      Cg[e] = 0.0;
+      if (row == col) dd[row] = 1.0;
+      continue;
+    }
+    const int a = ia[row], bb = ib[row], c = ia[col], d_ = ib[col];
+    double cv = 0.0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
+      cv -= hkm_entry(mr + KF_FX * msz, mr + KF_FS * msz, ldk, a, bb, c, d_);
+    }
+    // C_k[(ab),(cd)] : row index belongs to P_k, column index to P_{k+1}
+    if (corner) Cg[row * dp + col] = cv; else Cg[col * dp + row] = cv;
+    if (col <= row) {
+      double dv = 0.0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
+        dv += hkm_entry(mr + KF_XXX * msz, mr + KF_SIXX * msz, ldk, a, bb, c, d_);
+        dv += hkm_entry(mr + KF_KX * msz, mr + KF_KS * msz, ldk, a, bb, c, d_);
+      }
+      Dg[row * dp + col] = dv;
+      Dg[col * dp + row] = dv;
+      if (row == col) dd[row] = dv;
+    }
+  }
+}
+
+// Gather the adjoint pieces into svec right-hand sides:  v_j[(ab)] = w_ab * (adjV[j-1] - adjE[j])[a][b]
+// which: 0 -> Z (pass-2 rhs), 1 -> W3 (pass-1: rhs | u_tau | u_alpha) and U
+__global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
+  const int sid = blockIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE) return;
+  const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
+  const int km = (k == 0) ? dm.p - 1 : k - 1;
+  const double* av = w.adjV + (size_t)(b * dm.p + km) * NADJ * nxx;
+  const double* ae = w.adjE + (size_t)sid * NADJ * nxx;
+  // enumerate (a<=b) pairs: e -> (a,b)
+  int e = 0;
+  for (int a = 0; a < nx; ++a) {
+    for (int c = a + lane; c < nx; c += 64) {
+      const int idx = e + (c - a);
+      const double wgt = (a == c) ? 1.0 : 2.0;
+      const int o = a * nx + c;
+      if (pass == 1) {
+        const double g = (phase == PH_MAIN) ? wgt * (av[ADJ_G * nxx + o] - ae[ADJ_G * nxx + o]) : 0.0;
+        const double ut = -wgt * (av[ADJ_PSI * nxx + o] - ae[ADJ_PSI * nxx + o]);
+        const double ua = wgt * (av[ADJ_PHI * nxx + o] - ae[ADJ_PHI * nxx + o]);
+        double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3;
+        w3[0] = g; w3[1] = ut; w3[2] = ua;
+        double* u = w.U + ((size_t)sid * dp + idx) * 2;
+        u[0] = ut; u[1] = ua;
+      } else {
+        w.Z[(size_t)sid * dp + idx] = wgt * (av[ADJ_G * nxx + o] - ae[ADJ_G * nxx + o]);
+      }
+    }
+    e += nx - a;
+  }
+  // zero padding
+  for (int i = dm.d + lane; i < dp; i += 64) {
+    if (pass == 1) {
+      double* w3 = w.W3 + ((size_t)sid * dp + i) * 3; w3[0] = 0.0; w3[1] = 0.0; w3[2] = 0.0;
+      double* u = w.U + ((size_t)sid * dp + i) * 2; u[0] = 0.0; u[1] = 0.0;
+    } else w.Z[(size_t)sid * dp + i] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------ per-problem control (64 lanes per problem)
+__device__ __forceinline__ double psum(const double* part, int b, int p, int idx, int lane) {
+  double acc = 0.0;
+  for (int k = lane; k < p; k += 64) acc += part[(size_t)(b * p + k) * NPART + idx];
+  return wave_sum(acc);
+}
+__device__ __forceinline__ double pmin(const double* part, int b, int p, int idx, int lane) {
+  double acc = 1e300;
+  for (int k = lane; k < p; k += 64) acc = fmin(acc, part[(size_t)(b * p + k) * NPART + idx]);
+  return wave_min(acc);
+}
+
+// after k_stage_pre: mu, residual norms, phase logic (mirrors oracle/convexify_oracle.py sdp_step1)
+__global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p, nx = dm.nx, nxx = nx * nx;
+  const double xs = psum(w.part, b, p, Q_XS, lane), rd2 = psum(w.part, b, p, Q_RD2, lane);
+  const double s2 = psum(w.part, b, p, Q_S2, lane), trx2 = psum(w.part, b, p, Q_TRX2, lane);
+  const double hby = psum(w.part, b, p, Q_HBY, lane), trpsi = psum(w.part, b, p, Q_TRPSI, lane);
+  const double trphi2 = psum(w.part, b, p, Q_TRPHI2, lane), hbphi = psum(w.part, b, p, Q_HBPHI, lane);
+  const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
+  // dual residual of the P block:  r_P[j] = -(V_{j-1} Y_{j-1} V_{j-1}' - E Y_j E'),  Y = X1 - X2
+  double rp2 = 0.0;
+  for (int e = lane; e < p * nxx; e += 64) {
+    const int j = e / nxx, r = e - j * nxx;
+    const int a = r / nx, c = r - a * nx;
+    if (c < a) continue;
+    const int jm = (j == 0) ? p - 1 : j - 1;
+    const double* kfm = w.KF + (size_t)(b * p + jm) * 12 * nxx;
+    const double* kfj = w.KF + (size_t)(b * p + j) * 12 * nxx;
+    const double v = (kfm[KF_KX * nxx + r] - kfm[(KF_PER_LMI + KF_KX) * nxx + r]) -
+                     (kfj[KF_XXX * nxx + r] - kfj[(KF_PER_LMI + KF_XXX) * nxx + r]);
+    const double wv = (a == c) ? v : 2.0 * v;
+    rp2 = fma(wv, wv, rp2);
+  }
+  rp2 = wave_sum(rp2);
+  if (lane != 0) return;
+  const double N = 2.0 * p * dm.n + 1.0;
+  const double tau = pr[P_TAU], alpha = pr[P_ALPHA], s0 = pr[P_S0], x0 = pr[P_X0];
+  const double rd0 = (alpha - ALPHA_MIN) - s0;
+  const double mu = (xs + x0 * s0) / N;
+  const double r_tau = 1.0 - trx2, r_alpha = -hby - x0;
+  const double pinf = sqrt(r_tau * r_tau + r_alpha * r_alpha + rp2) / 2.0;
+  const double dinf = sqrt(rd2 + rd0 * rd0) / (1.0 + sqrt(s2));
+  const double relgap = N * mu / fmax(1.0, fabs(tau));
+  pr[P_MU] = mu; pr[P_RD0] = rd0; pr[P_PINF] = pinf; pr[P_DINF] = dinf; pr[P_RELGAP] = relgap; pr[P_SXS] = xs;
+  pr[P_BTT] = trpsi; pr[P_BTA] = -trphi2; pr[P_BAA] = hbphi + x0 / s0;
+  if (nbad > 0.0) ip[I_CHOLBAD] += (int)nbad;
+  if (!(mu > 0.0) || !(mu < 1e300) || nbad > 0.0 || !(s0 > 0.0) || !(x0 > 0.0)) {   // breakdown: stop this problem
+    ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_MAXITER;
+    return;
+  }
+  double mut = pr[P_MUT];
+  if (mut < 0.0 && relgap < 1e-2 && dinf < 1e-2) {
+    mut = exp2(rint(log2(o.tol * fmax(1.0, fabs(tau)) / N)));
+    pr[P_MUT] = mut;
+  }
+  int phase = ip[I_PHASE];
+  if (phase == PH_MAIN && mut > 0.0 && mu <= 2.0 * mut && dinf < o.tol && pinf < fmax(o.tol, 1e-6)) {
+    phase = PH_CENTER;
+    ip[I_PHASE] = phase;
+  }
+  if (phase == PH_MAIN && ip[I_ITERS] >= o.max_iter) {
+    ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_MAXITER;
+    return;
+  }
+  ip[I_ITERS] += 1;
+  if (phase == PH_CENTER) { ip[I_NCENT] += 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
+  else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
+}
+
+// step lengths from the per-stage extreme eigenvalues + the scalar (alpha) block
+__device__ __forceinline__ void raw_steps(const double* pr, double minx, double mins, double dx0, double ds0,
+                                          double* ap, double* ad) {
+  double a_p = (minx >= 0.0) ? 1e300 : -1.0 / minx;
+  double a_d = (mins >= 0.0) ? 1e300 : -1.0 / mins;
+  if (dx0 < 0.0) a_p = fmin(a_p, -pr[P_X0] / dx0);
+  if (ds0 < 0.0) a_d = fmin(a_d, -pr[P_S0] / ds0);
+  *ap = a_p; *ad = a_d;
+}
+
+// after the predictor direction (pass 1): Mehrotra centring parameter
+__global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_MAIN) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p;
+  const double minx = pmin(w.part, b, p, Q_MINX, lane), mins = pmin(w.part, b, p, Q_MINS, lane);
+  const double dxs = psum(w.part, b, p, Q_DXS, lane), xds = psum(w.part, b, p, Q_XDS, lane);
+  const double dxds = psum(w.part, b, p, Q_DXDS, lane);
+  if (lane != 0) return;
+  const double N = 2.0 * p * dm.n + 1.0;
+  const double s0 = pr[P_S0], x0 = pr[P_X0], mu = pr[P_MU];
+  const double ds0 = pr[P_DALPHA] + pr[P_RD0];
+  const double dx0 = -x0 - x0 * ds0 / s0;
+  double ap, ad;
+  raw_steps(pr, minx, mins, dx0, ds0, &ap, &ad);
+  ap = fmin(1.0, ap); ad = fmin(1.0, ad);
+  const double mu_aff = (pr[P_SXS] + ap * dxs + ad * xds + ap * ad * dxds + (x0 + ap * dx0) * (s0 + ad * ds0)) / N;
+  const double rat = mu_aff / mu;
+  double sigma = fmin(fmax(rat * rat * rat, 1e-6), 1.0);
+  if (!(sigma == sigma)) sigma = 1.0;
+  double sig_mu = sigma * mu;
+  if (pr[P_MUT] > 0.0) sig_mu = fmax(sig_mu, pr[P_MUT]);
+  pr[P_SIGMU] = sig_mu;
+  pr[P_CORR0] = dx0 * ds0 / s0;
+}
+
+// after the final direction (pass 2): step lengths, scalar updates
+__global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p;
+  const double minx = pmin(w.part, b, p, Q_MINX, lane), mins = pmin(w.part, b, p, Q_MINS, lane);
+  const double dp2 = psum(w.part, b, p, Q_DP2, lane), p2 = psum(w.part, b, p, Q_P2, lane);
+  if (lane != 0) return;
+  const double s0 = pr[P_S0], x0 = pr[P_X0];
+  const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
+  const double ds0 = dalpha + pr[P_RD0];
+  const double dx0 = pr[P_SIGMU] / s0 - x0 - x0 * ds0 / s0 - pr[P_CORR0];
+  double ap, ad;
+  raw_steps(pr, minx, mins, dx0, ds0, &ap, &ad);
+  if (phase == PH_MAIN) {
+    const double mn = fmin(ap, ad);
+    const double gam = 0.9 + 0.09 * fmin(mn, 1.0);
+    ap = fmin(1.0, gam * ap); ad = fmin(1.0, gam * ad);
+  } else {
+    ap = fmin(1.0, 0.95 * ap); ad = fmin(1.0, 0.95 * ad);
+    pr[P_STEPN] = sqrt(dtau * dtau + dalpha * dalpha + dp2) /
+                  (1.0 + sqrt(pr[P_TAU] * pr[P_TAU] + pr[P_ALPHA] * pr[P_ALPHA] + p2));
+  }
+  pr[P_AP] = ap; pr[P_AD] = ad;
+  pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
+  pr[P_TAU] += ad * dtau; pr[P_ALPHA] += ad * dalpha;
+}
+
+// after k_update: termination of the centering phase; recount active problems
+__global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= dm.B) return;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  double* pr = w.prob + (size_t)b * PS;
+  if (ip[I_PHASE] == PH_CENTER) {
+    const bool full = (pr[P_AP] == 1.0 && pr[P_AD] == 1.0);
+    const double stepn = pr[P_STEPN], prev = pr[P_PREVSTEPN];
+    if (full && stepn < o.center_tol) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    else if (full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+    pr[P_PREVSTEPN] = full ? stepn : -1.0;
+  }
+  if (ip[I_PHASE] != PH_DONE) atomicAdd(w.active, 1);
+}
+
+}  // namespace tmpc

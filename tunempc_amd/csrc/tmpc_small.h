@@ -1,0 +1,241 @@
+// Small dense helpers for the per-stage (nx+nu) x (nx+nu) blocks, n <= 32, fp64.
+// One 64-lane wavefront (blockDim.x == 64) owns one stage; matrices live in LDS with a
+// leading dimension of LD = 33 doubles (odd stride: the 4-row register blocks of `mm` hit
+// distinct banks for ds_read_b64).  Every helper ends with a barrier unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tmpc {
+
+constexpr int NMAX = 32;          // max stage-block size n = nx + nu + ns
+constexpr int LD = 33;            // LDS leading dimension (doubles)
+constexpr int MS = NMAX * LD;     // doubles per LDS matrix slot
+
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// global (rows x cols, row-major, ld = ldg) -> LDS slot (LD).  Coalesced along rows.
+__device__ __forceinline__ void g2s(double* __restrict__ s, const double* __restrict__ g, int rows, int cols,
+                                    int ldg, int lane) {
+  const int tot = rows * cols;
+  for (int e = lane; e < tot; e += 64) {
+    const int i = e / cols, j = e - i * cols;
+    s[i * LD + j] = g[(size_t)i * ldg + j];
+  }
+  wsync();
+}
+__device__ __forceinline__ void s2g(double* __restrict__ g, const double* __restrict__ s, int rows, int cols,
+                                    int ldg, int lane) {
+  const int tot = rows * cols;
+  for (int e = lane; e < tot; e += 64) {
+    const int i = e / cols, j = e - i * cols;
+    g[(size_t)i * ldg + j] = s[i * LD + j];
+  }
+  wsync();
+}
+// symmetrised store: g = (s + s')/2
+__device__ __forceinline__ void s2g_sym(double* __restrict__ g, const double* __restrict__ s, int n, int lane) {
+  const int tot = n * n;
+  for (int e = lane; e < tot; e += 64) {
+    const int i = e / n, j = e - i * n;
+    g[(size_t)i * n + j] = 0.5 * (s[i * LD + j] + s[j * LD + i]);
+  }
+  wsync();
+}
+__device__ __forceinline__ void s_sym(double* s, int n, int lane) {   // in place (s+s')/2
+  const int tot = n * n;
+  for (int e = lane; e < tot; e += 64) {
+    const int i = e / n, j = e - i * n;
+    if (j < i) {
+      const double v = 0.5 * (s[i * LD + j] + s[j * LD + i]);
+      s[i * LD + j] = v;
+      s[j * LD + i] = v;
+    }
+  }
+  wsync();
+}
+
+// C (M x N) {=, +=, -=} A (M x K) * B (K x N); element (i,k) of A at A[i*ars + k*acs], (k,j) of B at
+// B[k*brs + j*bcs]; C row-major with LD.  mode 0: '=', 1: '+=', 2: '-='.  M,N,K <= 32.
+// Lane (li,lj) = (lane>>3, lane&7) owns the 4x4 block rows 4li.., cols 4lj..; out-of-range rows/cols read
+// in-slot garbage that only reaches outputs which are never stored.
+__device__ __forceinline__ void mm(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
+                                   const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
+                                   int lane) {
+  const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+  if (i0 < M && j0 < N) {
+    for (int k = 0; k < K; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = A[(i0 + r) * ars + k * acs];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = B[k * brs + (j0 + c) * bcs];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+    }
+  }
+  wsync();   // all reads of A/B done before C (which may alias a consumed operand slot) is written
+  if (i0 < M && j0 < N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = i0 + r, j = j0 + c;
+        if (i < M && j < N) {
+          double* p = &C[i * LD + j];
+          if (mode == 0) *p = acc[r][c];
+          else if (mode == 1) *p += acc[r][c];
+          else *p -= acc[r][c];
+        }
+      }
+  }
+  wsync();
+}
+
+// In-place lower Cholesky of the symmetric n x n matrix in LDS slot A (only the lower triangle is
+// referenced/written).  Returns 0 on success; on a non-positive pivot the pivot is replaced by a tiny
+// positive number (Cholesky-with-shift) and the return value counts such events.
+__device__ __forceinline__ int chol_lower(double* A, int n, int lane) {
+  int nbad = 0;
+  const int row = lane & 31, half = lane >> 5;
+  for (int j = 0; j < n; ++j) {
+    double piv = A[j * LD + j];
+    if (!(piv > 0.0)) { piv = 1e-300; ++nbad; }
+    const double d = sqrt(piv);
+    wsync();
+    if (lane == 0) A[j * LD + j] = d;
+    if (half == 0 && row > j && row < n) A[row * LD + j] /= d;
+    wsync();
+    if (row > j && row < n) {
+      const double lij = A[row * LD + j];
+      for (int c = j + 1 + half; c <= row; c += 2) A[row * LD + c] -= lij * A[c * LD + j];
+    }
+    wsync();
+  }
+  return nbad;
+}
+
+// Li = L^-1 for lower-triangular L (n x n, LDS).  Li gets explicit zeros above the diagonal.
+__device__ __forceinline__ void tri_inv_lower(double* __restrict__ Li, const double* __restrict__ L, int n, int lane) {
+  if (lane < n) {
+    const int c = lane;
+    for (int i = 0; i < c; ++i) Li[i * LD + c] = 0.0;
+    Li[c * LD + c] = 1.0 / L[c * LD + c];
+    for (int i = c + 1; i < n; ++i) {
+      double acc = 0.0;
+      for (int k = c; k < i; ++k) acc = fma(L[i * LD + k], Li[k * LD + c], acc);
+      Li[i * LD + c] = -acc / L[i * LD + i];
+    }
+  }
+  wsync();
+}
+
+// Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and
+// leaves its eigenvalues on the diagonal.  cs: LDS scratch of >= 4*16 doubles.
+__device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int lane) {
+  const int m = (n + 1) & ~1;          // players (even)
+  const int np = m >> 1;               // pairs per round
+  if (n == 1) return;
+  for (int sweep = 0; sweep < 14; ++sweep) {
+    // convergence test: off-diagonal mass vs total
+    double off = 0.0, dia = 0.0;
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double v = A[i * LD + j];
+      if (i == j) dia += v * v; else off += v * v;
+    }
+    off = wave_sum(off); dia = wave_sum(dia);
+    if (off <= 1e-31 * (dia + off) || (dia + off) == 0.0) break;
+    for (int r = 0; r < m - 1; ++r) {
+      if (lane < np) {
+        const int t = lane;
+        int p = (t == 0) ? 0 : 1 + ((t - 1 + r) % (m - 1));
+        const int u = m - 1 - t;
+        int q = 1 + ((u - 1 + r) % (m - 1));
+        if (p > q) { const int tmp = p; p = q; q = tmp; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double app = A[p * LD + p], aqq = A[q * LD + q], apq = A[p * LD + q];
+          if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
+            const double theta = (aqq - app) / (2.0 * apq);
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(tt * tt + 1.0);
+            s = tt * c;
+          }
+        } else { q = -1; }
+        cs[4 * t + 0] = c; cs[4 * t + 1] = s;
+        cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
+      }
+      wsync();
+      // columns: (A[i][p], A[i][q]) <- (c a_ip - s a_iq, s a_ip + c a_iq)
+      for (int e = lane; e < np * 32; e += 64) {
+        const int t = e >> 5, i = e & 31;
+        const int q = (int)cs[4 * t + 3];
+        if (i < n && q >= 0) {
+          const double c = cs[4 * t], s = cs[4 * t + 1];
+          const int p = (int)cs[4 * t + 2];
+          const double aip = A[i * LD + p], aiq = A[i * LD + q];
+          A[i * LD + p] = c * aip - s * aiq;
+          A[i * LD + q] = s * aip + c * aiq;
+        }
+      }
+      wsync();
+      // rows
+      for (int e = lane; e < np * 32; e += 64) {
+        const int t = e >> 5, j = e & 31;
+        const int q = (int)cs[4 * t + 3];
+        if (j < n && q >= 0) {
+          const double c = cs[4 * t], s = cs[4 * t + 1];
+          const int p = (int)cs[4 * t + 2];
+          const double apj = A[p * LD + j], aqj = A[q * LD + j];
+          A[p * LD + j] = c * apj - s * aqj;
+          A[q * LD + j] = s * apj + c * aqj;
+        }
+      }
+      wsync();
+    }
+  }
+  wsync();
+}
+
+// min / max of the diagonal after jacobi_eigvals (wave-uniform result)
+__device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, double* mn, double* mx) {
+  double lo = 1e300, hi = -1e300;
+  if (lane < n) { lo = A[lane * LD + lane]; hi = lo; }
+  *mn = wave_min(lo); *mx = wave_max(hi);
+}
+
+// <A, B> over the n x n leading block (both LDS)
+__device__ __forceinline__ double dot_ss(const double* A, const double* B, int n, int lane) {
+  double acc = 0.0;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; acc = fma(A[i * LD + j], B[i * LD + j], acc); }
+  return wave_sum(acc);
+}
+__device__ __forceinline__ double trace_s(const double* A, int n, int lane) {
+  double acc = (lane < n) ? A[lane * LD + lane] : 0.0;
+  return wave_sum(acc);
+}
+
+}  // namespace tmpc

@@ -1,0 +1,444 @@
+// Per-stage kernels: one 64-lane wavefront per (problem b, stage k).  They evaluate the LMI blocks
+// M_k = alpha*Hb_k + V_k' P_{k+1} V_k - E' P_k E  (reference: convexifier.py:325-357), their
+// Cholesky factors / inverses, the HKM scaling pieces, residuals and step lengths.
+#pragma once
+#include "tmpc_common.h"
+#include "tmpc_small.h"
+
+namespace tmpc {
+
+#define TMPC_STAGE_PROLOGUE                                     \
+  const int sid = blockIdx.x;                                   \
+  const int b = sid / dm.p;                                     \
+  const int k = sid - b * dm.p;                                 \
+  const int lane = threadIdx.x;                                 \
+  const int n = dm.n, nx = dm.nx;                               \
+  const int nn = n * n, nxx = nx * nx;                          \
+  (void)k; (void)nn; (void)nxx;                                 \
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+
+// transposed store of the leading rows x cols block: g[j*ldg + i] = s[i][j]
+__device__ __forceinline__ void s2g_T(double* g, const double* s, int rows, int cols, int ldg, int lane) {
+  const int tot = rows * cols;
+  for (int e = lane; e < tot; e += 64) {
+    const int j = e / rows, i = e - j * rows;
+    g[(size_t)j * ldg + i] = s[i * LD + j];
+  }
+  wsync();
+}
+
+// ------------------------------------------------------------------ init: eigen-scan of H_k, V = [A B]
+// reference: convexifier.py:82 (pre-check) and :374-401 (autoScaling)
+__global__ void __launch_bounds__(64) k_init_stage(WS w, Dims dm) {
+  TMPC_STAGE_PROLOGUE
+  double* sH = sm; double* cs = sm + MS;
+  const double* Hg = w.H + (size_t)sid * nn;
+  for (int e = lane; e < nn; e += 64) {
+    const int i = e / n, j = e - i * n;
+    sH[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]);
+  }
+  wsync();
+  // Hb := sym(H) for now (scaled later by k_init_state)
+  s2g(w.Hb + (size_t)sid * nn, sH, n, n, n, lane);
+  jacobi_eigvals(sH, n, cs, lane);
+  double lo = 1e300, hi = -1e300, amin = 1e300, amax = 0.0;
+  if (lane < n) {
+    const double ev = sH[lane * LD + lane];
+    lo = ev; hi = ev;
+    const double a = fabs(ev);
+    if (a != 0.0) { amin = a; amax = a; }       // exact zeros excluded (convexifier.py:387-388)
+  }
+  lo = wave_min(lo); hi = wave_max(hi); amin = wave_min(amin); amax = wave_max(amax);
+  if (lane == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_MINEIG] = lo; q[Q_MAXEIG] = hi; q[Q_MINABS] = amin; q[Q_MAXABS] = amax;
+  }
+  // V = [A B]
+  const int mb = dm.mb;
+  double* Vg = w.V + (size_t)sid * nx * n;
+  const double* Ag = w.A + (size_t)sid * nxx;
+  const double* Bg = w.Bm + (size_t)sid * nx * mb;
+  for (int e = lane; e < nx * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    Vg[e] = (j < nx) ? Ag[i * nx + j] : Bg[i * mb + (j - nx)];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  double lo = 1e300, amin = 1e10 /* convexifier.py:383 */, amax = 0.0;
+  for (int k = lane; k < dm.p; k += 64) {
+    const double* q = w.part + (size_t)(b * dm.p + k) * NPART;
+    lo = fmin(lo, q[Q_MINEIG]); amin = fmin(amin, q[Q_MINABS]); amax = fmax(amax, q[Q_MAXABS]);
+  }
+  lo = wave_min(lo); amin = wave_min(amin); amax = wave_max(amax);
+  if (lane == 0) {
+    double* pr = w.prob + (size_t)b * PS;
+    int* ip = w.iprob + (size_t)b * IS;
+    for (int i = 0; i < PS; ++i) pr[i] = 0.0;
+    for (int i = 0; i < IS; ++i) ip[i] = 0;
+    const double s = 1.0 / amin, sbeta = amax / amin;
+    pr[P_S] = s; pr[P_SBETA] = sbeta; pr[P_MINEIG_H] = lo;
+    pr[P_TAU] = 2.0 * sbeta; pr[P_ALPHA] = 1.0; pr[P_S0] = 1.0; pr[P_X0] = 1.0 / (double)(dm.p * dm.n);
+    pr[P_MUT] = -1.0; pr[P_PREVSTEPN] = -1.0; pr[P_STEPN] = 1e300;
+    const int early = (lo > 0.0) ? 1 : 0;          // convexifier.py:83
+    ip[I_EARLY] = early;
+    ip[I_PHASE] = early ? PH_DONE : PH_MAIN;
+    ip[I_IPMSTATUS] = early ? IPM_OPTIMAL : IPM_MAXITER;
+    if (!early) atomicAdd(w.active, 1);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_init_state(WS w, Dims dm) {
+  TMPC_STAGE_PROLOGUE
+  const double* pr = w.prob + (size_t)b * PS;
+  const double s = pr[P_S], sbeta = pr[P_SBETA], tau = pr[P_TAU];
+  const double x0 = 1.0 / (double)(dm.p * n);
+  double* Hb = w.Hb + (size_t)sid * nn;
+  for (int e = lane; e < nn; e += 64) {
+    const int i = e / n, j = e - i * n;
+    const double hb = s * Hb[e];
+    Hb[e] = hb;
+    const double dg = (i == j) ? 1.0 : 0.0;
+    w.S1[(size_t)sid * nn + e] = sbeta * dg;
+    w.S2[(size_t)sid * nn + e] = tau * dg - hb;
+    w.X1[(size_t)sid * nn + e] = x0 * dg;
+    w.X2[(size_t)sid * nn + e] = x0 * dg;
+  }
+  for (int e = lane; e < nxx; e += 64) w.P[(size_t)sid * nxx + e] = 0.0;
+}
+
+// ------------------------------------------------------------------ M_k (or dM_k) into an LDS slot
+// out = coef*Hb_k + V' Pn V - E' Pk E ; uses sV (already loaded), scratch slots t0,t1,sHb
+__device__ __forceinline__ void build_M(double* out, const double* sV, double* t0, double* t1, const double* sHb,
+                                        const double* Pk, const double* Pn, double coef, int n, int nx, int lane) {
+  g2s(t0, Pn, nx, nx, nx, lane);
+  mm(t1, sV, 1, LD, t0, LD, 1, n, nx, nx, 0, lane);        // V' Pn   (n x nx)
+  mm(out, t1, LD, 1, sV, LD, 1, n, n, nx, 0, lane);        // (V' Pn) V
+  g2s(t0, Pk, nx, nx, nx, lane);
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    double v = out[i * LD + j] + coef * sHb[i * LD + j];
+    if (i < nx && j < nx) v -= t0[i * LD + j];
+    out[i * LD + j] = v;
+  }
+  wsync();
+}
+
+// V G V' (nx x nx) into `out`, scratch t
+__device__ __forceinline__ void adj_V(double* out, double* t, const double* sV, const double* G, int n, int nx, int lane) {
+  mm(t, sV, LD, 1, G, LD, 1, nx, n, n, 0, lane);           // V G    (nx x n)
+  mm(out, t, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);        // (V G) V'
+}
+
+constexpr int PRE_SLOTS = 11;
+// ------------------------------------------------------------------ stage_pre
+__global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
+  TMPC_STAGE_PROLOGUE
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double alpha = pr[P_ALPHA], tau = pr[P_TAU];
+  double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sS = sm + 3 * MS;
+  double* sLi = sm + 4 * MS; double* sSi = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
+  double* sHb = sm + 8 * MS; double* sPhi = sm + 9 * MS; double* t2 = sm + 10 * MS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  build_M(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
+  double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
+  int nbad = 0;
+  double* kf = w.KF + (size_t)sid * 12 * nxx;
+  for (int r = 0; r < 2; ++r) {
+    const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
+    const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
+    double* Rdg = (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn;
+    g2s(sX, Xg, n, n, n, lane);
+    g2s(sS, Sg, n, n, n, lane);
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double m = sM[i * LD + j], sv = sS[i * LD + j];
+      const double dg = (i == j) ? 1.0 : 0.0;
+      const double rd = (r == 0 ? (m - dg) : (tau * dg - m)) - sv;
+      Rdg[e] = rd;
+      rd2 = fma(rd, rd, rd2); s2 = fma(sv, sv, s2); xs = fma(sX[i * LD + j], sv, xs);
+    }
+    {
+      const double hx = dot_ss(sHb, sX, n, lane);
+      if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s(sX, n, lane); }
+    }
+    // S_r = L L',  L^-1,  S_r^-1
+    nbad += chol_lower(sS, n, lane);
+    tri_inv_lower(sLi, sS, n, lane);
+    s2g((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
+    mm(sSi, sLi, 1, LD, sLi, LD, 1, n, n, n, 0, lane);                   // Li' Li
+    s_sym(sSi, n, lane);
+    s2g((r ? w.S2i : w.S1i) + (size_t)sid * nn, sSi, n, n, n, lane);
+    // chol(X_r)^-1 for the primal step length
+    for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
+    wsync();
+    nbad += chol_lower(t0, n, lane);
+    tri_inv_lower(t1, t0, n, lane);
+    s2g((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
+    // Kronecker factors of the HKM Schur blocks
+    double* kfr = kf + (size_t)r * KF_PER_LMI * nxx;
+    mm(t0, sV, LD, 1, sX, LD, 1, nx, n, n, 0, lane);                     // V X     (nx x n)
+    mm(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);                    // V X V'
+    s2g(kfr + KF_KX * nxx, t1, nx, nx, nx, lane);
+    s2g_T(kfr + KF_FX * nxx, t0, nx, nx, nx, lane);                      // Fx = X[:nx,:] V' = ((VX)[:, :nx])'
+    s2g(kfr + KF_XXX * nxx, sX, nx, nx, nx, lane);
+    mm(t0, sV, LD, 1, sSi, LD, 1, nx, n, n, 0, lane);                    // V Si
+    mm(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);
+    s2g(kfr + KF_KS * nxx, t1, nx, nx, nx, lane);
+    s2g_T(kfr + KF_FS * nxx, t0, nx, nx, nx, lane);
+    s2g(kfr + KF_SIXX * nxx, sSi, nx, nx, nx, lane);
+    // Phi_r(Hb) = sym(X Hb Si)
+    mm(t0, sX, LD, 1, sHb, LD, 1, n, n, n, 0, lane);
+    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double phi = 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
+      if (r == 0) sPhi[i * LD + j] = phi; else sPhi[i * LD + j] += phi;
+      if (r == 1 && i == j) trphi2 += phi;
+    }
+    wsync();
+    if (r == 1) {
+      mm(t0, sX, LD, 1, sSi, LD, 1, n, n, n, 0, lane);                   // Psi = sym(X2 S2i)
+      s_sym(t0, n, lane);
+      trpsi = trace_s(t0, n, lane);
+      adj_V(t1, t2, sV, t0, n, nx, lane);
+      s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t1, nx, nx, nx, lane);
+      s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx, lane);
+    }
+  }
+  const double hbphi = dot_ss(sHb, sPhi, n, lane);
+  adj_V(t1, t2, sV, sPhi, n, nx, lane);
+  s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
+  s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, sPhi, nx, nx, nx, lane);
+  rd2 = wave_sum(rd2); s2 = wave_sum(s2); xs = wave_sum(xs); trphi2 = wave_sum(trphi2);
+  if (lane == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_XS] = xs; q[Q_RD2] = rd2; q[Q_S2] = s2; q[Q_TRX2] = trx2; q[Q_HBY] = hby;
+    q[Q_TRPSI] = trpsi; q[Q_TRPHI2] = trphi2; q[Q_HBPHI] = hbphi; q[Q_CHOLBAD] = (double)nbad;
+  }
+}
+
+constexpr int RHS_SLOTS = 8;
+// ------------------------------------------------------------------ stage_rhs: T_r and the adjoint of G = T1 - T2
+// pass 1 = predictor (sigma*mu = 0, no corrector term; main-phase problems only)
+// pass 2 = corrector (main phase) or pure centering step (centering phase)
+__global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
+  TMPC_STAGE_PROLOGUE
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
+  const bool use_corr = (pass == 2 && phase == PH_MAIN);
+  double* sV = sm; double* sX = sm + MS; double* sSi = sm + 2 * MS; double* sRd = sm + 3 * MS;
+  double* t0 = sm + 4 * MS; double* t1 = sm + 5 * MS; double* sG = sm + 6 * MS; double* sHb = sm + 7 * MS;
+  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  double trt2 = 0.0;
+  for (int r = 0; r < 2; ++r) {
+    g2s(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
+    g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    g2s(sRd, (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn, n, n, n, lane);
+    mm(t0, sX, LD, 1, sRd, LD, 1, n, n, n, 0, lane);
+    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
+    const double* cg = (r ? w.c2 : w.c1) + (size_t)sid * nn;
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      double t = sig * sSi[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
+      if (use_corr) t -= cg[e];
+      Tg[e] = t;
+      if (r == 0) sG[i * LD + j] = t; else { sG[i * LD + j] -= t; if (i == j) trt2 += t; }
+    }
+    wsync();
+  }
+  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  const double hbg = dot_ss(sHb, sG, n, lane);
+  adj_V(t1, t0, sV, sG, n, nx, lane);
+  s2g(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx, lane);
+  s2g(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, sG, nx, nx, nx, lane);
+  trt2 = wave_sum(trt2);
+  if (lane == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_TRT2] = trt2; q[Q_HBG] = hbg;
+  }
+}
+
+constexpr int DIR_SLOTS = 11;
+// ------------------------------------------------------------------ stage_dir: dS, dX, step-length eigenvalues, corrector term
+__global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
+  TMPC_STAGE_PROLOGUE
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
+  double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sSi = sm + 3 * MS;
+  double* sDS = sm + 4 * MS; double* sDX = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
+  double* sHb = sm + 8 * MS; double* sL = sm + 9 * MS; double* cs = sm + 10 * MS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  const double* dPk = w.dP + (size_t)sid * nxx;
+  build_M(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
+  double dxs = 0.0, xds = 0.0, dxds = 0.0, minx = 1e300, mins = 1e300;
+  for (int r = 0; r < 2; ++r) {
+    const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
+    const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
+    const double* Rdg = (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn;
+    const double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
+    double* dSg = (r ? w.dS2 : w.dS1) + (size_t)sid * nn;
+    double* dXg = (r ? w.dX2 : w.dX1) + (size_t)sid * nn;
+    g2s(sX, Xg, n, n, n, lane);
+    g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    // sDX := Ldy = dS - Rd   (linear part of the slack direction)
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double dm_ = sM[i * LD + j];
+      const double ldy = (r == 0) ? dm_ : ((i == j ? dtau : 0.0) - dm_);
+      sDX[i * LD + j] = ldy;
+      const double ds = ldy + Rdg[e];
+      sDS[i * LD + j] = ds;
+      dSg[e] = ds;
+    }
+    wsync();
+    mm(t0, sX, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
+    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double dx = Tg[e] - sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
+      sDX[i * LD + j] = dx;
+      dXg[e] = dx;
+      const double ds = sDS[i * LD + j];
+      dxs = fma(dx, Sg[e], dxs); xds = fma(sX[i * LD + j], ds, xds); dxds = fma(dx, ds, dxds);
+    }
+    wsync();
+    // dual step length: lambda_min( L^-1 dS L^-T )
+    g2s(sL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
+    mm(t0, sL, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
+    mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
+    s_sym(t1, n, lane);
+    jacobi_eigvals(t1, n, cs, lane);
+    { double lo, hi; diag_minmax(t1, n, lane, &lo, &hi); mins = fmin(mins, lo); }
+    // primal step length: lambda_min( LX^-1 dX LX^-T )
+    g2s(sL, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
+    mm(t0, sL, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
+    mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
+    s_sym(t1, n, lane);
+    jacobi_eigvals(t1, n, cs, lane);
+    { double lo, hi; diag_minmax(t1, n, lane, &lo, &hi); minx = fmin(minx, lo); }
+    if (pass == 1) {   // Mehrotra second-order term  sym(dX dS S^-1)
+      mm(t0, sDX, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
+      mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+      s2g_sym((r ? w.c2 : w.c1) + (size_t)sid * nn, t1, n, lane);
+    }
+  }
+  double dp2 = 0.0, p2 = 0.0;
+  const double* Pk = w.P + (size_t)sid * nxx;
+  for (int e = lane; e < nxx; e += 64) { dp2 = fma(dPk[e], dPk[e], dp2); p2 = fma(Pk[e], Pk[e], p2); }
+  dxs = wave_sum(dxs); xds = wave_sum(xds); dxds = wave_sum(dxds); dp2 = wave_sum(dp2); p2 = wave_sum(p2);
+  if (lane == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_MINX] = minx; q[Q_MINS] = mins; q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2;
+  }
+}
+
+// ------------------------------------------------------------------ update: X += ap dX, S += ad dS, P += ad dP
+__global__ void __launch_bounds__(64) k_update(WS w, Dims dm) {
+  TMPC_STAGE_PROLOGUE
+  (void)sm;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double ap = pr[P_AP], ad = pr[P_AD];
+  const size_t o = (size_t)sid * nn;
+  for (int e = lane; e < nn; e += 64) {
+    const int i = e / n, j = e - i * n;
+    const int et = j * n + i;
+    if (j <= i) {
+      const double x1 = 0.5 * ((w.X1[o + e] + ap * w.dX1[o + e]) + (w.X1[o + et] + ap * w.dX1[o + et]));
+      const double x2 = 0.5 * ((w.X2[o + e] + ap * w.dX2[o + e]) + (w.X2[o + et] + ap * w.dX2[o + et]));
+      const double s1 = 0.5 * ((w.S1[o + e] + ad * w.dS1[o + e]) + (w.S1[o + et] + ad * w.dS1[o + et]));
+      const double s2 = 0.5 * ((w.S2[o + e] + ad * w.dS2[o + e]) + (w.S2[o + et] + ad * w.dS2[o + et]));
+      w.X1[o + e] = x1; w.X1[o + et] = x1; w.X2[o + e] = x2; w.X2[o + et] = x2;
+      w.S1[o + e] = s1; w.S1[o + et] = s1; w.S2[o + e] = s2; w.S2[o + et] = s2;
+    }
+  }
+  for (int e = lane; e < nxx; e += 64) w.P[(size_t)sid * nxx + e] += ad * w.dP[(size_t)sid * nxx + e];
+}
+
+constexpr int FIN_SLOTS = 6;
+// ------------------------------------------------------------------ final: un-scale, supplement, status eigenvalues
+// reference: convexifier.py:403-440 (check_convergence) and :165-211 (convexHessianSuppl)
+__global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
+  TMPC_STAGE_PROLOGUE
+  const int* ip = w.iprob + (size_t)b * IS;
+  const double* pr = w.prob + (size_t)b * PS;
+  double* sV = sm; double* sM = sm + MS; double* t0 = sm + 2 * MS; double* t1 = sm + 3 * MS; double* sHb = sm + 4 * MS;
+  double* cs = sm + 5 * MS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  const double sc = ip[I_EARLY] ? 0.0 : 1.0 / (pr[P_S] * pr[P_ALPHA]);      // dP = sP*P/(s_alpha*alpha), convexifier.py:406
+  // Pout = sc * P
+  double* Po = w.Pout + (size_t)sid * nxx;
+  for (int e = lane; e < nxx; e += 64) Po[e] = sc * w.P[(size_t)sid * nxx + e];
+  double* Pon = w.Pout + (size_t)(b * dm.p + kn) * nxx;
+  const double* Pn = w.P + (size_t)(b * dm.p + kn) * nxx;
+  if (kn != k) { for (int e = lane; e < nxx; e += 64) Pon[e] = sc * Pn[e]; }   // same values any writer would store
+  __threadfence_block();
+  wsync();
+  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  // H (unscaled, symmetrised as in k_init_stage)
+  const double* Hg = w.H + (size_t)sid * nn;
+  for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; sHb[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
+  wsync();
+  // dH = V' Pst+ V - E' Pst E  (coef 0: no Hb term), then symmetrise (mtools.symmetrize, convexifier.py:206)
+  build_M(sM, sV, t0, t1, sHb, Po, Pon, 0.0, n, nx, lane);
+  s_sym(sM, n, lane);
+  double* dHg = w.dHc + (size_t)sid * nn;
+  double* Hcg = w.Hc + (size_t)sid * nn;
+  for (int e = lane; e < nn; e += 64) {
+    const int i = e / n, j = e - i * n;
+    const double dh = sM[i * LD + j];
+    dHg[e] = dh;
+    const double hc = sHb[i * LD + j] + dh;
+    Hcg[e] = hc;
+    t0[i * LD + j] = hc;
+  }
+  wsync();
+  jacobi_eigvals(t0, n, cs, lane);
+  double lo, hi;
+  diag_minmax(t0, n, lane, &lo, &hi);
+  if (lane == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_MINEIG] = lo; q[Q_MAXEIG] = hi;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_final_prob(WS w, Dims dm) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  double lo = 1e300, hi = -1e300, mc = 0.0;
+  for (int k = lane; k < dm.p; k += 64) {
+    const double* q = w.part + (size_t)(b * dm.p + k) * NPART;
+    lo = fmin(lo, q[Q_MINEIG]); hi = fmax(hi, q[Q_MAXEIG]);
+    mc = fmax(mc, (q[Q_MINEIG] > 0.0) ? q[Q_MAXEIG] / q[Q_MINEIG] : 1e300);
+  }
+  lo = wave_min(lo); hi = wave_max(hi); mc = wave_max(mc);
+  if (lane == 0) {
+    double* pr = w.prob + (size_t)b * PS;
+    int* ip = w.iprob + (size_t)b * IS;
+    pr[P_MINEIG_HC] = lo; pr[P_MAXEIG_HC] = hi; pr[P_MAXCOND] = mc;
+    // status rule of convexifier.py:442-451
+    int st;
+    if (lo > 0.0) st = (ip[I_IPMSTATUS] == IPM_OPTIMAL) ? ST_OPTIMAL : ST_FEASIBLE;
+    else st = ST_INFEASIBLE;
+    ip[I_STATUS] = st;
+    if (ip[I_EARLY]) { pr[P_KAPPA] = 0.0; pr[P_BETA] = 0.0; pr[P_ALPHA_OUT] = 1.0; }
+    else { pr[P_KAPPA] = pr[P_TAU]; pr[P_BETA] = pr[P_TAU] / pr[P_SBETA]; pr[P_ALPHA_OUT] = pr[P_ALPHA]; }
+  }
+}
+
+}  // namespace tmpc
