@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Benchmark of the convexify() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
+
+A "step" is one complete batched convexify (pre-check, scaling, SDP Step 1 to tolerance, reconstruction,
+status check) over one synthetic batch of `--batch` tuning problems per GPU, inputs resident in HBM.
+Workload: BASELINE.json configs[3] = synthetic (nx+nu)=32 (nx=24, m=8), p=64; the published batch of 4096
+is sharded over 8 GPUs, i.e. 512 problems per GPU (weak scaling: the per-GPU batch is fixed).  With N>1
+ranks, each step ends with one RCCL all-gather of Hc/kappa/status.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD CDNA4 datasheet figure; not in MI355X_MICROARCH.md)
+
+
+def factor_flops_per_problem(p, d):
+    """Algorithmic fp64 flops of one block-cyclic-tridiagonal Cholesky (k_factor), unpadded d."""
+    d3 = float(d) ** 3
+    if p == 1:
+        return d3 / 3.0
+    full = max(p - 2, 0) * (1.0 / 3 + 1 + 1 + 1 + 1 + 2) * d3     # chol, trsm O, trsm F, syrk O, syrk F, gemm F O'
+    return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
+
+
+def cpu_baseline(p_full, nx, mb, tol, budget_s=25.0):
+    """Oracle (numpy/LAPACK restatement of the same algorithm) timed on host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import convexify_oracle as co
+    p_s = min(p_full, 8)
+    A, B, H, _, _ = co.gen_problem(424242, p_s, nx, mb)
+    t0 = time.perf_counter()
+    nprob = 0
+    while True:
+        r = co.convexify_arrays(A, B, H, dict(tol=tol))
+        nprob += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or el + el / nprob > 1.3 * budget_s:
+            break
+    el = time.perf_counter() - t0
+    cores = int(os.environ.get('OPENBLAS_NUM_THREADS', os.cpu_count() or 1))
+    return {"value": nprob * p_s / el, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/convexify_oracle.py (numpy + OpenBLAS, {cores} threads) on {nprob} problem(s) of nx={nx}, m={mb}, "
+                      f"p={p_s} (same stage size n={nx + mb} as the workload, shorter period; cost is linear in p), "
+                      f"{r['iters']} IPM iterations, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=512, help='problems per GPU per step')
+    ap.add_argument('--p', type=int, default=64)
+    ap.add_argument('--nx', type=int, default=24)
+    ap.add_argument('--mb', type=int, default=8)
+    ap.add_argument('--tol', type=float, default=0.0, help='0 = library default')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--distinct', type=int, default=64, help='distinct synthetic problems generated per rank (tiled to --batch)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tunempc_amd._lib import HipConvexifier, FLAG_PROFILE
+    from tunempc_amd import synthetic
+    from tunempc_amd.dist import all_gather_results
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    p, nx, mb, n = args.p, args.nx, args.mb, args.nx + args.mb
+    nbl = args.batch
+    # synthetic data: `distinct` different seeded problems per rank, tiled to the per-GPU batch
+    nd = min(args.distinct, nbl)
+    A, B, H = synthetic.gen_batch(100000 + rank * 10000, nd, p, nx, mb)
+    reps = (nbl + nd - 1) // nd
+    tile = lambda x: torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:nbl].copy()).to(dev)
+    dA, dB, dH = tile(A), tile(B), tile(H)
+    h = HipConvexifier(p, nx, mb, chunk=0, flags=FLAG_PROFILE)
+    if args.tol > 0:
+        h.set_options(tol=args.tol, flags=FLAG_PROFILE)
+    out = None
+
+    def step():
+        nonlocal out
+        out = h.convexify_batch_device(dA, dB, dH, out)
+        if world > 1:
+            g = all_gather_results({k: out[k] for k in ('Hc', 'kappa', 'status')}, nbl * world)
+            return g
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    h.profile()   # reset accumulators
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+    prof = h.profile()
+    status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy()
+    ok = int((status == 0).sum())
+
+    if rank == 0:
+        total_units = nbl * world * p * args.steps
+        d = nx * (nx + 1) // 2
+        launches = max(prof['factor_launches'], 1.0)
+        # every k_factor launch processes one chunk of problems; chunks per step = ceil(nbl / chunk)
+        avg_ms = prof['factor_ms'] / launches
+        nchunks = (nbl + h.chunk - 1) // h.chunk
+        chunk = nbl / nchunks            # average problems per k_factor launch
+        fl = factor_flops_per_problem(p, d) * chunk
+        achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "stage-Hessian convexifications/sec at (nx+nu)=32, p=64",
+            "value": total_units / el,
+            "unit": "stage-convexifications/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: synthetic SPD-perturbed Hessians, (nx+nu)={n} (nx={nx}, m={mb}), p={p}, "
+                                   f"{nbl} problems per GPU ({nbl * world} total; published batch 4096 = 512 x 8 GPUs)",
+                       "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
+                       "distinct_problems_per_gpu": nd, "gap_tol": args.tol if args.tol > 0 else "library default (1e-5)",
+                       "ipm_iterations_max": int(iters.max()), "status_optimal": ok, "status_total": int(status.size),
+                       "kappa_mean": float(kappa.mean()),
+                       "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_factor<true> (block-cyclic-tridiagonal Cholesky, v_mfma_f64_16x16x4_f64)",
+                         "avg_launch_ms": avg_ms, "launches": int(launches), "problems_per_launch": chunk,
+                         "algorithmic_flops_per_launch": fl},
+            "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 1e-5)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

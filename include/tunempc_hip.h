@@ -68,8 +68,10 @@ uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
  * Larger batches are processed in chunks.  chunk <= 0 selects a default that fits free HBM. */
 int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
 int tmpc_destroy(tmpc_handle* h);
+/* Problems processed per launch wave (the chunk the workspace was sized for). */
+int tmpc_get_chunk(tmpc_handle* h);
 
-/* Solver options: tol = relative duality gap on kappa (max condition number), default 1e-6;
+/* Solver options: tol = relative duality gap on kappa (max condition number), default 1e-5;
  * center_tol = relative Newton step ending the final centering phase, default 1e-9;
  * max_iter / center_iter = iteration caps (defaults 50 / 12); flags = TMPC_FLAG_*.  Values <= 0 keep
  * the current setting (flags is always applied). */

@@ -31,12 +31,13 @@ H_k = [[Q,N],[N',R]] (n x n, n = nx+mb), V_k = [A_k B_k], E = [I 0].
 """
 import numpy as np
 import scipy.linalg as sla
+from scipy.linalg.blas import dtrsm
 
 ALPHA_MIN = 1e-8          # convexifier.py:245
 STATUS_OPTIMAL, STATUS_FEASIBLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
-DEFAULT_OPTS = dict(tol=1e-6, max_iter=50, center_iter=12, center_tol=1e-9)
+DEFAULT_OPTS = dict(tol=1e-5, max_iter=50, center_iter=12, center_tol=1e-9)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -122,20 +123,35 @@ def _smat(v, nx, ia, ib):
     return P
 
 
+_DUP_CACHE = {}
+
+
+def _dup(nx):
+    """Duplication matrix Dn (nx^2 x d, row-major vec): vec(E_ab) = Dn[:, (ab)] for the basis E_ab of _svec_grad."""
+    if nx not in _DUP_CACHE:
+        import scipy.sparse as sp
+        ia, ib = _tri_idx(nx)
+        d = len(ia)
+        rows = np.concatenate([ia * nx + ib, (ib * nx + ia)[ia != ib]])
+        cols = np.concatenate([np.arange(d), np.arange(d)[ia != ib]])
+        Dn = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(nx * nx, d))
+        _DUP_CACHE[nx] = (Dn, Dn.T.tocsr())
+    return _DUP_CACHE[nx]
+
+
 def _T(L, R, ia, ib):
-    """T(L,R)[..,(ab),(cd)] = <E_ab, L E_cd R'>  (d x d), L,R: [..., nx, nx] (not nec. symmetric)."""
-    def g(M, r, c):
-        return M[..., r[:, None], c[None, :]]
-    wc = np.where(ia == ib, 0.5, 1.0)[None, :]
-    wr = np.where(ia == ib, 0.5, 1.0)[:, None]
-    # (L E_cd R')_ab = L_ac R_bd + L_ad R_bc ; plus (a<->b)
-    return ((g(L, ia, ia) * g(R, ib, ib) + g(L, ia, ib) * g(R, ib, ia))
-            + (g(L, ib, ia) * g(R, ia, ib) + g(L, ib, ib) * g(R, ia, ia))) * (wc * wr)
+    """T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'> = [Dn' (L kron R) Dn]  (d x d); L,R: [nx,nx] or stacked [p,nx,nx].
+    Note T(L,R) == T(R,L), so the HKM block 0.5*(T(Lx,Ls)+T(Ls,Lx)) is just T(Lx,Ls)."""
+    if L.ndim == 3:
+        return np.stack([_T(L[k], R[k], ia, ib) for k in range(L.shape[0])])
+    Dn, Dt = _dup(L.shape[0])
+    K = np.kron(L, R)
+    return np.asarray(Dt @ (Dn.T @ K.T).T)
 
 
 def _hkm_block(Lx, Ls, ia, ib):
-    """0.5*(T(Lx,Ls)+T(Ls,Lx)): the d x d HKM Schur block(s) generated by the nx x nx pair(s) (Lx, Ls)."""
-    return 0.5 * (_T(Lx, Ls, ia, ib) + _T(Ls, Lx, ia, ib))
+    """the d x d HKM Schur block(s) generated by the nx x nx pair(s) (Lx, Ls):  0.5*(T(Lx,Ls)+T(Ls,Lx)) = T(Lx,Ls)."""
+    return _T(Lx, Ls, ia, ib)
 
 
 # ------------------------------------------------------------ block-cyclic-tridiagonal solve
@@ -186,11 +202,11 @@ class _CyclicBlockChol:
             sub = C[k].T.copy()                 # block [k+1, k]
             if k == p - 2:
                 sub = sub + Fpre                # fill meets the sub-diagonal
-                O[k] = sla.solve_triangular(Lkk[k], sub.T, lower=True).T
+                O[k] = dtrsm(1.0, Lkk[k], sub, side=1, lower=1, trans_a=1)
                 Dw[p - 1] -= O[k] @ O[k].T
             else:
-                O[k] = sla.solve_triangular(Lkk[k], sub.T, lower=True).T
-                F[k] = sla.solve_triangular(Lkk[k], Fpre.T, lower=True).T
+                O[k] = dtrsm(1.0, Lkk[k], sub, side=1, lower=1, trans_a=1)
+                F[k] = dtrsm(1.0, Lkk[k], Fpre, side=1, lower=1, trans_a=1)
                 Dw[k + 1] -= O[k] @ O[k].T
                 Dw[p - 1] -= F[k] @ F[k].T
                 Fpre = -F[k] @ O[k].T
@@ -294,6 +310,11 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             print(f"it {it:2d} ph{phase} tau={tau:.10f} alpha={alpha:.4e} mu={mu:.3e} pinf={pinf:.2e} dinf={dinf:.2e} relgap={relgap:.2e}")
         if trace is not None:
             trace.append(dict(it=it, tau=tau, mu=mu, pinf=pinf, dinf=dinf, phase=phase))
+        if it == 0:
+            mu0 = mu
+        if not (np.isfinite(mu) and np.isfinite(tau) and mu > 0) or mu > 1e6 * mu0:
+            status = 'diverged'          # dual unbounded / primal infeasible: leave with the last iterate
+            break
         if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
             mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau)) / N))
         if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < o['tol'] and pinf < max(o['tol'], 1e-6):

@@ -45,10 +45,11 @@ def cyclic_dense(D, Cc):
 
 def check_block_solve(h):
     for (p, d) in [(1, 6), (2, 10), (3, 10), (5, 21), (4, 78), (3, 136), (3, 300), (6, 45)]:
-        # random SPD block-cyclic-tridiagonal matrix
-        G = rng.standard_normal((p, d, 3 * d))
-        Cc = 0.3 * rng.standard_normal((p, d, d))
-        D = np.stack([G[k] @ G[k].T / (3 * d) + 2.0 * np.eye(d) for k in range(p)])
+        # random SPD block-cyclic-tridiagonal matrix  T = sum_k J_k' J_k + I,  J_k = [E_k F_k] on blocks (k, k+1)
+        E = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d); Fm = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d)
+        D = np.stack([np.eye(d) for _ in range(p)]); Cc = np.zeros((p, d, d))
+        for k in range(p):
+            D[k] += E[k].T @ E[k]; D[(k + 1) % p] += Fm[k].T @ Fm[k]; Cc[k] = E[k].T @ Fm[k]
         T = cyclic_dense(D, Cc)
         ev = np.linalg.eigvalsh(T)
         rhs = rng.standard_normal((p, d))

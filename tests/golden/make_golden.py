@@ -1,0 +1,63 @@
+"""Generates the committed golden vectors in tests/golden/*.npz.
+
+The reference stack (PICOS -> CVXOPT/MOSEK) cannot run in this container, so the
+vectors hold (a) literal inputs taken from the reference's own example (`examples/convex_lqr.py:40-46`,
+data only) and synthetic inputs from the seeded generator of BASELINE.md section 4, and (b) the outputs
+of the build's CPU oracle (oracle/convexify_oracle.py) for them, cross-checked by solver-independent
+invariants at generation time.  Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import convexify_oracle as co  # noqa: E402
+
+# examples/convex_lqr.py:40-46 (numeric literals of the reference's LQ example)
+LQR_A = np.array([[-0.3319, 0.7595, 1.5399], [-0.3393, 0.1250, 0.4245], [-0.5090, 0.9388, 0.8864]])
+LQR_B = np.array([[0.1060], [-1.3835], [-0.1496]])
+LQR_Q = np.array([[-1.0029, -0.0896, 1.1050], [-0.0896, 1.6790, -0.5762], [1.1050, -0.5762, -0.4381]])
+LQR_N = np.array([[-0.0420], [0.2112], [-0.2832]])
+LQR_R = np.array([[0.6192]])
+
+CASES = {
+    # name: (base_seed, nb, p, nx, mb, kwargs)
+    'c2_unicycle_shape': (2000, 2, 30, 4, 1, {}),
+    'c3_evaporation_shape': (3000, 3, 50, 2, 2, {}),
+    'mid_n16': (4000, 2, 6, 12, 4, {}),
+    'awe_shape_n15': (5000, 1, 40, 9, 6, {}),
+    'identity_family': (6000, 2, 5, 4, 2, {'identity': True}),
+}
+
+
+def solve_batch(A, B, H):
+    out = dict(Hc=[], P=[], kappa=[], alpha=[], beta=[], status=[], iters=[])
+    for b in range(A.shape[0]):
+        r = co.convexify_arrays(A[b], B[b], H[b])
+        inv = co.check_invariants(A[b], B[b], H[b], r)
+        assert inv['min_eig'] > 0 and inv['struct_err'] < 1e-12, inv
+        if not r['early_exit']:
+            assert inv['max_cond'] <= r['kappa'] * (1 + 1e-9), inv
+        for k in out:
+            out[k].append(r[k])
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def main():
+    H = co.build_hessian(LQR_Q, LQR_R, LQR_N)
+    A = LQR_A[None, None]; B = LQR_B[None, None]; Hs = H[None, None]
+    o = solve_batch(A, B, Hs)
+    np.savez(os.path.join(HERE, 'c1_convex_lqr.npz'), A=A, B=B, H=Hs, Q=LQR_Q, R=LQR_R, N=LQR_N, tol=co.DEFAULT_OPTS['tol'], **o)
+    print('c1_convex_lqr kappa', o['kappa'], 'iters', o['iters'])
+    for name, (seed, nb, p, nx, mb, kw) in CASES.items():
+        A, B, Hs = co.gen_batch(seed, nb, p, nx, mb, **kw)
+        o = solve_batch(A, B, Hs)
+        np.savez(os.path.join(HERE, name + '.npz'), A=A, B=B, H=Hs, tol=co.DEFAULT_OPTS['tol'], **o)
+        print(name, 'kappa', o['kappa'], 'iters', o['iters'], 'status', o['status'])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,257 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libtunempc_hip.so.
+Floating point: H/Hc must match the CPU oracle within 1e-8 relative Frobenius norm (BASELINE.json north_star);
+the tolerance is written at each assert."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+import convexify_oracle as co  # noqa: E402  (tests are the only place the product meets the oracle)
+
+PARITY = 1e-8       # relative Frobenius norm, BASELINE.json: "H/q within 1e-8 of reference"
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def hc():
+    from tunempc_amd._lib import HipConvexifier
+    cache = {}
+
+    def get(p, nx, mb, **kw):
+        key = (p, nx, mb, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = HipConvexifier(p, nx, mb, **kw)
+        return cache[key]
+    yield get
+    for h in cache.values():
+        h.close()
+
+
+def test_library_loaded_in_tree():
+    from tunempc_amd._lib import load_library, library_path
+    lib = load_library()
+    assert os.path.dirname(library_path()).endswith(os.path.join('tunempc_amd', 'lib'))
+    assert lib.tmpc_device_count() >= 1
+
+
+# ----------------------------------------------------------------------------- building blocks
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (128, 64, 48), (304, 48, 256), (304, 304, 304), (16, 16, 16), (48, 112, 80)])
+@pytest.mark.parametrize('flags', [0, 1])
+def test_mfma_gemm_nt(hc, M, N, K, flags):
+    """v_mfma_f64_16x16x4 tile GEMM (and its scalar-FMA twin) vs numpy; asymmetric operands catch transposes."""
+    h = hc(2, 3, 1)
+    h.set_options(flags=flags)
+    rng = np.random.default_rng(M * 1000 + N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
+    for mode, ref in [(0, C0 - A @ B.T), (1, A @ B.T), (2, -A @ B.T)]:
+        out = h.debug_gemm_nt(C0, A, B, mode)
+        assert rel(out, ref) < 1e-14
+    h.set_options(flags=0)
+
+
+def _spd_cyclic(rng, p, d):
+    E = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d); F = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d)
+    D = np.stack([np.eye(d) for _ in range(p)]); Cc = np.zeros((p, d, d))
+    for k in range(p):
+        D[k] += E[k].T @ E[k]; D[(k + 1) % p] += F[k].T @ F[k]; Cc[k] = E[k].T @ F[k]
+    T = np.zeros((p * d, p * d))
+    for k in range(p):
+        T[k*d:(k+1)*d, k*d:(k+1)*d] += D[k]
+        kn = (k + 1) % p
+        if kn == k:
+            T[k*d:(k+1)*d, k*d:(k+1)*d] += Cc[k] + Cc[k].T
+        else:
+            T[k*d:(k+1)*d, kn*d:(kn+1)*d] += Cc[k]; T[kn*d:(kn+1)*d, k*d:(k+1)*d] += Cc[k].T
+    return D, Cc, T
+
+
+@pytest.mark.parametrize('p,d', [(1, 6), (2, 10), (3, 10), (5, 21), (4, 78), (3, 136), (3, 300), (7, 45), (2, 3)])
+def test_block_cyclic_cholesky_solve(hc, p, d):
+    """k_factor + wg_cyclic_solve vs a dense numpy solve of the same SPD block-cyclic-tridiagonal system."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(p * 100 + d)
+    D, Cc, T = _spd_cyclic(rng, p, d)
+    rhs = rng.standard_normal((p, d))
+    x, nshift = h.debug_block_solve(D, Cc, rhs)
+    xref = np.linalg.solve(T, rhs.ravel()).reshape(p, d)
+    assert nshift == 0
+    assert rel(x, xref) < 1e-12
+
+
+@pytest.mark.parametrize('n', [1, 2, 4, 5, 15, 30, 32])
+def test_jacobi_eig_scan(hc, n):
+    """batched symmetric eigenvalue extremes (pre-check :82, autoScaling :374-401, status :438-440) vs LAPACK."""
+    nx = max(n - 1, 1); mb = n - nx
+    h = hc(3, nx, mb)
+    rng = np.random.default_rng(n)
+    H = rng.standard_normal((4, 3, n, n)); H = H + H.transpose(0, 1, 3, 2)
+    H[0, 0] = np.diag(np.arange(n, dtype=float))            # exact zero eigenvalue is excluded from min|eig|
+    out = h.eig_scan(H)
+    ev = np.linalg.eigvalsh(H)
+    aev = np.abs(ev)
+    amin = np.where(aev == 0, np.inf, aev).min(-1)
+    if n == 1:
+        amin[0, 0] = 1e300
+    ref = np.stack([ev[..., 0], ev[..., -1], amin, aev.max(-1)], -1)
+    scale = np.abs(ev).max()
+    assert np.abs(out[..., :2] - ref[..., :2]).max() < 1e-13 * scale
+    fin = np.isfinite(ref[..., 2]) & (ref[..., 2] < 1e299)
+    assert np.abs(out[..., 2][fin] - ref[..., 2][fin]).max() < 1e-13 * scale
+    assert np.abs(out[..., 3] - ref[..., 3]).max() < 1e-13 * scale
+
+
+@pytest.mark.parametrize('p,nx,mb', [(1, 3, 1), (4, 4, 2), (3, 24, 8)])
+def test_supplement(hc, p, nx, mb):
+    """convexHessianSuppl (convexifier.py:165-211) on the GPU vs numpy."""
+    h = hc(p, nx, mb)
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((2, p, nx, nx)); B = rng.standard_normal((2, p, nx, mb))
+    P = rng.standard_normal((2, p, nx, nx)); P = P + P.transpose(0, 1, 3, 2)
+    out = h.supplement_batch(A, B, P)
+    for b in range(2):
+        ref, _, _, _ = co.convex_hessian_suppl(A[b], B[b], P[b])
+        assert rel(out[b], ref) < 1e-14
+
+
+# ----------------------------------------------------------------------------- full path vs oracle
+@pytest.mark.parametrize('name', ['c1_convex_lqr', 'c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'awe_shape_n15',
+                                  'identity_family'])
+def test_golden_vectors(hc, golden_dir, name):
+    """HIP path vs the committed golden vectors (inputs + oracle outputs)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    A, B, H = g['A'], g['B'], g['H']
+    nb, p, nx, _ = A.shape
+    h = hc(p, nx, B.shape[3])
+    out = h.convexify_batch(A, B, H)
+    for b in range(nb):
+        assert int(out['status'][b]) == int(g['status'][b])
+        assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
+        assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+        assert rel(out['P'][b], g['P'][b]) < 1e-7
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(0, 3, 3, 3, 2), (20, 4, 1, 3, 1), (30, 4, 2, 3, 1), (13, 2, 30, 4, 1), (5, 4, 16, 3, 2),
+                                             (11, 2, 6, 12, 4), (12, 2, 4, 24, 8), (40, 3, 5, 2, 2), (41, 2, 7, 5, 0)])
+def test_parity_vs_oracle(hc, seed, nb, p, nx, mb):
+    """Same seeded inputs through the HIP path and the CPU oracle (covers p=1, p=2, mb=0, early-exit members)."""
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    h = hc(p, nx, mb)
+    out = h.convexify_batch(A, B, H)
+    for b in range(nb):
+        r = co.convexify_arrays(A[b], B[b], H[b])
+        assert int(out['status'][b]) == int(r['status'])
+        assert bool(out['info'][b, 13]) == bool(r['early_exit'])
+        assert rel(out['Hc'][b], r['Hc']) < PARITY
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        if not r['early_exit']:
+            assert abs(out['info'][b, 0] - r['s']) < 1e-12 * r['s'] and abs(out['info'][b, 1] - r['sbeta']) < 1e-12 * r['sbeta']
+
+
+def test_scalar_fma_and_mfma_paths_agree(hc):
+    A, B, H = co.gen_batch(11, 2, 6, 12, 4)
+    h = hc(6, 12, 4)
+    o1 = h.convexify_batch(A, B, H)
+    h.set_options(flags=1)
+    o2 = h.convexify_batch(A, B, H)
+    h.set_options(flags=0)
+    assert rel(o1['Hc'], o2['Hc']) < PARITY
+
+
+def test_device_resident_entry_matches_host_entry(hc):
+    import torch
+    A, B, H = co.gen_batch(5, 3, 8, 3, 2)
+    h = hc(8, 3, 2)
+    o1 = h.convexify_batch(A, B, H)
+    dev = torch.device('cuda', 0)
+    o2 = h.convexify_batch_device(*(torch.from_numpy(x).to(dev) for x in (A, B, H)))
+    torch.cuda.synchronize()
+    assert np.array_equal(o1['Hc'], o2['Hc'].cpu().numpy())
+    assert np.array_equal(o1['status'], o2['status'].cpu().numpy())
+
+
+def test_chunked_batches_equal_unchunked(hc):
+    """A batch larger than the workspace chunk is processed in waves; results must not depend on the chunking."""
+    A, B, H = co.gen_batch(60, 7, 5, 3, 1)
+    big = hc(5, 3, 1)
+    small = hc(5, 3, 1, chunk=3)
+    o1 = big.convexify_batch(A, B, H); o2 = small.convexify_batch(A, B, H)
+    assert np.array_equal(o1['Hc'], o2['Hc']) and np.array_equal(o1['iters'], o2['iters'])
+
+
+def test_infeasible_member_does_not_abort_batch(hc):
+    """B = 0 with R not PD can never be convexified: status 2 for that member only."""
+    A, B, H = co.gen_batch(70, 3, 2, 2, 1)
+    A[1] = 0.5 * np.eye(2); B[1] = 0.0
+    H[1] = co.build_hessian(np.eye(2), np.array([[-1.0]]), np.zeros((2, 1)))
+    h = hc(2, 2, 1)
+    out = h.convexify_batch(A, B, H)
+    assert int(out['status'][1]) == 2
+    for b in (0, 2):
+        r = co.convexify_arrays(A[b], B[b], H[b])
+        assert int(out['status'][b]) == int(r['status']) and rel(out['Hc'][b], r['Hc']) < PARITY
+
+
+# ----------------------------------------------------------------------------- reference-compatible API
+def test_dropin_convexify_lqr_example():
+    """examples/convex_lqr.py through the drop-in API: same call, same return structure, same assertion (:58)."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c1_convex_lqr.npz'))
+    A = np.matrix(g['A'][0, 0]); B = np.matrix(g['B'][0, 0]); Q = np.matrix(g['Q']); R = np.matrix(g['R']); N = np.matrix(g['N'])
+    dHc, dQc, dRc, dNc = convexifier.convexify(A, B, Q, R, N)
+    assert isinstance(dHc, list) and len(dHc) == 1 and dHc[0].shape == (4, 4)
+    An, Bn, Qn, Rn, Nn = (np.asarray(x) for x in (A, B, Q, R, N))
+
+    def gain(Q_, R_, N_):
+        P = sla.solve_discrete_are(An, Bn, Q_, R_, s=N_)
+        return np.linalg.solve(R_ + Bn.T @ P @ Bn, Bn.T @ P @ An + N_.T)
+    assert np.linalg.norm(gain(Qn, Rn, Nn) - gain(Qn + dQc[0], Rn + dRc[0], Nn + dNc[0])) < 1e-5
+    assert rel(np.asarray(dHc[0]) + co.build_hessian(Qn, Rn, Nn), g['Hc'][0, 0]) < PARITY
+
+
+def test_dropin_early_exit_and_infeasible():
+    from tunempc_amd import convexifier
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((3, 3)); B = rng.standard_normal((3, 1))
+    out = convexifier.convexify(A, B, 2 * np.eye(3), 2 * np.eye(1), np.zeros((3, 1)))
+    assert all(isinstance(o, np.ndarray) for o in out) and out[0].shape == (4, 4) and not out[0].any()   # convexifier.py:85
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        convexifier.convexify(0.5 * np.eye(2), np.zeros((2, 1)), np.eye(2), np.array([[-1.0]]), np.zeros((2, 1)))
+
+
+def test_dropin_tuner_convexify_list_inputs():
+    """Tuner.convexify slicing (tuner.py:145-158) over a sensitivities dict."""
+    from tunempc_amd.tuner import tuner_convexify
+    A, B, H = co.gen_batch(2000, 1, 30, 4, 1)
+    S = {'A': [A[0, k] for k in range(30)], 'B': [B[0, k] for k in range(30)], 'H': [H[0, k] for k in range(30)], 'C_As': None, 'G': None}
+    Hc = tuner_convexify(S, nx=4, p=30)
+    r = co.convexify_arrays(A[0], B[0], H[0])
+    assert len(Hc) == 30 and rel(np.stack(Hc), r['Hc']) < PARITY
+
+
+# ----------------------------------------------------------------------------- full-size properties (no oracle)
+def test_full_size_c4_properties(hc):
+    """BASELINE configs[3] stage size and period (nx=24, m=8, p=64), a small batch: size-independent properties --
+    Hc positive definite, cond(Hc_k) <= kappa, Hc - H has exactly the structure of eq. (18) for the returned P,
+    kappa no worse than the feasible point the generator hides, all members converge."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb = 64, 24, 8, 3
+    A, B, H = synthetic.gen_batch(777, nb, p, nx, mb)
+    h = hc(p, nx, mb)
+    out = h.convexify_batch(A, B, H)
+    assert (out['status'] == 0).all()
+    for b in range(nb):
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0
+        assert (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-9)
+        dH, _, _, _ = co.convex_hessian_suppl(A[b], B[b], out['P'][b])
+        assert rel(out['Hc'][b] - H[b], dH) < 1e-10
+        assert out['kappa'][b] <= 10.0 * (1 + 1e-6)          # the generator's Hhat has cond <= 10
+    # idempotence of the pre-check: convexified Hessians are already convex -> early exit, zero supplement
+    again = h.convexify_batch(A, B, out['Hc'])
+    assert (again['info'][:, 13] == 1).all() and not again['dHc'].any()

@@ -1,0 +1,106 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/*.h declares, the
+product fails loudly without a device (no CPU fallback), and the reference-interface mirrors behave."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'tunempc_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(tmpc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from tunempc_amd._lib import load_library, EXPORTS
+    lib = load_library()
+    declared = _declared_symbols()
+    assert declared, 'no declarations parsed'
+    assert sorted(EXPORTS) == declared
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b'gfx950' in lib.tmpc_version()
+
+
+def test_workspace_query_and_unsupported_dims():
+    from tunempc_amd._lib import load_library
+    lib = load_library()
+    # c4: 64 stages of d=300 (dp=304): D,O,F alone are 3*64*304^2*8 B = 142 MB per problem
+    per = lib.tmpc_workspace_bytes(1, 64, 24, 8)
+    assert 142e6 < per < 200e6
+    assert lib.tmpc_workspace_bytes(2, 64, 24, 8) > 1.9 * per
+    assert lib.tmpc_workspace_bytes(1, 64, 30, 8) == 0      # n = 38 > 32 unsupported
+    assert lib.tmpc_workspace_bytes(1, 0, 4, 1) == 0
+
+
+def _no_gpu():
+    from tunempc_amd._lib import load_library
+    return load_library().tmpc_device_count() < 1
+
+
+@pytest.mark.skipif(not _no_gpu(), reason='a HIP device is visible; the loud-failure path is for GPU-less hosts')
+def test_product_fails_loudly_without_device():
+    from tunempc_amd._lib import HipConvexifier
+    from tunempc_amd import convexifier
+    with pytest.raises(RuntimeError, match='no HIP device|no CPU fallback'):
+        HipConvexifier(3, 3, 1)
+    A = np.eye(2) * 0.5; B = np.ones((2, 1)); Q = -np.eye(2); R = np.eye(1); N = np.zeros((2, 1))
+    with pytest.raises(RuntimeError):
+        convexifier.convexify(A, B, Q, R, N)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under tunempc_amd/ may import or execute it."""
+    pkg = os.path.join(ROOT, 'tunempc_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'convexify_oracle' not in txt and 'proto_dense' not in txt, (dirpath, f)
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), (dirpath, f)
+
+
+def test_input_checks_mirror_reference_messages():
+    from tunempc_amd import preprocessing
+    M = np.eye(2)
+    with pytest.raises(AssertionError, match='Input arguments should be of same type!'):
+        preprocessing.input_checks({'A': [M], 'B': M})
+    with pytest.raises(AssertionError, match='Input data lists should have same length!'):
+        preprocessing.input_checks({'A': [M, M], 'B': [M]})
+    with pytest.raises(AssertionError, match='Data matrices should have same size along trajectory.'):
+        preprocessing.input_checks({'A': [M, np.eye(3)], 'B': [M, M]})
+    ragged = preprocessing.input_checks({'A': [M, M], 'C': [np.ones((1, 2)), np.ones((3, 2))]})   # C exempt (:180)
+    assert len(ragged['C']) == 2
+    wrapped = preprocessing.input_checks({'A': np.matrix(M), 'B': np.matrix(M)})
+    assert isinstance(wrapped['A'], list)
+
+
+def test_mtools():
+    from tunempc_amd import mtools
+    Q = np.array([[1.0, 2.0], [2.0, 3.0]]); R = np.array([[4.0]]); N = np.array([[5.0], [6.0]])
+    H = mtools.buildHessian(Q, R, N)
+    np.testing.assert_array_equal(H, [[1, 2, 5], [2, 3, 6], [5, 6, 4]])
+    S = np.array([[1.0, 2.0], [4.0, 3.0]])
+    np.testing.assert_array_equal(mtools.symmetrize(S), [[1, 3], [3, 3]])
+
+
+def test_synthetic_generator_matches_oracle_generator():
+    import convexify_oracle as co
+    from tunempc_amd import synthetic
+    a = synthetic.gen_batch(321, 2, 3, 4, 2)
+    b = co.gen_batch(321, 2, 3, 4, 2)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_g_argument_is_rejected_loudly():
+    from tunempc_amd import convexifier
+    A = np.eye(2) * 0.5; B = np.ones((2, 1)); Q = -np.eye(2); R = np.eye(1); N = np.zeros((2, 1))
+    with pytest.raises(NotImplementedError):
+        convexifier.convexify(A, B, Q, R, N, G=np.ones((1, 3)))

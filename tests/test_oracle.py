@@ -1,0 +1,132 @@
+"""CPU tests of the oracle (oracle/convexify_oracle.py): pinned against the reference's example literals,
+the dense unstructured cross-check, solver-independent invariants and the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import convexify_oracle as co
+import proto_dense
+
+
+def _lqr():
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c1_convex_lqr.npz'))
+    return g
+
+
+def test_lqr_literals_eigs_and_scaling(golden_dir):
+    """eig(H) of examples/convex_lqr.py:40-46 and the autoScaling factors (convexifier.py:374-401)."""
+    g = _lqr()
+    H = co.build_hessian(g['Q'], g['R'], g['N'])
+    ev = np.linalg.eigvalsh(H)
+    np.testing.assert_allclose(ev, [-1.89071596, 0.17894836, 0.62538381, 1.94358379], atol=5e-9)
+    s, sbeta = co.auto_scaling(H[None])
+    assert abs(s - 5.58820422) < 1e-7 and abs(sbeta - 10.86114315) < 1e-7
+
+
+def test_lqr_feedback_invariance():
+    """The reference's only executable assertion (examples/convex_lqr.py:52-58): tuned and indefinite weights
+    give the same LQR gain; plus Hc > 0 which the reference checks in check_convergence (:438-451)."""
+    g = _lqr()
+    A, B, Q, R, N = g['A'][0, 0], g['B'][0, 0], g['Q'], g['R'], g['N']
+    dHc, dQc, dRc, dNc = co.convexify(A, B, Q, R, N)
+    assert isinstance(dHc, list) and len(dHc) == 1
+
+    def gain(Q_, R_, N_):
+        P = sla.solve_discrete_are(A, B, Q_, R_, s=N_)
+        return np.linalg.solve(R_ + B.T @ P @ B, B.T @ P @ A + N_.T)
+
+    K = gain(Q, R, N)
+    np.testing.assert_allclose(K.ravel(), [0.05129923, 0.23896453, -0.25707625], atol=1e-7)
+    Kc = gain(Q + dQc[0], R + dRc[0], N + dNc[0])
+    assert np.linalg.norm(K - Kc) < 1e-5
+    Hc = co.build_hessian(Q, R, N) + dHc[0]
+    assert np.linalg.eigvalsh(Hc).min() > 0
+
+
+@pytest.mark.parametrize('seed,p,nx,mb', [(0, 3, 3, 2), (20, 1, 3, 1), (30, 2, 3, 1), (3, 5, 4, 2)])
+def test_structured_vs_dense(seed, p, nx, mb):
+    """Block-cyclic-tridiagonal oracle == unstructured dense IPM on the same SDP (same optimum kappa, same Hc)."""
+    A, B, H, _, _ = co.gen_problem(seed, p, nx, mb)
+    r = co.convexify_arrays(A, B, H)
+    rd = proto_dense.solve(A, B, H, tol=co.DEFAULT_OPTS['tol'], verbose=False, center_its=12)
+    assert abs(r['kappa'] - rd['tau']) < 5e-5 * r['kappa']
+    assert np.linalg.norm(r['Hc'] - rd['Hc']) / np.linalg.norm(r['Hc']) < 1e-4
+
+
+@pytest.mark.parametrize('seed,p,nx,mb', [(10, 4, 3, 2), (11, 8, 4, 1), (12, 3, 6, 3), (22, 1, 3, 1)])
+def test_invariants(seed, p, nx, mb):
+    A, B, H, Phat, Hhat = co.gen_problem(seed, p, nx, mb)
+    r = co.convexify_arrays(A, B, H)
+    inv = co.check_invariants(A, B, H, r)
+    assert not r['early_exit']
+    assert r['status'] == co.STATUS_OPTIMAL
+    assert inv['min_eig'] > 0                                   # Hc positive definite (convexifier.py:442)
+    assert inv['struct_err'] < 1e-12                            # Hc - H = sym(calH(P)) (eq. 18 structure)
+    assert inv['max_cond'] <= r['kappa'] * (1 + 1e-9)           # cond(Hc_k) <= sbeta*beta
+    kap_hat = max(np.linalg.cond(Hhat[k]) for k in range(p))   # a feasible point: optimum cannot be worse
+    assert r['kappa'] <= kap_hat * (1 + 1e-6)
+
+
+def test_known_optimum_identity_family():
+    """Hhat = I  =>  kappa* = 1 and Hc = c*I, the one family with a solver-independent answer."""
+    A, B, H, Phat, _ = co.gen_problem(77, 5, 4, 2, identity=True)
+    r = co.convexify_arrays(A, B, H)
+    assert abs(r['kappa'] - 1.0) < 2e-5
+    for k in range(5):
+        Hk = r['Hc'][k]
+        c = np.trace(Hk) / Hk.shape[0]
+        assert np.linalg.norm(Hk - c * np.eye(6)) < 2e-5 * c
+    np.testing.assert_allclose(r['Hc'], np.broadcast_to(np.eye(6), r['Hc'].shape), atol=5e-5)
+
+
+def test_early_exit_returns_bare_zero_arrays():
+    """convexifier.py:83-85: already-convex input returns four bare zero arrays (not lists)."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((3, 3)); B = rng.standard_normal((3, 1))
+    H = np.eye(4) * 2.0
+    out = co.convexify(A, B, H[:3, :3], H[3:, 3:], H[:3, 3:])
+    assert all(isinstance(o, np.ndarray) for o in out)
+    assert out[0].shape == (4, 4) and out[1].shape == (3, 3) and out[2].shape == (1, 1) and out[3].shape == (3, 1)
+    assert not any(o.any() for o in out)
+
+
+def test_infeasible_raises_value_error():
+    """B = 0 with R not PD: R-block of Hc can never become PD => ValueError (convexifier.py:157)."""
+    A = 0.5 * np.eye(2); B = np.zeros((2, 1))
+    Q = np.eye(2); R = np.array([[-1.0]]); N = np.zeros((2, 1))
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        co.convexify(A, B, Q, R, N)
+
+
+def test_input_checks_messages():
+    """preprocessing.py:167,171,178."""
+    M = np.eye(2)
+    with pytest.raises(AssertionError, match='same type'):
+        co.input_checks({'A': [M], 'B': M})
+    with pytest.raises(AssertionError, match='same length'):
+        co.input_checks({'A': [M, M], 'B': [M]})
+    with pytest.raises(AssertionError, match='same size'):
+        co.input_checks({'A': [M, np.eye(3)], 'B': [M, M]})
+    out = co.input_checks({'A': M, 'B': M})
+    assert isinstance(out['A'], list) and len(out['A']) == 1
+
+
+@pytest.mark.parametrize('name', ['c1_convex_lqr', 'c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'identity_family'])
+def test_golden_vectors(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    assert float(g['tol']) == co.DEFAULT_OPTS['tol']
+    for b in range(min(g['A'].shape[0], 2)):
+        r = co.convexify_arrays(g['A'][b], g['B'][b], g['H'][b])
+        assert int(r['status']) == int(g['status'][b])
+        assert np.linalg.norm(r['Hc'] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b]) < 1e-8
+        assert abs(r['kappa'] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+
+
+def test_gap_tolerance_reported():
+    """kappa - kappa* <= tol*kappa: tightening the tolerance moves kappa by less than the looser gap."""
+    A, B, H, _, _ = co.gen_problem(5, 8, 3, 2)
+    r5 = co.convexify_arrays(A, B, H, dict(tol=1e-5))
+    r4 = co.convexify_arrays(A, B, H, dict(tol=1e-4))
+    assert 0 <= r4['kappa'] - r5['kappa'] <= 1.2e-4 * r4['kappa']

@@ -16,7 +16,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
 # every symbol declared in include/tunempc_hip.h
 EXPORTS = [
-    'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_set_options',
+    'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve',
     'tmpc_last_error', 'tmpc_version',
@@ -48,6 +48,8 @@ def load_library():
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
     lib.tmpc_destroy.argtypes = [vp]
+    lib.tmpc_get_chunk.restype = C.c_int
+    lib.tmpc_get_chunk.argtypes = [vp]
     lib.tmpc_set_options.restype = C.c_int
     lib.tmpc_set_options.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
     lib.tmpc_convexify_batch_host.restype = C.c_int
@@ -93,6 +95,7 @@ class HipConvexifier:
         self.p, self.nx, self.mb, self.n = int(p), int(nx), int(mb), int(nx) + int(mb)
         self._h = C.c_void_p()
         _check(self.lib, self.lib.tmpc_create(C.byref(self._h), int(chunk), self.p, self.nx, self.mb), 'tmpc_create')
+        self.chunk = int(self.lib.tmpc_get_chunk(self._h))
         self.flags = int(flags)
         self.set_options(tol, center_tol, max_iter, center_iter, flags)
 

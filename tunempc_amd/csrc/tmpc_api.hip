@@ -284,7 +284,7 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) {
   tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
   if (!h) return TMPC_E_NOMEM;
   h->dm = make_dims(chunk, p, nx, mb);
-  h->opt.tol = 1e-6; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
+  h->opt.tol = 1e-5; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
   h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
   if (hipMalloc(&h->slab, h->slab_bytes) != hipSuccess) {
@@ -307,6 +307,8 @@ int tmpc_destroy(tmpc_handle* h) {
   free(h);
   return TMPC_OK;
 }
+
+int tmpc_get_chunk(tmpc_handle* h) { return h ? h->dm.B : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;

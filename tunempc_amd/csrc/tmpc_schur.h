@@ -145,7 +145,7 @@ __device__ __forceinline__ double pmin(const double* part, int b, int p, int idx
   return wave_min(acc);
 }
 
-// after k_stage_pre: mu, residual norms, phase logic (mirrors oracle/convexify_oracle.py sdp_step1)
+// after k_stage_pre: mu, residual norms, phase logic (the same control flow as the CPU restatement used by the tests)
 __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
@@ -184,7 +184,9 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   pr[P_MU] = mu; pr[P_RD0] = rd0; pr[P_PINF] = pinf; pr[P_DINF] = dinf; pr[P_RELGAP] = relgap; pr[P_SXS] = xs;
   pr[P_BTT] = trpsi; pr[P_BTA] = -trphi2; pr[P_BAA] = hbphi + x0 / s0;
   if (nbad > 0.0) ip[I_CHOLBAD] += (int)nbad;
-  if (!(mu > 0.0) || !(mu < 1e300) || nbad > 0.0 || !(s0 > 0.0) || !(x0 > 0.0)) {   // breakdown: stop this problem
+  if (ip[I_ITERS] == 0) pr[P_MU0] = mu;
+  // breakdown or divergence (dual unbounded = Step 1 infeasible): stop this problem with its last iterate
+  if (!(mu > 0.0) || !(mu < 1e300) || nbad > 0.0 || !(s0 > 0.0) || !(x0 > 0.0) || mu > 1e6 * pr[P_MU0] || !(fabs(tau) < 1e300)) {
     ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_MAXITER;
     return;
   }
