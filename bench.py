@@ -149,7 +149,7 @@ def main():
             "config": {"workload": f"BASELINE configs[3]: synthetic SPD-perturbed Hessians, (nx+nu)={n} (nx={nx}, m={mb}), p={p}, "
                                    f"{nbl} problems per GPU ({nbl * world} total; published batch 4096 = 512 x 8 GPUs)",
                        "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
-                       "distinct_problems_per_gpu": nd, "gap_tol": args.tol if args.tol > 0 else "library default (1e-5)",
+                       "distinct_problems_per_gpu": nd, "mu_tol": args.tol if args.tol > 0 else 2.0 ** -25,
                        "ipm_iterations_max": int(iters.max()), "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
@@ -161,7 +161,7 @@ def main():
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 1e-5)
+            line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 2.0 ** -25)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

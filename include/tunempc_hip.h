@@ -71,7 +71,8 @@ int tmpc_destroy(tmpc_handle* h);
 /* Problems processed per launch wave (the chunk the workspace was sized for). */
 int tmpc_get_chunk(tmpc_handle* h);
 
-/* Solver options: tol = relative duality gap on kappa (max condition number), default 1e-5;
+/* Solver options: tol = complementarity tolerance mu_target/kappa per unit cone dimension, default 2^-25
+ * (the relative duality gap on kappa, the max condition number, is then (2*p*n+1)*tol);
  * center_tol = relative Newton step ending the final centering phase, default 1e-9;
  * max_iter / center_iter = iteration caps (defaults 50 / 12); flags = TMPC_FLAG_*.  Values <= 0 keep
  * the current setting (flags is always applied). */
@@ -98,6 +99,10 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
  * [4] corrector pass + update, [5] number of k_factor launches, [6] total ms of convexify calls,
  * [7] IPM iterations (max over chunk, summed over chunks). */
 int tmpc_get_profile(tmpc_handle* h, double* out8);
+
+/* Per-iteration diagnostics of the LAST chunk solved: out[nb][80][10] = (iteration, phase, mu, tau, pinf, dinf,
+ * primal step, dual step, relative output change of the step, cumulative shifted pivots); nb <= chunk. */
+int tmpc_get_trace(tmpc_handle* h, int nb, double* out);
 
 /* Debug / unit-test entry points (tests call the kernels' building blocks through the same library). */
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);

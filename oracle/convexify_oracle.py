@@ -37,7 +37,10 @@ ALPHA_MIN = 1e-8          # convexifier.py:245
 STATUS_OPTIMAL, STATUS_FEASIBLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
-DEFAULT_OPTS = dict(tol=1e-5, max_iter=50, center_iter=12, center_tol=1e-9)
+# tol: complementarity tolerance relative to the optimal value, mu_target = tol * kappa (per unit of cone
+# dimension; the relative duality gap on kappa is then N*tol with N = 2*p*n + 1).  2^-25 keeps the HKM Schur
+# complement a factor >= 10 away from the fp64 breakdown observed at mu ~ 1e-8.
+DEFAULT_OPTS = dict(tol=2.0 ** -25, max_iter=50, center_iter=12, center_tol=1e-9)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -316,8 +319,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             status = 'diverged'          # dual unbounded / primal infeasible: leave with the last iterate
             break
         if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
-            mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau)) / N))
-        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < o['tol'] and pinf < max(o['tol'], 1e-6):
+            mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau))))
+        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and pinf < 1e-6:
             phase = 1
         if phase == 0 and it >= o['max_iter']:
             break
@@ -404,7 +407,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(mu_t)
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
             ap = min(1.0, 0.95 * ap); ad = min(1.0, 0.95 * ad)
-            stepn = np.sqrt(dtau ** 2 + dalpha ** 2 + np.sum(dP ** 2)) / (1.0 + np.sqrt(tau ** 2 + alpha ** 2 + np.sum(P ** 2)))
+            # first-order relative change of the output Hc_k = M_k/(s*alpha) in this step
+            dMc = dalpha * Hb + calH(A, B, dP)
+            stepn = np.sqrt(np.sum((dMc - (dalpha / alpha) * M) ** 2) / np.sum(M ** 2))
             if verbose:
                 print(f"      center |dy|rel={stepn:.3e} ap={ap:.3f} ad={ad:.3f}")
         X1 = symmetrize(X1 + ap * dX1); X2 = symmetrize(X2 + ap * dX2)

@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
-    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve',
+    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -62,6 +62,8 @@ def load_library():
     lib.tmpc_eig_scan_host.argtypes = [vp, C.c_int, dp, dp]
     lib.tmpc_get_profile.restype = C.c_int
     lib.tmpc_get_profile.argtypes = [vp, dp]
+    lib.tmpc_get_trace.restype = C.c_int
+    lib.tmpc_get_trace.argtypes = [vp, C.c_int, dp]
     lib.tmpc_debug_gemm_nt.restype = C.c_int
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
@@ -176,6 +178,12 @@ class HipConvexifier:
         _check(self.lib, self.lib.tmpc_get_profile(self._h, _dptr(out)), 'tmpc_get_profile')
         keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters']
         return dict(zip(keys, out.tolist()))
+
+    def trace(self, nb):
+        """[nb, 80, 10] per-iteration diagnostics of the last chunk (it, phase, mu, tau, pinf, dinf, ap, ad, step, shifts)."""
+        out = np.zeros((nb, 80, 10))
+        _check(self.lib, self.lib.tmpc_get_trace(self._h, nb, _dptr(out)), 'tmpc_get_trace')
+        return out
 
     # ------------------------------------------------------------------ unit-test hooks
     def debug_gemm_nt(self, Cm, A, B, mode=0, lower=False):

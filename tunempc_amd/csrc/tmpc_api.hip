@@ -85,6 +85,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
   w.W3 = c.take<double>(BP * dm.dp * 3); w.U = c.take<double>(BP * dm.dp * 2); w.TU = c.take<double>(BP * dm.dp * 2);
   w.Z = c.take<double>(BP * dm.dp);
   w.active = c.take<int>(64);
+  w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   if (h) {
     h->dA = c.take<double>(BP * nxx); h->dB = c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); h->dH = c.take<double>(BP * nn);
@@ -199,6 +200,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   const int BP = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
   HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   hipLaunchKernelGGL(k_init_stage, dim3(BP), dim3(64), slots_bytes(2), st, w, dm);
   hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, w, dm);
   hipLaunchKernelGGL(k_init_state, dim3(BP), dim3(64), 0, st, w, dm);
@@ -284,7 +286,7 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) {
   tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
   if (!h) return TMPC_E_NOMEM;
   h->dm = make_dims(chunk, p, nx, mb);
-  h->opt.tol = 1e-5; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
+  h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
   h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
   if (hipMalloc(&h->slab, h->slab_bytes) != hipSuccess) {
@@ -317,6 +319,12 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
   if (max_iter > 0) h->opt.max_iter = max_iter;
   if (center_iter > 0) h->opt.center_iter = center_iter;
   h->flags = flags;
+  return TMPC_OK;
+}
+
+int tmpc_get_trace(tmpc_handle* h, int nb, double* out) {
+  if (!h || !out || nb < 1 || nb > h->dm.B) return TMPC_E_ARG;
+  HIPCHK(hipMemcpy(out, h->ws.trace, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), hipMemcpyDeviceToHost));
   return TMPC_OK;
 }
 

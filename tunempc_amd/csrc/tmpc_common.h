@@ -6,6 +6,7 @@
 namespace tmpc {
 
 constexpr double ALPHA_MIN = 1e-8;     // reference: convexifier.py:245  (alpha > 1e-8)
+constexpr int TRACE_LEN = 80, TRACE_W = 10;
 constexpr int TB = 64;                 // tile size of the d x d block factorisation (potrf / trsm granularity)
 
 // ---- per-problem double scalars (prob[b*PS + idx])
@@ -29,7 +30,7 @@ enum {
   Q_XS = 0, Q_RD2, Q_S2, Q_TRX2, Q_HBY, Q_TRPSI, Q_TRPHI2, Q_HBPHI,   // stage_pre
   Q_TRT2, Q_HBG,                                                       // stage_rhs
   Q_MINX, Q_MINS, Q_DXS, Q_XDS, Q_DXDS, Q_DP2, Q_P2,                   // stage_dir
-  Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, NPART = 24
+  Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, Q_DH2, Q_M2, NPART = 24
 };
 
 // Kronecker-factor slots per stage (KF[((b*p+k)*12 + slot) * nx*nx])
@@ -49,7 +50,7 @@ struct Dims {
 };
 
 struct Opts {
-  double tol;          // relative duality gap on kappa (max condition number)
+  double tol;          // complementarity tolerance: mu_target = tol * kappa (relative gap on kappa = (2pn+1)*tol)
   double center_tol;   // relative Newton step that ends the centering phase
   int max_iter;
   int center_iter;
@@ -87,6 +88,7 @@ struct WS {
   double* TU;      // [B,p,dp,2]    T^-1 U
   double* Z;       // [B,p,dp]      rhs / solution
   int* active;     // [1] number of problems still iterating
+  double* trace;   // [B][TRACE_LEN][TRACE_W] per-iteration diagnostics (it, phase, mu, tau, pinf, dinf, ap, ad, stepn, shifts)
   // outputs
   double* Hc;      // [B,p,n,n]
   double* dHc;     // [B,p,n,n]

@@ -192,11 +192,11 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   }
   double mut = pr[P_MUT];
   if (mut < 0.0 && relgap < 1e-2 && dinf < 1e-2) {
-    mut = exp2(rint(log2(o.tol * fmax(1.0, fabs(tau)) / N)));
+    mut = exp2(rint(log2(o.tol * fmax(1.0, fabs(tau)))));
     pr[P_MUT] = mut;
   }
   int phase = ip[I_PHASE];
-  if (phase == PH_MAIN && mut > 0.0 && mu <= 2.0 * mut && dinf < o.tol && pinf < fmax(o.tol, 1e-6)) {
+  if (phase == PH_MAIN && mut > 0.0 && mu <= 2.0 * mut && dinf < 1e-6 && pinf < 1e-6) {
     phase = PH_CENTER;
     ip[I_PHASE] = phase;
   }
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p;
   const double minx = pmin(w.part, b, p, Q_MINX, lane), mins = pmin(w.part, b, p, Q_MINS, lane);
-  const double dp2 = psum(w.part, b, p, Q_DP2, lane), p2 = psum(w.part, b, p, Q_P2, lane);
+  const double dh2 = psum(w.part, b, p, Q_DH2, lane), m2 = psum(w.part, b, p, Q_M2, lane);
   if (lane != 0) return;
   const double s0 = pr[P_S0], x0 = pr[P_X0];
   const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
@@ -270,10 +270,15 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     ap = fmin(1.0, gam * ap); ad = fmin(1.0, gam * ad);
   } else {
     ap = fmin(1.0, 0.95 * ap); ad = fmin(1.0, 0.95 * ad);
-    pr[P_STEPN] = sqrt(dtau * dtau + dalpha * dalpha + dp2) /
-                  (1.0 + sqrt(pr[P_TAU] * pr[P_TAU] + pr[P_ALPHA] * pr[P_ALPHA] + p2));
   }
+  // relative first-order change of the output Hc (the quantity the parity gate measures) in this step
+  pr[P_STEPN] = sqrt(dh2 / m2);
   pr[P_AP] = ap; pr[P_AD] = ad;
+  if (w.trace && ip[I_ITERS] >= 1 && ip[I_ITERS] <= TRACE_LEN) {
+    double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
+    t[0] = (double)ip[I_ITERS]; t[1] = (double)phase; t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
+    t[6] = ap; t[7] = ad; t[8] = pr[P_STEPN]; t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
+  }
   pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
   pr[P_TAU] += ad * dtau; pr[P_ALPHA] += ad * dalpha;
 }

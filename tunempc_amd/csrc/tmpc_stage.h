@@ -337,13 +337,26 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
       s2g_sym((r ? w.c2 : w.c1) + (size_t)sid * nn, t1, n, lane);
     }
   }
+  // first-order relative change of the output Hc_k = M_k/(s*alpha):  dM_k - (dalpha/alpha) M_k,  M_k = S1 + Rd1 + I
+  double dh2 = 0.0, m2 = 0.0;
+  {
+    const double ra = dalpha / pr[P_ALPHA];
+    const double* S1g = w.S1 + (size_t)sid * nn; const double* R1g = w.Rd1 + (size_t)sid * nn;
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const double m = S1g[e] + R1g[e] + (i == j ? 1.0 : 0.0);
+      const double dh = sM[i * LD + j] - ra * m;
+      dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
+    }
+    dh2 = wave_sum(dh2); m2 = wave_sum(m2);
+  }
   double dp2 = 0.0, p2 = 0.0;
   const double* Pk = w.P + (size_t)sid * nxx;
   for (int e = lane; e < nxx; e += 64) { dp2 = fma(dPk[e], dPk[e], dp2); p2 = fma(Pk[e], Pk[e], p2); }
   dxs = wave_sum(dxs); xds = wave_sum(xds); dxds = wave_sum(dxds); dp2 = wave_sum(dp2); p2 = wave_sum(p2);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
-    q[Q_MINX] = minx; q[Q_MINS] = mins; q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2;
+    q[Q_MINX] = minx; q[Q_MINS] = mins; q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2; q[Q_DH2] = dh2; q[Q_M2] = m2;
   }
 }
 
