@@ -78,6 +78,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
   w.dS1 = c.take<double>(BP * nn); w.dS2 = c.take<double>(BP * nn); w.dX1 = c.take<double>(BP * nn); w.dX2 = c.take<double>(BP * nn);
   w.c1 = c.take<double>(BP * nn); w.c2 = c.take<double>(BP * nn);
   w.dP = c.take<double>(BP * nxx);
+  w.Wm = c.take<double>(BP * 4 * nn); w.eigmin = c.take<double>(BP * 4);
   w.KF = c.take<double>(BP * 12 * nxx); w.adjV = c.take<double>(BP * NADJ * nxx); w.adjE = c.take<double>(BP * NADJ * nxx);
   w.part = c.take<double>(BP * NPART); w.prob = c.take<double>((size_t)dm.B * PS); w.iprob = c.take<int>((size_t)dm.B * IS);
   w.D = c.take<double>(BP * bs); w.O = c.take<double>(BP * bs); w.F = c.take<double>(BP * bs);
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) k_debug_solve(WS w, Dims dm) {
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
 static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
-static size_t solve_lds(const Dims& dm) { return (size_t)(3 * dm.dp * 3 + TB * 3 + 8 + 8) * sizeof(double); }
+static size_t solve_lds(const Dims& dm) { return (size_t)solve_lds_doubles(dm.dp) * sizeof(double); }
 
 static int set_lds_attrs() {
   static bool done = false;
@@ -224,6 +225,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
+      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 64) * sizeof(double), st, w, dm, pass);
       if (pass == 1) {
         hipLaunchKernelGGL(k_ctrl_b, dim3(nb), dim3(64), 0, st, w, dm);
         if (prof) HIPCHK(hipEventRecord(h->ev[4], st));

@@ -71,6 +71,8 @@ struct WS {
   double* Rd1; double* Rd2; double* T1; double* T2;
   double* dS1; double* dS2; double* dX1; double* dX2; double* c1; double* c2;
   double* dP;      // [B,p,nx,nx]
+  double* Wm;      // [B,p,4,n,n]  step-length matrices (S1, X1, S2, X2 order: 2r dual, 2r+1 primal)
+  double* eigmin;  // [B,p,4]      their smallest eigenvalues
   double* KF;      // [B,p,12,nx,nx]
   double* adjV;    // [B,p,3,nx,nx]
   double* adjE;    // [B,p,3,nx,nx]

@@ -230,163 +230,163 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
 }
 
 // ------------------------------------------------------------------ triangular solves with the block factor
-// vectors: [p][dp][NC] (NC interleaved right-hand sides) in global memory, solved in place.
+// Right-hand sides: [p][dp][NC] in global memory (NC interleaved), solved in place.  Inside the kernel the
+// active vectors live in LDS as [NCP][xld] (row q = right-hand side q).  All matrix-vector work runs through one
+// primitive, a skinny GEMM on the fp64 matrix cores:  Y[q][i] (+)= sgn * sum_c Mop[i][c] X[q][c], Mop = M or M',
+// with the 64 x 16 slabs of M staged through LDS from coalesced global loads (the factors are streamed from
+// HBM exactly once per product).
+constexpr int NCP = 4;      // rows of the LDS vectors (>= max NC = 3)
 
-// y[r0 + i] -= sum_c M[i][c] * x[c]   for i < rows, c < cols  (M row-major ldm); wave per row
-template <int NC>
-__device__ __forceinline__ void mv_sub(double* y, const double* M, int ldm, const double* x, int rows, int cols) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = wv; i < rows; i += 4) {
-    double acc[NC];
+template <bool TRANS>
+__device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, int xld, const double* M, int ldm,
+                                          int rows, int cols, bool accumulate, double sgn, double* As, int nc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nks = cols / GK;
+  for (int m0 = 0; m0 < rows; m0 += 64) {
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double ra[4];
+    // slab loader
+    const int lrow = TRANS ? (tid >> 4) : (tid >> 2);            // TRANS: k index (0..15) ; else row (0..63)
+    const int lcol = TRANS ? ((tid & 15) * 4) : ((tid & 3) * 4); // TRANS: first i ; else first k
+    const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
+    const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
+    const size_t kstep = TRANS ? (size_t)GK * ldm : (size_t)GK;
 #pragma unroll
-    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-    const double* mr = M + (size_t)i * ldm;
-    for (int c = lane; c < cols; c += 64) {
-      const double m = mr[c];
+    for (int q = 0; q < 4; ++q) ra[q] = ok ? src[q] : 0.0;
+    for (int ks = 0; ks < nks; ++ks) {
+      __syncthreads();
+      if (TRANS) {
 #pragma unroll
-      for (int q = 0; q < NC; ++q) acc[q] = fma(m, x[c * NC + q], acc[q]);
+        for (int q = 0; q < 4; ++q) As[(lcol + q) * GLD + lrow] = ra[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) As[lrow * GLD + lcol + q] = ra[q];
+      }
+      __syncthreads();
+      if (ks + 1 < nks) {
+        const double* s2 = src + (size_t)(ks + 1) * kstep;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = ok ? s2[q] : 0.0;
+      }
+      if (m0 + 16 * wv < rows) {
+        const int k0 = ks * GK;
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+          const double a = As[(16 * wv + fr) * GLD + kk * 4 + fk];
+          const double bq = X[(fr & (NCP - 1)) * xld + k0 + kk * 4 + fk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
+        }
+      }
     }
+    if (m0 + 16 * wv < rows && fr < nc) {
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
-      double v = acc[q];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) y[i * NC + q] -= v;
+      for (int r = 0; r < 4; ++r) {
+        const int i = m0 + 16 * wv + fk + 4 * r;
+        if (i < rows) {
+          double* yp = Y + fr * yld + i;
+          *yp = (accumulate ? *yp : 0.0) + sgn * acc[r];
+        }
+      }
     }
   }
-}
-// y[c] -= sum_i M[i][c] * x[i]   (transposed product); thread per column
-template <int NC>
-__device__ __forceinline__ void mtv_sub(double* y, const double* M, int ldm, const double* x, int rows, int cols) {
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    double acc[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-    for (int i = 0; i < rows; ++i) {
-      const double m = M[(size_t)i * ldm + c];
-#pragma unroll
-      for (int q = 0; q < NC; ++q) acc[q] = fma(m, x[i * NC + q], acc[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < NC; ++q) y[c * NC + q] -= acc[q];
-  }
+  __syncthreads();
 }
 
-// z <- L_k^-1 z   (z: dp x NC in LDS), using the inverted diagonal tiles
-template <int NC>
-__device__ __forceinline__ void blk_fwd(double* z, double* tmp, const double* Dk, const double* Lik, int dp) {
+// z <- L_k^-1 z   (z: LDS [NCP][xld]), using the inverted diagonal tiles
+__device__ __forceinline__ void blk_fwd(double* z, int xld, double* tmp, int tld, const double* Dk, const double* Lik, int dp,
+                                        double* As, int nc) {
   int jt = 0;
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     const double* Ti = Lik + (size_t)jt * TB * TB;
-    // tmp = Ti * z[j0..]
-    for (int e = threadIdx.x; e < nb * NC; e += 256) tmp[e] = 0.0;
-    __syncthreads();
-    {
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      for (int i = wv; i < nb; i += 4) {
-        double acc[NC];
-#pragma unroll
-        for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-        for (int c = lane; c <= i; c += 64) {
-          const double m = Ti[i * TB + c];
-#pragma unroll
-          for (int q = 0; q < NC; ++q) acc[q] = fma(m, z[(j0 + c) * NC + q], acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-          double v = acc[q];
-          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-          if (lane == 0) tmp[i * NC + q] = v;
-        }
-      }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < nb * NC; e += 256) z[j0 * NC + e] = tmp[e];
+    wg_gemv16<false>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
+    for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; z[q * xld + j0 + i] = tmp[q * tld + i]; }
     __syncthreads();
     const int rem = dp - j0 - nb;
-    if (rem > 0) mv_sub<NC>(z + (size_t)(j0 + nb) * NC, Dk + (size_t)(j0 + nb) * dp + j0, dp, z + (size_t)j0 * NC, rem, nb);
-    __syncthreads();
+    if (rem > 0) wg_gemv16<false>(z + j0 + nb, xld, z + j0, xld, Dk + (size_t)(j0 + nb) * dp + j0, dp, rem, nb, true, -1.0, As, nc);
   }
 }
 // z <- L_k^-T z
-template <int NC>
-__device__ __forceinline__ void blk_bwd(double* z, double* tmp, const double* Dk, const double* Lik, int dp) {
+__device__ __forceinline__ void blk_bwd(double* z, int xld, double* tmp, int tld, const double* Dk, const double* Lik, int dp,
+                                        double* As, int nc) {
   const int nt = (dp + TB - 1) / TB;
   for (int jt = nt - 1; jt >= 0; --jt) {
     const int j0 = jt * TB;
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     const double* Ti = Lik + (size_t)jt * TB * TB;
-    // tmp = Ti' * z[j0..]
-    for (int c = threadIdx.x; c < nb; c += 256) {
-      double acc[NC];
-#pragma unroll
-      for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-      for (int i = c; i < nb; ++i) {
-        const double m = Ti[i * TB + c];
-#pragma unroll
-        for (int q = 0; q < NC; ++q) acc[q] = fma(m, z[(j0 + i) * NC + q], acc[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < NC; ++q) tmp[c * NC + q] = acc[q];
-    }
+    wg_gemv16<true>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
+    for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; z[q * xld + j0 + i] = tmp[q * tld + i]; }
     __syncthreads();
-    for (int e = threadIdx.x; e < nb * NC; e += 256) z[j0 * NC + e] = tmp[e];
-    __syncthreads();
-    if (j0 > 0) mtv_sub<NC>(z, Dk + (size_t)j0 * dp, dp, z + (size_t)j0 * NC, nb, j0);
-    __syncthreads();
+    if (j0 > 0) wg_gemv16<true>(z, xld, z + j0, xld, Dk + (size_t)j0 * dp, dp, j0, nb, true, -1.0, As, nc);
   }
 }
+
+__device__ __forceinline__ void vec_g2s(double* z, int xld, const double* R, int dp, int nc) {
+  for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; z[q * xld + i] = R[e]; }
+}
+__device__ __forceinline__ void vec_s2g(double* R, const double* z, int xld, int dp, int nc) {
+  for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; R[e] = z[q * xld + i]; }
+}
+
+constexpr int solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLD + 16; }
 
 // Solve T x = r for NC interleaved right-hand sides stored at R [p][dp][NC] (in place).
 template <int NC>
 __device__ __forceinline__ void wg_cyclic_solve(double* R, const double* D, const double* O, const double* F,
                                                 const double* Li, int p, int dp, int nt, double* lds) {
   const size_t bs = (size_t)dp * dp, ls = (size_t)nt * TB * TB;
-  double* zc = lds;                   // current stage      dp*NC
-  double* zn = zc + dp * NC;          // next stage         dp*NC
-  double* zl = zn + dp * NC;          // last stage         dp*NC
-  double* tmp = zl + dp * NC;         // TB*NC
+  const int xld = dp + 4, tld = TB + 4;
+  double* zc = lds;                   // current stage
+  double* zn = zc + NCP * xld;        // next stage
+  double* zl = zn + NCP * xld;        // last stage
+  double* tmp = zl + NCP * xld;       // NCP x tld
+  double* As = tmp + NCP * tld;       // 64 x GLD slab
   const int tid = threadIdx.x, len = dp * NC;
+  for (int e = tid; e < 3 * NCP * xld + NCP * tld; e += 256) lds[e] = 0.0;
+  __syncthreads();
   if (p == 1) {
-    for (int e = tid; e < len; e += 256) zc[e] = R[e];
+    vec_g2s(zc, xld, R, dp, NC);
     __syncthreads();
-    blk_fwd<NC>(zc, tmp, D, Li, dp);
-    blk_bwd<NC>(zc, tmp, D, Li, dp);
-    for (int e = tid; e < len; e += 256) R[e] = zc[e];
+    blk_fwd(zc, xld, tmp, tld, D, Li, dp, As, NC);
+    blk_bwd(zc, xld, tmp, tld, D, Li, dp, As, NC);
+    vec_s2g(R, zc, xld, dp, NC);
     __syncthreads();
     return;
   }
   // ---- forward
-  for (int e = tid; e < len; e += 256) { zc[e] = R[e]; zl[e] = R[(size_t)(p - 1) * len + e]; }
+  vec_g2s(zc, xld, R, dp, NC);
+  vec_g2s(zl, xld, R + (size_t)(p - 1) * len, dp, NC);
   __syncthreads();
   for (int k = 0; k < p - 1; ++k) {
-    blk_fwd<NC>(zc, tmp, D + k * bs, Li + k * ls, dp);
-    for (int e = tid; e < len; e += 256) R[(size_t)k * len + e] = zc[e];
-    if (k + 1 < p - 1) { for (int e = tid; e < len; e += 256) zn[e] = R[(size_t)(k + 1) * len + e]; }
-    __syncthreads();
+    blk_fwd(zc, xld, tmp, tld, D + k * bs, Li + k * ls, dp, As, NC);
+    vec_s2g(R + (size_t)k * len, zc, xld, dp, NC);
     if (k + 1 < p - 1) {
-      mv_sub<NC>(zn, O + k * bs, dp, zc, dp, dp);
-      mv_sub<NC>(zl, F + k * bs, dp, zc, dp, dp);
+      vec_g2s(zn, xld, R + (size_t)(k + 1) * len, dp, NC);
+      __syncthreads();
+      wg_gemv16<false>(zn, xld, zc, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);
+      wg_gemv16<false>(zl, xld, zc, xld, F + k * bs, dp, dp, dp, true, -1.0, As, NC);
+      for (int e = tid; e < NCP * xld; e += 256) zc[e] = zn[e];
+      __syncthreads();
     } else {
-      mv_sub<NC>(zl, O + k * bs, dp, zc, dp, dp);      // k = p-2: O_k couples into the last block
+      __syncthreads();
+      wg_gemv16<false>(zl, xld, zc, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);   // k = p-2 couples into the last block
     }
-    __syncthreads();
-    if (k + 1 < p - 1) { for (int e = tid; e < len; e += 256) zc[e] = zn[e]; }
-    __syncthreads();
   }
-  blk_fwd<NC>(zl, tmp, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp);
+  blk_fwd(zl, xld, tmp, tld, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp, As, NC);
   // ---- backward
-  blk_bwd<NC>(zl, tmp, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp);
-  for (int e = tid; e < len; e += 256) { R[(size_t)(p - 1) * len + e] = zl[e]; zn[e] = zl[e]; }
+  blk_bwd(zl, xld, tmp, tld, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp, As, NC);
+  vec_s2g(R + (size_t)(p - 1) * len, zl, xld, dp, NC);
+  for (int e = tid; e < NCP * xld; e += 256) zn[e] = zl[e];
   __syncthreads();
   for (int k = p - 2; k >= 0; --k) {
-    for (int e = tid; e < len; e += 256) zc[e] = R[(size_t)k * len + e];
+    vec_g2s(zc, xld, R + (size_t)k * len, dp, NC);
     __syncthreads();
-    mtv_sub<NC>(zc, O + k * bs, dp, zn, dp, dp);          // O_k' x_{k+1}
-    __syncthreads();
-    if (k < p - 2) { mtv_sub<NC>(zc, F + k * bs, dp, zl, dp, dp); __syncthreads(); }
-    blk_bwd<NC>(zc, tmp, D + k * bs, Li + k * ls, dp);
-    for (int e = tid; e < len; e += 256) { R[(size_t)k * len + e] = zc[e]; zn[e] = zc[e]; }
+    wg_gemv16<true>(zc, xld, zn, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);          // O_k' x_{k+1}
+    if (k < p - 2) wg_gemv16<true>(zc, xld, zl, xld, F + k * bs, dp, dp, dp, true, -1.0, As, NC);
+    blk_bwd(zc, xld, tmp, tld, D + k * bs, Li + k * ls, dp, As, NC);
+    vec_s2g(R + (size_t)k * len, zc, xld, dp, NC);
+    for (int e = tid; e < NCP * xld; e += 256) zn[e] = zc[e];
     __syncthreads();
   }
 }
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
   double* Z = w.Z + (size_t)b * vl;
   double* TU = w.TU + (size_t)b * vl * 2;
   const double* U = w.U + (size_t)b * vl * 2;
-  double* red = lds + 3 * dp * 3 + TB * 3 + 8;
+  double* red = lds + solve_lds_doubles(dp) - 8;
   const bool have_rhs = (pass == 2) || (phase == PH_MAIN);
   if (pass == 1) {
     wg_cyclic_solve<3>(W3, D, O, F, Li, p, dp, nt, lds);

@@ -139,9 +139,13 @@ __device__ __forceinline__ double psum(const double* part, int b, int p, int idx
   for (int k = lane; k < p; k += 64) acc += part[(size_t)(b * p + k) * NPART + idx];
   return wave_sum(acc);
 }
-__device__ __forceinline__ double pmin(const double* part, int b, int p, int idx, int lane) {
+// min over stages of the smallest step-length eigenvalue; which = 0: dual (S1,S2), 1: primal (X1,X2)
+__device__ __forceinline__ double emin(const double* eigmin, int b, int p, int which, int lane) {
   double acc = 1e300;
-  for (int k = lane; k < p; k += 64) acc = fmin(acc, part[(size_t)(b * p + k) * NPART + idx]);
+  for (int k = lane; k < p; k += 64) {
+    const double* e = eigmin + (size_t)(b * p + k) * 4;
+    acc = fmin(acc, fmin(e[which], e[2 + which]));
+  }
   return wave_min(acc);
 }
 
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
   if (ip[I_PHASE] != PH_MAIN) return;
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p;
-  const double minx = pmin(w.part, b, p, Q_MINX, lane), mins = pmin(w.part, b, p, Q_MINS, lane);
+  const double minx = emin(w.eigmin, b, p, 1, lane), mins = emin(w.eigmin, b, p, 0, lane);
   const double dxs = psum(w.part, b, p, Q_DXS, lane), xds = psum(w.part, b, p, Q_XDS, lane);
   const double dxds = psum(w.part, b, p, Q_DXDS, lane);
   if (lane != 0) return;
@@ -255,7 +259,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
   if (phase == PH_DONE) return;
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p;
-  const double minx = pmin(w.part, b, p, Q_MINX, lane), mins = pmin(w.part, b, p, Q_MINS, lane);
+  const double minx = emin(w.eigmin, b, p, 1, lane), mins = emin(w.eigmin, b, p, 0, lane);
   const double dh2 = psum(w.part, b, p, Q_DH2, lane), m2 = psum(w.part, b, p, Q_M2, lane);
   if (lane != 0) return;
   const double s0 = pr[P_S0], x0 = pr[P_X0];

@@ -153,8 +153,12 @@ __device__ __forceinline__ void tri_inv_lower(double* __restrict__ Li, const dou
 }
 
 // Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and
-// leaves its eigenvalues on the diagonal.  cs: LDS scratch of >= 4*16 doubles.
-__device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int lane) {
+// leaves its eigenvalues on the diagonal.  cs: LDS scratch of >= 4*16 doubles.  One single-wave block works
+// on one matrix (the block barrier is then a wave-local barrier).
+// tol2: stop when off-diagonal mass <= tol2 * total mass (eigenvalue error ~ sqrt(tol2)*||A||, quadratically
+// better for separated eigenvalues).
+__device__ __forceinline__ void jacobi_impl(double* A, int n, double* cs, int lane, double tol2) {
+#define TMPC_JSYNC() wsync()
   const int m = (n + 1) & ~1;          // players (even)
   const int np = m >> 1;               // pairs per round
   if (n == 1) return;
@@ -167,7 +171,7 @@ __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int
       if (i == j) dia += v * v; else off += v * v;
     }
     off = wave_sum(off); dia = wave_sum(dia);
-    if (off <= 1e-31 * (dia + off) || (dia + off) == 0.0) break;
+    if (off <= tol2 * (dia + off) || (dia + off) == 0.0) break;
     for (int r = 0; r < m - 1; ++r) {
       if (lane < np) {
         const int t = lane;
@@ -188,7 +192,7 @@ __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int
         cs[4 * t + 0] = c; cs[4 * t + 1] = s;
         cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
       }
-      wsync();
+      TMPC_JSYNC();
       // columns: (A[i][p], A[i][q]) <- (c a_ip - s a_iq, s a_ip + c a_iq)
       for (int e = lane; e < np * 32; e += 64) {
         const int t = e >> 5, i = e & 31;
@@ -201,7 +205,7 @@ __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int
           A[i * LD + q] = s * aip + c * aiq;
         }
       }
-      wsync();
+      TMPC_JSYNC();
       // rows
       for (int e = lane; e < np * 32; e += 64) {
         const int t = e >> 5, j = e & 31;
@@ -214,11 +218,13 @@ __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int
           A[q * LD + j] = s * apj + c * aqj;
         }
       }
-      wsync();
+      TMPC_JSYNC();
     }
   }
-  wsync();
+  TMPC_JSYNC();
+#undef TMPC_JSYNC
 }
+__device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int lane) { jacobi_impl(A, n, cs, lane, 1e-31); }
 
 // min / max of the diagonal after jacobi_eigvals (wave-uniform result)
 __device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, double* mn, double* mx) {

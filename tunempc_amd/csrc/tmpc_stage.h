@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
   }
 }
 
-constexpr int DIR_SLOTS = 11;
+constexpr int DIR_SLOTS = 10;
 // ------------------------------------------------------------------ stage_dir: dS, dX, step-length eigenvalues, corrector term
 __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
@@ -279,13 +279,13 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
   double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sSi = sm + 3 * MS;
   double* sDS = sm + 4 * MS; double* sDX = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
-  double* sHb = sm + 8 * MS; double* sL = sm + 9 * MS; double* cs = sm + 10 * MS;
+  double* sHb = sm + 8 * MS; double* sL = sm + 9 * MS;
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   const double* dPk = w.dP + (size_t)sid * nxx;
   build_M(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
-  double dxs = 0.0, xds = 0.0, dxds = 0.0, minx = 1e300, mins = 1e300;
+  double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
@@ -317,20 +317,16 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
       dxs = fma(dx, Sg[e], dxs); xds = fma(sX[i * LD + j], ds, xds); dxds = fma(dx, ds, dxds);
     }
     wsync();
-    // dual step length: lambda_min( L^-1 dS L^-T )
+    // step-length matrices  W_S = L^-1 dS L^-T  and  W_X = LX^-1 dX LX^-T ; their smallest eigenvalues are
+    // computed by k_eigmin (one wave per matrix, 16 waves per CU) -- slots 2r (dual) and 2r+1 (primal)
     g2s(sL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
     mm(t0, sL, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
     mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
-    s_sym(t1, n, lane);
-    jacobi_eigvals(t1, n, cs, lane);
-    { double lo, hi; diag_minmax(t1, n, lane, &lo, &hi); mins = fmin(mins, lo); }
-    // primal step length: lambda_min( LX^-1 dX LX^-T )
+    s2g_sym(w.Wm + ((size_t)sid * 4 + 2 * r) * nn, t1, n, lane);
     g2s(sL, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
     mm(t0, sL, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
     mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
-    s_sym(t1, n, lane);
-    jacobi_eigvals(t1, n, cs, lane);
-    { double lo, hi; diag_minmax(t1, n, lane, &lo, &hi); minx = fmin(minx, lo); }
+    s2g_sym(w.Wm + ((size_t)sid * 4 + 2 * r + 1) * nn, t1, n, lane);
     if (pass == 1) {   // Mehrotra second-order term  sym(dX dS S^-1)
       mm(t0, sDX, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
       mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
@@ -356,8 +352,30 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   dxs = wave_sum(dxs); xds = wave_sum(xds); dxds = wave_sum(dxds); dp2 = wave_sum(dp2); p2 = wave_sum(p2);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
-    q[Q_MINX] = minx; q[Q_MINS] = mins; q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2; q[Q_DH2] = dh2; q[Q_M2] = m2;
+    q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2; q[Q_DH2] = dh2; q[Q_M2] = m2;
   }
+}
+
+// ------------------------------------------------------------------ smallest eigenvalue of one step-length matrix
+// one single-wave block per matrix (4 per stage): 8.9 KB of LDS each -> ~17 blocks (waves) resident per CU
+__global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
+  const int mid = blockIdx.x;              // (b*p + k)*4 + which
+  const int b = (mid >> 2) / dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x, n = dm.n;
+  double* A = sm;
+  double* cs = A + MS;
+  const double* Wg = w.Wm + (size_t)mid * n * n;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = Wg[e]; }
+  wsync();
+  jacobi_impl(A, n, cs, lane, 1e-18);
+  double lo = 1e300;
+  if (lane < n) lo = A[lane * LD + lane];
+  lo = wave_min(lo);
+  if (lane == 0) w.eigmin[mid] = lo;
 }
 
 // ------------------------------------------------------------------ update: X += ap dX, S += ad dS, P += ad dP
