@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
-    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve',
+    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -68,6 +68,8 @@ def load_library():
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
     lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
+    lib.tmpc_debug_factor_bench.restype = C.c_int
+    lib.tmpc_debug_factor_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     lib.tmpc_last_error.restype = C.c_char_p
     lib.tmpc_version.restype = C.c_char_p
     _LIB = lib
@@ -192,6 +194,11 @@ class HipConvexifier:
         M, N = Cm.shape; K = A.shape[1]
         _check(self.lib, self.lib.tmpc_debug_gemm_nt(self._h, _dptr(Cm), _dptr(A), _dptr(B), M, N, K, int(mode), int(lower)), 'tmpc_debug_gemm_nt')
         return Cm
+
+    def debug_factor_bench(self, nb, p, d, reps=3):
+        out = np.zeros(2)
+        _check(self.lib, self.lib.tmpc_debug_factor_bench(self._h, nb, p, d, reps, _dptr(out)), 'tmpc_debug_factor_bench')
+        return out
 
     def debug_block_solve(self, D, Ccpl, rhs):
         D = np.ascontiguousarray(D, dtype=np.float64); Ccpl = np.ascontiguousarray(Ccpl, dtype=np.float64)

@@ -179,8 +179,9 @@ static int set_lds_attrs() {
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_final_stage, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -217,8 +218,8 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
     if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
-    if (dm.flags & 1) hipLaunchKernelGGL(k_factor<false>, dim3(nb), dim3(256), factor_lds(), st, w, dm);
-    else hipLaunchKernelGGL(k_factor<true>, dim3(nb), dim3(256), factor_lds(), st, w, dm);
+    if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
+    else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
@@ -453,6 +454,71 @@ int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double*
   return TMPC_OK;
 }
 
+// Isolated timing of k_factor (variant A/B): nb copies of one random SPD block-cyclic-tridiagonal system.
+// ms_out[v] = average kernel time of variant v over `reps` launches (inputs restored before every launch).
+int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, double* ms_out2) {
+  if (!h || nb < 1 || p < 2 || d < 1 || reps < 1 || !ms_out2) return TMPC_E_ARG;
+  Dims dm; memset(&dm, 0, sizeof(dm));
+  dm.B = nb; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB;
+  const int dp = dm.dp;
+  const size_t bs = (size_t)dp * dp, per = (size_t)p * bs;
+  std::vector<double> hD(per, 0.0), hO(per, 0.0), hF(per, 0.0), hdd((size_t)p * dp, 1.0);
+  // T = sum_k J_k' J_k + I  with J_k = [E_k F_k] on blocks (k, k+1): SPD by construction
+  std::vector<double> E((size_t)p * d * d), G((size_t)p * d * d);
+  unsigned long long st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((double)(st % 2000001) / 1000000.0 - 1.0) / sqrt((double)d); };
+  for (auto& x : E) x = rnd();
+  for (auto& x : G) x = rnd();
+  for (int k = 0; k < p; ++k)
+    for (int i = 0; i < dp; ++i) hD[k * bs + (size_t)i * dp + i] = 1.0;
+  for (int k = 0; k < p; ++k) {
+    const int kn = (k + 1) % p;
+    const double* Ek = &E[(size_t)k * d * d]; const double* Gk = &G[(size_t)k * d * d];
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) {
+        double ee = 0, gg = 0, eg = 0;
+        for (int r = 0; r < d; ++r) { ee += Ek[r * d + i] * Ek[r * d + j]; gg += Gk[r * d + i] * Gk[r * d + j]; eg += Ek[r * d + i] * Gk[r * d + j]; }
+        hD[k * bs + (size_t)i * dp + j] += ee; hD[kn * bs + (size_t)i * dp + j] += gg;
+        if (k == p - 1) hF[(size_t)i * dp + j] = eg; else hO[k * bs + (size_t)j * dp + i] = eg;
+      }
+  }
+  for (int k = 0; k < p; ++k) for (int i = 0; i < dp; ++i) hdd[(size_t)k * dp + i] = hD[k * bs + (size_t)i * dp + i];
+  WS w; memset(&w, 0, sizeof(w));
+  double *pD, *pO, *pF;
+  HIPCHK(hipMalloc(&pD, per * 8)); HIPCHK(hipMalloc(&pO, per * 8)); HIPCHK(hipMalloc(&pF, per * 8));
+  HIPCHK(hipMalloc(&w.D, nb * per * 8)); HIPCHK(hipMalloc(&w.O, nb * per * 8)); HIPCHK(hipMalloc(&w.F, nb * per * 8));
+  HIPCHK(hipMalloc(&w.Linv, (size_t)nb * p * dm.nt * TB * TB * 8)); HIPCHK(hipMalloc(&w.Ddiag, (size_t)nb * p * dp * 8));
+  HIPCHK(hipMalloc(&w.iprob, (size_t)nb * IS * sizeof(int)));
+  HIPCHK(hipMemset(w.iprob, 0, (size_t)nb * IS * sizeof(int)));
+  HIPCHK(hipMemcpy(pD, hD.data(), per * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(pO, hO.data(), per * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(pF, hF.data(), per * 8, hipMemcpyHostToDevice));
+  for (int b = 0; b < nb; ++b) HIPCHK(hipMemcpy(w.Ddiag + (size_t)b * p * dp, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int v = 0; v < 2; ++v) ms_out2[v] = 0.0;
+  for (int r = 0; r < reps + 1; ++r) {
+    for (int v = 0; v < 2; ++v) {
+      for (int b = 0; b < nb; ++b) {
+        HIPCHK(hipMemcpyAsync(w.D + b * per, pD, per * 8, hipMemcpyDeviceToDevice, 0));
+        HIPCHK(hipMemcpyAsync(w.O + b * per, pO, per * 8, hipMemcpyDeviceToDevice, 0));
+        HIPCHK(hipMemcpyAsync(w.F + b * per, pF, per * 8, hipMemcpyDeviceToDevice, 0));
+      }
+      HIPCHK(hipEventRecord(e0, 0));
+      if (v == 0) hipLaunchKernelGGL((k_factor<true, 0>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
+      else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
+      HIPCHK(hipEventRecord(e1, 0));
+      HIPCHK(hipEventSynchronize(e1));
+      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) ms_out2[v] += ms / reps;
+    }
+  }
+  int nsh = 0; HIPCHK(hipMemcpy(&nsh, w.iprob + I_NSHIFT, sizeof(int), hipMemcpyDeviceToHost));
+  if (nsh) { snprintf(g_err, sizeof(g_err), "factor bench: %d shifted pivots", nsh); }
+  hipFree(pD); hipFree(pO); hipFree(pF); hipFree(w.D); hipFree(w.O); hipFree(w.F); hipFree(w.Linv); hipFree(w.Ddiag); hipFree(w.iprob);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return TMPC_OK;
+}
+
 // Factor + solve one block-cyclic-tridiagonal system given dense blocks (unit test of k_factor / wg_cyclic_solve):
 // D [p][d][d] diagonal blocks, Ccpl [p][d][d] with Ccpl[k] = T[block k, block k+1 mod p], rhs/x [p][d].
 int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift) {
@@ -483,8 +549,8 @@ int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const 
   HIPCHK(hipMemcpy(w.Ddiag, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(w.Z, hz.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(w.iprob, hip_, sizeof(hip_), hipMemcpyHostToDevice));
-  if (dm.flags & 1) hipLaunchKernelGGL(k_factor<false>, dim3(1), dim3(256), factor_lds(), 0, w, dm);
-  else hipLaunchKernelGGL(k_factor<true>, dim3(1), dim3(256), factor_lds(), 0, w, dm);
+  if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(1), dim3(256), factor_lds(), 0, w, dm);
+  else hipLaunchKernelGGL((k_factor<true, 1>), dim3(1), dim3(256), factor_lds(), 0, w, dm);
   hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(256), solve_lds(dm), 0, w, dm);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(hz.data(), w.Z, (size_t)p * dp * 8, hipMemcpyDeviceToHost));

@@ -16,26 +16,187 @@ namespace tmpc {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GK = 16;             // K slab staged in LDS per step
-constexpr int GLD = GK + 1;        // LDS leading dim (doubles) of the A/B slabs
-constexpr int FACT_LDS_DOUBLES = 64 * 65 + 64 * 65 + 64 + 8;   // potrf tile + inverse + diag ref (+counter); the GEMM slabs (2*64*GLD) alias the front
+constexpr int GK = 32;             // K slab staged in LDS per step
+constexpr int GLD = GK + 2;        // LDS leading dim (doubles) of the A/B slabs: (2r + k) mod 32 is conflict-free for the MFMA fragment reads
+constexpr int FACT_LDS_DOUBLES = 4 * 2 * 64 * 17 + 64;   // two (A,B) slab pairs; the potrf tile + inverse + diag ref (2*64*65+72) alias the front
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
 
 // C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
+// Workgroup tile 64 x 64 (each wave a 32 x 32 quadrant = 2 x 2 MFMA tiles).  The K slabs (GK = 32 columns) of ALL
+// tiles of the call form one software-pipelined stream: while the 32 MFMAs of slab s run, the global loads of
+// slab s+1 -- possibly the first slab of the NEXT tile -- are in flight and land in the other LDS buffer; the C
+// fragment of a read-modify-write tile is prefetched at the tile's first slab.  One barrier per slab, and only
+// one exposed memory latency per call instead of two per tile.
 // lower: skip 64x64 tiles strictly above the block diagonal (SYRK-style update of a symmetric block).
-// In-place use (C aliasing A with K == N-tile width) is safe: a C tile is stored only after all of its
-// A slabs have been loaded.
+// In-place use (C aliasing A with one N-tile and K == its width) is safe: a tile's A slabs are all in LDS before
+// its C fragment is stored, and the next tile reads other rows.
+constexpr int SLD = 17, SUBD = 64 * SLD, SLABD = 2 * SUBD;   // sub-slab leading dim / doubles per sub-slab / per (operand) slab
+typedef const double __attribute__((address_space(1)))* gcptr;
+typedef double __attribute__((address_space(1)))* gptr;
 template <bool USE_MFMA>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
                                            double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;
+  // slab loader: row (0..63); each thread moves two 32-byte pieces, k = lk..lk+3 and 16+lk..16+lk+3, into two
+  // 16-column sub-slabs of leading dimension 17 (the low-conflict layout of the single-buffered baseline)
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;
+  const int nks = (K + GK - 1) / GK;
+  const int fr = lane & 15, fk = lane >> 4;
+  double4_t acc[2][2], cpre[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; cpre[i][j] = acc[i][j]; }
+  double ra[8], rb[8];
+  int m0 = 0, n0 = 0, ks = 0;            // current slab
+  // ---- prologue: first slab -> LDS buffer 0
+  {
+    gcptr ap = (gcptr)(A + (size_t)lrow * lda + lk);
+    gcptr bp = (gcptr)(B + (size_t)lrow * ldb + lk);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const bool kok = (h2 * 16 + lk) < K;
+      const bool aok = (lrow < M) && kok, bok = (lrow < N) && kok;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 16 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 16 + q] : 0.0; }
+    }
+    __syncthreads();                       // LDS free (previous user)
+    double* As = lds; double* Bs = lds + SLABD;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { As[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bs[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
+    __syncthreads();
+  }
+  int buf = 0;
+  while (m0 < M) {
+    // ---- next slab of the stream
+    int nm0 = m0, nn0 = n0, nks_ = ks + 1;
+    if (nks_ == nks) {
+      nks_ = 0; nn0 = n0 + 64;
+      if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + 64; }
+    }
+    const bool more = nm0 < M;
+    if (more) {
+      const int kn = nks_ * GK + lk;
+      gcptr ap = (gcptr)(A + (size_t)(nm0 + lrow) * lda + kn);
+      gcptr bp = (gcptr)(B + (size_t)(nn0 + lrow) * ldb + kn);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const bool kok = (kn + h2 * 16) < K;
+        const bool aok = (nm0 + lrow < M) && kok, bok = (nn0 + lrow < N) && kok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 16 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 16 + q] : 0.0; }
+      }
+    }
+    if (ks == 0 && mode == GM_SUB) {       // prefetch the C fragment of this tile
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wr * 32 + i * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wc * 32 + j * 16;
+          if (rbase < M && cbase < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cpre[i][j][r] = ((gcptr)C)[(size_t)(rbase + fk + 4 * r) * ldc + cbase + fr];
+          }
+        }
+      }
+    }
+    // ---- compute current slab
+    {
+      const double* As = lds + buf * (2 * SLABD);
+      const double* Bs = As + SLABD;
+      const int krem = K - ks * GK;
+      if (USE_MFMA) {
+#define TMPC_MFMA_STEP(kk)                                                                  \
+  {                                                                                         \
+    const int so = ((kk) >> 2) * SUBD + ((kk) & 3) * 4 + fk;                                \
+    const double a0 = As[so + (wr * 32 + fr) * SLD];                                        \
+    const double a1 = As[so + (wr * 32 + 16 + fr) * SLD];                                   \
+    const double b0 = Bs[so + (wc * 32 + fr) * SLD];                                        \
+    const double b1 = Bs[so + (wc * 32 + 16 + fr) * SLD];                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);           \
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);           \
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);           \
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);           \
+  }
+        if (krem >= GK) {
+#pragma unroll
+          for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+        }
+#undef TMPC_MFMA_STEP
+      } else {   // debug path: same fragment ownership, scalar FMAs
+        const int kmax = (krem >= GK) ? GK : krem;
+        for (int kk = 0; kk < kmax; ++kk) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = wr * 32 + i * 16 + fk + 4 * r, col = wc * 32 + j * 16 + fr;
+                acc[i][j][r] = fma(As[(kk >> 4) * SUBD + row * SLD + (kk & 15)], Bs[(kk >> 4) * SUBD + col * SLD + (kk & 15)], acc[i][j][r]);
+              }
+        }
+      }
+    }
+    // ---- stage the next slab into the other buffer
+    if (more) {
+      double* An = lds + (buf ^ 1) * (2 * SLABD);
+      double* Bn = An + SLABD;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { An[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
+    }
+    // ---- tile finished: store its C fragment (reg r -> row (lane>>4) + 4r, col lane&15)
+    if (ks == nks - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wr * 32 + i * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wc * 32 + j * 16;
+          if (rbase < M && cbase < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              gptr cp = (gptr)C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;
+              const double v = acc[i][j][r];
+              if (mode == GM_SUB) *cp = cpre[i][j][r] - v; else if (mode == GM_SET) *cp = v; else *cp = -v;
+            }
+          }
+          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+    m0 = nm0; n0 = nn0; ks = nks_;
+  }
+}
+
+constexpr int GK0 = 16, GLD0 = 17;   // variant 0: single-buffered 16-column slabs, two barriers per slab (round-1 baseline)
+// C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
+// lower: skip 64x64 tiles strictly above the block diagonal (SYRK-style update of a symmetric block).
+// In-place use (C aliasing A with K == N-tile width) is safe: a C tile is stored only after all of its
+// A slabs have been loaded.
+template <bool USE_MFMA>
+__device__ __forceinline__ void wg_gemm_nt_v0(double* C, int ldc, const double* A, int lda,
+                                           const double* B, int ldb, int M, int N, int K, int mode, bool lower,
+                                           double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
   double* As = lds;
-  double* Bs = lds + 64 * GLD;
+  double* Bs = lds + 64 * GLD0;
   const int lrow = tid >> 2, lk = (tid & 3) * 4;     // slab loader: row, first k
-  const int nks = K / GK;
+  const int nks = K / GK0;
   for (int m0 = 0; m0 < M; m0 += 64) {
     for (int n0 = 0; n0 < N; n0 += 64) {
       if (lower && n0 > m0) continue;
@@ -53,22 +214,22 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       for (int ks = 0; ks < nks; ++ks) {
         __syncthreads();                     // previous slab fully consumed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { As[lrow * GLD + lk + q] = ra[q]; Bs[lrow * GLD + lk + q] = rb[q]; }
+        for (int q = 0; q < 4; ++q) { As[lrow * GLD0 + lk + q] = ra[q]; Bs[lrow * GLD0 + lk + q] = rb[q]; }
         __syncthreads();
         if (ks + 1 < nks) {
-          const double* ap2 = ap + (size_t)(ks + 1) * GK;
-          const double* bp2 = bp + (size_t)(ks + 1) * GK;
+          const double* ap2 = ap + (size_t)(ks + 1) * GK0;
+          const double* bp2 = bp + (size_t)(ks + 1) * GK0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) { ra[q] = arow_ok ? ap2[q] : 0.0; rb[q] = brow_ok ? bp2[q] : 0.0; }
         }
         const int fr = lane & 15, fk = lane >> 4;
         if (USE_MFMA) {
 #pragma unroll
-          for (int kk = 0; kk < GK / 4; ++kk) {
-            const double a0 = As[(wr * 32 + fr) * GLD + kk * 4 + fk];
-            const double a1 = As[(wr * 32 + 16 + fr) * GLD + kk * 4 + fk];
-            const double b0 = Bs[(wc * 32 + fr) * GLD + kk * 4 + fk];
-            const double b1 = Bs[(wc * 32 + 16 + fr) * GLD + kk * 4 + fk];
+          for (int kk = 0; kk < GK0 / 4; ++kk) {
+            const double a0 = As[(wr * 32 + fr) * GLD0 + kk * 4 + fk];
+            const double a1 = As[(wr * 32 + 16 + fr) * GLD0 + kk * 4 + fk];
+            const double b0 = Bs[(wc * 32 + fr) * GLD0 + kk * 4 + fk];
+            const double b1 = Bs[(wc * 32 + 16 + fr) * GLD0 + kk * 4 + fk];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
@@ -83,7 +244,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
               for (int r = 0; r < 4; ++r) {
                 const int row = wr * 32 + i * 16 + fk + 4 * r, col = wc * 32 + j * 16 + fr;
                 double s = acc[i][j][r];
-                for (int kk = 0; kk < GK; ++kk) s = fma(As[row * GLD + kk], Bs[col * GLD + kk], s);
+                for (int kk = 0; kk < GK0; ++kk) s = fma(As[row * GLD0 + kk], Bs[col * GLD0 + kk], s);
                 acc[i][j][r] = s;
               }
         }
@@ -109,6 +270,14 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     }
   }
   __syncthreads();
+}
+
+
+template <bool USE_MFMA, int VAR>
+__device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N,
+                                        int K, int mode, bool lower, double* lds) {
+  if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
+  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
@@ -165,7 +334,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
 
 // Left-looking blocked Cholesky of the block column headed by Dk, applied also to the rows of R1 (and R2):
 //   Dk = L L' ;  R1 <- R1 L^-T ;  R2 <- R2 L^-T        (R1/R2 may be null)
-template <bool USE_MFMA>
+template <bool USE_MFMA, int VAR>
 __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R2, double* Linv_k, const double* dref,
                                                int dp, double* lds) {
   int nbad = 0;
@@ -173,22 +342,22 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     if (j0 > 0) {
-      wg_gemm_nt<USE_MFMA>(Dk + (size_t)j0 * dp + j0, dp, Dk + (size_t)j0 * dp, dp, Dk + (size_t)j0 * dp, dp, dp - j0, nb, j0, GM_SUB, false, lds);
-      if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
-      if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)j0 * dp + j0, dp, Dk + (size_t)j0 * dp, dp, Dk + (size_t)j0 * dp, dp, dp - j0, nb, j0, GM_SUB, false, lds);
+      if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+      if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
     double* Ti = Linv_k + (size_t)jt * TB * TB;
     nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
-      wg_gemm_nt<USE_MFMA>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
-    if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
-    if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
+    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
   }
   return nbad;
 }
 
-template <bool USE_MFMA>
+template <bool USE_MFMA, int VAR>
 __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
   const int b = blockIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
@@ -207,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
     // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'   (C stored in F[0])
     for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += F[e] + F[(size_t)j * dp + i]; }
     __syncthreads();
-    nbad += wg_block_column<USE_MFMA>(D, nullptr, nullptr, Li, dref, dp, lds);
+    nbad += wg_block_column<USE_MFMA, VAR>(D, nullptr, nullptr, Li, dref, dp, lds);
   } else {
     for (int k = 0; k < p - 1; ++k) {
       double* Dk = D + k * bs; double* Ok = O + k * bs; double* Fk = F + k * bs;
@@ -216,15 +385,15 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
         for (int e = tid; e < dp * dp; e += 256) Ok[e] += Fk[e];
         __syncthreads();
       }
-      nbad += wg_block_column<USE_MFMA>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
+      nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
       // Schur updates
-      wg_gemm_nt<USE_MFMA>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+      wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
       if (!last) {
-        wg_gemm_nt<USE_MFMA>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-        wg_gemm_nt<USE_MFMA>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+        wg_gemm<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+        wg_gemm<USE_MFMA, VAR>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
       }
     }
-    nbad += wg_block_column<USE_MFMA>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds);
+    nbad += wg_block_column<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds);
   }
   if (tid == 0 && nbad) ip[I_NSHIFT] += nbad;
 }
@@ -236,13 +405,14 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
 // with the 64 x 16 slabs of M staged through LDS from coalesced global loads (the factors are streamed from
 // HBM exactly once per product).
 constexpr int NCP = 4;      // rows of the LDS vectors (>= max NC = 3)
+constexpr int GKV = 16, GLDV = GKV + 1;   // K slab of the skinny GEMM
 
 template <bool TRANS>
 __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, int xld, const double* M, int ldm,
                                           int rows, int cols, bool accumulate, double sgn, double* As, int nc) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  const int nks = cols / GK;
+  const int nks = cols / GKV;
   for (int m0 = 0; m0 < rows; m0 += 64) {
     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
     double ra[4];
@@ -251,17 +421,17 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     const int lcol = TRANS ? ((tid & 15) * 4) : ((tid & 3) * 4); // TRANS: first i ; else first k
     const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
     const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
-    const size_t kstep = TRANS ? (size_t)GK * ldm : (size_t)GK;
+    const size_t kstep = TRANS ? (size_t)GKV * ldm : (size_t)GKV;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ra[q] = ok ? src[q] : 0.0;
     for (int ks = 0; ks < nks; ++ks) {
       __syncthreads();
       if (TRANS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) As[(lcol + q) * GLD + lrow] = ra[q];
+        for (int q = 0; q < 4; ++q) As[(lcol + q) * GLDV + lrow] = ra[q];
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) As[lrow * GLD + lcol + q] = ra[q];
+        for (int q = 0; q < 4; ++q) As[lrow * GLDV + lcol + q] = ra[q];
       }
       __syncthreads();
       if (ks + 1 < nks) {
@@ -270,10 +440,10 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
         for (int q = 0; q < 4; ++q) ra[q] = ok ? s2[q] : 0.0;
       }
       if (m0 + 16 * wv < rows) {
-        const int k0 = ks * GK;
+        const int k0 = ks * GKV;
 #pragma unroll
-        for (int kk = 0; kk < GK / 4; ++kk) {
-          const double a = As[(16 * wv + fr) * GLD + kk * 4 + fk];
+        for (int kk = 0; kk < GKV / 4; ++kk) {
+          const double a = As[(16 * wv + fr) * GLDV + kk * 4 + fk];
           const double bq = X[(fr & (NCP - 1)) * xld + k0 + kk * 4 + fk];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
         }
@@ -329,7 +499,7 @@ __device__ __forceinline__ void vec_s2g(double* R, const double* z, int xld, int
   for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; R[e] = z[q * xld + i]; }
 }
 
-constexpr int solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLD + 16; }
+constexpr int solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
 
 // Solve T x = r for NC interleaved right-hand sides stored at R [p][dp][NC] (in place).
 template <int NC>
@@ -341,7 +511,7 @@ __device__ __forceinline__ void wg_cyclic_solve(double* R, const double* D, cons
   double* zn = zc + NCP * xld;        // next stage
   double* zl = zn + NCP * xld;        // last stage
   double* tmp = zl + NCP * xld;       // NCP x tld
-  double* As = tmp + NCP * tld;       // 64 x GLD slab
+  double* As = tmp + NCP * tld;       // 64 x GLDV slab
   const int tid = threadIdx.x, len = dp * NC;
   for (int e = tid; e < 3 * NCP * xld + NCP * tld; e += 256) lds[e] = 0.0;
   __syncthreads();
