@@ -279,14 +279,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
     I = np.eye(n)
     N = 2 * p * n + 1
     # ---- initial point (infeasible start)
-    tau = 2.0 * sbeta
-    alpha = 1.0
+    # everything O(1) from the start: alpha*Hb has eigenvalues in [-1, 1], S2 = tau*I - alpha*Hb in [1, 3]
+    tau = 2.0
+    alpha = 1.0 / sbeta
     P = np.zeros((p, nx, nx))
-    S1 = np.broadcast_to(sbeta * I, (p, n, n)).copy()
-    S2 = tau * I - Hb                                  # feasible: eig(Hb) <= sbeta
+    S1 = np.broadcast_to(I, (p, n, n)).copy()
+    S2 = tau * I - alpha * Hb
     X1 = np.broadcast_to(I / (p * n), (p, n, n)).copy()
     X2 = X1.copy()
-    s0 = 1.0
+    s0 = alpha
     x0 = 1.0 / (p * n)
     mu_t = None
     phase = 0
@@ -420,7 +421,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation
             # at the rounding floor, or on the iteration cap
             full = (ap == 1.0 and ad == 1.0)
-            if full and stepn < o['center_tol']:
+            # extrapolated next step (contraction factor of the last two full steps): stop one iteration early
+            # when Newton is already converging super-linearly
+            est = stepn * min(1.0, stepn / prev_stepn) if prev_stepn is not None else stepn
+            if full and (stepn < o['center_tol'] or est < 0.1 * o['center_tol']):
                 status = 'optimal'
                 break
             if full and prev_stepn is not None and stepn > 0.5 * prev_stepn and stepn < 1e-6:

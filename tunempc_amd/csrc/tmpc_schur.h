@@ -11,14 +11,15 @@
 
 namespace tmpc {
 
-// 0.5*(T(Lx,Ls)+T(Ls,Lx)) [(ab),(cd)],   T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>
+// HKM block entry 0.5*(T(Lx,Ls)+T(Ls,Lx))[(ab),(cd)] with T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>; the two T's
+// consist of the same four products, so the entry is T(Lx,Ls)[(ab),(cd)].
 __device__ __forceinline__ double hkm_entry(const double* __restrict__ Lx, const double* __restrict__ Ls, int ldk,
                                             int a, int b, int c, int d_) {
   const double xac = Lx[a * ldk + c], xad = Lx[a * ldk + d_], xbc = Lx[b * ldk + c], xbd = Lx[b * ldk + d_];
   const double sac = Ls[a * ldk + c], sad = Ls[a * ldk + d_], sbc = Ls[b * ldk + c], sbd = Ls[b * ldk + d_];
-  const double t = (xac * sbd + xad * sbc + xbc * sad + xbd * sac) + (sac * xbd + sad * xbc + sbc * xad + sbd * xac);
+  const double t = (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
   const double wr = (a == b) ? 0.5 : 1.0, wc = (c == d_) ? 0.5 : 1.0;
-  return 0.5 * wr * wc * t;
+  return wr * wc * t;
 }
 
 // One 256-thread workgroup per (problem, stage): D_k, and the coupling block C_k = T[P_k, P_{k+1}]
@@ -297,7 +298,8 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
   if (ip[I_PHASE] == PH_CENTER) {
     const bool full = (pr[P_AP] == 1.0 && pr[P_AD] == 1.0);
     const double stepn = pr[P_STEPN], prev = pr[P_PREVSTEPN];
-    if (full && stepn < o.center_tol) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    const double est = (prev >= 0.0) ? stepn * fmin(1.0, stepn / prev) : stepn;     // extrapolated next step
+    if (full && (stepn < o.center_tol || est < 0.1 * o.center_tol)) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     pr[P_PREVSTEPN] = full ? stepn : -1.0;

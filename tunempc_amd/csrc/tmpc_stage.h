@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
     for (int i = 0; i < IS; ++i) ip[i] = 0;
     const double s = 1.0 / amin, sbeta = amax / amin;
     pr[P_S] = s; pr[P_SBETA] = sbeta; pr[P_MINEIG_H] = lo;
-    pr[P_TAU] = 2.0 * sbeta; pr[P_ALPHA] = 1.0; pr[P_S0] = 1.0; pr[P_X0] = 1.0 / (double)(dm.p * dm.n);
+    // everything O(1) from the start: alpha*Hb has eigenvalues in [-1, 1], S2 = tau*I - alpha*Hb in [1, 3]
+    pr[P_TAU] = 2.0; pr[P_ALPHA] = 1.0 / sbeta; pr[P_S0] = 1.0 / sbeta; pr[P_X0] = 1.0 / (double)(dm.p * dm.n);
     pr[P_MUT] = -1.0; pr[P_PREVSTEPN] = -1.0; pr[P_STEPN] = 1e300;
     const int early = (lo > 0.0) ? 1 : 0;          // convexifier.py:83
     ip[I_EARLY] = early;
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
 __global__ void __launch_bounds__(64) k_init_state(WS w, Dims dm) {
   TMPC_STAGE_PROLOGUE
   const double* pr = w.prob + (size_t)b * PS;
-  const double s = pr[P_S], sbeta = pr[P_SBETA], tau = pr[P_TAU];
+  const double s = pr[P_S], tau = pr[P_TAU], alpha = pr[P_ALPHA];
   const double x0 = 1.0 / (double)(dm.p * n);
   double* Hb = w.Hb + (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) {
@@ -100,8 +101,8 @@ __global__ void __launch_bounds__(64) k_init_state(WS w, Dims dm) {
     const double hb = s * Hb[e];
     Hb[e] = hb;
     const double dg = (i == j) ? 1.0 : 0.0;
-    w.S1[(size_t)sid * nn + e] = sbeta * dg;
-    w.S2[(size_t)sid * nn + e] = tau * dg - hb;
+    w.S1[(size_t)sid * nn + e] = dg;
+    w.S2[(size_t)sid * nn + e] = tau * dg - alpha * hb;
     w.X1[(size_t)sid * nn + e] = x0 * dg;
     w.X2[(size_t)sid * nn + e] = x0 * dg;
   }
@@ -131,7 +132,7 @@ __device__ __forceinline__ void adj_V(double* out, double* t, const double* sV, 
   mm(out, t, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);        // (V G) V'
 }
 
-constexpr int PRE_SLOTS = 11;
+constexpr int PRE_SLOTS = 9;     // 76 KB of LDS: two single-wave blocks per CU
 // ------------------------------------------------------------------ stage_pre
 __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   TMPC_STAGE_PROLOGUE
@@ -141,7 +142,9 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   const double alpha = pr[P_ALPHA], tau = pr[P_TAU];
   double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sS = sm + 3 * MS;
   double* sLi = sm + 4 * MS; double* sSi = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
-  double* sHb = sm + 8 * MS; double* sPhi = sm + 9 * MS; double* t2 = sm + 10 * MS;
+  double* sHb = sm + 8 * MS;
+  double* sPhi = sM;      // M is consumed by the residuals below, then its slot accumulates Phi(Hb)
+  double* t2 = sS;        // the S slot is free once L^-1 has been formed
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
@@ -149,20 +152,26 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
   int nbad = 0;
   double* kf = w.KF + (size_t)sid * 12 * nxx;
+  // residuals of both slack blocks first (frees the M slot)
   for (int r = 0; r < 2; ++r) {
-    const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
     double* Rdg = (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn;
-    g2s(sX, Xg, n, n, n, lane);
-    g2s(sS, Sg, n, n, n, lane);
     for (int e = lane; e < nn; e += 64) {
       const int i = e / n, j = e - i * n;
-      const double m = sM[i * LD + j], sv = sS[i * LD + j];
+      const double m = sM[i * LD + j], sv = Sg[e];
       const double dg = (i == j) ? 1.0 : 0.0;
       const double rd = (r == 0 ? (m - dg) : (tau * dg - m)) - sv;
       Rdg[e] = rd;
-      rd2 = fma(rd, rd, rd2); s2 = fma(sv, sv, s2); xs = fma(sX[i * LD + j], sv, xs);
+      rd2 = fma(rd, rd, rd2); s2 = fma(sv, sv, s2);
     }
+  }
+  wsync();
+  for (int r = 0; r < 2; ++r) {
+    const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
+    const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
+    g2s(sX, Xg, n, n, n, lane);
+    g2s(sS, Sg, n, n, n, lane);
+    for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
       const double hx = dot_ss(sHb, sX, n, lane);
       if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s(sX, n, lane); }
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
   }
 }
 
-constexpr int DIR_SLOTS = 10;
+constexpr int DIR_SLOTS = 9;      // 76 KB of LDS: two single-wave blocks per CU
 // ------------------------------------------------------------------ stage_dir: dS, dX, step-length eigenvalues, corrector term
 __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
@@ -279,7 +288,8 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
   double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sSi = sm + 3 * MS;
   double* sDS = sm + 4 * MS; double* sDX = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
-  double* sHb = sm + 8 * MS; double* sL = sm + 9 * MS;
+  double* sHb = sm + 8 * MS;
+  double* sL = sHb;       // Hb is only needed to build dM
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
@@ -371,7 +381,7 @@ __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
   const double* Wg = w.Wm + (size_t)mid * n * n;
   for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = Wg[e]; }
   wsync();
-  jacobi_impl(A, n, cs, lane, 1e-18);
+  jacobi_impl(A, n, cs, lane, 1e-13);   // off-diagonal mass <= 1e-13: eigenvalue error << the 1 % step-length margin
   double lo = 1e300;
   if (lane < n) lo = A[lane * LD + lane];
   lo = wave_min(lo);
