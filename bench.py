@@ -78,11 +78,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    use_dist = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
 
     p, nx, mb, n = args.p, args.nx, args.mb, args.nx + args.mb
@@ -101,7 +102,7 @@ def main():
     def step():
         nonlocal out
         out = h.convexify_batch_device(dA, dB, dH, out)
-        if world > 1:
+        if use_dist:
             g = all_gather_results({k: out[k] for k in ('Hc', 'kappa', 'status')}, nbl * world)
             return g
         return out
@@ -109,19 +110,19 @@ def main():
     for _ in range(args.warmup):
         step()
     h.profile()   # reset accumulators
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
     prof = h.profile()
@@ -165,7 +166,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

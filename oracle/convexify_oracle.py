@@ -280,15 +280,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
     N = 2 * p * n + 1
     # ---- initial point (infeasible start)
     # everything O(1) from the start: alpha*Hb has eigenvalues in [-1, 1], S2 = tau*I - alpha*Hb in [1, 3]
-    tau = 2.0
+    tau = o.get('init_tau', 2.0)
     alpha = 1.0 / sbeta
     P = np.zeros((p, nx, nx))
-    S1 = np.broadcast_to(I, (p, n, n)).copy()
+    S1 = np.broadcast_to(o.get('init_s', 1.0) * I, (p, n, n)).copy()
     S2 = tau * I - alpha * Hb
-    X1 = np.broadcast_to(I / (p * n), (p, n, n)).copy()
+    X1 = np.broadcast_to(o.get('init_x', 1.0) * I / (p * n), (p, n, n)).copy()
     X2 = X1.copy()
     s0 = alpha
-    x0 = 1.0 / (p * n)
+    x0 = o.get('init_x', 1.0) / (p * n)
     mu_t = None
     phase = 0
     ncent = 0

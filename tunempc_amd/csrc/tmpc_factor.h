@@ -273,61 +273,206 @@ __device__ __forceinline__ void wg_gemm_nt_v0(double* C, int ldc, const double* 
 }
 
 
+// Big-tile variant for the K = dp Schur updates (D_{k+1} -= O O', D_{p-1} -= F F', F_{k+1} = -F O'):
+// workgroup tile up to 128 x 128 (waves 2 x 2, each up to 64 x 64 = 4 x 4 MFMA tiles, 128 accumulator registers),
+// K slabs of 16 columns, double-buffered, same flattened slab stream as wg_gemm_nt.  A 128-tile moves half the
+// operand bytes per flop of a 64-tile, which is what matters once two workgroups per CU make the 64-tile
+// kernel HBM-bound on panel re-reads.  Tile heights/widths are balanced (304 -> 112 + 96 + 96) instead of
+// 128 + 128 + 48.  The C fragment is read in the epilogue (no register budget for a prefetch copy).
+__device__ __forceinline__ void wg_gemm_nt_big(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
+                                               int M, int N, int K, int mode, bool lower, double* lds) {
+  constexpr int BK = 16, BLD = 17, BSL = 128 * BLD;          // slab: 128 rows x 16 k, leading dim 17
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int lrow = tid >> 1, lk = (tid & 1) * 4;             // loader: row 0..127; k = lk..lk+3 and 8+lk..8+lk+3
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nks = K / BK;
+  const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
+  const int th = ((M + ntm - 1) / ntm + 15) / 16 * 16;        // balanced tile height / width (multiples of 16)
+  const int tw = ((N + ntn - 1) / ntn + 15) / 16 * 16;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double ra[8], rb[8];
+  int m0 = 0, n0 = 0, ks = 0;
+  {
+    gcptr ap = (gcptr)(A + (size_t)lrow * lda + lk);
+    gcptr bp = (gcptr)(B + (size_t)lrow * ldb + lk);
+    const bool aok = (lrow < th) && (lrow < M), bok = (lrow < tw) && (lrow < N);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 8 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 8 + q] : 0.0; }
+    __syncthreads();
+    double* As = lds; double* Bs = lds + BSL;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { As[lrow * BLD + h2 * 8 + lk + q] = ra[h2 * 4 + q]; Bs[lrow * BLD + h2 * 8 + lk + q] = rb[h2 * 4 + q]; }
+    __syncthreads();
+  }
+  int buf = 0;
+  while (m0 < M) {
+    int nm0 = m0, nn0 = n0, nks_ = ks + 1;
+    if (nks_ == nks) {
+      nks_ = 0; nn0 = n0 + tw;
+      if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + th; }
+    }
+    const bool more = nm0 < M;
+    if (more) {
+      const int kn = nks_ * BK + lk;
+      gcptr ap = (gcptr)(A + (size_t)(nm0 + lrow) * lda + kn);
+      gcptr bp = (gcptr)(B + (size_t)(nn0 + lrow) * ldb + kn);
+      const bool aok = (lrow < th) && (nm0 + lrow < M), bok = (lrow < tw) && (nn0 + lrow < N);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 8 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 8 + q] : 0.0; }
+    }
+    // sub-tile validity of this wave (wave-uniform)
+    bool vi[4], vj[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wr * 64 + i * 16; vi[i] = (r < th) && (m0 + r < M); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = wc * 64 + j * 16; vj[j] = (c < tw) && (n0 + c < N) && !(lower && (n0 + c) > (m0 + th - 1)); }
+    {
+      const double* As = lds + buf * (2 * BSL);
+      const double* Bs = As + BSL;
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double a[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + fr) * BLD + kk * 4 + fk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = Bs[(wc * 64 + j * 16 + fr) * BLD + kk * 4 + fk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!vi[i]) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (vj[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      double* An = lds + (buf ^ 1) * (2 * BSL);
+      double* Bn = An + BSL;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { An[lrow * BLD + h2 * 8 + lk + q] = ra[h2 * 4 + q]; Bn[lrow * BLD + h2 * 8 + lk + q] = rb[h2 * 4 + q]; }
+    }
+    if (ks == nks - 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (vi[i] && vj[j]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              gptr cp = (gptr)C + (size_t)(m0 + wr * 64 + i * 16 + fk + 4 * r) * ldc + n0 + wc * 64 + j * 16 + fr;
+              const double v = acc[i][j][r];
+              if (mode == GM_SUB) *cp -= v; else if (mode == GM_SET) *cp = v; else *cp = -v;
+            }
+          }
+          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+    m0 = nm0; n0 = nn0; ks = nks_;
+  }
+}
+
 template <bool USE_MFMA, int VAR>
 __device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N,
                                         int K, int mode, bool lower, double* lds) {
   if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
+  else if (VAR == 4) { if (K >= 128) wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
   else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
 // dref: assembled diagonal entries (pivot reference).  Returns number of shifted pivots (thread-uniform).
+// Both loops are organised so that all 256 threads work: four lanes share every dot product (k strided by 4,
+// two xor-shuffles to combine), i.e. column-Crout for L and row-wise forward substitution for L^-1.
 __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds) {
   const int tid = threadIdx.x;
   double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
   double* Si = S + 64 * 65;                // 64 x 65
-  double* dr = Si + 64 * 65;               // 64
-  int* s_badp = (int*)(dr + 64);
-  if (tid == 0) *s_badp = 0;
+  double* dr = Si + 64 * 65;               // 64 pivot references, then [64] = current pivot, [65] = shift counter
   for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * 65 + j] = T[(size_t)i * ldt + j]; }
   if (tid < nb) dr[tid] = dref[tid];
+  if (tid == 0) dr[65] = 0.0;
   __syncthreads();
-  const int row = tid & 63, cg = tid >> 6;
+  const int row = tid >> 2, seg = tid & 3;
+  // ---- L: column Crout.  s_i = A[i][j] - sum_{k<j} L[i][k] L[j][k]
   for (int j = 0; j < nb; ++j) {
-    double piv = S[j * 65 + j];
-    const double ref = fabs(dr[j]);
-    bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
-    if (bad) piv = (ref > 0.0 ? ref : 1.0) * 1e20;       // Cholesky-with-shift: freeze this direction
-    const double dj = sqrt(piv);
+    double acc = 0.0;
+    if (row >= j && row < nb) {
+      const double* li = S + row * 65;
+      const double* lj = S + j * 65;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int k = seg;
+      for (; k + 12 < j; k += 16) {          // four independent chains: the LDS loads of a group issue back to back
+        a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 4], lj[k + 4], a1);
+        a2 = fma(li[k + 8], lj[k + 8], a2); a3 = fma(li[k + 12], lj[k + 12], a3);
+      }
+      for (; k < j; k += 4) a0 = fma(li[k], lj[k], a0);
+      acc = (a0 + a1) + (a2 + a3);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    double sij = 0.0;
+    if (row >= j && row < nb) sij = S[row * 65 + j] - acc;
+    if (row == j && seg == 0) {
+      double piv = sij;
+      const double ref = fabs(dr[j]);
+      if (!(piv > 1e-15 * ref) || !(piv > 0.0)) { piv = (ref > 0.0 ? ref : 1.0) * 1e20; dr[65] += 1.0; }   // Cholesky-with-shift
+      dr[64] = sqrt(piv);
+    }
     __syncthreads();
-    if (tid == 0) { S[j * 65 + j] = dj; if (bad) *s_badp += 1; }
-    if (cg == 0 && row > j && row < nb) S[row * 65 + j] /= dj;
-    __syncthreads();
-    if (row > j && row < nb) {
-      const double lij = S[row * 65 + j];
-      for (int c = j + 1 + cg; c <= row; c += 4) S[row * 65 + c] -= lij * S[c * 65 + j];
+    if (seg == 0 && row >= j && row < nb) {
+      const double dj = dr[64];
+      S[row * 65 + j] = (row == j) ? dj : sij / dj;
     }
     __syncthreads();
   }
-  // inverse, one column per thread (threads 0..nb-1)
-  if (tid < nb) {
-    const int c = tid;
-    for (int i = 0; i < c; ++i) Si[i * 65 + c] = 0.0;
-    Si[c * 65 + c] = 1.0 / S[c * 65 + c];
-    for (int i = c + 1; i < nb; ++i) {
-      double acc = 0.0;
-      for (int k2 = c; k2 < i; ++k2) acc = fma(S[i * 65 + k2], Si[k2 * 65 + c], acc);
-      Si[i * 65 + c] = -acc / S[i * 65 + i];
+  // ---- L^-1 by rows:  Ti[i][c] = (delta_ic - sum_{c<=k<i} L[i][k] Ti[k][c]) / L[i][i]
+  const int col = tid >> 2;
+  for (int i = 0; i < nb; ++i) {
+    double acc = 0.0;
+    if (col < i) {
+      const double* li = S + i * 65;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int k = col + seg;
+      for (; k + 12 < i; k += 16) {
+        a0 = fma(li[k], Si[k * 65 + col], a0); a1 = fma(li[k + 4], Si[(k + 4) * 65 + col], a1);
+        a2 = fma(li[k + 8], Si[(k + 8) * 65 + col], a2); a3 = fma(li[k + 12], Si[(k + 12) * 65 + col], a3);
+      }
+      for (; k < i; k += 4) a0 = fma(li[k], Si[k * 65 + col], a0);
+      acc = (a0 + a1) + (a2 + a3);
     }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (seg == 0 && col < nb) {
+      const double lii = S[i * 65 + i];
+      double v;
+      if (col < i) v = -acc / lii; else if (col == i) v = 1.0 / lii; else v = 0.0;
+      Si[i * 65 + col] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int e = tid; e < nb * nb; e += 256) {
     const int i = e / nb, j = e - i * nb;
     if (j <= i) T[(size_t)i * ldt + j] = S[i * 65 + j];
     Ti[i * TB + j] = Si[i * 65 + j];
   }
   __syncthreads();
-  const int nb_bad = *s_badp;
+  const int nb_bad = (int)dr[65];
   __syncthreads();
   return nb_bad;
 }
@@ -347,7 +492,7 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
       if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
     double* Ti = Linv_k + (size_t)jt * TB * TB;
-    nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
+    if (VAR != 2) nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
       wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
@@ -387,10 +532,18 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
       }
       nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
       // Schur updates
-      wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
-      if (!last) {
-        wg_gemm<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-        wg_gemm<USE_MFMA, VAR>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+      if (USE_MFMA && VAR == 3 && dp > 64) {
+        wg_gemm_nt_big(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+        if (!last) {
+          wg_gemm_nt_big(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+          wg_gemm_nt_big(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+        }
+      } else {
+        wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+        if (!last) {
+          wg_gemm<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+          wg_gemm<USE_MFMA, VAR>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+        }
       }
     }
     nbad += wg_block_column<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds);
