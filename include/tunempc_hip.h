@@ -108,6 +108,8 @@ int tmpc_get_trace(tmpc_handle* h, int nb, double* out);
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
 int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift);
 
+/* Smallest eigenvalue of nmat symmetric n x n matrices (Householder tridiagonalisation + Sturm multisection). */
+int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out);
 /* Isolated A/B timing of the block factorisation kernel: ms_out2[0] = baseline GEMM variant, [1] = current. */
 int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, double* ms_out2);
 

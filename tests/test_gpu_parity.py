@@ -106,6 +106,25 @@ def test_jacobi_eig_scan(hc, n):
     assert np.abs(out[..., 3] - ref[..., 3]).max() < 1e-13 * scale
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 16, 31, 32])
+def test_tridiagonal_min_eig(hc, n):
+    """Householder + Sturm multisection (the step-length primitive) vs LAPACK, incl. clustered and degenerate spectra."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(100 + n)
+    W = rng.standard_normal((40, n, n)); W = W + W.transpose(0, 2, 1)
+    W[0] = np.eye(n) * 3.0                                   # already diagonal, all eigenvalues equal
+    W[1] = np.diag(np.linspace(-2, 5, n)) if n > 1 else W[1]
+    if n > 2:
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        W[2] = (q * np.r_[-1.0, -1.0 + 1e-9, np.linspace(0, 1, n - 2)]) @ q.T      # nearly double smallest eigenvalue
+        W[3] = 1e-8 * W[3]                                                           # tiny scale
+        W[4] = 1e6 * W[4]
+    out = h.debug_min_eig(W)
+    ref = np.linalg.eigvalsh((W + W.transpose(0, 2, 1)) / 2)[:, 0]
+    scale = np.abs(np.linalg.eigvalsh((W + W.transpose(0, 2, 1)) / 2)).max(-1)
+    assert (np.abs(out - ref) <= 1e-12 * np.maximum(scale, 1e-300)).all(), np.abs(out - ref).max()
+
+
 @pytest.mark.parametrize('p,nx,mb', [(1, 3, 1), (4, 4, 2), (3, 24, 8)])
 def test_supplement(hc, p, nx, mb):
     """convexHessianSuppl (convexifier.py:165-211) on the GPU vs numpy."""

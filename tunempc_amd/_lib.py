@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
-    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench',
+    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -70,6 +70,8 @@ def load_library():
     lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
     lib.tmpc_debug_factor_bench.restype = C.c_int
     lib.tmpc_debug_factor_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    lib.tmpc_debug_min_eig.restype = C.c_int
+    lib.tmpc_debug_min_eig.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     lib.tmpc_last_error.restype = C.c_char_p
     lib.tmpc_version.restype = C.c_char_p
     _LIB = lib
@@ -194,6 +196,13 @@ class HipConvexifier:
         M, N = Cm.shape; K = A.shape[1]
         _check(self.lib, self.lib.tmpc_debug_gemm_nt(self._h, _dptr(Cm), _dptr(A), _dptr(B), M, N, K, int(mode), int(lower)), 'tmpc_debug_gemm_nt')
         return Cm
+
+    def debug_min_eig(self, W):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        nmat, n, _ = W.shape
+        out = np.empty(nmat)
+        _check(self.lib, self.lib.tmpc_debug_min_eig(self._h, nmat, n, _dptr(W), _dptr(out)), 'tmpc_debug_min_eig')
+        return out
 
     def debug_factor_bench(self, nb, p, d, reps=3):
         out = np.zeros(2)

@@ -154,6 +154,17 @@ __global__ void __launch_bounds__(64) k_supplement(const double* A, const double
 }
 
 // ---------------------------------------------------------------------------------- debug kernels
+__global__ void __launch_bounds__(64) k_debug_min_eig(const double* W, double* out, int n) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int mid = blockIdx.x, lane = threadIdx.x;
+  double* A = sm; double* cs = A + MS;
+  const double* Wg = W + (size_t)mid * n * n;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = 0.5 * (Wg[i * n + j] + Wg[j * n + i]); }
+  wsync();
+  const double lo = tridiag_min_eig(A, n, cs, lane);
+  if (lane == 0) out[mid] = lo;
+}
+
 template <bool USE_MFMA>
 __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -229,7 +240,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
-      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 64) * sizeof(double), st, w, dm, pass);
+      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
       if (pass == 1) {
         hipLaunchKernelGGL(k_ctrl_b, dim3(nb), dim3(64), 0, st, w, dm);
         if (prof) HIPCHK(hipEventRecord(h->ev[4], st));
@@ -454,6 +465,19 @@ int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double*
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(C, dC, (size_t)M * N * 8, hipMemcpyDeviceToHost));
   hipFree(dC); hipFree(dA); hipFree(dB);
+  return TMPC_OK;
+}
+
+// smallest eigenvalue of nmat symmetric n x n matrices (the step-length primitive of k_eigmin)
+int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out) {
+  if (!h || nmat < 1 || n < 1 || n > NMAX || !W || !out) return TMPC_E_ARG;
+  double *dW, *dO;
+  HIPCHK(hipMalloc(&dW, (size_t)nmat * n * n * 8)); HIPCHK(hipMalloc(&dO, (size_t)nmat * 8));
+  HIPCHK(hipMemcpy(dW, W, (size_t)nmat * n * n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_min_eig, dim3(nmat), dim3(64), (size_t)(MS + 160) * sizeof(double), 0, dW, dO, n);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, dO, (size_t)nmat * 8, hipMemcpyDeviceToHost));
+  hipFree(dW); hipFree(dO);
   return TMPC_OK;
 }
 

@@ -226,6 +226,86 @@ __device__ __forceinline__ void jacobi_impl(double* A, int n, double* cs, int la
 }
 __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int lane) { jacobi_impl(A, n, cs, lane, 1e-31); }
 
+// Smallest eigenvalue of the symmetric n x n LDS matrix A (destroyed): Householder tridiagonalisation
+// (backward stable, ~4/3 n^3 flops, a quarter of the LDS traffic of a converged Jacobi) followed by Sturm-count
+// multisection over 64 shifts per round.  One single-wave block; vv: LDS scratch of >= 3*32 doubles.
+// Wave-uniform return value.
+__device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, int lane) {
+  double* dd = vv + 32;       // diagonal
+  double* ee = vv + 64;       // off-diagonal: ee[i] couples i and i+1
+  if (n == 1) return A[0];
+  for (int j = 0; j + 2 < n; ++j) {
+    const int m = n - j - 1;                 // length of the column below the diagonal
+    const double xi = (lane < m) ? A[(j + 1 + lane) * LD + j] : 0.0;
+    const double x0 = __shfl(xi, 0, 64);
+    const double sigma = wave_sum((lane >= 1 && lane < m) ? xi * xi : 0.0);
+    if (sigma == 0.0) {                      // already tridiagonal in this column
+      if (lane == 0) ee[j] = x0;
+      wsync();
+      continue;
+    }
+    const double mu = sqrt(x0 * x0 + sigma);
+    const double v0 = (x0 <= 0.0) ? (x0 - mu) : (-sigma / (x0 + mu));
+    const double beta = 2.0 * v0 * v0 / (sigma + v0 * v0);
+    if (lane < m) vv[lane] = (lane == 0) ? 1.0 : xi / v0;
+    if (lane == 0) ee[j] = mu;               // |H x| = mu e_1 (sign irrelevant for eigenvalues of the tridiagonal)
+    wsync();
+    // p = beta * A22 v
+    double pi = 0.0;
+    if (lane < m) {
+      const double* ar = A + (j + 1 + lane) * LD + j + 1;
+      double a0 = 0.0, a1 = 0.0;
+      int c = 0;
+      for (; c + 1 < m; c += 2) { a0 = fma(ar[c], vv[c], a0); a1 = fma(ar[c + 1], vv[c + 1], a1); }
+      if (c < m) a0 = fma(ar[c], vv[c], a0);
+      pi = beta * (a0 + a1);
+    }
+    const double kk = 0.5 * beta * wave_sum((lane < m) ? pi * vv[lane] : 0.0);
+    wsync();
+    if (lane < m) vv[96 + lane] = pi - kk * vv[lane];     // w
+    wsync();
+    // A22 -= v w' + w v'
+    for (int e = lane; e < m * m; e += 64) {
+      const int r = e / m, c = e - r * m;
+      A[(j + 1 + r) * LD + j + 1 + c] -= vv[r] * vv[96 + c] + vv[96 + r] * vv[c];
+    }
+    wsync();
+  }
+  if (lane < n) dd[lane] = A[lane * LD + lane];
+  if (lane == 0) ee[n - 2] = A[(n - 1) * LD + n - 2];
+  wsync();
+  // Gershgorin lower bound, min-diagonal upper bound of lambda_min
+  double glo = 1e300, ghi = 1e300;
+  if (lane < n) {
+    const double el = (lane > 0) ? fabs(ee[lane - 1]) : 0.0, er = (lane < n - 1) ? fabs(ee[lane]) : 0.0;
+    glo = dd[lane] - el - er; ghi = dd[lane];
+  }
+  double lo = wave_min(glo), hi = wave_min(ghi);
+  const double scale = fmax(fabs(lo), fabs(hi));
+  lo -= 1e-14 * scale + 1e-300;
+  // multisection: lane l counts eigenvalues below sigma_l; lambda_min lies in the last interval with count 0
+  for (int round = 0; round < 7 && (hi - lo) > 4e-16 * fmax(scale, 1e-300); ++round) {
+    const double h = (hi - lo) / 65.0;
+    const double sig = lo + h * (double)(lane + 1);
+    int cnt = 0;
+    double q = dd[0] - sig;
+    if (q < 0.0) ++cnt;
+    for (int i = 1; i < n; ++i) {
+      if (fabs(q) < 1e-300) q = (q < 0.0) ? -1e-300 : 1e-300;
+      const double e2 = ee[i - 1] * ee[i - 1];
+      q = dd[i] - sig - e2 / q;
+      if (q < 0.0) ++cnt;
+    }
+    // number of shifts with zero eigenvalues below them
+    const unsigned long long mask = __ballot(cnt == 0);
+    const int nz = __popcll(mask);            // counts are monotone in sigma: the first nz shifts have count 0
+    const double nlo = lo + h * (double)nz;   // sigma_{nz-1} (or lo)
+    const double nhi = (nz < 64) ? lo + h * (double)(nz + 1) : hi;
+    lo = nlo; hi = nhi;
+  }
+  return 0.5 * (lo + hi);
+}
+
 // min / max of the diagonal after jacobi_eigvals (wave-uniform result)
 __device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, double* mn, double* mx) {
   double lo = 1e300, hi = -1e300;

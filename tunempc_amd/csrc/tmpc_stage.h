@@ -381,10 +381,7 @@ __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
   const double* Wg = w.Wm + (size_t)mid * n * n;
   for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = Wg[e]; }
   wsync();
-  jacobi_impl(A, n, cs, lane, 1e-13);   // off-diagonal mass <= 1e-13: eigenvalue error << the 1 % step-length margin
-  double lo = 1e300;
-  if (lane < n) lo = A[lane * LD + lane];
-  lo = wave_min(lo);
+  const double lo = tridiag_min_eig(A, n, cs, lane);
   if (lane == 0) w.eigmin[mid] = lo;
 }
 
