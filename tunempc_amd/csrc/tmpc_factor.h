@@ -32,6 +32,11 @@ enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A 
 // In-place use (C aliasing A with one N-tile and K == its width) is safe: a tile's A slabs are all in LDS before
 // its C fragment is stored, and the next tile reads other rows.
 constexpr int SLD = 17, SUBD = 64 * SLD, SLABD = 2 * SUBD;   // sub-slab leading dim / doubles per sub-slab / per (operand) slab
+#ifdef TMPC_NT
+#define TMPC_LD(p) __builtin_nontemporal_load(p)
+#else
+#define TMPC_LD(p) (*(p))
+#endif
 typedef const double __attribute__((address_space(1)))* gcptr;
 typedef double __attribute__((address_space(1)))* gptr;
 template <bool USE_MFMA>
@@ -61,7 +66,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       const bool kok = (h2 * 16 + lk) < K;
       const bool aok = (lrow < M) && kok, bok = (lrow < N) && kok;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 16 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 16 + q] : 0.0; }
+      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? TMPC_LD(ap + h2 * 16 + q) : 0.0; rb[h2 * 4 + q] = bok ? TMPC_LD(bp + h2 * 16 + q) : 0.0; }
     }
     __syncthreads();                       // LDS free (previous user)
     double* As = lds; double* Bs = lds + SLABD;
@@ -89,7 +94,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         const bool kok = (kn + h2 * 16) < K;
         const bool aok = (nm0 + lrow < M) && kok, bok = (nn0 + lrow < N) && kok;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 16 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 16 + q] : 0.0; }
+        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? TMPC_LD(ap + h2 * 16 + q) : 0.0; rb[h2 * 4 + q] = bok ? TMPC_LD(bp + h2 * 16 + q) : 0.0; }
       }
     }
     if (ks == 0 && mode == GM_SUB) {       // prefetch the C fragment of this tile
@@ -745,8 +750,9 @@ __global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
   double* TU = w.TU + (size_t)b * vl * 2;
   const double* U = w.U + (size_t)b * vl * 2;
   double* red = lds + solve_lds_doubles(dp) - 8;
-  const bool have_rhs = (pass == 2) || (phase == PH_MAIN);
-  if (pass == 1) {
+  if (pass == 1 && phase != PH_MAIN) return;           // centering: everything happens in pass 2
+  const bool three = (pass == 1) || (phase != PH_MAIN);
+  if (three) {
     wg_cyclic_solve<3>(W3, D, O, F, Li, p, dp, nt, lds);
     double s00 = 0.0, s01 = 0.0, s11 = 0.0;
     for (size_t e = tid; e < vl; e += 256) {
@@ -761,7 +767,6 @@ __global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
     wg_cyclic_solve<1>(Z, D, O, F, Li, p, dp, nt, lds);
   }
   __syncthreads();
-  if (!have_rhs) return;
   // border:  rb = [rhs_tau, rhs_alpha] - U' z ;  db = Sb^-1 rb ;  dp = z - TU db
   double u0 = 0.0, u1 = 0.0;
   for (size_t e = tid; e < vl; e += 256) { const double z = Z[e]; u0 = fma(U[e * 2], z, u0); u1 = fma(U[e * 2 + 1], z, u1); }

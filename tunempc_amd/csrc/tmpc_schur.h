@@ -100,6 +100,10 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE) return;
+  // main phase: pass 1 solves [predictor rhs | u_tau | u_alpha], pass 2 the corrector rhs alone;
+  // centering phase: no predictor, so pass 1 is skipped and pass 2 solves [rhs | u_tau | u_alpha] in one sweep
+  if (pass == 1 && phase != PH_MAIN) return;
+  const bool three = (pass == 1) || (phase != PH_MAIN);
   const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* av = w.adjV + (size_t)(b * dm.p + km) * NADJ * nxx;
@@ -111,8 +115,8 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
       const int idx = e + (c - a);
       const double wgt = (a == c) ? 1.0 : 2.0;
       const int o = a * nx + c;
-      if (pass == 1) {
-        const double g = (phase == PH_MAIN) ? wgt * (av[ADJ_G * nxx + o] - ae[ADJ_G * nxx + o]) : 0.0;
+      const double g = wgt * (av[ADJ_G * nxx + o] - ae[ADJ_G * nxx + o]);
+      if (three) {
         const double ut = -wgt * (av[ADJ_PSI * nxx + o] - ae[ADJ_PSI * nxx + o]);
         const double ua = wgt * (av[ADJ_PHI * nxx + o] - ae[ADJ_PHI * nxx + o]);
         double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3;
@@ -120,14 +124,14 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
         double* u = w.U + ((size_t)sid * dp + idx) * 2;
         u[0] = ut; u[1] = ua;
       } else {
-        w.Z[(size_t)sid * dp + idx] = wgt * (av[ADJ_G * nxx + o] - ae[ADJ_G * nxx + o]);
+        w.Z[(size_t)sid * dp + idx] = g;
       }
     }
     e += nx - a;
   }
   // zero padding
   for (int i = dm.d + lane; i < dp; i += 64) {
-    if (pass == 1) {
+    if (three) {
       double* w3 = w.W3 + ((size_t)sid * dp + i) * 3; w3[0] = 0.0; w3[1] = 0.0; w3[2] = 0.0;
       double* u = w.U + ((size_t)sid * dp + i) * 2; u[0] = 0.0; u[1] = 0.0;
     } else w.Z[(size_t)sid * dp + i] = 0.0;
