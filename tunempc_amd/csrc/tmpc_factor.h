@@ -42,7 +42,7 @@ typedef double __attribute__((address_space(1)))* gptr;
 template <bool USE_MFMA>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
-                                           double* lds) {
+                                           double* lds, bool btri = false) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;
   // slab loader: row (0..63); each thread moves two 32-byte pieces, k = lk..lk+3 and 16+lk..16+lk+3, into two
@@ -111,11 +111,14 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         }
       }
     }
-    // ---- compute current slab
+    // ---- compute current slab.  (Skipping the 16 x 16 sub-tiles that lie outside M x N, above the diagonal of a
+    // symmetric update or under the zero half of a triangular B was measured: 20 % fewer MFMAs, no time gained --
+    // the per-MFMA branches cost what the skipped issue slots save -- so the MFMAs are unconditional.)
     {
       const double* As = lds + buf * (2 * SLABD);
       const double* Bs = As + SLABD;
       const int krem = K - ks * GK;
+      (void)btri;
       if (USE_MFMA) {
 #define TMPC_MFMA_STEP(kk)                                                                  \
   {                                                                                         \
@@ -392,12 +395,118 @@ __device__ __forceinline__ void wg_gemm_nt_big(double* C, int ldc, const double*
   }
 }
 
+// The three Schur updates of one stage fused:  Dn -= O O',  Dl -= F F' (lower tiles),  Fn = -F O' (all tiles).
+// For a lower tile (r >= c) the four operand slabs O_r, F_r, O_c, F_c are staged once and feed three MFMA
+// accumulator sets (12.3 flop per operand byte instead of 8 for three separate GEMMs); upper tiles only need
+// F_r and O_c.  Same flattened, double-buffered slab stream as wg_gemm_nt; K slabs of 16 columns.
+__device__ __forceinline__ void wg_schur_fused(double* Dn, double* Dl, double* Fn, const double* O, const double* F,
+                                               int dp, double* lds) {
+  constexpr int FK = 16, FLD = 17, FSL = 64 * FLD;          // one slab: 64 rows x 16 k
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;             // loader: row 0..63, k = lk..lk+3
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nks = dp / FK;
+  double4_t aoo[2][2], aff[2][2], afo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { aoo[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; aff[i][j] = aoo[i][j]; afo[i][j] = aoo[i][j]; }
+  double r0[4], r1[4], r2[4], r3[4];                          // O_r, F_r, O_c, F_c pieces
+  int m0 = 0, n0 = 0, ks = 0;
+#define TMPC_FUSED_LOAD(M0, N0, KS)                                                                      \
+  {                                                                                                      \
+    const bool low = (N0) <= (M0);                                                                       \
+    const bool rok = ((M0) + lrow) < dp, cok = ((N0) + lrow) < dp;                                       \
+    gcptr po = (gcptr)(O + (size_t)((M0) + lrow) * dp + (KS) * FK + lk);                                 \
+    gcptr pf = (gcptr)(F + (size_t)((M0) + lrow) * dp + (KS) * FK + lk);                                 \
+    gcptr qo = (gcptr)(O + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
+    gcptr qf = (gcptr)(F + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+      r0[q] = (rok && low) ? po[q] : 0.0; r1[q] = rok ? pf[q] : 0.0;                                     \
+      r2[q] = cok ? qo[q] : 0.0; r3[q] = (cok && low) ? qf[q] : 0.0;                                     \
+    }                                                                                                    \
+  }
+#define TMPC_FUSED_STORE(BUF)                                                                            \
+  {                                                                                                      \
+    double* b_ = lds + (BUF) * (4 * FSL);                                                                \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+      b_[lrow * FLD + lk + q] = r0[q]; b_[FSL + lrow * FLD + lk + q] = r1[q];                            \
+      b_[2 * FSL + lrow * FLD + lk + q] = r2[q]; b_[3 * FSL + lrow * FLD + lk + q] = r3[q];              \
+    }                                                                                                    \
+  }
+  TMPC_FUSED_LOAD(0, 0, 0)
+  __syncthreads();
+  TMPC_FUSED_STORE(0)
+  __syncthreads();
+  int buf = 0;
+  while (m0 < dp) {
+    int nm0 = m0, nn0 = n0, nks_ = ks + 1;
+    if (nks_ == nks) { nks_ = 0; nn0 = n0 + 64; if (nn0 >= dp) { nn0 = 0; nm0 = m0 + 64; } }
+    const bool more = nm0 < dp;
+    if (more) TMPC_FUSED_LOAD(nm0, nn0, nks_)
+    const bool low = n0 <= m0;
+    {
+      const double* b_ = lds + buf * (4 * FSL);
+#pragma unroll
+      for (int kk = 0; kk < FK / 4; ++kk) {
+        const int o0 = (wr * 32 + fr) * FLD + kk * 4 + fk, o1 = o0 + 16 * FLD;
+        const int c0 = (wc * 32 + fr) * FLD + kk * 4 + fk, c1 = c0 + 16 * FLD;
+        const double f0 = b_[FSL + o0], f1 = b_[FSL + o1];
+        const double bo0 = b_[2 * FSL + c0], bo1 = b_[2 * FSL + c1];
+        afo[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bo0, afo[0][0], 0, 0, 0);
+        afo[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bo1, afo[0][1], 0, 0, 0);
+        afo[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bo0, afo[1][0], 0, 0, 0);
+        afo[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bo1, afo[1][1], 0, 0, 0);
+        if (low) {
+          const double a0 = b_[o0], a1 = b_[o1];
+          const double bf0 = b_[3 * FSL + c0], bf1 = b_[3 * FSL + c1];
+          aoo[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bo0, aoo[0][0], 0, 0, 0);
+          aoo[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bo1, aoo[0][1], 0, 0, 0);
+          aoo[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bo0, aoo[1][0], 0, 0, 0);
+          aoo[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bo1, aoo[1][1], 0, 0, 0);
+          aff[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bf0, aff[0][0], 0, 0, 0);
+          aff[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bf1, aff[0][1], 0, 0, 0);
+          aff[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bf0, aff[1][0], 0, 0, 0);
+          aff[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bf1, aff[1][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) TMPC_FUSED_STORE(buf ^ 1)
+    if (ks == nks - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wr * 32 + i * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cbase = n0 + wc * 32 + j * 16;
+          if (rbase < dp && cbase < dp) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const size_t off = (size_t)(rbase + fk + 4 * r) * dp + cbase + fr;
+              ((gptr)Fn)[off] = -afo[i][j][r];
+              if (low) { ((gptr)Dn)[off] -= aoo[i][j][r]; ((gptr)Dl)[off] -= aff[i][j][r]; }
+            }
+          }
+          aoo[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; aff[i][j] = aoo[i][j]; afo[i][j] = aoo[i][j];
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+    m0 = nm0; n0 = nn0; ks = nks_;
+  }
+#undef TMPC_FUSED_LOAD
+#undef TMPC_FUSED_STORE
+}
+
 template <bool USE_MFMA, int VAR>
 __device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N,
-                                        int K, int mode, bool lower, double* lds) {
+                                        int K, int mode, bool lower, double* lds, bool btri = false) {
   if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
+  else if (VAR == 7) { /* ablation: no panel GEMMs at all */ }
   else if (VAR == 4) { if (K >= 128) wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
-  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
+  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds, btri);
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
@@ -500,9 +609,9 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
     if (VAR != 2) nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
-      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
-    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
-    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds, true);
+    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds, true);
+    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds, true);
   }
   return nbad;
 }
@@ -537,12 +646,22 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
       }
       nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
       // Schur updates
-      if (USE_MFMA && VAR == 3 && dp > 64) {
+      if (VAR == 5) {
+        // ablation: no Schur updates
+      } else if (VAR == 6) {
+        wg_gemm<USE_MFMA, 1>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+        if (!last) {
+          wg_gemm<USE_MFMA, 1>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+          wg_gemm<USE_MFMA, 1>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+        }
+      } else if (USE_MFMA && VAR == 3 && dp > 64) {
         wg_gemm_nt_big(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
         if (!last) {
           wg_gemm_nt_big(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
           wg_gemm_nt_big(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
         }
+      } else if (USE_MFMA && VAR == 1 && !last && k + 1 != p - 1) {
+        wg_schur_fused(D + (k + 1) * bs, D + (size_t)(p - 1) * bs, F + (k + 1) * bs, Ok, Fk, dp, lds);
       } else {
         wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
         if (!last) {
