@@ -60,24 +60,33 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   double* Cg = corner ? (w.F + (size_t)(b * dm.p) * dp * dp) : (w.O + (size_t)sid * dp * dp);
   double* dd = w.Ddiag + (size_t)sid * dp;
   const int tot = dp * dp;
+  // Every store is coalesced along the fastest index of the STORED matrix: e -> (row, col) of the stored block.
+  // D_k: only the lower triangle is ever read (left-looking panels + the lower half of the diagonal tiles), so
+  // only col <= row is computed and written.  The coupling block is stored transposed (O_k = C_k') except for
+  // the cyclic corner, so the roles of (ab) and (cd) are swapped instead of transposing the store.
   for (int e = tid; e < tot; e += 256) {
     const int row = e / dp, col = e - row * dp;
     if (row >= d || col >= d) {
-      Dg[e] = (row == col) ? 1.0 : 0.0;
+      if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0;
       Cg[e] = 0.0;
       if (row == col) dd[row] = 1.0;
       continue;
     }
-    const int a = ia[row], bb = ib[row], c = ia[col], d_ = ib[col];
-    double cv = 0.0;
+    // coupling block: C_k[(ab),(cd)] with (ab) in P_k, (cd) in P_{k+1}; stored entry (row, col) is C_k[row][col]
+    // for the corner and C_k[col][row] otherwise
+    {
+      const int ra = corner ? row : col, rc = corner ? col : row;
+      const int a = ia[ra], bb = ib[ra], c = ia[rc], d_ = ib[rc];
+      double cv = 0.0;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
-      cv -= hkm_entry(mr + KF_FX * msz, mr + KF_FS * msz, ldk, a, bb, c, d_);
+      for (int r = 0; r < 2; ++r) {
+        const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
+        cv -= hkm_entry(mr + KF_FX * msz, mr + KF_FS * msz, ldk, a, bb, c, d_);
+      }
+      Cg[e] = cv;
     }
-    // C_k[(ab),(cd)] : row index belongs to P_k, column index to P_{k+1}
-    if (corner) Cg[row * dp + col] = cv; else Cg[col * dp + row] = cv;
     if (col <= row) {
+      const int a = ia[row], bb = ib[row], c = ia[col], d_ = ib[col];
       double dv = 0.0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -85,8 +94,7 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
         dv += hkm_entry(mr + KF_XXX * msz, mr + KF_SIXX * msz, ldk, a, bb, c, d_);
         dv += hkm_entry(mr + KF_KX * msz, mr + KF_KS * msz, ldk, a, bb, c, d_);
       }
-      Dg[row * dp + col] = dv;
-      Dg[col * dp + row] = dv;
+      Dg[e] = dv;
       if (row == col) dd[row] = dv;
     }
   }
