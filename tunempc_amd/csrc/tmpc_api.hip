@@ -198,6 +198,7 @@ static int set_lds_attrs() {
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -538,6 +539,7 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
       else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 4) hipLaunchKernelGGL((k_factor<true, 4>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 5) hipLaunchKernelGGL((k_factor<true, 5>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 6) hipLaunchKernelGGL((k_factor<true, 6>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
+      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 8) hipLaunchKernelGGL((k_factor<true, 8>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 7) hipLaunchKernelGGL((k_factor<true, 7>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 3) hipLaunchKernelGGL((k_factor<true, 3>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else if (v == 0) hipLaunchKernelGGL((k_factor<true, 0>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
@@ -554,6 +556,17 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
   hipEventDestroy(e0); hipEventDestroy(e1);
   return TMPC_OK;
 }
+
+#ifdef TMPC_CYCLE_PROF
+extern "C" int tmpc_debug_cycle_prof(double* out16) {
+  unsigned long long h[16];
+  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(tmpc::g_prof), sizeof(h)));
+  for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+  unsigned long long z[16] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tmpc::g_prof), z, sizeof(z)));
+  return 0;
+}
+#endif
 
 // Factor + solve one block-cyclic-tridiagonal system given dense blocks (unit test of k_factor / wg_cyclic_solve):
 // D [p][d][d] diagonal blocks, Ccpl [p][d][d] with Ccpl[k] = T[block k, block k+1 mod p], rhs/x [p][d].

@@ -32,12 +32,29 @@ enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A 
 // In-place use (C aliasing A with one N-tile and K == its width) is safe: a tile's A slabs are all in LDS before
 // its C fragment is stored, and the next tile reads other rows.
 constexpr int SLD = 17, SUBD = 64 * SLD, SLABD = 2 * SUBD;   // sub-slab leading dim / doubles per sub-slab / per (operand) slab
+#ifdef TMPC_CYCLE_PROF
+__device__ unsigned long long g_prof[16];
+#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[i] += t_ - tprev_; tprev_ = t_; } }
+#define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
+#else
+#define TMPC_T(i)
+#define TMPC_T0()
+#endif
 #ifdef TMPC_NT
 #define TMPC_LD(p) __builtin_nontemporal_load(p)
 #else
 #define TMPC_LD(p) (*(p))
 #endif
 typedef const double __attribute__((address_space(1)))* gcptr;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef const double2_t __attribute__((address_space(1)))* gcptr2;
+// 32-byte piece (4 doubles, 32-byte aligned) as two 16-byte loads
+#define TMPC_LD4(dst, off, p, ok)                                                       \
+  {                                                                                     \
+    const double2_t u0_ = (ok) ? ((gcptr2)(p))[0] : (double2_t){0.0, 0.0};              \
+    const double2_t u1_ = (ok) ? ((gcptr2)(p))[1] : (double2_t){0.0, 0.0};              \
+    dst[(off) + 0] = u0_[0]; dst[(off) + 1] = u0_[1]; dst[(off) + 2] = u1_[0]; dst[(off) + 3] = u1_[1]; \
+  }
 typedef double __attribute__((address_space(1)))* gptr;
 template <bool USE_MFMA>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
@@ -65,8 +82,8 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     for (int h2 = 0; h2 < 2; ++h2) {
       const bool kok = (h2 * 16 + lk) < K;
       const bool aok = (lrow < M) && kok, bok = (lrow < N) && kok;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? TMPC_LD(ap + h2 * 16 + q) : 0.0; rb[h2 * 4 + q] = bok ? TMPC_LD(bp + h2 * 16 + q) : 0.0; }
+      TMPC_LD4(ra, h2 * 4, ap + h2 * 16, aok)
+      TMPC_LD4(rb, h2 * 4, bp + h2 * 16, bok)
     }
     __syncthreads();                       // LDS free (previous user)
     double* As = lds; double* Bs = lds + SLABD;
@@ -77,6 +94,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     __syncthreads();
   }
   int buf = 0;
+  TMPC_T0()
   while (m0 < M) {
     // ---- next slab of the stream
     int nm0 = m0, nn0 = n0, nks_ = ks + 1;
@@ -93,10 +111,11 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       for (int h2 = 0; h2 < 2; ++h2) {
         const bool kok = (kn + h2 * 16) < K;
         const bool aok = (nm0 + lrow < M) && kok, bok = (nn0 + lrow < N) && kok;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? TMPC_LD(ap + h2 * 16 + q) : 0.0; rb[h2 * 4 + q] = bok ? TMPC_LD(bp + h2 * 16 + q) : 0.0; }
+        TMPC_LD4(ra, h2 * 4, ap + h2 * 16, aok)
+        TMPC_LD4(rb, h2 * 4, bp + h2 * 16, bok)
       }
     }
+    TMPC_T(0)
     if (ks == 0 && mode == GM_SUB) {       // prefetch the C fragment of this tile
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -111,6 +130,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         }
       }
     }
+    TMPC_T(1)
     // ---- compute current slab.  (Skipping the 16 x 16 sub-tiles that lie outside M x N, above the diagonal of a
     // symmetric update or under the zero half of a triangular B was measured: 20 % fewer MFMAs, no time gained --
     // the per-MFMA branches cost what the skipped issue slots save -- so the MFMAs are unconditional.)
@@ -155,6 +175,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         }
       }
     }
+    TMPC_T(2)
     // ---- stage the next slab into the other buffer
     if (more) {
       double* An = lds + (buf ^ 1) * (2 * SLABD);
@@ -164,6 +185,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) { An[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
     }
+    TMPC_T(3)
     // ---- tile finished: store its C fragment (reg r -> row (lane>>4) + 4r, col lane&15)
     if (ks == nks - 1) {
 #pragma unroll
@@ -184,10 +206,124 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         }
       }
     }
+    TMPC_T(4)
     __syncthreads();
+    TMPC_T(5)
     buf ^= 1;
     m0 = nm0; n0 = nn0; ks = nks_;
   }
+}
+
+// Variant with the global loads issued TWO slabs ahead (two register sets, same two LDS buffers): doubles the
+// bytes each workgroup keeps in flight.  Everything else as wg_gemm_nt.
+template <bool USE_MFMA>
+__device__ __forceinline__ void wg_gemm_nt_d2(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
+                                              int M, int N, int K, int mode, bool lower, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;
+  const int nks = (K + GK - 1) / GK;
+  const int fr = lane & 15, fk = lane >> 4;
+  double4_t acc[2][2], cpre[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; cpre[i][j] = acc[i][j]; }
+  double ra[8], rb[8], rc[8], rd[8];
+#define TMPC_NEXT(m_, n_, k_, pm, pn, pk)                                               \
+  {                                                                                     \
+    m_ = pm; n_ = pn; k_ = pk + 1;                                                      \
+    if (k_ == nks) { k_ = 0; n_ = pn + 64; if (n_ >= N || (lower && n_ > m_)) { n_ = 0; m_ = pm + 64; } } \
+  }
+#define TMPC_LOAD(RA, RB, m_, n_, k_)                                                   \
+  if (m_ < M) {                                                                         \
+    const int kn = k_ * GK + lk;                                                        \
+    gcptr ap = (gcptr)(A + (size_t)(m_ + lrow) * lda + kn);                             \
+    gcptr bp = (gcptr)(B + (size_t)(n_ + lrow) * ldb + kn);                             \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                                  \
+      const bool kok = (kn + h2 * 16) < K;                                              \
+      const bool aok = (m_ + lrow < M) && kok, bok = (n_ + lrow < N) && kok;            \
+      TMPC_LD4(RA, h2 * 4, ap + h2 * 16, aok)                                            \
+      TMPC_LD4(RB, h2 * 4, bp + h2 * 16, bok)                                            \
+    }                                                                                   \
+  }
+#define TMPC_STORE(RA, RB, BUF)                                                         \
+  {                                                                                     \
+    double* An = lds + (BUF) * (2 * SLABD); double* Bn = An + SLABD;                    \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
+        An[h2 * SUBD + lrow * SLD + lk + q] = RA[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = RB[h2 * 4 + q]; } \
+  }
+  int m0 = 0, n0 = 0, ks = 0, m1, n1, k1, m2, n2, k2;
+  TMPC_NEXT(m1, n1, k1, m0, n0, ks)
+  TMPC_LOAD(ra, rb, m0, n0, ks)
+  __syncthreads();
+  TMPC_STORE(ra, rb, 0)
+  TMPC_LOAD(ra, rb, m1, n1, k1)            // slab 1 in flight in (ra, rb)
+  __syncthreads();
+  int buf = 0;
+#define TMPC_STEP(RA, RB, RC, RD)                                                                  \
+  {                                                                                                \
+    TMPC_NEXT(m2, n2, k2, m1, n1, k1)                                                              \
+    TMPC_LOAD(RC, RD, m2, n2, k2)                        /* two slabs ahead */                     \
+    if (ks == 0 && mode == GM_SUB) {                                                               \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+        const int rbase = m0 + wr * 32 + i * 16;                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+          const int cbase = n0 + wc * 32 + j * 16;                                                 \
+          if (rbase < M && cbase < N) {                                                            \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                          \
+              cpre[i][j][r] = ((gcptr)C)[(size_t)(rbase + fk + 4 * r) * ldc + cbase + fr];        \
+          }                                                                                        \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+    {                                                                                              \
+      const double* As = lds + buf * (2 * SLABD);                                                  \
+      const double* Bs = As + SLABD;                                                               \
+      const int nkk = (K - ks * GK >= GK) ? GK / 4 : (K - ks * GK) / 4;                            \
+      _Pragma("unroll") for (int kk = 0; kk < GK / 4; ++kk) {                                      \
+        if (kk < nkk) {                                                                            \
+          const int so = (kk >> 2) * SUBD + (kk & 3) * 4 + fk;                                     \
+          const double a0 = As[so + (wr * 32 + fr) * SLD], a1 = As[so + (wr * 32 + 16 + fr) * SLD]; \
+          const double b0 = Bs[so + (wc * 32 + fr) * SLD], b1 = Bs[so + (wc * 32 + 16 + fr) * SLD]; \
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);            \
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);            \
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);            \
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);            \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+    if (m1 < M) TMPC_STORE(RA, RB, buf ^ 1)                                                        \
+    if (ks == nks - 1) {                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+        const int rbase = m0 + wr * 32 + i * 16;                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+          const int cbase = n0 + wc * 32 + j * 16;                                                 \
+          if (rbase < M && cbase < N) {                                                            \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
+              gptr cp = (gptr)C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;                 \
+              const double v = acc[i][j][r];                                                       \
+              if (mode == GM_SUB) *cp = cpre[i][j][r] - v; else if (mode == GM_SET) *cp = v; else *cp = -v; \
+            }                                                                                      \
+          }                                                                                        \
+          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};                                             \
+        }                                                                                          \
+      }                                                                                            \
+    }                                                                                              \
+    __syncthreads();                                                                               \
+    buf ^= 1;                                                                                      \
+    m0 = m1; n0 = n1; ks = k1; m1 = m2; n1 = n2; k1 = k2;                                          \
+  }
+  while (m0 < M) {
+    TMPC_STEP(ra, rb, rc, rd)
+    if (m0 >= M) break;
+    TMPC_STEP(rc, rd, ra, rb)
+  }
+#undef TMPC_STEP
+#undef TMPC_STORE
+#undef TMPC_LOAD
+#undef TMPC_NEXT
 }
 
 constexpr int GK0 = 16, GLD0 = 17;   // variant 0: single-buffered 16-column slabs, two barriers per slab (round-1 baseline)
@@ -422,10 +558,8 @@ __device__ __forceinline__ void wg_schur_fused(double* Dn, double* Dl, double* F
     gcptr pf = (gcptr)(F + (size_t)((M0) + lrow) * dp + (KS) * FK + lk);                                 \
     gcptr qo = (gcptr)(O + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
     gcptr qf = (gcptr)(F + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-      r0[q] = (rok && low) ? po[q] : 0.0; r1[q] = rok ? pf[q] : 0.0;                                     \
-      r2[q] = cok ? qo[q] : 0.0; r3[q] = (cok && low) ? qf[q] : 0.0;                                     \
-    }                                                                                                    \
+    TMPC_LD4(r0, 0, po, (rok && low)) TMPC_LD4(r1, 0, pf, rok)                                           \
+    TMPC_LD4(r2, 0, qo, cok) TMPC_LD4(r3, 0, qf, (cok && low))                                           \
   }
 #define TMPC_FUSED_STORE(BUF)                                                                            \
   {                                                                                                      \
@@ -505,6 +639,7 @@ __device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int
                                         int K, int mode, bool lower, double* lds, bool btri = false) {
   if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
   else if (VAR == 7) { /* ablation: no panel GEMMs at all */ }
+  else if (VAR == 8) { if (USE_MFMA) wg_gemm_nt_d2<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
   else if (VAR == 4) { if (K >= 128) wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
   else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds, btri);
 }
@@ -648,11 +783,11 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
       // Schur updates
       if (VAR == 5) {
         // ablation: no Schur updates
-      } else if (VAR == 6) {
-        wg_gemm<USE_MFMA, 1>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
+      } else if (VAR == 6 || VAR == 8) {
+        wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
         if (!last) {
-          wg_gemm<USE_MFMA, 1>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-          wg_gemm<USE_MFMA, 1>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
+          wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
+          wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
         }
       } else if (USE_MFMA && VAR == 3 && dp > 64) {
         wg_gemm_nt_big(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
