@@ -67,6 +67,10 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
   const int nks = (K + GK - 1) / GK;
   const int fr = lane & 15, fk = lane >> 4;
+  // The MFMA is issued as C' = B_pi * A' with the columns of the B sub-tile permuted (pi(c) = 4*(c&3) + (c>>2)):
+  // lane (fr, fk) then owns C[row fr][cols 4*fk .. 4*fk+3] of every 16 x 16 sub-tile -- 32 contiguous bytes, i.e.
+  // two 16-byte accesses instead of four 8-byte ones for the C prefetch and the epilogue.
+  const int fp = 4 * (fr & 3) + (fr >> 2);
   double4_t acc[2][2], cpre[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -124,8 +128,9 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         for (int j = 0; j < 2; ++j) {
           const int cbase = n0 + wc * 32 + j * 16;
           if (rbase < M && cbase < N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cpre[i][j][r] = ((gcptr)C)[(size_t)(rbase + fk + 4 * r) * ldc + cbase + fr];
+            gcptr2 cp2 = (gcptr2)(C + (size_t)(rbase + fr) * ldc + cbase + 4 * fk);
+            const double2_t u0 = cp2[0], u1 = cp2[1];
+            cpre[i][j][0] = u0[0]; cpre[i][j][1] = u0[1]; cpre[i][j][2] = u1[0]; cpre[i][j][3] = u1[1];
           }
         }
       }
@@ -145,12 +150,12 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     const int so = ((kk) >> 2) * SUBD + ((kk) & 3) * 4 + fk;                                \
     const double a0 = As[so + (wr * 32 + fr) * SLD];                                        \
     const double a1 = As[so + (wr * 32 + 16 + fr) * SLD];                                   \
-    const double b0 = Bs[so + (wc * 32 + fr) * SLD];                                        \
-    const double b1 = Bs[so + (wc * 32 + 16 + fr) * SLD];                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);           \
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);           \
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);           \
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);           \
+    const double b0 = Bs[so + (wc * 32 + fp) * SLD];                                        \
+    const double b1 = Bs[so + (wc * 32 + 16 + fp) * SLD];                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);           \
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);           \
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);           \
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);           \
   }
         if (krem >= GK) {
 #pragma unroll
@@ -169,7 +174,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int row = wr * 32 + i * 16 + fk + 4 * r, col = wc * 32 + j * 16 + fr;
+                const int row = wr * 32 + i * 16 + fr, col = wc * 32 + j * 16 + 4 * fk + r;
                 acc[i][j][r] = fma(As[(kk >> 4) * SUBD + row * SLD + (kk & 15)], Bs[(kk >> 4) * SUBD + col * SLD + (kk & 15)], acc[i][j][r]);
               }
         }
@@ -186,7 +191,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         for (int q = 0; q < 4; ++q) { An[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
     }
     TMPC_T(3)
-    // ---- tile finished: store its C fragment (reg r -> row (lane>>4) + 4r, col lane&15)
+    // ---- tile finished: store its C fragment (reg r -> row lane&15, col 4*(lane>>4) + r)
     if (ks == nks - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -195,12 +200,11 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         for (int j = 0; j < 2; ++j) {
           const int cbase = n0 + wc * 32 + j * 16;
           if (rbase < M && cbase < N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              gptr cp = (gptr)C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;
-              const double v = acc[i][j][r];
-              if (mode == GM_SUB) *cp = cpre[i][j][r] - v; else if (mode == GM_SET) *cp = v; else *cp = -v;
-            }
+            double4_t v = acc[i][j];
+            if (mode == GM_SUB) v = cpre[i][j] - v; else if (mode == GM_NEG) v = -v;
+            typedef double2_t __attribute__((address_space(1)))* gptr2;
+            gptr2 cp2 = (gptr2)(C + (size_t)(rbase + fr) * ldc + cbase + 4 * fk);
+            cp2[0] = (double2_t){v[0], v[1]}; cp2[1] = (double2_t){v[2], v[3]};
           }
           acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
         }
@@ -834,8 +838,7 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
     const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
     const size_t kstep = TRANS ? (size_t)GKV * ldm : (size_t)GKV;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ra[q] = ok ? src[q] : 0.0;
+    TMPC_LD4(ra, 0, src, ok)
     for (int ks = 0; ks < nks; ++ks) {
       __syncthreads();
       if (TRANS) {
@@ -848,8 +851,7 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
       __syncthreads();
       if (ks + 1 < nks) {
         const double* s2 = src + (size_t)(ks + 1) * kstep;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = ok ? s2[q] : 0.0;
+        TMPC_LD4(ra, 0, s2, ok)
       }
       if (m0 + 16 * wv < rows) {
         const int k0 = ks * GKV;
