@@ -33,10 +33,25 @@ def factor_flops_per_problem(p, d):
     return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
 
 
+def hbm_traffic_per_launch():
+    """HBM bytes per k_factor launch from the committed PMC passes (profiles/r1_traffic.json); PMC counters cannot be
+    collected from inside this process, so this is the profiled value for the same launch geometry, or None."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def cpu_baseline(p_full, nx, mb, tol, budget_s=25.0):
     """Oracle (numpy/LAPACK restatement of the same algorithm) timed on host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import convexify_oracle as co
+    cores = min(os.cpu_count() or 1, 32)       # 300 x 300 blocks: more BLAS threads only add contention
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cores)
+    except Exception:
+        cores = int(os.environ.get('OPENBLAS_NUM_THREADS', os.cpu_count() or 1))
     p_s = min(p_full, 8)
     A, B, H, _, _ = co.gen_problem(424242, p_s, nx, mb)
     t0 = time.perf_counter()
@@ -48,7 +63,6 @@ def cpu_baseline(p_full, nx, mb, tol, budget_s=25.0):
         if el > budget_s or el + el / nprob > 1.3 * budget_s:
             break
     el = time.perf_counter() - t0
-    cores = int(os.environ.get('OPENBLAS_NUM_THREADS', os.cpu_count() or 1))
     return {"value": nprob * p_s / el, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
             "sample": f"oracle/convexify_oracle.py (numpy + OpenBLAS, {cores} threads) on {nprob} problem(s) of nx={nx}, m={mb}, "
                       f"p={p_s} (same stage size n={nx + mb} as the workload, shorter period; cost is linear in p), "
@@ -155,7 +169,9 @@ def main():
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F64_MFMA_TFLOPS,
+                         "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
                          "kernel": "k_factor<true> (block-cyclic-tridiagonal Cholesky, v_mfma_f64_16x16x4_f64)",
                          "avg_launch_ms": avg_ms, "launches": int(launches), "problems_per_launch": chunk,
                          "algorithmic_flops_per_launch": fl},
