@@ -192,13 +192,6 @@ static int set_lds_attrs() {
   HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_factor<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -535,14 +528,7 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
         HIPCHK(hipMemcpyAsync(w.F + b * per, pF, per * 8, hipMemcpyDeviceToDevice, 0));
       }
       HIPCHK(hipEventRecord(e0, 0));
-      if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 2) hipLaunchKernelGGL((k_factor<true, 2>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 4) hipLaunchKernelGGL((k_factor<true, 4>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 5) hipLaunchKernelGGL((k_factor<true, 5>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 6) hipLaunchKernelGGL((k_factor<true, 6>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 8) hipLaunchKernelGGL((k_factor<true, 8>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 7) hipLaunchKernelGGL((k_factor<true, 7>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0 && getenv("TMPC_ABL") && atoi(getenv("TMPC_ABL")) == 3) hipLaunchKernelGGL((k_factor<true, 3>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else if (v == 0) hipLaunchKernelGGL((k_factor<true, 0>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
+      if (v == 0) hipLaunchKernelGGL((k_factor<true, 0>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
       HIPCHK(hipEventRecord(e1, 0));
       HIPCHK(hipEventSynchronize(e1));

@@ -59,7 +59,7 @@ typedef double __attribute__((address_space(1)))* gptr;
 template <bool USE_MFMA>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
-                                           double* lds, bool btri = false) {
+                                           double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;
   // slab loader: row (0..63); each thread moves two 32-byte pieces, k = lk..lk+3 and 16+lk..16+lk+3, into two
@@ -143,7 +143,6 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       const double* As = lds + buf * (2 * SLABD);
       const double* Bs = As + SLABD;
       const int krem = K - ks * GK;
-      (void)btri;
       if (USE_MFMA) {
 #define TMPC_MFMA_STEP(kk)                                                                  \
   {                                                                                         \
@@ -216,118 +215,6 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     buf ^= 1;
     m0 = nm0; n0 = nn0; ks = nks_;
   }
-}
-
-// Variant with the global loads issued TWO slabs ahead (two register sets, same two LDS buffers): doubles the
-// bytes each workgroup keeps in flight.  Everything else as wg_gemm_nt.
-template <bool USE_MFMA>
-__device__ __forceinline__ void wg_gemm_nt_d2(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
-                                              int M, int N, int K, int mode, bool lower, double* lds) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;
-  const int lrow = tid >> 2, lk = (tid & 3) * 4;
-  const int nks = (K + GK - 1) / GK;
-  const int fr = lane & 15, fk = lane >> 4;
-  double4_t acc[2][2], cpre[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; cpre[i][j] = acc[i][j]; }
-  double ra[8], rb[8], rc[8], rd[8];
-#define TMPC_NEXT(m_, n_, k_, pm, pn, pk)                                               \
-  {                                                                                     \
-    m_ = pm; n_ = pn; k_ = pk + 1;                                                      \
-    if (k_ == nks) { k_ = 0; n_ = pn + 64; if (n_ >= N || (lower && n_ > m_)) { n_ = 0; m_ = pm + 64; } } \
-  }
-#define TMPC_LOAD(RA, RB, m_, n_, k_)                                                   \
-  if (m_ < M) {                                                                         \
-    const int kn = k_ * GK + lk;                                                        \
-    gcptr ap = (gcptr)(A + (size_t)(m_ + lrow) * lda + kn);                             \
-    gcptr bp = (gcptr)(B + (size_t)(n_ + lrow) * ldb + kn);                             \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                                  \
-      const bool kok = (kn + h2 * 16) < K;                                              \
-      const bool aok = (m_ + lrow < M) && kok, bok = (n_ + lrow < N) && kok;            \
-      TMPC_LD4(RA, h2 * 4, ap + h2 * 16, aok)                                            \
-      TMPC_LD4(RB, h2 * 4, bp + h2 * 16, bok)                                            \
-    }                                                                                   \
-  }
-#define TMPC_STORE(RA, RB, BUF)                                                         \
-  {                                                                                     \
-    double* An = lds + (BUF) * (2 * SLABD); double* Bn = An + SLABD;                    \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                    \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                   \
-        An[h2 * SUBD + lrow * SLD + lk + q] = RA[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = RB[h2 * 4 + q]; } \
-  }
-  int m0 = 0, n0 = 0, ks = 0, m1, n1, k1, m2, n2, k2;
-  TMPC_NEXT(m1, n1, k1, m0, n0, ks)
-  TMPC_LOAD(ra, rb, m0, n0, ks)
-  __syncthreads();
-  TMPC_STORE(ra, rb, 0)
-  TMPC_LOAD(ra, rb, m1, n1, k1)            // slab 1 in flight in (ra, rb)
-  __syncthreads();
-  int buf = 0;
-#define TMPC_STEP(RA, RB, RC, RD)                                                                  \
-  {                                                                                                \
-    TMPC_NEXT(m2, n2, k2, m1, n1, k1)                                                              \
-    TMPC_LOAD(RC, RD, m2, n2, k2)                        /* two slabs ahead */                     \
-    if (ks == 0 && mode == GM_SUB) {                                                               \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
-        const int rbase = m0 + wr * 32 + i * 16;                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
-          const int cbase = n0 + wc * 32 + j * 16;                                                 \
-          if (rbase < M && cbase < N) {                                                            \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                          \
-              cpre[i][j][r] = ((gcptr)C)[(size_t)(rbase + fk + 4 * r) * ldc + cbase + fr];        \
-          }                                                                                        \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-    {                                                                                              \
-      const double* As = lds + buf * (2 * SLABD);                                                  \
-      const double* Bs = As + SLABD;                                                               \
-      const int nkk = (K - ks * GK >= GK) ? GK / 4 : (K - ks * GK) / 4;                            \
-      _Pragma("unroll") for (int kk = 0; kk < GK / 4; ++kk) {                                      \
-        if (kk < nkk) {                                                                            \
-          const int so = (kk >> 2) * SUBD + (kk & 3) * 4 + fk;                                     \
-          const double a0 = As[so + (wr * 32 + fr) * SLD], a1 = As[so + (wr * 32 + 16 + fr) * SLD]; \
-          const double b0 = Bs[so + (wc * 32 + fr) * SLD], b1 = Bs[so + (wc * 32 + 16 + fr) * SLD]; \
-          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);            \
-          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);            \
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);            \
-          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);            \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-    if (m1 < M) TMPC_STORE(RA, RB, buf ^ 1)                                                        \
-    if (ks == nks - 1) {                                                                           \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
-        const int rbase = m0 + wr * 32 + i * 16;                                                   \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
-          const int cbase = n0 + wc * 32 + j * 16;                                                 \
-          if (rbase < M && cbase < N) {                                                            \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
-              gptr cp = (gptr)C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;                 \
-              const double v = acc[i][j][r];                                                       \
-              if (mode == GM_SUB) *cp = cpre[i][j][r] - v; else if (mode == GM_SET) *cp = v; else *cp = -v; \
-            }                                                                                      \
-          }                                                                                        \
-          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};                                             \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-    __syncthreads();                                                                               \
-    buf ^= 1;                                                                                      \
-    m0 = m1; n0 = n1; ks = k1; m1 = m2; n1 = n2; k1 = k2;                                          \
-  }
-  while (m0 < M) {
-    TMPC_STEP(ra, rb, rc, rd)
-    if (m0 >= M) break;
-    TMPC_STEP(rc, rd, ra, rb)
-  }
-#undef TMPC_STEP
-#undef TMPC_STORE
-#undef TMPC_LOAD
-#undef TMPC_NEXT
 }
 
 constexpr int GK0 = 16, GLD0 = 17;   // variant 0: single-buffered 16-column slabs, two barriers per slab (round-1 baseline)
@@ -420,120 +307,6 @@ __device__ __forceinline__ void wg_gemm_nt_v0(double* C, int ldc, const double* 
   __syncthreads();
 }
 
-
-// Big-tile variant for the K = dp Schur updates (D_{k+1} -= O O', D_{p-1} -= F F', F_{k+1} = -F O'):
-// workgroup tile up to 128 x 128 (waves 2 x 2, each up to 64 x 64 = 4 x 4 MFMA tiles, 128 accumulator registers),
-// K slabs of 16 columns, double-buffered, same flattened slab stream as wg_gemm_nt.  A 128-tile moves half the
-// operand bytes per flop of a 64-tile, which is what matters once two workgroups per CU make the 64-tile
-// kernel HBM-bound on panel re-reads.  Tile heights/widths are balanced (304 -> 112 + 96 + 96) instead of
-// 128 + 128 + 48.  The C fragment is read in the epilogue (no register budget for a prefetch copy).
-__device__ __forceinline__ void wg_gemm_nt_big(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
-                                               int M, int N, int K, int mode, bool lower, double* lds) {
-  constexpr int BK = 16, BLD = 17, BSL = 128 * BLD;          // slab: 128 rows x 16 k, leading dim 17
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;
-  const int lrow = tid >> 1, lk = (tid & 1) * 4;             // loader: row 0..127; k = lk..lk+3 and 8+lk..8+lk+3
-  const int fr = lane & 15, fk = lane >> 4;
-  const int nks = K / BK;
-  const int ntm = (M + 127) / 128, ntn = (N + 127) / 128;
-  const int th = ((M + ntm - 1) / ntm + 15) / 16 * 16;        // balanced tile height / width (multiples of 16)
-  const int tw = ((N + ntn - 1) / ntn + 15) / 16 * 16;
-  double4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  double ra[8], rb[8];
-  int m0 = 0, n0 = 0, ks = 0;
-  {
-    gcptr ap = (gcptr)(A + (size_t)lrow * lda + lk);
-    gcptr bp = (gcptr)(B + (size_t)lrow * ldb + lk);
-    const bool aok = (lrow < th) && (lrow < M), bok = (lrow < tw) && (lrow < N);
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 8 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 8 + q] : 0.0; }
-    __syncthreads();
-    double* As = lds; double* Bs = lds + BSL;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { As[lrow * BLD + h2 * 8 + lk + q] = ra[h2 * 4 + q]; Bs[lrow * BLD + h2 * 8 + lk + q] = rb[h2 * 4 + q]; }
-    __syncthreads();
-  }
-  int buf = 0;
-  while (m0 < M) {
-    int nm0 = m0, nn0 = n0, nks_ = ks + 1;
-    if (nks_ == nks) {
-      nks_ = 0; nn0 = n0 + tw;
-      if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + th; }
-    }
-    const bool more = nm0 < M;
-    if (more) {
-      const int kn = nks_ * BK + lk;
-      gcptr ap = (gcptr)(A + (size_t)(nm0 + lrow) * lda + kn);
-      gcptr bp = (gcptr)(B + (size_t)(nn0 + lrow) * ldb + kn);
-      const bool aok = (lrow < th) && (nm0 + lrow < M), bok = (lrow < tw) && (nn0 + lrow < N);
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ra[h2 * 4 + q] = aok ? ap[h2 * 8 + q] : 0.0; rb[h2 * 4 + q] = bok ? bp[h2 * 8 + q] : 0.0; }
-    }
-    // sub-tile validity of this wave (wave-uniform)
-    bool vi[4], vj[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wr * 64 + i * 16; vi[i] = (r < th) && (m0 + r < M); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = wc * 64 + j * 16; vj[j] = (c < tw) && (n0 + c < N) && !(lower && (n0 + c) > (m0 + th - 1)); }
-    {
-      const double* As = lds + buf * (2 * BSL);
-      const double* Bs = As + BSL;
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        double a[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + fr) * BLD + kk * 4 + fk];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = Bs[(wc * 64 + j * 16 + fr) * BLD + kk * 4 + fk];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (!vi[i]) continue;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (vj[j]) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    if (more) {
-      double* An = lds + (buf ^ 1) * (2 * BSL);
-      double* Bn = An + BSL;
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { An[lrow * BLD + h2 * 8 + lk + q] = ra[h2 * 4 + q]; Bn[lrow * BLD + h2 * 8 + lk + q] = rb[h2 * 4 + q]; }
-    }
-    if (ks == nks - 1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (vi[i] && vj[j]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              gptr cp = (gptr)C + (size_t)(m0 + wr * 64 + i * 16 + fk + 4 * r) * ldc + n0 + wc * 64 + j * 16 + fr;
-              const double v = acc[i][j][r];
-              if (mode == GM_SUB) *cp -= v; else if (mode == GM_SET) *cp = v; else *cp = -v;
-            }
-          }
-          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        }
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-    m0 = nm0; n0 = nn0; ks = nks_;
-  }
-}
 
 // The three Schur updates of one stage fused:  Dn -= O O',  Dl -= F F' (lower tiles),  Fn = -F O' (all tiles).
 // For a lower tile (r >= c) the four operand slabs O_r, F_r, O_c, F_c are staged once and feed three MFMA
@@ -638,14 +411,12 @@ __device__ __forceinline__ void wg_schur_fused(double* Dn, double* Dl, double* F
 #undef TMPC_FUSED_STORE
 }
 
+// VAR 0: round-1 baseline GEMM (kept for the A/B bench of tmpc_debug_factor_bench); VAR 1: current.
 template <bool USE_MFMA, int VAR>
 __device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N,
-                                        int K, int mode, bool lower, double* lds, bool btri = false) {
+                                        int K, int mode, bool lower, double* lds) {
   if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
-  else if (VAR == 7) { /* ablation: no panel GEMMs at all */ }
-  else if (VAR == 8) { if (USE_MFMA) wg_gemm_nt_d2<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
-  else if (VAR == 4) { if (K >= 128) wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds); }
-  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds, btri);
+  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
@@ -745,12 +516,12 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
       if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
     double* Ti = Linv_k + (size_t)jt * TB * TB;
-    if (VAR != 2) nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
+    nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
-      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds, true);
-    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds, true);
-    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds, true);
+      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
+    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
   }
   return nbad;
 }
@@ -785,21 +556,7 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
       }
       nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
       // Schur updates
-      if (VAR == 5) {
-        // ablation: no Schur updates
-      } else if (VAR == 6 || VAR == 8) {
-        wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
-        if (!last) {
-          wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-          wg_gemm<USE_MFMA, (VAR == 8 ? 8 : 1)>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
-        }
-      } else if (USE_MFMA && VAR == 3 && dp > 64) {
-        wg_gemm_nt_big(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
-        if (!last) {
-          wg_gemm_nt_big(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-          wg_gemm_nt_big(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
-        }
-      } else if (USE_MFMA && VAR == 1 && !last && k + 1 != p - 1) {
+      if (USE_MFMA && VAR == 1 && !last) {
         wg_schur_fused(D + (k + 1) * bs, D + (size_t)(p - 1) * bs, F + (k + 1) * bs, Ok, Fk, dp, lds);
       } else {
         wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
