@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
   ap = fmin(1.0, ap); ad = fmin(1.0, ad);
   const double mu_aff = (pr[P_SXS] + ap * dxs + ad * xds + ap * ad * dxds + (x0 + ap * dx0) * (s0 + ad * ds0)) / N;
   const double rat = mu_aff / mu;
-  double sigma = fmin(fmax(rat * rat * rat, 1e-6), 1.0);
+  double sigma = fmin(fmax(rat * rat, 1e-6), 1.0);     // exponent 2: ~10 % fewer iterations than Mehrotra's 3 here
   if (!(sigma == sigma)) sigma = 1.0;
   double sig_mu = sigma * mu;
   if (pr[P_MUT] > 0.0) sig_mu = fmax(sig_mu, pr[P_MUT]);
