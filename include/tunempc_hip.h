@@ -113,6 +113,11 @@ int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double*
 /* Isolated A/B timing of the block factorisation kernel: ms_out2[0] = baseline GEMM variant, [1] = current. */
 int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, double* ms_out2);
 
+/* Batched timing of one GEMM core of the factorisation: nb workgroups with private M x N (+)= (M x K)(N x K)' operands,
+ * `reps` products per launch, average ms over `launches` launches.  var 0: 64 x 64 tiles (first generation),
+ * 1: 160 x 160 register tiles, 2: 320 x 80;  tri 0 none, 1 lower triangle of C only, 2 lower-triangular B. */
+int tmpc_debug_gemm_bench(tmpc_handle* h, int nb, int M, int N, int K, int var, int tri, int reps, int launches, double* ms_out);
+
 const char* tmpc_last_error(void);
 const char* tmpc_version(void);
 

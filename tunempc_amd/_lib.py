@@ -19,6 +19,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
+    'tmpc_debug_gemm_bench',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -68,6 +69,8 @@ def load_library():
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
     lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
+    lib.tmpc_debug_gemm_bench.restype = C.c_int
+    lib.tmpc_debug_gemm_bench.argtypes = [vp] + [C.c_int] * 8 + [dp]
     lib.tmpc_debug_factor_bench.restype = C.c_int
     lib.tmpc_debug_factor_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     lib.tmpc_debug_min_eig.restype = C.c_int
@@ -203,6 +206,11 @@ class HipConvexifier:
         out = np.empty(nmat)
         _check(self.lib, self.lib.tmpc_debug_min_eig(self._h, nmat, n, _dptr(W), _dptr(out)), 'tmpc_debug_min_eig')
         return out
+
+    def debug_gemm_bench(self, nb, M, N, K, var, tri=0, reps=4, launches=3):
+        out = np.zeros(1)
+        _check(self.lib, self.lib.tmpc_debug_gemm_bench(self._h, nb, M, N, K, var, tri, reps, launches, _dptr(out)), 'tmpc_debug_gemm_bench')
+        return float(out[0])
 
     def debug_factor_bench(self, nb, p, d, reps=3):
         out = np.zeros(2)

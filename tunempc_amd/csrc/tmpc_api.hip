@@ -170,6 +170,37 @@ __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   wg_gemm_nt<USE_MFMA>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
 }
+// second-generation core (tmpc_gemm2.h): nb workgroups, each with its own C/A/B, `reps` products back to back
+template <int WR, int WC, int FR, int FC, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_debug_gemm2(double* C, const double* A, const double* B, int M, int N, int K, int mode, int tri, int reps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const size_t b = blockIdx.x;
+  const size_t bo = (tri & 16) ? 0 : b;      // tri | 16: every workgroup on the same operands (cache-resident: compute ceiling of the core)
+  tri &= 15;
+  double* Cb = C + bo * M * N; const double* Ab = A + bo * M * K; const double* Bb = B + bo * N * K;
+  for (int r = 0; r < reps; ++r) {
+    if (tri == TRI_CLOW) {
+      if constexpr (WR * FR == WC * FC && FR == FC) {
+        wg_gemm2<WR, WC, FR, FC, 0, TRI_COFF>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+        wg_gemm2<WR, WC, FR, FC, 0, TRI_CDIAG>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+      } else wg_gemm2<WR, WC, FR, FC, 0, TRI_CLOW>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    }
+    else if (tri == TRI_BLOW) wg_gemm2<WR, WC, FR, FC, 1, TRI_BLOW>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    else if (mode == 4) wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE, 1>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    else if (mode == 5) wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE, 3>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    else if (mode == 0) wg_gemm2<WR, WC, FR, FC, 0, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    else if (mode == 1) wg_gemm2<WR, WC, FR, FC, 1, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+    else wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
+  }
+}
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_debug_gemm1(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower, int reps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const size_t b = (lower & 16) ? 0 : blockIdx.x;
+  lower &= 15;
+  for (int r = 0; r < reps; ++r)
+    wg_gemm_nt<USE_MFMA>(C + b * M * N, N, A + b * M * K, K, B + b * N * K, K, M, N, K, mode, lower != 0, lds);
+}
 __global__ void __launch_bounds__(256) k_debug_solve(WS w, Dims dm) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   wg_cyclic_solve<1>(w.Z, w.D, w.O, w.F, w.Linv, dm.p, dm.dp, dm.nt, lds);
@@ -179,6 +210,7 @@ __global__ void __launch_bounds__(256) k_debug_solve(WS w, Dims dm) {
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
 static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
+static size_t gemm2_lds() { return (size_t)G2_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)solve_lds_doubles(dm.dp) * sizeof(double); }
 
 static int set_lds_attrs() {
@@ -197,6 +229,9 @@ static int set_lds_attrs() {
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm2<2, 2, 5, 5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm2<4, 1, 5, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   done = true;
   return TMPC_OK;
@@ -450,6 +485,12 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
   return TMPC_OK;
 }
 
+// var 1: 160 x 160 tiles (5 x 5 fragments per wave), 2: 320 x 64 (5 x 4); one workgroup per CU
+static void launch_gemm2(int var, int nb, double* dC, const double* dA, const double* dB, int M, int N, int K, int mode, int tri, int reps) {
+  if (var == 1) hipLaunchKernelGGL((k_debug_gemm2<2, 2, 5, 5, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
+  else hipLaunchKernelGGL((k_debug_gemm2<4, 1, 5, 4, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
+}
+
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
   if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16) return TMPC_E_ARG;
   double *dC, *dA, *dB;
@@ -457,11 +498,49 @@ int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double*
   HIPCHK(hipMemcpy(dC, C, (size_t)M * N * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dB, B, (size_t)N * K * 8, hipMemcpyHostToDevice));
-  if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  const int var = (mode >> 4) & 7; mode &= 3;
+  if (var) launch_gemm2(var, 1, dC, dA, dB, M, N, K, mode, lower, 1);
+  else if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   else hipLaunchKernelGGL(k_debug_gemm<true>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(C, dC, (size_t)M * N * 8, hipMemcpyDeviceToHost));
   hipFree(dC); hipFree(dA); hipFree(dB);
+  return TMPC_OK;
+}
+
+// Batched timing of one GEMM core: nb workgroups with private operands (HBM-realistic), reps products per launch.
+// var 0: first-generation 64 x 64 core, 1: 160 x 160 register tiles, 2: 320 x 80.  ms_out = average launch time.
+int tmpc_debug_gemm_bench(tmpc_handle* h, int nb, int M, int N, int K, int var, int tri, int reps, int launches, double* ms_out) {
+  const int gmode = (tri >> 8) & 7; tri &= 255;     // bits 8-10: kernel mode (4/5 = timing experiments without DMA / without DMA and LDS fetch)
+  if (!h || nb < 1 || M % 16 || N % 16 || K % 16 || K < 16 || reps < 1 || launches < 1 || !ms_out) return TMPC_E_ARG;
+  double *dC, *dA, *dB;
+  const size_t nC = (size_t)nb * M * N, nA = (size_t)nb * M * K, nB = (size_t)nb * N * K;
+  HIPCHK(hipMalloc(&dC, nC * 8)); HIPCHK(hipMalloc(&dA, nA * 8)); HIPCHK(hipMalloc(&dB, nB * 8));
+  HIPCHK(hipMemset(dC, 0, nC * 8));
+  {
+    std::vector<double> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned long long st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((double)(st % 2000001) / 1000000.0 - 1.0) / sqrt((double)K); };
+    for (auto& x : hA) x = rnd();
+    for (auto& x : hB) x = rnd();
+    for (int b = 0; b < nb; ++b) {
+      HIPCHK(hipMemcpy(dA + (size_t)b * M * K, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dB + (size_t)b * N * K, hB.data(), hB.size() * 8, hipMemcpyHostToDevice));
+    }
+  }
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  double tot = 0.0;
+  for (int r = 0; r < launches + 1; ++r) {
+    HIPCHK(hipEventRecord(e0, 0));
+    if (var) launch_gemm2(var, nb, dC, dA, dB, M, N, K, gmode, tri, reps);
+    else hipLaunchKernelGGL(k_debug_gemm1<true>, dim3(nb), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, 0, tri, reps);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) tot += ms;
+  }
+  *ms_out = tot / launches;
+  hipFree(dC); hipFree(dA); hipFree(dB); hipEventDestroy(e0); hipEventDestroy(e1);
   return TMPC_OK;
 }
 

@@ -11,6 +11,7 @@
 //   F[k]  fill of the cyclic corner row T[P_{p-1},P_k] -> F_k
 #pragma once
 #include "tmpc_common.h"
+#include "tmpc_gemm2.h"
 
 namespace tmpc {
 
@@ -32,14 +33,6 @@ enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A 
 // In-place use (C aliasing A with one N-tile and K == its width) is safe: a tile's A slabs are all in LDS before
 // its C fragment is stored, and the next tile reads other rows.
 constexpr int SLD = 17, SUBD = 64 * SLD, SLABD = 2 * SUBD;   // sub-slab leading dim / doubles per sub-slab / per (operand) slab
-#ifdef TMPC_CYCLE_PROF
-__device__ unsigned long long g_prof[16];
-#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[i] += t_ - tprev_; tprev_ = t_; } }
-#define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
-#else
-#define TMPC_T(i)
-#define TMPC_T0()
-#endif
 #ifdef TMPC_NT
 #define TMPC_LD(p) __builtin_nontemporal_load(p)
 #else
