@@ -421,9 +421,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation
             # at the rounding floor, or on the iteration cap
             full = (ap == 1.0 and ad == 1.0)
-            # extrapolated next step (contraction factor of the last two full steps): stop one iteration early
-            # when Newton is already converging super-linearly
-            est = stepn * min(1.0, stepn / prev_stepn) if prev_stepn is not None else stepn
+            # extrapolated next step from the contraction r of the last two full steps: r * stepn if Newton converged
+            # linearly, r^2 * stepn in its quadratic regime; r^1.5 sits between the two and stops one iteration early
+            # when the convergence is already super-linear
+            est = stepn * min(1.0, stepn / prev_stepn) ** 1.5 if prev_stepn is not None else stepn
             if full and (stepn < o['center_tol'] or est < 0.1 * o['center_tol']):
                 status = 'optimal'
                 break

@@ -55,6 +55,30 @@ def test_mfma_gemm_nt(hc, M, N, K, flags):
     h.set_options(flags=0)
 
 
+@pytest.mark.parametrize('M,N,K,var,mode,tri', [
+    (304, 304, 304, 1, 0, 0), (304, 304, 304, 1, 1, 0), (304, 304, 304, 1, 2, 0), (304, 304, 304, 1, 0, 1), (496, 496, 496, 1, 0, 1),
+    (608, 304, 304, 1, 2, 0), (16, 16, 16, 1, 0, 0), (32, 32, 304, 1, 0, 1), (304, 64, 256, 2, 0, 0), (240, 64, 64, 2, 0, 0),
+    (304, 64, 64, 2, 1, 2), (48, 48, 48, 2, 1, 2), (336, 96, 64, 2, 0, 0)])
+def test_register_tile_gemm_core(hc, M, N, K, var, mode, tri):
+    """Experimental second-generation core (tmpc_gemm2.h: v_mfma_f64_4x4x4, LDS-DMA, three-buffer pipeline; reached only
+    through the debug entry) vs numpy: all modes, ragged edges, symmetric (lower-only) output, triangular B."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(M * 1000 + N + K + var)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
+    if tri == 2:
+        B = np.tril(B)
+    out = h.debug_gemm_nt(C0, A, B, mode=mode | (var << 4), lower=tri)
+    P = A @ B.T
+    ref = C0 - P if mode == 0 else (P if mode == 1 else -P)
+    if tri == 1:      # only the fragments on and below the diagonal are written
+        nf = M // 16
+        mask = np.kron(np.tril(np.ones((nf, nf))), np.ones((16, 16))) > 0
+        assert np.abs(out - ref)[mask].max() < 1e-12 * K
+        assert np.abs(out - C0)[~mask].max() == 0.0
+    else:
+        assert np.abs(out - ref).max() < 1e-12 * K
+
+
 def _spd_cyclic(rng, p, d):
     E = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d); F = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d)
     D = np.stack([np.eye(d) for _ in range(p)]); Cc = np.zeros((p, d, d))

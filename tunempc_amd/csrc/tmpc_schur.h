@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
   if (ip[I_PHASE] == PH_CENTER) {
     const bool full = (pr[P_AP] == 1.0 && pr[P_AD] == 1.0);
     const double stepn = pr[P_STEPN], prev = pr[P_PREVSTEPN];
-    const double est = (prev >= 0.0) ? stepn * fmin(1.0, stepn / prev) : stepn;     // extrapolated next step
+    const double rr = (prev >= 0.0) ? fmin(1.0, stepn / prev) : 1.0;                 // contraction of the last two full steps
+    const double est = stepn * rr * sqrt(rr);     // extrapolated next step: between linear (r) and quadratic (r^2) convergence
     if (full && (stepn < o.center_tol || est < 0.1 * o.center_tol)) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
