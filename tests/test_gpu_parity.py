@@ -298,3 +298,38 @@ def test_full_size_c4_properties(hc):
     # idempotence of the pre-check: convexified Hessians are already convex -> early exit, zero supplement
     again = h.convexify_batch(A, B, out['Hc'])
     assert (again['info'][:, 13] == 1).all() and not again['dHc'].any()
+
+
+# ----------------------------------------------------------------------------- consumer row: tracking reference
+@pytest.mark.parametrize('n,ns', [(4, 1), (5, 30), (15, 40), (32, 257)])
+def test_tracking_reference_parity(hc, n, ns):
+    """tmpc_tracking_reference_host vs the numpy restatement of pmpc.py:961-974 (W = Hc/ts, yref = wref - Hc^-1 q)."""
+    from oracle import tracking_oracle
+    h = hc(1, n, 0)
+    rng = np.random.default_rng(n * 100 + ns)
+    X = rng.standard_normal((ns, n, n)); H = X @ np.swapaxes(X, 1, 2) / n + 0.3 * np.eye(n)
+    q = rng.standard_normal((ns, n)); w = rng.standard_normal((ns, n))
+    W, y, info = h.tracking_reference(H, q, w, 0.05)
+    Wr, yr = tracking_oracle.tracking_reference(H, q, w, 0.05)
+    assert not info.any()
+    assert rel(W, Wr) < 1e-15 and rel(y, yr) < 1e-11
+    Hbad = H.copy(); Hbad[0] = -Hbad[0]
+    _, _, info = h.tracking_reference(Hbad, q, w, 0.05)
+    assert info[0] > 0 and not info[1:].any()
+
+
+def test_tracking_reference_python_mirror(hc):
+    """tunempc_amd.pmpc.tracking_reference over lists (the shapes Pmpc holds: q rows 1 x n, wref columns n x 1) after a real convexify."""
+    from tunempc_amd import pmpc, convexifier
+    from oracle import convexify_oracle as orc, tracking_oracle
+    A, B, H = orc.gen_problem(20, 6, 3, 2)[:3]
+    Q = [H[k][:3, :3] for k in range(6)]; R = [H[k][3:, 3:] for k in range(6)]; N = [H[k][:3, 3:] for k in range(6)]
+    dHc, _, _, _ = convexifier.convexify(list(A), list(B), Q, R, N, opts={'rho': 1e-3, 'solver': 'hip', 'force': False})
+    Hc = [H[k] + dHc[k] for k in range(6)]
+    rng = np.random.default_rng(1)
+    q = [rng.standard_normal((1, 5)) for _ in range(6)]; w = [rng.standard_normal((5, 1)) for _ in range(6)]
+    W, y = pmpc.tracking_reference(Hc, q, w, 0.2)
+    Wr, yr = tracking_oracle.tracking_reference(np.stack(Hc), np.stack([v[0] for v in q]), np.stack([v[:, 0] for v in w]), 0.2)
+    assert rel(np.stack(W), Wr) < 1e-14 and rel(np.stack(y), yr) < 1e-10
+    with pytest.raises(ValueError, match='not positive definite'):
+        pmpc.tracking_reference([-m for m in Hc], q, w, 0.2)

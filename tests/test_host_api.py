@@ -62,7 +62,7 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith(('.py', '.h', '.hip')):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert 'convexify_oracle' not in txt and 'proto_dense' not in txt, (dirpath, f)
+                assert 'convexify_oracle' not in txt and 'proto_dense' not in txt and 'tracking_oracle' not in txt, (dirpath, f)
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), (dirpath, f)
 
 
@@ -104,3 +104,30 @@ def test_g_argument_is_rejected_loudly():
     A = np.eye(2) * 0.5; B = np.ones((2, 1)); Q = -np.eye(2); R = np.eye(1); N = np.zeros((2, 1))
     with pytest.raises(NotImplementedError):
         convexifier.convexify(A, B, Q, R, N, G=np.ones((1, 3)))
+
+
+def test_rotate_tuning_mirrors_reference_indexing():
+    """pmpc.py:773-781: Href[k][j] = H[(k + j) % Nref]."""
+    from tunempc_amd import pmpc
+    from oracle import tracking_oracle
+    H = [np.full((2, 2), float(i)) for i in range(5)]; q = [np.full((1, 2), 10.0 + i) for i in range(5)]
+    Href, qref = pmpc.rotate_tuning(H, q, 7)
+    assert len(Href) == 5 and all(len(r) == 7 for r in Href)
+    assert Href[3][4][0, 0] == (3 + 4) % 5 and qref[4][6][0, 0] == 10.0 + (4 + 6) % 5
+    assert [[m[0, 0] for m in row] for row in Href] == [[m[0, 0] for m in row] for row in tracking_oracle.rotate(H, 7)]
+    with pytest.raises(AssertionError):
+        pmpc.rotate_tuning(H, q[:-1], 3)
+
+
+def test_tracking_oracle_closed_form():
+    """yref = wref - (H/ts)^-1 q/ts = wref - H^-1 q and W = H/ts (pmpc.py:961-974); ts cancels in yref."""
+    from oracle import tracking_oracle
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((6, 5, 5)); H = X @ np.swapaxes(X, 1, 2) + 0.5 * np.eye(5)
+    q = rng.standard_normal((6, 5)); w = rng.standard_normal((6, 5))
+    W1, y1 = tracking_oracle.tracking_reference(H, q, w, 0.1)
+    W2, y2 = tracking_oracle.tracking_reference(H, q, w, 7.0)
+    assert np.allclose(y1, y2, rtol=0, atol=1e-12) and np.allclose(W1 * 0.1, W2 * 7.0)
+    for k in range(6):
+        assert np.allclose(H[k] @ (w[k] - y1[k]), q[k], atol=1e-12)
+        assert np.allclose(y1[k], w[k] - np.linalg.inv(H[k] / 0.1) @ q[k] / 0.1, atol=1e-12)   # the reference's expression verbatim

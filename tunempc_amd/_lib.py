@@ -19,7 +19,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
-    'tmpc_debug_gemm_bench',
+    'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -69,6 +69,8 @@ def load_library():
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
     lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
+    lib.tmpc_tracking_reference_host.restype = C.c_int
+    lib.tmpc_tracking_reference_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_double, dp, dp, ip]
     lib.tmpc_debug_gemm_bench.restype = C.c_int
     lib.tmpc_debug_gemm_bench.argtypes = [vp] + [C.c_int] * 8 + [dp]
     lib.tmpc_debug_factor_bench.restype = C.c_int
@@ -206,6 +208,20 @@ class HipConvexifier:
         out = np.empty(nmat)
         _check(self.lib, self.lib.tmpc_debug_min_eig(self._h, nmat, n, _dptr(W), _dptr(out)), 'tmpc_debug_min_eig')
         return out
+
+    def tracking_reference(self, Hc, q, wref, ts):
+        """W_k = sym(Hc_k)/ts, yref_k = wref_k - Hc_k^-1 q_k for a stack of stages (pmpc.py:961-974).
+        Hc [..., n, n], q/wref [..., n] -> (W [..., n, n], yref [..., n], info [...])."""
+        Hc = np.ascontiguousarray(Hc, dtype=np.float64); q = np.ascontiguousarray(q, dtype=np.float64)
+        wref = np.ascontiguousarray(wref, dtype=np.float64)
+        n = self.nx + self.mb
+        if Hc.shape[-2:] != (n, n) or q.shape != Hc.shape[:-1] or wref.shape != q.shape:
+            raise ValueError('tracking_reference: expected Hc [..., %d, %d] and q, wref [..., %d]' % (n, n, n))
+        ns = int(np.prod(Hc.shape[:-2], dtype=np.int64))
+        W = np.empty_like(Hc); yref = np.empty_like(q); info = np.zeros(Hc.shape[:-2], dtype=np.int32)
+        _check(self.lib, self.lib.tmpc_tracking_reference_host(self._h, ns, _dptr(Hc), _dptr(q), _dptr(wref), float(ts), _dptr(W), _dptr(yref),
+                                                              info.ctypes.data_as(C.POINTER(C.c_int32))), 'tmpc_tracking_reference_host')
+        return W, yref, info
 
     def debug_gemm_bench(self, nb, M, N, K, var, tri=0, reps=4, launches=3):
         out = np.zeros(1)

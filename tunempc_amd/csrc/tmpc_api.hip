@@ -153,6 +153,37 @@ __global__ void __launch_bounds__(64) k_supplement(const double* A, const double
   s2g_sym(dHc + (size_t)sid * n * n, sM, n, lane);
 }
 
+// Tracking-MPC reference (pmpc.py:961-974): W = sym(Hc)/ts, yref = wref - Hc^-1 q by Cholesky + two substitutions.
+// One single-wave block per stage.
+__global__ void __launch_bounds__(64) k_tracking_ref(const double* Hc, const double* q, const double* wref, double inv_ts,
+                                                     double* W, double* yref, int* info, int n) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const size_t sid = blockIdx.x;
+  const int lane = threadIdx.x;
+  double* A = sm; double* v = sm + MS;
+  const double* Hg = Hc + sid * n * n;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
+  if (lane < n) v[lane] = q[sid * n + lane];
+  wsync();
+  if (W) for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; W[sid * n * n + e] = A[i * LD + j] * inv_ts; }
+  wsync();
+  const int nbad = chol_lower(A, n, lane);
+  for (int j = 0; j < n; ++j) {             // L z = q
+    if (lane == j) v[j] /= A[j * LD + j];
+    wsync();
+    if (lane > j && lane < n) v[lane] -= A[lane * LD + j] * v[j];
+    wsync();
+  }
+  for (int j = n - 1; j >= 0; --j) {        // L' x = z
+    if (lane == j) v[j] /= A[j * LD + j];
+    wsync();
+    if (lane < j) v[lane] -= A[j * LD + lane] * v[j];
+    wsync();
+  }
+  if (lane < n) yref[sid * n + lane] = wref[sid * n + lane] - v[lane];
+  if (info && lane == 0) info[sid] = nbad;
+}
+
 // ---------------------------------------------------------------------------------- debug kernels
 __global__ void __launch_bounds__(64) k_debug_min_eig(const double* W, double* out, int n) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -489,6 +520,30 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
 static void launch_gemm2(int var, int nb, double* dC, const double* dA, const double* dB, int M, int N, int K, int mode, int tri, int reps) {
   if (var == 1) hipLaunchKernelGGL((k_debug_gemm2<2, 2, 5, 5, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
   else hipLaunchKernelGGL((k_debug_gemm2<4, 1, 5, 4, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
+}
+
+int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, const double* q, const double* wref,
+                                 double ts, double* W, double* yref, int32_t* info) {
+  if (!h || nstage < 1 || !Hc || !q || !wref || !yref || !(ts > 0.0)) return TMPC_E_ARG;
+  const int n = h->dm.n;
+  const size_t nn = (size_t)n * n;
+  double *dH = nullptr, *dW = nullptr, *dv = nullptr;     // dv: q | wref | yref
+  int* di = nullptr;
+  HIPCHK(hipMalloc(&dH, (size_t)nstage * nn * 8));
+  if (W) HIPCHK(hipMalloc(&dW, (size_t)nstage * nn * 8));
+  HIPCHK(hipMalloc(&dv, (size_t)nstage * n * 3 * 8));
+  HIPCHK(hipMalloc(&di, (size_t)nstage * sizeof(int)));
+  HIPCHK(hipMemcpy(dH, Hc, (size_t)nstage * nn * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dv, q, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dv + (size_t)nstage * n, wref, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_tracking_ref, dim3((unsigned)nstage), dim3(64), (size_t)(MS + 64) * sizeof(double), 0, dH, dv, dv + (size_t)nstage * n,
+                     1.0 / ts, dW, dv + (size_t)2 * nstage * n, di, n);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(yref, dv + (size_t)2 * nstage * n, (size_t)nstage * n * 8, hipMemcpyDeviceToHost));
+  if (W) HIPCHK(hipMemcpy(W, dW, (size_t)nstage * nn * 8, hipMemcpyDeviceToHost));
+  if (info) HIPCHK(hipMemcpy(info, di, (size_t)nstage * sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(dH); if (dW) hipFree(dW); hipFree(dv); hipFree(di);
+  return TMPC_OK;
 }
 
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
