@@ -131,3 +131,53 @@ def test_tracking_oracle_closed_form():
     for k in range(6):
         assert np.allclose(H[k] @ (w[k] - y1[k]), q[k], atol=1e-12)
         assert np.allclose(y1[k], w[k] - np.linalg.inv(H[k] / 0.1) @ q[k] / 0.1, atol=1e-12)   # the reference's expression verbatim
+
+
+def test_sensitivity_postprocessing_mirrors_reference():
+    """pocp.py:322-361 restated with explicit loops (the reference's own formulation) vs tunempc_amd.pocp."""
+    from tunempc_amd import pocp
+    rng = np.random.default_rng(5)
+    p, nx, nu, nh = 4, 3, 2, 3
+    n = nx + nu
+    C = [rng.standard_normal((nh, n)) for _ in range(p)]
+    mu = [np.array([0.0, 1e-3, 0.0]), np.zeros(3), np.array([2.0, 0.0, -1e-9]), np.array([1e-16, 0.0, 0.0])]
+    C_As, idx = pocp.active_set(C, mu)
+    assert idx == [[1], [], [0, 2], []]                          # 1e-16 is below the 1e-15 threshold of pocp.py:73
+    assert C_As[1] is None and C_As[3] is None
+    assert np.array_equal(C_As[0], C[0][[1]]) and np.array_equal(C_As[2], C[2][[0, 2]])
+    q = pocp.cost_gradient(mu, C)
+    for k in range(p):
+        ref = np.zeros((1, n))
+        for i in range(nh):
+            ref -= mu[k][i] * C[k][i:i + 1, :]
+        assert q[k].shape == (1, n) and np.allclose(q[k], ref, atol=1e-15)
+    assert all(np.array_equal(v, np.zeros((1, n))) for v in pocp.cost_gradient(None, None, N=p, n=n))
+    Hbig = rng.standard_normal((p * n + 2, p * n + 2))
+    Hs = pocp.stage_hessians(Hbig, n, p)
+    assert len(Hs) == p and all(np.array_equal(Hs[i], Hbig[i * n:(i + 1) * n, i * n:(i + 1) * n]) for i in range(p))
+
+
+def test_pack_batch_layout():
+    from tunempc_amd import pocp
+    rng = np.random.default_rng(6)
+    p, nx, nu = 3, 2, 1
+    n = nx + nu
+
+    def one(seed, with_c):
+        r = np.random.default_rng(seed)
+        S = {'A': [r.standard_normal((nx, nx)) for _ in range(p)], 'B': [r.standard_normal((nx, nu)) for _ in range(p)],
+             'H': [r.standard_normal((n, n)) for _ in range(p)], 'q': [r.standard_normal((1, n)) for _ in range(p)]}
+        if with_c:
+            S['C_As'] = [r.standard_normal((2, n)), None, r.standard_normal((1, n))]
+        return S
+    S0, S1 = one(1, True), one(2, False)
+    out = pocp.pack_batch([S0, S1], nx)
+    assert out['A'].shape == (2, p, nx, nx) and out['B'].shape == (2, p, nx, nu) and out['H'].shape == (2, p, n, n)
+    assert out['A'].flags['C_CONTIGUOUS'] and out['H'].dtype == np.float64
+    assert np.array_equal(out['H'][1, 2], S1['H'][2]) and np.array_equal(out['q'][0, 1], S0['q'][1][0])
+    assert out['nc'].tolist() == [[2, 0, 1], [0, 0, 0]] and out['C'].shape == (2, p, 2, n)
+    assert np.array_equal(out['C'][0, 2, 0], S0['C_As'][2][0]) and not out['C'][0, 2, 1].any() and not out['C'][1].any()
+    with pytest.raises(AssertionError, match='same length'):
+        pocp.pack_batch([S0, {**S1, 'A': S1['A'][:-1]}], nx)
+    with pytest.raises(AssertionError, match='same size along trajectory'):
+        pocp.pack_batch([{**S1, 'H': [S1['H'][0], np.eye(n + 1), S1['H'][2]]}], nx)
