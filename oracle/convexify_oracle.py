@@ -321,7 +321,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             break
         if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
             mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau))))
-        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and pinf < 1e-6:
+        # (a full Newton step removes the linear residuals: centering may start with pinf well above the final accuracy)
+        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and pinf < 1e-3:
             phase = 1
         if phase == 0 and it >= o['max_iter']:
             break
