@@ -90,6 +90,12 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nb, const double* dA, const 
 
 /* convexHessianSuppl (convexifier.py:165-211) alone: dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E). */
 int tmpc_supplement_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, double* dHc);
+/* The same with the constraint and regularisation terms of convexifier.py:196-204:
+ *   dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E + J_k' diag(w_k) J_k + T_k),
+ * J [nb][p][nr][n]: rows of G_k (weights Fg_k) followed by rows of C_k (weights F_k), zero-weight padding up to nr rows
+ * per stage (ragged C_k, per-stage None = all weights zero); wts [nb][p][nr]; T [nb][p][n][n].  J/wts and T may be NULL. */
+int tmpc_supplement_terms_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, int nr,
+                                     const double* J, const double* wts, const double* T, double* dHc);
 
 /* Consumer side of the tuned matrices, the tracking-MPC reference update (pmpc.py:961-974; set-up :594-609):
  *   W_k = sym(Hc_k) / ts,   yref_k = wref_k - (Hc_k/ts)^-1 q_k / ts = wref_k - Hc_k^-1 q_k      for nstage independent stages.

@@ -100,10 +100,21 @@ def calH_adj(A, B, G):
     return np.roll(W, 1, axis=0) - G[:, :nx, :nx]
 
 
-def convex_hessian_suppl(A, B, P):
-    """convexifier.py:165-211 without G/C/T terms: dHc_k = sym(calH_k(P)); slices dQ,dR,dN."""
+def convex_hessian_suppl(A, B, P, G=None, Fg=None, C=None, F=None, T=None):
+    """convexifier.py:165-211: dHc_k = sym(calH_k(P) [+ G_k' diag(Fg_k) G_k] [+ C_k' diag(F_k) C_k] [+ T_k]); slices
+    dQ, dR, dN.  G [p,ng,n], Fg [p,ng]; C, F: lists of p entries ((nc_k x n) / (nc_k) or None, :198-201); T [p,n,n]."""
     nx = A.shape[1]
-    dH = symmetrize(calH(A, B, P))
+    Hco = calH(A, B, P).copy()
+    for i in range(A.shape[0]):
+        if G is not None:
+            Gi = np.asarray(G[i], dtype=np.float64)
+            Hco[i] = Hco[i] + Gi.T @ np.diagflat(np.asarray(Fg[i], dtype=np.float64)) @ Gi            # :196-197
+        if F is not None and C is not None and C[i] is not None:
+            Ci = np.asarray(C[i], dtype=np.float64)
+            Hco[i] = Hco[i] + Ci.T @ np.diagflat(np.asarray(F[i], dtype=np.float64)) @ Ci             # :198-201
+        if T is not None:
+            Hco[i] = Hco[i] + np.asarray(T[i], dtype=np.float64)                                      # :202-203
+    dH = symmetrize(Hco)
     return dH, dH[:, :nx, :nx], dH[:, nx:, nx:], dH[:, :nx, nx:]
 
 

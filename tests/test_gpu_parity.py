@@ -333,3 +333,25 @@ def test_tracking_reference_python_mirror(hc):
     assert rel(np.stack(W), Wr) < 1e-14 and rel(np.stack(y), yr) < 1e-10
     with pytest.raises(ValueError, match='not positive definite'):
         pmpc.tracking_reference([-m for m in Hc], q, w, 0.2)
+
+
+def test_supplement_with_constraint_and_regularisation_terms(hc):
+    """convexHessianSuppl with the G/Fg, ragged C/F and T terms (convexifier.py:196-204) vs the numpy restatement."""
+    from tunempc_amd import convexifier
+    from oracle import convexify_oracle as orc
+    rng = np.random.default_rng(11)
+    p, nx, mb, ng = 5, 4, 2, 3
+    n = nx + mb
+    A = rng.standard_normal((p, nx, nx)); B = rng.standard_normal((p, nx, mb))
+    P = rng.standard_normal((p, nx, nx)); P = P + np.swapaxes(P, 1, 2)
+    G = [rng.standard_normal((ng, n)) for _ in range(p)]; Fg = [rng.uniform(0, 1, (ng, 1)) for _ in range(p)]
+    C = [rng.standard_normal((2, n)), None, rng.standard_normal((1, n)), rng.standard_normal((3, n)), None]
+    F = [rng.uniform(0, 1, (2, 1)), None, rng.uniform(0, 1, (1, 1)), rng.uniform(0, 1, (3, 1)), None]
+    T = [rng.uniform(0, 1, (n, n)) for _ in range(p)]
+    Q = R = N = None
+    for kw in [dict(), dict(G=G, Fg=Fg), dict(C=C, F=F), dict(T=T), dict(G=G, Fg=Fg, C=C, F=F, T=T), dict(C=C)]:
+        dHc, dQc, dRc, dNc = convexifier.convexHessianSuppl(list(A), list(B), Q, R, N, list(P), **kw)
+        ref = orc.convex_hessian_suppl(A, B, P, **kw)
+        assert rel(np.stack(dHc), ref[0]) < 1e-14, kw.keys()
+        assert rel(np.stack(dQc), ref[1]) < 1e-14 and rel(np.stack(dRc), ref[2]) < 1e-14 and rel(np.stack(dNc), ref[3]) < 1e-14
+        assert all(np.array_equal(d, d.T) for d in dHc)

@@ -132,3 +132,27 @@ def test_gap_tolerance_reported():
     r5 = co.convexify_arrays(A, B, H, dict(tol=1e-5 / N))
     r4 = co.convexify_arrays(A, B, H, dict(tol=1e-4 / N))
     assert 0 <= r4['kappa'] - r5['kappa'] <= 1.5e-4 * r4['kappa']
+
+
+def test_supplement_terms_restatement():
+    """convex_hessian_suppl with G/C/T terms against the reference's per-stage expressions written out (convexifier.py:190-206)."""
+    rng = np.random.default_rng(2)
+    p, nx, mb = 3, 3, 2
+    n = nx + mb
+    A = rng.standard_normal((p, nx, nx)); B = rng.standard_normal((p, nx, mb))
+    P = rng.standard_normal((p, nx, nx)); P = P + np.swapaxes(P, 1, 2)
+    G = [rng.standard_normal((2, n)) for _ in range(p)]; Fg = [rng.uniform(0, 1, (2, 1)) for _ in range(p)]
+    C = [rng.standard_normal((1, n)), None, rng.standard_normal((2, n))]; F = [rng.uniform(0, 1, (1, 1)), None, rng.uniform(0, 1, (2, 1))]
+    T = [rng.uniform(0, 1, (n, n)) for _ in range(p)]
+    dH, dQ, dR, dN = co.convex_hessian_suppl(A, B, P, G=G, Fg=Fg, C=C, F=F, T=T)
+    for i in range(p):
+        dP1, dP2 = P[i], P[(i + 1) % p]
+        Qco = A[i].T @ dP2 @ A[i] - dP1; Rco = B[i].T @ dP2 @ B[i]; Nco = (B[i].T @ dP2.T @ A[i]).T
+        Hco = np.block([[Qco, Nco], [Nco.T, Rco]])
+        Hco = Hco + G[i].T @ np.diagflat(Fg[i]) @ G[i]
+        if C[i] is not None:
+            Hco = Hco + C[i].T @ np.diagflat(F[i]) @ C[i]
+        Hco = Hco + T[i]
+        Hs = (Hco + Hco.T) / 2
+        assert np.allclose(dH[i], Hs, atol=1e-13)
+        assert np.array_equal(dQ[i], dH[i][:nx, :nx]) and np.array_equal(dR[i], dH[i][nx:, nx:]) and np.array_equal(dN[i], dH[i][:nx, nx:])

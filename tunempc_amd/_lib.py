@@ -19,7 +19,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
-    'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host',
+    'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -69,6 +69,8 @@ def load_library():
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
     lib.tmpc_debug_block_solve.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, ip]
+    lib.tmpc_supplement_terms_batch_host.restype = C.c_int
+    lib.tmpc_supplement_terms_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, dp]
     lib.tmpc_tracking_reference_host.restype = C.c_int
     lib.tmpc_tracking_reference_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_double, dp, dp, ip]
     lib.tmpc_debug_gemm_bench.restype = C.c_int
@@ -173,6 +175,23 @@ class HipConvexifier:
         nb = A.shape[0]
         dH = np.empty((nb, self.p, self.n, self.n))
         _check(self.lib, self.lib.tmpc_supplement_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(P), _dptr(dH)), 'tmpc_supplement_batch_host')
+        return dH
+
+    def supplement_terms_batch(self, A, B, P, J=None, wts=None, T=None):
+        """dHc = sym(calH(P) + J' diag(w) J + T) per stage (convexifier.py:165-211); J [nb,p,nr,n], wts [nb,p,nr], T [nb,p,n,n]."""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        nb, nr = A.shape[0], 0
+        if J is not None:
+            J = np.ascontiguousarray(J, dtype=np.float64); wts = np.ascontiguousarray(wts, dtype=np.float64)
+            nr = J.shape[2]
+            assert J.shape == (nb, self.p, nr, self.n) and wts.shape == (nb, self.p, nr), (J.shape, wts.shape)
+        if T is not None:
+            T = np.ascontiguousarray(T, dtype=np.float64)
+            assert T.shape == (nb, self.p, self.n, self.n), T.shape
+        dH = np.empty((nb, self.p, self.n, self.n))
+        _check(self.lib, self.lib.tmpc_supplement_terms_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(P), nr, _dptr(J), _dptr(wts), _dptr(T), _dptr(dH)),
+               'tmpc_supplement_terms_batch_host')
         return dH
 
     def eig_scan(self, H):

@@ -136,12 +136,33 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
 
 
 def convexHessianSuppl(A, B, Q, R, N, dP, G=None, Fg=None, C=None, F=None, T=None):
-    """Construct the convexified Hessian supplement from dP (convexifier.py:165-211), on the GPU."""
-    if G or F or T:
-        raise NotImplementedError('G/F/T terms of convexHessianSuppl are not built yet')
+    """Construct the convexified Hessian supplement from dP (convexifier.py:165-211), on the GPU:
+    dHc_k = sym(A'P+A - P etc. [+ G_k' diag(Fg_k) G_k] [+ C_k' diag(F_k) C_k] [+ T_k]).  As in the reference the G term
+    needs Fg, the C term is applied only when F is given and C_k is not None (:198-201)."""
     As = np.stack([_to_array(a) for a in A]); Bs = np.stack([_to_array(b) for b in B])
     Ps = np.stack([_to_array(p_) for p_ in dP])
     period, nx, _ = As.shape
-    dH = _handle(period, nx, Bs.shape[2]).supplement_batch(As[None], Bs[None], Ps[None])[0]
+    n = nx + Bs.shape[2]
+    rows = [[] for _ in range(period)]; wts = [[] for _ in range(period)]
+    if G:
+        for i in range(period):
+            Gi = _to_array(G[i]); fi = np.reshape(_to_array(Fg[i]), (-1,))
+            assert Gi.shape == (fi.shape[0], n), 'G_k (ng x n) and Fg_k (ng) expected'
+            rows[i].append(Gi); wts[i].append(fi)
+    if F:
+        for i in range(period):
+            if C[i] is not None:
+                Ci = _to_array(C[i]); fi = np.reshape(_to_array(F[i]), (-1,))
+                assert Ci.shape == (fi.shape[0], n), 'C_k (nc_k x n) and F_k (nc_k) expected'
+                rows[i].append(Ci); wts[i].append(fi)
+    nr = max(sum(r.shape[0] for r in rows[i]) for i in range(period))
+    J = W = None
+    if nr > 0:
+        J = np.zeros((1, period, nr, n)); W = np.zeros((1, period, nr))
+        for i in range(period):
+            if rows[i]:
+                Ji = np.vstack(rows[i]); J[0, i, :Ji.shape[0]] = Ji; W[0, i, :Ji.shape[0]] = np.concatenate(wts[i])
+    Ts = np.stack([_to_array(t) for t in T])[None] if T else None
+    dH = _handle(period, nx, Bs.shape[2]).supplement_terms_batch(As[None], Bs[None], Ps[None], J, W, Ts)[0]
     dHc = [dH[k] for k in range(period)]
     return dHc, [d[:nx, :nx] for d in dHc], [d[nx:, nx:] for d in dHc], [d[:nx, nx:] for d in dHc]

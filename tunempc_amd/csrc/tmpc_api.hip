@@ -136,7 +136,11 @@ __global__ void __launch_bounds__(64) k_eig_scan(const double* H, double* out, i
 }
 
 // dHc = sym(V' P+ V - E' P E) for arbitrary P (tmpc_supplement_batch_host); uses ws.V built from A,B
-__global__ void __launch_bounds__(64) k_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm) {
+// dHc_k = sym(V' P_{k+1} V - E' P_k E  +  J_k' diag(w_k) J_k  +  T_k)   (convexifier.py:165-211: the rows of J are the
+// equality-constraint Jacobian G_k with weights Fg_k followed by the active-constraint Jacobian C_k with weights F_k,
+// zero-weight padding up to nr rows; T_k the free regularisation of Step 3).  J, wts, T may be null.
+__global__ void __launch_bounds__(64) k_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm,
+                                                   int nr, const double* J, const double* wts, const double* T) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
@@ -150,6 +154,18 @@ __global__ void __launch_bounds__(64) k_supplement(const double* A, const double
   wsync();
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   build_M(sM, sV, t0, t1, sZ, P + (size_t)sid * nxx, P + (size_t)(b * dm.p + kn) * nxx, 0.0, n, nx, lane);
+  if (J || T) {
+    const double* Jg = J ? J + (size_t)sid * nr * n : nullptr;
+    const double* wg = wts ? wts + (size_t)sid * nr : nullptr;
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      double acc = sM[i * LD + j];
+      if (Jg) for (int r = 0; r < nr; ++r) acc = fma(wg[r] * Jg[r * n + i], Jg[r * n + j], acc);
+      if (T) acc += T[(size_t)sid * n * n + e];
+      sM[i * LD + j] = acc;
+    }
+    wsync();
+  }
   s2g_sym(dHc + (size_t)sid * n * n, sM, n, lane);
 }
 
@@ -481,23 +497,39 @@ int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const do
   return TMPC_OK;
 }
 
-int tmpc_supplement_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* P, double* dHc) {
-  if (!h || nbt < 1 || !A || !P || !dHc || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+int tmpc_supplement_terms_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* P, int nr,
+                                     const double* J, const double* wts, const double* T, double* dHc) {
+  if (!h || nbt < 1 || !A || !P || !dHc || (h->dm.mb > 0 && !B) || nr < 0 || ((J != nullptr) != (wts != nullptr)) || (J && nr < 1)) return TMPC_E_ARG;
   hipStream_t st = 0;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
+  double *dJ = nullptr, *dw = nullptr;
+  const size_t capst = (size_t)dm.B * dm.p;             // stages per chunk
+  if (J) { HIPCHK(hipMalloc(&dJ, capst * nr * dm.n * 8)); HIPCHK(hipMalloc(&dw, capst * nr * 8)); }
   for (int off = 0; off < nbt; off += dm.B) {
     const int nb = std::min(dm.B, nbt - off);
-    const size_t BP = (size_t)nb * dm.p;
+    const size_t BP = (size_t)nb * dm.p, so = (size_t)off * dm.p;
     Dims d2 = dm; d2.B = nb;
-    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
-    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->ws.P, P + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2);
-    HIPCHK(hipMemcpyAsync(dHc + (size_t)off * dm.p * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h->dA, A + so * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + so * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->ws.P, P + so * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (J) {
+      HIPCHK(hipMemcpyAsync(dJ, J + so * nr * dm.n, BP * nr * dm.n * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(dw, wts + so * nr, BP * nr * 8, hipMemcpyHostToDevice, st));
+    }
+    if (T) HIPCHK(hipMemcpyAsync(h->dH, T + so * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2, nr, dJ, dw,
+                       T ? h->dH : nullptr);
+    HIPCHK(hipMemcpyAsync(dHc + so * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
+  if (dJ) hipFree(dJ);
+  if (dw) hipFree(dw);
   return TMPC_OK;
+}
+
+int tmpc_supplement_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* P, double* dHc) {
+  return tmpc_supplement_terms_batch_host(h, nbt, A, B, P, 0, nullptr, nullptr, nullptr, dHc);
 }
 
 int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
