@@ -5,6 +5,18 @@
 
 namespace tmpc {
 
+// optional in-kernel cycle split (scripts/cycle_prof.py, scripts/gemm2_prof.py, scripts/stage_prof.py; -DTMPC_CYCLE_PROF builds only)
+#ifdef TMPC_CYCLE_PROF
+__device__ unsigned long long g_prof[16];
+#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[i] += t_ - tprev_; tprev_ = t_; } }
+#define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
+#else
+#define TMPC_T(i)
+#define TMPC_T0()
+#endif
+
+
+
 constexpr double ALPHA_MIN = 1e-8;     // reference: convexifier.py:245  (alpha > 1e-8)
 constexpr int TRACE_LEN = 80, TRACE_W = 10;
 constexpr int TB = 64;                 // tile size of the d x d block factorisation (potrf / trsm granularity)

@@ -22,15 +22,6 @@
 
 namespace tmpc {
 
-#ifdef TMPC_CYCLE_PROF
-__device__ unsigned long long g_prof[16];
-#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[i] += t_ - tprev_; tprev_ = t_; } }
-#define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
-#else
-#define TMPC_T(i)
-#define TMPC_T0()
-#endif
-
 // TRI_CLOW: lower triangle of a square C only (tiles above the diagonal skipped, fragments above it not stored);
 // TRI_BLOW: B lower-triangular (B[n][k] = 0 for k > n: trailing k-slabs of a tile column skipped);
 // TRI_CDIAG / TRI_COFF: the two halves of TRI_CLOW for square tiles -- diagonal tiles only, with the compile-time

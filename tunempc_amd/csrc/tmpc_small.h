@@ -33,7 +33,15 @@ __device__ __forceinline__ double wave_max(double v) {
 __device__ __forceinline__ void g2s(double* __restrict__ s, const double* __restrict__ g, int rows, int cols,
                                     int ldg, int lane) {
   const int tot = rows * cols;
-  for (int e = lane; e < tot; e += 64) {
+  int e = lane;
+  for (; e + 192 < tot; e += 256) {            // four loads in flight per lane: one exposed memory latency per 256 elements
+    int i[4], j[4]; double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int eu = e + 64 * u; i[u] = eu / cols; j[u] = eu - i[u] * cols; v[u] = g[(size_t)i[u] * ldg + j[u]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[i[u] * LD + j[u]] = v[u];
+  }
+  for (; e < tot; e += 64) {
     const int i = e / cols, j = e - i * cols;
     s[i * LD + j] = g[(size_t)i * ldg + j];
   }
@@ -114,42 +122,125 @@ __device__ __forceinline__ void mm(double* __restrict__ C, const double* __restr
   wsync();
 }
 
+// 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
 // In-place lower Cholesky of the symmetric n x n matrix in LDS slot A (only the lower triangle is
 // referenced/written).  Returns 0 on success; on a non-positive pivot the pivot is replaced by a tiny
 // positive number (Cholesky-with-shift) and the return value counts such events.
+// Left-looking (Crout): column j = A[:, j] - L[:, :j] L[j, :j]', two lanes per row share the dot product (k strided by
+// 2), the pivot travels by shuffle, so a column costs ONE barrier and no read-modify-write of LDS (the right-looking
+// version it replaces took three barriers, a square root and a division on the critical path of every column: 48 k
+// cycles per 32 x 32 matrix, a quarter of k_stage_pre).
 __device__ __forceinline__ int chol_lower(double* A, int n, int lane) {
   int nbad = 0;
   const int row = lane & 31, half = lane >> 5;
+  const bool mine = row < n;
   for (int j = 0; j < n; ++j) {
-    double piv = A[j * LD + j];
-    if (!(piv > 0.0)) { piv = 1e-300; ++nbad; }
-    const double d = sqrt(piv);
-    wsync();
-    if (lane == 0) A[j * LD + j] = d;
-    if (half == 0 && row > j && row < n) A[row * LD + j] /= d;
-    wsync();
-    if (row > j && row < n) {
-      const double lij = A[row * LD + j];
-      for (int c = j + 1 + half; c <= row; c += 2) A[row * LD + c] -= lij * A[c * LD + j];
+    double acc = 0.0;
+    if (mine && row >= j) {
+      const double* li = A + row * LD;
+      const double* lj = A + j * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = half;
+      for (; k + 2 < j; k += 4) { a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 2], lj[k + 2], a1); }
+      for (; k < j; k += 2) a0 = fma(li[k], lj[k], a0);
+      acc = a0 + a1;
     }
+    acc += __shfl_xor(acc, 32, 64);
+    double sij = 0.0;
+    if (mine && row >= j) sij = A[row * LD + j] - acc;
+    double piv = __shfl(sij, j, 64);
+    if (!(piv > 0.0)) { piv = 1e-300; ++nbad; }
+    const double rinv = rsqrt_nr(piv);
+    if (half == 0 && mine && row >= j) A[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
     wsync();
   }
   return nbad;
 }
 
 // Li = L^-1 for lower-triangular L (n x n, LDS).  Li gets explicit zeros above the diagonal.
+// Row-wise forward substitution: row i of L^-1 from the rows above, Li[i][c] = -(sum_{c<=k<i} L[i][k] Li[k][c]) / L[i][i];
+// two lanes per column share the sum, L[i][k] is a broadcast read, Li[k][c] runs along the lanes, the reciprocal
+// diagonal is computed once per lane and shuffled -- one barrier per row, no division inside the loop.
 __device__ __forceinline__ void tri_inv_lower(double* __restrict__ Li, const double* __restrict__ L, int n, int lane) {
-  if (lane < n) {
-    const int c = lane;
-    for (int i = 0; i < c; ++i) Li[i * LD + c] = 0.0;
-    Li[c * LD + c] = 1.0 / L[c * LD + c];
-    for (int i = c + 1; i < n; ++i) {
-      double acc = 0.0;
-      for (int k = c; k < i; ++k) acc = fma(L[i * LD + k], Li[k * LD + c], acc);
-      Li[i * LD + c] = -acc / L[i * LD + i];
+  const int c = lane & 31, half = lane >> 5;
+  double rdl = 1.0;
+  if (lane < n) rdl = 1.0 / L[lane * LD + lane];
+  for (int i = 0; i < n; ++i) {
+    const double rdi = __shfl(rdl, i, 64);
+    double acc = 0.0;
+    if (c < i) {
+      const double* li = L + i * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = c + half;
+      for (; k + 2 < i; k += 4) { a0 = fma(li[k], Li[k * LD + c], a0); a1 = fma(li[k + 2], Li[(k + 2) * LD + c], a1); }
+      for (; k < i; k += 2) a0 = fma(li[k], Li[k * LD + c], a0);
+      acc = a0 + a1;
     }
+    acc += __shfl_xor(acc, 32, 64);
+    if (half == 0 && c < n) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
+    wsync();
   }
-  wsync();
+}
+
+// Two matrices at once: lanes 0..31 factor A, lanes 32..63 factor B (one lane per row, full-length dot products, pivots
+// by v_readlane) -- the two dependency chains share every barrier and every latency, so the pair costs what one costs.
+__device__ __forceinline__ int chol_lower_pair(double* A, double* B, int n, int lane) {
+  int nbad = 0;
+  const int row = lane & 31, half = lane >> 5;
+  double* Mx = half ? B : A;
+  const bool mine = row < n;
+  for (int j = 0; j < n; ++j) {
+    double sij = 0.0;
+    if (mine && row >= j) {
+      const double* li = Mx + row * LD;
+      const double* lj = Mx + j * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = 0;
+      for (; k + 1 < j; k += 2) { a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 1], lj[k + 1], a1); }
+      if (k < j) a0 = fma(li[k], lj[k], a0);
+      sij = li[j] - (a0 + a1);
+    }
+    const double pa = __shfl(sij, j, 64), pb = __shfl(sij, 32 + j, 64);      // wave-uniform source lanes
+    if (!(pa > 0.0)) ++nbad;
+    if (!(pb > 0.0)) ++nbad;
+    double piv = half ? pb : pa;
+    if (!(piv > 0.0)) piv = 1e-300;
+    const double rinv = rsqrt_nr(piv);
+    if (mine && row >= j) Mx[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
+    wsync();
+  }
+  return nbad;
+}
+// LiA = LA^-1 (lanes 0..31) and LiB = LB^-1 (lanes 32..63), one lane per column
+__device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, const double* __restrict__ LA,
+                                                   double* __restrict__ LiB, const double* __restrict__ LB, int n, int lane) {
+  const int c = lane & 31, half = lane >> 5;
+  const double* L = half ? LB : LA;
+  double* Li = half ? LiB : LiA;
+  double rdl = 1.0;
+  if (c < n) rdl = 1.0 / L[c * LD + c];
+  for (int i = 0; i < n; ++i) {
+    const double ra = __shfl(rdl, i, 64), rb = __shfl(rdl, 32 + i, 64);
+    const double rdi = half ? rb : ra;
+    double acc = 0.0;
+    if (c < i) {
+      const double* li = L + i * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = c;
+      for (; k + 1 < i; k += 2) { a0 = fma(li[k], Li[k * LD + c], a0); a1 = fma(li[k + 1], Li[(k + 1) * LD + c], a1); }
+      if (k < i) a0 = fma(li[k], Li[k * LD + c], a0);
+      acc = a0 + a1;
+    }
+    if (c < n) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
+    wsync();
+  }
 }
 
 // Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and

@@ -146,9 +146,12 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   double* sPhi = sM;      // M is consumed by the residuals below, then its slot accumulates Phi(Hb)
   double* t2 = sS;        // the S slot is free once L^-1 has been formed
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  TMPC_T0()
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  TMPC_T(8)
   build_M(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
+  TMPC_T(9)
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
   int nbad = 0;
   double* kf = w.KF + (size_t)sid * 12 * nxx;
@@ -166,29 +169,34 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
     }
   }
   wsync();
+  TMPC_T(10)
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
     g2s(sX, Xg, n, n, n, lane);
     g2s(sS, Sg, n, n, n, lane);
+    TMPC_T(8)
     for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
       const double hx = dot_ss(sHb, sX, n, lane);
       if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s(sX, n, lane); }
     }
-    // S_r = L L',  L^-1,  S_r^-1
-    nbad += chol_lower(sS, n, lane);
-    tri_inv_lower(sLi, sS, n, lane);
-    s2g((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
-    mm(sSi, sLi, 1, LD, sLi, LD, 1, n, n, n, 0, lane);                   // Li' Li
-    s_sym(sSi, n, lane);
-    s2g((r ? w.S2i : w.S1i) + (size_t)sid * nn, sSi, n, n, n, lane);
-    // chol(X_r)^-1 for the primal step length
+    // S_r = L L', X_r = Lx Lx' (for the primal step length) and both inverses, the two matrices side by side in one wave
     for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
     wsync();
-    nbad += chol_lower(t0, n, lane);
-    tri_inv_lower(t1, t0, n, lane);
+    TMPC_T(10)
+    nbad += chol_lower_pair(sS, t0, n, lane);
+    TMPC_T(11)
+    tri_inv_lower_pair(sLi, sS, t1, t0, n, lane);
+    TMPC_T(12)
+    s2g((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
     s2g((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
+    TMPC_T(13)
+    mm(sSi, sLi, 1, LD, sLi, LD, 1, n, n, n, 0, lane);                   // Li' Li
+    TMPC_T(14)
+    s_sym(sSi, n, lane);
+    s2g((r ? w.S2i : w.S1i) + (size_t)sid * nn, sSi, n, n, n, lane);
+    TMPC_T(13)
     // Kronecker factors of the HKM Schur blocks
     double* kfr = kf + (size_t)r * KF_PER_LMI * nxx;
     mm(t0, sV, LD, 1, sX, LD, 1, nx, n, n, 0, lane);                     // V X     (nx x n)
@@ -220,6 +228,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
       s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx, lane);
     }
   }
+  TMPC_T(15)
   const double hbphi = dot_ss(sHb, sPhi, n, lane);
   adj_V(t1, t2, sV, sPhi, n, nx, lane);
   s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
