@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import convexify_oracle as co  # noqa: E402
+import reference_sdp as rs  # noqa: E402
 
 # examples/convex_lqr.py:40-46 (numeric literals of the reference's LQ example)
 LQR_A = np.array([[-0.3319, 0.7595, 1.5399], [-0.3393, 0.1250, 0.4245], [-0.5090, 0.9388, 0.8864]])
@@ -57,6 +58,35 @@ def main():
         o = solve_batch(A, B, Hs)
         np.savez(os.path.join(HERE, name + '.npz'), A=A, B=B, H=Hs, tol=co.DEFAULT_OPTS['tol'], **o)
         print(name, 'kappa', o['kappa'], 'iters', o['iters'], 'status', o['status'])
+    steps23()
+
+
+def rblock_problem(p=2, nx=2, nu=1, seed=0):
+    """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
+    Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
+    rng = np.random.default_rng(seed)
+    A = [0.5 * np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) for _ in range(p)]
+    B = [np.zeros((nx, nu)) for _ in range(p)]
+    Q = [np.eye(nx) for _ in range(p)]; R = [-0.5 * np.eye(nu) for _ in range(p)]; N = [np.zeros((nx, nu)) for _ in range(p)]
+    Cu = [np.hstack([np.zeros((nu, nx)), np.eye(nu)]) for _ in range(p)]
+    return A, B, Q, R, N, Cu
+
+
+def steps23():
+    """Vectors for the NEXT scope row (Steps 2/3 and the G term, convexifier.py:116-157): inputs + the outputs of the dense
+    restatement oracle/reference_sdp.py.  The minimiser is not unique in F/T beyond the optimal value, so what is pinned is
+    the step taken, the status, kappa and the objective; dHc is stored for reference."""
+    A, B, Q, R, N, Cu = rblock_problem()
+    for name, kw, opts in [('n1_step2_active_constraints', dict(C=Cu), {'rho': 1e-3}),
+                           ('n1_step1_equality_term', dict(G=Cu), {'rho': 1e-3}),
+                           ('n1_step3_force', dict(), {'rho': 1e-3, 'force': True})]:
+        dHc, dQc, dRc, dNc, info = rs.convexify_reference(A, B, Q, R, N, opts=opts, **kw)
+        res = info['result']
+        assert all(np.linalg.eigvalsh(h)[0] > 0 for h in res['Hc'])
+        np.savez(os.path.join(HERE, name + '.npz'), A=np.stack(A), B=np.stack(B), Q=np.stack(Q), R=np.stack(R), N=np.stack(N), Cu=np.stack(Cu),
+                 rho=opts['rho'], force=bool(opts.get('force', False)), step=info['step'], status=info['status'], kappa=info['kappa'],
+                 objective=res['objective'], beta=res['beta'], alpha=res['alpha'], dHc=np.stack(dHc))
+        print(name, 'step', info['step'], info['status'], 'kappa', info['kappa'], 'objective', res['objective'])
 
 
 if __name__ == '__main__':
