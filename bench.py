@@ -174,7 +174,9 @@ def main():
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
                          "kernel": "k_factor<true> (block-cyclic-tridiagonal Cholesky, v_mfma_f64_16x16x4_f64)",
                          "avg_launch_ms": avg_ms, "launches": int(launches), "problems_per_launch": chunk,
-                         "algorithmic_flops_per_launch": fl},
+                         "algorithmic_flops_per_launch": fl,
+                         "peak_note": "datasheet FP64 matrix peak; measured register-only issue rate of v_mfma_f64_16x16x4 on this part: "
+                                      "36 (1 wave/SIMD) / 48 (2+) TFLOP/s, of v_mfma_f64_4x4x4: 71-75 (profiles/r1_mfma_f64_issue_rate.txt)"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         if not args.no_cpu_baseline and world == 1:
