@@ -180,7 +180,8 @@ def test_golden_vectors(hc, golden_dir, name):
 
 
 @pytest.mark.parametrize('seed,nb,p,nx,mb', [(0, 3, 3, 3, 2), (20, 4, 1, 3, 1), (30, 4, 2, 3, 1), (13, 2, 30, 4, 1), (5, 4, 16, 3, 2),
-                                             (11, 2, 6, 12, 4), (12, 2, 4, 24, 8), (40, 3, 5, 2, 2), (41, 2, 7, 5, 1)])
+                                             (11, 2, 6, 12, 4), (12, 2, 4, 24, 8), (40, 3, 5, 2, 2), (41, 2, 7, 5, 1),
+                                             (50, 1, 3, 31, 1), (51, 1, 3, 17, 3)])      # maximum n = 32 with d = 496; odd sizes (d = 153, dp = 160)
 def test_parity_vs_oracle(hc, seed, nb, p, nx, mb):
     """Same seeded inputs through the HIP path and the CPU oracle (covers p=1, p=2, early-exit members)."""
     A, B, H = co.gen_batch(seed, nb, p, nx, mb)
