@@ -303,6 +303,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
     mu_t = None
     phase = 0
     ncent = 0
+    njam = 0
+    nshiftrun = 0
     status = 'max_iter'
     it = 0
     shift_used = 0.0
@@ -360,6 +362,12 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
           b_aa = np.sum(Hb * PhiH) + x0 / s0
           chol = _CyclicBlockChol(D, C)
           shift_used = max(shift_used, chol.shift)
+          nshiftrun = nshiftrun + 1 if chol.shift > 0.0 else 0
+          if (phase == 1 and chol.shift > 0.0) or nshiftrun >= 2:
+              # numerical breakdown of the Schur factorisation while centering (cond(T) ~ (tau/mu)^2): keep the last
+              # iterate, strictly feasible and close to the central path at ~2 mu_t, and report it as inaccurate
+              status = 'optimal_inaccurate'
+              break
           U = np.stack([u_tau, u_alpha], axis=2)                  # [p,d,2]
           TU = chol.solve(U)
           Sb = np.array([[b_tt, b_ta], [b_ta, b_aa]]) - np.einsum('kdi,kdj->ij', U, TU)
@@ -425,6 +433,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             stepn = np.sqrt(np.sum((dMc - (dalpha / alpha) * M) ** 2) / np.sum(M ** 2))
             if verbose:
                 print(f"      center |dy|rel={stepn:.3e} ap={ap:.3f} ad={ad:.3f}")
+        njam = njam + 1 if (ap < 1e-6 and ad < 1e-6) else 0
+        if njam >= 2:                      # step lengths collapsed twice in a row: stop with the last iterate
+            status = 'optimal_inaccurate'
+            break
         X1 = symmetrize(X1 + ap * dX1); X2 = symmetrize(X2 + ap * dX2)
         S1 = symmetrize(S1 + ad * dS1); S2 = symmetrize(S2 + ad * dS2)
         x0 += ap * dx0; s0 += ad * ds0

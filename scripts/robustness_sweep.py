@@ -1,0 +1,65 @@
+"""Robustness sweep of the HIP path outside the benchmark distribution: scale of the hidden P (how indefinite H is),
+conditioning of the hidden SPD target, spectral radius of A, shapes.  Checks status and the solver-independent invariants
+(Hc > 0, cond(Hc_k) <= kappa, Hc - H = sym(calH(P)))."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tunempc_amd._lib as L
+if os.environ.get('TMPC_LIB'):
+    L.library_path = lambda: os.path.join(ROOT, 'tunempc_amd', 'lib', os.environ['TMPC_LIB'])
+from tunempc_amd._lib import HipConvexifier
+
+
+def gen(seed, p, nx, mb, sigP, cond_exp, rad):
+    rng = np.random.default_rng(seed)
+    n = nx + mb
+    A = np.zeros((p, nx, nx)); B = np.zeros((p, nx, mb)); Phat = np.zeros((p, nx, nx)); Hhat = np.zeros((p, n, n))
+    for k in range(p):
+        a = rng.standard_normal((nx, nx)) / np.sqrt(nx)
+        A[k] = a * (rad / np.max(np.abs(np.linalg.eigvals(a))))
+        B[k] = rng.standard_normal((nx, mb)) / np.sqrt(nx)
+        W, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        Hhat[k] = (W * 10.0 ** rng.uniform(0, cond_exp, n)) @ W.T
+        pk = rng.standard_normal((nx, nx)); Phat[k] = sigP * (pk + pk.T) / 2
+    V = np.concatenate([A, B], axis=2)
+    dH = np.swapaxes(V, 1, 2) @ np.roll(Phat, -1, axis=0) @ V
+    dH[:, :nx, :nx] -= Phat
+    H = Hhat - dH
+    return A, B, (H + np.swapaxes(H, 1, 2)) / 2
+
+
+def calH(A, B, P):
+    V = np.concatenate([A, B], axis=2); nx = A.shape[1]
+    d = np.swapaxes(V, 1, 2) @ np.roll(P, -1, axis=0) @ V
+    d[:, :nx, :nx] -= P
+    return (d + np.swapaxes(d, 1, 2)) / 2
+
+
+rows = []
+nbad = 0
+for (p, nx, mb) in [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]:
+    h = HipConvexifier(p, nx, mb)
+    for sigP in (0.1, 1.0, 10.0, 100.0):
+        for cond_exp in (1, 3, 5):
+            for rad in (0.5, 0.9, 1.2):
+                nb = 8
+                ABH = [gen(7000 + 17 * b, p, nx, mb, sigP, cond_exp, rad) for b in range(nb)]
+                A = np.stack([x[0] for x in ABH]); B = np.stack([x[1] for x in ABH]); H = np.stack([x[2] for x in ABH])
+                out = h.convexify_batch(A, B, H)
+                ok = 0
+                for b in range(nb):
+                    early = bool(out['info'][b, 13])
+                    ev = np.linalg.eigvalsh(out['Hc'][b])
+                    struct = np.abs(out['Hc'][b] - H[b] - calH(A[b], B[b], out['P'][b])).max() / max(1.0, np.abs(H[b]).max())
+                    cond = (ev[:, -1] / ev[:, 0]).max()
+                    good = out['status'][b] == 0 and ev.min() > 0 and struct < 1e-10 and (early or cond <= out['kappa'][b] * (1 + 1e-7))
+                    ok += bool(good)
+                rows.append(dict(p=p, nx=nx, mb=mb, sigP=sigP, cond_exp=cond_exp, rad=rad, ok=ok, nb=nb, iters_max=int(out['iters'].max()),
+                                 status=np.bincount(out['status'], minlength=3).tolist(), kappa_max=float(out['kappa'].max())))
+                if ok != nb:
+                    nbad += 1
+                    print('NOT ALL OK', rows[-1])
+    h.close()
+print('cases', len(rows), 'with a failing member', nbad, 'max iterations', max(r['iters_max'] for r in rows))
+json.dump(rows, open(os.path.join(ROOT, 'gpurun_out', 'robustness_sweep.json'), 'w'))

@@ -224,6 +224,7 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
     return;
   }
   ip[I_ITERS] += 1;
+  ip[I_SHIFT0] = ip[I_NSHIFT];
   if (phase == PH_CENTER) { ip[I_NCENT] += 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
   else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
 }
@@ -288,7 +289,25 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     const double gam = 0.9 + 0.09 * fmin(mn, 1.0);
     ap = fmin(1.0, gam * ap); ad = fmin(1.0, gam * ad);
   } else {
-    ap = fmin(1.0, 0.95 * ap); ad = fmin(1.0, 0.95 * ad);
+#ifndef TMPC_CENTER_DAMP
+#define TMPC_CENTER_DAMP 0.95
+#endif
+    ap = fmin(1.0, TMPC_CENTER_DAMP * ap); ad = fmin(1.0, TMPC_CENTER_DAMP * ad);
+  }
+  // Numerical breakdown: frozen pivots in this iteration's Schur factorisation during the centering phase (cond(T) grows
+  // like (tau/mu)^2 and reaches 1/eps near the default mu_t when H is badly scaled) or in two main-phase iterations in
+  // a row, or two iterations in a row whose step lengths collapse.  The direction is then worthless: keep the last iterate (it is a strictly feasible point
+  // close to the central path at ~2 mu_t), report it as inaccurate, and do not hold the rest of the batch hostage until
+  // the iteration cap.
+  {
+    const bool jam = (ap < 1e-6 && ad < 1e-6);
+    const bool froze = ip[I_NSHIFT] != ip[I_SHIFT0];
+    ip[I_JAM] = jam ? ip[I_JAM] + 1 : 0;
+    ip[I_SHIFTRUN] = froze ? ip[I_SHIFTRUN] + 1 : 0;
+    if ((phase == PH_CENTER && froze) || ip[I_SHIFTRUN] >= 2 || ip[I_JAM] >= 2) {
+      ap = 0.0; ad = 0.0;
+      ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
+    }
   }
   // relative first-order change of the output Hc (the quantity the parity gate measures) in this step
   pr[P_STEPN] = sqrt(dh2 / m2);
