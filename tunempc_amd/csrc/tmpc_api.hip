@@ -116,7 +116,7 @@ __global__ void k_output(WS w, Dims dm, double* alpha, double* beta, double* kap
     o[0] = pr[P_S]; o[1] = pr[P_SBETA]; o[2] = pr[P_MINEIG_H]; o[3] = pr[P_MINEIG_HC]; o[4] = pr[P_MAXCOND];
     o[5] = pr[P_MU]; o[6] = pr[P_MUT]; o[7] = pr[P_PINF]; o[8] = pr[P_DINF]; o[9] = pr[P_RELGAP];
     o[10] = (double)ip[I_IPMSTATUS]; o[11] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]); o[12] = (double)ip[I_NCENT];
-    o[13] = (double)ip[I_EARLY]; o[14] = pr[P_STEPN]; o[15] = 0.0;
+    o[13] = (double)ip[I_EARLY]; o[14] = pr[P_STEPN]; o[15] = pr[P_MINPIV];
   }
 }
 

@@ -416,14 +416,14 @@ __device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int
 // dref: assembled diagonal entries (pivot reference).  Returns number of shifted pivots (thread-uniform).
 // Both loops are organised so that all 256 threads work: four lanes share every dot product (k strided by 4,
 // two xor-shuffles to combine), i.e. column-Crout for L and row-wise forward substitution for L^-1.
-__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds) {
+__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
   const int tid = threadIdx.x;
   double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
   double* Si = S + 64 * 65;                // 64 x 65
   double* dr = Si + 64 * 65;               // 64 pivot references, then [64] = current pivot, [65] = shift counter
   for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * 65 + j] = T[(size_t)i * ldt + j]; }
   if (tid < nb) dr[tid] = dref[tid];
-  if (tid == 0) dr[65] = 0.0;
+  if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }          // shift counter, smallest pivot / reference diagonal of this tile
   __syncthreads();
   const int row = tid >> 2, seg = tid & 3;
   // ---- L: column Crout.  s_i = A[i][j] - sum_{k<j} L[i][k] L[j][k]
@@ -448,6 +448,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
     if (row == j && seg == 0) {
       double piv = sij;
       const double ref = fabs(dr[j]);
+      if (ref > 0.0) dr[66] = fmin(dr[66], fmax(piv, 0.0) / ref);
       if (!(piv > 1e-15 * ref) || !(piv > 0.0)) { piv = (ref > 0.0 ? ref : 1.0) * 1e20; dr[65] += 1.0; }   // Cholesky-with-shift
       dr[64] = sqrt(piv);
     }
@@ -490,6 +491,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
   }
   __syncthreads();
   const int nb_bad = (int)dr[65];
+  *minr = fmin(*minr, dr[66]);
   __syncthreads();
   return nb_bad;
 }
@@ -498,7 +500,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
 //   Dk = L L' ;  R1 <- R1 L^-T ;  R2 <- R2 L^-T        (R1/R2 may be null)
 template <bool USE_MFMA, int VAR>
 __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R2, double* Linv_k, const double* dref,
-                                               int dp, double* lds) {
+                                               int dp, double* lds, double* minr) {
   int nbad = 0;
   int jt = 0;
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
@@ -509,7 +511,7 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
       if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
     double* Ti = Linv_k + (size_t)jt * TB * TB;
-    nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds);
+    nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds, minr);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
       wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
@@ -534,11 +536,12 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
   const double* dref = w.Ddiag + (size_t)b * p * dp;
   const size_t ls = (size_t)dm.nt * TB * TB;
   int nbad = 0;
+  double minr = 1.0;                       // smallest pivot relative to the assembled diagonal in this factorisation
   if (p == 1) {
     // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'   (C stored in F[0])
     for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += F[e] + F[(size_t)j * dp + i]; }
     __syncthreads();
-    nbad += wg_block_column<USE_MFMA, VAR>(D, nullptr, nullptr, Li, dref, dp, lds);
+    nbad += wg_block_column<USE_MFMA, VAR>(D, nullptr, nullptr, Li, dref, dp, lds, &minr);
   } else {
     for (int k = 0; k < p - 1; ++k) {
       double* Dk = D + k * bs; double* Ok = O + k * bs; double* Fk = F + k * bs;
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
         for (int e = tid; e < dp * dp; e += 256) Ok[e] += Fk[e];
         __syncthreads();
       }
-      nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds);
+      nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds, &minr);
       // Schur updates
       if (USE_MFMA && VAR == 1 && !last) {
         wg_schur_fused(D + (k + 1) * bs, D + (size_t)(p - 1) * bs, F + (k + 1) * bs, Ok, Fk, dp, lds);
@@ -559,9 +562,10 @@ __global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
         }
       }
     }
-    nbad += wg_block_column<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds);
+    nbad += wg_block_column<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds, &minr);
   }
   if (tid == 0 && nbad) ip[I_NSHIFT] += nbad;
+  if (tid == 0 && w.prob) { double* pr = w.prob + (size_t)b * PS; pr[P_MINPIV] = fmin(pr[P_MINPIV], minr); }
 }
 
 // ------------------------------------------------------------------ triangular solves with the block factor
