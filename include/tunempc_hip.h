@@ -55,7 +55,7 @@ extern "C" {
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
  *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter),
  *                 11 #shifted pivots, 12 centering iterations, 13 early-exit flag (convexifier.py:83-85),
- *                 14 last centering step norm, 15 smallest Cholesky pivot of the Schur factorisations relative to the assembled diagonal (1e-15 = frozen)                                          */
+ *                 14 last centering step norm, 15 smallest Cholesky pivot of the Schur factorisations relative to the assembled diagonal (1 if never below 1e-8; <= 1e-15 = frozen)                                          */
 
 typedef struct tmpc_handle tmpc_handle;
 

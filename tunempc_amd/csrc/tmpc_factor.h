@@ -448,7 +448,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
     if (row == j && seg == 0) {
       double piv = sij;
       const double ref = fabs(dr[j]);
-      if (ref > 0.0) dr[66] = fmin(dr[66], fmax(piv, 0.0) / ref);
+      if (piv < 1e-8 * ref) dr[66] = fmin(dr[66], fmax(piv, 0.0) / ref);    // (division only on the rare small pivots)
       if (!(piv > 1e-15 * ref) || !(piv > 0.0)) { piv = (ref > 0.0 ? ref : 1.0) * 1e20; dr[65] += 1.0; }   // Cholesky-with-shift
       dr[64] = sqrt(piv);
     }
