@@ -271,10 +271,13 @@ def _max_step(Li, dX):
 
 
 # ------------------------------------------------------------ the SDP solve (Step 1)
-def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
+def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
-    constr=False, force=False, G=None) for one tuning problem.  Returns dict with P (= dP of
-    convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags."""
+    constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
+    convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags.
+    G [p, ng, n] (optional): equality-constraint Jacobians; M_k gains G_k' diag(phi_k) G_k with the cost-free
+    multipliers phi_k = s*Fg_k >= 0 of convexifier.py:249-255 / :346-347 (they belong to Step 1 whenever G is given).
+    They are handled as extra border columns of the Schur complement (each one touches only P_k and P_{k+1})."""
     o = dict(DEFAULT_OPTS)
     if opts:
         o.update(opts)
@@ -300,6 +303,14 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
     X2 = X1.copy()
     s0 = alpha
     x0 = o.get('init_x', 1.0) / (p * n)
+    ng = 0
+    if G is not None:
+        G = np.asarray(G, dtype=np.float64)
+        ng = G.shape[1]
+        GG = G[:, :, :, None] * G[:, :, None, :]           # [p, ng, n, n]: g g' per constraint row
+        phi = np.ones((p, ng))                             # slack of phi >= 0 is phi itself
+        z = np.full((p, ng), x0)                           # its multiplier
+        N = N + p * ng
     mu_t = None
     phase = 0
     ncent = 0
@@ -312,15 +323,18 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
     stepn = np.inf
     for it in range(o['max_iter'] + o['center_iter'] + 1):
         M = alpha * Hb + calH(A, B, P)
+        if ng:
+            M = M + np.einsum('ki,kiab->kab', phi, GG)
         Rd1 = (M - I) - S1
         Rd2 = (tau * I - M) - S2
         rd0 = (alpha - ALPHA_MIN) - s0
-        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0) / N
+        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0)) / N
         Y = X1 - X2
         r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
         r_alpha = -np.sum(Hb * Y) - x0
         r_P = -calH_adj(A, B, Y)
-        pinf = np.sqrt(r_tau ** 2 + r_alpha ** 2 + np.sum(_svec_grad(r_P, ia, ib) ** 2)) / 2.0
+        r_phi2 = np.sum((-np.einsum('kiab,kab->ki', GG, Y) - z) ** 2) if ng else 0.0
+        pinf = np.sqrt(r_tau ** 2 + r_alpha ** 2 + np.sum(_svec_grad(r_P, ia, ib) ** 2) + r_phi2) / 2.0
         dinf = np.sqrt(np.sum(Rd1 ** 2) + np.sum(Rd2 ** 2) + rd0 ** 2) / (1.0 + np.sqrt(np.sum(S1 ** 2) + np.sum(S2 ** 2)))
         relgap = N * mu / max(1.0, abs(tau))
         if verbose:
@@ -369,10 +383,34 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
               status = 'optimal_inaccurate'
               break
           U = np.stack([u_tau, u_alpha], axis=2)                  # [p,d,2]
+          Bb = np.array([[b_tt, b_ta], [b_ta, b_aa]])
+          if ng:
+              # one border column per multiplier phi_{k,i}: W = Phi_k(g g') lives at stage k only, so the column has
+              # entries at P_k (-W[:nx,:nx]) and P_{k+1} (V W V') and nowhere else
+              W = symmetrize(X1[:, None] @ GG @ S1i[:, None]) + symmetrize(X2[:, None] @ GG @ S2i[:, None])   # [p,ng,n,n]
+              Ug = np.zeros((p, d, p * ng))
+              for k in range(p):
+                  for i in range(ng):
+                      Wk = np.zeros((p, n, n)); Wk[k] = W[k, i]
+                      Ug[:, :, k * ng + i] = _svec_grad(calH_adj(A, B, Wk), ia, ib)
+              U = np.concatenate([U, Ug], axis=2)
+              nb_ = 2 + p * ng
+              Bfull = np.zeros((nb_, nb_)); Bfull[:2, :2] = Bb
+              GXG1 = G @ X1 @ np.swapaxes(G, 1, 2); GSG1 = G @ S1i @ np.swapaxes(G, 1, 2)     # [p,ng,ng]
+              GXG2 = G @ X2 @ np.swapaxes(G, 1, 2); GSG2 = G @ S2i @ np.swapaxes(G, 1, 2)
+              Bpp = GXG1 * np.swapaxes(GSG1, 1, 2) + GXG2 * np.swapaxes(GSG2, 1, 2)             # <g_i g_i', Phi(g_j g_j')>
+              c_tau = -np.einsum('kiab,kab->ki', GG, Psi)                                        # <g g', -Psi_k>
+              c_alpha = np.einsum('kiab,kab->ki', GG, PhiH)
+              for k in range(p):
+                  sl = slice(2 + k * ng, 2 + (k + 1) * ng)
+                  Bfull[sl, sl] = symmetrize(Bpp[k][None])[0] + np.diag(z[k] / phi[k])
+                  Bfull[0, sl] = c_tau[k]; Bfull[sl, 0] = c_tau[k]
+                  Bfull[1, sl] = c_alpha[k]; Bfull[sl, 1] = c_alpha[k]
+              Bb = Bfull
           TU = chol.solve(U)
-          Sb = np.array([[b_tt, b_ta], [b_ta, b_aa]]) - np.einsum('kdi,kdj->ij', U, TU)
+          Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
 
-        def direction(sig_mu, corr1=None, corr2=None, corr0=0.0):
+        def direction(sig_mu, corr1=None, corr2=None, corr0=0.0, corrp=None):
             T1 = sig_mu * S1i - symmetrize(X1 @ Rd1 @ S1i)
             T2 = sig_mu * S2i - symmetrize(X2 @ Rd2 @ S2i)
             if corr1 is not None:
@@ -381,13 +419,20 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
             rhs_tau = np.trace(T2, axis1=1, axis2=2).sum() - 1.0
             rhs_alpha = np.sum(Hb * (T1 - T2)) + t0
             rhs_P = _svec_grad(calH_adj(A, B, T1 - T2), ia, ib)      # [p,d]
-            z = chol.solve(rhs_P[:, :, None])[:, :, 0]
-            rb = np.array([rhs_tau, rhs_alpha]) - np.einsum('kdi,kd->i', U, z)
+            zsol = chol.solve(rhs_P[:, :, None])[:, :, 0]
+            rbv = np.array([rhs_tau, rhs_alpha])
+            if ng:
+                tphi = sig_mu / phi - (corrp if corrp is not None else 0.0)
+                rbv = np.concatenate([rbv, (np.einsum('kiab,kab->ki', GG, T1 - T2) + tphi).ravel()])
+            rb = rbv - np.einsum('kdi,kd->i', U, zsol)
             db = np.linalg.solve(Sb, rb)
-            dp = z - TU @ db
-            dtau, dalpha = db
+            dp = zsol - TU @ db
+            dtau, dalpha = db[0], db[1]
             dP = _smat(dp, nx, ia, ib)
             dM = dalpha * Hb + calH(A, B, dP)
+            if ng:
+                dphi = db[2:].reshape(p, ng)
+                dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
             dS1 = dM + Rd1
             dS2 = dtau * I - dM + Rd2
             dX1 = sig_mu * S1i - X1 - symmetrize(X1 @ dS1 @ S1i)
@@ -396,40 +441,47 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
                 dX1 = dX1 - corr1; dX2 = dX2 - corr2
             ds0 = dalpha + rd0
             dx0 = sig_mu / s0 - x0 - x0 * ds0 / s0 - corr0
-            return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0
+            if ng:
+                dz = sig_mu / phi - z - z * dphi / phi - (corrp if corrp is not None else 0.0)
+                return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz
+            return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, None, None
 
-        def steps(dS1, dS2, dX1, dX2, ds0, dx0):
+        def steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi=None, dz=None):
             LX1i = np.linalg.inv(np.linalg.cholesky(X1)); LX2i = np.linalg.inv(np.linalg.cholesky(X2))
             ap = min(_max_step(LX1i, dX1), _max_step(LX2i, dX2))
             ad = min(_max_step(L1i, dS1), _max_step(L2i, dS2))
             if dx0 < 0: ap = min(ap, -x0 / dx0)
             if ds0 < 0: ad = min(ad, -s0 / ds0)
+            if ng:
+                if (dz < 0).any(): ap = min(ap, (-z[dz < 0] / dz[dz < 0]).min())
+                if (dphi < 0).any(): ad = min(ad, (-phi[dphi < 0] / dphi[dphi < 0]).min())
             return ap, ad
 
         if phase == 0:
-            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(0.0)
-            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(0.0)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             ap = min(1.0, ap); ad = min(1.0, ad)
             mu_aff = (np.sum((X1 + ap * dX1) * (S1 + ad * dS1)) + np.sum((X2 + ap * dX2) * (S2 + ad * dS2))
-                      + (x0 + ap * dx0) * (s0 + ad * ds0)) / N
+                      + (x0 + ap * dx0) * (s0 + ad * ds0) + (np.sum((z + ap * dz) * (phi + ad * dphi)) if ng else 0.0)) / N
             sigma = min(max((mu_aff / mu) ** 2, 1e-6), 1.0)     # exponent 2: ~10 % fewer iterations than Mehrotra's 3 on this SDP family
             sig_mu = sigma * mu
             if mu_t is not None:
                 sig_mu = max(sig_mu, mu_t)
             corr1 = symmetrize(dX1 @ dS1 @ S1i); corr2 = symmetrize(dX2 @ dS2 @ S2i)
             corr0 = dx0 * ds0 / s0
-            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(sig_mu, corr1, corr2, corr0)
-            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            corrp = dz * dphi / phi if ng else None
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(sig_mu, corr1, corr2, corr0, corrp)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             mn = min(ap, ad)
             gam = 0.9 + 0.09 * min(mn, 1.0)
             ap = min(1.0, gam * ap); ad = min(1.0, gam * ad)
         else:
             ncent += 1
-            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0 = direction(mu_t)
-            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0)
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(mu_t)
+            ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             ap = min(1.0, 0.95 * ap); ad = min(1.0, 0.95 * ad)
             # first-order relative change of the output Hc_k = M_k/(s*alpha) in this step
-            dMc = dalpha * Hb + calH(A, B, dP)
+            dMc = dM
             stepn = np.sqrt(np.sum((dMc - (dalpha / alpha) * M) ** 2) / np.sum(M ** 2))
             if verbose:
                 print(f"      center |dy|rel={stepn:.3e} ap={ap:.3f} ad={ad:.3f}")
@@ -441,6 +493,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
         S1 = symmetrize(S1 + ad * dS1); S2 = symmetrize(S2 + ad * dS2)
         x0 += ap * dx0; s0 += ad * ds0
         tau += ad * dtau; alpha += ad * dalpha; P = P + ad * dP
+        if ng:
+            z = z + ap * dz; phi = phi + ad * dphi
         if phase == 1:
             # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation
             # at the rounding floor, or on the iteration cap
@@ -460,13 +514,16 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None):
                 break
             prev_stepn = stepn if full else None
     Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
-    return dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
-                ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
+    out = dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
+               ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
+    if ng:
+        out['Fg'] = phi / (s * alpha)                   # convexifier.py:410 (s_F = s_alpha = s)
+    return out
 
 
-def check_convergence(A, B, H, P, ipm_status):
+def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None):
     """convexifier.py:403-456 (status rule :442-451)."""
-    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P)
+    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P, G=G, Fg=Fg)
     Hc = H + dHc
     ev = np.linalg.eigvalsh(Hc)
     min_eig = ev.min(); max_cond = (ev[:, -1] / ev[:, 0]).max() if min_eig > 0 else np.inf
@@ -477,9 +534,9 @@ def check_convergence(A, B, H, P, ipm_status):
     return st, dHc, dQc, dRc, dNc, min_eig, max_cond
 
 
-def convexify_arrays(A, B, H, opts=None, verbose=False):
-    """Array-level restatement of convexifier.convexify (Step 1 only, no G/C):
-    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, dHc, Hc, P, alpha, beta, kappa, iters, early_exit)."""
+def convexify_arrays(A, B, H, opts=None, verbose=False, G=None):
+    """Array-level restatement of convexifier.convexify (Step 1, optional equality-constraint term G [p,ng,n]):
+    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, dHc, Hc, P, alpha, beta, kappa, iters, early_exit[, Fg])."""
     A = np.asarray(A, float); B = np.asarray(B, float); H = symmetrize(np.asarray(H, float))
     p, nx, _ = A.shape
     n = H.shape[1]
@@ -487,8 +544,8 @@ def convexify_arrays(A, B, H, opts=None, verbose=False):
     if np.linalg.eigvalsh(H)[:, 0].min() > 0:
         return dict(status=STATUS_OPTIMAL, early_exit=True, dHc=np.zeros_like(H), Hc=H.copy(),
                     P=np.zeros((p, nx, nx)), alpha=1.0, beta=0.0, kappa=0.0, iters=0)
-    r = sdp_step1(A, B, H, opts, verbose)
-    st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'])
+    r = sdp_step1(A, B, H, opts, verbose, G=G)
+    st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'], G=G, Fg=r.get('Fg'))
     r.update(status=st, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond)
     return r
 

@@ -117,3 +117,22 @@ def test_steps23_golden_vectors(name, kw):
     assert info['step'] == int(g['step']) and info['status'] == str(g['status'])
     assert abs(info['result']['objective'] / float(g['objective']) - 1.0) < 1e-6
     assert abs(info['kappa'] / float(g['kappa']) - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize('seed,p,nx,nu,ng', [(20, 3, 3, 2, 2), (0, 3, 3, 2, 1), (30, 2, 3, 1, 3)])
+def test_structured_oracle_with_equality_term_matches_dense_model(seed, p, nx, nu, ng):
+    """Step 1 with G (cost-free multipliers Fg >= 0, convexifier.py:249-255): the structured oracle (extra border columns)
+    and the dense restatement reach the same optimal value; the extra freedom can only lower kappa*."""
+    A, B, H = co.gen_problem(seed, p, nx, nu)[:3]
+    G = np.random.default_rng(seed + 1).standard_normal((p, ng, nx + nu))
+    r = co.convexify_arrays(A, B, H, G=G)
+    r0 = co.convexify_arrays(A, B, H)
+    Q, R, N = _split(H, nx)
+    ref = rs.solve_step(list(A), list(B), Q, R, N, G=[g for g in G], constr=False)
+    assert r['status'] == co.STATUS_OPTIMAL and ref['status'] == 'Optimal'
+    assert abs(r['kappa'] / (ref['beta'] * r['sbeta']) - 1.0) < 1e-5
+    assert r['kappa'] <= r0['kappa'] * (1 + 1e-9)
+    assert (r['Fg'] >= 0).all()
+    ev = np.linalg.eigvalsh(r['Hc'])
+    assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= r['kappa'] * (1 + 1e-8)
+    assert np.abs(r['Hc'] - H - co.convex_hessian_suppl(A, B, r['P'], G=G, Fg=r['Fg'])[0]).max() < 1e-12
