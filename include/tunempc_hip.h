@@ -68,6 +68,10 @@ uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
 /* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.
  * Larger batches are processed in chunks.  chunk <= 0 selects a default that fits free HBM. */
 int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
+/* The same with room for `ng` equality-constraint rows per stage (0 <= ng <= 8), for tmpc_convexify_eq_batch_host.
+ * Such a handle also serves every call that takes no G. */
+uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng);
+int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng);
 int tmpc_destroy(tmpc_handle* h);
 /* Problems processed per launch wave (the chunk the workspace was sized for). */
 int tmpc_get_chunk(tmpc_handle* h);
@@ -87,6 +91,14 @@ int tmpc_convexify_batch_host(tmpc_handle* h, int nb, const double* A, const dou
 int tmpc_convexify_batch_device(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH,
                                 double* dHc_out, double* ddHc_out, double* dP_out, double* d_alpha, double* d_beta,
                                 double* d_kappa, int32_t* d_status, int32_t* d_iters, double* d_info, void* stream);
+
+/* Step 1 with the equality-constraint term (convexifier.py:249-255 multipliers Fg_k >= 0, :346-347 term G_k' diag(Fg_k) G_k
+ * in M_k, :409-411 un-scaling): G [nb][p][ng][n] with ng of tmpc_create_eq; Fg [nb][p][ng] out.  dHc includes the G term
+ * (convexifier.py:196-197).  The multipliers are eliminated stage by stage before the block factorisation
+ * (tunempc_amd/csrc/tmpc_phi.h). */
+int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* G,
+                                 double* Hc, double* dHc, double* P, double* Fg, double* alpha, double* beta, double* kappa,
+                                 int32_t* status, int32_t* iters, double* info);
 
 /* convexHessianSuppl (convexifier.py:165-211) alone: dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E). */
 int tmpc_supplement_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, double* dHc);

@@ -558,16 +558,17 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
     if G is not None:
         arg['G'] = G
     arg = input_checks(arg)
-    if 'G' in arg or 'C' in arg:
-        raise NotImplementedError('oracle: Steps with G/C terms not restated yet')
+    Gs = np.stack([np.atleast_2d(np.asarray(g, float)) for g in arg['G']]) if 'G' in arg else None
     nx = np.shape(arg['A'][0])[0]; nu = np.shape(arg['B'][0])[1]
     Hs = np.stack([build_hessian(np.asarray(q, float), np.asarray(r, float), np.asarray(nn, float))
                    for q, r, nn in zip(arg['Q'], arg['R'], arg['N'])])
     As = np.stack([np.asarray(a, float) for a in arg['A']]); Bs = np.stack([np.asarray(b, float) for b in arg['B']])
-    res = convexify_arrays(As, Bs, Hs, opts)
+    res = convexify_arrays(As, Bs, Hs, opts, G=Gs)
     if res['early_exit']:
         return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))   # :85
     if res['status'] == STATUS_INFEASIBLE:
+        if 'G' in arg or 'C' in arg:
+            raise NotImplementedError('oracle: Steps 2/3 live in oracle/reference_sdp.py')
         raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
     dH = res['dHc']
     return ([dH[k] for k in range(len(dH))], [dH[k][:nx, :nx] for k in range(len(dH))],

@@ -61,6 +61,33 @@ def main():
     steps23()
 
 
+EQ_CASES = {
+    # name: (base_seed, nb, p, nx, mb, ng): Step 1 with the equality-constraint term (convexifier.py:249-255, :346-347)
+    'eq_term_n5': (7000, 2, 3, 3, 2, 2),
+    'eq_term_p1': (20, 2, 1, 3, 1, 1),          # member 1 is already convex
+    'eq_term_n9': (7200, 2, 4, 6, 3, 4),
+}
+
+
+def equality_term():
+    """Inputs (A, B, H from the seeded generator, G standard normal) and the structured oracle's outputs with Fg."""
+    for name, (seed, nb, p, nx, mb, ng) in EQ_CASES.items():
+        A, B, Hs = co.gen_batch(seed, nb, p, nx, mb)
+        G = np.random.default_rng(seed + 99).standard_normal((nb, p, ng, nx + mb))
+        out = dict(Hc=[], P=[], Fg=[], kappa=[], alpha=[], beta=[], status=[], iters=[])
+        for b in range(nb):
+            r = co.convexify_arrays(A[b], B[b], Hs[b], G=G[b])
+            r.setdefault('Fg', np.zeros((p, ng)))          # already-convex member (convexifier.py:83-85): no multipliers
+            assert r['status'] == co.STATUS_OPTIMAL and (r['Fg'] >= 0).all()
+            ev = np.linalg.eigvalsh(r['Hc'])
+            assert ev.min() > 0 and (r['early_exit'] or (ev[:, -1] / ev[:, 0]).max() <= r['kappa'] * (1 + 1e-9))
+            assert np.abs(r['Hc'] - Hs[b] - co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'])[0]).max() < 1e-12
+            for k in out:
+                out[k].append(r[k])
+        np.savez(os.path.join(HERE, name + '.npz'), A=A, B=B, H=Hs, G=G, tol=co.DEFAULT_OPTS['tol'], **{k: np.array(v) for k, v in out.items()})
+        print(name, 'kappa', out['kappa'], 'iters', out['iters'])
+
+
 def rblock_problem(p=2, nx=2, nu=1, seed=0):
     """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
     Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
@@ -90,4 +117,8 @@ def steps23():
 
 
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['eq']:
+        equality_term()          # only the equality-term vectors (the others stay byte-identical)
+    else:
+        main()
+        equality_term()

@@ -241,6 +241,76 @@ def test_infeasible_member_does_not_abort_batch(hc):
         assert int(out['status'][b]) == int(r['status']) and rel(out['Hc'][b], r['Hc']) < PARITY
 
 
+# ----------------------------------------------------------------------------- Step 1 with the equality-constraint term
+def _eq_inputs(seed, nb, p, nx, mb, ng):
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    G = np.random.default_rng(1000 + seed).standard_normal((nb, p, ng, nx + mb))
+    return A, B, H, G
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng', [(20, 2, 3, 3, 2, 2), (0, 3, 3, 3, 2, 1), (30, 2, 2, 3, 1, 2), (20, 2, 1, 3, 1, 1),
+                                                (7, 2, 5, 4, 2, 3), (11, 2, 4, 6, 3, 4), (5, 2, 8, 8, 4, 8), (12, 1, 3, 24, 8, 5)])
+def test_equality_term_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng):
+    """convexifier.py:249-255 / :346-347: the multipliers Fg_k >= 0 of G_k join Step 1.  HIP path (stage-local elimination,
+    tmpc_phi.h) vs the CPU oracle (border columns); p = 1, p = 2, early-exit members and the maximum ng = 8 included."""
+    A, B, H, G = _eq_inputs(seed, nb, p, nx, mb, ng)
+    out = hc(p, nx, mb, ng=ng).convexify_eq_batch(A, B, H, G)
+    for b in range(nb):
+        r = co.convexify_arrays(A[b], B[b], H[b], G=G[b])
+        assert int(out['status'][b]) == int(r['status']) and bool(out['info'][b, 13]) == bool(r['early_exit'])
+        assert rel(out['Hc'][b], r['Hc']) < PARITY
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        if r['early_exit']:
+            assert not out['Fg'][b].any() and not out['dHc'][b].any()
+            continue
+        assert (out['Fg'][b] >= 0).all() and rel(out['Fg'][b], r['Fg']) < 1e-7
+        # the supplement is what convexHessianSuppl builds from (P, Fg): convexifier.py:196-197
+        assert rel(out['dHc'][b], co.convex_hessian_suppl(A[b], B[b], out['P'][b], G=G[b], Fg=out['Fg'][b])[0]) < 1e-12
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-8)
+
+
+@pytest.mark.parametrize('name', ['eq_term_n5', 'eq_term_p1', 'eq_term_n9'])
+def test_equality_term_golden_vectors(hc, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    A, B, H, G = g['A'], g['B'], g['H'], g['G']
+    nb, p, nx, _ = A.shape
+    out = hc(p, nx, B.shape[3], ng=G.shape[2]).convexify_eq_batch(A, B, H, G)
+    for b in range(nb):
+        assert int(out['status'][b]) == int(g['status'][b])
+        assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
+        assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+        assert np.linalg.norm(out['Fg'][b] - g['Fg'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['Fg'][b]))
+
+
+def test_equality_term_handle_serves_plain_calls_and_chunks(hc):
+    """A handle created with ng > 0 gives the plain Step 1 bit for bit; chunked equality-term batches equal unchunked ones."""
+    A, B, H, G = _eq_inputs(7, 5, 5, 4, 2, 3)
+    hq = hc(5, 4, 2, ng=3)
+    plain = hc(5, 4, 2).convexify_batch(A, B, H)
+    np.testing.assert_array_equal(hq.convexify_batch(A, B, H)['Hc'], plain['Hc'])
+    full = hq.convexify_eq_batch(A, B, H, G)
+    part = hc(5, 4, 2, ng=3, chunk=2).convexify_eq_batch(A, B, H, G)
+    np.testing.assert_array_equal(full['Hc'], part['Hc'])
+    np.testing.assert_array_equal(full['Fg'], part['Fg'])
+    assert (full['kappa'] <= plain['kappa'] * (1 + 1e-9)).all()       # the extra freedom can only lower kappa*
+
+
+def test_equality_term_dense_model_vector(hc, golden_dir):
+    """B = 0, R < 0: Step 1 is infeasible without G and feasible with it (the vector of the dense model, oracle/reference_sdp.py)."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(golden_dir, 'n1_step1_equality_term.npz'))
+    p = g['A'].shape[0]
+    lst = lambda a: [a[k] for k in range(p)]
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        convexifier.convexify(lst(g['A']), lst(g['B']), lst(g['Q']), lst(g['R']), lst(g['N']))
+    dHc, dQc, dRc, dNc = convexifier.convexify(lst(g['A']), lst(g['B']), lst(g['Q']), lst(g['R']), lst(g['N']), G=lst(g['Cu']))
+    H = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
+    ev = np.linalg.eigvalsh(H + np.stack(dHc))
+    assert ev.min() > 0 and abs((ev[:, -1] / ev[:, 0]).max() / float(g['kappa']) - 1.0) < 1e-4
+    assert all(dRc[k][0, 0] > 0.5 for k in range(p))
+
+
 # ----------------------------------------------------------------------------- reference-compatible API
 def test_dropin_convexify_lqr_example():
     """examples/convex_lqr.py through the drop-in API: same call, same return structure, same assertion (:58)."""

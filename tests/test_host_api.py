@@ -99,11 +99,12 @@ def test_synthetic_generator_matches_oracle_generator():
         np.testing.assert_array_equal(x, y)
 
 
-def test_g_argument_is_rejected_loudly():
+def test_too_many_equality_rows_are_rejected_loudly():
+    """The HIP path eliminates at most NG_MAX multipliers per stage; more is an error raised before any device call."""
     from tunempc_amd import convexifier
     A = np.eye(2) * 0.5; B = np.ones((2, 1)); Q = -np.eye(2); R = np.eye(1); N = np.zeros((2, 1))
     with pytest.raises(NotImplementedError):
-        convexifier.convexify(A, B, Q, R, N, G=np.ones((1, 3)))
+        convexifier.convexify(A, B, Q, R, N, G=np.ones((convexifier.NG_MAX + 1, 3)))
 
 
 def test_rotate_tuning_mirrors_reference_indexing():

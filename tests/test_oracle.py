@@ -125,6 +125,28 @@ def test_golden_vectors(golden_dir, name):
         assert abs(r['kappa'] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
 
 
+@pytest.mark.parametrize('name', ['eq_term_n5', 'eq_term_p1', 'eq_term_n9'])
+def test_equality_term_golden_vectors(golden_dir, name):
+    """Step 1 with G (convexifier.py:249-255): the oracle reproduces the committed outputs, Fg included."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    b = 0
+    r = co.convexify_arrays(g['A'][b], g['B'][b], g['H'][b], G=g['G'][b])
+    assert int(r['status']) == int(g['status'][b])
+    assert np.linalg.norm(r['Hc'] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b]) < 1e-8
+    assert np.linalg.norm(r['Fg'] - g['Fg'][b]) / np.linalg.norm(g['Fg'][b]) < 1e-7
+    assert abs(r['kappa'] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+
+
+def test_dropin_oracle_accepts_equality_jacobians():
+    """convexify(..., G=...) -> the supplement carries the G' diag(Fg) G term (convexifier.py:196-197)."""
+    A, B, H = co.gen_problem(20, 3, 3, 2)[:3]
+    G = np.random.default_rng(21).standard_normal((3, 2, 5))
+    Q = [h[:3, :3] for h in H]; R = [h[3:, 3:] for h in H]; N = [h[:3, 3:] for h in H]
+    dHc, dQc, dRc, dNc = co.convexify(list(A), list(B), Q, R, N, G=list(G))
+    r = co.convexify_arrays(A, B, H, G=G)
+    assert np.abs(np.stack(dHc) - r['dHc']).max() == 0.0 and np.linalg.eigvalsh(H + np.stack(dHc)).min() > 0
+
+
 def test_gap_tolerance_reported():
     """kappa - kappa* <= tol*kappa: tightening the tolerance moves kappa by less than the looser gap."""
     A, B, H, _, _ = co.gen_problem(5, 8, 3, 2)

@@ -7,9 +7,10 @@ include/tunempc_hip.h.  `opts['solver']` selects the backend: 'hip' (default her
 'mosek' / 'cvxopt' strings are accepted and mapped to 'hip' because those solvers do not exist on this
 stack).  There is no CPU path in this package.
 
-Scope of this round: Step 1 (eta_F = 0, eta_T = 0) without equality-constraint
-regularisation.  Problems that need Step 2 / Step 3 (active-constraint or forced regularisation,
-convexifier.py:116-157) raise NotImplementedError when G or C are supplied and Step 1 is infeasible.
+Scope of this round: Step 1 (eta_F = 0, eta_T = 0), with the equality-constraint
+multipliers Fg (convexifier.py:249-255) when G is given (up to NG_MAX rows per stage).  Problems that need
+Step 2 / Step 3 (active-constraint or forced regularisation, convexifier.py:116-157) raise NotImplementedError
+when G or C are supplied and Step 1 is infeasible.
 """
 import numpy as np
 
@@ -21,11 +22,14 @@ from ._lib import HipConvexifier, STATUS_NAMES
 _HANDLES = {}
 
 
-def _handle(p, nx, mb):
-    key = (p, nx, mb)
+NG_MAX = 8       # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
+
+
+def _handle(p, nx, mb, ng=0):
+    key = (p, nx, mb, ng)
     h = _HANDLES.get(key)
     if h is None:
-        h = HipConvexifier(p, nx, mb)
+        h = HipConvexifier(p, nx, mb, ng=ng)
         _HANDLES[key] = h
     return h
 
@@ -37,16 +41,26 @@ def _to_array(m):
     return np.atleast_2d(np.asarray(m, dtype=np.float64))
 
 
-def convexify_batch(A, B, H, tol=None, handle=None):
+def convexify_batch(A, B, H, tol=None, handle=None, G=None):
     """Batched Step 1.  A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict with
     Hc, dHc [nb,p,n,n], P [nb,p,nx,nx], alpha, beta, kappa [nb], status [nb] (0 Optimal, 1 Feasible,
-    2 Infeasible; convexifier.py:442-451), iters [nb], info [nb,16]."""
+    2 Infeasible; convexifier.py:442-451), iters [nb], info [nb,16].
+    G [nb,p,ng,n] (optional): equality-constraint Jacobians; their multipliers Fg [nb,p,ng] (convexifier.py:249-255)
+    join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
     mb = B.shape[3]
-    h = handle or _handle(p, nx, mb)
+    ng = 0
+    if G is not None:
+        G = np.asarray(G, dtype=np.float64)
+        ng = G.shape[2]
+        if ng > NG_MAX:
+            raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
+    h = handle or _handle(p, nx, mb, ng)
     if tol is not None:
         h.set_options(tol=tol)
+    if ng > 0:
+        return h.convexify_eq_batch(A, B, H, G)
     return h.convexify_batch(A, B, H)
 
 
@@ -74,8 +88,6 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         arg['G'] = G
 
     arg = preprocessing.input_checks(arg)
-    if 'G' in arg:
-        raise NotImplementedError('equality-constraint regularisation Fg (convexifier.py:249-255) is not built yet')
     period = len(arg['A'])
     Logger.logger.info('Convexify Hessians along {:d}-periodic steady state trajectory.'.format(period))
 
@@ -95,7 +107,12 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     Logger.logger.info(50 * '*')
     Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
     Logger.logger.info('solving SDP...')
-    res = convexify_batch(As[None], Bs[None], Hs[None])
+    Gs = None
+    if 'G' in arg:        # the multipliers Fg_k >= 0 belong to every step, Step 1 included (convexifier.py:249-255)
+        Gs = np.stack([_to_array(g) for g in arg['G']])
+        if Gs.shape[1] == 0:
+            Gs = None
+    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None])
 
     if res['info'][0, 13] != 0.0:      # already convex: convexifier.py:83-85 (bare zero arrays, as the reference)
         Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')

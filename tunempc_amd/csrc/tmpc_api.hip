@@ -12,6 +12,7 @@
 #include "tmpc_stage.h"
 #include "tmpc_schur.h"
 #include "tmpc_factor.h"
+#include "tmpc_phi.h"
 
 using namespace tmpc;
 
@@ -35,6 +36,7 @@ struct tmpc_handle {
   size_t slab_bytes;
   // chunk-local copies of the user inputs when called with host pointers
   double *dA, *dB, *dH;          // device staging for host API (chunk sized)
+  double* dG;                    // [chunk][p][ng][n] staging of the equality-constraint Jacobians
   double* d_info;                // [chunk][16]
   double* d_abk;                 // [chunk][3]
   int32_t* d_si;                 // [chunk][2]
@@ -45,8 +47,9 @@ struct tmpc_handle {
 // ---------------------------------------------------------------------------------- sizes
 static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
 
-static Dims make_dims(int chunk, int p, int nx, int mb) {
+static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0) {
   Dims d;
+  d.ng = ng;
   d.B = chunk; d.p = p; d.nx = nx; d.mb = mb; d.n = nx + mb;
   d.d = nx * (nx + 1) / 2;
   d.dp = (d.d + 15) / 16 * 16;
@@ -88,6 +91,15 @@ static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
   w.active = c.take<int>(64);
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
+  w.G = nullptr; w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
+  if (dm.ng > 0) {
+    const size_t g = dm.ng;
+    w.phi = c.take<double>(BP * g); w.zph = c.take<double>(BP * g); w.dphi = c.take<double>(BP * g); w.dzph = c.take<double>(BP * g);
+    w.corrp = c.take<double>(BP * g); w.Fg = c.take<double>(BP * g);
+    w.pvec = c.take<double>(BP * 2 * g * (2 * dm.n + 2 * dm.nx)); w.psm = c.take<double>(BP * (g * g + 8 * g));
+    double* dG = c.take<double>(BP * g * dm.n);
+    if (h) h->dG = dG;
+  }
   if (h) {
     h->dA = c.take<double>(BP * nxx); h->dB = c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); h->dH = c.take<double>(BP * nn);
     h->d_info = c.take<double>((size_t)dm.B * TMPC_INFO_STRIDE); h->d_abk = c.take<double>((size_t)dm.B * 3);
@@ -280,25 +292,34 @@ static int set_lds_attrs() {
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm2<4, 1, 5, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   done = true;
   return TMPC_OK;
 }
 
 // one chunk (dm.B = actual number of problems in this chunk, <= capacity); inputs already on device
-static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st) {
+static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
+                     const double* dG = nullptr) {
   Dims dm = h->dm;
   dm.B = nb;
+  if (!dG) dm.ng = 0;            // a handle created with ng > 0 also serves calls without the equality-constraint term
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
   WS w = h->ws;
-  w.A = dA; w.Bm = dB; w.H = dH;
+  w.A = dA; w.Bm = dB; w.H = dH; w.G = dG;
   const Opts o = h->opt;
   const int BP = nb * dm.p;
+  const bool eq = dm.ng > 0;
+  const size_t phi_schur_lds = (size_t)5 * dm.ng * dm.d * sizeof(double);
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
   HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   hipLaunchKernelGGL(k_init_stage, dim3(BP), dim3(64), slots_bytes(2), st, w, dm);
   hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, w, dm);
   hipLaunchKernelGGL(k_init_state, dim3(BP), dim3(64), 0, st, w, dm);
+  if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BP), dim3(64), 0, st, w, dm);
   int active = 0;
   HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -307,19 +328,25 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   while (active > 0 && it < cap) {
     if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), slots_bytes(PHI_SLOTS), st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(nb), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_schur, dim3(BP), dim3(256), phi_schur_lds, st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
     if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
     else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(1), st, w, dm, pass);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), slots_bytes(5), st, w, dm, pass);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (pass == 1) {
         hipLaunchKernelGGL(k_ctrl_b, dim3(nb), dim3(64), 0, st, w, dm);
         if (prof) HIPCHK(hipEventRecord(h->ev[4], st));
@@ -328,6 +355,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
       }
     }
     hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[5], st));
@@ -359,29 +387,33 @@ int tmpc_device_count(void) {
   return n;
 }
 
-uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) {
-  if (chunk < 1 || !dims_ok(p, nx, mb)) return 0;
+uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng) {
+  if (chunk < 1 || !dims_ok(p, nx, mb) || ng < 0 || ng > NGM) return 0;
   WS w;
-  Dims dm = make_dims(chunk, p, nx, mb);
+  Dims dm = make_dims(chunk, p, nx, mb, ng);
   return (uint64_t)carve(w, dm, nullptr, nullptr);
 }
+uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) { return tmpc_workspace_bytes_eq(chunk, p, nx, mb, 0); }
 
-int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) {
+int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) { return tmpc_create_eq(out, chunk, p, nx, mb, 0); }
+
+int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) {
   if (!out) return TMPC_E_ARG;
   *out = nullptr;
   if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
+  if (ng < 0 || ng > NGM) { snprintf(g_err, sizeof(g_err), "unsupported number of equality-constraint rows ng=%d (need 0<=ng<=%d)", ng, NGM); return TMPC_E_UNSUPPORTED; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }
   if (chunk <= 0) {
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    const uint64_t per = tmpc_workspace_bytes(1, p, nx, mb);
+    const uint64_t per = tmpc_workspace_bytes_eq(1, p, nx, mb, ng);
     uint64_t fit = (uint64_t)(0.6 * (double)fr) / std::max<uint64_t>(per, 1);
     chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(512, fit));
   }
   tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
   if (!h) return TMPC_E_NOMEM;
-  h->dm = make_dims(chunk, p, nx, mb);
+  h->dm = make_dims(chunk, p, nx, mb, ng);
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
   h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
@@ -493,6 +525,30 @@ int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const do
     if (rc != TMPC_OK) return rc;
     rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
     if (rc != TMPC_OK) return rc;
+  }
+  return TMPC_OK;
+}
+
+int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, const double* G,
+                                 double* Hc, double* dHc, double* P, double* Fg, double* alpha, double* beta, double* kappa,
+                                 int32_t* status, int32_t* iters, double* info) {
+  if (!h || nbt < 1 || !A || !H || !G || !Fg || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  if (h->dm.ng < 1) { snprintf(g_err, sizeof(g_err), "handle was created without equality-constraint rows (use tmpc_create_eq)"); return TMPC_E_ARG; }
+  hipStream_t st = 0;
+  const Dims& dm = h->dm;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.ng * dm.n;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t BP = (size_t)nb * dm.p;
+    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dG, G + (size_t)off * dm.p * gn, BP * gn * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st, h->dG);
+    if (rc != TMPC_OK) return rc;
+    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
+    if (rc != TMPC_OK) return rc;
+    HIPCHK(hipMemcpy(Fg + (size_t)off * dm.p * dm.ng, h->ws.Fg, BP * dm.ng * sizeof(double), hipMemcpyDeviceToHost));
   }
   return TMPC_OK;
 }

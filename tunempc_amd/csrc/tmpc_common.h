@@ -42,7 +42,9 @@ enum {
   Q_XS = 0, Q_RD2, Q_S2, Q_TRX2, Q_HBY, Q_TRPSI, Q_TRPHI2, Q_HBPHI,   // stage_pre
   Q_TRT2, Q_HBG,                                                       // stage_rhs
   Q_MINX, Q_MINS, Q_DXS, Q_XDS, Q_DXDS, Q_DP2, Q_P2,                   // stage_dir
-  Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, Q_DH2, Q_M2, NPART = 24
+  Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, Q_DH2, Q_M2,
+  Q_RPHI2,                                                             // phi_pre (equality-constraint multipliers)
+  NPART = 26
 };
 
 // Kronecker-factor slots per stage (KF[((b*p+k)*12 + slot) * nx*nx])
@@ -59,7 +61,9 @@ struct Dims {
   int dp;       // d padded to a multiple of 16
   int nt;       // ceil(dp / TB)
   int flags;    // bit0: debug - replace MFMA by scalar FMAs
+  int ng;       // rows of the equality-constraint Jacobian G_k per stage (0: none), <= NGM
 };
+constexpr int NGM = 8;   // max ng (the stage-local elimination keeps 5 * ng * d doubles in LDS: 155 KB at ng = 8, d = 496)
 
 struct Opts {
   double tol;          // complementarity tolerance: mu_target = tol * kappa (relative gap on kappa = (2pn+1)*tol)
@@ -107,6 +111,12 @@ struct WS {
   double* Hc;      // [B,p,n,n]
   double* dHc;     // [B,p,n,n]
   double* Pout;    // [B,p,nx,nx]
+  // equality-constraint term of Step 1 (convexifier.py:249-255, :346-347): M_k += G_k' diag(phi_k) G_k, phi_k = s*Fg_k >= 0
+  const double* G; // [B,p,ng,n] input
+  double* phi; double* zph; double* dphi; double* dzph; double* corrp;   // [B,p,ng] multipliers (slack = phi itself), their duals, directions, Mehrotra term
+  double* pvec;    // [B,p,2,ng,2n+2nx]  per cone block r and row i: w = X_r g, u = S_r^-1 g, V w, V u
+  double* psm;     // [B,p,ng*ng+8*ng]   K = T_phiphi^-1, c_tau, c_alpha, K c_tau, K c_alpha, r_phi, K r_phi
+  double* Fg;      // [B,p,ng] output: phi / (s*alpha)
 };
 
 }  // namespace tmpc
