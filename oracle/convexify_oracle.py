@@ -271,13 +271,25 @@ def _max_step(Li, dX):
 
 
 # ------------------------------------------------------------ the SDP solve (Step 1)
-def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
+def _arrow(t, v, w):
+    """[[t, w v'], [w v, t I]]: the LMI form of  t >= || w v ||_2  (the epigraph of one norm term of convexifier.py:276-283)."""
+    m = len(v)
+    S = t * np.eye(m + 1)
+    S[0, 1:] = w * v; S[1:, 0] = w * v
+    return S
+
+
+def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
     constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
     convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags.
     G [p, ng, n] (optional): equality-constraint Jacobians; M_k gains G_k' diag(phi_k) G_k with the cost-free
     multipliers phi_k = s*Fg_k >= 0 of convexifier.py:249-255 / :346-347 (they belong to Step 1 whenever G is given).
-    They are handled as extra border columns of the Schur complement (each one touches only P_k and P_{k+1})."""
+    They are handled as extra border columns of the Schur complement (each one touches only P_k and P_{k+1}).
+    C (list of p entries, (nc_k x n) or None) together with rho: Step 2 (`constr=True`, convexifier.py:116-131): multipliers
+    f_k = s*F_k >= 0 of the active constraints (:258-266, term :348-350) and the objective terms rho*||F_k||, rho*||Fg_k||
+    (:276-283), each norm as an epigraph variable t with the arrow LMI [[t, w v'], [w v, t I]] >> 0 and w = rho*sbeta/s (the
+    objective is tau = sbeta*beta plus the sum of the t).  All of them are stage-local border columns as well."""
     o = dict(DEFAULT_OPTS)
     if opts:
         o.update(opts)
@@ -303,14 +315,36 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
     X2 = X1.copy()
     s0 = alpha
     x0 = o.get('init_x', 1.0) / (p * n)
-    ng = 0
+    ng = 0                                                 # rows of [G_k; C_k] per stage (padded to the longest stage, `mask` = real rows)
+    ng0 = 0                                                # of which equality-constraint rows
+    constr = C is not None and rho is not None
+    ncs = [0] * p
+    if constr:
+        ncs = [0 if C[k] is None else np.atleast_2d(np.asarray(C[k], dtype=np.float64)).shape[0] for k in range(p)]
     if G is not None:
         G = np.asarray(G, dtype=np.float64)
-        ng = G.shape[1]
+        ng0 = G.shape[1]
+    ng = ng0 + max(ncs)
+    arrows = []                                            # epigraph blocks: dict(k, idx (rows of stage k), t, X)
+    if ng:
+        J = np.zeros((p, ng, n)); mask = np.zeros((p, ng), dtype=bool)
+        if ng0:
+            J[:, :ng0] = G; mask[:, :ng0] = True
+        for k in range(p):
+            if ncs[k]:
+                J[k, ng0:ng0 + ncs[k]] = np.atleast_2d(np.asarray(C[k], dtype=np.float64)); mask[k, ng0:ng0 + ncs[k]] = True
+        G = J
         GG = G[:, :, :, None] * G[:, :, None, :]           # [p, ng, n, n]: g g' per constraint row
         phi = np.ones((p, ng))                             # slack of phi >= 0 is phi itself
-        z = np.full((p, ng), x0)                           # its multiplier
-        N = N + p * ng
+        z = np.where(mask, x0, 0.0)                        # its multiplier
+        N = N + int(mask.sum())
+        if constr:
+            wr = rho * sbeta / s
+            for k in range(p):
+                for idx in ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else []):
+                    m = len(idx)
+                    arrows.append(dict(k=k, idx=idx, t=1.0 + wr * np.sqrt(m), X=x0 * np.eye(m + 1)))
+                    N = N + m + 1
     mu_t = None
     phase = 0
     ncent = 0
@@ -328,12 +362,20 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
         Rd1 = (M - I) - S1
         Rd2 = (tau * I - M) - S2
         rd0 = (alpha - ALPHA_MIN) - s0
-        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0)) / N
+        for a in arrows:
+            a['S'] = _arrow(a['t'], phi[a['k'], a['idx']], wr)
+        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0) + sum(np.sum(a['X'] * a['S']) for a in arrows)) / N
         Y = X1 - X2
         r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
         r_alpha = -np.sum(Hb * Y) - x0
         r_P = -calH_adj(A, B, Y)
-        r_phi2 = np.sum((-np.einsum('kiab,kab->ki', GG, Y) - z) ** 2) if ng else 0.0
+        r_phi2 = 0.0
+        if ng:
+            r_phi = -np.einsum('kiab,kab->ki', GG, Y) - z
+            for a in arrows:                                   # the arrow LMI holds 2 w phi_i off the diagonal; its own variable t has cost 1
+                r_phi[a['k'], a['idx']] -= 2.0 * wr * a['X'][0, 1:]
+                r_phi2 += (1.0 - np.trace(a['X'])) ** 2
+            r_phi2 += np.sum((r_phi * mask) ** 2)
         pinf = np.sqrt(r_tau ** 2 + r_alpha ** 2 + np.sum(_svec_grad(r_P, ia, ib) ** 2) + r_phi2) / 2.0
         dinf = np.sqrt(np.sum(Rd1 ** 2) + np.sum(Rd2 ** 2) + rd0 ** 2) / (1.0 + np.sqrt(np.sum(S1 ** 2) + np.sum(S2 ** 2)))
         relgap = N * mu / max(1.0, abs(tau))
@@ -394,7 +436,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
                       Wk = np.zeros((p, n, n)); Wk[k] = W[k, i]
                       Ug[:, :, k * ng + i] = _svec_grad(calH_adj(A, B, Wk), ia, ib)
               U = np.concatenate([U, Ug], axis=2)
-              nb_ = 2 + p * ng
+              U = np.concatenate([U, np.zeros((p, d, len(arrows)))], axis=2)       # the epigraph variables do not reach P
+              nb_ = 2 + p * ng + len(arrows)
               Bfull = np.zeros((nb_, nb_)); Bfull[:2, :2] = Bb
               GXG1 = G @ X1 @ np.swapaxes(G, 1, 2); GSG1 = G @ S1i @ np.swapaxes(G, 1, 2)     # [p,ng,ng]
               GXG2 = G @ X2 @ np.swapaxes(G, 1, 2); GSG2 = G @ S2i @ np.swapaxes(G, 1, 2)
@@ -403,14 +446,26 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
               c_alpha = np.einsum('kiab,kab->ki', GG, PhiH)
               for k in range(p):
                   sl = slice(2 + k * ng, 2 + (k + 1) * ng)
-                  Bfull[sl, sl] = symmetrize(Bpp[k][None])[0] + np.diag(z[k] / phi[k])
+                  Bfull[sl, sl] = symmetrize(Bpp[k][None])[0] + np.diag(np.where(mask[k], z[k] / phi[k], 1.0))
                   Bfull[0, sl] = c_tau[k]; Bfull[sl, 0] = c_tau[k]
                   Bfull[1, sl] = c_alpha[k]; Bfull[sl, 1] = c_alpha[k]
+              for e, a in enumerate(arrows):
+                  te = 2 + p * ng + e
+                  a['Si'] = np.linalg.inv(a['S'])
+                  Pe = symmetrize(a['X'] @ a['Si'])
+                  Bfull[te, te] = np.trace(Pe)
+                  cols = 2 + a['k'] * ng + a['idx']
+                  m = len(a['idx'])
+                  for q in range(m):
+                      Eq = np.zeros((m + 1, m + 1)); Eq[0, q + 1] = wr; Eq[q + 1, 0] = wr
+                      Bfull[cols[q], te] = Bfull[te, cols[q]] = 2.0 * wr * Pe[0, q + 1]
+                      Fq = symmetrize(a['X'] @ Eq @ a['Si'])
+                      Bfull[cols, cols[q]] += 2.0 * wr * Fq[0, 1:]
               Bb = Bfull
           TU = chol.solve(U)
           Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
 
-        def direction(sig_mu, corr1=None, corr2=None, corr0=0.0, corrp=None):
+        def direction(sig_mu, corr1=None, corr2=None, corr0=0.0, corrp=None, corre=None):
             T1 = sig_mu * S1i - symmetrize(X1 @ Rd1 @ S1i)
             T2 = sig_mu * S2i - symmetrize(X2 @ Rd2 @ S2i)
             if corr1 is not None:
@@ -423,7 +478,13 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             rbv = np.array([rhs_tau, rhs_alpha])
             if ng:
                 tphi = sig_mu / phi - (corrp if corrp is not None else 0.0)
-                rbv = np.concatenate([rbv, (np.einsum('kiab,kab->ki', GG, T1 - T2) + tphi).ravel()])
+                rph = np.einsum('kiab,kab->ki', GG, T1 - T2) + tphi
+                rt = np.zeros(len(arrows))
+                for e, a in enumerate(arrows):
+                    a['T'] = sig_mu * a['Si'] - (corre[e] if corre is not None else 0.0)
+                    rph[a['k'], a['idx']] += 2.0 * wr * a['T'][0, 1:]
+                    rt[e] = np.trace(a['T']) - 1.0
+                rbv = np.concatenate([rbv, (rph * mask).ravel(), rt])
             rb = rbv - np.einsum('kdi,kd->i', U, zsol)
             db = np.linalg.solve(Sb, rb)
             dp = zsol - TU @ db
@@ -431,8 +492,12 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             dP = _smat(dp, nx, ia, ib)
             dM = dalpha * Hb + calH(A, B, dP)
             if ng:
-                dphi = db[2:].reshape(p, ng)
+                dphi = db[2:2 + p * ng].reshape(p, ng)
                 dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
+                for e, a in enumerate(arrows):
+                    a['dt'] = db[2 + p * ng + e]
+                    a['dS'] = _arrow(a['dt'], dphi[a['k'], a['idx']], wr)
+                    a['dX'] = sig_mu * a['Si'] - a['X'] - symmetrize(a['X'] @ a['dS'] @ a['Si']) - (corre[e] if corre is not None else 0.0)
             dS1 = dM + Rd1
             dS2 = dtau * I - dM + Rd2
             dX1 = sig_mu * S1i - X1 - symmetrize(X1 @ dS1 @ S1i)
@@ -442,7 +507,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             ds0 = dalpha + rd0
             dx0 = sig_mu / s0 - x0 - x0 * ds0 / s0 - corr0
             if ng:
-                dz = sig_mu / phi - z - z * dphi / phi - (corrp if corrp is not None else 0.0)
+                dz = (sig_mu / phi - z - z * dphi / phi - (corrp if corrp is not None else 0.0)) * mask
                 return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz
             return dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, None, None
 
@@ -455,6 +520,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             if ng:
                 if (dz < 0).any(): ap = min(ap, (-z[dz < 0] / dz[dz < 0]).min())
                 if (dphi < 0).any(): ad = min(ad, (-phi[dphi < 0] / dphi[dphi < 0]).min())
+            for a in arrows:
+                ap = min(ap, _max_step(np.linalg.inv(np.linalg.cholesky(a['X']))[None], a['dX'][None]))
+                ad = min(ad, _max_step(np.linalg.inv(np.linalg.cholesky(a['S']))[None], a['dS'][None]))
             return ap, ad
 
         if phase == 0:
@@ -462,7 +530,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             ap = min(1.0, ap); ad = min(1.0, ad)
             mu_aff = (np.sum((X1 + ap * dX1) * (S1 + ad * dS1)) + np.sum((X2 + ap * dX2) * (S2 + ad * dS2))
-                      + (x0 + ap * dx0) * (s0 + ad * ds0) + (np.sum((z + ap * dz) * (phi + ad * dphi)) if ng else 0.0)) / N
+                      + (x0 + ap * dx0) * (s0 + ad * ds0) + (np.sum((z + ap * dz) * (phi + ad * dphi)) if ng else 0.0)
+                      + sum(np.sum((a['X'] + ap * a['dX']) * (a['S'] + ad * a['dS'])) for a in arrows)) / N
             sigma = min(max((mu_aff / mu) ** 2, 1e-6), 1.0)     # exponent 2: ~10 % fewer iterations than Mehrotra's 3 on this SDP family
             sig_mu = sigma * mu
             if mu_t is not None:
@@ -470,7 +539,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
             corr1 = symmetrize(dX1 @ dS1 @ S1i); corr2 = symmetrize(dX2 @ dS2 @ S2i)
             corr0 = dx0 * ds0 / s0
             corrp = dz * dphi / phi if ng else None
-            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(sig_mu, corr1, corr2, corr0, corrp)
+            corre = [symmetrize(a['dX'] @ a['dS'] @ a['Si']) for a in arrows]
+            dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(sig_mu, corr1, corr2, corr0, corrp, corre)
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             mn = min(ap, ad)
             gam = 0.9 + 0.09 * min(mn, 1.0)
@@ -495,6 +565,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
         tau += ad * dtau; alpha += ad * dalpha; P = P + ad * dP
         if ng:
             z = z + ap * dz; phi = phi + ad * dphi
+        for a in arrows:
+            a['X'] = symmetrize(a['X'] + ap * a['dX']); a['t'] += ad * a['dt']
         if phase == 1:
             # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation
             # at the rounding floor, or on the iteration cap
@@ -516,14 +588,17 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None):
     Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
     out = dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
                ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
-    if ng:
-        out['Fg'] = phi / (s * alpha)                   # convexifier.py:410 (s_F = s_alpha = s)
+    if ng0:
+        out['Fg'] = phi[:, :ng0] / (s * alpha)          # convexifier.py:410 (s_F = s_alpha = s)
+    if constr:
+        out['F'] = [phi[k, ng0:ng0 + ncs[k]] / (s * alpha) if ncs[k] else None for k in range(p)]     # convexifier.py:415-420
+        out['objective'] = tau / sbeta + sum(a['t'] for a in arrows) / sbeta       # beta + sum rho ||F_k|| (+ rho ||Fg_k||)
     return out
 
 
-def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None):
+def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None, C=None, F=None):
     """convexifier.py:403-456 (status rule :442-451)."""
-    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P, G=G, Fg=Fg)
+    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P, G=G, Fg=Fg, C=C, F=F)
     Hc = H + dHc
     ev = np.linalg.eigvalsh(Hc)
     min_eig = ev.min(); max_cond = (ev[:, -1] / ev[:, 0]).max() if min_eig > 0 else np.inf
@@ -534,9 +609,10 @@ def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None):
     return st, dHc, dQc, dRc, dNc, min_eig, max_cond
 
 
-def convexify_arrays(A, B, H, opts=None, verbose=False, G=None):
-    """Array-level restatement of convexifier.convexify (Step 1, optional equality-constraint term G [p,ng,n]):
-    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, dHc, Hc, P, alpha, beta, kappa, iters, early_exit[, Fg])."""
+def convexify_arrays(A, B, H, opts=None, verbose=False, G=None, C=None, rho=1e-3):
+    """Array-level restatement of convexifier.convexify, Steps 1 and 2 (optional equality-constraint term G [p,ng,n]; C: list of
+    p active-constraint Jacobians (nc_k x n) or None, used by Step 2 when Step 1 is infeasible, convexifier.py:116-131):
+    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, step, dHc, Hc, P, alpha, beta, kappa, iters, early_exit[, Fg][, F])."""
     A = np.asarray(A, float); B = np.asarray(B, float); H = symmetrize(np.asarray(H, float))
     p, nx, _ = A.shape
     n = H.shape[1]
@@ -546,12 +622,17 @@ def convexify_arrays(A, B, H, opts=None, verbose=False, G=None):
                     P=np.zeros((p, nx, nx)), alpha=1.0, beta=0.0, kappa=0.0, iters=0)
     r = sdp_step1(A, B, H, opts, verbose, G=G)
     st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'], G=G, Fg=r.get('Fg'))
-    r.update(status=st, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond)
+    r.update(status=st, step=1, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond)
+    if st == STATUS_INFEASIBLE and C is not None:          # Step 2 (eta_F = 1): convexifier.py:116-131
+        it1 = r['iters']
+        r = sdp_step1(A, B, H, opts, verbose, G=G, C=C, rho=rho)
+        st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'], G=G, Fg=r.get('Fg'), C=C, F=r['F'])
+        r.update(status=st, step=2, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond, iters_step1=it1)
     return r
 
 
 def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
-    """Drop-in restatement of convexifier.convexify (convexifier.py:36-163) for Step 1."""
+    """Drop-in restatement of convexifier.convexify (convexifier.py:36-163), Steps 1 and 2 (Step 3: oracle/reference_sdp.py)."""
     arg = dict(A=A, B=B, Q=Q, R=R, N=N)
     if C is not None:
         arg['C'] = C
@@ -563,12 +644,15 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
     Hs = np.stack([build_hessian(np.asarray(q, float), np.asarray(r, float), np.asarray(nn, float))
                    for q, r, nn in zip(arg['Q'], arg['R'], arg['N'])])
     As = np.stack([np.asarray(a, float) for a in arg['A']]); Bs = np.stack([np.asarray(b, float) for b in arg['B']])
-    res = convexify_arrays(As, Bs, Hs, opts, G=Gs)
+    Cs = [None if c is None else np.atleast_2d(np.asarray(c, float)) for c in arg['C']] if 'C' in arg else None
+    rho = (opts or {}).get('rho', 1e-3)
+    sopts = {k: v for k, v in (opts or {}).items() if k not in ('rho', 'solver', 'force')} or None
+    res = convexify_arrays(As, Bs, Hs, sopts, G=Gs, C=Cs, rho=rho)
     if res['early_exit']:
         return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))   # :85
     if res['status'] == STATUS_INFEASIBLE:
-        if 'G' in arg or 'C' in arg:
-            raise NotImplementedError('oracle: Steps 2/3 live in oracle/reference_sdp.py')
+        if (opts or {}).get('force', False):
+            raise NotImplementedError('oracle: Step 3 lives in oracle/reference_sdp.py')
         raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
     dH = res['dHc']
     return ([dH[k] for k in range(len(dH))], [dH[k][:nx, :nx] for k in range(len(dH))],

@@ -136,3 +136,39 @@ def test_structured_oracle_with_equality_term_matches_dense_model(seed, p, nx, n
     ev = np.linalg.eigvalsh(r['Hc'])
     assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= r['kappa'] * (1 + 1e-8)
     assert np.abs(r['Hc'] - H - co.convex_hessian_suppl(A, B, r['P'], G=G, Fg=r['Fg'])[0]).max() < 1e-12
+
+
+@pytest.mark.parametrize('seed,p,nx,nu,ng,ncs,rho', [(20, 3, 3, 2, 0, [2, 0, 1], 1e-3), (0, 3, 3, 2, 2, [1, 2, 0], 1.0), (30, 2, 3, 1, 1, [1, 1], 1e-3),
+                                                   (20, 1, 3, 1, 0, [2], 1.0)])
+def test_structured_oracle_step2_matches_dense_model(seed, p, nx, nu, ng, ncs, rho):
+    """Step 2 model (constr=True, convexifier.py:258-283): multipliers F_k >= 0 of ragged active-constraint Jacobians (None
+    entries included), norms rho*||F_k|| and rho*||Fg_k|| in the objective.  The structured oracle (stage-local border columns,
+    arrow LMIs for the norms) and the dense restatement reach the same objective."""
+    A, B, H = co.gen_problem(seed, p, nx, nu)[:3]
+    rng = np.random.default_rng(seed + 5)
+    G = rng.standard_normal((p, ng, nx + nu)) if ng else None
+    C = [rng.standard_normal((c, nx + nu)) if c else None for c in ncs]
+    r = co.sdp_step1(A, B, H, G=G, C=C, rho=rho)
+    Q, R, N = _split(H, nx)
+    ref = rs.solve_step(list(A), list(B), Q, R, N, G=None if G is None else [g for g in G], C=C, rho=rho, constr=True)
+    assert r['ipm_status'] == 'optimal' and ref['status'] == 'Optimal'
+    assert abs(r['objective'] / ref['objective'] - 1.0) < 5e-6
+    assert all((f is None) == (c is None) and (f is None or (f >= 0).all()) for f, c in zip(r['F'], C))
+    dHc = co.convex_hessian_suppl(A, B, r['P'], G=G, Fg=r.get('Fg'), C=C, F=r['F'])[0]
+    ev = np.linalg.eigvalsh(H + dHc)
+    assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= r['kappa'] * (1 + 1e-8)
+
+
+def test_structured_oracle_takes_step2_when_step1_is_infeasible():
+    """The dense model's vector: B = 0, R < 0 -> Step 1 infeasible, Step 2 feasible through C (convexifier.py:116-131)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'n1_step2_active_constraints.npz'))
+    p = g['A'].shape[0]
+    H = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
+    C = [g['Cu'][k] for k in range(p)]
+    assert co.convexify_arrays(g['A'], g['B'], H)['status'] == co.STATUS_INFEASIBLE
+    r = co.convexify_arrays(g['A'], g['B'], H, C=C, rho=float(g['rho']))
+    assert r['step'] == 2 == int(g['step']) and r['status'] == co.STATUS_OPTIMAL
+    assert abs(r['objective'] / float(g['objective']) - 1.0) < 2e-6 and abs(r['kappa'] / float(g['kappa']) - 1.0) < 1e-4
+    out = co.convexify([a for a in g['A']], [b for b in g['B']], [q for q in g['Q']], [x for x in g['R']], [x for x in g['N']],
+                       C=C, opts={'rho': float(g['rho'])})
+    assert np.abs(np.stack(out[0]) - r['dHc']).max() == 0.0 and all(x[0, 0] > 0.5 for x in out[2])
