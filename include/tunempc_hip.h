@@ -72,6 +72,10 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
  * Such a handle also serves every call that takes no G. */
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng);
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng);
+/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 8, (ng+nc)*nx*(nx+1)/2 <= 4096),
+ * for tmpc_convexify_step2_batch_host. */
+uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc);
+int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc);
 int tmpc_destroy(tmpc_handle* h);
 /* Problems processed per launch wave (the chunk the workspace was sized for). */
 int tmpc_get_chunk(tmpc_handle* h);
@@ -99,6 +103,16 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nb, const double* dA, const 
 int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* G,
                                  double* Hc, double* dHc, double* P, double* Fg, double* alpha, double* beta, double* kappa,
                                  int32_t* status, int32_t* iters, double* info);
+
+/* The model of Step 2 (convexifier.py:116-131: setUpModelPicos with constr=True, :258-266 multipliers F_k >= 0 of the active
+ * constraints, :276-283 objective beta + sum rho*||F_k|| + sum rho*||Fg_k||, :348-350 term C_k' diag(F_k) C_k, :415-420 un-scaling).
+ * J [nb][p][ng+nc][n]: per stage the ng rows of G_k, then the rows of C_k, zero padding up to nc (ng, nc of tmpc_create_con);
+ * ncnt int32 [nb][p]: rows of C_k actually present (0 for a stage whose C_k is None).  FgF [nb][p][ng+nc] out: Fg_k, then F_k,
+ * zeros in the padding.  dHc includes both constraint terms.  The caller decides when to take this step (after Step 1 came
+ * back Infeasible, as convexify() does). */
+int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* J,
+                                    const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
+                                    double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);
 
 /* convexHessianSuppl (convexifier.py:165-211) alone: dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E). */
 int tmpc_supplement_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, double* dHc);

@@ -21,6 +21,7 @@ EXPORTS = [
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
     'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_workspace_bytes_eq', 'tmpc_create_eq', 'tmpc_convexify_eq_batch_host',
+    'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -52,6 +53,12 @@ def load_library():
     lib.tmpc_create_eq.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_convexify_eq_batch_host.restype = C.c_int
     lib.tmpc_convexify_eq_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
+    lib.tmpc_workspace_bytes_con.restype = C.c_uint64
+    lib.tmpc_workspace_bytes_con.argtypes = [C.c_int] * 6
+    lib.tmpc_create_con.restype = C.c_int
+    lib.tmpc_create_con.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_convexify_step2_batch_host.restype = C.c_int
+    lib.tmpc_convexify_step2_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, C.c_double, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
     lib.tmpc_create.restype = C.c_int
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
@@ -108,14 +115,15 @@ def _check(lib, rc, what):
 class HipConvexifier:
     """Handle for batched convexification of problems of one shape (p, nx, mb) on the current HIP device."""
 
-    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0):
+    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0, nc=0):
         self.lib = load_library()
         if self.lib.tmpc_device_count() < 1:
             raise RuntimeError("tunempc_amd: no HIP device visible; the convexify hot path has no CPU fallback")
         self.p, self.nx, self.mb, self.n = int(p), int(nx), int(mb), int(nx) + int(mb)
         self._h = C.c_void_p()
         self.ng = int(ng)     # rows of the equality-constraint Jacobian per stage (convexifier.py:249-255), 0: none
-        _check(self.lib, self.lib.tmpc_create_eq(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng), 'tmpc_create_eq')
+        self.nc = int(nc)     # room for active-constraint rows per stage (Step 2, convexifier.py:258-266), 0: none
+        _check(self.lib, self.lib.tmpc_create_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_con')
         self.chunk = int(self.lib.tmpc_get_chunk(self._h))
         self.flags = int(flags)
         self.set_options(tol, center_tol, max_iter, center_iter, flags)
@@ -172,6 +180,28 @@ class HipConvexifier:
                                                    _dptr(out['beta']), _dptr(out['kappa']), _iptr(out['status']),
                                                    _iptr(out['iters']), _dptr(out['info']))
         _check(self.lib, rc, 'tmpc_convexify_eq_batch_host')
+        return out
+
+    def convexify_step2_batch(self, A, B, H, J, ncnt, rho):
+        """The Step 2 model (convexifier.py:116-131).  J [nb,p,ng+nc,n]: rows of G_k, then rows of C_k, zero padding;
+        ncnt [nb,p] int32: rows of C_k present -> outputs of convexify_batch + FgF [nb,p,ng+nc] (Fg_k, then F_k)."""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        H = np.ascontiguousarray(H, dtype=np.float64); J = np.ascontiguousarray(J, dtype=np.float64)
+        ncnt = np.ascontiguousarray(ncnt, dtype=np.int32)
+        nb = A.shape[0]
+        nr = self.ng + self.nc
+        assert A.shape == (nb, self.p, self.nx, self.nx), A.shape
+        assert B.shape == (nb, self.p, self.nx, self.mb), B.shape
+        assert H.shape == (nb, self.p, self.n, self.n), H.shape
+        assert self.nc > 0 and J.shape == (nb, self.p, nr, self.n) and ncnt.shape == (nb, self.p), (J.shape, ncnt.shape, nr)
+        out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), FgF=np.empty((nb, self.p, nr)),
+                   alpha=np.empty(nb), beta=np.empty(nb), kappa=np.empty(nb), status=np.empty(nb, np.int32),
+                   iters=np.empty(nb, np.int32), info=np.empty((nb, INFO_STRIDE)))
+        rc = self.lib.tmpc_convexify_step2_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(J), _iptr(ncnt), float(rho),
+                                                      _dptr(out['Hc']), _dptr(out['dHc']), _dptr(out['P']), _dptr(out['FgF']),
+                                                      _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
+                                                      _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
+        _check(self.lib, rc, 'tmpc_convexify_step2_batch_host')
         return out
 
     # ------------------------------------------------------------------ device-resident entry (torch tensors)

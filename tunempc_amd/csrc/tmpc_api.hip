@@ -36,7 +36,8 @@ struct tmpc_handle {
   size_t slab_bytes;
   // chunk-local copies of the user inputs when called with host pointers
   double *dA, *dB, *dH;          // device staging for host API (chunk sized)
-  double* dG;                    // [chunk][p][ng][n] staging of the equality-constraint Jacobians
+  double* dG;                    // [chunk][p][nr][n] staging of the equality- / active-constraint Jacobians
+  int32_t* dncnt;                // [chunk][p] rows of C_k per stage (Step 2)
   double* d_info;                // [chunk][16]
   double* d_abk;                 // [chunk][3]
   int32_t* d_si;                 // [chunk][2]
@@ -47,9 +48,10 @@ struct tmpc_handle {
 // ---------------------------------------------------------------------------------- sizes
 static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
 
-static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0) {
+static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0) {
   Dims d;
-  d.ng = ng;
+  d.ng = ng; d.nr = ng + nc; d.constr = 0;
+  d.nz = d.nr + (nc > 0 ? 2 : 0);          // room for the two epigraph variables of Step 2
   d.B = chunk; d.p = p; d.nx = nx; d.mb = mb; d.n = nx + mb;
   d.d = nx * (nx + 1) / 2;
   d.dp = (d.d + 15) / 16 * 16;
@@ -91,14 +93,23 @@ static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
   w.active = c.take<int>(64);
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
-  w.G = nullptr; w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
-  if (dm.ng > 0) {
-    const size_t g = dm.ng;
+  w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
+  w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
+  w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
+  if (dm.nr > 0) {
+    const size_t g = dm.nr, z = dm.nz;
     w.phi = c.take<double>(BP * g); w.zph = c.take<double>(BP * g); w.dphi = c.take<double>(BP * g); w.dzph = c.take<double>(BP * g);
     w.corrp = c.take<double>(BP * g); w.Fg = c.take<double>(BP * g);
-    w.pvec = c.take<double>(BP * 2 * g * (2 * dm.n + 2 * dm.nx)); w.psm = c.take<double>(BP * (g * g + 8 * g));
+    w.pvec = c.take<double>(BP * 2 * g * (2 * dm.n + 2 * dm.nx)); w.psm = c.take<double>(BP * (z * z + 6 * z));
+    w.asum = c.take<double>(BP * 5);
     double* dG = c.take<double>(BP * g * dm.n);
-    if (h) h->dG = dG;
+    int32_t* dn = c.take<int32_t>(BP);
+    if (h) { h->dG = dG; h->dncnt = dn; }
+    if (dm.nz > dm.nr) {
+      w.at = c.take<double>(BP * 2); w.adt = c.take<double>(BP * 2);
+      w.aX = c.take<double>(BP * 2 * AE); w.adX = c.take<double>(BP * 2 * AE); w.acor = c.take<double>(BP * 2 * AE);
+      w.aSi = c.take<double>(BP * 2 * AE); w.aLi = c.take<double>(BP * 2 * AE); w.aLXi = c.take<double>(BP * 2 * AE);
+    }
   }
   if (h) {
     h->dA = c.take<double>(BP * nxx); h->dB = c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); h->dH = c.take<double>(BP * nn);
@@ -302,17 +313,20 @@ static int set_lds_attrs() {
 
 // one chunk (dm.B = actual number of problems in this chunk, <= capacity); inputs already on device
 static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
-                     const double* dG = nullptr) {
+                     const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0) {
   Dims dm = h->dm;
   dm.B = nb;
-  if (!dG) dm.ng = 0;            // a handle created with ng > 0 also serves calls without the equality-constraint term
+  // a handle created with room for G / C rows also serves calls without them; Step 2 (constr) when the C counts are given
+  if (!dG) { dm.ng = 0; dm.nr = 0; dm.nz = 0; }
+  dm.constr = (dG && dncnt) ? 1 : 0;
+  if (dG && !dncnt) { dm.nr = dm.ng; }
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
   WS w = h->ws;
-  w.A = dA; w.Bm = dB; w.H = dH; w.G = dG;
+  w.A = dA; w.Bm = dB; w.H = dH; w.G = dG; w.ncnt = dncnt; w.rho = rho;
   const Opts o = h->opt;
   const int BP = nb * dm.p;
-  const bool eq = dm.ng > 0;
-  const size_t phi_schur_lds = (size_t)5 * dm.ng * dm.d * sizeof(double);
+  const bool eq = dm.nr > 0;
+  const size_t phi_schur_lds = (size_t)5 * dm.nr * dm.d * sizeof(double);
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
   HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
@@ -328,7 +342,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   while (active > 0 && it < cap) {
     if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), slots_bytes(PHI_SLOTS), st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(nb), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
@@ -339,11 +353,11 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
     if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(1), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), slots_bytes(5), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm, pass);
@@ -387,33 +401,43 @@ int tmpc_device_count(void) {
   return n;
 }
 
-uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng) {
-  if (chunk < 1 || !dims_ok(p, nx, mb) || ng < 0 || ng > NGM) return 0;
+static bool rows_ok(int nx, int ng, int nc) {
+  // k_phi_schur keeps 5 * (ng + nc) * d doubles in LDS
+  return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM && (size_t)5 * (ng + nc) * (nx * (nx + 1) / 2) * sizeof(double) <= (size_t)160 * 1024;
+}
+uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) {
+  if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
   WS w;
-  Dims dm = make_dims(chunk, p, nx, mb, ng);
+  Dims dm = make_dims(chunk, p, nx, mb, ng, nc);
   return (uint64_t)carve(w, dm, nullptr, nullptr);
 }
+uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng) { return tmpc_workspace_bytes_con(chunk, p, nx, mb, ng, 0); }
 uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) { return tmpc_workspace_bytes_eq(chunk, p, nx, mb, 0); }
 
 int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) { return tmpc_create_eq(out, chunk, p, nx, mb, 0); }
 
-int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) {
+int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) { return tmpc_create_con(out, chunk, p, nx, mb, ng, 0); }
+
+int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) {
   if (!out) return TMPC_E_ARG;
   *out = nullptr;
   if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
-  if (ng < 0 || ng > NGM) { snprintf(g_err, sizeof(g_err), "unsupported number of equality-constraint rows ng=%d (need 0<=ng<=%d)", ng, NGM); return TMPC_E_UNSUPPORTED; }
+  if (!rows_ok(nx, ng, nc)) {
+    snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d and (ng+nc)*nx*(nx+1)/2 <= 4096)", ng, nc, NGM, NCM);
+    return TMPC_E_UNSUPPORTED;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }
   if (chunk <= 0) {
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    const uint64_t per = tmpc_workspace_bytes_eq(1, p, nx, mb, ng);
+    const uint64_t per = tmpc_workspace_bytes_con(1, p, nx, mb, ng, nc);
     uint64_t fit = (uint64_t)(0.6 * (double)fr) / std::max<uint64_t>(per, 1);
     chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(512, fit));
   }
   tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
   if (!h) return TMPC_E_NOMEM;
-  h->dm = make_dims(chunk, p, nx, mb, ng);
+  h->dm = make_dims(chunk, p, nx, mb, ng, nc);
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
   h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
@@ -549,6 +573,34 @@ int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nbt, const double* A, const
     rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
     if (rc != TMPC_OK) return rc;
     HIPCHK(hipMemcpy(Fg + (size_t)off * dm.p * dm.ng, h->ws.Fg, BP * dm.ng * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return TMPC_OK;
+}
+
+int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, const double* J,
+                                    const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
+                                    double* beta, double* kappa, int32_t* status, int32_t* iters, double* info) {
+  if (!h || nbt < 1 || !A || !H || !J || !ncnt || !FgF || !(rho > 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  const Dims& dm = h->dm;
+  if (dm.nz <= dm.nr) { snprintf(g_err, sizeof(g_err), "handle was created without active-constraint rows (use tmpc_create_con with nc > 0)"); return TMPC_E_ARG; }
+  const int ncmax = dm.nr - dm.ng;
+  for (size_t i = 0; i < (size_t)nbt * dm.p; ++i)
+    if (ncnt[i] < 0 || ncnt[i] > ncmax) { snprintf(g_err, sizeof(g_err), "ncnt[%zu]=%d outside 0..%d", i, ncnt[i], ncmax); return TMPC_E_ARG; }
+  hipStream_t st = 0;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.nr * dm.n;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t BP = (size_t)nb * dm.p;
+    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dG, J + (size_t)off * dm.p * gn, BP * gn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dncnt, ncnt + (size_t)off * dm.p, BP * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st, h->dG, h->dncnt, rho);
+    if (rc != TMPC_OK) return rc;
+    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
+    if (rc != TMPC_OK) return rc;
+    HIPCHK(hipMemcpy(FgF + (size_t)off * dm.p * dm.nr, h->ws.Fg, BP * dm.nr * sizeof(double), hipMemcpyDeviceToHost));
   }
   return TMPC_OK;
 }

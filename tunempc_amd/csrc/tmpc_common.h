@@ -43,7 +43,7 @@ enum {
   Q_TRT2, Q_HBG,                                                       // stage_rhs
   Q_MINX, Q_MINS, Q_DXS, Q_XDS, Q_DXDS, Q_DP2, Q_P2,                   // stage_dir
   Q_MINEIG, Q_MINABS, Q_MAXABS, Q_MAXEIG, Q_CHOLBAD, Q_DH2, Q_M2,
-  Q_RPHI2,                                                             // phi_pre (equality-constraint multipliers)
+  Q_RPHI2, Q_NCONE,                                                    // phi_pre (stage-local multipliers): residual, cone dimension
   NPART = 26
 };
 
@@ -62,8 +62,15 @@ struct Dims {
   int nt;       // ceil(dp / TB)
   int flags;    // bit0: debug - replace MFMA by scalar FMAs
   int ng;       // rows of the equality-constraint Jacobian G_k per stage (0: none), <= NGM
+  int nr;       // row stride of the stage-local multipliers: ng + (max rows of the active-constraint Jacobians C_k, Step 2), <= NRM
+  int nz;       // stride of the stage-local variable vector: nr (+ 2 epigraph variables of the norm terms in Step 2)
+  int constr;   // 1: Step 2 model (convexifier.py:116-131): multipliers of C_k and the rho-norm terms
 };
-constexpr int NGM = 8;   // max ng (the stage-local elimination keeps 5 * ng * d doubles in LDS: 155 KB at ng = 8, d = 496)
+constexpr int NGM = 8;   // max ng
+constexpr int NCM = 8;   // max rows of C_k
+constexpr int NRM = NGM + NCM, NZM = NRM + 2;
+constexpr int NAM = 8;   // max rows under one norm term; its arrow LMI is (NAM+1) x (NAM+1)
+constexpr int AEL = NAM + 1, AE = AEL * AEL;
 
 struct Opts {
   double tol;          // complementarity tolerance: mu_target = tol * kappa (relative gap on kappa = (2pn+1)*tol)
@@ -112,11 +119,19 @@ struct WS {
   double* dHc;     // [B,p,n,n]
   double* Pout;    // [B,p,nx,nx]
   // equality-constraint term of Step 1 (convexifier.py:249-255, :346-347): M_k += G_k' diag(phi_k) G_k, phi_k = s*Fg_k >= 0
-  const double* G; // [B,p,ng,n] input
-  double* phi; double* zph; double* dphi; double* dzph; double* corrp;   // [B,p,ng] multipliers (slack = phi itself), their duals, directions, Mehrotra term
-  double* pvec;    // [B,p,2,ng,2n+2nx]  per cone block r and row i: w = X_r g, u = S_r^-1 g, V w, V u
-  double* psm;     // [B,p,ng*ng+8*ng]   K = T_phiphi^-1, c_tau, c_alpha, K c_tau, K c_alpha, r_phi, K r_phi
-  double* Fg;      // [B,p,ng] output: phi / (s*alpha)
+  // Step 2 (convexifier.py:258-266, :348-350): the rows of C_k follow those of G_k, phi_k = s*[Fg_k; F_k] >= 0.
+  const double* G; // [B,p,nr,n] input: rows of G_k, then rows of C_k, zero padding
+  const int* ncnt; // [B,p] rows of C_k per stage (nullptr: none)
+  double rho;      // weight of the norm terms (convexifier.py:276-283); in the scaled problem w = rho*sbeta/s
+  double* phi; double* zph; double* dphi; double* dzph; double* corrp;   // [B,p,nr] multipliers (slack = phi itself), their duals, directions, Mehrotra term
+  double* pvec;    // [B,p,2,nr,2n+2nx]  per cone block r and row i: w = X_r g, u = S_r^-1 g, V w, V u
+  double* psm;     // [B,p,nz*nz+6*nz]   K = T_zz^-1, c_tau, c_alpha, K c_tau, K c_alpha, r_z, K r_z
+  double* Fg;      // [B,p,nr] output: phi / (s*alpha)
+  // norm terms t >= ||w v|| as arrow LMIs S = [[t, w v'], [w v, t I]] (always feasible: S is rebuilt from t and phi), up to two per stage
+  double* at; double* adt;              // [B,p,2]   epigraph variables and their directions
+  double* aX; double* adX; double* acor; // [B,p,2,AE] primal blocks, directions, Mehrotra term
+  double* aSi; double* aLi; double* aLXi; // [B,p,2,AE] S^-1, L_S^-1, L_X^-1
+  double* asum;    // [B,p,5]   <dX,S>, <X,dS>, <dX,dS>, min eig dual, min eig primal of the arrow blocks (joined in k_phi_steps)
 };
 
 }  // namespace tmpc

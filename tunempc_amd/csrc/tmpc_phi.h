@@ -1,14 +1,21 @@
-// Equality-constraint term of Step 1 (reference: convexifier.py:249-255, :346-347, :409-411).
+// Stage-local multipliers of the convexifier SDP:
+//   * the equality-constraint term of every step (reference: convexifier.py:249-255, :346-347, :409-411), and
+//   * Step 2 (:116-131): the multipliers F_k >= 0 of the active-constraint Jacobians C_k (:258-266, :348-350, :415-420) and the
+//     objective terms rho*||F_k||, rho*||Fg_k|| (:276-283).
 //
-// With G given, M_k = alpha*Hb_k + calH_k(P) + G_k' diag(phi_k) G_k with cost-free multipliers phi_k = s*Fg_k >= 0 (ng per
-// stage; their slack is phi itself, dual z).  phi_k touches only the two cone blocks of stage k, so in the HKM Schur
-// system its columns reach P_k, P_{k+1}, tau and alpha only.  They are eliminated stage by stage BEFORE the block
-// factorisation (K_k = T_phiphi^-1, ng x ng):
+// M_k = alpha*Hb_k + calH_k(P) + J_k' diag(phi_k) J_k with J_k = [G_k; C_k] and phi_k = s*[Fg_k; F_k] >= 0 (their slack is phi
+// itself, dual z).  Each norm term is an epigraph variable t with the arrow LMI S = [[t, w v'], [w v, t I]] >> 0, v the
+// multipliers under the norm and w = rho*sbeta/s (the scaled objective is tau + sum t); S is a function of (t, phi) alone, so it
+// is rebuilt instead of iterated and never carries a residual; its primal block X is (m+1) x (m+1).
+// The stage-local vector y_loc = (phi_k, t_k) touches only the cone blocks of stage k, so in the HKM Schur system its columns
+// reach P_k, P_{k+1}, tau and alpha only.  They are eliminated stage by stage BEFORE the block factorisation
+// (K_k = T_loc,loc^-1, at most 18 x 18):
 //     D_k     -= a_k K_k a_k' + b_{k-1} K_{k-1} b_{k-1}'        a_k,i = -svec(W_i[:nx,:nx]),  b_k,i = svec(V_k W_i V_k'),
 //     C_k     -= a_k K_k b_k'                                   W_i = sum_r sym(X_r g_i g_i' S_r^-1) = sum_r sym(w_ri u_ri')
-//     u_tau, u_alpha, rhs  -= a_k K_k (c_tau | c_alpha | r_phi)_k + b_{k-1} K_{k-1} (...)_{k-1},   and the 2 x 2 border likewise,
-// so that k_schur / k_factor / k_solve stay what they are; afterwards dphi_k = K_k (r_phi - T_phi,y dy).
-// Every kernel here is one single-wave workgroup per stage and only runs when dm.ng > 0.
+//     u_tau, u_alpha, rhs  -= a_k K_k (c_tau | c_alpha | r_loc)_k + b_{k-1} K_{k-1} (...)_{k-1},   and the 2 x 2 border likewise,
+// (a, b are zero for the epigraph entries) so that k_schur / k_factor / k_solve stay what they are; afterwards
+// dy_loc = K_k (r_loc - T_loc,y dy).  Every kernel here is one single-wave workgroup per stage (k_phi_schur: 256 threads) and
+// only runs when dm.nr > 0.
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_small.h"
@@ -16,12 +23,31 @@
 
 namespace tmpc {
 
+struct PhiStage {
+  int nrow;          // rows of [G_k; C_k] at this stage
+  int na;            // norm terms (arrow blocks) at this stage
+  int nz;            // nrow + na
+  int a0[2], am[2];  // arrow block e covers rows a0[e] .. a0[e] + am[e] - 1; its epigraph variable is entry nrow + e
+};
+__device__ __forceinline__ PhiStage phi_stage(const WS& w, const Dims& dm, size_t sid) {
+  PhiStage s;
+  const int nc = w.ncnt ? w.ncnt[sid] : 0;
+  s.nrow = dm.ng + nc; s.na = 0;
+  s.a0[0] = s.a0[1] = 0; s.am[0] = s.am[1] = 0;
+  if (dm.constr) {
+    if (dm.ng > 0) { s.a0[s.na] = 0; s.am[s.na] = dm.ng; ++s.na; }
+    if (nc > 0) { s.a0[s.na] = dm.ng; s.am[s.na] = nc; ++s.na; }
+  }
+  s.nz = s.nrow + s.na;
+  return s;
+}
+
 __device__ __forceinline__ int pv_len(const Dims& dm) { return 2 * dm.n + 2 * dm.nx; }
 __device__ __forceinline__ double* pv_at(double* pvec, const Dims& dm, size_t sid, int r, int i) {
-  return pvec + ((sid * 2 + r) * dm.ng + i) * (size_t)pv_len(dm);
+  return pvec + ((sid * 2 + r) * dm.nr + i) * (size_t)pv_len(dm);
 }
-// psm offsets (doubles): K, c_tau, c_alpha, K c_tau, K c_alpha, r_phi, K r_phi
-__device__ __forceinline__ double* psm_at(double* psm, const Dims& dm, size_t sid) { return psm + sid * (size_t)(dm.ng * dm.ng + 8 * dm.ng); }
+// psm offsets (doubles, stride g = dm.nz): K, c_tau, c_alpha, K c_tau, K c_alpha, r_loc, K r_loc
+__device__ __forceinline__ double* psm_at(double* psm, const Dims& dm, size_t sid) { return psm + sid * (size_t)(dm.nz * dm.nz + 6 * dm.nz); }
 #define PSM_K(q) (q)
 #define PSM_CT(q, g) ((q) + (g) * (g))
 #define PSM_CA(q, g) ((q) + (g) * (g) + (g))
@@ -30,18 +56,67 @@ __device__ __forceinline__ double* psm_at(double* psm, const Dims& dm, size_t si
 #define PSM_RPHI(q, g) ((q) + (g) * (g) + 4 * (g))
 #define PSM_KR(q, g) ((q) + (g) * (g) + 5 * (g))
 
+__device__ __forceinline__ double phi_wr(const WS& w, const double* pr) { return w.rho * pr[P_SBETA] / pr[P_S]; }
+
+// LDS slot (stride LD) <- arrow(t, v, wr) of size (m+1)
+__device__ __forceinline__ void arrow_s(double* S, double t, const double* v, double wr, int m, int lane) {
+  const int ne = m + 1;
+  for (int e = lane; e < ne * ne; e += 64) {
+    const int i = e / ne, j = e - i * ne;
+    double x = 0.0;
+    if (i == j) x = t;
+    else if (i == 0) x = wr * v[j - 1];
+    else if (j == 0) x = wr * v[i - 1];
+    S[i * LD + j] = x;
+  }
+  wsync();
+}
+// LDS slot (stride LD) <-> global (stride AEL)
+__device__ __forceinline__ void a_g2s(double* S, const double* g, int ne, int lane) {
+  for (int e = lane; e < ne * ne; e += 64) { const int i = e / ne, j = e - i * ne; S[i * LD + j] = g[i * AEL + j]; }
+  wsync();
+}
+__device__ __forceinline__ void a_s2g(double* g, const double* S, int ne, int lane) {
+  for (int e = lane; e < ne * ne; e += 64) { const int i = e / ne, j = e - i * ne; g[i * AEL + j] = S[i * LD + j]; }
+  wsync();
+}
+__device__ __forceinline__ void a_s2g_sym(double* g, const double* S, int ne, int lane) {
+  for (int e = lane; e < ne * ne; e += 64) { const int i = e / ne, j = e - i * ne; g[i * AEL + j] = 0.5 * (S[i * LD + j] + S[j * LD + i]); }
+  wsync();
+}
+__device__ __forceinline__ double a_dot(const double* A, const double* B, int ne, int lane) {   // <A, B> of two LDS slots
+  double v = 0.0;
+  for (int e = lane; e < ne * ne; e += 64) { const int i = e / ne, j = e - i * ne; v = fma(A[i * LD + j], B[i * LD + j], v); }
+  return wave_sum(v);
+}
+
 // after k_init_state
 __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
   const size_t sid = blockIdx.x;
   const int lane = threadIdx.x;
-  if (lane < dm.ng) {
-    w.phi[sid * dm.ng + lane] = 1.0;
-    w.zph[sid * dm.ng + lane] = 1.0 / (double)(dm.p * dm.n);
-    w.corrp[sid * dm.ng + lane] = 0.0;
+  const int b = (int)(sid / dm.p);
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const double x0 = 1.0 / (double)(dm.p * dm.n);
+  if (lane < dm.nr) {
+    w.phi[sid * dm.nr + lane] = 1.0;
+    w.zph[sid * dm.nr + lane] = (lane < ps.nrow) ? x0 : 0.0;
+    w.corrp[sid * dm.nr + lane] = 0.0;
+    w.dphi[sid * dm.nr + lane] = 0.0; w.dzph[sid * dm.nr + lane] = 0.0;
+  }
+  if (dm.constr) {
+    const double wr = phi_wr(w, w.prob + (size_t)b * PS);
+    for (int e = 0; e < ps.na; ++e) {
+      if (lane == 0) { w.at[sid * 2 + e] = 1.0 + wr * sqrt((double)ps.am[e]); w.adt[sid * 2 + e] = 0.0; }
+      for (int q = lane; q < AE; q += 64) {
+        w.aX[(sid * 2 + e) * AE + q] = ((q / AEL) == (q % AEL)) ? x0 : 0.0;
+        w.acor[(sid * 2 + e) * AE + q] = 0.0;
+      }
+    }
   }
 }
 
-constexpr int PHI_SLOTS = 6;
+// LDS of k_phi_pre (doubles)
+constexpr int PHI_PRE_LDS = 4 * MS + NRM * NMAX + 4 * NRM * NMAX + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;
 // after k_stage_pre (needs S_r^-1), before k_ctrl_a: vectors w, u, V w, V u; K; c_tau, c_alpha; border / mu / pinf partials
 __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -49,18 +124,23 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
   const int b = sid / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
-  const int n = dm.n, nx = dm.nx, nn = n * n, ng = dm.ng;
+  const double* pr = w.prob + (size_t)b * PS;
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const int n = dm.n, nx = dm.nx, nn = n * n, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sX = sm; double* sSi = sm + MS; double* sHb = sm + 2 * MS; double* sV = sm + 3 * MS;
-  double* gl = sm + 4 * MS;                 // [ng][NMAX]
-  double* wl = gl + NGM * NMAX;             // [2][ng][NMAX]
-  double* ul = wl + 2 * NGM * NMAX;         // [2][ng][NMAX]
-  double* sc = ul + 2 * NGM * NMAX;         // GXG[2][ng][ng], GSG[2][ng][ng], ct[ng], ca[ng]
-  const double* Gg = w.G + (size_t)sid * ng * n;
+  double* gl = sm + 4 * MS;                 // [nrow][NMAX]
+  double* wl = gl + NRM * NMAX;             // [2][nrow][NMAX]
+  double* ul = wl + 2 * NRM * NMAX;         // [2][nrow][NMAX]
+  double* GXG = ul + 2 * NRM * NMAX;        // [2][NRM][NRM]
+  double* GSG = GXG + 2 * NRM * NRM;        // [2][NRM][NRM]
+  double* Tm = GSG + 2 * NRM * NRM;         // [NZM][2*NZM+1]  T_loc,loc | I  ->  I | K
+  double* ctl = Tm + NZM * (2 * NZM + 1); double* cal = ctl + NZM; double* rres = cal + NZM; double* kv = rres + NZM;
+  constexpr int TL = 2 * NZM + 1;
+  const double* Gg = w.G + (size_t)sid * dm.nr * n;
   for (int e = lane; e < ng * n; e += 64) gl[(e / n) * NMAX + (e % n)] = Gg[e];
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  double* GXG = sc; double* GSG = sc + 2 * NGM * NGM; double* ctl = GSG + 2 * NGM * NGM; double* cal = ctl + NGM;
-  if (lane < NGM) { ctl[lane] = 0.0; cal[lane] = 0.0; }
+  if (lane < NZM) { ctl[lane] = 0.0; cal[lane] = 0.0; rres[lane] = 0.0; }
   for (int r = 0; r < 2; ++r) {
     g2s(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
     g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
@@ -68,13 +148,13 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
       if (lane < n) {
         double a0 = 0.0, a1 = 0.0;
         for (int c = 0; c < n; ++c) { const double g = gl[i * NMAX + c]; a0 = fma(sX[lane * LD + c], g, a0); a1 = fma(sSi[lane * LD + c], g, a1); }
-        wl[(r * NGM + i) * NMAX + lane] = a0; ul[(r * NGM + i) * NMAX + lane] = a1;
+        wl[(r * NRM + i) * NMAX + lane] = a0; ul[(r * NRM + i) * NMAX + lane] = a1;
       }
     }
     wsync();
     for (int i = 0; i < ng; ++i) {
       double* pv = pv_at(w.pvec, dm, sid, r, i);
-      const double* wi = wl + (r * NGM + i) * NMAX; const double* ui = ul + (r * NGM + i) * NMAX;
+      const double* wi = wl + (r * NRM + i) * NMAX; const double* ui = ul + (r * NRM + i) * NMAX;
       if (lane < n) { pv[lane] = wi[lane]; pv[n + lane] = ui[lane]; }
       if (lane < nx) {
         double a0 = 0.0, a1 = 0.0;
@@ -89,44 +169,108 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
       wu = wave_sum(wu);
       if (lane == 0) { cal[i] += hu; if (r == 1) ctl[i] = -wu; }
       for (int j = 0; j < ng; ++j) {
-        double x = (lane < n) ? gl[i * NMAX + lane] * wl[(r * NGM + j) * NMAX + lane] : 0.0;
-        double y = (lane < n) ? gl[i * NMAX + lane] * ul[(r * NGM + j) * NMAX + lane] : 0.0;
+        double x = (lane < n) ? gl[i * NMAX + lane] * wl[(r * NRM + j) * NMAX + lane] : 0.0;
+        double y = (lane < n) ? gl[i * NMAX + lane] * ul[(r * NRM + j) * NMAX + lane] : 0.0;
         x = wave_sum(x); y = wave_sum(y);
-        if (lane == 0) { GXG[(r * NGM + i) * NGM + j] = x; GSG[(r * NGM + i) * NGM + j] = y; }
+        if (lane == 0) { GXG[(r * NRM + i) * NRM + j] = x; GSG[(r * NRM + i) * NRM + j] = y; }
       }
     }
     wsync();
   }
-  if (lane == 0) {
-    double* q = psm_at(w.psm, dm, sid);
-    const double* phi = w.phi + (size_t)sid * ng; const double* z = w.zph + (size_t)sid * ng;
-    double T[NGM][NGM], Ki[NGM][NGM];
-    for (int i = 0; i < ng; ++i)
-      for (int j = 0; j < ng; ++j) {
-        double t = 0.0;
-        for (int r = 0; r < 2; ++r)
-          t += 0.5 * (GXG[(r * NGM + i) * NGM + j] * GSG[(r * NGM + j) * NGM + i] + GXG[(r * NGM + j) * NGM + i] * GSG[(r * NGM + i) * NGM + j]);
-        T[i][j] = t + ((i == j) ? z[i] / phi[i] : 0.0);
-        Ki[i][j] = (i == j) ? 1.0 : 0.0;
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
+  // T_loc,loc | I
+  for (int e = lane; e < nz * 2 * nz; e += 64) {
+    const int i = e / (2 * nz), j = e - i * 2 * nz;
+    double t = 0.0;
+    if (j >= nz) t = (j - nz == i) ? 1.0 : 0.0;
+    else if (i < ng && j < ng) {
+      for (int r = 0; r < 2; ++r)
+        t += 0.5 * (GXG[(r * NRM + i) * NRM + j] * GSG[(r * NRM + j) * NRM + i] + GXG[(r * NRM + j) * NRM + i] * GSG[(r * NRM + i) * NRM + j]);
+      if (i == j) t += z[i] / phi[i];
+    }
+    Tm[i * TL + j] = t;
+  }
+  double xs = 0.0;
+  if (lane < ng) {
+    xs = phi[lane] * z[lane];
+    rres[lane] = -(GXG[(0 * NRM + lane) * NRM + lane] - GXG[(1 * NRM + lane) * NRM + lane]) - z[lane];     // stationarity residual of phi_i
+  }
+  xs = wave_sum(xs);
+  wsync();
+  double ncone = (double)ng;
+  // norm terms: arrow blocks
+  if (ps.na > 0) {
+    const double wr = phi_wr(w, pr);
+    double* aS = sX; double* aXs = sSi; double* aW = sHb; double* aLi = sV;
+    for (int e = 0; e < ps.na; ++e) {
+      const int m = ps.am[e], ne = m + 1, c0 = ps.a0[e], te = ng + e;
+      const size_t ao = ((size_t)sid * 2 + e) * AE;
+      arrow_s(aS, w.at[(size_t)sid * 2 + e], phi + c0, wr, m, lane);
+      a_g2s(aXs, w.aX + ao, ne, lane);
+      xs += a_dot(aXs, aS, ne, lane);
+      // L_X^-1 (primal step length)
+      for (int q = lane; q < ne * ne; q += 64) { const int i = q / ne, j = q - i * ne; aW[i * LD + j] = aXs[i * LD + j]; }
+      wsync();
+      chol_lower(aW, ne, lane);
+      tri_inv_lower(aLi, aW, ne, lane);
+      a_s2g(w.aLXi + ao, aLi, ne, lane);
+      // L_S^-1, S^-1 = L^-T L^-1
+      chol_lower(aS, ne, lane);
+      tri_inv_lower(aLi, aS, ne, lane);
+      a_s2g(w.aLi + ao, aLi, ne, lane);
+      mm(aW, aLi, 1, LD, aLi, LD, 1, ne, ne, ne, 0, lane);          // aW = S^-1
+      a_s2g(w.aSi + ao, aW, ne, lane);
+      // Schur entries of the block:  <E_a, sym(X E_q S^-1)>, <E_q, sym(X S^-1)>, tr(X S^-1)
+      const double trp = a_dot(aXs, aW, ne, lane);
+      if (lane < m) {
+        const int q = lane;
+        double u0 = 0.0, u1 = 0.0;
+        for (int r = 0; r < ne; ++r) { u0 = fma(aXs[r], aW[r * LD + q + 1], u0); u1 = fma(aXs[(q + 1) * LD + r], aW[r * LD], u1); }
+        const double v = wr * (u0 + u1);
+        Tm[(c0 + q) * TL + te] = v; Tm[te * TL + c0 + q] = v;
+        rres[c0 + q] -= 2.0 * wr * aXs[q + 1];
       }
-    for (int c = 0; c < ng; ++c) {           // Gauss-Jordan (T is symmetric positive definite)
-      const double piv = 1.0 / T[c][c];
-      for (int j = 0; j < ng; ++j) { T[c][j] *= piv; Ki[c][j] *= piv; }
-      for (int i = 0; i < ng; ++i)
-        if (i != c) { const double f = T[i][c]; for (int j = 0; j < ng; ++j) { T[i][j] -= f * T[c][j]; Ki[i][j] -= f * Ki[c][j]; } }
+      if (lane == 0) { Tm[te * TL + te] = trp; }
+      for (int qq = lane; qq < m * m; qq += 64) {
+        const int a = qq / m, q = qq - a * m;
+        const double v = wr * wr * (aXs[0] * aW[(q + 1) * LD + a + 1] + aXs[q + 1] * aW[a + 1] + aXs[(a + 1) * LD] * aW[(q + 1) * LD]
+                                    + aXs[(a + 1) * LD + q + 1] * aW[0]);
+        Tm[(c0 + a) * TL + c0 + q] += v;
+      }
+      double trx = (lane < ne) ? aXs[lane * LD + lane] : 0.0;
+      trx = wave_sum(trx);
+      if (lane == 0) rres[te] = 1.0 - trx;
+      ncone += (double)ne;
+      wsync();
     }
-    double xs = 0.0, rp2 = 0.0, ctkct = 0.0, ctkca = 0.0, cakca = 0.0;
-    for (int i = 0; i < ng; ++i) {
-      double kct = 0.0, kca = 0.0;
-      for (int j = 0; j < ng; ++j) { PSM_K(q)[i * ng + j] = Ki[i][j]; kct += Ki[i][j] * ctl[j]; kca += Ki[i][j] * cal[j]; }
-      PSM_CT(q, ng)[i] = ctl[i]; PSM_CA(q, ng)[i] = cal[i]; PSM_KCT(q, ng)[i] = kct; PSM_KCA(q, ng)[i] = kca;
-      ctkct += ctl[i] * kct; ctkca += ctl[i] * kca; cakca += cal[i] * kca;
-      xs += phi[i] * z[i];
-      const double rphi = -(GXG[(0 * NGM + i) * NGM + i] - GXG[(1 * NGM + i) * NGM + i]) - z[i];     // stationarity residual of phi_i
-      rp2 += rphi * rphi;
+  }
+  // Gauss-Jordan on [T | I] (T symmetric positive definite): one lane per column, the pivot column travels through kv
+  for (int c = 0; c < nz; ++c) {
+    if (lane < nz) kv[lane] = Tm[lane * TL + c];
+    wsync();
+    if (lane < 2 * nz) {
+      const double pc = Tm[c * TL + lane] / kv[c];
+      for (int i = 0; i < nz; ++i)
+        if (i != c) Tm[i * TL + lane] = fma(-kv[i], pc, Tm[i * TL + lane]);
+      Tm[c * TL + lane] = pc;
     }
+    wsync();
+  }
+  double* q = psm_at(w.psm, dm, sid);
+  for (int e = lane; e < nz * nz; e += 64) { const int i = e / nz, j = e - i * nz; PSM_K(q)[i * nzs + j] = Tm[i * TL + nz + j]; }
+  double kct = 0.0, kca = 0.0, rr = 0.0;
+  if (lane < nz) {
+    for (int j = 0; j < nz; ++j) { kct = fma(Tm[lane * TL + nz + j], ctl[j], kct); kca = fma(Tm[lane * TL + nz + j], cal[j], kca); }
+    PSM_CT(q, nzs)[lane] = ctl[lane]; PSM_CA(q, nzs)[lane] = cal[lane]; PSM_KCT(q, nzs)[lane] = kct; PSM_KCA(q, nzs)[lane] = kca;
+    rr = rres[lane];
+  }
+  const double ctkct = wave_sum((lane < nz) ? ctl[lane] * kct : 0.0);
+  const double ctkca = wave_sum((lane < nz) ? ctl[lane] * kca : 0.0);
+  const double cakca = wave_sum((lane < nz) ? cal[lane] * kca : 0.0);
+  const double rp2 = wave_sum(rr * rr);
+  if (lane == 0) {
     double* pq = w.part + (size_t)sid * NPART;
-    pq[Q_XS] += xs; pq[Q_RPHI2] = rp2;
+    pq[Q_XS] += xs; pq[Q_RPHI2] = rp2; pq[Q_NCONE] = ncone;
     pq[Q_TRPSI] -= ctkct;       // b_tt
     pq[Q_TRPHI2] += ctkca;      // b_ta = -trphi2
     pq[Q_HBPHI] -= cakca;       // b_aa (+ x0/s0)
@@ -138,7 +282,7 @@ __device__ __forceinline__ double phi_avec(const double* pvec, const Dims& dm, s
   const int n = dm.n;
   double v = 0.0;
   for (int r = 0; r < 2; ++r) {
-    const double* pv = pvec + ((sid * 2 + r) * dm.ng + i) * (size_t)(2 * dm.n + 2 * dm.nx);
+    const double* pv = pvec + ((sid * 2 + r) * dm.nr + i) * (size_t)(2 * dm.n + 2 * dm.nx);
     v += 0.5 * (pv[a] * pv[n + c] + pv[c] * pv[n + a]);
   }
   return -((a == c) ? v : 2.0 * v);
@@ -147,35 +291,47 @@ __device__ __forceinline__ double phi_bvec(const double* pvec, const Dims& dm, s
   const int n = dm.n, nx = dm.nx;
   double v = 0.0;
   for (int r = 0; r < 2; ++r) {
-    const double* pv = pvec + ((sid * 2 + r) * dm.ng + i) * (size_t)(2 * dm.n + 2 * dm.nx);
+    const double* pv = pvec + ((sid * 2 + r) * dm.nr + i) * (size_t)(2 * dm.n + 2 * dm.nx);
     v += 0.5 * (pv[2 * n + a] * pv[2 * n + nx + c] + pv[2 * n + c] * pv[2 * n + nx + a]);
   }
   return (a == c) ? v : 2.0 * v;
 }
 
-// after k_schur, before k_factor: rank-ng corrections of D_k (lower triangle + pivot reference) and of the coupling block
+// after k_schur, before k_factor: rank-nrow corrections of D_k (lower triangle + pivot reference) and of the coupling block
 __global__ void __launch_bounds__(256) k_phi_schur(WS w, Dims dm) {
   const int sid = blockIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
-  const int tid = threadIdx.x, nx = dm.nx, d = dm.d, dp = dm.dp, ng = dm.ng;
+  const int tid = threadIdx.x, nx = dm.nx, d = dm.d, dp = dm.dp, nzs = dm.nz;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* av = sm; double* Kav = av + ng * d; double* bm = Kav + ng * d; double* Kbm = bm + ng * d; double* Kbv = Kbm + ng * d;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const size_t sm1 = (size_t)b * dm.p + km;
+  const int ng = stage_rows(w, dm, sid), ngm = stage_rows(w, dm, sm1);
+  double* av = sm; double* Kav = av + dm.nr * d; double* bm = Kav + dm.nr * d; double* Kbm = bm + dm.nr * d; double* Kbv = Kbm + dm.nr * d;
   double* qk = psm_at(w.psm, dm, sid); double* qm = psm_at(w.psm, dm, sm1);
   // enumerate idx -> (a, c)
   for (int idx = tid; idx < d; idx += 256) {
     int a = 0, rem = idx;
     while (rem >= nx - a) { rem -= nx - a; ++a; }
     const int c = a + rem;
-    double ai[NGM], bi[NGM], bmi[NGM];
-    for (int i = 0; i < ng; ++i) { ai[i] = phi_avec(w.pvec, dm, sid, i, a, c); bi[i] = phi_bvec(w.pvec, dm, sid, i, a, c); bmi[i] = phi_bvec(w.pvec, dm, sm1, i, a, c); }
+    for (int i = 0; i < ng; ++i) { av[i * d + idx] = phi_avec(w.pvec, dm, sid, i, a, c); Kbv[i * d + idx] = phi_bvec(w.pvec, dm, sid, i, a, c); }
+    for (int i = 0; i < ngm; ++i) bm[i * d + idx] = phi_bvec(w.pvec, dm, sm1, i, a, c);
+  }
+  __syncthreads();
+  // K a, K b (this stage) and K b (previous stage); Kbv holds b on entry
+  for (int idx = tid; idx < d; idx += 256) {
+    double ka[NRM], kb[NRM];
     for (int i = 0; i < ng; ++i) {
-      double ka = 0.0, kb = 0.0, kbm = 0.0;
-      for (int j = 0; j < ng; ++j) { ka += PSM_K(qk)[i * ng + j] * ai[j]; kb += PSM_K(qk)[i * ng + j] * bi[j]; kbm += PSM_K(qm)[i * ng + j] * bmi[j]; }
-      av[i * d + idx] = ai[i]; Kav[i * d + idx] = ka; bm[i * d + idx] = bmi[i]; Kbm[i * d + idx] = kbm; Kbv[i * d + idx] = kb;
+      double x = 0.0, y = 0.0;
+      for (int j = 0; j < ng; ++j) { x = fma(PSM_K(qk)[i * nzs + j], av[j * d + idx], x); y = fma(PSM_K(qk)[i * nzs + j], Kbv[j * d + idx], y); }
+      ka[i] = x; kb[i] = y;
+    }
+    for (int i = 0; i < ng; ++i) { Kav[i * d + idx] = ka[i]; Kbv[i * d + idx] = kb[i]; }
+    for (int i = 0; i < ngm; ++i) {
+      double x = 0.0;
+      for (int j = 0; j < ngm; ++j) x = fma(PSM_K(qm)[i * nzs + j], bm[j * d + idx], x);
+      Kbm[i * d + idx] = x;
     }
   }
   __syncthreads();
@@ -195,7 +351,8 @@ __global__ void __launch_bounds__(256) k_phi_schur(WS w, Dims dm) {
     }
     if (col <= row) {
       double dv = 0.0;
-      for (int i = 0; i < ng; ++i) { dv = fma(av[i * d + row], Kav[i * d + col], dv); dv = fma(bm[i * d + row], Kbm[i * d + col], dv); }
+      for (int i = 0; i < ng; ++i) dv = fma(av[i * d + row], Kav[i * d + col], dv);
+      for (int i = 0; i < ngm; ++i) dv = fma(bm[i * d + row], Kbm[i * d + col], dv);
       const double nv = Dg[o] - dv;
       Dg[o] = nv;
       if (row == col) dd[row] = nv;
@@ -203,7 +360,7 @@ __global__ void __launch_bounds__(256) k_phi_schur(WS w, Dims dm) {
   }
 }
 
-// after k_stage_rhs, before k_gather / k_solve: r_phi, K r_phi, and the eliminated part of the border right-hand sides
+// after k_stage_rhs, before k_gather / k_solve: r_loc, K r_loc, and the eliminated part of the border right-hand sides
 __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
@@ -214,30 +371,44 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass) {
   const double* pr = w.prob + (size_t)b * PS;
   const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
   const bool use_corr = (pass == 2 && phase == PH_MAIN);
-  const int n = dm.n, nn = n * n, ng = dm.ng;
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const int n = dm.n, nn = n * n, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sG = sm;                         // T1 - T2
+  double* rl = sm + MS;                    // [NZM]
   const double* T1 = w.T1 + (size_t)sid * nn; const double* T2 = w.T2 + (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; sG[i * LD + j] = T1[e] - T2[e]; }
   wsync();
-  const double* Gg = w.G + (size_t)sid * ng * n;
+  const double* Gg = w.G + (size_t)sid * dm.nr * n;
   double* q = psm_at(w.psm, dm, sid);
-  double rl[NGM];
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* cp = w.corrp + (size_t)sid * dm.nr;
   for (int i = 0; i < ng; ++i) {
     double t = 0.0;
     if (lane < n) { for (int c = 0; c < n; ++c) t = fma(sG[lane * LD + c], Gg[i * n + c], t); t *= Gg[i * n + lane]; }
-    rl[i] = wave_sum(t);
+    t = wave_sum(t);
+    if (lane == 0) rl[i] = t + sig / phi[i] - (use_corr ? cp[i] : 0.0);
   }
-  if (lane == 0) {
-    const double* phi = w.phi + (size_t)sid * ng; const double* cp = w.corrp + (size_t)sid * ng;
-    double r[NGM];
-    for (int i = 0; i < ng; ++i) { r[i] = rl[i] + sig / phi[i] - (use_corr ? cp[i] : 0.0); PSM_RPHI(q, ng)[i] = r[i]; }
-    double ctkr = 0.0, cakr = 0.0;
-    for (int i = 0; i < ng; ++i) {
-      double kr = 0.0;
-      for (int j = 0; j < ng; ++j) kr += PSM_K(q)[i * ng + j] * r[j];
-      PSM_KR(q, ng)[i] = kr;
-      ctkr += PSM_CT(q, ng)[i] * kr; cakr += PSM_CA(q, ng)[i] * kr;
+  wsync();
+  if (ps.na > 0) {
+    const double wr = phi_wr(w, pr);
+    for (int e = 0; e < ps.na; ++e) {
+      const int m = ps.am[e], ne = m + 1, c0 = ps.a0[e];
+      const double* Si = w.aSi + ((size_t)sid * 2 + e) * AE; const double* co = w.acor + ((size_t)sid * 2 + e) * AE;
+      // T_e = sig S^-1 - corr:  r_i += 2 w T_e[0][i+1],  r_t = tr T_e - 1
+      if (lane < m) rl[c0 + lane] += 2.0 * wr * (sig * Si[lane + 1] - (use_corr ? co[lane + 1] : 0.0));
+      double tr = (lane < ne) ? sig * Si[lane * AEL + lane] - (use_corr ? co[lane * AEL + lane] : 0.0) : 0.0;
+      tr = wave_sum(tr);
+      if (lane == 0) rl[ng + e] = tr - 1.0;
     }
+    wsync();
+  }
+  double kr = 0.0;
+  if (lane < nz) {
+    for (int j = 0; j < nz; ++j) kr = fma(PSM_K(q)[lane * nzs + j], rl[j], kr);
+    PSM_RPHI(q, nzs)[lane] = rl[lane]; PSM_KR(q, nzs)[lane] = kr;
+  }
+  const double ctkr = wave_sum((lane < nz) ? PSM_CT(q, nzs)[lane] * kr : 0.0);
+  const double cakr = wave_sum((lane < nz) ? PSM_CA(q, nzs)[lane] * kr : 0.0);
+  if (lane == 0) {
     double* pq = w.part + (size_t)sid * NPART;
     pq[Q_TRT2] -= ctkr;     // rhs_tau   = sum trT2 - 1
     pq[Q_HBG] -= cakr;      // rhs_alpha = sum <Hb, T1 - T2> + t0
@@ -252,9 +423,10 @@ __global__ void __launch_bounds__(64) k_phi_gather(WS w, Dims dm, int pass) {
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
   const bool three = (pass == 1) || (phase != PH_MAIN);
-  const int nx = dm.nx, dp = dm.dp, ng = dm.ng;
+  const int nx = dm.nx, dp = dm.dp, nzs = dm.nz;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const size_t sm1 = (size_t)b * dm.p + km;
+  const int ng = stage_rows(w, dm, sid), ngm = stage_rows(w, dm, sm1);
   double* qk = psm_at(w.psm, dm, sid); double* qm = psm_at(w.psm, dm, sm1);
   int e = 0;
   for (int a = 0; a < nx; ++a) {
@@ -262,10 +434,12 @@ __global__ void __launch_bounds__(64) k_phi_gather(WS w, Dims dm, int pass) {
       const int idx = e + (c - a);
       double g = 0.0, ut = 0.0, ua = 0.0;
       for (int i = 0; i < ng; ++i) {
-        const double ai = phi_avec(w.pvec, dm, sid, i, a, c), bi = phi_bvec(w.pvec, dm, sm1, i, a, c);
-        g += ai * PSM_KR(qk, ng)[i] + bi * PSM_KR(qm, ng)[i];
-        ut += ai * PSM_KCT(qk, ng)[i] + bi * PSM_KCT(qm, ng)[i];
-        ua += ai * PSM_KCA(qk, ng)[i] + bi * PSM_KCA(qm, ng)[i];
+        const double ai = phi_avec(w.pvec, dm, sid, i, a, c);
+        g += ai * PSM_KR(qk, nzs)[i]; ut += ai * PSM_KCT(qk, nzs)[i]; ua += ai * PSM_KCA(qk, nzs)[i];
+      }
+      for (int i = 0; i < ngm; ++i) {
+        const double bi = phi_bvec(w.pvec, dm, sm1, i, a, c);
+        g += bi * PSM_KR(qm, nzs)[i]; ut += bi * PSM_KCT(qm, nzs)[i]; ua += bi * PSM_KCA(qm, nzs)[i];
       }
       if (three) {
         double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3;
@@ -280,7 +454,8 @@ __global__ void __launch_bounds__(64) k_phi_gather(WS w, Dims dm, int pass) {
   }
 }
 
-// after k_solve, before k_stage_dir: dphi = K (r_phi - T_phi,y dy), dz; Mehrotra second-order term in pass 1
+// after k_solve, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
+// Mehrotra second-order terms in pass 1
 __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
@@ -292,14 +467,16 @@ __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass) {
   const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
   const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
   const bool use_corr = (pass == 2 && phase == PH_MAIN);
-  const int n = dm.n, nx = dm.nx, nn = n * n, nxx = nx * nx, ng = dm.ng;
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const int n = dm.n, nx = dm.nx, nn = n * n, nxx = nx * nx, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sV = sm; double* sM = sm + MS; double* t0 = sm + 2 * MS; double* t1 = sm + 3 * MS; double* sHb = sm + 4 * MS;
+  double* tl = sm + 5 * MS;                // [NZM] r_loc - T_loc,y dy
+  double* dl = tl + NZM;                   // [NZM] dy_loc
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   build_M(sM, sV, t0, t1, sHb, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dalpha*Hb + calH(dP)
   double* q = psm_at(w.psm, dm, sid);
-  double tl[NGM];
   for (int i = 0; i < ng; ++i) {
     double t = 0.0;
     for (int r = 0; r < 2; ++r) {
@@ -308,26 +485,79 @@ __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass) {
       if (lane < n) { for (int c = 0; c < n; ++c) x = fma(sM[lane * LD + c], pv[n + c], x); x *= pv[lane]; }
       t += wave_sum(x);
     }
-    tl[i] = t + dtau * PSM_CT(q, ng)[i];
+    if (lane == 0) tl[i] = PSM_RPHI(q, nzs)[i] - (t + dtau * PSM_CT(q, nzs)[i]);
+  }
+  if (lane < ps.na) tl[ng + lane] = PSM_RPHI(q, nzs)[ng + lane];          // the epigraph variables do not couple to (P, tau, alpha)
+  wsync();
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
+  double* cp = w.corrp + (size_t)sid * dm.nr;
+  double* dph = w.dphi + (size_t)sid * dm.nr; double* dzp = w.dzph + (size_t)sid * dm.nr;
+  if (lane < nz) {
+    double v = 0.0;
+    for (int j = 0; j < nz; ++j) v = fma(PSM_K(q)[lane * nzs + j], tl[j], v);
+    dl[lane] = v;
+    if (lane < ng) {
+      dph[lane] = v;
+      const double dz = sig / phi[lane] - z[lane] - z[lane] * v / phi[lane] - (use_corr ? cp[lane] : 0.0);
+      dzp[lane] = dz;
+      if (pass == 1) cp[lane] = dz * v / phi[lane];
+    }
+  }
+  wsync();
+  double dxs = 0.0, xds = 0.0, dxds = 0.0, emd = 0.0, emp = 0.0;
+  if (ps.na > 0) {
+    const double wr = phi_wr(w, pr);
+    double* aS = sV; double* aX = sM; double* aSi = sHb; double* aDS = sm + 5 * MS + 2 * NZM;   // aDS, aDX: two more slots
+    double* aDX = aDS + MS;
+    double* vv = aDX + MS;                 // tridiag scratch (>= 96 doubles)
+    for (int e = 0; e < ps.na; ++e) {
+      const int m = ps.am[e], ne = m + 1, c0 = ps.a0[e];
+      const size_t ao = ((size_t)sid * 2 + e) * AE;
+      const double dt = dl[ng + e];
+      if (lane == 0) w.adt[(size_t)sid * 2 + e] = dt;
+      arrow_s(aS, w.at[(size_t)sid * 2 + e], phi + c0, wr, m, lane);
+      arrow_s(aDS, dt, dl + c0, wr, m, lane);
+      a_g2s(aX, w.aX + ao, ne, lane);
+      a_g2s(aSi, w.aSi + ao, ne, lane);
+      // dX = sig S^-1 - X - sym(X dS S^-1) - corr
+      mm(t0, aX, LD, 1, aDS, LD, 1, ne, ne, ne, 0, lane);
+      mm(t1, t0, LD, 1, aSi, LD, 1, ne, ne, ne, 0, lane);
+      for (int qq = lane; qq < ne * ne; qq += 64) {
+        const int i = qq / ne, j = qq - i * ne;
+        aDX[i * LD + j] = sig * aSi[i * LD + j] - aX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]) - (use_corr ? w.acor[ao + i * AEL + j] : 0.0);
+      }
+      wsync();
+      a_s2g(w.adX + ao, aDX, ne, lane);
+      dxs += a_dot(aDX, aS, ne, lane); xds += a_dot(aX, aDS, ne, lane); dxds += a_dot(aDX, aDS, ne, lane);
+      if (pass == 1) {      // sym(dX dS S^-1)
+        mm(t0, aDX, LD, 1, aDS, LD, 1, ne, ne, ne, 0, lane);
+        mm(t1, t0, LD, 1, aSi, LD, 1, ne, ne, ne, 0, lane);
+        a_s2g_sym(w.acor + ao, t1, ne, lane);
+      }
+      // step-length matrices L^-1 dS L^-T, LX^-1 dX LX^-T
+      a_g2s(aX, w.aLi + ao, ne, lane);
+      mm(t0, aX, LD, 1, aDS, LD, 1, ne, ne, ne, 0, lane);
+      mm(t1, t0, LD, 1, aX, 1, LD, ne, ne, ne, 0, lane);
+      s_sym(t1, ne, lane);
+      emd = fmin(emd, tridiag_min_eig(t1, ne, vv, lane));
+      wsync();
+      a_g2s(aX, w.aLXi + ao, ne, lane);
+      mm(t0, aX, LD, 1, aDX, LD, 1, ne, ne, ne, 0, lane);
+      mm(t1, t0, LD, 1, aX, 1, LD, ne, ne, ne, 0, lane);
+      s_sym(t1, ne, lane);
+      emp = fmin(emp, tridiag_min_eig(t1, ne, vv, lane));
+      wsync();
+    }
   }
   if (lane == 0) {
-    const double* phi = w.phi + (size_t)sid * ng; const double* z = w.zph + (size_t)sid * ng;
-    double* cp = w.corrp + (size_t)sid * ng;
-    double* dph = w.dphi + (size_t)sid * ng; double* dzp = w.dzph + (size_t)sid * ng;
-    for (int i = 0; i < ng; ++i) {
-      double v = 0.0;
-      for (int j = 0; j < ng; ++j) v += PSM_K(q)[i * ng + j] * (PSM_RPHI(q, ng)[j] - tl[j]);
-      dph[i] = v;
-    }
-    for (int i = 0; i < ng; ++i) {
-      const double dz = sig / phi[i] - z[i] - z[i] * dph[i] / phi[i] - (use_corr ? cp[i] : 0.0);
-      dzp[i] = dz;
-    }
-    if (pass == 1) for (int i = 0; i < ng; ++i) cp[i] = dzp[i] * dph[i] / phi[i];
+    double* as = w.asum + (size_t)sid * 5;
+    as[0] = dxs; as[1] = xds; as[2] = dxds; as[3] = emd; as[4] = emp;
   }
 }
+constexpr int PHI_DIR_LDS = 5 * MS + 2 * NZM + 2 * MS + 128;
 
-// after k_stage_dir and k_eigmin, before k_ctrl_b / k_ctrl_c: the linear cone joins the step-length minima and the mu_aff sums
+// after k_stage_dir and k_eigmin, before k_ctrl_b / k_ctrl_c: the linear cone and the arrow blocks join the step-length minima and
+// the mu_aff sums
 __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
   const int sid = blockIdx.x * 64 + threadIdx.x;
   if (sid >= dm.B * dm.p) return;
@@ -335,10 +565,11 @@ __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
-  const int ng = dm.ng;
-  const double* phi = w.phi + (size_t)sid * ng; const double* z = w.zph + (size_t)sid * ng;
-  const double* dph = w.dphi + (size_t)sid * ng; const double* dzp = w.dzph + (size_t)sid * ng;
-  double ls = 1e300, lx = 1e300, dxs = 0.0, xds = 0.0, dxds = 0.0;
+  const int ng = stage_rows(w, dm, sid);
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
+  const double* dph = w.dphi + (size_t)sid * dm.nr; const double* dzp = w.dzph + (size_t)sid * dm.nr;
+  const double* as = w.asum + (size_t)sid * 5;
+  double ls = as[3], lx = as[4], dxs = as[0], xds = as[1], dxds = as[2];      // zero without arrow blocks
   for (int i = 0; i < ng; ++i) {
     ls = fmin(ls, dph[i] / phi[i]); lx = fmin(lx, dzp[i] / z[i]);       // "eigenvalues" of the 1 x 1 blocks: step = -1/lambda
     dxs += dzp[i] * phi[i]; xds += z[i] * dph[i]; dxds += dzp[i] * dph[i];
@@ -358,9 +589,20 @@ __global__ void __launch_bounds__(64) k_phi_update(WS w, Dims dm) {
   if (ip[I_PHASE] == PH_DONE) return;
   const double* pr = w.prob + (size_t)b * PS;
   const double ap = pr[P_AP], ad = pr[P_AD];
-  for (int i = 0; i < dm.ng; ++i) {
-    w.phi[(size_t)sid * dm.ng + i] += ad * w.dphi[(size_t)sid * dm.ng + i];
-    w.zph[(size_t)sid * dm.ng + i] += ap * w.dzph[(size_t)sid * dm.ng + i];
+  const PhiStage ps = phi_stage(w, dm, sid);
+  for (int i = 0; i < ps.nrow; ++i) {
+    w.phi[(size_t)sid * dm.nr + i] += ad * w.dphi[(size_t)sid * dm.nr + i];
+    w.zph[(size_t)sid * dm.nr + i] += ap * w.dzph[(size_t)sid * dm.nr + i];
+  }
+  for (int e = 0; e < ps.na; ++e) {
+    w.at[(size_t)sid * 2 + e] += ad * w.adt[(size_t)sid * 2 + e];
+    const int ne = ps.am[e] + 1;
+    double* X = w.aX + ((size_t)sid * 2 + e) * AE; const double* dX = w.adX + ((size_t)sid * 2 + e) * AE;
+    for (int i = 0; i < ne; ++i)
+      for (int j = 0; j <= i; ++j) {
+        const double v = 0.5 * ((X[i * AEL + j] + ap * dX[i * AEL + j]) + (X[j * AEL + i] + ap * dX[j * AEL + i]));
+        X[i * AEL + j] = v; X[j * AEL + i] = v;
+      }
   }
 }
 

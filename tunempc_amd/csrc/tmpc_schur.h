@@ -189,9 +189,10 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
     rp2 = fma(wv, wv, rp2);
   }
   rp2 = wave_sum(rp2);
-  if (dm.ng > 0) rp2 += psum(w.part, b, p, Q_RPHI2, lane);      // stationarity residual of the equality-constraint multipliers
+  double ncone = 0.0;
+  if (dm.nr > 0) { rp2 += psum(w.part, b, p, Q_RPHI2, lane); ncone = psum(w.part, b, p, Q_NCONE, lane); }   // stage-local multipliers: stationarity residual, cone dimension
   if (lane != 0) return;
-  const double N = 2.0 * p * dm.n + 1.0 + (double)p * dm.ng;     // cone dimension (+ the ng nonnegative multipliers per stage)
+  const double N = 2.0 * p * dm.n + 1.0 + ncone;     // cone dimension
   const double tau = pr[P_TAU], alpha = pr[P_ALPHA], s0 = pr[P_S0], x0 = pr[P_X0];
   const double rd0 = (alpha - ALPHA_MIN) - s0;
   const double mu = (xs + x0 * s0) / N;
@@ -250,8 +251,9 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
   const double minx = emin(w.eigmin, b, p, 1, lane), mins = emin(w.eigmin, b, p, 0, lane);
   const double dxs = psum(w.part, b, p, Q_DXS, lane), xds = psum(w.part, b, p, Q_XDS, lane);
   const double dxds = psum(w.part, b, p, Q_DXDS, lane);
+  const double ncone = (dm.nr > 0) ? psum(w.part, b, p, Q_NCONE, lane) : 0.0;
   if (lane != 0) return;
-  const double N = 2.0 * p * dm.n + 1.0 + (double)p * dm.ng;     // cone dimension (+ the ng nonnegative multipliers per stage)
+  const double N = 2.0 * p * dm.n + 1.0 + ncone;     // cone dimension
   const double s0 = pr[P_S0], x0 = pr[P_X0], mu = pr[P_MU];
   const double ds0 = pr[P_DALPHA] + pr[P_RD0];
   const double dx0 = -x0 - x0 * ds0 / s0;

@@ -132,6 +132,8 @@ __device__ __forceinline__ void adj_V(double* out, double* t, const double* sV, 
   mm(out, t, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);        // (V G) V'
 }
 
+// rows of [G_k; C_k] present at stage sid
+__device__ __forceinline__ int stage_rows(const WS& w, const Dims& dm, size_t sid) { return dm.ng + (w.ncnt ? w.ncnt[sid] : 0); }
 // out (n x n LDS slot) += scale * sum_i coef[i] g_i g_i'   (equality-constraint term, G rows and coefficients in global memory)
 __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const double* coef, double scale, int ng, int n, int lane) {
   for (int e = lane; e < n * n; e += 64) {
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   TMPC_T(8)
   build_M(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
-  if (dm.ng > 0) add_gtg(sM, w.G + (size_t)sid * dm.ng * n, w.phi + (size_t)sid * dm.ng, 1.0, dm.ng, n, lane);   // + G' diag(phi) G
+  if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
   TMPC_T(9)
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
   int nbad = 0;
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   const double* dPk = w.dP + (size_t)sid * nxx;
   build_M(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
-  if (dm.ng > 0) add_gtg(sM, w.G + (size_t)sid * dm.ng * n, w.dphi + (size_t)sid * dm.ng, 1.0, dm.ng, n, lane);   // + G' diag(dphi) G
+  if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
@@ -457,9 +459,10 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
   wsync();
   // dH = V' Pst+ V - E' Pst E  (coef 0: no Hb term), then symmetrise (mtools.symmetrize, convexifier.py:206)
   build_M(sM, sV, t0, t1, sHb, Po, Pon, 0.0, n, nx, lane);
-  if (dm.ng > 0) {                          // Fg = sF*phi/(s_alpha*alpha) (convexifier.py:409-411) and its term of the supplement (:196-197)
-    if (lane < dm.ng) w.Fg[(size_t)sid * dm.ng + lane] = sc * w.phi[(size_t)sid * dm.ng + lane];
-    add_gtg(sM, w.G + (size_t)sid * dm.ng * n, w.phi + (size_t)sid * dm.ng, sc, dm.ng, n, lane);
+  if (dm.nr > 0) {                          // [Fg; F] = sF*phi/(s_alpha*alpha) (convexifier.py:409-420) and their terms of the supplement (:196-201)
+    const int nrow = stage_rows(w, dm, sid);
+    if (lane < dm.nr) w.Fg[(size_t)sid * dm.nr + lane] = (lane < nrow) ? sc * w.phi[(size_t)sid * dm.nr + lane] : 0.0;
+    add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, sc, nrow, n, lane);
   }
   s_sym(sM, n, lane);
   double* dHg = w.dHc + (size_t)sid * nn;
