@@ -88,6 +88,51 @@ def equality_term():
         print(name, 'kappa', out['kappa'], 'iters', out['iters'])
 
 
+STEP2_CASES = {
+    # name: (base_seed, nb, p, nx, mb, ng, rows of C_k per stage (0: None), rho): the Step 2 model (convexifier.py:116-131)
+    'step2_ragged_n5': (7300, 2, 3, 3, 2, 0, [2, 0, 1], 1e-3),
+    'step2_with_g_n6': (7400, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 1e-2),
+    'step2_p1': (20, 1, 1, 3, 1, 0, [2], 1.0),
+}
+
+
+def step2_inputs(seed, nb, p, nx, mb, ng, ncs):
+    n = nx + mb
+    A, B, Hs = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed + 5)
+    nc = max(ncs)
+    G = rng.standard_normal((nb, p, ng, n))
+    C = np.zeros((nb, p, nc, n)); ncnt = np.tile(np.asarray(ncs, np.int32), (nb, 1))
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+    return A, B, Hs, G, C, ncnt
+
+
+def step2():
+    """Inputs and the structured oracle's outputs for the Step 2 model, solved directly (whether or not Step 1 is feasible)."""
+    for name, (seed, nb, p, nx, mb, ng, ncs, rho) in STEP2_CASES.items():
+        A, B, Hs, G, C, ncnt = step2_inputs(seed, nb, p, nx, mb, ng, ncs)
+        out = dict(Hc=[], P=[], F=[], Fg=[], kappa=[], alpha=[], beta=[], status=[], iters=[], objective=[])
+        for b in range(nb):
+            assert np.linalg.eigvalsh(Hs[b])[:, 0].min() < 0
+            Cl = [C[b, k, :ncs[k]] if ncs[k] else None for k in range(p)]
+            Gb = G[b] if ng else None
+            r = co.sdp_step1(A[b], B[b], Hs[b], G=Gb, C=Cl, rho=rho)
+            st, dHc = co.check_convergence(A[b], B[b], Hs[b], r['P'], r['ipm_status'], G=Gb, Fg=r.get('Fg'), C=Cl, F=r['F'])[:2]
+            assert st == co.STATUS_OPTIMAL
+            Fp = np.zeros((p, max(ncs)))
+            for k in range(p):
+                if ncs[k]:
+                    Fp[k, :ncs[k]] = r['F'][k]
+            r.update(Hc=Hs[b] + dHc, F=Fp, status=st, Fg=r.get('Fg', np.zeros((p, 0))))
+            for k in out:
+                out[k].append(r[k])
+        np.savez(os.path.join(HERE, name + '.npz'), A=A, B=B, H=Hs, G=G, C=C, ncnt=ncnt, rho=rho, tol=co.DEFAULT_OPTS['tol'],
+                 **{k: np.array(v) for k, v in out.items()})
+        print(name, 'kappa', out['kappa'], 'iters', out['iters'], 'objective', out['objective'])
+
+
 def rblock_problem(p=2, nx=2, nu=1, seed=0):
     """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
     Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
@@ -119,6 +164,9 @@ def steps23():
 if __name__ == '__main__':
     if sys.argv[1:] == ['eq']:
         equality_term()          # only the equality-term vectors (the others stay byte-identical)
+    elif sys.argv[1:] == ['step2']:
+        step2()
     else:
         main()
         equality_term()
+        step2()

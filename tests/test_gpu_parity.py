@@ -311,6 +311,102 @@ def test_equality_term_dense_model_vector(hc, golden_dir):
     assert all(dRc[k][0, 0] > 0.5 for k in range(p))
 
 
+# ----------------------------------------------------------------------------- Step 2: active-constraint multipliers + norm terms
+def _step2_inputs(seed, nb, p, nx, mb, ng, ncs):
+    n = nx + mb
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed + 5)
+    nc = max(max(ncs), 1)
+    G = rng.standard_normal((nb, p, ng, n))
+    C = np.zeros((nb, p, nc, n)); ncnt = np.tile(np.asarray(ncs, np.int32), (nb, 1))
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+    return A, B, H, G, C, ncnt
+
+
+def _step2_oracle(A, B, H, G, C, ncnt, rho):
+    p = A.shape[0]
+    Cl = [C[k, :ncnt[k]] if ncnt[k] else None for k in range(p)]
+    Gb = G if G.shape[1] else None
+    r = co.sdp_step1(A, B, H, G=Gb, C=Cl, rho=rho)
+    st, dHc = co.check_convergence(A, B, H, r['P'], r['ipm_status'], G=Gb, Fg=r.get('Fg'), C=Cl, F=r['F'])[:2]
+    return r, st, dHc, Cl
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng,ncs,rho', [
+    (20, 2, 3, 3, 2, 0, [2, 0, 1], 1e-3), (0, 1, 3, 3, 2, 2, [1, 2, 0], 1.0), (30, 2, 2, 3, 1, 1, [1, 1], 1e-3), (20, 1, 1, 3, 1, 0, [2], 1.0),
+    (7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 1e-2), (11, 2, 4, 6, 3, 2, [4, 0, 8, 1], 1e-3), (12, 1, 3, 24, 8, 4, [8, 3, 0], 1e-3),
+    (13, 1, 3, 8, 2, 2, [0, 0, 0], 1e-2)])
+def test_step2_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng, ncs, rho):
+    """convexifier.py:116-131 (constr=True): multipliers F_k >= 0 of ragged active-constraint Jacobians (stages without C_k
+    included), the norm terms rho*||F_k|| and rho*||Fg_k|| as arrow LMIs.  HIP path (stage-local elimination, tmpc_phi.h) vs the
+    CPU oracle (border columns); p = 1, p = 2, the maximum row counts and a case with G only (every C_k None)."""
+    A, B, H, G, C, ncnt = _step2_inputs(seed, nb, p, nx, mb, ng, ncs)
+    J = np.concatenate([G, C], axis=2)
+    out = hc(p, nx, mb, ng=ng, nc=C.shape[2]).convexify_step2_batch(A, B, H, J, ncnt, rho)
+    for b in range(nb):
+        r, st, dHc, Cl = _step2_oracle(A[b], B[b], H[b], G[b], C[b], ncnt[b], rho)
+        assert int(out['status'][b]) == int(st)
+        assert rel(out['Hc'][b], H[b] + dHc) < PARITY
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        Fo = out['FgF'][b]
+        assert (Fo >= 0).all()
+        for k in range(p):
+            if ng:
+                assert np.linalg.norm(Fo[k, :ng] - r['Fg'][k]) <= 1e-7 * max(1.0, np.linalg.norm(r['Fg'][k]))
+            if ncnt[b, k]:
+                assert np.linalg.norm(Fo[k, ng:ng + ncnt[b, k]] - r['F'][k]) <= 1e-7 * max(1.0, np.linalg.norm(r['F'][k]))
+            assert not Fo[k, ng + ncnt[b, k]:].any()
+        # the supplement is what convexHessianSuppl builds from (P, Fg, F): convexifier.py:196-201
+        Fl = [Fo[k, ng:ng + ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        ref = co.convex_hessian_suppl(A[b], B[b], out['P'][b], G=G[b] if ng else None, Fg=Fo[:, :ng] if ng else None, C=Cl, F=Fl)[0]
+        assert rel(out['dHc'][b], ref) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['step2_ragged_n5', 'step2_with_g_n6', 'step2_p1'])
+def test_step2_golden_vectors(hc, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    A, B, H, G, C, ncnt = g['A'], g['B'], g['H'], g['G'], g['C'], g['ncnt']
+    nb, p, nx, _ = A.shape
+    ng = G.shape[2]
+    out = hc(p, nx, B.shape[3], ng=ng, nc=C.shape[2]).convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, float(g['rho']))
+    for b in range(nb):
+        assert int(out['status'][b]) == int(g['status'][b])
+        assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
+        assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+        assert np.linalg.norm(out['FgF'][b][:, ng:] - g['F'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['F'][b]))
+        if ng:
+            assert np.linalg.norm(out['FgF'][b][:, :ng] - g['Fg'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['Fg'][b]))
+
+
+def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
+    """convexify(..., C=...) on the dense model's vector (B = 0, R < 0): Step 1 infeasible -> Step 2 -> EQUIVALENCE TYPE B;
+    without C the reference's ValueError; force asks for Step 3, which this build does not have."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(golden_dir, 'n1_step2_active_constraints.npz'))
+    p = g['A'].shape[0]
+    lst = lambda a: [a[k] for k in range(p)]
+    args = (lst(g['A']), lst(g['B']), lst(g['Q']), lst(g['R']), lst(g['N']))
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        convexifier.convexify(*args)
+    with pytest.raises(NotImplementedError):
+        convexifier.convexify(*args, opts={'rho': 1e-3, 'force': True})
+    dHc, dQc, dRc, dNc = convexifier.convexify(*args, C=lst(g['Cu']), opts={'rho': float(g['rho'])})
+    ref = co.convexify(*args, C=lst(g['Cu']), opts={'rho': float(g['rho'])})
+    H = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
+    assert rel(H + np.stack(dHc), H + np.stack(ref[0])) < PARITY
+    ev = np.linalg.eigvalsh(H + np.stack(dHc))
+    assert ev.min() > 0 and abs((ev[:, -1] / ev[:, 0]).max() / float(g['kappa']) - 1.0) < 1e-4
+    assert all(dRc[k][0, 0] > 0.5 for k in range(p))
+    # a stage without active constraints (None entry, preprocessing.py:180) and a ragged list
+    Cr = [g['Cu'][0], None] if p == 2 else lst(g['Cu'])
+    out = convexifier.convexify(*args, C=[np.vstack([g['Cu'][0], [[1.0, 0.0, 0.0]]]), g['Cu'][1]], opts={'rho': float(g['rho'])})
+    assert np.linalg.eigvalsh(H + np.stack(out[0])).min() > 0
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        convexifier.convexify(*args, C=Cr, opts={'rho': float(g['rho'])})        # stage 1 keeps R < 0 without its constraint
+
+
 # ----------------------------------------------------------------------------- reference-compatible API
 def test_dropin_convexify_lqr_example():
     """examples/convex_lqr.py through the drop-in API: same call, same return structure, same assertion (:58)."""

@@ -137,6 +137,24 @@ def test_equality_term_golden_vectors(golden_dir, name):
     assert abs(r['kappa'] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
 
 
+@pytest.mark.parametrize('name', ['step2_ragged_n5', 'step2_with_g_n6', 'step2_p1'])
+def test_step2_golden_vectors(golden_dir, name):
+    """Step 2 model (convexifier.py:116-131): the oracle reproduces the committed outputs (Hc, F, Fg, objective)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    b = 0
+    p = g['A'].shape[1]
+    ng = g['G'].shape[2]
+    C = [g['C'][b, k, :g['ncnt'][b, k]] if g['ncnt'][b, k] else None for k in range(p)]
+    G = g['G'][b] if ng else None
+    r = co.sdp_step1(g['A'][b], g['B'][b], g['H'][b], G=G, C=C, rho=float(g['rho']))
+    dHc = co.convex_hessian_suppl(g['A'][b], g['B'][b], r['P'], G=G, Fg=r.get('Fg'), C=C, F=r['F'])[0]
+    assert np.linalg.norm(g['H'][b] + dHc - g['Hc'][b]) / np.linalg.norm(g['Hc'][b]) < 1e-8
+    assert abs(r['kappa'] - g['kappa'][b]) < 1e-9 * g['kappa'][b] and abs(r['objective'] - g['objective'][b]) < 1e-9 * g['objective'][b]
+    for k in range(p):
+        if C[k] is not None:
+            assert np.linalg.norm(r['F'][k] - g['F'][b, k, :len(r['F'][k])]) <= 1e-7 * max(1.0, np.linalg.norm(r['F'][k]))
+
+
 def test_dropin_oracle_accepts_equality_jacobians():
     """convexify(..., G=...) -> the supplement carries the G' diag(Fg) G term (convexifier.py:196-197)."""
     A, B, H = co.gen_problem(20, 3, 3, 2)[:3]

@@ -7,10 +7,10 @@ include/tunempc_hip.h.  `opts['solver']` selects the backend: 'hip' (default her
 'mosek' / 'cvxopt' strings are accepted and mapped to 'hip' because those solvers do not exist on this
 stack).  There is no CPU path in this package.
 
-Scope of this round: Step 1 (eta_F = 0, eta_T = 0), with the equality-constraint
-multipliers Fg (convexifier.py:249-255) when G is given (up to NG_MAX rows per stage).  Problems that need
-Step 2 / Step 3 (active-constraint or forced regularisation, convexifier.py:116-157) raise NotImplementedError
-when G or C are supplied and Step 1 is infeasible.
+Scope: Step 1 (eta_F = 0, eta_T = 0), with the equality-constraint multipliers Fg
+(convexifier.py:249-255) when G is given (up to NG_MAX rows per stage), and Step 2 (eta_F = 1: multipliers F of the
+active constraints C and the rho-norm terms, convexifier.py:116-131) when Step 1 is infeasible and C is given.
+Step 3 (forced regularisation T, convexifier.py:137-147) raises NotImplementedError.
 """
 import numpy as np
 
@@ -23,15 +23,21 @@ _HANDLES = {}
 
 
 NG_MAX = 8       # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
+NC_MAX = 8       # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
-def _handle(p, nx, mb, ng=0):
-    key = (p, nx, mb, ng)
+def _handle(p, nx, mb, ng=0, nc=0):
+    key = (p, nx, mb, ng, nc)
     h = _HANDLES.get(key)
     if h is None:
-        h = HipConvexifier(p, nx, mb, ng=ng)
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
         _HANDLES[key] = h
     return h
+
+
+def _rows_supported(nx, ng, nc):
+    """tmpc_create_con: the stage-local elimination keeps 5*(ng+nc)*d doubles in LDS."""
+    return ng <= NG_MAX and nc <= NC_MAX and (ng + nc) * (nx * (nx + 1) // 2) <= 4096
 
 
 def _to_array(m):
@@ -62,6 +68,31 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None):
     if ng > 0:
         return h.convexify_eq_batch(A, B, H, G)
     return h.convexify_batch(A, B, H)
+
+
+def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
+    """Batched Step 2 model (convexifier.py:116-131, setUpModelPicos with constr=True): A, B, H as in convexify_batch;
+    C [nb,p,nc,n] active-constraint Jacobians zero-padded to nc rows, ncnt [nb,p] rows present per stage (0: C_k is None);
+    G [nb,p,ng,n] optional.  Returns the dict of convexify_batch plus 'F' [nb,p,nc] (zeros in the padding) and, with G, 'Fg'."""
+    A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
+    C = np.asarray(C, dtype=np.float64); ncnt = np.asarray(ncnt, dtype=np.int32)
+    nb, p, nx, _ = A.shape
+    mb = B.shape[3]
+    nc = C.shape[2]
+    ng = 0 if G is None else np.shape(G)[2]
+    if nc < 1 or not _rows_supported(nx, ng, nc):
+        raise NotImplementedError('the HIP path handles up to {} equality- and 1..{} active-constraint rows per stage with '
+                                  '(ng+nc)*nx*(nx+1)/2 <= 4096 (got ng={}, nc={}, nx={})'.format(NG_MAX, NC_MAX, ng, nc, nx))
+    J = C if ng == 0 else np.concatenate([np.asarray(G, dtype=np.float64), C], axis=2)
+    h = handle or _handle(p, nx, mb, ng, nc)
+    if tol is not None:
+        h.set_options(tol=tol)
+    out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    FgF = out.pop('FgF')
+    out['F'] = FgF[:, :, ng:]
+    if ng:
+        out['Fg'] = FgF[:, :, :ng]
+    return out
 
 
 def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip', 'force': False}):
@@ -130,8 +161,36 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     else:
         Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
         Logger.logger.info('!! Problem infeasible !!')
-        if 'C' in arg or 'G' in arg or (opts or {}).get('force', False):
-            raise NotImplementedError('Step 2/3 of the convexifier (convexifier.py:116-157) are not built yet')
+
+    if status == 'Infeasible' and 'C' in arg:        # convexifier.py:116-131
+        Logger.logger.info(50 * '*')
+        Logger.logger.info('Step 2: (η_F = 1), (η_T = 0)')
+        Cl = [None if c is None else _to_array(c) for c in arg['C']]
+        rows = [0 if c is None else c.shape[0] for c in Cl]
+        nc = max(1, max(rows))
+        Cp = np.zeros((period, nc, nx + nu))
+        for k, c in enumerate(Cl):
+            if rows[k]:
+                Cp[k, :rows[k]] = c
+        Logger.logger.info('solving SDP...')
+        res = convexify_step2_batch(As[None], Bs[None], Hs[None], Cp[None], np.asarray(rows, np.int32)[None],
+                                    (opts or {}).get('rho', 1e-3), G=None if Gs is None else Gs[None])
+        status = STATUS_NAMES[int(res['status'][0])]
+        Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
+        Logger.logger.debug('beta: {}'.format(res['beta'][0]))
+        if status in ['Optimal', 'Feasible']:
+            Logger.logger.info('{} solution found.'.format(status))
+            Logger.logger.info('Maximum condition number: {}'.format(res['info'][0, 4]))
+            Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+            Logger.logger.info('EQUIVALENCE TYPE B')
+            Logger.logger.info(50 * '*')
+        else:
+            Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+            Logger.logger.info('!! Problem infeasible !!')
+
+    if status == 'Infeasible':
+        if (opts or {}).get('force', False):
+            raise NotImplementedError('Step 3 of the convexifier (forced regularisation T, convexifier.py:137-147) is not built yet')
         Logger.logger.warning('!! Strict dissipativity does not hold locally !!')
         Logger.logger.warning('!! The provided indefinite LQ MPC problem is not stabilising !!')
         Logger.logger.warning(50 * '*')
