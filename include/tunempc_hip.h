@@ -148,6 +148,14 @@ int tmpc_get_trace(tmpc_handle* h, int nb, double* out);
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
 int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift);
 
+/* Scaled stage-local multipliers of the LAST chunk solved (row stride nr of that call): phi, their duals z and the last
+ * directions, each [nb][p][nr]; any pointer may be NULL. */
+int tmpc_debug_get_multipliers(tmpc_handle* h, int nb, int nr, double* phi, double* z, double* dphi, double* dz);
+
+/* Raw workspace read-back for diagnostics (scripts/eq_debug.py): which = 0 psm, 1 pvec, 2 Ddiag, 3 D, 4 part, 5 O, 6 F;
+ * `count` doubles from `offset` (no bounds check beyond the pointer being allocated). */
+int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t count, double* out);
+
 /* Smallest eigenvalue of nmat symmetric n x n matrices (Householder tridiagonalisation + Sturm multisection). */
 int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out);
 /* Isolated A/B timing of the block factorisation kernel: ms_out2[0] = baseline GEMM variant, [1] = current. */

@@ -279,6 +279,20 @@ def _arrow(t, v, w):
     return S
 
 
+def _arrow_start(a, m, mu):
+    """t = a + delta with mu * tr(arrow(t, v)^-1) = 1 for ||w v|| = a: the eigenvalues of the arrow matrix are t - a, t + a and
+    t (m - 1 times).  Bisection on delta in [mu, (m+1) mu] (60 halvings, the same loop as k_phi_init)."""
+    lo, hi = mu, (m + 1.0) * mu
+    for _ in range(60):
+        dl = 0.5 * (lo + hi)
+        f = mu * (1.0 / dl + 1.0 / (dl + 2.0 * a) + (m - 1.0) / (dl + a)) - 1.0
+        if f > 0.0:
+            lo = dl
+        else:
+            hi = dl
+    return a + 0.5 * (lo + hi)
+
+
 def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
     constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
@@ -335,15 +349,26 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 J[k, ng0:ng0 + ncs[k]] = np.atleast_2d(np.asarray(C[k], dtype=np.float64)); mask[k, ng0:ng0 + ncs[k]] = True
         G = J
         GG = G[:, :, :, None] * G[:, :, None, :]           # [p, ng, n, n]: g g' per constraint row
-        phi = np.ones((p, ng))                             # slack of phi >= 0 is phi itself
-        z = np.where(mask, x0, 0.0)                        # its multiplier
+        # slack of phi >= 0 is phi itself, z its multiplier.  Start: phi_i = min(1, 1/|g_i|^2), so that the term g_i' phi_i g_i
+        # is O(1) whatever the scaling of the Jacobian rows, and z_i = x0/phi_i on the central path (two iterations fewer on
+        # average than phi = 1, and no 25+-iteration stragglers with rows of norm 5)
+        g2 = np.maximum(np.sum(G * G, axis=2), 1e-300)
+        phi = np.where(mask, np.minimum(1.0, 1.0 / g2), 1.0)
+        z = np.where(mask, x0 / phi, 0.0)
         N = N + int(mask.sum())
         if constr:
             wr = rho * sbeta / s
             for k in range(p):
                 for idx in ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else []):
                     m = len(idx)
-                    arrows.append(dict(k=k, idx=idx, t=1.0 + wr * np.sqrt(m), X=x0 * np.eye(m + 1)))
+                    # start ON the central path of the norm term: multipliers z_i = w/sqrt(m) (the gradient of w||phi|| at equal
+                    # phi_i: their stationarity residual vanishes), phi_i = x0/z_i (<= 1), X = x0 S^-1 with tr X = 1 (the cost of t),
+                    # i.e. S within delta ~ x0 of the cone boundary.  (phi = 1, X = x0 I, S = O(1) leaves residuals ~ 1 per norm
+                    # term; with 2p terms the first Newton steps blow mu up by three orders of magnitude and the iteration diverges.)
+                    ph = min(1.0, x0 * np.sqrt(m) / wr)
+                    phi[k, idx] = ph; z[k, idx] = x0 / ph
+                    t0 = _arrow_start(wr * ph * np.sqrt(m), m, x0)
+                    arrows.append(dict(k=k, idx=idx, t=t0, X=x0 * np.linalg.inv(_arrow(t0, phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
     phase = 0

@@ -21,7 +21,7 @@ EXPORTS = [
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
     'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_workspace_bytes_eq', 'tmpc_create_eq', 'tmpc_convexify_eq_batch_host',
-    'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
+    'tmpc_debug_get_multipliers', 'tmpc_debug_get_array', 'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -59,6 +59,10 @@ def load_library():
     lib.tmpc_create_con.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_convexify_step2_batch_host.restype = C.c_int
     lib.tmpc_convexify_step2_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, C.c_double, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
+    lib.tmpc_debug_get_multipliers.restype = C.c_int
+    lib.tmpc_debug_get_multipliers.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
+    lib.tmpc_debug_get_array.restype = C.c_int
+    lib.tmpc_debug_get_array.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, dp]
     lib.tmpc_create.restype = C.c_int
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
@@ -181,6 +185,16 @@ class HipConvexifier:
                                                    _iptr(out['iters']), _dptr(out['info']))
         _check(self.lib, rc, 'tmpc_convexify_eq_batch_host')
         return out
+
+    def debug_array(self, which, offset, count):
+        out = np.empty(int(count))
+        _check(self.lib, self.lib.tmpc_debug_get_array(self._h, int(which), int(offset), int(count), _dptr(out)), 'tmpc_debug_get_array')
+        return out
+
+    def debug_multipliers(self, nb, nr):
+        out = [np.empty((nb, self.p, nr)) for _ in range(4)]
+        _check(self.lib, self.lib.tmpc_debug_get_multipliers(self._h, nb, nr, *[_dptr(o) for o in out]), 'tmpc_debug_get_multipliers')
+        return dict(phi=out[0], z=out[1], dphi=out[2], dz=out[3])
 
     def convexify_step2_batch(self, A, B, H, J, ncnt, rho):
         """The Step 2 model (convexifier.py:116-131).  J [nb,p,ng+nc,n]: rows of G_k, then rows of C_k, zero padding;

@@ -480,6 +480,34 @@ int tmpc_get_trace(tmpc_handle* h, int nb, double* out) {
   return TMPC_OK;
 }
 
+int tmpc_debug_get_multipliers(tmpc_handle* h, int nb, int nr, double* phi, double* z, double* dphi, double* dz) {
+  if (!h || nb < 1 || nb > h->dm.B || nr < 1 || nr > h->dm.nr || !h->ws.phi) return TMPC_E_ARG;
+  const size_t cnt = (size_t)nb * h->dm.p * nr * sizeof(double);
+  if (phi) HIPCHK(hipMemcpy(phi, h->ws.phi, cnt, hipMemcpyDeviceToHost));
+  if (z) HIPCHK(hipMemcpy(z, h->ws.zph, cnt, hipMemcpyDeviceToHost));
+  if (dphi) HIPCHK(hipMemcpy(dphi, h->ws.dphi, cnt, hipMemcpyDeviceToHost));
+  if (dz) HIPCHK(hipMemcpy(dz, h->ws.dzph, cnt, hipMemcpyDeviceToHost));
+  return TMPC_OK;
+}
+
+int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t count, double* out) {
+  if (!h || !out) return TMPC_E_ARG;
+  const double* src = nullptr;
+  switch (which) {
+    case 0: src = h->ws.psm; break;
+    case 1: src = h->ws.pvec; break;
+    case 2: src = h->ws.Ddiag; break;
+    case 3: src = h->ws.D; break;
+    case 4: src = h->ws.part; break;
+    case 5: src = h->ws.O; break;
+    case 6: src = h->ws.F; break;
+    default: return TMPC_E_ARG;
+  }
+  if (!src) return TMPC_E_ARG;
+  HIPCHK(hipMemcpy(out, src + offset, count * sizeof(double), hipMemcpyDeviceToHost));
+  return TMPC_OK;
+}
+
 int tmpc_get_profile(tmpc_handle* h, double* out8) {
   if (!h || !out8) return TMPC_E_ARG;
   for (int i = 0; i < 8; ++i) { out8[i] = h->prof[i]; h->prof[i] = 0.0; }

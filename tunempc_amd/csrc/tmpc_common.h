@@ -29,7 +29,8 @@ enum {
   P_MAXEIG_HC, P_MU0, P_MINPIV, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
-enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, IS = 16 };   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
+enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, IS = 16 };   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
+//   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
 // phases
 enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2 };
 // ipm status

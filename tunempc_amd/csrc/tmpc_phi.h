@@ -98,17 +98,48 @@ __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
   const PhiStage ps = phi_stage(w, dm, sid);
   const double x0 = 1.0 / (double)(dm.p * dm.n);
   if (lane < dm.nr) {
-    w.phi[sid * dm.nr + lane] = 1.0;
-    w.zph[sid * dm.nr + lane] = (lane < ps.nrow) ? x0 : 0.0;
+    // phi_i = min(1, 1/|g_i|^2): the term g_i' phi_i g_i is O(1) whatever the scaling of the Jacobian rows; z_i = x0/phi_i
+    double ph = 1.0;
+    if (lane < ps.nrow) {
+      const double* g = w.G + (sid * dm.nr + lane) * dm.n;
+      double g2 = 0.0;
+      for (int c = 0; c < dm.n; ++c) g2 = fma(g[c], g[c], g2);
+      ph = fmin(1.0, 1.0 / fmax(g2, 1e-300));
+    }
+    w.phi[sid * dm.nr + lane] = ph;
+    w.zph[sid * dm.nr + lane] = (lane < ps.nrow) ? x0 / ph : 0.0;
     w.corrp[sid * dm.nr + lane] = 0.0;
     w.dphi[sid * dm.nr + lane] = 0.0; w.dzph[sid * dm.nr + lane] = 0.0;
   }
+  __syncthreads();
   if (dm.constr) {
+    // Norm terms start ON their central path: z_i = w/sqrt(m) (the gradient of w||phi|| at equal phi_i, so the stationarity residual
+    // of phi_i vanishes), phi_i = x0/z_i (<= 1), t = w||phi|| + delta with x0 tr(S^-1) = 1 (the cost of t), X = x0 S^-1.  With phi = 1,
+    // X = x0 I, S = O(1) each of the 2p terms carries a residual ~ 1 and the first Newton steps blow mu up by 1e3 (diverges at p = 64).
     const double wr = phi_wr(w, w.prob + (size_t)b * PS);
     for (int e = 0; e < ps.na; ++e) {
-      if (lane == 0) { w.at[sid * 2 + e] = 1.0 + wr * sqrt((double)ps.am[e]); w.adt[sid * 2 + e] = 0.0; }
+      const int m = ps.am[e], c0 = ps.a0[e];
+      const double ph = fmin(1.0, x0 * sqrt((double)m) / wr);
+      if (lane < m) { w.phi[sid * dm.nr + c0 + lane] = ph; w.zph[sid * dm.nr + c0 + lane] = x0 / ph; }
+      const double a = wr * ph * sqrt((double)m);
+      double lo = x0, hi = (m + 1.0) * x0;                 // eigenvalues of S: delta, delta + 2a, delta + a (m - 1 times)
+      for (int it = 0; it < 60; ++it) {
+        const double dl = 0.5 * (lo + hi);
+        const double f = x0 * (1.0 / dl + 1.0 / (dl + 2.0 * a) + (m - 1.0) / (dl + a)) - 1.0;
+        if (f > 0.0) lo = dl; else hi = dl;
+      }
+      const double t = a + 0.5 * (lo + hi);
+      const double u = wr * ph, gam = t * t - m * u * u;
+      if (lane == 0) { w.at[sid * 2 + e] = t; w.adt[sid * 2 + e] = 0.0; }
       for (int q = lane; q < AE; q += 64) {
-        w.aX[(sid * 2 + e) * AE + q] = ((q / AEL) == (q % AEL)) ? x0 : 0.0;
+        const int i = q / AEL, j = q % AEL;
+        double v = 0.0;                                    // closed-form inverse of the arrow matrix
+        if (i <= m && j <= m) {
+          if (i == 0 && j == 0) v = t / gam;
+          else if (i == 0 || j == 0) v = -u / gam;
+          else v = ((i == j) ? 1.0 / t : 0.0) + u * u / (t * gam);
+        }
+        w.aX[(sid * 2 + e) * AE + q] = x0 * v;
         w.acor[(sid * 2 + e) * AE + q] = 0.0;
       }
     }
@@ -589,6 +620,7 @@ __global__ void __launch_bounds__(64) k_phi_update(WS w, Dims dm) {
   if (ip[I_PHASE] == PH_DONE) return;
   const double* pr = w.prob + (size_t)b * PS;
   const double ap = pr[P_AP], ad = pr[P_AD];
+  if (ap == 0.0 && ad == 0.0) return;      // discarded direction
   const PhiStage ps = phi_stage(w, dm, sid);
   for (int i = 0; i < ps.nrow; ++i) {
     w.phi[(size_t)sid * dm.nr + i] += ad * w.dphi[(size_t)sid * dm.nr + i];

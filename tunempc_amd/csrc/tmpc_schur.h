@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   const int tid = threadIdx.x;
   const int nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
   const int ldk = nx + 1;
+  // relative lift of the diagonal after an iteration whose factorisation froze pivots (k_ctrl_c): 1e-12
+  const int reg = ip[I_REG];
+  const double regf = (reg <= 0) ? 1.0 : 1.0 + 1e-13 * ((reg == 1) ? 10.0 : (reg == 2) ? 100.0 : 1000.0);
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // 12 matrices: [r][0..5] = Xxx, Sixx (stage k), Kx, Ks (stage k-1), Fx, Fs (stage k)
   double* mats = sm;
@@ -94,6 +97,7 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
         dv += hkm_entry(mr + KF_XXX * msz, mr + KF_SIXX * msz, ldk, a, bb, c, d_);
         dv += hkm_entry(mr + KF_KX * msz, mr + KF_KS * msz, ldk, a, bb, c, d_);
       }
+      if (row == col) dv *= regf;
       Dg[e] = dv;
       if (row == col) dd[row] = dv;
     }
@@ -297,6 +301,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
 #endif
     ap = fmin(1.0, TMPC_CENTER_DAMP * ap); ad = fmin(1.0, TMPC_CENTER_DAMP * ad);
   }
+  bool retry = false;
   // Numerical breakdown: frozen pivots in this iteration's Schur factorisation during the centering phase (cond(T) grows
   // like (tau/mu)^2 and reaches 1/eps near the default mu_t when H is badly scaled) or in two main-phase iterations in
   // a row, or two iterations in a row whose step lengths collapse.  The direction is then worthless: keep the last iterate (it is a strictly feasible point
@@ -307,21 +312,33 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     const bool froze = ip[I_NSHIFT] != ip[I_SHIFT0];
     ip[I_JAM] = jam ? ip[I_JAM] + 1 : 0;
     ip[I_SHIFTRUN] = froze ? ip[I_SHIFTRUN] + 1 : 0;
-    if ((phase == PH_CENTER && froze) || ip[I_SHIFTRUN] >= 2 || ip[I_JAM] >= 2) {
+    // a direction that is not finite (a cascade of frozen pivots can overflow the fill row) is a breakdown as well
+    const bool nonfin = !(fabs(dtau) < 1e300) || !(fabs(dalpha) < 1e300) || !(ap == ap) || !(ad == ad) || !(dh2 == dh2);
+    if ((froze || nonfin) && ip[I_REG] < 1) {
+      // first answer to frozen pivots: discard this direction, lift the Schur diagonal by 1e-12 relative
+      // from now on and repeat the iteration from the same iterate -- the matrix sits within ~1e-13 (diagonally scaled) of
+      // singular near mu_t, and e.g. the stage-local elimination of an active multiplier (tmpc_phi.h) can use that margin up.
+      // (Larger lifts were tried: they damp the weakest eigen-direction, centering turns linear and a lockstep batch waits.)
+      ip[I_REG] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
+      ap = 0.0; ad = 0.0; retry = true;
+    } else if ((phase == PH_CENTER && froze) || ip[I_SHIFTRUN] >= 2 || ip[I_JAM] >= 2 || nonfin) {
       ap = 0.0; ad = 0.0;
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
     }
   }
+  const bool stopped = (ip[I_PHASE] == PH_DONE) || retry;
   // relative first-order change of the output Hc (the quantity the parity gate measures) in this step
-  pr[P_STEPN] = sqrt(dh2 / m2);
+  if (!stopped) pr[P_STEPN] = sqrt(dh2 / m2);
   pr[P_AP] = ap; pr[P_AD] = ad;
   if (w.trace && ip[I_ITERS] >= 1 && ip[I_ITERS] <= TRACE_LEN) {
     double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
     t[0] = (double)ip[I_ITERS]; t[1] = (double)phase; t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
     t[6] = ap; t[7] = ad; t[8] = pr[P_STEPN]; t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
   }
-  pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
-  pr[P_TAU] += ad * dtau; pr[P_ALPHA] += ad * dalpha;
+  if (!stopped) {        // (0 * NaN would poison the kept iterate)
+    pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
+    pr[P_TAU] += ad * dtau; pr[P_ALPHA] += ad * dalpha;
+  }
 }
 
 // after k_update: termination of the centering phase; recount active problems
@@ -339,6 +356,9 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     if (full && (stepn < o.center_tol || est < 0.1 * o.center_tol)) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+    // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting there is
+    // nothing more to gain (and the rest of a lockstep batch is waiting)
+    else if (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     pr[P_PREVSTEPN] = full ? stepn : -1.0;
   }
   if (ip[I_PHASE] != PH_DONE) atomicAdd(w.active, 1);

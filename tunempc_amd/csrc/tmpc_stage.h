@@ -417,6 +417,7 @@ __global__ void __launch_bounds__(64) k_update(WS w, Dims dm) {
   if (ip[I_PHASE] == PH_DONE) return;
   const double* pr = w.prob + (size_t)b * PS;
   const double ap = pr[P_AP], ad = pr[P_AD];
+  if (ap == 0.0 && ad == 0.0) return;      // discarded direction (it may hold NaN: 0 * NaN would poison the iterate)
   const size_t o = (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) {
     const int i = e / n, j = e - i * n;
