@@ -52,6 +52,66 @@ def test_sharded_all_gather_matches_serial():
         assert list(st) == [r['status'] for r in ref]
 
 
+def _worker_step2(rank, world, port, nb, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import convexify_oracle as co
+    from tunempc_amd.dist import convexify_batch_sharded
+    A, B, H, G, C, ncnt = _step2_batch(co, nb)
+
+    def solve_fn(a, b, h, G, C, ncnt):
+        Hc, F, kap = [], [], []
+        for i in range(a.shape[0]):
+            Cl = [C[i, k, :ncnt[i, k]].numpy() if ncnt[i, k] else None for k in range(a.shape[1])]
+            r = co.sdp_step1(a[i].numpy(), b[i].numpy(), h[i].numpy(), G=G[i].numpy(), C=Cl, rho=1e-2)
+            dHc = co.convex_hessian_suppl(a[i].numpy(), b[i].numpy(), r['P'], G=G[i].numpy(), Fg=r['Fg'], C=Cl, F=r['F'])[0]
+            Fp = np.zeros(tuple(C.shape[1:3]))
+            for k, f in enumerate(r['F']):
+                if f is not None:
+                    Fp[k, :len(f)] = f
+            Hc.append(h[i].numpy() + dHc); F.append(Fp); kap.append(r['kappa'])
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float64)
+        return dict(Hc=torch.from_numpy(np.stack(Hc)) if Hc else z(0, *h.shape[1:]), F=torch.from_numpy(np.stack(F)) if F else z(0, *C.shape[1:3]),
+                    kappa=torch.tensor(kap, dtype=torch.float64))
+
+    g = convexify_batch_sharded(A, B, H, solve_fn, keys=('Hc', 'F', 'kappa'), extra=dict(G=G, C=C, ncnt=ncnt))
+    ret[rank] = (g['Hc'].numpy(), g['F'].numpy(), g['kappa'].numpy())
+    dist.destroy_process_group()
+
+
+def _step2_batch(co, nb, p=2, nx=3, mb=1, ng=1, nc=2):
+    A, B, H = (torch.from_numpy(x) for x in co.gen_batch(30, nb, p, nx, mb))
+    rng = np.random.default_rng(7)
+    G = torch.from_numpy(rng.standard_normal((nb, p, ng, nx + mb)))
+    C = rng.standard_normal((nb, p, nc, nx + mb)); ncnt = rng.integers(0, nc + 1, size=(nb, p))
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, ncnt[b, k]:] = 0.0
+    return A, B, H, G, torch.from_numpy(C), torch.from_numpy(ncnt)
+
+
+def test_sharded_step2_inputs_travel_with_their_problems():
+    """The Jacobians and row counts of Step 2 are per-problem inputs: they shard with the batch, the multipliers gather with Hc."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import convexify_oracle as co
+    nb, world = 3, 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_step2, args=(world, port, nb, ret), nprocs=world, join=True)
+    A, B, H, G, C, ncnt = _step2_batch(co, nb)
+    for b in range(nb):
+        Cl = [C[b, k, :ncnt[b, k]].numpy() if ncnt[b, k] else None for k in range(A.shape[1])]
+        r = co.sdp_step1(A[b].numpy(), B[b].numpy(), H[b].numpy(), G=G[b].numpy(), C=Cl, rho=1e-2)
+        for rank in range(world):
+            Hc, F, kap = ret[rank]
+            assert Hc.shape[0] == nb and abs(kap[b] - r['kappa']) < 1e-12 * r['kappa']
+            for k, f in enumerate(r['F']):
+                if f is not None:
+                    np.testing.assert_allclose(F[b, k, :len(f)], f, rtol=0, atol=1e-12)
+
+
 def test_shard_range_partitions():
     from tunempc_amd.dist import shard_range
     for nb in (1, 7, 512, 4096):

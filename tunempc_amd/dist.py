@@ -34,13 +34,15 @@ def all_gather_results(local, nb_total, group=None):
     return out
 
 
-def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status')):
+def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status'), extra=None):
     """A, B, H: full-batch torch tensors (every rank holds or can generate the full batch; only its slice is
-    read).  solve_fn(A_loc, B_loc, H_loc) -> dict of torch tensors (local batch leading).  Returns the
-    gathered dict (full batch on every rank)."""
+    read).  solve_fn(A_loc, B_loc, H_loc, **extra_loc) -> dict of torch tensors (local batch leading).  `extra`: dict of
+    further per-problem inputs sliced the same way -- the equality-/active-constraint Jacobians and row counts of
+    Step 1 with G and of Step 2 (G [nb,p,ng,n], C [nb,p,nc,n], ncnt [nb,p]).  Returns the gathered dict (full batch on
+    every rank); add 'Fg' / 'F' to `keys` to gather the multipliers as well."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nb = A.shape[0]
     lo, hi = shard_range(nb, rank, world)
-    loc = solve_fn(A[lo:hi], B[lo:hi], H[lo:hi])
+    loc = solve_fn(A[lo:hi], B[lo:hi], H[lo:hi], **{k: v[lo:hi] for k, v in (extra or {}).items()})
     return all_gather_results({k: loc[k] for k in keys}, nb, group)
