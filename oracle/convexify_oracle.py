@@ -55,19 +55,21 @@ def build_hessian(Q, R, N):
 
 
 def input_checks(arg):
-    """preprocessing.py:157-185 (same assertion messages)."""
-    msg1 = "Input arguments should be of same type!"
-    assert all(type(a) == type(arg['A']) for a in arg.values()), msg1
-    if type(arg['A']) == list:
-        msg2 = "Input data lists should have same length!"
-        assert all(len(a) == len(arg['A']) for a in arg.values()), msg2
+    """Behaviour of preprocessing.py:157-185: all entries lists of equal length or all bare matrices (then wrapped in
+    one-element lists); constant shape along the trajectory for every key but the ragged 'C'.  Same three messages."""
+    kind = type(arg['A'])
+    for value in arg.values():
+        assert type(value) == kind, "Input arguments should be of same type!"                      # :167
+    if kind is list:
+        for value in arg.values():
+            assert len(value) == len(arg['A']), "Input data lists should have same length!"         # :171
     else:
-        for key in list(arg.keys()):
+        for key in tuple(arg):
             arg[key] = [arg[key]]
-    msg3 = "Data matrices should have same size along trajectory."
-    for key, a in arg.items():
+    for key, stages in arg.items():
         if key != 'C':
-            assert all(np.shape(m) == np.shape(a[0]) for m in a), msg3
+            for m in stages:
+                assert np.shape(m) == np.shape(stages[0]), "Data matrices should have same size along trajectory."   # :178
     return arg
 
 
