@@ -114,6 +114,14 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nb, const double* A, con
                                     const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);
 
+/* Device-resident form of the two entries above (inputs and outputs in HBM, work queued on `stream`): d_ncnt == NULL is Step 1
+ * with G (dJ = G [nb][p][ng][n], FgF [nb][p][ng]); otherwise the Step 2 model (dJ [nb][p][ng+nc][n], d_ncnt [nb][p] with
+ * 0 <= ncnt <= nc -- not checked here --, FgF [nb][p][ng+nc]). */
+int tmpc_convexify_con_batch_device(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, const double* dJ,
+                                    const int32_t* d_ncnt, double rho, double* dHc_out, double* ddHc_out, double* dP_out, double* dFgF,
+                                    double* d_alpha, double* d_beta, double* d_kappa, int32_t* d_status, int32_t* d_iters,
+                                    double* d_info, void* stream);
+
 /* convexHessianSuppl (convexifier.py:165-211) alone: dHc_k = sym(V_k' P_{k+1} V_k - E' P_k E). */
 int tmpc_supplement_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* P, double* dHc);
 /* The same with the constraint and regularisation terms of convexifier.py:196-204:

@@ -380,6 +380,24 @@ def test_step2_golden_vectors(hc, golden_dir, name):
             assert np.linalg.norm(out['FgF'][b][:, :ng] - g['Fg'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['Fg'][b]))
 
 
+def test_device_resident_constraint_entries_match_host_entries(hc):
+    """tmpc_convexify_con_batch_device (torch tensors in HBM) == the host-buffer entries, for Step 1 with G and for Step 2."""
+    import torch
+    A, B, H, G, C, ncnt = _step2_inputs(7, 3, 5, 4, 2, 3, [0, 3, 1, 2, 3])
+    J = np.concatenate([G, C], axis=2)
+    h = hc(5, 4, 2, ng=3, nc=C.shape[2])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ref = h.convexify_eq_batch(A, B, H, G)
+    dev = h.convexify_con_batch_device(t(A), t(B), t(H), t(G))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dev['Hc'].cpu().numpy(), ref['Hc']); np.testing.assert_array_equal(dev['FgF'].cpu().numpy(), ref['Fg'])
+    ref = h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    dev = h.convexify_con_batch_device(t(A), t(B), t(H), t(J), ncnt=t(ncnt), rho=1e-2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dev['Hc'].cpu().numpy(), ref['Hc']); np.testing.assert_array_equal(dev['FgF'].cpu().numpy(), ref['FgF'])
+    np.testing.assert_array_equal(dev['status'].cpu().numpy(), ref['status'])
+
+
 def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
     """convexify(..., C=...) on the dense model's vector (B = 0, R < 0): Step 1 infeasible -> Step 2 -> EQUIVALENCE TYPE B;
     without C the reference's ValueError; force asks for Step 3, which this build does not have."""

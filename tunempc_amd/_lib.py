@@ -21,7 +21,7 @@ EXPORTS = [
     'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
     'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_workspace_bytes_eq', 'tmpc_create_eq', 'tmpc_convexify_eq_batch_host',
-    'tmpc_debug_get_multipliers', 'tmpc_debug_get_array', 'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
+    'tmpc_convexify_con_batch_device', 'tmpc_debug_get_multipliers', 'tmpc_debug_get_array', 'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 
@@ -63,6 +63,8 @@ def load_library():
     lib.tmpc_debug_get_multipliers.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     lib.tmpc_debug_get_array.restype = C.c_int
     lib.tmpc_debug_get_array.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, dp]
+    lib.tmpc_convexify_con_batch_device.restype = C.c_int
+    lib.tmpc_convexify_con_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_double] + [vp] * 10 + [vp]
     lib.tmpc_create.restype = C.c_int
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
@@ -238,6 +240,30 @@ class HipConvexifier:
                                                   ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']),
                                                   ptr(out['iters']), ptr(out['info']), C.c_void_p(st))
         _check(self.lib, rc, 'tmpc_convexify_batch_device')
+        return out
+
+    def convexify_con_batch_device(self, A, B, H, J, ncnt=None, rho=0.0, stream=None):
+        """Device-resident Step 1 with G (ncnt None, J = G [nb,p,ng,n]) or Step 2 model (J [nb,p,ng+nc,n], ncnt [nb,p] int32):
+        torch CUDA tensors in, torch tensors out (the dict of convexify_batch_device plus 'FgF')."""
+        import torch
+        nb = A.shape[0]
+        for t in (A, B, H, J):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        assert ncnt is None or (ncnt.is_cuda and ncnt.dtype == torch.int32 and ncnt.is_contiguous())
+        nr = self.ng if ncnt is None else self.ng + self.nc
+        assert tuple(J.shape) == (nb, self.p, nr, self.n), (tuple(J.shape), nr)
+        dev = A.device
+        f64 = lambda *sh: torch.empty(sh, dtype=torch.float64, device=dev)
+        out = dict(Hc=torch.empty_like(H), dHc=torch.empty_like(H), P=torch.empty_like(A), FgF=f64(nb, self.p, nr), alpha=f64(nb), beta=f64(nb),
+                   kappa=f64(nb), status=torch.empty(nb, dtype=torch.int32, device=dev), iters=torch.empty(nb, dtype=torch.int32, device=dev),
+                   info=f64(nb, INFO_STRIDE))
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        rc = self.lib.tmpc_convexify_con_batch_device(self._h, nb, ptr(A), ptr(B), ptr(H), ptr(J), ptr(ncnt) if ncnt is not None else None,
+                                                      float(rho), ptr(out['Hc']), ptr(out['dHc']), ptr(out['P']), ptr(out['FgF']),
+                                                      ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']),
+                                                      ptr(out['iters']), ptr(out['info']), C.c_void_p(st))
+        _check(self.lib, rc, 'tmpc_convexify_con_batch_device')
         return out
 
     def supplement_batch(self, A, B, P):

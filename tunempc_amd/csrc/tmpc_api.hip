@@ -560,6 +560,31 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nbt, const double* dA, const
   return TMPC_OK;
 }
 
+int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH, const double* dJ,
+                                    const int32_t* d_ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
+                                    double* beta, double* kappa, int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (!h || nbt < 1 || !dA || !dH || !dJ || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  const Dims& dm = h->dm;
+  if (d_ncnt ? (dm.nz <= dm.nr || !(rho > 0.0)) : dm.ng < 1) {
+    snprintf(g_err, sizeof(g_err), "handle has no room for this call (Step 2 needs tmpc_create_con with nc > 0 and rho > 0, Step 1 with G needs ng > 0)");
+    return TMPC_E_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nr = d_ncnt ? dm.nr : dm.ng;           // row stride of J and FgF in this call
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
+  for (int off = 0; off < nbt; off += dm.B) {
+    const int nb = std::min(dm.B, nbt - off);
+    const size_t o = (size_t)off * dm.p;
+    int rc = run_chunk(h, nb, dA + o * nxx, dB ? dB + o * dm.nx * dm.mb : nullptr, dH + o * nn, st, dJ + o * nr * dm.n,
+                       d_ncnt ? d_ncnt + o : nullptr, rho);
+    if (rc != TMPC_OK) return rc;
+    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToDevice, st);
+    if (rc != TMPC_OK) return rc;
+    if (FgF) HIPCHK(hipMemcpyAsync(FgF + o * nr, h->ws.Fg, (size_t)nb * dm.p * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  return TMPC_OK;
+}
+
 int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H,
                               double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
                               int32_t* status, int32_t* iters, double* info) {
