@@ -398,6 +398,24 @@ def test_device_resident_constraint_entries_match_host_entries(hc):
     np.testing.assert_array_equal(dev['status'].cpu().numpy(), ref['status'])
 
 
+def test_step_logic_for_a_batch(golden_dir):
+    """convexify_steps_batch: Step 1 for all, Step 2 only for the members Step 1 cannot convexify (here the dense model's vector,
+    B = 0 and R < 0), next to a member that Step 1 solves and one that is already convex."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(golden_dir, 'n1_step2_active_constraints.npz'))
+    p, nx = g['A'].shape[0], g['A'].shape[1]
+    Hr = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
+    A1, B1, H1 = co.gen_batch(0, 2, p, nx, g['B'].shape[2])                # member 0 (seed 0): indefinite, Step 1 suffices
+    A = np.stack([A1[0], g['A'], A1[1]]); B = np.stack([B1[0], g['B'], B1[1]]); H = np.stack([H1[0], Hr, np.stack([np.eye(nx + 1)] * p)])
+    C = np.stack([g['Cu']] * 3); ncnt = np.full((3, p), g['Cu'].shape[1], np.int32)
+    out = convexifier.convexify_steps_batch(A, B, H, C=C, ncnt=ncnt, rho=float(g['rho']))
+    assert list(out['step']) == [1, 2, 0] and list(out['status']) == [0, 0, 0]
+    r0 = co.convexify_arrays(A[0], B[0], H[0])
+    r1 = co.convexify_arrays(A[1], B[1], H[1], C=[c for c in g['Cu']], rho=float(g['rho']))
+    assert rel(out['Hc'][0], r0['Hc']) < PARITY and rel(out['Hc'][1], r1['Hc']) < PARITY and r1['step'] == 2
+    assert not out['F'][0].any() and not out['F'][2].any() and (out['F'][1] > 0).all() and not out['dHc'][2].any()
+
+
 def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
     """convexify(..., C=...) on the dense model's vector (B = 0, R < 0): Step 1 infeasible -> Step 2 -> EQUIVALENCE TYPE B;
     without C the reference's ValueError; force asks for Step 3, which this build does not have."""
