@@ -503,6 +503,46 @@ def test_full_size_c4_properties(hc):
     assert (again['info'][:, 13] == 1).all() and not again['dHc'].any()
 
 
+def test_full_size_step2_properties(hc):
+    """The Step 2 model and Step 1 with G at the benchmark stage size and period (nx=24, m=8, p=64; the oracle needs minutes
+    there): size-independent properties -- every member converges, Hc positive definite, cond(Hc_k) <= kappa, the supplement is
+    exactly calH(P) + G' diag(Fg) G + C' diag(F) C for the returned (P, Fg, F), multipliers >= 0 and zero in the padding, the extra
+    freedom can only lower kappa, and a larger rho can only raise it.  (At p = 64 the first start point of the norm terms made
+    this model diverge while every small parity case passed.)"""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb, ng, nc = 64, 24, 8, 4, 2, 4
+    n = nx + mb
+    A, B, H = synthetic.gen_batch(777, nb, p, nx, mb)
+    rng = np.random.default_rng(3)
+    G = rng.standard_normal((nb, p, ng, n)); C = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, ncnt[b, k]:] = 0.0
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    plain = h.convexify_batch(A, B, H)
+    eq = h.convexify_eq_batch(A, B, H, G)
+    kap = {}
+    for rho in (1e-3, 1.0):
+        out = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, rho)
+        assert (out['status'] == 0).all() and out['iters'].max() <= 30
+        kap[rho] = out['kappa']
+        for b in range(nb):
+            ev = np.linalg.eigvalsh(out['Hc'][b])
+            assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-8)
+            Fo = out['FgF'][b]
+            assert (Fo >= 0).all() and all(not Fo[k, ng + ncnt[b, k]:].any() for k in range(p))
+            Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+            Fl = [Fo[k, ng:ng + ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+            ref = co.convex_hessian_suppl(A[b], B[b], out['P'][b], G=G[b], Fg=Fo[:, :ng], C=Cl, F=Fl)[0]
+            assert rel(out['Hc'][b] - H[b], ref) < 1e-10
+    assert (eq['status'] == 0).all() and (eq['kappa'] <= plain['kappa'] * (1 + 1e-9)).all()
+    assert (kap[1e-3] <= kap[1.0] * (1 + 1e-7)).all()
+    for b in range(nb):
+        ref = co.convex_hessian_suppl(A[b], B[b], eq['P'][b], G=G[b], Fg=eq['Fg'][b])[0]
+        assert rel(eq['Hc'][b] - H[b], ref) < 1e-10 and (eq['Fg'][b] >= 0).all()
+
+
 # ----------------------------------------------------------------------------- consumer row: tracking reference
 @pytest.mark.parametrize('n,ns', [(4, 1), (5, 30), (15, 40), (32, 257)])
 def test_tracking_reference_parity(hc, n, ns):
