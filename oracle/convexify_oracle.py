@@ -295,7 +295,7 @@ def _arrow_start(a, m, mu):
     return a + 0.5 * (lo + hi)
 
 
-def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None):
+def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None, force=False):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
     constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
     convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags.
@@ -305,7 +305,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     C (list of p entries, (nc_k x n) or None) together with rho: Step 2 (`constr=True`, convexifier.py:116-131): multipliers
     f_k = s*F_k >= 0 of the active constraints (:258-266, term :348-350) and the objective terms rho*||F_k||, rho*||Fg_k||
     (:276-283), each norm as an epigraph variable t with the arrow LMI [[t, w v'], [w v, t I]] >> 0 and w = rho*sbeta/s (the
-    objective is tau = sbeta*beta plus the sum of the t).  All of them are stage-local border columns as well."""
+    objective is tau = sbeta*beta plus the sum of the t).  All of them are stage-local border columns as well.
+    force (with rho): Step 3 (convexifier.py:137-147): T_k symmetric with every entry > 0 (:269-273), term s_T*T_k in HcE_k
+    (:352-353) and rho*||T_k||_F in the objective (:284-285).  The n(n+1)/2 free entries of T_k are further stage-local
+    multipliers whose "row" is the basis matrix E_ab instead of g g'; the Frobenius norm weighs off-diagonal entries by sqrt(2)."""
     o = dict(DEFAULT_OPTS)
     if opts:
         o.update(opts)
@@ -334,43 +337,59 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     ng = 0                                                 # rows of [G_k; C_k] per stage (padded to the longest stage, `mask` = real rows)
     ng0 = 0                                                # of which equality-constraint rows
     constr = C is not None and rho is not None
+    force = bool(force) and rho is not None
+    nT = n * (n + 1) // 2 if force else 0                  # free entries of T_k (Step 3)
     ncs = [0] * p
     if constr:
         ncs = [0 if C[k] is None else np.atleast_2d(np.asarray(C[k], dtype=np.float64)).shape[0] for k in range(p)]
     if G is not None:
         G = np.asarray(G, dtype=np.float64)
         ng0 = G.shape[1]
-    ng = ng0 + max(ncs)
+    nJ = ng0 + max(ncs)                                    # rows of [G_k; C_k]
+    ng = nJ + nT
     arrows = []                                            # epigraph blocks: dict(k, idx (rows of stage k), t, X)
     if ng:
-        J = np.zeros((p, ng, n)); mask = np.zeros((p, ng), dtype=bool)
+        J = np.zeros((p, nJ, n)); mask = np.zeros((p, ng), dtype=bool)
         if ng0:
             J[:, :ng0] = G; mask[:, :ng0] = True
         for k in range(p):
             if ncs[k]:
                 J[k, ng0:ng0 + ncs[k]] = np.atleast_2d(np.asarray(C[k], dtype=np.float64)); mask[k, ng0:ng0 + ncs[k]] = True
-        G = J
-        GG = G[:, :, :, None] * G[:, :, None, :]           # [p, ng, n, n]: g g' per constraint row
+        GG = np.zeros((p, ng, n, n))                       # direction matrix of every multiplier: g g' per constraint row, E_ab per entry of T_k
+        GG[:, :nJ] = J[:, :, :, None] * J[:, :, None, :]
+        cw = np.ones(ng)                                   # weight under the norm term
+        if nT:
+            ta, tb = np.triu_indices(n)
+            for q in range(nT):
+                GG[:, nJ + q, ta[q], tb[q]] = 1.0; GG[:, nJ + q, tb[q], ta[q]] = 1.0
+            cw[nJ:] = np.where(ta == tb, 1.0, np.sqrt(2.0))
+            mask[:, nJ:] = True
         # slack of phi >= 0 is phi itself, z its multiplier.  Start: phi_i = min(1, 1/|g_i|^2), so that the term g_i' phi_i g_i
         # is O(1) whatever the scaling of the Jacobian rows, and z_i = x0/phi_i on the central path (two iterations fewer on
         # average than phi = 1, and no 25+-iteration stragglers with rows of norm 5)
-        g2 = np.maximum(np.sum(G * G, axis=2), 1e-300)
+        g2 = np.maximum(np.sqrt(np.sum(GG * GG, axis=(2, 3))), 1e-300)        # |g g'|_F = |g|^2
         phi = np.where(mask, np.minimum(1.0, 1.0 / g2), 1.0)
         z = np.where(mask, x0 / phi, 0.0)
         N = N + int(mask.sum())
-        if constr:
+        if constr or force:
             wr = rho * sbeta / s
             for k in range(p):
-                for idx in ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else []):
+                blocks = []
+                if constr:
+                    blocks = ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else [])
+                if nT:
+                    blocks.append(nJ + np.arange(nT))
+                for idx in blocks:
                     m = len(idx)
+                    w2 = float(np.sum(cw[idx] ** 2))               # = m for the unweighted norms of Step 2
                     # start ON the central path of the norm term: multipliers z_i = w/sqrt(m) (the gradient of w||phi|| at equal
                     # phi_i: their stationarity residual vanishes), phi_i = x0/z_i (<= 1), X = x0 S^-1 with tr X = 1 (the cost of t),
                     # i.e. S within delta ~ x0 of the cone boundary.  (phi = 1, X = x0 I, S = O(1) leaves residuals ~ 1 per norm
                     # term; with 2p terms the first Newton steps blow mu up by three orders of magnitude and the iteration diverges.)
-                    ph = min(1.0, x0 * np.sqrt(m) / wr)
+                    ph = min(1.0, x0 * np.sqrt(w2) / wr)
                     phi[k, idx] = ph; z[k, idx] = x0 / ph
-                    t0 = _arrow_start(wr * ph * np.sqrt(m), m, x0)
-                    arrows.append(dict(k=k, idx=idx, t=t0, X=x0 * np.linalg.inv(_arrow(t0, phi[k, idx], wr))))
+                    t0 = _arrow_start(wr * ph * np.sqrt(w2), m, x0)
+                    arrows.append(dict(k=k, idx=idx, t=t0, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
     phase = 0
@@ -390,7 +409,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         Rd2 = (tau * I - M) - S2
         rd0 = (alpha - ALPHA_MIN) - s0
         for a in arrows:
-            a['S'] = _arrow(a['t'], phi[a['k'], a['idx']], wr)
+            a['S'] = _arrow(a['t'], cw[a['idx']] * phi[a['k'], a['idx']], wr)
         mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0) + sum(np.sum(a['X'] * a['S']) for a in arrows)) / N
         Y = X1 - X2
         r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
@@ -400,7 +419,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         if ng:
             r_phi = -np.einsum('kiab,kab->ki', GG, Y) - z
             for a in arrows:                                   # the arrow LMI holds 2 w phi_i off the diagonal; its own variable t has cost 1
-                r_phi[a['k'], a['idx']] -= 2.0 * wr * a['X'][0, 1:]
+                r_phi[a['k'], a['idx']] -= 2.0 * wr * cw[a['idx']] * a['X'][0, 1:]
                 r_phi2 += (1.0 - np.trace(a['X'])) ** 2
             r_phi2 += np.sum((r_phi * mask) ** 2)
         pinf = np.sqrt(r_tau ** 2 + r_alpha ** 2 + np.sum(_svec_grad(r_P, ia, ib) ** 2) + r_phi2) / 2.0
@@ -466,9 +485,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
               U = np.concatenate([U, np.zeros((p, d, len(arrows)))], axis=2)       # the epigraph variables do not reach P
               nb_ = 2 + p * ng + len(arrows)
               Bfull = np.zeros((nb_, nb_)); Bfull[:2, :2] = Bb
-              GXG1 = G @ X1 @ np.swapaxes(G, 1, 2); GSG1 = G @ S1i @ np.swapaxes(G, 1, 2)     # [p,ng,ng]
-              GXG2 = G @ X2 @ np.swapaxes(G, 1, 2); GSG2 = G @ S2i @ np.swapaxes(G, 1, 2)
-              Bpp = GXG1 * np.swapaxes(GSG1, 1, 2) + GXG2 * np.swapaxes(GSG2, 1, 2)             # <g_i g_i', Phi(g_j g_j')>
+              Bpp = np.einsum('kvab,kwab->kvw', GG, W)                                           # <A_v, Phi(A_w)>  (= (g_v'X g_w)(g_w'S^-1 g_v) summed over the two LMIs for rows)
               c_tau = -np.einsum('kiab,kab->ki', GG, Psi)                                        # <g g', -Psi_k>
               c_alpha = np.einsum('kiab,kab->ki', GG, PhiH)
               for k in range(p):
@@ -484,10 +501,11 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                   cols = 2 + a['k'] * ng + a['idx']
                   m = len(a['idx'])
                   for q in range(m):
-                      Eq = np.zeros((m + 1, m + 1)); Eq[0, q + 1] = wr; Eq[q + 1, 0] = wr
-                      Bfull[cols[q], te] = Bfull[te, cols[q]] = 2.0 * wr * Pe[0, q + 1]
+                      wq = wr * cw[a['idx'][q]]
+                      Eq = np.zeros((m + 1, m + 1)); Eq[0, q + 1] = wq; Eq[q + 1, 0] = wq
+                      Bfull[cols[q], te] = Bfull[te, cols[q]] = 2.0 * wq * Pe[0, q + 1]
                       Fq = symmetrize(a['X'] @ Eq @ a['Si'])
-                      Bfull[cols, cols[q]] += 2.0 * wr * Fq[0, 1:]
+                      Bfull[cols, cols[q]] += 2.0 * wr * cw[a['idx']] * Fq[0, 1:]
               Bb = Bfull
           TU = chol.solve(U)
           Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
@@ -509,7 +527,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 rt = np.zeros(len(arrows))
                 for e, a in enumerate(arrows):
                     a['T'] = sig_mu * a['Si'] - (corre[e] if corre is not None else 0.0)
-                    rph[a['k'], a['idx']] += 2.0 * wr * a['T'][0, 1:]
+                    rph[a['k'], a['idx']] += 2.0 * wr * cw[a['idx']] * a['T'][0, 1:]
                     rt[e] = np.trace(a['T']) - 1.0
                 rbv = np.concatenate([rbv, (rph * mask).ravel(), rt])
             rb = rbv - np.einsum('kdi,kd->i', U, zsol)
@@ -523,7 +541,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
                 for e, a in enumerate(arrows):
                     a['dt'] = db[2 + p * ng + e]
-                    a['dS'] = _arrow(a['dt'], dphi[a['k'], a['idx']], wr)
+                    a['dS'] = _arrow(a['dt'], cw[a['idx']] * dphi[a['k'], a['idx']], wr)
                     a['dX'] = sig_mu * a['Si'] - a['X'] - symmetrize(a['X'] @ a['dS'] @ a['Si']) - (corre[e] if corre is not None else 0.0)
             dS1 = dM + Rd1
             dS2 = dtau * I - dM + Rd2
@@ -619,13 +637,18 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         out['Fg'] = phi[:, :ng0] / (s * alpha)          # convexifier.py:410 (s_F = s_alpha = s)
     if constr:
         out['F'] = [phi[k, ng0:ng0 + ncs[k]] / (s * alpha) if ncs[k] else None for k in range(p)]     # convexifier.py:415-420
-        out['objective'] = tau / sbeta + sum(a['t'] for a in arrows) / sbeta       # beta + sum rho ||F_k|| (+ rho ||Fg_k||)
+    if nT:
+        Tm = np.zeros((p, n, n))
+        Tm[:, ta, tb] = phi[:, nJ:] / (s * alpha); Tm[:, tb, ta] = phi[:, nJ:] / (s * alpha)            # convexifier.py:422-423 (s_T = s_alpha = s)
+        out['T'] = Tm
+    if constr or nT:
+        out['objective'] = tau / sbeta + sum(a['t'] for a in arrows) / sbeta       # beta + sum rho ||F_k|| (+ rho ||Fg_k||) (+ rho ||T_k||_F)
     return out
 
 
-def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None, C=None, F=None):
+def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None, C=None, F=None, T=None):
     """convexifier.py:403-456 (status rule :442-451)."""
-    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P, G=G, Fg=Fg, C=C, F=F)
+    dHc, dQc, dRc, dNc = convex_hessian_suppl(A, B, P, G=G, Fg=Fg, C=C, F=F, T=T)
     Hc = H + dHc
     ev = np.linalg.eigvalsh(Hc)
     min_eig = ev.min(); max_cond = (ev[:, -1] / ev[:, 0]).max() if min_eig > 0 else np.inf
@@ -636,10 +659,11 @@ def check_convergence(A, B, H, P, ipm_status, G=None, Fg=None, C=None, F=None):
     return st, dHc, dQc, dRc, dNc, min_eig, max_cond
 
 
-def convexify_arrays(A, B, H, opts=None, verbose=False, G=None, C=None, rho=1e-3):
-    """Array-level restatement of convexifier.convexify, Steps 1 and 2 (optional equality-constraint term G [p,ng,n]; C: list of
-    p active-constraint Jacobians (nc_k x n) or None, used by Step 2 when Step 1 is infeasible, convexifier.py:116-131):
-    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, step, dHc, Hc, P, alpha, beta, kappa, iters, early_exit[, Fg][, F])."""
+def convexify_arrays(A, B, H, opts=None, verbose=False, G=None, C=None, rho=1e-3, force=False):
+    """Array-level restatement of convexifier.convexify, Steps 1 to 3 (optional equality-constraint term G [p,ng,n]; C: list of
+    p active-constraint Jacobians (nc_k x n) or None, used by Step 2 when Step 1 is infeasible, convexifier.py:116-131; force:
+    Step 3 when the problem is still infeasible, :137-147):
+    A [p,nx,nx], B [p,nx,mb], H [p,n,n] -> dict(status, step, dHc, Hc, P, alpha, beta, kappa, iters, early_exit[, Fg][, F][, T])."""
     A = np.asarray(A, float); B = np.asarray(B, float); H = symmetrize(np.asarray(H, float))
     p, nx, _ = A.shape
     n = H.shape[1]
@@ -655,11 +679,17 @@ def convexify_arrays(A, B, H, opts=None, verbose=False, G=None, C=None, rho=1e-3
         r = sdp_step1(A, B, H, opts, verbose, G=G, C=C, rho=rho)
         st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'], G=G, Fg=r.get('Fg'), C=C, F=r['F'])
         r.update(status=st, step=2, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond, iters_step1=it1)
+    if st == STATUS_INFEASIBLE and force:                  # Step 3 (eta_T = 1): convexifier.py:137-147, constr as left by the steps before
+        constr = r['step'] == 2
+        r = sdp_step1(A, B, H, opts, verbose, G=G, C=C if constr else None, rho=rho, force=True)
+        st, dHc, dQc, dRc, dNc, min_eig, max_cond = check_convergence(A, B, H, r['P'], r['ipm_status'], G=G, Fg=r.get('Fg'),
+                                                                      C=C if constr else None, F=r.get('F'), T=r['T'])
+        r.update(status=st, step=3, early_exit=False, dHc=dHc, Hc=H + dHc, min_eig=min_eig, max_cond=max_cond)
     return r
 
 
 def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
-    """Drop-in restatement of convexifier.convexify (convexifier.py:36-163), Steps 1 and 2 (Step 3: oracle/reference_sdp.py)."""
+    """Drop-in restatement of convexifier.convexify (convexifier.py:36-163), Steps 1 to 3."""
     arg = dict(A=A, B=B, Q=Q, R=R, N=N)
     if C is not None:
         arg['C'] = C
@@ -674,12 +704,10 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts=None):
     Cs = [None if c is None else np.atleast_2d(np.asarray(c, float)) for c in arg['C']] if 'C' in arg else None
     rho = (opts or {}).get('rho', 1e-3)
     sopts = {k: v for k, v in (opts or {}).items() if k not in ('rho', 'solver', 'force')} or None
-    res = convexify_arrays(As, Bs, Hs, sopts, G=Gs, C=Cs, rho=rho)
+    res = convexify_arrays(As, Bs, Hs, sopts, G=Gs, C=Cs, rho=rho, force=bool((opts or {}).get('force', False)))
     if res['early_exit']:
         return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))   # :85
-    if res['status'] == STATUS_INFEASIBLE:
-        if (opts or {}).get('force', False):
-            raise NotImplementedError('oracle: Step 3 lives in oracle/reference_sdp.py')
+    if res['status'] == STATUS_INFEASIBLE and not (opts or {}).get('force', False):
         raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
     dH = res['dHc']
     return ([dH[k] for k in range(len(dH))], [dH[k][:nx, :nx] for k in range(len(dH))],

@@ -172,3 +172,38 @@ def test_structured_oracle_takes_step2_when_step1_is_infeasible():
     out = co.convexify([a for a in g['A']], [b for b in g['B']], [q for q in g['Q']], [x for x in g['R']], [x for x in g['N']],
                        C=C, opts={'rho': float(g['rho'])})
     assert np.abs(np.stack(out[0]) - r['dHc']).max() == 0.0 and all(x[0, 0] > 0.5 for x in out[2])
+
+
+@pytest.mark.parametrize('seed,p,nx,nu,ng,ncs,rho', [(20, 3, 3, 2, 0, None, 1e-3), (0, 2, 2, 1, 1, [1, 0], 1.0), (30, 2, 3, 1, 0, [1, 1], 1e-3), (20, 1, 3, 1, 0, None, 1e-3)])
+def test_structured_oracle_step3_matches_dense_model(seed, p, nx, nu, ng, ncs, rho):
+    """Step 3 model (force=True, convexifier.py:269-273, :284-285, :352-353): T_k symmetric, every entry > 0, rho*||T_k||_F in
+    the objective, with and without the Step 2 terms.  The n(n+1)/2 entries of T_k are stage-local multipliers whose direction
+    is a basis matrix; the structured oracle and the dense restatement reach the same objective."""
+    A, B, H = co.gen_problem(seed, p, nx, nu)[:3]
+    rng = np.random.default_rng(seed + 5)
+    G = rng.standard_normal((p, ng, nx + nu)) if ng else None
+    C = [rng.standard_normal((c, nx + nu)) if c else None for c in ncs] if ncs else None
+    r = co.sdp_step1(A, B, H, G=G, C=C, rho=rho, force=True)
+    Q, R, N = _split(H, nx)
+    ref = rs.solve_step(list(A), list(B), Q, R, N, G=None if G is None else [g for g in G], C=C, rho=rho, constr=C is not None, force=True)
+    assert r['ipm_status'] == 'optimal' and ref['status'] == 'Optimal'
+    assert abs(r['objective'] / ref['objective'] - 1.0) < 1e-5
+    assert (r['T'] > 0).all() and np.abs(r['T'] - np.swapaxes(r['T'], 1, 2)).max() == 0.0
+    dHc = co.convex_hessian_suppl(A, B, r['P'], G=G, Fg=r.get('Fg'), C=C, F=r.get('F'), T=r['T'])[0]
+    ev = np.linalg.eigvalsh(H + dHc)
+    assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= r['kappa'] * (1 + 1e-8)
+
+
+def test_structured_oracle_takes_step3_when_forced():
+    """The dense model's vector: B = 0, R < 0, no constraints -> Steps 1 infeasible, force -> Step 3 (convexifier.py:137-147)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'n1_step3_force.npz'))
+    p = g['A'].shape[0]
+    H = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        co.convexify([a for a in g['A']], [b for b in g['B']], [q for q in g['Q']], [x for x in g['R']], [x for x in g['N']])
+    r = co.convexify_arrays(g['A'], g['B'], H, rho=float(g['rho']), force=True)
+    assert r['step'] == 3 == int(g['step']) and r['status'] == co.STATUS_OPTIMAL
+    assert abs(r['objective'] / float(g['objective']) - 1.0) < 2e-6 and abs(r['kappa'] / float(g['kappa']) - 1.0) < 1e-4
+    out = co.convexify([a for a in g['A']], [b for b in g['B']], [q for q in g['Q']], [x for x in g['R']], [x for x in g['N']],
+                       opts={'rho': float(g['rho']), 'force': True})
+    assert np.abs(np.stack(out[0]) - r['dHc']).max() == 0.0 and all(x[0, 0] > 0.5 for x in out[2])
