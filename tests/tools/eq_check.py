@@ -1,8 +1,8 @@
 """Step 1 with the equality-constraint term G on the GPU (tmpc_convexify_eq_batch_host) against the structured oracle.
-Usage: python scripts/eq_check.py   (needs a GPU; prints relative errors and iteration counts per case)."""
+Usage: python tests/tools/eq_check.py   (needs a GPU; prints relative errors and iteration counts per case)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from oracle import convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier
 

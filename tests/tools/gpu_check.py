@@ -1,7 +1,7 @@
 """First-contact GPU diagnostics: building blocks, then full solves vs the oracle.  Writes gpurun_out/gpu_check.log"""
 import os, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier, FLAG_NO_MFMA, FLAG_PROFILE

@@ -1,8 +1,8 @@
 """Step 2 (active-constraint multipliers + norm terms) on the GPU against the structured oracle.
-Usage: python scripts/step2_check.py   (needs a GPU)."""
+Usage: python tests/tools/step2_check.py   (needs a GPU)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from oracle import convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier
 

@@ -2,7 +2,7 @@
 solver-independent invariants (Hc > 0, cond <= kappa, supplement = calH(P) + G'FgG + C'FC, multipliers >= 0)."""
 import os, sys, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier
