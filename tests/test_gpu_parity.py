@@ -197,6 +197,15 @@ def test_parity_vs_oracle(hc, seed, nb, p, nx, mb):
             assert abs(out['info'][b, 0] - r['s']) < 1e-12 * r['s'] and abs(out['info'][b, 1] - r['sbeta']) < 1e-12 * r['sbeta']
 
 
+def test_empty_batch_returns_empty_outputs(hc):
+    h = hc(3, 3, 2, ng=1, nc=2)
+    z = lambda *sh: np.zeros(sh)
+    for out in (h.convexify_batch(z(0, 3, 3, 3), z(0, 3, 3, 2), z(0, 3, 5, 5)),
+                h.convexify_eq_batch(z(0, 3, 3, 3), z(0, 3, 3, 2), z(0, 3, 5, 5), z(0, 3, 1, 5)),
+                h.convexify_step2_batch(z(0, 3, 3, 3), z(0, 3, 3, 2), z(0, 3, 5, 5), z(0, 3, 3, 5), np.zeros((0, 3), np.int32), 1e-3)):
+        assert out['Hc'].shape == (0, 3, 5, 5) and out['status'].shape == (0,) and out['kappa'].shape == (0,)
+
+
 def test_scalar_fma_and_mfma_paths_agree(hc):
     A, B, H = co.gen_batch(11, 2, 6, 12, 4)
     h = hc(6, 12, 4)

@@ -163,6 +163,8 @@ class HipConvexifier:
         out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), alpha=np.empty(nb), beta=np.empty(nb),
                    kappa=np.empty(nb), status=np.empty(nb, np.int32), iters=np.empty(nb, np.int32),
                    info=np.empty((nb, INFO_STRIDE)))
+        if nb == 0:
+            return out          # empty batch: empty outputs, no device call (the C ABI rejects nb < 1)
         rc = self.lib.tmpc_convexify_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(out['Hc']), _dptr(out['dHc']),
                                                 _dptr(out['P']), _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
                                                 _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
@@ -181,6 +183,8 @@ class HipConvexifier:
         out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), Fg=np.empty((nb, self.p, self.ng)),
                    alpha=np.empty(nb), beta=np.empty(nb), kappa=np.empty(nb), status=np.empty(nb, np.int32),
                    iters=np.empty(nb, np.int32), info=np.empty((nb, INFO_STRIDE)))
+        if nb == 0:
+            return out          # empty batch: empty outputs, no device call (the C ABI rejects nb < 1)
         rc = self.lib.tmpc_convexify_eq_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(G), _dptr(out['Hc']),
                                                    _dptr(out['dHc']), _dptr(out['P']), _dptr(out['Fg']), _dptr(out['alpha']),
                                                    _dptr(out['beta']), _dptr(out['kappa']), _iptr(out['status']),
@@ -213,6 +217,8 @@ class HipConvexifier:
         out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), FgF=np.empty((nb, self.p, nr)),
                    alpha=np.empty(nb), beta=np.empty(nb), kappa=np.empty(nb), status=np.empty(nb, np.int32),
                    iters=np.empty(nb, np.int32), info=np.empty((nb, INFO_STRIDE)))
+        if nb == 0:
+            return out          # empty batch: empty outputs, no device call (the C ABI rejects nb < 1)
         rc = self.lib.tmpc_convexify_step2_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(J), _iptr(ncnt), float(rho),
                                                       _dptr(out['Hc']), _dptr(out['dHc']), _dptr(out['P']), _dptr(out['FgF']),
                                                       _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
