@@ -405,6 +405,9 @@ def test_device_resident_constraint_entries_match_host_entries(hc):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(dev['Hc'].cpu().numpy(), ref['Hc']); np.testing.assert_array_equal(dev['FgF'].cpu().numpy(), ref['FgF'])
     np.testing.assert_array_equal(dev['status'].cpu().numpy(), ref['status'])
+    # chunked Step 2 batches (3 problems through a 2-problem workspace) equal unchunked ones
+    part = hc(5, 4, 2, ng=3, nc=C.shape[2], chunk=2).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    np.testing.assert_array_equal(part['Hc'], ref['Hc']); np.testing.assert_array_equal(part['FgF'], ref['FgF'])
 
 
 def test_step_logic_for_a_batch(golden_dir):
