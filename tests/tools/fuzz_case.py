@@ -1,0 +1,45 @@
+"""Replays one case of parity_fuzz.py (same random stream) and prints the GPU traces and the oracle's of one member/model.
+Usage: python tests/tools/fuzz_case.py <case> <member> <model> [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import convexify_oracle as co
+from tunempc_amd._lib import HipConvexifier
+want, bsel, model = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+rng = np.random.default_rng(int(sys.argv[4]) if len(sys.argv) > 4 else 2024)
+for case in range(want + 1):
+    p = int(rng.integers(1, 13)); nx = int(rng.integers(1, 9)); mb = int(rng.integers(1, 5))
+    n = nx + mb
+    ng = int(rng.integers(1, 4)); nc = int(rng.integers(1, 5))
+    seed = int(rng.integers(0, 10 ** 6))
+    nb = 3
+    sig = float(10.0 ** rng.uniform(-0.5, 1.0))
+    gs = float(10.0 ** rng.uniform(-1, 1))
+    G = gs * rng.standard_normal((nb, p, ng, n)); C = gs * rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    rho = float(10.0 ** rng.uniform(-3, 0))
+A, B, H = co.gen_batch(seed, nb, p, nx, mb, sigP=sig)
+for b in range(nb):
+    for k in range(p):
+        C[b, k, ncnt[b, k]:] = 0.0
+print('case', want, 'p', p, 'nx', nx, 'mb', mb, 'ng', ng, 'nc', nc, 'seed', seed, 'sigP', sig, 'gs', gs, 'rho', rho)
+h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
+if model == 'plain':
+    o = h.convexify_batch(A, B, H)
+elif model == 'G':
+    o = h.convexify_eq_batch(A, B, H, G)
+else:
+    o = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, rho)
+tr = h.trace(nb)
+b = bsel
+print('gpu status', o['status'][b], 'iters', o['iters'][b], 'kappa', o['kappa'][b], 'info', o['info'][b, 10:16])
+for row in tr[b]:
+    if row[0] == 0: break
+    print('  it %2d ph %d mu %.3e tau %.8f pinf %.2e dinf %.2e ap %.3f ad %.3f step %.2e shifts %d' % tuple(row))
+t = []
+Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+r = co.sdp_step1(A[b], B[b], H[b], trace=t, G=None if model == 'plain' else G[b], C=Cl if model == 'step2' else None, rho=rho if model == 'step2' else None)
+print('oracle', r['ipm_status'], 'iters', r['iters'], 'kappa', r['kappa'], 'shift', r['shift'])
+for x in t:
+    print('  it %2d ph %d mu %.3e tau %.8f pinf %.2e dinf %.2e' % (x['it'] + 1, x['phase'], x['mu'], x['tau'], x['pinf'], x['dinf']))
