@@ -50,6 +50,8 @@ extern "C" {
 
 #define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments instead of v_mfma_f64_16x16x4 */
 #define TMPC_FLAG_PROFILE 2      /* record hipEvent timings per phase (tmpc_get_profile)           */
+#define TMPC_FLAG_ELIM 4         /* stage-local multipliers (G / Step 2): eliminate them BEFORE the block factorisation (first design,
+                                    kept for A/B; loses digits on active multipliers) instead of carrying them inside the blocks */
 
 #define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
@@ -72,7 +74,7 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
  * Such a handle also serves every call that takes no G. */
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng);
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng);
-/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 8, (ng+nc)*nx*(nx+1)/2 <= 4096),
+/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 8),
  * for tmpc_convexify_step2_batch_host. */
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc);
 int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc);

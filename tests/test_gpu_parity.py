@@ -346,6 +346,7 @@ def _step2_oracle(A, B, H, G, C, ncnt, rho):
 @pytest.mark.parametrize('seed,nb,p,nx,mb,ng,ncs,rho', [
     (20, 2, 3, 3, 2, 0, [2, 0, 1], 1e-3), (0, 1, 3, 3, 2, 2, [1, 2, 0], 1.0), (30, 2, 2, 3, 1, 1, [1, 1], 1e-3), (20, 1, 1, 3, 1, 0, [2], 1.0),
     (7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 1e-2), (11, 2, 4, 6, 3, 2, [4, 0, 8, 1], 1e-3), (12, 1, 3, 24, 8, 4, [8, 3, 0], 1e-3),
+    (52, 1, 3, 31, 1, 8, [8, 5, 0], 1e-3),           # the largest block: d = 496 plus 18 multipliers (dp = 528)
     (13, 1, 3, 8, 2, 2, [0, 0, 0], 1e-2)])
 def test_step2_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng, ncs, rho):
     """convexifier.py:116-131 (constr=True): multipliers F_k >= 0 of ragged active-constraint Jacobians (stages without C_k
@@ -426,6 +427,18 @@ def test_step_logic_for_a_batch(golden_dir):
     r1 = co.convexify_arrays(A[1], B[1], H[1], C=[c for c in g['Cu']], rho=float(g['rho']))
     assert rel(out['Hc'][0], r0['Hc']) < PARITY and rel(out['Hc'][1], r1['Hc']) < PARITY and r1['step'] == 2
     assert not out['F'][0].any() and not out['F'][2].any() and (out['F'][1] > 0).all() and not out['dHc'][2].any()
+
+
+def test_eliminated_form_agrees_with_the_block_form(hc):
+    """TMPC_FLAG_ELIM (multipliers eliminated stage by stage before the factorisation, the first design) and the default (multipliers
+    inside the blocks, pivoted after the P blocks they couple to) solve the same Newton systems: same answers on a benign case."""
+    from tunempc_amd._lib import FLAG_ELIM
+    A, B, H, G, C, ncnt = _step2_inputs(7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3])
+    J = np.concatenate([G, C], axis=2)
+    a = hc(5, 4, 2, ng=3, nc=C.shape[2]).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    e = hc(5, 4, 2, ng=3, nc=C.shape[2], flags=FLAG_ELIM).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    assert (a['status'] == 0).all() and (e['status'] == 0).all()
+    assert rel(a['Hc'], e['Hc']) < PARITY and rel(a['FgF'], e['FgF']) < 1e-7
 
 
 def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):

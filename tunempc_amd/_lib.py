@@ -12,6 +12,7 @@ _LIB = None
 INFO_STRIDE = 16
 FLAG_NO_MFMA = 1
 FLAG_PROFILE = 2
+FLAG_ELIM = 4          # stage-local multipliers eliminated before the factorisation (first design, A/B only)
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
 # every symbol declared in include/tunempc_hip.h

@@ -36,8 +36,8 @@ def _handle(p, nx, mb, ng=0, nc=0):
 
 
 def _rows_supported(nx, ng, nc):
-    """tmpc_create_con: the stage-local elimination keeps 5*(ng+nc)*d doubles in LDS."""
-    return ng <= NG_MAX and nc <= NC_MAX and (ng + nc) * (nx * (nx + 1) // 2) <= 4096
+    """tmpc_create_con: up to NG_MAX + NC_MAX stage-local multipliers ride in each block of the factorisation."""
+    return ng <= NG_MAX and nc <= NC_MAX
 
 
 def _to_array(m):
@@ -81,8 +81,8 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     nc = C.shape[2]
     ng = 0 if G is None else np.shape(G)[2]
     if nc < 1 or not _rows_supported(nx, ng, nc):
-        raise NotImplementedError('the HIP path handles up to {} equality- and 1..{} active-constraint rows per stage with '
-                                  '(ng+nc)*nx*(nx+1)/2 <= 4096 (got ng={}, nc={}, nx={})'.format(NG_MAX, NC_MAX, ng, nc, nx))
+        raise NotImplementedError('the HIP path handles up to {} equality- and 1..{} active-constraint rows per stage '
+                                  '(got ng={}, nc={})'.format(NG_MAX, NC_MAX, ng, nc))
     J = C if ng == 0 else np.concatenate([np.asarray(G, dtype=np.float64), C], axis=2)
     h = handle or _handle(p, nx, mb, ng, nc)
     if tol is not None:

@@ -54,7 +54,7 @@ static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0) 
   d.nz = d.nr + (nc > 0 ? 2 : 0);          // room for the two epigraph variables of Step 2
   d.B = chunk; d.p = p; d.nx = nx; d.mb = mb; d.n = nx + mb;
   d.d = nx * (nx + 1) / 2;
-  d.dp = (d.d + 15) / 16 * 16;
+  d.dp = (d.d + d.nz + 15) / 16 * 16;      // room for the stage-local multipliers inside the blocks (run_chunk narrows it when unused)
   d.nt = (d.dp + TB - 1) / TB;
   d.flags = 0;
   return d;
@@ -320,6 +320,14 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   if (!dG) { dm.ng = 0; dm.nr = 0; dm.nz = 0; }
   dm.constr = (dG && dncnt) ? 1 : 0;
   if (dG && !dncnt) { dm.nr = dm.ng; }
+  // stage-local multipliers: inside the blocks (block size d + nz) unless TMPC_FLAG_ELIM asks for the eliminated form
+  const bool aug = dm.nr > 0 && !(h->flags & TMPC_FLAG_ELIM);
+  if (dm.nr > 0 && !aug && (size_t)5 * dm.nr * dm.d * sizeof(double) > (size_t)160 * 1024) {
+    snprintf(g_err, sizeof(g_err), "TMPC_FLAG_ELIM keeps 5*(ng+nc)*d doubles in LDS: (ng+nc)*d <= 4096 needed (got %d*%d)", dm.nr, dm.d);
+    return TMPC_E_UNSUPPORTED;
+  }
+  dm.dp = (dm.d + (aug ? dm.nz : 0) + 15) / 16 * 16;
+  dm.nt = (dm.dp + TB - 1) / TB;
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
   WS w = h->ws;
   w.A = dA; w.Bm = dB; w.H = dH; w.G = dG; w.ncnt = dncnt; w.rho = rho;
@@ -342,22 +350,24 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   while (active > 0 && it < cap) {
     if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, aug ? 1 : 0);
     hipLaunchKernelGGL(k_ctrl_a, dim3(nb), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_schur, dim3(BP), dim3(256), phi_schur_lds, st, w, dm);
+    if (eq && !aug) hipLaunchKernelGGL(k_phi_schur, dim3(BP), dim3(256), phi_schur_lds, st, w, dm);
+    if (aug) hipLaunchKernelGGL(k_aug_fill, dim3(BP), dim3(64), 0, st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
     if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
     else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, aug ? 1 : 0);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (eq && !aug) hipLaunchKernelGGL(k_phi_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (aug) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, aug ? 1 : 0);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm, pass);
@@ -402,8 +412,8 @@ int tmpc_device_count(void) {
 }
 
 static bool rows_ok(int nx, int ng, int nc) {
-  // k_phi_schur keeps 5 * (ng + nc) * d doubles in LDS
-  return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM && (size_t)5 * (ng + nc) * (nx * (nx + 1) / 2) * sizeof(double) <= (size_t)160 * 1024;
+  (void)nx;
+  return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM;
 }
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) {
   if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
@@ -423,7 +433,7 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   *out = nullptr;
   if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
   if (!rows_ok(nx, ng, nc)) {
-    snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d and (ng+nc)*nx*(nx+1)/2 <= 4096)", ng, nc, NGM, NCM);
+    snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
   }
   int ndev = 0;

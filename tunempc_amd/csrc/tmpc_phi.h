@@ -149,7 +149,9 @@ __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
 // LDS of k_phi_pre (doubles)
 constexpr int PHI_PRE_LDS = 4 * MS + NRM * NMAX + 4 * NRM * NMAX + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;
 // after k_stage_pre (needs S_r^-1), before k_ctrl_a: vectors w, u, V w, V u; K; c_tau, c_alpha; border / mu / pinf partials
-__global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
+// aug: the multipliers stay in the block system (k_aug_fill): T_loc,loc itself is stored instead of its inverse and the border
+// scalars are left alone.
+__global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
   const int b = sid / dm.p;
@@ -276,7 +278,11 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
     }
   }
   // Gauss-Jordan on [T | I] (T symmetric positive definite): one lane per column, the pivot column travels through kv
-  for (int c = 0; c < nz; ++c) {
+  if (aug) {
+    for (int e = lane; e < nz * nz; e += 64) { const int i = e / nz, j = e - i * nz; Tm[i * TL + nz + j] = Tm[i * TL + j]; }
+    wsync();
+  }
+  for (int c = 0; c < (aug ? 0 : nz); ++c) {
     if (lane < nz) kv[lane] = Tm[lane * TL + c];
     wsync();
     if (lane < 2 * nz) {
@@ -302,9 +308,11 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm) {
   if (lane == 0) {
     double* pq = w.part + (size_t)sid * NPART;
     pq[Q_XS] += xs; pq[Q_RPHI2] = rp2; pq[Q_NCONE] = ncone;
-    pq[Q_TRPSI] -= ctkct;       // b_tt
-    pq[Q_TRPHI2] += ctkca;      // b_ta = -trphi2
-    pq[Q_HBPHI] -= cakca;       // b_aa (+ x0/s0)
+    if (!aug) {
+      pq[Q_TRPSI] -= ctkct;       // b_tt
+      pq[Q_TRPHI2] += ctkca;      // b_ta = -trphi2
+      pq[Q_HBPHI] -= cakca;       // b_aa (+ x0/s0)
+    }
   }
 }
 
@@ -392,7 +400,7 @@ __global__ void __launch_bounds__(256) k_phi_schur(WS w, Dims dm) {
 }
 
 // after k_stage_rhs, before k_gather / k_solve: r_loc, K r_loc, and the eliminated part of the border right-hand sides
-__global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass) {
+__global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
   const int b = sid / dm.p;
@@ -439,7 +447,7 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass) {
   }
   const double ctkr = wave_sum((lane < nz) ? PSM_CT(q, nzs)[lane] * kr : 0.0);
   const double cakr = wave_sum((lane < nz) ? PSM_CA(q, nzs)[lane] * kr : 0.0);
-  if (lane == 0) {
+  if (lane == 0 && !aug) {
     double* pq = w.part + (size_t)sid * NPART;
     pq[Q_TRT2] -= ctkr;     // rhs_tau   = sum trT2 - 1
     pq[Q_HBG] -= cakr;      // rhs_alpha = sum <Hb, T1 - T2> + t0
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(64) k_phi_gather(WS w, Dims dm, int pass) {
 
 // after k_solve, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
 // Mehrotra second-order terms in pass 1
-__global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass) {
+__global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = blockIdx.x, lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
@@ -525,7 +533,12 @@ __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass) {
   double* dph = w.dphi + (size_t)sid * dm.nr; double* dzp = w.dzph + (size_t)sid * dm.nr;
   if (lane < nz) {
     double v = 0.0;
-    for (int j = 0; j < nz; ++j) v = fma(PSM_K(q)[lane * nzs + j], tl[j], v);
+    if (aug) {        // the block solve already produced dy_loc: tail of the solution vector of block k+1
+      const size_t vi = ((size_t)b * dm.p + kn) * dm.dp + dm.d + lane;
+      v = w.Z[vi] - w.TU[vi * 2] * dtau - w.TU[vi * 2 + 1] * dalpha;
+    } else {
+      for (int j = 0; j < nz; ++j) v = fma(PSM_K(q)[lane * nzs + j], tl[j], v);
+    }
     dl[lane] = v;
     if (lane < ng) {
       dph[lane] = v;
@@ -609,6 +622,69 @@ __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
   e[0] = fmin(e[0], ls); e[1] = fmin(e[1], lx);
   double* pq = w.part + (size_t)sid * NPART;
   pq[Q_DXS] += dxs; pq[Q_XDS] += xds; pq[Q_DXDS] += dxds;
+}
+
+// ---- augmented-block form: y_loc of stage k rides in block k+1 behind P_{k+1}, i.e. it is pivoted AFTER the two P blocks it
+// couples to (the order of the oracle's border solve).  Rows d .. d+nz-1 of block k+1:
+//   D_{k+1}[d+i][0..d) = b_k,i   D_{k+1}[d+i][d+j] = T_loc,loc[i][j]   coupling block [block k+1][block k]: row d+i = a_k,i
+// after k_schur (which writes identity there), before k_factor
+__global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
+  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const int nx = dm.nx, d = dm.d, dp = dm.dp, nzs = dm.nz, nz = ps.nz, ng = ps.nrow, p = dm.p;
+  const int kn = (k + 1 == p) ? 0 : k + 1;
+  const size_t bs = (size_t)dp * dp;
+  double* Dn = w.D + ((size_t)b * p + kn) * bs;
+  double* ddn = w.Ddiag + ((size_t)b * p + kn) * dp;
+  const bool corner = (k == p - 1);
+  double* Cg = corner ? (w.F + (size_t)(b * p) * bs) : (w.O + (size_t)sid * bs);
+  const double* q = psm_at(w.psm, dm, sid);
+  for (int i = 0; i < nz; ++i) {
+    double* drow = Dn + (size_t)(d + i) * dp;
+    // local block (lower triangle) and its pivot reference
+    for (int j = lane; j <= i; j += 64) drow[d + j] = PSM_K(q)[i * nzs + j];
+    if (lane == 0) ddn[d + i] = PSM_K(q)[i * nzs + i];
+    if (i >= ng) continue;                   // epigraph variables do not couple to P
+    int e = 0;
+    for (int a = 0; a < nx; ++a) {
+      for (int c = a + lane; c < nx; c += 64) {
+        const int idx = e + (c - a);
+        const double av = phi_avec(w.pvec, dm, sid, i, a, c), bv = phi_bvec(w.pvec, dm, sid, i, a, c);
+        if (p == 1) { drow[idx] = av + bv; continue; }          // both couplings land in the one P block
+        drow[idx] = bv;
+        if (corner) Cg[(size_t)idx * dp + d + i] = av;          // [block p-1][block 0]
+        else Cg[(size_t)(d + i) * dp + idx] = av;               // [block k+1][block k]
+      }
+      e += nx - a;
+    }
+  }
+}
+
+// after k_gather (which zero-pads the tails): right-hand side and border-column entries of y_loc in the vectors of block k+1
+__global__ void __launch_bounds__(64) k_aug_gather(WS w, Dims dm, int pass) {
+  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  const bool three = (pass == 1) || (phase != PH_MAIN);
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  const int nzs = dm.nz;
+  const double* q = psm_at(w.psm, dm, sid);
+  if (lane < ps.nz) {
+    const size_t vi = ((size_t)b * dm.p + kn) * dm.dp + dm.d + lane;
+    const double r = PSM_RPHI(q, nzs)[lane], ct = PSM_CT(q, nzs)[lane], ca = PSM_CA(q, nzs)[lane];
+    if (three) {
+      double* w3 = w.W3 + vi * 3; w3[0] = r; w3[1] = ct; w3[2] = ca;
+      double* u = w.U + vi * 2; u[0] = ct; u[1] = ca;
+    } else {
+      w.Z[vi] = r;
+    }
+  }
 }
 
 // with k_update
