@@ -100,7 +100,7 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nb, const double* dA, const 
 
 /* Step 1 with the equality-constraint term (convexifier.py:249-255 multipliers Fg_k >= 0, :346-347 term G_k' diag(Fg_k) G_k
  * in M_k, :409-411 un-scaling): G [nb][p][ng][n] with ng of tmpc_create_eq; Fg [nb][p][ng] out.  dHc includes the G term
- * (convexifier.py:196-197).  The multipliers are eliminated stage by stage before the block factorisation
+ * (convexifier.py:196-197).  The multipliers of stage k ride inside block k+1 of the block factorisation
  * (tunempc_amd/csrc/tmpc_phi.h). */
 int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* G,
                                  double* Hc, double* dHc, double* P, double* Fg, double* alpha, double* beta, double* kappa,

@@ -7,15 +7,22 @@
 // itself, dual z).  Each norm term is an epigraph variable t with the arrow LMI S = [[t, w v'], [w v, t I]] >> 0, v the
 // multipliers under the norm and w = rho*sbeta/s (the scaled objective is tau + sum t); S is a function of (t, phi) alone, so it
 // is rebuilt instead of iterated and never carries a residual; its primal block X is (m+1) x (m+1).
-// The stage-local vector y_loc = (phi_k, t_k) touches only the cone blocks of stage k, so in the HKM Schur system its columns
-// reach P_k, P_{k+1}, tau and alpha only.  They are eliminated stage by stage BEFORE the block factorisation
-// (K_k = T_loc,loc^-1, at most 18 x 18):
-//     D_k     -= a_k K_k a_k' + b_{k-1} K_{k-1} b_{k-1}'        a_k,i = -svec(W_i[:nx,:nx]),  b_k,i = svec(V_k W_i V_k'),
-//     C_k     -= a_k K_k b_k'                                   W_i = sum_r sym(X_r g_i g_i' S_r^-1) = sum_r sym(w_ri u_ri')
-//     u_tau, u_alpha, rhs  -= a_k K_k (c_tau | c_alpha | r_loc)_k + b_{k-1} K_{k-1} (...)_{k-1},   and the 2 x 2 border likewise,
-// (a, b are zero for the epigraph entries) so that k_schur / k_factor / k_solve stay what they are; afterwards
-// dy_loc = K_k (r_loc - T_loc,y dy).  Every kernel here is one single-wave workgroup per stage (k_phi_schur: 256 threads) and
-// only runs when dm.nr > 0.
+// The stage-local vector y_loc = (phi_k, t_k) (at most 18 entries) touches only the cone blocks of stage k, so in the HKM Schur
+// system its rows reach P_k, P_{k+1}, tau and alpha only:
+//     a_k,i = -svec(W_i[:nx,:nx]) (P_k),   b_k,i = svec(V_k W_i V_k') (P_{k+1}),   W_i = sum_r sym(X_r g_i g_i' S_r^-1) = sum_r sym(w_ri u_ri'),
+//     c_tau, c_alpha (border), T_loc,loc (own block; zero coupling for the epigraph entries).
+// DEFAULT (block form): y_loc of stage k rides in block k+1 of the block-cyclic-tridiagonal system, behind P_{k+1} (block size
+// d + nz instead of d): rows d.. of D_{k+1} hold b_k and T_loc,loc, the same rows of the coupling block hold a_k (k_aug_fill), the
+// tails of the right-hand side / border vectors hold r_loc, c_tau, c_alpha (k_aug_gather), and dy_loc is the tail of the block
+// solution.  y_loc is then pivoted AFTER the two P blocks it couples to -- the order of the oracle's border solve -- and k_schur,
+// k_factor, k_solve run unchanged on the larger blocks.
+// TMPC_FLAG_ELIM (first design, kept for A/B): y_loc is eliminated stage by stage BEFORE the factorisation with K_k = T_loc,loc^-1:
+//     D_k -= a_k K_k a_k' + b_{k-1} K_{k-1} b_{k-1}',  C_k -= a_k K_k b_k',  border columns, 2 x 2 border and right-hand sides likewise,
+//     dy_loc = K_k (r_loc - T_loc,y dy).
+// It loses digits whenever a multiplier is active (z/phi << T_phiphi) and its direction g g' is nearly reachable by calH(dP): D - aKa'
+// then cancels to ~ (z/phi)/T_phiphi of D; replayed in numpy the direction error reaches 1e-6 .. 0.4 on such problems while the
+// block form stays at rounding level.
+// Every kernel here is one single-wave workgroup per stage (k_phi_schur: 256 threads) and only runs when dm.nr > 0.
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_small.h"
