@@ -592,31 +592,38 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
     const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
     const size_t kstep = TRANS ? (size_t)GKV * ldm : (size_t)GKV;
+    // two slabs of loads in flight per thread (ra: even slabs, rb: odd slabs): the solve streams the factors once and is bound by
+    // bytes in flight (512 workgroups x 8 KB with a single prefetch: 4.4 TB/s)
+    double rb[4];
     TMPC_LD4(ra, 0, src, ok)
-    for (int ks = 0; ks < nks; ++ks) {
-      __syncthreads();
-      if (TRANS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) As[(lcol + q) * GLDV + lrow] = ra[q];
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) As[lrow * GLDV + lcol + q] = ra[q];
-      }
-      __syncthreads();
-      if (ks + 1 < nks) {
-        const double* s2 = src + (size_t)(ks + 1) * kstep;
-        TMPC_LD4(ra, 0, s2, ok)
-      }
-      if (m0 + 16 * wv < rows) {
-        const int k0 = ks * GKV;
-#pragma unroll
-        for (int kk = 0; kk < GKV / 4; ++kk) {
-          const double a = As[(16 * wv + fr) * GLDV + kk * 4 + fk];
-          const double bq = X[(fr & (NCP - 1)) * xld + k0 + kk * 4 + fk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);
-        }
-      }
+    if (nks > 1) { const double* s1 = src + kstep; TMPC_LD4(rb, 0, s1, ok) }
+#define TMPC_GEMV_SLAB(RG, KS)                                                                                  \
+    {                                                                                                             \
+      __syncthreads();                                                                                            \
+      if (TRANS) {                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) As[(lcol + q) * GLDV + lrow] = RG[q];                     \
+      } else {                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) As[lrow * GLDV + lcol + q] = RG[q];                       \
+      }                                                                                                           \
+      __syncthreads();                                                                                            \
+      if ((KS) + 2 < nks) {                                                                                       \
+        const double* s2 = src + (size_t)((KS) + 2) * kstep;                                                      \
+        TMPC_LD4(RG, 0, s2, ok)                                                                                   \
+      }                                                                                                           \
+      if (m0 + 16 * wv < rows) {                                                                                  \
+        const int k0 = (KS) * GKV;                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < GKV / 4; ++kk) {                                                 \
+          const double a = As[(16 * wv + fr) * GLDV + kk * 4 + fk];                                               \
+          const double bq = X[(fr & (NCP - 1)) * xld + k0 + kk * 4 + fk];                                         \
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc, 0, 0, 0);                                        \
+        }                                                                                                         \
+      }                                                                                                           \
     }
+    for (int ks = 0; ks < nks; ks += 2) {
+      TMPC_GEMV_SLAB(ra, ks)
+      if (ks + 1 < nks) TMPC_GEMV_SLAB(rb, ks + 1)
+    }
+#undef TMPC_GEMV_SLAB
     if (m0 + 16 * wv < rows && fr < nc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
