@@ -592,11 +592,13 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
     const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
     const size_t kstep = TRANS ? (size_t)GKV * ldm : (size_t)GKV;
-    // two slabs of loads in flight per thread (ra: even slabs, rb: odd slabs): the solve streams the factors once and is bound by
-    // bytes in flight (512 workgroups x 8 KB with a single prefetch: 4.4 TB/s)
-    double rb[4];
+    // four slabs of loads in flight per thread (ra..rd, slab ks mod 4): the solve streams the factors once and is bound by
+    // bytes in flight (512 workgroups x 8 KB with a single prefetch: 4.4 TB/s; two in flight: 5.2)
+    double rb[4], rc[4], rd[4];
     TMPC_LD4(ra, 0, src, ok)
     if (nks > 1) { const double* s1 = src + kstep; TMPC_LD4(rb, 0, s1, ok) }
+    if (nks > 2) { const double* s1 = src + 2 * kstep; TMPC_LD4(rc, 0, s1, ok) }
+    if (nks > 3) { const double* s1 = src + 3 * kstep; TMPC_LD4(rd, 0, s1, ok) }
 #define TMPC_GEMV_SLAB(RG, KS)                                                                                  \
     {                                                                                                             \
       __syncthreads();                                                                                            \
@@ -606,8 +608,8 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
         _Pragma("unroll") for (int q = 0; q < 4; ++q) As[lrow * GLDV + lcol + q] = RG[q];                       \
       }                                                                                                           \
       __syncthreads();                                                                                            \
-      if ((KS) + 2 < nks) {                                                                                       \
-        const double* s2 = src + (size_t)((KS) + 2) * kstep;                                                      \
+      if ((KS) + 4 < nks) {                                                                                       \
+        const double* s2 = src + (size_t)((KS) + 4) * kstep;                                                      \
         TMPC_LD4(RG, 0, s2, ok)                                                                                   \
       }                                                                                                           \
       if (m0 + 16 * wv < rows) {                                                                                  \
@@ -619,9 +621,11 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
         }                                                                                                         \
       }                                                                                                           \
     }
-    for (int ks = 0; ks < nks; ks += 2) {
+    for (int ks = 0; ks < nks; ks += 4) {
       TMPC_GEMV_SLAB(ra, ks)
       if (ks + 1 < nks) TMPC_GEMV_SLAB(rb, ks + 1)
+      if (ks + 2 < nks) TMPC_GEMV_SLAB(rc, ks + 2)
+      if (ks + 3 < nks) TMPC_GEMV_SLAB(rd, ks + 3)
     }
 #undef TMPC_GEMV_SLAB
     if (m0 + 16 * wv < rows && fr < nc) {
