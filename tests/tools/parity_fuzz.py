@@ -1,6 +1,6 @@
 """Randomised parity run (outside pytest): random shapes and seeds, plain Step 1 / Step 1 with G / Step 2 model, HIP path vs the
 oracle.  Prints every member whose status differs or whose Hc differs by more than 1e-8, and the worst error per model.
-Usage: python tests/tools/parity_fuzz.py [ncases] [seed]"""
+Usage: python tests/tools/parity_fuzz.py [ncases] [seed] [pmax] [nxmax]"""
 import os, sys, json, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,10 +10,12 @@ from tunempc_amd._lib import HipConvexifier
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+pmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+nxmax = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 worst = dict(plain=0.0, G=0.0, step2=0.0); bad = []; count = dict(plain=0, G=0, step2=0)
 t0 = time.time()
 for case in range(ncases):
-    p = int(rng.integers(1, 13)); nx = int(rng.integers(1, 9)); mb = int(rng.integers(1, 5))      # mb = 0 (a stage block without inputs) is degenerate: kappa* = 1 with both LMIs active everywhere
+    p = int(rng.integers(1, pmax + 1)); nx = int(rng.integers(1, nxmax + 1)); mb = int(rng.integers(1, 5))      # mb = 0 (a stage block without inputs) is degenerate: kappa* = 1 with both LMIs active everywhere
     n = nx + mb
     ng = int(rng.integers(1, 4)); nc = int(rng.integers(1, 5))
     seed = int(rng.integers(0, 10 ** 6))
