@@ -70,11 +70,11 @@ uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
 /* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.
  * Larger batches are processed in chunks.  chunk <= 0 selects a default that fits free HBM. */
 int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
-/* The same with room for `ng` equality-constraint rows per stage (0 <= ng <= 8), for tmpc_convexify_eq_batch_host.
+/* The same with room for `ng` equality-constraint rows per stage (0 <= ng <= 16), for tmpc_convexify_eq_batch_host.
  * Such a handle also serves every call that takes no G. */
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng);
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng);
-/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 8),
+/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 16),
  * for tmpc_convexify_step2_batch_host. */
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc);
 int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc);

@@ -347,6 +347,7 @@ def _step2_oracle(A, B, H, G, C, ncnt, rho):
     (20, 2, 3, 3, 2, 0, [2, 0, 1], 1e-3), (0, 1, 3, 3, 2, 2, [1, 2, 0], 1.0), (30, 2, 2, 3, 1, 1, [1, 1], 1e-3), (20, 1, 1, 3, 1, 0, [2], 1.0),
     (7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 1e-2), (11, 2, 4, 6, 3, 2, [4, 0, 8, 1], 1e-3), (12, 1, 3, 24, 8, 4, [8, 3, 0], 1e-3),
     (52, 1, 3, 31, 1, 8, [8, 5, 0], 1e-3),           # the largest block: d = 496 plus 18 multipliers (dp = 528)
+    (14, 1, 3, 6, 2, 12, [16, 9, 0], 1e-2),          # the most multipliers: 12 + 16 rows and two norm terms of 12 and 16
     (13, 1, 3, 8, 2, 2, [0, 0, 0], 1e-2)])
 def test_step2_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng, ncs, rho):
     """convexifier.py:116-131 (constr=True): multipliers F_k >= 0 of ragged active-constraint Jacobians (stages without C_k

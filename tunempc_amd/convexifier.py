@@ -22,8 +22,8 @@ from ._lib import HipConvexifier, STATUS_NAMES
 _HANDLES = {}
 
 
-NG_MAX = 8       # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
-NC_MAX = 8       # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
+NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
+NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
 def _handle(p, nx, mb, ng=0, nc=0):

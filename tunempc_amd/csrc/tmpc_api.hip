@@ -322,8 +322,8 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   if (dG && !dncnt) { dm.nr = dm.ng; }
   // stage-local multipliers: inside the blocks (block size d + nz) unless TMPC_FLAG_ELIM asks for the eliminated form
   const bool aug = dm.nr > 0 && !(h->flags & TMPC_FLAG_ELIM);
-  if (dm.nr > 0 && !aug && (size_t)5 * dm.nr * dm.d * sizeof(double) > (size_t)160 * 1024) {
-    snprintf(g_err, sizeof(g_err), "TMPC_FLAG_ELIM keeps 5*(ng+nc)*d doubles in LDS: (ng+nc)*d <= 4096 needed (got %d*%d)", dm.nr, dm.d);
+  if (dm.nr > 0 && !aug && ((size_t)5 * dm.nr * dm.d * sizeof(double) > (size_t)160 * 1024 || dm.nz > 32)) {
+    snprintf(g_err, sizeof(g_err), "TMPC_FLAG_ELIM keeps 5*(ng+nc)*d doubles in LDS and inverts at most 32 x 32: (ng+nc)*d <= 4096 and ng+nc+2 <= 32 needed (got %d rows, d = %d)", dm.nr, dm.d);
     return TMPC_E_UNSUPPORTED;
   }
   dm.dp = (dm.d + (aug ? dm.nz : 0) + 15) / 16 * 16;

@@ -67,10 +67,10 @@ struct Dims {
   int nz;       // stride of the stage-local variable vector: nr (+ 2 epigraph variables of the norm terms in Step 2)
   int constr;   // 1: Step 2 model (convexifier.py:116-131): multipliers of C_k and the rho-norm terms
 };
-constexpr int NGM = 8;   // max ng
-constexpr int NCM = 8;   // max rows of C_k
+constexpr int NGM = 16;  // max ng
+constexpr int NCM = 16;  // max rows of C_k
 constexpr int NRM = NGM + NCM, NZM = NRM + 2;
-constexpr int NAM = 8;   // max rows under one norm term; its arrow LMI is (NAM+1) x (NAM+1)
+constexpr int NAM = 16;  // max rows under one norm term; its arrow LMI is (NAM+1) x (NAM+1)
 constexpr int AEL = NAM + 1, AE = AEL * AEL;
 
 struct Opts {
