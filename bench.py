@@ -33,11 +33,18 @@ def factor_flops_per_problem(p, d):
     return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
 
 
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_factor.h')]
+
+
 def hbm_traffic_per_launch():
-    """HBM bytes per k_factor launch from the committed PMC passes (profiles/r1_traffic.json); PMC counters cannot be
-    collected from inside this process, so this is the profiled value for the same launch geometry, or None."""
+    """HBM bytes per k_cr_update launch from the committed PMC passes (profiles/r2_traffic.json, written by
+    scripts/pmc_traffic.py from separate rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from
+    inside this process).  None when the file is missing or OLDER than the kernel sources: a stale number is not reported."""
     try:
-        return float(json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))['hbm_bytes_per_launch'])
+        if any(os.path.getmtime(f) > os.path.getmtime(TRAFFIC_JSON) for f in KERNEL_SOURCES):
+            return None
+        return float(json.load(open(TRAFFIC_JSON))['hbm_bytes_per_launch'])
     except Exception:
         return None
 
@@ -80,7 +87,7 @@ def main():
     ap.add_argument('--mb', type=int, default=8)
     ap.add_argument('--tol', type=float, default=0.0, help='0 = library default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--distinct', type=int, default=64, help='distinct synthetic problems generated per rank (tiled to --batch)')
+    ap.add_argument('--distinct', type=int, default=512, help='distinct synthetic problems generated per rank (tiled to --batch when smaller)')
     args = ap.parse_args()
 
     import torch
@@ -93,8 +100,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     use_dist = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 ranks with python -m torch.distributed.run '
+                         f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if use_dist:
@@ -146,13 +154,18 @@ def main():
     if rank == 0:
         total_units = nbl * world * p * args.steps
         d = nx * (nx + 1) // 2
-        launches = max(prof['factor_launches'], 1.0)
-        # every k_factor launch processes one chunk of problems; chunks per step = ceil(nbl / chunk)
-        avg_ms = prof['factor_ms'] / launches
-        nchunks = (nbl + h.chunk - 1) // h.chunk
-        chunk = nbl / nchunks            # average problems per k_factor launch
-        fl = factor_flops_per_problem(p, d) * chunk
-        achieved = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        d3 = float(d) ** 3
+        from tunempc_amd._lib import cr_schedule
+        sched = cr_schedule(p)
+        upd_levels = int((sched['levels'][:, 3] > 0).sum())              # levels with a k_cr_update launch
+        phases = max(prof['factor_launches'], 1.0)                       # factorisation phases (one per IPM iteration and chunk)
+        nfac = max(prof['problem_factorisations'], 1.0)                  # problem-factorisations: only problems still iterating are factored
+        # dominant kernel: k_cr_update (symmetric updates + fill edges): 4 d^3 per elimination with two neighbours, d^3 for the last pair
+        upd_flops = nfac * (max(p - 2, 0) * 4.0 + (1.0 if p >= 2 else 0.0)) * d3
+        upd_launches = phases * max(upd_levels, 1)
+        upd_ms = prof['update_ms']
+        achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        phase_tf = nfac * factor_flops_per_problem(p, d) / (prof['factor_ms'] * 1e-3) / 1e12 if prof['factor_ms'] > 0 else 0.0
         line = {
             "metric": "stage-Hessian convexifications/sec at (nx+nu)=32, p=64",
             "value": total_units / el,
@@ -165,16 +178,22 @@ def main():
                                    f"{nbl} problems per GPU ({nbl * world} total; published batch 4096 = 512 x 8 GPUs)",
                        "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
                        "distinct_problems_per_gpu": nd, "mu_tol": args.tol if args.tol > 0 else 2.0 ** -25,
-                       "ipm_iterations_max": int(iters.max()), "status_optimal": ok, "status_total": int(status.size),
+                       "ipm_iterations_max": int(iters.max()), "ipm_iterations_mean": float(iters.mean()),
+                       "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                          "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_traffic.json)",
-                         "kernel": "k_factor<true> (block-cyclic-tridiagonal Cholesky, v_mfma_f64_16x16x4_f64)",
-                         "avg_launch_ms": avg_ms, "launches": int(launches), "problems_per_launch": chunk,
-                         "algorithmic_flops_per_launch": fl,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
+                         "kernel": "k_cr_update<true> (symmetric updates and fill edges of the cyclic-reduction block Cholesky, v_mfma_f64_16x16x4_f64)",
+                         "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
+                         "algorithmic_flops_per_launch": upd_flops / upd_launches,
+                         "factorisation_phase": {"kernels": "k_cr_potrf + k_cr_trsm + k_cr_update, all levels", "tflops": phase_tf,
+                                                 "frac": phase_tf / PEAK_F64_MFMA_TFLOPS, "avg_ms": prof['factor_ms'] / phases,
+                                                 "problems_per_phase": nfac / phases,
+                                                 "potrf_ms": prof['potrf_ms'] / phases, "trsm_ms": prof['trsm_ms'] / phases,
+                                                 "update_ms": upd_ms / phases},
                          "peak_note": "datasheet FP64 matrix peak; measured register-only issue rate of v_mfma_f64_16x16x4 on this part: "
                                       "36 (1 wave/SIMD) / 48 (2+) TFLOP/s, of v_mfma_f64_4x4x4: 71-75 (profiles/r1_mfma_f64_issue_rate.txt)"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},

@@ -25,6 +25,8 @@
  * The caller owns every buffer; the library never frees or keeps caller memory.  `_device` variants
  * take device pointers and enqueue on `stream` (a hipStream_t passed as void*); they synchronise the
  * stream internally once per interior-point iteration (a 4-byte "problems still active" read-back).
+ * nb = 0 is a no-op that returns TMPC_OK (an empty shard of a batch split over several GPUs).
+ * Unit-test and diagnostic entry points are declared in tunempc_hip_debug.h, not here.
  * All functions return 0 on success or a negative TMPC_E_* code; per-problem solver outcomes are in
  * status[] so that one infeasible member does not abort a batch.
  */
@@ -50,8 +52,6 @@ extern "C" {
 
 #define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments instead of v_mfma_f64_16x16x4 */
 #define TMPC_FLAG_PROFILE 2      /* record hipEvent timings per phase (tmpc_get_profile)           */
-#define TMPC_FLAG_ELIM 4         /* stage-local multipliers (G / Step 2): eliminate them BEFORE the block factorisation (first design,
-                                    kept for A/B; loses digits on active multipliers) instead of carrying them inside the blocks */
 
 #define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
@@ -144,37 +144,16 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
  * out[b*p+k][0..3] = min eig, max eig, min |eig| (zeros excluded), max |eig| of sym(H[b][k]). */
 int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
 
-/* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set:
- * out[0] stage_pre+ctrl, [1] schur assembly, [2] block factorisation (k_factor), [3] predictor pass,
- * [4] corrector pass + update, [5] number of k_factor launches, [6] total ms of convexify calls,
- * [7] IPM iterations (max over chunk, summed over chunks). */
-int tmpc_get_profile(tmpc_handle* h, double* out8);
+/* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set, 16 doubles:
+ * out[0] stage_pre+ctrl, [1] schur assembly, [2] block factorisation (all kernels of tmpc_cr.h's factor phase), [3] predictor
+ * pass, [4] corrector pass + update, [5] number of factorisation phases (= IPM iterations of the chunks), [6] total ms of the
+ * convexify calls, [7] IPM iterations (max over chunk, summed over chunks), [8] problem-factorisations (sum over the phases of
+ * the problems still iterating), [9] / [10] / [11] ms inside k_cr_potrf / k_cr_trsm / k_cr_update, [12..15] reserved. */
+int tmpc_get_profile(tmpc_handle* h, double* out16);
 
 /* Per-iteration diagnostics of the LAST chunk solved: out[nb][80][10] = (iteration, phase, mu, tau, pinf, dinf,
  * primal step, dual step, relative output change of the step, cumulative shifted pivots); nb <= chunk. */
 int tmpc_get_trace(tmpc_handle* h, int nb, double* out);
-
-/* Debug / unit-test entry points (tests call the kernels' building blocks through the same library). */
-int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
-int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift);
-
-/* Scaled stage-local multipliers of the LAST chunk solved (row stride nr of that call): phi, their duals z and the last
- * directions, each [nb][p][nr]; any pointer may be NULL. */
-int tmpc_debug_get_multipliers(tmpc_handle* h, int nb, int nr, double* phi, double* z, double* dphi, double* dz);
-
-/* Raw workspace read-back for diagnostics (scripts/eq_debug.py): which = 0 psm, 1 pvec, 2 Ddiag, 3 D, 4 part, 5 O, 6 F;
- * `count` doubles from `offset` (no bounds check beyond the pointer being allocated). */
-int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t count, double* out);
-
-/* Smallest eigenvalue of nmat symmetric n x n matrices (Householder tridiagonalisation + Sturm multisection). */
-int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out);
-/* Isolated A/B timing of the block factorisation kernel: ms_out2[0] = baseline GEMM variant, [1] = current. */
-int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, double* ms_out2);
-
-/* Batched timing of one GEMM core of the factorisation: nb workgroups with private M x N (+)= (M x K)(N x K)' operands,
- * `reps` products per launch, average ms over `launches` launches.  var 0: 64 x 64 tiles (first generation),
- * 1: 160 x 160 register tiles, 2: 320 x 80;  tri 0 none, 1 lower triangle of C only, 2 lower-triangular B. */
-int tmpc_debug_gemm_bench(tmpc_handle* h, int nb, int M, int N, int K, int var, int tri, int reps, int launches, double* ms_out);
 
 const char* tmpc_last_error(void);
 const char* tmpc_version(void);

@@ -1,10 +1,16 @@
+"""Isolated timing of the cyclic-reduction block factorisation and of one solve (tmpc_debug_factor_bench)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tunempc_amd._lib import HipConvexifier
 h = HipConvexifier(2, 3, 1)
-for (nb, p, d) in [(64, 8, 300), (256, 8, 300), (512, 8, 300), (512, 8, 210), (512, 16, 136)]:
+cases = [(512, 8, 300), (64, 8, 300), (8, 8, 300), (512, 64, 300), (64, 64, 300), (8, 64, 300), (1, 64, 300), (64, 200, 210), (1, 30, 10)]
+if len(sys.argv) > 1:
+    cases = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
+for (nb, p, d) in cases:
     ms = h.debug_factor_bench(nb, p, d, reps=3)
     d3 = float(d) ** 3
-    fl = nb * ((p - 2) * 6.3333 * d3 + 2.3333 * d3 + d3 / 3)
-    print(f"nb {nb} p {p} d {d}: v0 {ms[0]:.2f} ms ({fl/ms[0]/1e9:.2f} TF/s)   v1 {ms[1]:.2f} ms ({fl/ms[1]/1e9:.2f} TF/s)", h.lib.tmpc_last_error().decode())
+    fl = nb * (max(p - 2, 0) * 6.3333 * d3 + 2.3333 * d3 + d3 / 3)
+    byt = nb * p * 5 * 0.5 * (2 * d * d * 8)        # one solve streams D (lower), and the two O blocks of every node twice
+    print(f"nb {nb:4d} p {p:3d} d {d:3d}: factor {ms[0]:8.3f} ms ({fl/ms[0]/1e9:6.2f} TF/s algorithmic)   solve {ms[1]:7.3f} ms ({byt/ms[1]/1e9:6.2f} TB/s)",
+          h.lib.tmpc_last_error().decode(), flush=True)

@@ -32,6 +32,10 @@ CASES = {
     'awe_shape_n15': (5000, 1, 40, 9, 6, {}),
     'identity_family': (6000, 2, 5, 4, 2, {'identity': True}),
 }
+# BASELINE.json configs[4]: AWE-shaped synthetic, p=200, n=30 (nx=20, m=10).  One problem: the oracle needs minutes here.
+C5_CASES = {
+    'c5_awe_synthetic_p200_n30': (8000, 1, 200, 20, 10, {}),
+}
 
 
 def solve_batch(A, B, H):
@@ -45,6 +49,14 @@ def solve_batch(A, B, H):
         for k in out:
             out[k].append(r[k])
     return {k: np.array(v) for k, v in out.items()}
+
+
+def c5():
+    for name, (seed, nb, p, nx, mb, kw) in C5_CASES.items():
+        A, B, Hs = co.gen_batch(seed, nb, p, nx, mb, **kw)
+        o = solve_batch(A, B, Hs)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), A=A, B=B, H=Hs, tol=co.DEFAULT_OPTS['tol'], **o)
+        print(name, 'kappa', o['kappa'], 'iters', o['iters'], 'status', o['status'])
 
 
 def main():
@@ -166,7 +178,10 @@ if __name__ == '__main__':
         equality_term()          # only the equality-term vectors (the others stay byte-identical)
     elif sys.argv[1:] == ['step2']:
         step2()
+    elif sys.argv[1:] == ['c5']:
+        c5()
     else:
         main()
         equality_term()
         step2()
+        c5()

@@ -55,30 +55,6 @@ def test_mfma_gemm_nt(hc, M, N, K, flags):
     h.set_options(flags=0)
 
 
-@pytest.mark.parametrize('M,N,K,var,mode,tri', [
-    (304, 304, 304, 1, 0, 0), (304, 304, 304, 1, 1, 0), (304, 304, 304, 1, 2, 0), (304, 304, 304, 1, 0, 1), (496, 496, 496, 1, 0, 1),
-    (608, 304, 304, 1, 2, 0), (16, 16, 16, 1, 0, 0), (32, 32, 304, 1, 0, 1), (304, 64, 256, 2, 0, 0), (240, 64, 64, 2, 0, 0),
-    (304, 64, 64, 2, 1, 2), (48, 48, 48, 2, 1, 2), (336, 96, 64, 2, 0, 0)])
-def test_register_tile_gemm_core(hc, M, N, K, var, mode, tri):
-    """Experimental second-generation core (tmpc_gemm2.h: v_mfma_f64_4x4x4, LDS-DMA, three-buffer pipeline; reached only
-    through the debug entry) vs numpy: all modes, ragged edges, symmetric (lower-only) output, triangular B."""
-    h = hc(2, 3, 1)
-    rng = np.random.default_rng(M * 1000 + N + K + var)
-    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
-    if tri == 2:
-        B = np.tril(B)
-    out = h.debug_gemm_nt(C0, A, B, mode=mode | (var << 4), lower=tri)
-    P = A @ B.T
-    ref = C0 - P if mode == 0 else (P if mode == 1 else -P)
-    if tri == 1:      # only the fragments on and below the diagonal are written
-        nf = M // 16
-        mask = np.kron(np.tril(np.ones((nf, nf))), np.ones((16, 16))) > 0
-        assert np.abs(out - ref)[mask].max() < 1e-12 * K
-        assert np.abs(out - C0)[~mask].max() == 0.0
-    else:
-        assert np.abs(out - ref).max() < 1e-12 * K
-
-
 def _spd_cyclic(rng, p, d):
     E = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d); F = rng.standard_normal((p, 2 * d, d)) / np.sqrt(2 * d)
     D = np.stack([np.eye(d) for _ in range(p)]); Cc = np.zeros((p, d, d))
@@ -95,9 +71,10 @@ def _spd_cyclic(rng, p, d):
     return D, Cc, T
 
 
-@pytest.mark.parametrize('p,d', [(1, 6), (2, 10), (3, 10), (5, 21), (4, 78), (3, 136), (3, 300), (7, 45), (2, 3)])
+@pytest.mark.parametrize('p,d', [(1, 6), (2, 10), (3, 10), (5, 21), (4, 78), (3, 136), (3, 300), (7, 45), (2, 3), (6, 20), (8, 33), (9, 16), (13, 10),
+                                 (16, 70), (30, 10), (64, 24), (200, 5)])
 def test_block_cyclic_cholesky_solve(hc, p, d):
-    """k_factor + wg_cyclic_solve vs a dense numpy solve of the same SPD block-cyclic-tridiagonal system."""
+    """Cyclic-reduction block factorisation + solves (tmpc_cr.h) vs a dense numpy solve of the same SPD block-cyclic-tridiagonal system."""
     h = hc(2, 3, 1)
     rng = np.random.default_rng(p * 100 + d)
     D, Cc, T = _spd_cyclic(rng, p, d)
@@ -430,18 +407,6 @@ def test_step_logic_for_a_batch(golden_dir):
     assert not out['F'][0].any() and not out['F'][2].any() and (out['F'][1] > 0).all() and not out['dHc'][2].any()
 
 
-def test_eliminated_form_agrees_with_the_block_form(hc):
-    """TMPC_FLAG_ELIM (multipliers eliminated stage by stage before the factorisation, the first design) and the default (multipliers
-    inside the blocks, pivoted after the P blocks they couple to) solve the same Newton systems: same answers on a benign case."""
-    from tunempc_amd._lib import FLAG_ELIM
-    A, B, H, G, C, ncnt = _step2_inputs(7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3])
-    J = np.concatenate([G, C], axis=2)
-    a = hc(5, 4, 2, ng=3, nc=C.shape[2]).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
-    e = hc(5, 4, 2, ng=3, nc=C.shape[2], flags=FLAG_ELIM).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
-    assert (a['status'] == 0).all() and (e['status'] == 0).all()
-    assert rel(a['Hc'], e['Hc']) < PARITY and rel(a['FgF'], e['FgF']) < 1e-7
-
-
 def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
     """convexify(..., C=...) on the dense model's vector (B = 0, R < 0): Step 1 infeasible -> Step 2 -> EQUIVALENCE TYPE B;
     without C the reference's ValueError; force asks for Step 3, which this build does not have."""
@@ -567,6 +532,68 @@ def test_full_size_step2_properties(hc):
     for b in range(nb):
         ref = co.convex_hessian_suppl(A[b], B[b], eq['P'][b], G=G[b], Fg=eq['Fg'][b])[0]
         assert rel(eq['Hc'][b] - H[b], ref) < 1e-10 and (eq['Fg'][b] >= 0).all()
+
+
+def test_c5_golden_p200_n30(hc, golden_dir):
+    """BASELINE configs[4] (AWE-shaped synthetic: p=200, nx=20, m=10, n=30, d=210): HIP path vs the committed oracle vector."""
+    g = np.load(os.path.join(golden_dir, 'c5_awe_synthetic_p200_n30.npz'))
+    A, B, H = g['A'], g['B'], g['H']
+    nb, p, nx, _ = A.shape
+    assert (p, nx, B.shape[3]) == (200, 20, 10)
+    h = hc(p, nx, B.shape[3], chunk=2)
+    out = h.convexify_batch(A, B, H)
+    for b in range(nb):
+        assert int(out['status'][b]) == int(g['status'][b]) == 0
+        assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
+        assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
+
+
+def test_full_size_c5_properties(hc):
+    """BASELINE configs[4] full shape (p=200, nx=20, m=10), a small batch (the published 512 shard to 64 per GPU; the
+    properties do not depend on the batch size): every member converges, Hc positive definite, cond(Hc_k) <= kappa,
+    Hc - H = sym(calH(P)) for the returned P, kappa no worse than the generator's hidden feasible point, idempotence."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb = 200, 20, 10, 3
+    A, B, H = synthetic.gen_batch(555, nb, p, nx, mb)
+    h = hc(p, nx, mb, chunk=4)
+    out = h.convexify_batch(A, B, H)
+    assert (out['status'] == 0).all() and out['iters'].max() <= 30
+    for b in range(nb):
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0
+        assert (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-9)
+        dH, _, _, _ = co.convex_hessian_suppl(A[b], B[b], out['P'][b])
+        assert rel(out['Hc'][b] - H[b], dH) < 1e-10
+        assert out['kappa'][b] <= 10.0 * (1 + 1e-6)
+    again = h.convexify_batch(A, B, out['Hc'])
+    assert (again['info'][:, 13] == 1).all() and not again['dHc'].any()
+
+
+def test_sharded_path_with_hip_handle_and_nccl(hc):
+    """tunempc_amd.dist.convexify_batch_sharded with the REAL HIP handle as solve_fn and the nccl (= RCCL) backend, world
+    size 1 (the GPU box has one device): the code path bench.py --gpus N runs per rank, checked against the plain call."""
+    import torch
+    import torch.distributed as dist
+    from tunempc_amd.dist import convexify_batch_sharded
+    A, B, H = co.gen_batch(910, 5, 4, 3, 2)
+    h = hc(4, 3, 2)
+    ref = h.convexify_batch(A, B, H)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        dA, dB, dH = (torch.from_numpy(x).to(dev) for x in (A, B, H))
+        g = convexify_batch_sharded(dA, dB, dH, lambda a, b, c: h.convexify_batch_device(a.contiguous(), b.contiguous(), c.contiguous()))
+        torch.cuda.synchronize()
+        assert np.array_equal(g['Hc'].cpu().numpy(), ref['Hc'])
+        assert np.array_equal(g['status'].cpu().numpy(), ref['status'])
+        assert np.array_equal(g['kappa'].cpu().numpy(), ref['kappa'])
+    finally:
+        if own:
+            dist.destroy_process_group()
 
 
 # ----------------------------------------------------------------------------- consumer row: tracking reference

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, 'include', 'tunempc_hip.h')).read()
+def _declared_symbols(header='tunempc_hip.h'):
+    src = open(os.path.join(ROOT, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(tmpc_[a-z0-9_]+)\s*\(', src)))
 
@@ -18,12 +18,14 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     import __graft_entry__ as g
     g.build()
-    from tunempc_amd._lib import load_library, EXPORTS
+    from tunempc_amd._lib import load_library, EXPORTS, DEBUG_EXPORTS
     lib = load_library()
     declared = _declared_symbols()
     assert declared, 'no declarations parsed'
     assert sorted(EXPORTS) == declared
-    for s in declared:
+    debug = _declared_symbols('tunempc_hip_debug.h')
+    assert sorted(DEBUG_EXPORTS) == debug and not [d for d in declared if d.startswith('tmpc_debug')]
+    for s in declared + debug:
         assert hasattr(lib, s), s
     assert b'gfx950' in lib.tmpc_version()
 

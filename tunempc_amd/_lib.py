@@ -12,18 +12,21 @@ _LIB = None
 INFO_STRIDE = 16
 FLAG_NO_MFMA = 1
 FLAG_PROFILE = 2
-FLAG_ELIM = 4          # stage-local multipliers eliminated before the factorisation (first design, A/B only)
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
-# every symbol declared in include/tunempc_hip.h
+# every symbol declared in include/tunempc_hip.h (the drop-in boundary) ...
 EXPORTS = [
-    'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_create', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
-    'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_supplement_batch_host',
-    'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_factor_bench', 'tmpc_debug_min_eig',
-    'tmpc_debug_gemm_bench', 'tmpc_tracking_reference_host', 'tmpc_supplement_terms_batch_host',
-    'tmpc_workspace_bytes_eq', 'tmpc_create_eq', 'tmpc_convexify_eq_batch_host',
-    'tmpc_convexify_con_batch_device', 'tmpc_debug_get_multipliers', 'tmpc_debug_get_array', 'tmpc_workspace_bytes_con', 'tmpc_create_con', 'tmpc_convexify_step2_batch_host',
+    'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
+    'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
+    'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
+    'tmpc_convexify_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
+    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace',
     'tmpc_last_error', 'tmpc_version',
+]
+# ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
+DEBUG_EXPORTS = [
+    'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_cr_schedule', 'tmpc_debug_get_multipliers', 'tmpc_debug_get_array',
+    'tmpc_debug_min_eig', 'tmpc_debug_factor_bench',
 ]
 
 
@@ -94,8 +97,8 @@ def load_library():
     lib.tmpc_supplement_terms_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, dp]
     lib.tmpc_tracking_reference_host.restype = C.c_int
     lib.tmpc_tracking_reference_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_double, dp, dp, ip]
-    lib.tmpc_debug_gemm_bench.restype = C.c_int
-    lib.tmpc_debug_gemm_bench.argtypes = [vp] + [C.c_int] * 8 + [dp]
+    lib.tmpc_debug_cr_schedule.restype = C.c_int
+    lib.tmpc_debug_cr_schedule.argtypes = [C.c_int, ip, C.c_int]
     lib.tmpc_debug_factor_bench.restype = C.c_int
     lib.tmpc_debug_factor_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     lib.tmpc_debug_min_eig.restype = C.c_int
@@ -306,9 +309,10 @@ class HipConvexifier:
         return out
 
     def profile(self):
-        out = np.zeros(8)
+        out = np.zeros(16)
         _check(self.lib, self.lib.tmpc_get_profile(self._h, _dptr(out)), 'tmpc_get_profile')
-        keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters']
+        keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters',
+                'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms']
         return dict(zip(keys, out.tolist()))
 
     def trace(self, nb):
@@ -346,12 +350,8 @@ class HipConvexifier:
                                                               info.ctypes.data_as(C.POINTER(C.c_int32))), 'tmpc_tracking_reference_host')
         return W, yref, info
 
-    def debug_gemm_bench(self, nb, M, N, K, var, tri=0, reps=4, launches=3):
-        out = np.zeros(1)
-        _check(self.lib, self.lib.tmpc_debug_gemm_bench(self._h, nb, M, N, K, var, tri, reps, launches, _dptr(out)), 'tmpc_debug_gemm_bench')
-        return float(out[0])
-
     def debug_factor_bench(self, nb, p, d, reps=3):
+        """(factorisation ms, single-rhs solve ms) of nb copies of one random SPD block-cyclic-tridiagonal system."""
         out = np.zeros(2)
         _check(self.lib, self.lib.tmpc_debug_factor_bench(self._h, nb, p, d, reps, _dptr(out)), 'tmpc_debug_factor_bench')
         return out
@@ -363,3 +363,20 @@ class HipConvexifier:
         x = np.empty((p, d)); ns = np.zeros(1, np.int32)
         _check(self.lib, self.lib.tmpc_debug_block_solve(self._h, p, d, _dptr(D), _dptr(Ccpl), _dptr(rhs), _dptr(x), _iptr(ns)), 'tmpc_debug_block_solve')
         return x, int(ns[0])
+
+
+def cr_schedule(p):
+    """The elimination schedule of the block factorisation for period p (host only): dict(prep, levels [(eoff, nelim, uoff, nupd)],
+    elim [nelim, 8], upd [nupd, 8], orient [p]) -- see include/tunempc_hip_debug.h."""
+    lib = load_library()
+    n = lib.tmpc_debug_cr_schedule(int(p), None, 0)
+    if n < 0:
+        raise ValueError('cr_schedule: p >= 1 expected')
+    buf = np.zeros(n, np.int32)
+    lib.tmpc_debug_cr_schedule(int(p), _iptr(buf), n)
+    nlev, prep, ne, nu = (int(v) for v in buf[:4])
+    o = 4
+    levels = buf[o:o + 4 * nlev].reshape(nlev, 4); o += 4 * nlev
+    elim = buf[o:o + 8 * ne].reshape(ne, 8); o += 8 * ne
+    upd = buf[o:o + 8 * nu].reshape(nu, 8); o += 8 * nu
+    return dict(prep=prep, levels=levels, elim=elim, upd=upd, orient=buf[o:o + p].copy())

@@ -19,20 +19,42 @@ from . import preprocessing
 from .logger import Logger
 from ._lib import HipConvexifier, STATUS_NAMES
 
-_HANDLES = {}
+_HANDLES = {}        # (p, nx, mb, ng) -> HipConvexifier; at most _MAX_HANDLES shapes stay resident (least recently used goes first)
+_MAX_HANDLES = 4
+_MAX_CHUNK = 512     # problems per workspace chunk the drop-in paths ever ask for (larger batches run chunk by chunk)
+DEFAULT_TOL = 2.0 ** -25
 
 
 NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
 NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
-def _handle(p, nx, mb, ng=0, nc=0):
-    key = (p, nx, mb, ng, nc)
-    h = _HANDLES.get(key)
+def _handle(p, nx, mb, ng=0, nc=0, nb=1):
+    """One cached handle per problem shape.  Its workspace is sized for the batch actually asked for (next power of two of nb,
+    at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
+    pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
+    of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk."""
+    key = (p, nx, mb, ng)       # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
+    want = 1
+    while want < min(max(int(nb), 1), _MAX_CHUNK):
+        want *= 2
+    h = _HANDLES.pop(key, None)
+    if h is not None and (h.nc < nc or h.chunk < want):
+        nc, want = max(nc, h.nc), max(want, h.chunk)
+        h.close()
+        h = None
     if h is None:
-        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
-        _HANDLES[key] = h
+        while len(_HANDLES) >= _MAX_HANDLES:
+            _HANDLES.pop(next(iter(_HANDLES))).close()
+        h = HipConvexifier(p, nx, mb, chunk=want, ng=ng, nc=nc)
+    _HANDLES[key] = h           # most recently used last
     return h
+
+
+def release_handles():
+    """Free every cached workspace (device memory) of the drop-in entry points."""
+    while _HANDLES:
+        _HANDLES.popitem()[1].close()
 
 
 def _rows_supported(nx, ng, nc):
@@ -47,7 +69,7 @@ def _to_array(m):
     return np.atleast_2d(np.asarray(m, dtype=np.float64))
 
 
-def convexify_batch(A, B, H, tol=None, handle=None, G=None):
+def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0):
     """Batched Step 1.  A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict with
     Hc, dHc [nb,p,n,n], P [nb,p,nx,nx], alpha, beta, kappa [nb], status [nb] (0 Optimal, 1 Feasible,
     2 Infeasible; convexifier.py:442-451), iters [nb], info [nb,16].
@@ -62,9 +84,9 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None):
         ng = G.shape[2]
         if ng > NG_MAX:
             raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
-    h = handle or _handle(p, nx, mb, ng)
-    if tol is not None:
-        h.set_options(tol=tol)
+    h = handle or _handle(p, nx, mb, ng, nc_hint, nb)      # nc_hint: room for the C rows of a Step 2 that may follow (same handle)
+    if handle is None or tol is not None:
+        h.set_options(tol=tol if tol is not None else DEFAULT_TOL)      # per call: a cached handle never keeps an earlier caller's tolerance
     if ng > 0:
         return h.convexify_eq_batch(A, B, H, G)
     return h.convexify_batch(A, B, H)
@@ -83,13 +105,19 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     if nc < 1 or not _rows_supported(nx, ng, nc):
         raise NotImplementedError('the HIP path handles up to {} equality- and 1..{} active-constraint rows per stage '
                                   '(got ng={}, nc={})'.format(NG_MAX, NC_MAX, ng, nc))
-    J = C if ng == 0 else np.concatenate([np.asarray(G, dtype=np.float64), C], axis=2)
-    h = handle or _handle(p, nx, mb, ng, nc)
-    if tol is not None:
-        h.set_options(tol=tol)
+    if ncnt.shape != (nb, p) or (ncnt < 0).any() or (ncnt > nc).any():
+        raise ValueError('ncnt must be an int array [nb, p] with 0 <= ncnt <= C.shape[2] = {}'.format(nc))
+    h = handle or _handle(p, nx, mb, ng, nc, nb)
+    if handle is None or tol is not None:
+        h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
+    # the handle may have more room than this call needs (it is shared between the steps): zero rows are padding
+    J = np.zeros((nb, p, h.ng + h.nc, nx + mb))
+    if ng:
+        J[:, :, :ng] = np.asarray(G, dtype=np.float64)
+    J[:, :, h.ng:h.ng + nc] = C
     out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
     FgF = out.pop('FgF')
-    out['F'] = FgF[:, :, ng:]
+    out['F'] = FgF[:, :, h.ng:h.ng + nc]
     if ng:
         out['Fg'] = FgF[:, :, :ng]
     return out
@@ -107,6 +135,8 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
     out['step'] = np.where(out['info'][:, 13] != 0.0, 0, 1).astype(np.int32)
     if C is None:
         return out
+    if ncnt is None:
+        raise ValueError('convexify_steps_batch: C needs ncnt [nb, p], the rows of C_k present per stage (0 where C_k is None)')
     C = np.asarray(C, dtype=np.float64); ncnt = np.asarray(ncnt, dtype=np.int32)
     out['F'] = np.zeros((nb, p, C.shape[2]))
     redo = np.where(out['status'] == 2)[0]
@@ -116,6 +146,30 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
             out[key][redo] = val
         out['step'][redo] = 2
     return out
+
+
+_IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged'}     # info[10]; plays the role of M.status (convexifier.py:365, :443)
+
+
+def _log_solution(res):
+    """The log lines of solveSDP (convexifier.py:365-370) and check_convergence (:441-453) for one solved problem."""
+    status = STATUS_NAMES[int(res['status'][0])]
+    ipm = _IPM_STATUS.get(int(res['info'][0, 10]), 'unknown')
+    if ipm == 'optimal':
+        Logger.logger.debug('SDP solution:')
+        Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
+        Logger.logger.debug('beta: {}'.format(res['beta'][0]))
+    else:
+        Logger.logger.debug('solution status: {} ...'.format(ipm))
+    if status in ['Optimal', 'Feasible']:
+        Logger.logger.info('{} solution found.'.format(status))
+        Logger.logger.info('Maximum condition number: {}'.format(res['info'][0, 4]))
+        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+    else:
+        Logger.logger.info('SDP solver status: {}'.format(ipm))
+        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
+        Logger.logger.info('!! Problem infeasible !!')
+    return status
 
 
 def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip', 'force': False}):
@@ -156,41 +210,47 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     if solver not in ('hip', 'mosek', 'cvxopt'):
         raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))
 
-    Logger.logger.info('Construct SDP...')
-    Logger.logger.info('')
-    Logger.logger.info(50 * '*')
-    Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
-    Logger.logger.info('solving SDP...')
     Gs = None
     if 'G' in arg:        # the multipliers Fg_k >= 0 belong to every step, Step 1 included (convexifier.py:249-255)
         Gs = np.stack([_to_array(g) for g in arg['G']])
         if Gs.shape[1] == 0:
             Gs = None
-    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None])
+    Cl = rows = None
+    nc = 0
+    if 'C' in arg:
+        Cl = [None if c is None else _to_array(c) for c in arg['C']]
+        rows = [0 if c is None else c.shape[0] for c in Cl]
+        nc = max(1, max(rows))
 
-    if res['info'][0, 13] != 0.0:      # already convex: convexifier.py:83-85 (bare zero arrays, as the reference)
+    if Gs is not None and Gs.shape[1] > NG_MAX:
+        raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, Gs.shape[1]))
+
+    # check if hessian is already convex (convexifier.py:82-85: before anything is constructed or logged about the SDP):
+    # batched eigenvalue scan on the device
+    h = _handle(period, nx, nu, 0 if Gs is None else Gs.shape[1], nc if nc <= NC_MAX else 0, 1)
+    if h.eig_scan(Hs[None])[0, :, 0].min() > 0:
         Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')
         return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))
 
-    status = STATUS_NAMES[int(res['status'][0])]
-    Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
-    Logger.logger.debug('beta: {}'.format(res['beta'][0]))
+    Logger.logger.info('Construct SDP...')
+    Logger.logger.info('')
+    Logger.logger.info(50 * '*')
+    Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
+    Logger.logger.info('solving SDP...')
+    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None], nc_hint=nc if nc <= NC_MAX else 0)
+
+    if res['info'][0, 13] != 0.0:      # (the library's own pre-check; same answer as the scan above)
+        Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')
+        return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))
+
+    status = _log_solution(res)
     if status in ['Optimal', 'Feasible']:
-        Logger.logger.info('{} solution found.'.format(status))
-        Logger.logger.info('Maximum condition number: {}'.format(res['info'][0, 4]))
-        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
         Logger.logger.info('EQUIVALENCE TYPE A')
         Logger.logger.info(50 * '*')
-    else:
-        Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
-        Logger.logger.info('!! Problem infeasible !!')
 
     if status == 'Infeasible' and 'C' in arg:        # convexifier.py:116-131
         Logger.logger.info(50 * '*')
         Logger.logger.info('Step 2: (η_F = 1), (η_T = 0)')
-        Cl = [None if c is None else _to_array(c) for c in arg['C']]
-        rows = [0 if c is None else c.shape[0] for c in Cl]
-        nc = max(1, max(rows))
         Cp = np.zeros((period, nc, nx + nu))
         for k, c in enumerate(Cl):
             if rows[k]:
@@ -198,29 +258,24 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         Logger.logger.info('solving SDP...')
         res = convexify_step2_batch(As[None], Bs[None], Hs[None], Cp[None], np.asarray(rows, np.int32)[None],
                                     (opts or {}).get('rho', 1e-3), G=None if Gs is None else Gs[None])
-        status = STATUS_NAMES[int(res['status'][0])]
-        Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
-        Logger.logger.debug('beta: {}'.format(res['beta'][0]))
+        status = _log_solution(res)
         if status in ['Optimal', 'Feasible']:
-            Logger.logger.info('{} solution found.'.format(status))
-            Logger.logger.info('Maximum condition number: {}'.format(res['info'][0, 4]))
-            Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
             Logger.logger.info('EQUIVALENCE TYPE B')
             Logger.logger.info(50 * '*')
-        else:
-            Logger.logger.info('Minimum eigenvalue: {}'.format(res['info'][0, 3]))
-            Logger.logger.info('!! Problem infeasible !!')
 
     if status == 'Infeasible':
-        if (opts or {}).get('force', False):
-            raise NotImplementedError('Step 3 of the convexifier (forced regularisation T, convexifier.py:137-147) is not built yet')
         Logger.logger.warning('!! Strict dissipativity does not hold locally !!')
         Logger.logger.warning('!! The provided indefinite LQ MPC problem is not stabilising !!')
         Logger.logger.warning(50 * '*')
-        Logger.logger.warning('Consider operating the system at another orbit of different period p')
-        Logger.logger.warning('Convexification and stabilization of the MPC scheme can be enforced by enabling "force"-flag.')
-        Logger.logger.warning('In this case there are no guarantees of (local, first-order) equivalence.')
-        raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
+        if (opts or {}).get('force', False):                                  # convexifier.py:137-147
+            Logger.logger.info('Step 3: (η_F = 1), (η_T = 1)')
+            Logger.logger.info('Enforcing convexification...')
+            raise NotImplementedError('Step 3 of the convexifier (forced regularisation T, convexifier.py:137-147) is not built yet')
+        else:
+            Logger.logger.warning('Consider operating the system at another orbit of different period p')
+            Logger.logger.warning('Convexification and stabilization of the MPC scheme can be enforced by enabling "force"-flag.')
+            Logger.logger.warning('In this case there are no guarantees of (local, first-order) equivalence.')
+            raise ValueError('Convexification is not possible if the system is not optimally operated at the optimal orbit.')
 
     Logger.logger.info('')
     Logger.logger.info('Hessians convexified.')
@@ -262,6 +317,6 @@ def convexHessianSuppl(A, B, Q, R, N, dP, G=None, Fg=None, C=None, F=None, T=Non
             if rows[i]:
                 Ji = np.vstack(rows[i]); J[0, i, :Ji.shape[0]] = Ji; W[0, i, :Ji.shape[0]] = np.concatenate(wts[i])
     Ts = np.stack([_to_array(t) for t in T])[None] if T else None
-    dH = _handle(period, nx, Bs.shape[2]).supplement_terms_batch(As[None], Bs[None], Ps[None], J, W, Ts)[0]
+    dH = _handle(period, nx, Bs.shape[2], 0, 0, 1).supplement_terms_batch(As[None], Bs[None], Ps[None], J, W, Ts)[0]
     dHc = [dH[k] for k in range(period)]
     return dHc, [d[:nx, :nx] for d in dHc], [d[nx:, nx:] for d in dHc], [d[:nx, nx:] for d in dHc]

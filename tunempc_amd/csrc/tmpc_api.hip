@@ -2,16 +2,19 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <new>
 #include <string.h>
 #include <algorithm>
 #include <vector>
 
 #include "../../include/tunempc_hip.h"
+#include "../../include/tunempc_hip_debug.h"
 #include "tmpc_common.h"
 #include "tmpc_small.h"
 #include "tmpc_stage.h"
 #include "tmpc_schur.h"
 #include "tmpc_factor.h"
+#include "tmpc_cr.h"
 #include "tmpc_phi.h"
 
 using namespace tmpc;
@@ -26,6 +29,13 @@ static int set_err(const char* what, hipError_t e, int line) {
     hipError_t e_ = (x);                                     \
     if (e_ != hipSuccess) return set_err(#x, e_, __LINE__);  \
   } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T> T* as() const { return (T*)p; }
+};
 
 struct tmpc_handle {
   Dims dm;          // dm.B = chunk capacity
@@ -42,8 +52,28 @@ struct tmpc_handle {
   double* d_abk;                 // [chunk][3]
   int32_t* d_si;                 // [chunk][2]
   hipEvent_t ev[8];
-  double prof[8];
+  double prof[16];               // see tmpc_get_profile
+  std::vector<hipEvent_t> kev;   // profile mode: event pairs around the launches of one factorisation (class = index % 3)
+  int device;                    // HIP device the workspace lives on
+  CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
+  int* d_sched;                  // device copy: elimination records | update records | orientation
+  int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
 };
+
+// device copy of a schedule: [elim | upd | orient]
+static int cr_upload(const CrSched& sc, int** out) {
+  std::vector<int> flat(sc.elim);
+  flat.insert(flat.end(), sc.upd.begin(), sc.upd.end());
+  flat.insert(flat.end(), sc.orient.begin(), sc.orient.end());
+  *out = nullptr;
+  if (hipMalloc(out, flat.size() * sizeof(int)) != hipSuccess) return TMPC_E_NOMEM;
+  if (hipMemcpy(*out, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { hipFree(*out); *out = nullptr; return TMPC_E_HIP; }
+  return TMPC_OK;
+}
+static CrDev cr_dev(const CrSched& sc, const int* d_sched, const int* alist) {
+  CrDev c; c.elim = d_sched; c.upd = d_sched + sc.elim.size(); c.orient = d_sched + sc.elim.size() + sc.upd.size(); c.alist = alist;
+  return c;
+}
 
 // ---------------------------------------------------------------------------------- sizes
 static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
@@ -91,6 +121,8 @@ static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
   w.W3 = c.take<double>(BP * dm.dp * 3); w.U = c.take<double>(BP * dm.dp * 2); w.TU = c.take<double>(BP * dm.dp * 2);
   w.Z = c.take<double>(BP * dm.dp);
   w.active = c.take<int>(64);
+  w.alist = c.take<int>((size_t)dm.B);
+  w.cr_orient = nullptr;
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
@@ -240,78 +272,99 @@ __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   wg_gemm_nt<USE_MFMA>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
 }
-// second-generation core (tmpc_gemm2.h): nb workgroups, each with its own C/A/B, `reps` products back to back
-template <int WR, int WC, int FR, int FC, int OCC>
-__global__ void __launch_bounds__(256, OCC) k_debug_gemm2(double* C, const double* A, const double* B, int M, int N, int K, int mode, int tri, int reps) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const size_t b = blockIdx.x;
-  const size_t bo = (tri & 16) ? 0 : b;      // tri | 16: every workgroup on the same operands (cache-resident: compute ceiling of the core)
-  tri &= 15;
-  double* Cb = C + bo * M * N; const double* Ab = A + bo * M * K; const double* Bb = B + bo * N * K;
-  for (int r = 0; r < reps; ++r) {
-    if (tri == TRI_CLOW) {
-      if constexpr (WR * FR == WC * FC && FR == FC) {
-        wg_gemm2<WR, WC, FR, FC, 0, TRI_COFF>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-        wg_gemm2<WR, WC, FR, FC, 0, TRI_CDIAG>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-      } else wg_gemm2<WR, WC, FR, FC, 0, TRI_CLOW>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    }
-    else if (tri == TRI_BLOW) wg_gemm2<WR, WC, FR, FC, 1, TRI_BLOW>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    else if (mode == 4) wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE, 1>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    else if (mode == 5) wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE, 3>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    else if (mode == 0) wg_gemm2<WR, WC, FR, FC, 0, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    else if (mode == 1) wg_gemm2<WR, WC, FR, FC, 1, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-    else wg_gemm2<WR, WC, FR, FC, 2, TRI_NONE>(Cb, N, Ab, K, Bb, K, M, N, K, lds);
-  }
-}
-template <bool USE_MFMA>
-__global__ void __launch_bounds__(256, 2) k_debug_gemm1(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower, int reps) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const size_t b = (lower & 16) ? 0 : blockIdx.x;
-  lower &= 15;
-  for (int r = 0; r < reps; ++r)
-    wg_gemm_nt<USE_MFMA>(C + b * M * N, N, A + b * M * K, K, B + b * N * K, K, M, N, K, mode, lower != 0, lds);
-}
-__global__ void __launch_bounds__(256) k_debug_solve(WS w, Dims dm) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg_cyclic_solve<1>(w.Z, w.D, w.O, w.F, w.Linv, dm.p, dm.dp, dm.nt, lds);
-}
-
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
 static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
-static size_t gemm2_lds() { return (size_t)G2_LDS_DOUBLES * sizeof(double); }
-static size_t solve_lds(const Dims& dm) { return (size_t)solve_lds_doubles(dm.dp) * sizeof(double); }
+static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 
-static int set_lds_attrs() {
-  static bool done = false;
-  if (done) return TMPC_OK;
+// kernels whose dynamic LDS exceeds the 64 KB default: the attribute is per device
+static int set_lds_attrs(int device) {
+  static bool done[64] = {false};
+  if (device >= 0 && device < 64 && done[device]) return TMPC_OK;
   const int big = 160 * 1024;
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_final_stage, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_factor<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm2<2, 2, 5, 5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm2<4, 1, 5, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  done = true;
+  if (device >= 0 && device < 64) done[device] = true;
   return TMPC_OK;
 }
 
-// one chunk (dm.B = actual number of problems in this chunk, <= capacity); inputs already on device
+// ---------------------------------------------------------------------------------- block factorisation / solves (tmpc_cr.h)
+static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
+
+// Cholesky of the block-cyclic-tridiagonal Schur matrices of the `count` problems listed in alist (device), level by level.
+// rs / mt: rows per workgroup of the triangular solves / edge of the output tile of the updates; 0 = by the amount of work
+// (whole 128-wide pieces while every CU still gets several workgroups, 64 otherwise).  The result does not depend on them.
+static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st,
+                      int rs_opt, int mt_opt, std::vector<hipEvent_t>* kev = nullptr, int* nkev = nullptr) {
+  const CrDev cd = cr_dev(sc, d_sched, alist);
+  int ke = 0;
+  // profile mode: an event before and after every launch; pair i belongs to class i % 3 (potrf, trsm, update)
+  auto mark = [&](int cls) {
+    if (!kev) return;
+    while ((int)kev->size() <= ke) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; kev->push_back(e); }
+    (void)cls;
+    hipEventRecord((*kev)[ke++], st);
+  };
+  const bool mf = !(dm.flags & 1);
+  if (sc.prep) hipLaunchKernelGGL(k_cr_prep, dim3(count), dim3(256), 0, st, w, dm, cd, sc.prep);
+  const int nt64 = (dm.dp + 63) / 64;
+  for (const CrLevel& lv : sc.lev) {
+    mark(0);
+    if (mf) hipLaunchKernelGGL(k_cr_potrf<true>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    else hipLaunchKernelGGL(k_cr_potrf<false>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    mark(0);
+    if (lv.nupd == 0) { mark(1); mark(1); mark(2); mark(2); continue; }                  // last node: nothing left to update
+    const long work64 = (long)count * lv.nelim * 2 * nt64;                 // 64-row strips of this level
+    const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
+    const int mt = mt_opt > 0 ? mt_opt : (work64 >= 16384 ? 128 : 64);
+    const int nstrip = (dm.dp + rs - 1) / rs, nm = (dm.dp + mt - 1) / mt;
+    const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
+    const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
+    mark(1);
+    if (mf) hipLaunchKernelGGL(k_cr_trsm<true>, dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
+    else hipLaunchKernelGGL(k_cr_trsm<false>, dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
+    mark(1); mark(2);
+    if (mf) hipLaunchKernelGGL(k_cr_update<true>, dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
+    else hipLaunchKernelGGL(k_cr_update<false>, dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
+    mark(2);
+  }
+  if (nkev) *nkev = ke;
+}
+
+// forward and backward substitution with that factor for the right-hand sides of `pass` (W3 / Z, see cr_nc)
+static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st, int pass) {
+  const CrDev cd = cr_dev(sc, d_sched, alist);
+  const size_t lds = solve_lds(dm);
+  for (const CrLevel& lv : sc.lev) {
+    hipLaunchKernelGGL(k_cr_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
+    if (lv.nupd) hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), lds, st, w, dm, cd, lv.uoff, lv.nupd, count, pass);
+  }
+  for (size_t l = sc.lev.size(); l-- > 0;) {
+    const CrLevel& lv = sc.lev[l];
+    hipLaunchKernelGGL(k_cr_bwd, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
+  }
+}
+
+// one chunk (nb = actual number of problems in this chunk, <= capacity); inputs already on device
 static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
                      const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0) {
   Dims dm = h->dm;
@@ -319,67 +372,68 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   // a handle created with room for G / C rows also serves calls without them; Step 2 (constr) when the C counts are given
   if (!dG) { dm.ng = 0; dm.nr = 0; dm.nz = 0; }
   dm.constr = (dG && dncnt) ? 1 : 0;
-  if (dG && !dncnt) { dm.nr = dm.ng; }
-  // stage-local multipliers: inside the blocks (block size d + nz) unless TMPC_FLAG_ELIM asks for the eliminated form
-  const bool aug = dm.nr > 0 && !(h->flags & TMPC_FLAG_ELIM);
-  if (dm.nr > 0 && !aug && ((size_t)5 * dm.nr * dm.d * sizeof(double) > (size_t)160 * 1024 || dm.nz > 32)) {
-    snprintf(g_err, sizeof(g_err), "TMPC_FLAG_ELIM keeps 5*(ng+nc)*d doubles in LDS and inverts at most 32 x 32: (ng+nc)*d <= 4096 and ng+nc+2 <= 32 needed (got %d rows, d = %d)", dm.nr, dm.d);
-    return TMPC_E_UNSUPPORTED;
-  }
-  dm.dp = (dm.d + (aug ? dm.nz : 0) + 15) / 16 * 16;
+  if (dG && !dncnt) { dm.nr = dm.ng; dm.nz = dm.ng; }
+  // stage-local multipliers ride inside the blocks (block size d + nz)
+  const bool eq = dm.nr > 0;
+  dm.dp = (dm.d + (eq ? dm.nz : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
-  WS w = h->ws;
-  w.A = dA; w.Bm = dB; w.H = dH; w.G = dG; w.ncnt = dncnt; w.rho = rho;
+  WS wall = h->ws;                       // view over ALL problems of the chunk (init / final kernels)
+  wall.A = dA; wall.Bm = dB; wall.H = dH; wall.G = dG; wall.ncnt = dncnt; wall.rho = rho;
+  wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
+  WS w = wall;                           // view over the problems still iterating (per-iteration kernels map blockIdx through alist)
+  int* alist = wall.alist;
+  wall.alist = nullptr;
   const Opts o = h->opt;
-  const int BP = nb * dm.p;
-  const bool eq = dm.nr > 0;
-  const size_t phi_schur_lds = (size_t)5 * dm.nr * dm.d * sizeof(double);
+  const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
   HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
-  hipLaunchKernelGGL(k_init_stage, dim3(BP), dim3(64), slots_bytes(2), st, w, dm);
-  hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, w, dm);
-  hipLaunchKernelGGL(k_init_state, dim3(BP), dim3(64), 0, st, w, dm);
-  if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BP), dim3(64), 0, st, w, dm);
+  hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
+  {
+    WS wi = wall; wi.alist = alist;      // k_init_prob fills the list (its own index is blockIdx: alist is only written)
+    hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, wi, dm);
+  }
+  hipLaunchKernelGGL(k_init_state, dim3(BPall), dim3(64), 0, st, wall, dm);
+  if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BPall), dim3(64), 0, st, wall, dm);
   int active = 0;
   HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   const int cap = o.max_iter + o.center_iter + 2;
   int it = 0;
   while (active > 0 && it < cap) {
+    const int BP = active * dm.p;        // grids cover the problems still iterating only
     if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, aug ? 1 : 0);
-    hipLaunchKernelGGL(k_ctrl_a, dim3(nb), dim3(64), 0, st, w, dm, o);
+    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
+    hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
-    if (eq && !aug) hipLaunchKernelGGL(k_phi_schur, dim3(BP), dim3(256), phi_schur_lds, st, w, dm);
-    if (aug) hipLaunchKernelGGL(k_aug_fill, dim3(BP), dim3(64), 0, st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_aug_fill, dim3(BP), dim3(64), 0, st, w, dm);
     if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
-    if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
-    else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), st, w, dm);
+    int nkev = 0;
+    cr_factor(w, dm, h->sched, h->d_sched, alist, active, st, h->rs, h->mt, prof ? &h->kev : nullptr, &nkev);
     if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, aug ? 1 : 0);
+      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      if (eq && !aug) hipLaunchKernelGGL(k_phi_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      if (aug) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      hipLaunchKernelGGL(k_solve, dim3(nb), dim3(256), solve_lds(dm), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, aug ? 1 : 0);
+      if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass);
+      hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm, pass);
+      if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (pass == 1) {
-        hipLaunchKernelGGL(k_ctrl_b, dim3(nb), dim3(64), 0, st, w, dm);
+        hipLaunchKernelGGL(k_ctrl_b, dim3(active), dim3(64), 0, st, w, dm);
         if (prof) HIPCHK(hipEventRecord(h->ev[4], st));
       } else {
-        hipLaunchKernelGGL(k_ctrl_c, dim3(nb), dim3(64), 0, st, w, dm);
+        hipLaunchKernelGGL(k_ctrl_c, dim3(active), dim3(64), 0, st, w, dm);
       }
     }
     hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BP + 63) / 64), dim3(64), 0, st, w, dm);
+    if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(h->ev[5], st));
@@ -389,21 +443,30 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
       float ms;
       for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1])); h->prof[i] += ms; }
       h->prof[5] += 1.0;
+      h->prof[8] += (double)active;
+      for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1])); h->prof[9 + (i / 2) % 3] += ms; }
     }
     ++it;
   }
   h->prof[7] += it;
-  hipLaunchKernelGGL(k_final_stage, dim3(BP), dim3(64), slots_bytes(FIN_SLOTS), st, w, dm);
-  hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, w, dm);
+  hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
+  hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, wall, dm);
   HIPCHK(hipGetLastError());
   return TMPC_OK;
 }
+
+// every entry point runs on the device the handle was created on (kernel attributes and the workspace belong to it)
+#define ON_DEVICE(h)                                                                              \
+  do {                                                                                            \
+    int cur_ = -1;                                                                                \
+    if (hipGetDevice(&cur_) != hipSuccess || cur_ != (h)->device) HIPCHK(hipSetDevice((h)->device)); \
+  } while (0)
 
 // ---------------------------------------------------------------------------------- C ABI
 extern "C" {
 
 const char* tmpc_last_error(void) { return g_err; }
-const char* tmpc_version(void) { return "tunempc_amd 0.1 (gfx950, fp64 MFMA)"; }
+const char* tmpc_version(void) { return "tunempc_amd 0.2 (gfx950, fp64 MFMA, cyclic-reduction block factorisation)"; }
 
 int tmpc_device_count(void) {
   int n = 0;
@@ -445,21 +508,29 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
     uint64_t fit = (uint64_t)(0.6 * (double)fr) / std::max<uint64_t>(per, 1);
     chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(512, fit));
   }
-  tmpc_handle* h = (tmpc_handle*)calloc(1, sizeof(tmpc_handle));
+  tmpc_handle* h = new (std::nothrow) tmpc_handle();
   if (!h) return TMPC_E_NOMEM;
+  memset(h->prof, 0, sizeof(h->prof)); h->slab = nullptr; h->d_sched = nullptr;
+  h->dA = h->dB = h->dH = h->dG = nullptr; h->dncnt = nullptr; h->d_info = h->d_abk = nullptr; h->d_si = nullptr;
+  if (hipGetDevice(&h->device) != hipSuccess) { delete h; return TMPC_E_HIP; }
   h->dm = make_dims(chunk, p, nx, mb, ng, nc);
+  h->sched = cr_build(p);
+  { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
+  { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
   h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
   if (hipMalloc(&h->slab, h->slab_bytes) != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "hipMalloc(%zu bytes) failed", h->slab_bytes);
-    free(h);
+    delete h;
     return TMPC_E_NOMEM;
   }
   carve(h->ws, h->dm, (char*)h->slab, h);
-  for (int i = 0; i < 8; ++i) { if (hipEventCreate(&h->ev[i]) != hipSuccess) { hipFree(h->slab); free(h); return TMPC_E_HIP; } }
-  int rc = set_lds_attrs();
-  if (rc != TMPC_OK) { hipFree(h->slab); free(h); return rc; }
+  int rc = cr_upload(h->sched, &h->d_sched);
+  if (rc != TMPC_OK) { hipFree(h->slab); delete h; return rc; }
+  for (int i = 0; i < 8; ++i) { if (hipEventCreate(&h->ev[i]) != hipSuccess) { hipFree(h->slab); hipFree(h->d_sched); delete h; return TMPC_E_HIP; } }
+  rc = set_lds_attrs(h->device);
+  if (rc != TMPC_OK) { hipFree(h->slab); hipFree(h->d_sched); delete h; return rc; }
   *out = h;
   return TMPC_OK;
 }
@@ -467,8 +538,10 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
 int tmpc_destroy(tmpc_handle* h) {
   if (!h) return TMPC_E_ARG;
   for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
+  for (hipEvent_t e : h->kev) hipEventDestroy(e);
   hipFree(h->slab);
-  free(h);
+  hipFree(h->d_sched);
+  delete h;
   return TMPC_OK;
 }
 
@@ -518,9 +591,9 @@ int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t co
   return TMPC_OK;
 }
 
-int tmpc_get_profile(tmpc_handle* h, double* out8) {
-  if (!h || !out8) return TMPC_E_ARG;
-  for (int i = 0; i < 8; ++i) { out8[i] = h->prof[i]; h->prof[i] = 0.0; }
+int tmpc_get_profile(tmpc_handle* h, double* out16) {
+  if (!h || !out16) return TMPC_E_ARG;
+  for (int i = 0; i < 16; ++i) { out16[i] = h->prof[i]; h->prof[i] = 0.0; }
   return TMPC_OK;
 }
 
@@ -547,7 +620,9 @@ static int copy_out(tmpc_handle* h, int nb, size_t off, double* Hc, double* dHc,
 int tmpc_convexify_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH,
                                 double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
                                 int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (h && nbt == 0) return TMPC_OK;           // empty shard
   if (!h || nbt < 1 || !dA || !dH || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
@@ -573,7 +648,9 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nbt, const double* dA, const
 int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH, const double* dJ,
                                     const int32_t* d_ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (h && nbt == 0) return TMPC_OK;           // empty shard
   if (!h || nbt < 1 || !dA || !dH || !dJ || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  ON_DEVICE(h);
   const Dims& dm = h->dm;
   if (d_ncnt ? (dm.nz <= dm.nr || !(rho > 0.0)) : dm.ng < 1) {
     snprintf(g_err, sizeof(g_err), "handle has no room for this call (Step 2 needs tmpc_create_con with nc > 0 and rho > 0, Step 1 with G needs ng > 0)");
@@ -598,7 +675,9 @@ int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, c
 int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H,
                               double* Hc, double* dHc, double* P, double* alpha, double* beta, double* kappa,
                               int32_t* status, int32_t* iters, double* info) {
+  if (h && nbt == 0) return TMPC_OK;
   if (!h || nbt < 1 || !A || !H || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  ON_DEVICE(h);
   hipStream_t st = 0;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
@@ -621,6 +700,7 @@ int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nbt, const double* A, const
                                  int32_t* status, int32_t* iters, double* info) {
   if (!h || nbt < 1 || !A || !H || !G || !Fg || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
   if (h->dm.ng < 1) { snprintf(g_err, sizeof(g_err), "handle was created without equality-constraint rows (use tmpc_create_eq)"); return TMPC_E_ARG; }
+  ON_DEVICE(h);
   hipStream_t st = 0;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.ng * dm.n;
@@ -649,6 +729,7 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, co
   const int ncmax = dm.nr - dm.ng;
   for (size_t i = 0; i < (size_t)nbt * dm.p; ++i)
     if (ncnt[i] < 0 || ncnt[i] > ncmax) { snprintf(g_err, sizeof(g_err), "ncnt[%zu]=%d outside 0..%d", i, ncnt[i], ncmax); return TMPC_E_ARG; }
+  ON_DEVICE(h);
   hipStream_t st = 0;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.nr * dm.n;
   for (int off = 0; off < nbt; off += dm.B) {
@@ -674,9 +755,11 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* h, int nbt, const double* A, c
   hipStream_t st = 0;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
-  double *dJ = nullptr, *dw = nullptr;
+  ON_DEVICE(h);
+  DevBuf bJ, bw;
   const size_t capst = (size_t)dm.B * dm.p;             // stages per chunk
-  if (J) { HIPCHK(hipMalloc(&dJ, capst * nr * dm.n * 8)); HIPCHK(hipMalloc(&dw, capst * nr * 8)); }
+  if (J) { HIPCHK(bJ.alloc(capst * nr * dm.n * 8)); HIPCHK(bw.alloc(capst * nr * 8)); }
+  double* dJ = J ? bJ.as<double>() : nullptr; double* dw = J ? bw.as<double>() : nullptr;
   for (int off = 0; off < nbt; off += dm.B) {
     const int nb = std::min(dm.B, nbt - off);
     const size_t BP = (size_t)nb * dm.p, so = (size_t)off * dm.p;
@@ -694,8 +777,6 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* h, int nbt, const double* A, c
     HIPCHK(hipMemcpyAsync(dHc + so * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
-  if (dJ) hipFree(dJ);
-  if (dw) hipFree(dw);
   return TMPC_OK;
 }
 
@@ -705,6 +786,7 @@ int tmpc_supplement_batch_host(tmpc_handle* h, int nbt, const double* A, const d
 
 int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
   if (!h || nbt < 1 || !H || !out) return TMPC_E_ARG;
+  ON_DEVICE(h);
   hipStream_t st = 0;
   const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n;
@@ -719,23 +801,18 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
   return TMPC_OK;
 }
 
-// var 1: 160 x 160 tiles (5 x 5 fragments per wave), 2: 320 x 64 (5 x 4); one workgroup per CU
-static void launch_gemm2(int var, int nb, double* dC, const double* dA, const double* dB, int M, int N, int K, int mode, int tri, int reps) {
-  if (var == 1) hipLaunchKernelGGL((k_debug_gemm2<2, 2, 5, 5, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
-  else hipLaunchKernelGGL((k_debug_gemm2<4, 1, 5, 4, 1>), dim3(nb), dim3(256), gemm2_lds(), 0, dC, dA, dB, M, N, K, mode, tri, reps);
-}
-
 int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, const double* q, const double* wref,
                                  double ts, double* W, double* yref, int32_t* info) {
   if (!h || nstage < 1 || !Hc || !q || !wref || !yref || !(ts > 0.0)) return TMPC_E_ARG;
+  ON_DEVICE(h);
   const int n = h->dm.n;
   const size_t nn = (size_t)n * n;
-  double *dH = nullptr, *dW = nullptr, *dv = nullptr;     // dv: q | wref | yref
-  int* di = nullptr;
-  HIPCHK(hipMalloc(&dH, (size_t)nstage * nn * 8));
-  if (W) HIPCHK(hipMalloc(&dW, (size_t)nstage * nn * 8));
-  HIPCHK(hipMalloc(&dv, (size_t)nstage * n * 3 * 8));
-  HIPCHK(hipMalloc(&di, (size_t)nstage * sizeof(int)));
+  DevBuf bH, bW, bv, bi;                                   // bv: q | wref | yref
+  HIPCHK(bH.alloc((size_t)nstage * nn * 8));
+  if (W) HIPCHK(bW.alloc((size_t)nstage * nn * 8));
+  HIPCHK(bv.alloc((size_t)nstage * n * 3 * 8));
+  HIPCHK(bi.alloc((size_t)nstage * sizeof(int)));
+  double* dH = bH.as<double>(); double* dW = W ? bW.as<double>() : nullptr; double* dv = bv.as<double>(); int* di = bi.as<int>();
   HIPCHK(hipMemcpy(dH, Hc, (size_t)nstage * nn * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dv, q, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dv + (size_t)nstage * n, wref, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
@@ -745,93 +822,144 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
   HIPCHK(hipMemcpy(yref, dv + (size_t)2 * nstage * n, (size_t)nstage * n * 8, hipMemcpyDeviceToHost));
   if (W) HIPCHK(hipMemcpy(W, dW, (size_t)nstage * nn * 8, hipMemcpyDeviceToHost));
   if (info) HIPCHK(hipMemcpy(info, di, (size_t)nstage * sizeof(int), hipMemcpyDeviceToHost));
-  hipFree(dH); if (dW) hipFree(dW); hipFree(dv); hipFree(di);
   return TMPC_OK;
 }
 
+// ---------------------------------------------------------------------------------- debug / unit-test entries (tunempc_hip_debug.h)
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
-  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16) return TMPC_E_ARG;
-  double *dC, *dA, *dB;
-  HIPCHK(hipMalloc(&dC, (size_t)M * N * 8)); HIPCHK(hipMalloc(&dA, (size_t)M * K * 8)); HIPCHK(hipMalloc(&dB, (size_t)N * K * 8));
+  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16 || mode < 0 || mode > 2) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  DevBuf bC, bA, bB;
+  HIPCHK(bC.alloc((size_t)M * N * 8)); HIPCHK(bA.alloc((size_t)M * K * 8)); HIPCHK(bB.alloc((size_t)N * K * 8));
+  double* dC = bC.as<double>(); double* dA = bA.as<double>(); double* dB = bB.as<double>();
   HIPCHK(hipMemcpy(dC, C, (size_t)M * N * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dB, B, (size_t)N * K * 8, hipMemcpyHostToDevice));
-  const int var = (mode >> 4) & 7; mode &= 3;
-  if (var) launch_gemm2(var, 1, dC, dA, dB, M, N, K, mode, lower, 1);
-  else if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   else hipLaunchKernelGGL(k_debug_gemm<true>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(C, dC, (size_t)M * N * 8, hipMemcpyDeviceToHost));
-  hipFree(dC); hipFree(dA); hipFree(dB);
-  return TMPC_OK;
-}
-
-// Batched timing of one GEMM core: nb workgroups with private operands (HBM-realistic), reps products per launch.
-// var 0: first-generation 64 x 64 core, 1: 160 x 160 register tiles, 2: 320 x 80.  ms_out = average launch time.
-int tmpc_debug_gemm_bench(tmpc_handle* h, int nb, int M, int N, int K, int var, int tri, int reps, int launches, double* ms_out) {
-  const int gmode = (tri >> 8) & 7; tri &= 255;     // bits 8-10: kernel mode (4/5 = timing experiments without DMA / without DMA and LDS fetch)
-  if (!h || nb < 1 || M % 16 || N % 16 || K % 16 || K < 16 || reps < 1 || launches < 1 || !ms_out) return TMPC_E_ARG;
-  double *dC, *dA, *dB;
-  const size_t nC = (size_t)nb * M * N, nA = (size_t)nb * M * K, nB = (size_t)nb * N * K;
-  HIPCHK(hipMalloc(&dC, nC * 8)); HIPCHK(hipMalloc(&dA, nA * 8)); HIPCHK(hipMalloc(&dB, nB * 8));
-  HIPCHK(hipMemset(dC, 0, nC * 8));
-  {
-    std::vector<double> hA((size_t)M * K), hB((size_t)N * K);
-    unsigned long long st = 88172645463325252ull;
-    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((double)(st % 2000001) / 1000000.0 - 1.0) / sqrt((double)K); };
-    for (auto& x : hA) x = rnd();
-    for (auto& x : hB) x = rnd();
-    for (int b = 0; b < nb; ++b) {
-      HIPCHK(hipMemcpy(dA + (size_t)b * M * K, hA.data(), hA.size() * 8, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(dB + (size_t)b * N * K, hB.data(), hB.size() * 8, hipMemcpyHostToDevice));
-    }
-  }
-  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  double tot = 0.0;
-  for (int r = 0; r < launches + 1; ++r) {
-    HIPCHK(hipEventRecord(e0, 0));
-    if (var) launch_gemm2(var, nb, dC, dA, dB, M, N, K, gmode, tri, reps);
-    else hipLaunchKernelGGL(k_debug_gemm1<true>, dim3(nb), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, 0, tri, reps);
-    HIPCHK(hipEventRecord(e1, 0));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    if (r > 0) tot += ms;
-  }
-  *ms_out = tot / launches;
-  hipFree(dC); hipFree(dA); hipFree(dB); hipEventDestroy(e0); hipEventDestroy(e1);
   return TMPC_OK;
 }
 
 // smallest eigenvalue of nmat symmetric n x n matrices (the step-length primitive of k_eigmin)
 int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out) {
   if (!h || nmat < 1 || n < 1 || n > NMAX || !W || !out) return TMPC_E_ARG;
-  double *dW, *dO;
-  HIPCHK(hipMalloc(&dW, (size_t)nmat * n * n * 8)); HIPCHK(hipMalloc(&dO, (size_t)nmat * 8));
-  HIPCHK(hipMemcpy(dW, W, (size_t)nmat * n * n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_debug_min_eig, dim3(nmat), dim3(64), (size_t)(MS + 160) * sizeof(double), 0, dW, dO, n);
+  ON_DEVICE(h);
+  DevBuf bW, bO;
+  HIPCHK(bW.alloc((size_t)nmat * n * n * 8)); HIPCHK(bO.alloc((size_t)nmat * 8));
+  HIPCHK(hipMemcpy(bW.p, W, (size_t)nmat * n * n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_min_eig, dim3(nmat), dim3(64), (size_t)(MS + 160) * sizeof(double), 0, bW.as<double>(), bO.as<double>(), n);
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, dO, (size_t)nmat * 8, hipMemcpyDeviceToHost));
-  hipFree(dW); hipFree(dO);
+  HIPCHK(hipMemcpy(out, bO.p, (size_t)nmat * 8, hipMemcpyDeviceToHost));
   return TMPC_OK;
 }
 
-// Isolated timing of k_factor (variant A/B): nb copies of one random SPD block-cyclic-tridiagonal system.
-// ms_out[v] = average kernel time of variant v over `reps` launches (inputs restored before every launch).
+// The elimination schedule of the block factorisation for period p (host only, no device): out = [nlev, prep, nelim, nupd,
+// levels (eoff, nelim, uoff, nupd) x nlev, elimination records x 8 ints, update records x 8 ints, orientation x p].
+// Returns the number of ints (call with cap = 0 to size the buffer), or TMPC_E_ARG.
+int tmpc_debug_cr_schedule(int p, int32_t* out, int cap) {
+  if (p < 1) return TMPC_E_ARG;
+  const CrSched sc = cr_build(p);
+  std::vector<int> flat;
+  flat.push_back((int)sc.lev.size()); flat.push_back(sc.prep); flat.push_back((int)sc.elim.size() / CR_EW); flat.push_back((int)sc.upd.size() / CR_UW);
+  for (const CrLevel& lv : sc.lev) { flat.push_back(lv.eoff); flat.push_back(lv.nelim); flat.push_back(lv.uoff); flat.push_back(lv.nupd); }
+  flat.insert(flat.end(), sc.elim.begin(), sc.elim.end());
+  flat.insert(flat.end(), sc.upd.begin(), sc.upd.end());
+  flat.insert(flat.end(), sc.orient.begin(), sc.orient.end());
+  if (out && cap >= (int)flat.size()) memcpy(out, flat.data(), flat.size() * sizeof(int));
+  return (int)flat.size();
+}
+
+// stand-alone workspace for the unit test / timing of the block factorisation: nb copies of one system
+struct CrBench {
+  WS w; Dims dm; CrSched sc; int* d_sched = nullptr; DevBuf D, O, F, Li, dd, Z, W3, ip, pr, al;
+  int init(int nb, int p, int d, int flags) {
+    memset(&w, 0, sizeof(w)); memset(&dm, 0, sizeof(dm));
+    dm.B = nb; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB; dm.flags = flags & TMPC_FLAG_NO_MFMA;
+    const size_t bs = (size_t)dm.dp * dm.dp, per = (size_t)p * bs;
+    sc = cr_build(p);
+    int rc = cr_upload(sc, &d_sched);
+    if (rc != TMPC_OK) return rc;
+    if (D.alloc(nb * per * 8) != hipSuccess || O.alloc(nb * per * 8) != hipSuccess || F.alloc(nb * per * 8) != hipSuccess ||
+        Li.alloc((size_t)nb * p * dm.nt * TB * TB * 8) != hipSuccess || dd.alloc((size_t)nb * p * dm.dp * 8) != hipSuccess ||
+        Z.alloc((size_t)nb * p * dm.dp * 8) != hipSuccess || W3.alloc((size_t)nb * p * dm.dp * 3 * 8) != hipSuccess ||
+        ip.alloc((size_t)nb * IS * sizeof(int)) != hipSuccess || pr.alloc((size_t)nb * PS * 8) != hipSuccess || al.alloc((size_t)nb * sizeof(int)) != hipSuccess)
+      return TMPC_E_NOMEM;
+    w.D = D.as<double>(); w.O = O.as<double>(); w.F = F.as<double>(); w.Linv = Li.as<double>(); w.Ddiag = dd.as<double>();
+    w.Z = Z.as<double>(); w.W3 = W3.as<double>(); w.iprob = ip.as<int>(); w.prob = pr.as<double>(); w.alist = al.as<int>();
+    std::vector<int> ids(nb); for (int i = 0; i < nb; ++i) ids[i] = i;
+    std::vector<double> one((size_t)nb * PS, 1.0);
+    if (hipMemcpy(w.alist, ids.data(), nb * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return TMPC_E_HIP;
+    if (hipMemset(w.iprob, 0, (size_t)nb * IS * sizeof(int)) != hipSuccess) return TMPC_E_HIP;       // phase = PH_MAIN
+    if (hipMemcpy(w.prob, one.data(), one.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return TMPC_E_HIP;
+    return TMPC_OK;
+  }
+  ~CrBench() { if (d_sched) hipFree(d_sched); }
+};
+
+// host image of one system in the storage of tmpc_cr.h: D [p][dp][dp] (identity padding), edge slot k in the orientation of the schedule
+static void cr_pack(const CrSched& sc, int p, int d, int dp, const double* D, const double* Ccpl, std::vector<double>& hD, std::vector<double>& hO,
+                    std::vector<double>& hdd) {
+  const size_t bs = (size_t)dp * dp;
+  hD.assign(p * bs, 0.0); hO.assign(p * bs, 0.0); hdd.assign((size_t)p * dp, 1.0);
+  for (int k = 0; k < p; ++k) {
+    for (int i = 0; i < dp; ++i)
+      for (int j = 0; j < dp; ++j) {
+        double dv = (i == j) ? 1.0 : 0.0, cv = 0.0;
+        if (i < d && j < d) { dv = D[((size_t)k * d + i) * d + j]; cv = Ccpl[((size_t)k * d + i) * d + j]; }    // Ccpl[k] = T[block k, block k+1]
+        hD[k * bs + (size_t)i * dp + j] = dv;
+        if (sc.orient[k]) hO[k * bs + (size_t)i * dp + j] = cv; else hO[k * bs + (size_t)j * dp + i] = cv;
+      }
+    for (int i = 0; i < d; ++i) hdd[(size_t)k * dp + i] = D[((size_t)k * d + i) * d + i];
+  }
+}
+
+// Factor + solve one block-cyclic-tridiagonal system given dense blocks (unit test of the kernels of tmpc_cr.h):
+// D [p][d][d] diagonal blocks, Ccpl [p][d][d] with Ccpl[k] = T[block k, block k+1 mod p], rhs/x [p][d].
+int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift) {
+  if (!h || p < 1 || d < 1 || !D || !Ccpl || !rhs || !x) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  CrBench cb;
+  int rc = cb.init(1, p, d, h->flags);
+  if (rc != TMPC_OK) return rc;
+  const int dp = cb.dm.dp;
+  const size_t bs = (size_t)dp * dp;
+  std::vector<double> hD, hO, hdd, hz((size_t)p * dp, 0.0);
+  cr_pack(cb.sc, p, d, dp, D, Ccpl, hD, hO, hdd);
+  for (int k = 0; k < p; ++k) for (int i = 0; i < d; ++i) hz[(size_t)k * dp + i] = rhs[(size_t)k * d + i];
+  HIPCHK(hipMemcpy(cb.w.D, hD.data(), p * bs * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cb.w.O, hO.data(), p * bs * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cb.w.Ddiag, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(cb.w.Z, hz.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, 1, 0, h->rs, h->mt);
+  cr_solve(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, 1, 0, 2);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipGetLastError());
+  int hip_[IS];
+  HIPCHK(hipMemcpy(hz.data(), cb.w.Z, (size_t)p * dp * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hip_, cb.w.iprob, sizeof(hip_), hipMemcpyDeviceToHost));
+  for (int k = 0; k < p; ++k) for (int i = 0; i < d; ++i) x[(size_t)k * d + i] = hz[(size_t)k * dp + i];
+  if (nshift) *nshift = hip_[I_NSHIFT];
+  return TMPC_OK;
+}
+
+// Isolated timing of the block factorisation and of one single-right-hand-side solve: nb copies of one random SPD
+// block-cyclic-tridiagonal system (restored before every repetition).  ms_out2[0] = factorisation, [1] = solve, averages over `reps`.
 int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, double* ms_out2) {
-  if (!h || nb < 1 || p < 2 || d < 1 || reps < 1 || !ms_out2) return TMPC_E_ARG;
-  Dims dm; memset(&dm, 0, sizeof(dm));
-  dm.B = nb; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB;
-  const int dp = dm.dp;
+  if (!h || nb < 1 || p < 1 || d < 1 || reps < 1 || !ms_out2) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  CrBench cb;
+  int rc = cb.init(nb, p, d, h->flags);
+  if (rc != TMPC_OK) return rc;
+  const int dp = cb.dm.dp;
   const size_t bs = (size_t)dp * dp, per = (size_t)p * bs;
-  std::vector<double> hD(per, 0.0), hO(per, 0.0), hF(per, 0.0), hdd((size_t)p * dp, 1.0);
-  // T = sum_k J_k' J_k + I  with J_k = [E_k F_k] on blocks (k, k+1): SPD by construction
-  std::vector<double> E((size_t)p * d * d), G((size_t)p * d * d);
+  // T = sum_k J_k' J_k + I  with J_k = [E_k G_k] on blocks (k, k+1): SPD by construction
+  std::vector<double> E((size_t)p * d * d), G((size_t)p * d * d), Dd((size_t)p * d * d, 0.0), Cc((size_t)p * d * d, 0.0);
   unsigned long long st = 88172645463325252ull;
   auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((double)(st % 2000001) / 1000000.0 - 1.0) / sqrt((double)d); };
-  for (auto& x : E) x = rnd();
-  for (auto& x : G) x = rnd();
-  for (int k = 0; k < p; ++k)
-    for (int i = 0; i < dp; ++i) hD[k * bs + (size_t)i * dp + i] = 1.0;
+  for (auto& v : E) v = rnd();
+  for (auto& v : G) v = rnd();
   for (int k = 0; k < p; ++k) {
     const int kn = (k + 1) % p;
     const double* Ek = &E[(size_t)k * d * d]; const double* Gk = &G[(size_t)k * d * d];
@@ -839,98 +967,50 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
       for (int j = 0; j < d; ++j) {
         double ee = 0, gg = 0, eg = 0;
         for (int r = 0; r < d; ++r) { ee += Ek[r * d + i] * Ek[r * d + j]; gg += Gk[r * d + i] * Gk[r * d + j]; eg += Ek[r * d + i] * Gk[r * d + j]; }
-        hD[k * bs + (size_t)i * dp + j] += ee; hD[kn * bs + (size_t)i * dp + j] += gg;
-        if (k == p - 1) hF[(size_t)i * dp + j] = eg; else hO[k * bs + (size_t)j * dp + i] = eg;
+        Dd[((size_t)k * d + i) * d + j] += ee + (i == j ? 1.0 : 0.0); Dd[((size_t)kn * d + i) * d + j] += gg;
+        Cc[((size_t)k * d + i) * d + j] = eg;
       }
   }
-  for (int k = 0; k < p; ++k) for (int i = 0; i < dp; ++i) hdd[(size_t)k * dp + i] = hD[k * bs + (size_t)i * dp + i];
-  WS w; memset(&w, 0, sizeof(w));
-  double *pD, *pO, *pF;
-  HIPCHK(hipMalloc(&pD, per * 8)); HIPCHK(hipMalloc(&pO, per * 8)); HIPCHK(hipMalloc(&pF, per * 8));
-  HIPCHK(hipMalloc(&w.D, nb * per * 8)); HIPCHK(hipMalloc(&w.O, nb * per * 8)); HIPCHK(hipMalloc(&w.F, nb * per * 8));
-  HIPCHK(hipMalloc(&w.Linv, (size_t)nb * p * dm.nt * TB * TB * 8)); HIPCHK(hipMalloc(&w.Ddiag, (size_t)nb * p * dp * 8));
-  HIPCHK(hipMalloc(&w.iprob, (size_t)nb * IS * sizeof(int)));
-  HIPCHK(hipMemset(w.iprob, 0, (size_t)nb * IS * sizeof(int)));
-  HIPCHK(hipMemcpy(pD, hD.data(), per * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(pO, hO.data(), per * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(pF, hF.data(), per * 8, hipMemcpyHostToDevice));
-  for (int b = 0; b < nb; ++b) HIPCHK(hipMemcpy(w.Ddiag + (size_t)b * p * dp, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  for (int v = 0; v < 2; ++v) ms_out2[v] = 0.0;
+  std::vector<double> hD, hO, hdd;
+  cr_pack(cb.sc, p, d, dp, Dd.data(), Cc.data(), hD, hO, hdd);
+  DevBuf pD, pO;
+  HIPCHK(pD.alloc(per * 8)); HIPCHK(pO.alloc(per * 8));
+  HIPCHK(hipMemcpy(pD.p, hD.data(), per * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(pO.p, hO.data(), per * 8, hipMemcpyHostToDevice));
+  for (int b = 0; b < nb; ++b) HIPCHK(hipMemcpy(cb.w.Ddiag + (size_t)b * p * dp, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(cb.w.Z, 0, (size_t)nb * p * dp * 8));
+  hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  ms_out2[0] = ms_out2[1] = 0.0;
   for (int r = 0; r < reps + 1; ++r) {
-    for (int v = 0; v < 2; ++v) {
-      for (int b = 0; b < nb; ++b) {
-        HIPCHK(hipMemcpyAsync(w.D + b * per, pD, per * 8, hipMemcpyDeviceToDevice, 0));
-        HIPCHK(hipMemcpyAsync(w.O + b * per, pO, per * 8, hipMemcpyDeviceToDevice, 0));
-        HIPCHK(hipMemcpyAsync(w.F + b * per, pF, per * 8, hipMemcpyDeviceToDevice, 0));
-      }
-      HIPCHK(hipEventRecord(e0, 0));
-      if (v == 0) hipLaunchKernelGGL((k_factor<true, 0>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      else hipLaunchKernelGGL((k_factor<true, 1>), dim3(nb), dim3(256), factor_lds(), 0, w, dm);
-      HIPCHK(hipEventRecord(e1, 0));
-      HIPCHK(hipEventSynchronize(e1));
-      float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-      if (r > 0) ms_out2[v] += ms / reps;
+    for (int b = 0; b < nb; ++b) {
+      HIPCHK(hipMemcpyAsync(cb.w.D + b * per, pD.p, per * 8, hipMemcpyDeviceToDevice, 0));
+      HIPCHK(hipMemcpyAsync(cb.w.O + b * per, pO.p, per * 8, hipMemcpyDeviceToDevice, 0));
     }
+    HIPCHK(hipEventRecord(e0, 0));
+    cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, nb, 0, h->rs, h->mt);
+    HIPCHK(hipEventRecord(e1, 0));
+    cr_solve(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, nb, 0, 2);
+    HIPCHK(hipEventRecord(e2, 0));
+    HIPCHK(hipEventSynchronize(e2));
+    float ms0, ms1; HIPCHK(hipEventElapsedTime(&ms0, e0, e1)); HIPCHK(hipEventElapsedTime(&ms1, e1, e2));
+    if (r > 0) { ms_out2[0] += ms0 / reps; ms_out2[1] += ms1 / reps; }
   }
-  int nsh = 0; HIPCHK(hipMemcpy(&nsh, w.iprob + I_NSHIFT, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipGetLastError());
+  int nsh = 0; HIPCHK(hipMemcpy(&nsh, cb.w.iprob + I_NSHIFT, sizeof(int), hipMemcpyDeviceToHost));
   if (nsh) { snprintf(g_err, sizeof(g_err), "factor bench: %d shifted pivots", nsh); }
-  hipFree(pD); hipFree(pO); hipFree(pF); hipFree(w.D); hipFree(w.O); hipFree(w.F); hipFree(w.Linv); hipFree(w.Ddiag); hipFree(w.iprob);
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
   return TMPC_OK;
 }
 
 #ifdef TMPC_CYCLE_PROF
-extern "C" int tmpc_debug_cycle_prof(double* out16) {
-  unsigned long long h[16];
-  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(tmpc::g_prof), sizeof(h)));
-  for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+int tmpc_debug_cycle_prof(double* out16) {
+  unsigned long long hh[16];
+  HIPCHK(hipMemcpyFromSymbol(hh, HIP_SYMBOL(tmpc::g_prof), sizeof(hh)));
+  for (int i = 0; i < 16; ++i) out16[i] = (double)hh[i];
   unsigned long long z[16] = {0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tmpc::g_prof), z, sizeof(z)));
   return 0;
 }
 #endif
-
-// Factor + solve one block-cyclic-tridiagonal system given dense blocks (unit test of k_factor / wg_cyclic_solve):
-// D [p][d][d] diagonal blocks, Ccpl [p][d][d] with Ccpl[k] = T[block k, block k+1 mod p], rhs/x [p][d].
-int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const double* Ccpl, const double* rhs, double* x, int32_t* nshift) {
-  if (!h || p < 1 || d < 1 || !D || !Ccpl || !rhs || !x) return TMPC_E_ARG;
-  Dims dm; memset(&dm, 0, sizeof(dm));
-  dm.B = 1; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB; dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
-  const int dp = dm.dp;
-  const size_t bs = (size_t)dp * dp;
-  std::vector<double> hD(p * bs, 0.0), hO(p * bs, 0.0), hF(p * bs, 0.0), hdd((size_t)p * dp, 1.0), hz((size_t)p * dp, 0.0);
-  for (int k = 0; k < p; ++k) {
-    for (int i = 0; i < dp; ++i)
-      for (int j = 0; j < dp; ++j) {
-        double dv = (i == j) ? 1.0 : 0.0, cv = 0.0;
-        if (i < d && j < d) { dv = D[((size_t)k * d + i) * d + j]; cv = Ccpl[((size_t)k * d + i) * d + j]; }
-        hD[k * bs + (size_t)i * dp + j] = dv;
-        if (k == p - 1) hF[(size_t)i * dp + j] = cv; else hO[k * bs + (size_t)j * dp + i] = cv;
-      }
-    for (int i = 0; i < d; ++i) { hdd[(size_t)k * dp + i] = D[((size_t)k * d + i) * d + i]; hz[(size_t)k * dp + i] = rhs[(size_t)k * d + i]; }
-  }
-  WS w; memset(&w, 0, sizeof(w));
-  int hip_[IS]; memset(hip_, 0, sizeof(hip_));
-  HIPCHK(hipMalloc(&w.D, p * bs * 8)); HIPCHK(hipMalloc(&w.O, p * bs * 8)); HIPCHK(hipMalloc(&w.F, p * bs * 8));
-  HIPCHK(hipMalloc(&w.Linv, (size_t)p * dm.nt * TB * TB * 8)); HIPCHK(hipMalloc(&w.Ddiag, (size_t)p * dp * 8));
-  HIPCHK(hipMalloc(&w.Z, (size_t)p * dp * 8)); HIPCHK(hipMalloc(&w.iprob, sizeof(hip_)));
-  HIPCHK(hipMemcpy(w.D, hD.data(), p * bs * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(w.O, hO.data(), p * bs * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(w.F, hF.data(), p * bs * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(w.Ddiag, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(w.Z, hz.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(w.iprob, hip_, sizeof(hip_), hipMemcpyHostToDevice));
-  if (dm.flags & 1) hipLaunchKernelGGL((k_factor<false, 1>), dim3(1), dim3(256), factor_lds(), 0, w, dm);
-  else hipLaunchKernelGGL((k_factor<true, 1>), dim3(1), dim3(256), factor_lds(), 0, w, dm);
-  hipLaunchKernelGGL(k_debug_solve, dim3(1), dim3(256), solve_lds(dm), 0, w, dm);
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(hz.data(), w.Z, (size_t)p * dp * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hip_, w.iprob, sizeof(hip_), hipMemcpyDeviceToHost));
-  for (int k = 0; k < p; ++k) for (int i = 0; i < d; ++i) x[(size_t)k * d + i] = hz[(size_t)k * dp + i];
-  if (nshift) *nshift = hip_[I_NSHIFT];
-  hipFree(w.D); hipFree(w.O); hipFree(w.F); hipFree(w.Linv); hipFree(w.Ddiag); hipFree(w.Z); hipFree(w.iprob);
-  return TMPC_OK;
-}
 
 }  // extern "C"

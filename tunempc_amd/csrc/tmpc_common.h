@@ -105,8 +105,8 @@ struct WS {
   int* iprob;      // [B,IS]
   // Schur system
   double* D;       // [B,p,dp,dp]   diagonal blocks -> Cholesky factors (diag tiles hold L_jj, inverse in Linv)
-  double* O;       // [B,p,dp,dp]   sub-diagonal blocks T[P_{k+1},P_k] -> O_k
-  double* F;       // [B,p,dp,dp]   cyclic fill row T[P_{p-1},P_k]    -> F_k
+  double* O;       // [B,p,dp,dp]   edge slots 0..p-1: coupling block of stages k, k+1 (orientation cr_orient[k]) -> O factors (tmpc_cr.h)
+  double* F;       // [B,p,dp,dp]   edge slots p..2p-1: fill blocks of the cyclic reduction
   double* Linv;    // [B,p,nt,TB,TB] inverses of the diagonal tiles
   double* Ddiag;   // [B,p,dp]      assembled diagonal of D (pivot reference for Cholesky-with-shift)
   double* W3;      // [B,p,dp,3]    pass-1 right-hand sides [rhs | u_tau | u_alpha] -> solutions
@@ -114,6 +114,9 @@ struct WS {
   double* TU;      // [B,p,dp,2]    T^-1 U
   double* Z;       // [B,p,dp]      rhs / solution
   int* active;     // [1] number of problems still iterating
+  int* alist;      // [B] their indices, compacted (written by k_init_prob / k_ctrl_d).  The per-iteration kernels are launched over
+                   // `active` problems and map blockIdx through this list; nullptr = identity (init / final kernels, all problems)
+  const int* cr_orient;  // [p] storage orientation of the coupling block of stage k (tmpc_cr.h): 0: T[P_{k+1},P_k], 1: T[P_k,P_{k+1}]
   double* trace;   // [B][TRACE_LEN][TRACE_W] per-iteration diagnostics (it, phase, mu, tau, pinf, dinf, ap, ad, stepn, shifts)
   // outputs
   double* Hc;      // [B,p,n,n]
@@ -134,5 +137,14 @@ struct WS {
   double* aSi; double* aLi; double* aLXi; // [B,p,2,AE] S^-1, L_S^-1, L_X^-1
   double* asum;    // [B,p,5]   <dX,S>, <X,dS>, <dX,dS>, min eig dual, min eig primal of the arrow blocks (joined in k_phi_steps)
 };
+
+// (problem, stage) of this workgroup for kernels with one workgroup per stage: blockIdx.x = (index in the active list) * p + k
+__device__ __forceinline__ int stage_id(const WS& w, const Dims& dm) {
+  if (!w.alist) return blockIdx.x;
+  const int bi = blockIdx.x / dm.p;
+  return w.alist[bi] * dm.p + (blockIdx.x - bi * dm.p);
+}
+// problem of this workgroup for kernels with one workgroup per problem
+__device__ __forceinline__ int prob_id(const WS& w) { return w.alist ? w.alist[blockIdx.x] : (int)blockIdx.x; }
 
 }  // namespace tmpc

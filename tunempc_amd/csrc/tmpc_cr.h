@@ -1,0 +1,360 @@
+// Block-cyclic-tridiagonal Cholesky by CYCLIC REDUCTION, as batched tile kernels.
+//
+// The HKM Schur matrix couples stage k only to k-1 and k+1 (mod p): its block graph is a cycle.  Eliminating a node of
+// a cycle always costs the same (Cholesky of its diagonal block, two triangular solves, two symmetric updates and one
+// fill block between its two neighbours: 6 1/3 d^3), whichever node goes first -- the sequential order pays the fill as
+// a travelling corner row, cyclic reduction pays it as the edge of the next, half as long cycle.  So the odd-even order
+// costs no extra flops but exposes p/2, p/4, ... independent eliminations per level, and every phase of a level is a
+// batched tile kernel over (active problem, node, tile):
+//
+//   k_cr_potrf   one workgroup per eliminated node      D_i = L_i L_i'  (64 x 64 tile Cholesky + inverted diagonal tiles)
+//   k_cr_trsm    per node, neighbour, row strip         O_x <- T[x,i] L_i^-T        (x = the two neighbours a, b of i)
+//   k_cr_update  per surviving node: lower tiles        D_s -= O_s O_s' (one or two eliminated neighbours)
+//                per eliminated node: all tiles         T[x,y] (=|-=) -O_x O_y'     (the fill edge, x,y = a,b)
+//
+// Grids are sized by the number of problems still iterating (compacted list), so the tail of a lockstep batch and
+// small batches of long-period problems keep the chip busy; workgroups working on the same node are placed on one XCD
+// (block b runs on XCD b % 8) so that the operand panels they share are served by that XCD's L2.
+//
+// Storage (all dp x dp, row-major): D[node] -> L (diagonal tiles hold L_jj, inverses in Linv); edge slots 0..p-1 live
+// in w.O (slot k = edge between stage k and k+1 mod p), fill slots p..2p-1 in w.F.  Every edge is stored with its
+// COLUMNS belonging to the endpoint that is eliminated first (schedule: cr_build), which turns every product into the
+// same NT form C (+)= A B'.
+#pragma once
+#include <climits>
+#include <vector>
+
+#include "tmpc_common.h"
+#include "tmpc_factor.h"
+
+namespace tmpc {
+
+// ------------------------------------------------------------------ schedule (host)
+constexpr int CR_EW = 8;   // ints per elimination record
+constexpr int CR_UW = 8;   // ints per update record
+// elimination record: node, na, nb (neighbours, -1: none), ea, eb (slots of T[na,node], T[nb,node]; -1: none),
+//                     fill slot (-1: none), fx (0: fill rows = na / cols = nb, 1: rows = nb / cols = na), facc (1: the edge exists already)
+enum { CE_NODE = 0, CE_NA, CE_NB, CE_EA, CE_EB, CE_FILL, CE_FX, CE_FACC };
+// update record of a surviving node: node, e0, src0, e1, src1 (slots whose rows belong to `node`, and the eliminated node each came from; -1: none)
+enum { CU_NODE = 0, CU_E0, CU_S0, CU_E1, CU_S1 };
+
+struct CrLevel { int eoff, nelim, uoff, nupd; };
+struct CrSched {
+  int p = 0;
+  int prep = 0;                   // 1: p == 1, fold the self-loop D_0 += E_0 + E_0';  2: p == 2, merge the double edge E_0 += E_1
+  std::vector<int> orient;        // [p] 0: slot k holds T[k+1,k] (columns = stage k), 1: T[k,k+1] (columns = stage k+1)
+  std::vector<int> elim, upd;     // flat records
+  std::vector<CrLevel> lev;
+};
+
+static inline CrSched cr_build(int p) {
+  CrSched s; s.p = p; s.orient.assign(p, 0);
+  auto push_elim = [&](int node, int na, int nb, int ea, int eb, int fill, int fx, int facc) {
+    const int r[CR_EW] = {node, na, nb, ea, eb, fill, fx, facc};
+    s.elim.insert(s.elim.end(), r, r + CR_EW);
+  };
+  auto push_upd = [&](int node, int e0, int s0, int e1, int s1) {
+    const int r[CR_UW] = {node, e0, s0, e1, s1, 0, 0, 0};
+    s.upd.insert(s.upd.end(), r, r + CR_UW);
+  };
+  if (p == 1) {
+    s.prep = 1;
+    s.lev.push_back({0, 1, 0, 0});
+    push_elim(0, -1, -1, -1, -1, -1, 0, 0);
+    return s;
+  }
+  // pass 1: the level at which every node is eliminated
+  std::vector<int> lvl(p, INT_MAX);
+  auto positions = [](int n) {
+    std::vector<int> pos;
+    if (n <= 4) pos.push_back(1);                        // short cycles: one node at a time (two fills would meet in one block)
+    else for (int i = 1; i < n; i += 2) pos.push_back(i);
+    return pos;
+  };
+  {
+    std::vector<int> cyc(p);
+    for (int i = 0; i < p; ++i) cyc[i] = i;
+    int L = 0;
+    while ((int)cyc.size() > 1) {
+      const int n = (int)cyc.size();
+      std::vector<char> gone(n, 0);
+      for (int i : positions(n)) { lvl[cyc[i]] = L; gone[i] = 1; }
+      std::vector<int> nxt;
+      for (int i = 0; i < n; ++i) if (!gone[i]) nxt.push_back(cyc[i]);
+      cyc.swap(nxt); ++L;
+    }
+    lvl[cyc[0]] = L;
+  }
+  for (int k = 0; k < p; ++k) {
+    const int kn = (k + 1) % p;
+    s.orient[k] = (lvl[k] < lvl[kn]) ? 0 : 1;            // columns = the endpoint eliminated first (never equal: neighbours do not share a level)
+  }
+  if (p == 2) { s.prep = 2; s.orient[0] = 1; s.orient[1] = 0; }     // both edges as T[0,1] (node 1 goes first), merged into slot 0
+  // pass 2: records
+  std::vector<int> cyc(p), es(p);
+  for (int i = 0; i < p; ++i) { cyc[i] = i; es[i] = i; }  // es[i] = slot of the edge between cyc[i] and cyc[i+1 mod n]
+  int nfill = 0;
+  while ((int)cyc.size() > 1) {
+    const int n = (int)cyc.size();
+    CrLevel lv; lv.eoff = (int)s.elim.size() / CR_EW; lv.uoff = (int)s.upd.size() / CR_UW;
+    const std::vector<int> pos = positions(n);
+    std::vector<char> gone(n, 0);
+    std::vector<int> fillof(n, -1);                       // fill slot created by the node at position i
+    for (int i : pos) {
+      gone[i] = 1;
+      const int c = cyc[i], a = cyc[i - 1], b = cyc[(i + 1) % n];
+      if (n == 2) { push_elim(c, a, -1, es[0], -1, -1, 0, 0); continue; }
+      int fill, facc = 0;
+      if (n == 3) { fill = es[2]; facc = 1; }            // the neighbours are adjacent already: accumulate into their edge
+      else fill = p + nfill++;
+      fillof[i] = fill;
+      const int fx = (lvl[b] < lvl[a]) ? 0 : 1;          // columns of the fill = the neighbour eliminated first
+      push_elim(c, a, b, es[i - 1], es[i], fill, fx, facc);
+    }
+    // surviving nodes next to an eliminated one
+    if (n == 2) push_upd(cyc[0], es[0], cyc[1], -1, -1);
+    for (int i = 0; i < n && n > 2; ++i) {
+      if (gone[i]) continue;
+      const int il = (i + n - 1) % n, ir = (i + 1) % n;
+      int e0 = -1, s0 = -1, e1 = -1, s1 = -1;
+      if (gone[il]) { e0 = es[il]; s0 = cyc[il]; }       // edge between cyc[il] and cyc[i]
+      if (gone[ir]) { if (e0 < 0) { e0 = es[i]; s0 = cyc[ir]; } else { e1 = es[i]; s1 = cyc[ir]; } }
+      if (e0 >= 0) push_upd(cyc[i], e0, s0, e1, s1);
+    }
+    // next cycle
+    std::vector<int> ncyc, nes;
+    for (int i = 0; i < n; ++i) {
+      if (gone[i]) continue;
+      ncyc.push_back(cyc[i]);
+      const int ir = (i + 1) % n;
+      nes.push_back(gone[ir] ? fillof[ir] : es[i]);
+    }
+    if (n == 2) { nes.assign(1, -1); }
+    if (n == 3) { nes.assign(2, es[2]); }
+    lv.nelim = (int)s.elim.size() / CR_EW - lv.eoff; lv.nupd = (int)s.upd.size() / CR_UW - lv.uoff;
+    s.lev.push_back(lv);
+    cyc.swap(ncyc); es.swap(nes);
+  }
+  CrLevel lv; lv.eoff = (int)s.elim.size() / CR_EW; lv.nelim = 1; lv.uoff = (int)s.upd.size() / CR_UW; lv.nupd = 0;
+  push_elim(cyc[0], -1, -1, -1, -1, -1, 0, 0);
+  s.lev.push_back(lv);
+  return s;
+}
+
+// ------------------------------------------------------------------ device helpers
+struct CrDev {               // device copy of the schedule
+  const int* elim; const int* upd; const int* orient;
+  const int* alist;          // [count] problems to factor / solve (compacted)
+};
+
+__device__ __forceinline__ double* cr_edge(const WS& w, const Dims& dm, int b, int slot) {
+  const size_t bs = (size_t)dm.dp * dm.dp;
+  return (slot < dm.p) ? w.O + ((size_t)b * dm.p + slot) * bs : w.F + ((size_t)b * dm.p + (slot - dm.p)) * bs;
+}
+// XCD-aware work-item id: block i runs on XCD i % 8, so items are dealt to the XCDs in contiguous runs (the tiles of one
+// node -- consecutive items -- share their operands through one L2).  gridDim.x is a multiple of 8; -1: no item.
+__device__ __forceinline__ int cr_item(int nitems) {
+  const int i = blockIdx.x, per = gridDim.x >> 3;
+  const int v = (i & 7) * per + (i >> 3);
+  return v < nitems ? v : -1;
+}
+__device__ __forceinline__ void atomic_min_pos(double* addr, double v) {      // v, *addr >= 0: order-preserving as unsigned integers
+  atomicMin((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// p == 1 / p == 2 preparation (one workgroup per active problem)
+__global__ void __launch_bounds__(256) k_cr_prep(WS w, Dims dm, CrDev cr, int prep) {
+  const int b = cr.alist[blockIdx.x];
+  const int dp = dm.dp, tid = threadIdx.x;
+  double* D = w.D + (size_t)b * dm.p * dp * dp;
+  if (prep == 1) {            // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'
+    const double* E = cr_edge(w, dm, b, 0);
+    for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += E[e] + E[(size_t)j * dp + i]; }
+  } else {                    // two edges between the same pair of nodes
+    double* E0 = cr_edge(w, dm, b, 0); const double* E1 = cr_edge(w, dm, b, 1);
+    for (int e = tid; e < dp * dp; e += 256) E0[e] += E1[e];
+  }
+}
+
+// ---- phase 1: Cholesky of the diagonal blocks of this level's eliminated nodes
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp;
+  const size_t bs = (size_t)dp * dp;
+  double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
+  double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const double* dref = w.Ddiag + ((size_t)b * dm.p + node) * dp;
+  double minr = 1.0;
+  const int nbad = wg_block_column<USE_MFMA>(Dk, nullptr, nullptr, Li, dref, dp, lds, &minr);
+  if (threadIdx.x == 0) {
+    if (nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
+    if (w.prob && minr < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, minr);
+  }
+}
+
+// ---- phase 2: O_x <- T[x,i] L_i^-T for the (up to) two neighbours, `rs` rows per workgroup
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int rs) {
+  const int nstrip = (dm.dp + rs - 1) / rs;
+  const int per = 2 * nstrip;
+  const int it = cr_item(count * nelim * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int g = it / per, r = it - g * per;
+  const int b = cr.alist[g / nelim];
+  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
+  const int which = r / nstrip, strip = r - which * nstrip;
+  const int slot = which ? er[CE_EB] : er[CE_EA];
+  if (slot < 0) return;
+  const int node = er[CE_NODE], dp = dm.dp;
+  const size_t bs = (size_t)dp * dp;
+  const double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
+  const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const int r0 = strip * rs;
+  const int rows = (dp - r0 < rs) ? dp - r0 : rs;
+  double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
+  int jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    if (j0 > 0) wg_gemm_nt<USE_MFMA>(X + j0, dp, X, dp, Dk + (size_t)j0 * dp, dp, rows, nb, j0, GM_SUB, false, lds);
+    wg_gemm_nt<USE_MFMA>(X + j0, dp, X + j0, dp, Li + (size_t)jt * TB * TB, TB, rows, nb, nb, GM_SET, false, lds);
+  }
+}
+
+// ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, `mt` x `mt` output per workgroup
+template <bool USE_MFMA>
+__global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int mt) {
+  const int nm = (dm.dp + mt - 1) / mt;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
+  const int per = nupd * ntl + nelim * ntf;
+  const int it = cr_item(count * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / per];
+  int r = it % per;
+  const int dp = dm.dp;
+  const size_t bs = (size_t)dp * dp;
+  if (r < nupd * ntl) {
+    const int* ur = cr.upd + (size_t)(uoff + r / ntl) * CR_UW;
+    int t = r % ntl, tm = 0;
+    while (t > tm) { t -= tm + 1; ++tm; }               // t -> (tm, tn), tn <= tm
+    const int tn = t;
+    const int m0 = tm * mt, n0 = tn * mt;
+    const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;
+    double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
+    const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
+    wg_gemm_nt<USE_MFMA>(C, dp, O0 + (size_t)m0 * dp, dp, O0 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
+    if (ur[CU_E1] >= 0) {
+      const double* O1 = cr_edge(w, dm, b, ur[CU_E1]);
+      wg_gemm_nt<USE_MFMA>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
+    }
+  } else {
+    r -= nupd * ntl;
+    const int* er = cr.elim + (size_t)(eoff + r / ntf) * CR_EW;
+    if (er[CE_FILL] < 0) return;
+    const int t = r % ntf;
+    const int tm = t / nm, tn = t - tm * nm;
+    const int m0 = tm * mt, n0 = tn * mt;
+    const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;
+    const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
+    const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
+    double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
+    wg_gemm_nt<USE_MFMA>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
+  }
+}
+
+// ------------------------------------------------------------------ triangular solves in the same order
+// Right-hand sides R [p][dp][NC] (NC interleaved), in place.  Forward, level by level: z_i <- L_i^-1 z_i for the eliminated nodes,
+// then z_s -= O_s z_i for the surviving neighbours; backward in reverse: z_i <- L_i^-T (z_i - O_a' z_a - O_b' z_b).
+// The matrix-vector work is the skinny MFMA GEMM of tmpc_factor.h (wg_gemv16); every factor block is streamed once per sweep.
+constexpr int cr_solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
+
+// which right-hand sides a problem solves in this pass: pass 1 (main phase only) [rhs | u_tau | u_alpha] in W3; pass 2 the
+// corrector rhs alone in Z (main phase) or all three (centering: no predictor).  0: nothing to do.
+__device__ __forceinline__ int cr_nc(const WS& w, int b, int pass) {
+  const int phase = w.iprob[(size_t)b * IS + I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
+  return ((pass == 1) || (phase != PH_MAIN)) ? 3 : 1;
+}
+__device__ __forceinline__ double* cr_rhs(const WS& w, const Dims& dm, int b, int node, int nc) {
+  return ((nc == 3) ? w.W3 : w.Z) + ((size_t)b * dm.p + node) * dm.dp * nc;
+}
+
+__global__ void __launch_bounds__(256) k_cr_fwd_diag(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int nc = cr_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp, xld = dp + 4, tld = TB + 4;
+  double* zc = lds; double* tmp = lds + 3 * NCP * xld; double* As = tmp + NCP * tld;
+  for (int e = threadIdx.x; e < NCP * xld; e += 256) zc[e] = 0.0;
+  for (int e = threadIdx.x; e < NCP * tld; e += 256) tmp[e] = 0.0;
+  __syncthreads();
+  double* R = cr_rhs(w, dm, b, node, nc);
+  vec_g2s(zc, xld, R, dp, nc);
+  __syncthreads();
+  blk_fwd(zc, xld, tmp, tld, w.D + ((size_t)b * dm.p + node) * dp * dp, w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB, dp, As, nc);
+  vec_s2g(R, zc, xld, dp, nc);
+}
+
+__global__ void __launch_bounds__(256) k_cr_fwd_off(WS w, Dims dm, CrDev cr, int uoff, int nupd, int count, int pass) {
+  const int it = cr_item(count * nupd);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nupd];
+  const int nc = cr_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* ur = cr.upd + (size_t)(uoff + it % nupd) * CR_UW;
+  const int dp = dm.dp, xld = dp + 4, tld = TB + 4;
+  double* zs = lds; double* zi = zs + NCP * xld; double* As = lds + 3 * NCP * xld + NCP * tld;
+  for (int e = threadIdx.x; e < 2 * NCP * xld; e += 256) lds[e] = 0.0;
+  __syncthreads();
+  double* R = cr_rhs(w, dm, b, ur[CU_NODE], nc);
+  vec_g2s(zs, xld, R, dp, nc);
+  for (int q = 0; q < 2; ++q) {
+    const int slot = ur[q ? CU_E1 : CU_E0];
+    if (slot < 0) break;
+    vec_g2s(zi, xld, cr_rhs(w, dm, b, ur[q ? CU_S1 : CU_S0], nc), dp, nc);
+    __syncthreads();
+    wg_gemv16<false>(zs, xld, zi, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);      // z_s -= O_s z_i
+  }
+  __syncthreads();
+  vec_s2g(R, zs, xld, dp, nc);
+}
+
+__global__ void __launch_bounds__(256) k_cr_bwd(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int nc = cr_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp, xld = dp + 4, tld = TB + 4;
+  double* zc = lds; double* zn = zc + NCP * xld; double* tmp = lds + 3 * NCP * xld; double* As = tmp + NCP * tld;
+  for (int e = threadIdx.x; e < 3 * NCP * xld + NCP * tld; e += 256) lds[e] = 0.0;
+  __syncthreads();
+  double* R = cr_rhs(w, dm, b, node, nc);
+  vec_g2s(zc, xld, R, dp, nc);
+  for (int q = 0; q < 2; ++q) {
+    const int slot = er[q ? CE_EB : CE_EA];
+    if (slot < 0) continue;
+    __syncthreads();
+    vec_g2s(zn, xld, cr_rhs(w, dm, b, er[q ? CE_NB : CE_NA], nc), dp, nc);
+    __syncthreads();
+    wg_gemv16<true>(zc, xld, zn, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);       // z_i -= O_x' z_x
+  }
+  __syncthreads();
+  blk_bwd(zc, xld, tmp, tld, w.D + ((size_t)b * dm.p + node) * dp * dp, w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB, dp, As, nc);
+  vec_s2g(R, zc, xld, dp, nc);
+}
+
+}  // namespace tmpc

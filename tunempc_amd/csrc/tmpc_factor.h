@@ -1,17 +1,9 @@
-// Block-cyclic-tridiagonal Cholesky of the HKM Schur matrix and the matching triangular solves.
-//
-// One 256-thread workgroup (4 wavefronts) per tuning problem walks the p stages sequentially (they are
-// chained through P_k / P_{k+1}); all the d x d block work is GEMM-shaped and runs on the fp64 matrix
-// cores: v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile
-// (2 x 2 MFMA tiles), K staged through LDS 16 columns at a time with register prefetch of the next slab.
-//
-// Storage per stage k (all dp x dp, row-major, dp = d rounded up to 16, padding = identity / zero):
-//   D[k]  diagonal block  -> L_k   (64 x 64 diagonal tiles hold L_jj; their inverses go to Linv)
-//   O[k]  T[P_{k+1},P_k]  -> O_k = T[..] L_k^-T
-//   F[k]  fill of the cyclic corner row T[P_{p-1},P_k] -> F_k
+// Building blocks of the block factorisation of the HKM Schur matrix (tmpc_cr.h holds the kernels): the fp64 MFMA tile GEMM
+// C (+)= A B' (v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile = 2 x 2 MFMA
+// tiles, K staged through LDS in double-buffered 32-column slabs), the 64 x 64 tile Cholesky with its inverse, the
+// left-looking blocked Cholesky of a d x d block, and the skinny MFMA GEMM that carries the triangular solves.
 #pragma once
 #include "tmpc_common.h"
-#include "tmpc_gemm2.h"
 
 namespace tmpc {
 
@@ -210,208 +202,6 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
   }
 }
 
-constexpr int GK0 = 16, GLD0 = 17;   // variant 0: single-buffered 16-column slabs, two barriers per slab (round-1 baseline)
-// C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
-// lower: skip 64x64 tiles strictly above the block diagonal (SYRK-style update of a symmetric block).
-// In-place use (C aliasing A with K == N-tile width) is safe: a C tile is stored only after all of its
-// A slabs have been loaded.
-template <bool USE_MFMA>
-__device__ __forceinline__ void wg_gemm_nt_v0(double* C, int ldc, const double* A, int lda,
-                                           const double* B, int ldb, int M, int N, int K, int mode, bool lower,
-                                           double* lds) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;
-  double* As = lds;
-  double* Bs = lds + 64 * GLD0;
-  const int lrow = tid >> 2, lk = (tid & 3) * 4;     // slab loader: row, first k
-  const int nks = K / GK0;
-  for (int m0 = 0; m0 < M; m0 += 64) {
-    for (int n0 = 0; n0 < N; n0 += 64) {
-      if (lower && n0 > m0) continue;
-      double4_t acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-      double ra[4], rb[4];
-      const bool arow_ok = (m0 + lrow) < M, brow_ok = (n0 + lrow) < N;
-      const double* ap = A + (size_t)(m0 + lrow) * lda + lk;
-      const double* bp = B + (size_t)(n0 + lrow) * ldb + lk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ra[q] = arow_ok ? ap[q] : 0.0; rb[q] = brow_ok ? bp[q] : 0.0; }
-      for (int ks = 0; ks < nks; ++ks) {
-        __syncthreads();                     // previous slab fully consumed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { As[lrow * GLD0 + lk + q] = ra[q]; Bs[lrow * GLD0 + lk + q] = rb[q]; }
-        __syncthreads();
-        if (ks + 1 < nks) {
-          const double* ap2 = ap + (size_t)(ks + 1) * GK0;
-          const double* bp2 = bp + (size_t)(ks + 1) * GK0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { ra[q] = arow_ok ? ap2[q] : 0.0; rb[q] = brow_ok ? bp2[q] : 0.0; }
-        }
-        const int fr = lane & 15, fk = lane >> 4;
-        if (USE_MFMA) {
-#pragma unroll
-          for (int kk = 0; kk < GK0 / 4; ++kk) {
-            const double a0 = As[(wr * 32 + fr) * GLD0 + kk * 4 + fk];
-            const double a1 = As[(wr * 32 + 16 + fr) * GLD0 + kk * 4 + fk];
-            const double b0 = Bs[(wc * 32 + fr) * GLD0 + kk * 4 + fk];
-            const double b1 = Bs[(wc * 32 + 16 + fr) * GLD0 + kk * 4 + fk];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-          }
-        } else {   // debug path: same fragment ownership, scalar FMAs
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = wr * 32 + i * 16 + fk + 4 * r, col = wc * 32 + j * 16 + fr;
-                double s = acc[i][j][r];
-                for (int kk = 0; kk < GK0; ++kk) s = fma(As[row * GLD0 + kk], Bs[col * GLD0 + kk], s);
-                acc[i][j][r] = s;
-              }
-        }
-      }
-      // epilogue: C/D fragment of v_mfma_f64_16x16x4: reg r -> row (lane>>4) + 4r, col lane&15
-      const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + wr * 32 + i * 16;
-        if (rbase >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cbase = n0 + wc * 32 + j * 16;
-          if (cbase >= N) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double* cp = C + (size_t)(rbase + fk + 4 * r) * ldc + cbase + fr;
-            const double v = acc[i][j][r];
-            if (mode == GM_SUB) *cp -= v; else if (mode == GM_SET) *cp = v; else *cp = -v;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-
-// The three Schur updates of one stage fused:  Dn -= O O',  Dl -= F F' (lower tiles),  Fn = -F O' (all tiles).
-// For a lower tile (r >= c) the four operand slabs O_r, F_r, O_c, F_c are staged once and feed three MFMA
-// accumulator sets (12.3 flop per operand byte instead of 8 for three separate GEMMs); upper tiles only need
-// F_r and O_c.  Same flattened, double-buffered slab stream as wg_gemm_nt; K slabs of 16 columns.
-__device__ __forceinline__ void wg_schur_fused(double* Dn, double* Dl, double* Fn, const double* O, const double* F,
-                                               int dp, double* lds) {
-  constexpr int FK = 16, FLD = 17, FSL = 64 * FLD;          // one slab: 64 rows x 16 k
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;
-  const int lrow = tid >> 2, lk = (tid & 3) * 4;             // loader: row 0..63, k = lk..lk+3
-  const int fr = lane & 15, fk = lane >> 4;
-  const int nks = dp / FK;
-  double4_t aoo[2][2], aff[2][2], afo[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { aoo[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; aff[i][j] = aoo[i][j]; afo[i][j] = aoo[i][j]; }
-  double r0[4], r1[4], r2[4], r3[4];                          // O_r, F_r, O_c, F_c pieces
-  int m0 = 0, n0 = 0, ks = 0;
-#define TMPC_FUSED_LOAD(M0, N0, KS)                                                                      \
-  {                                                                                                      \
-    const bool low = (N0) <= (M0);                                                                       \
-    const bool rok = ((M0) + lrow) < dp, cok = ((N0) + lrow) < dp;                                       \
-    gcptr po = (gcptr)(O + (size_t)((M0) + lrow) * dp + (KS) * FK + lk);                                 \
-    gcptr pf = (gcptr)(F + (size_t)((M0) + lrow) * dp + (KS) * FK + lk);                                 \
-    gcptr qo = (gcptr)(O + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
-    gcptr qf = (gcptr)(F + (size_t)((N0) + lrow) * dp + (KS) * FK + lk);                                 \
-    TMPC_LD4(r0, 0, po, (rok && low)) TMPC_LD4(r1, 0, pf, rok)                                           \
-    TMPC_LD4(r2, 0, qo, cok) TMPC_LD4(r3, 0, qf, (cok && low))                                           \
-  }
-#define TMPC_FUSED_STORE(BUF)                                                                            \
-  {                                                                                                      \
-    double* b_ = lds + (BUF) * (4 * FSL);                                                                \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-      b_[lrow * FLD + lk + q] = r0[q]; b_[FSL + lrow * FLD + lk + q] = r1[q];                            \
-      b_[2 * FSL + lrow * FLD + lk + q] = r2[q]; b_[3 * FSL + lrow * FLD + lk + q] = r3[q];              \
-    }                                                                                                    \
-  }
-  TMPC_FUSED_LOAD(0, 0, 0)
-  __syncthreads();
-  TMPC_FUSED_STORE(0)
-  __syncthreads();
-  int buf = 0;
-  while (m0 < dp) {
-    int nm0 = m0, nn0 = n0, nks_ = ks + 1;
-    if (nks_ == nks) { nks_ = 0; nn0 = n0 + 64; if (nn0 >= dp) { nn0 = 0; nm0 = m0 + 64; } }
-    const bool more = nm0 < dp;
-    if (more) TMPC_FUSED_LOAD(nm0, nn0, nks_)
-    const bool low = n0 <= m0;
-    {
-      const double* b_ = lds + buf * (4 * FSL);
-#pragma unroll
-      for (int kk = 0; kk < FK / 4; ++kk) {
-        const int o0 = (wr * 32 + fr) * FLD + kk * 4 + fk, o1 = o0 + 16 * FLD;
-        const int c0 = (wc * 32 + fr) * FLD + kk * 4 + fk, c1 = c0 + 16 * FLD;
-        const double f0 = b_[FSL + o0], f1 = b_[FSL + o1];
-        const double bo0 = b_[2 * FSL + c0], bo1 = b_[2 * FSL + c1];
-        afo[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bo0, afo[0][0], 0, 0, 0);
-        afo[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bo1, afo[0][1], 0, 0, 0);
-        afo[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bo0, afo[1][0], 0, 0, 0);
-        afo[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bo1, afo[1][1], 0, 0, 0);
-        if (low) {
-          const double a0 = b_[o0], a1 = b_[o1];
-          const double bf0 = b_[3 * FSL + c0], bf1 = b_[3 * FSL + c1];
-          aoo[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bo0, aoo[0][0], 0, 0, 0);
-          aoo[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bo1, aoo[0][1], 0, 0, 0);
-          aoo[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bo0, aoo[1][0], 0, 0, 0);
-          aoo[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bo1, aoo[1][1], 0, 0, 0);
-          aff[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bf0, aff[0][0], 0, 0, 0);
-          aff[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, bf1, aff[0][1], 0, 0, 0);
-          aff[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bf0, aff[1][0], 0, 0, 0);
-          aff[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, bf1, aff[1][1], 0, 0, 0);
-        }
-      }
-    }
-    if (more) TMPC_FUSED_STORE(buf ^ 1)
-    if (ks == nks - 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + wr * 32 + i * 16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cbase = n0 + wc * 32 + j * 16;
-          if (rbase < dp && cbase < dp) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const size_t off = (size_t)(rbase + fk + 4 * r) * dp + cbase + fr;
-              ((gptr)Fn)[off] = -afo[i][j][r];
-              if (low) { ((gptr)Dn)[off] -= aoo[i][j][r]; ((gptr)Dl)[off] -= aff[i][j][r]; }
-            }
-          }
-          aoo[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; aff[i][j] = aoo[i][j]; afo[i][j] = aoo[i][j];
-        }
-      }
-    }
-    __syncthreads();
-    buf ^= 1;
-    m0 = nm0; n0 = nn0; ks = nks_;
-  }
-#undef TMPC_FUSED_LOAD
-#undef TMPC_FUSED_STORE
-}
-
-// VAR 0: round-1 baseline GEMM (kept for the A/B bench of tmpc_debug_factor_bench); VAR 1: current.
-template <bool USE_MFMA, int VAR>
-__device__ __forceinline__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N,
-                                        int K, int mode, bool lower, double* lds) {
-  if (VAR == 0) wg_gemm_nt_v0<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
-  else wg_gemm_nt<USE_MFMA>(C, ldc, A, lda, B, ldb, M, N, K, mode, lower, lds);
-}
-
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
 // dref: assembled diagonal entries (pivot reference).  Returns number of shifted pivots (thread-uniform).
 // Both loops are organised so that all 256 threads work: four lanes share every dot product (k strided by 4,
@@ -498,7 +288,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
 
 // Left-looking blocked Cholesky of the block column headed by Dk, applied also to the rows of R1 (and R2):
 //   Dk = L L' ;  R1 <- R1 L^-T ;  R2 <- R2 L^-T        (R1/R2 may be null)
-template <bool USE_MFMA, int VAR>
+template <bool USE_MFMA>
 __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R2, double* Linv_k, const double* dref,
                                                int dp, double* lds, double* minr) {
   int nbad = 0;
@@ -506,66 +296,19 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     if (j0 > 0) {
-      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)j0 * dp + j0, dp, Dk + (size_t)j0 * dp, dp, Dk + (size_t)j0 * dp, dp, dp - j0, nb, j0, GM_SUB, false, lds);
-      if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
-      if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+      wg_gemm_nt<USE_MFMA>(Dk + (size_t)j0 * dp + j0, dp, Dk + (size_t)j0 * dp, dp, Dk + (size_t)j0 * dp, dp, dp - j0, nb, j0, GM_SUB, false, lds);
+      if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
+      if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
     double* Ti = Linv_k + (size_t)jt * TB * TB;
     nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds, minr);
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
-      wg_gemm<USE_MFMA, VAR>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
-    if (R1) wg_gemm<USE_MFMA, VAR>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
-    if (R2) wg_gemm<USE_MFMA, VAR>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+      wg_gemm_nt<USE_MFMA>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
+    if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+    if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
   }
   return nbad;
-}
-
-template <bool USE_MFMA, int VAR>
-__global__ void __launch_bounds__(256, 2) k_factor(WS w, Dims dm) {
-  const int b = blockIdx.x;
-  int* ip = w.iprob + (size_t)b * IS;
-  if (ip[I_PHASE] == PH_DONE) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int p = dm.p, dp = dm.dp, tid = threadIdx.x;
-  const size_t bs = (size_t)dp * dp;
-  double* D = w.D + (size_t)b * p * bs;
-  double* O = w.O + (size_t)b * p * bs;
-  double* F = w.F + (size_t)b * p * bs;
-  double* Li = w.Linv + (size_t)b * p * dm.nt * TB * TB;
-  const double* dref = w.Ddiag + (size_t)b * p * dp;
-  const size_t ls = (size_t)dm.nt * TB * TB;
-  int nbad = 0;
-  double minr = 1.0;                       // smallest pivot relative to the assembled diagonal in this factorisation
-  if (p == 1) {
-    // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'   (C stored in F[0])
-    for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += F[e] + F[(size_t)j * dp + i]; }
-    __syncthreads();
-    nbad += wg_block_column<USE_MFMA, VAR>(D, nullptr, nullptr, Li, dref, dp, lds, &minr);
-  } else {
-    for (int k = 0; k < p - 1; ++k) {
-      double* Dk = D + k * bs; double* Ok = O + k * bs; double* Fk = F + k * bs;
-      const bool last = (k == p - 2);
-      if (last) {   // the fill of the cyclic corner meets the sub-diagonal block
-        for (int e = tid; e < dp * dp; e += 256) Ok[e] += Fk[e];
-        __syncthreads();
-      }
-      nbad += wg_block_column<USE_MFMA, VAR>(Dk, Ok, last ? nullptr : Fk, Li + k * ls, dref + (size_t)k * dp, dp, lds, &minr);
-      // Schur updates
-      if (USE_MFMA && VAR == 1 && !last) {
-        wg_schur_fused(D + (k + 1) * bs, D + (size_t)(p - 1) * bs, F + (k + 1) * bs, Ok, Fk, dp, lds);
-      } else {
-        wg_gemm<USE_MFMA, VAR>(D + (k + 1) * bs, dp, Ok, dp, Ok, dp, dp, dp, dp, GM_SUB, true, lds);
-        if (!last) {
-          wg_gemm<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, dp, Fk, dp, Fk, dp, dp, dp, dp, GM_SUB, true, lds);
-          wg_gemm<USE_MFMA, VAR>(F + (k + 1) * bs, dp, Fk, dp, Ok, dp, dp, dp, dp, GM_NEG, false, lds);
-        }
-      }
-    }
-    nbad += wg_block_column<USE_MFMA, VAR>(D + (size_t)(p - 1) * bs, nullptr, nullptr, Li + (size_t)(p - 1) * ls, dref + (size_t)(p - 1) * dp, dp, lds, &minr);
-  }
-  if (tid == 0 && nbad) ip[I_NSHIFT] += nbad;
-  if (tid == 0 && w.prob) { double* pr = w.prob + (size_t)b * PS; pr[P_MINPIV] = fmin(pr[P_MINPIV], minr); }
 }
 
 // ------------------------------------------------------------------ triangular solves with the block factor
@@ -678,68 +421,6 @@ __device__ __forceinline__ void vec_s2g(double* R, const double* z, int xld, int
   for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; R[e] = z[q * xld + i]; }
 }
 
-constexpr int solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
-
-// Solve T x = r for NC interleaved right-hand sides stored at R [p][dp][NC] (in place).
-template <int NC>
-__device__ __forceinline__ void wg_cyclic_solve(double* R, const double* D, const double* O, const double* F,
-                                                const double* Li, int p, int dp, int nt, double* lds) {
-  const size_t bs = (size_t)dp * dp, ls = (size_t)nt * TB * TB;
-  const int xld = dp + 4, tld = TB + 4;
-  double* zc = lds;                   // current stage
-  double* zn = zc + NCP * xld;        // next stage
-  double* zl = zn + NCP * xld;        // last stage
-  double* tmp = zl + NCP * xld;       // NCP x tld
-  double* As = tmp + NCP * tld;       // 64 x GLDV slab
-  const int tid = threadIdx.x, len = dp * NC;
-  for (int e = tid; e < 3 * NCP * xld + NCP * tld; e += 256) lds[e] = 0.0;
-  __syncthreads();
-  if (p == 1) {
-    vec_g2s(zc, xld, R, dp, NC);
-    __syncthreads();
-    blk_fwd(zc, xld, tmp, tld, D, Li, dp, As, NC);
-    blk_bwd(zc, xld, tmp, tld, D, Li, dp, As, NC);
-    vec_s2g(R, zc, xld, dp, NC);
-    __syncthreads();
-    return;
-  }
-  // ---- forward
-  vec_g2s(zc, xld, R, dp, NC);
-  vec_g2s(zl, xld, R + (size_t)(p - 1) * len, dp, NC);
-  __syncthreads();
-  for (int k = 0; k < p - 1; ++k) {
-    blk_fwd(zc, xld, tmp, tld, D + k * bs, Li + k * ls, dp, As, NC);
-    vec_s2g(R + (size_t)k * len, zc, xld, dp, NC);
-    if (k + 1 < p - 1) {
-      vec_g2s(zn, xld, R + (size_t)(k + 1) * len, dp, NC);
-      __syncthreads();
-      wg_gemv16<false>(zn, xld, zc, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);
-      wg_gemv16<false>(zl, xld, zc, xld, F + k * bs, dp, dp, dp, true, -1.0, As, NC);
-      for (int e = tid; e < NCP * xld; e += 256) zc[e] = zn[e];
-      __syncthreads();
-    } else {
-      __syncthreads();
-      wg_gemv16<false>(zl, xld, zc, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);   // k = p-2 couples into the last block
-    }
-  }
-  blk_fwd(zl, xld, tmp, tld, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp, As, NC);
-  // ---- backward
-  blk_bwd(zl, xld, tmp, tld, D + (size_t)(p - 1) * bs, Li + (size_t)(p - 1) * ls, dp, As, NC);
-  vec_s2g(R + (size_t)(p - 1) * len, zl, xld, dp, NC);
-  for (int e = tid; e < NCP * xld; e += 256) zn[e] = zl[e];
-  __syncthreads();
-  for (int k = p - 2; k >= 0; --k) {
-    vec_g2s(zc, xld, R + (size_t)k * len, dp, NC);
-    __syncthreads();
-    wg_gemv16<true>(zc, xld, zn, xld, O + k * bs, dp, dp, dp, true, -1.0, As, NC);          // O_k' x_{k+1}
-    if (k < p - 2) wg_gemv16<true>(zc, xld, zl, xld, F + k * bs, dp, dp, dp, true, -1.0, As, NC);
-    blk_bwd(zc, xld, tmp, tld, D + k * bs, Li + k * ls, dp, As, NC);
-    vec_s2g(R + (size_t)k * len, zc, xld, dp, NC);
-    for (int e = tid; e < NCP * xld; e += 256) zn[e] = zc[e];
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ double wg_reduce_sum(double v, double* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -751,30 +432,24 @@ __device__ __forceinline__ double wg_reduce_sum(double v, double* red) {
   return r;
 }
 
-// pass 1: solve [rhs | u_tau | u_alpha]; pass 2: solve rhs.  Then the 2x2 border system and dP.
-__global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
-  const int b = blockIdx.x;
+// After the block solves (tmpc_cr.h) of pass 1 ([rhs | u_tau | u_alpha]) or pass 2 (rhs; all three while centering): the 2 x 2
+// border system of (tau, alpha) and dP.  One workgroup per active problem.
+__global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* alist, int pass) {
+  const int b = alist[blockIdx.x];
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ double red[8];
   double* pr = w.prob + (size_t)b * PS;
-  const int p = dm.p, dp = dm.dp, nt = dm.nt, tid = threadIdx.x, nx = dm.nx;
-  const size_t bs = (size_t)dp * dp;
-  const double* D = w.D + (size_t)b * p * bs;
-  const double* O = w.O + (size_t)b * p * bs;
-  const double* F = w.F + (size_t)b * p * bs;
-  const double* Li = w.Linv + (size_t)b * p * nt * TB * TB;
+  const int p = dm.p, dp = dm.dp, tid = threadIdx.x, nx = dm.nx;
   const size_t vl = (size_t)p * dp;
   double* W3 = w.W3 + (size_t)b * vl * 3;
   double* Z = w.Z + (size_t)b * vl;
   double* TU = w.TU + (size_t)b * vl * 2;
   const double* U = w.U + (size_t)b * vl * 2;
-  double* red = lds + solve_lds_doubles(dp) - 8;
   if (pass == 1 && phase != PH_MAIN) return;           // centering: everything happens in pass 2
   const bool three = (pass == 1) || (phase != PH_MAIN);
   if (three) {
-    wg_cyclic_solve<3>(W3, D, O, F, Li, p, dp, nt, lds);
     double s00 = 0.0, s01 = 0.0, s11 = 0.0;
     for (size_t e = tid; e < vl; e += 256) {
       const double t0 = W3[e * 3 + 1], t1 = W3[e * 3 + 2];
@@ -784,8 +459,6 @@ __global__ void __launch_bounds__(256) k_solve(WS w, Dims dm, int pass) {
     }
     s00 = wg_reduce_sum(s00, red); s01 = wg_reduce_sum(s01, red); s11 = wg_reduce_sum(s11, red);
     if (tid == 0) { pr[P_SB00] = pr[P_BTT] - s00; pr[P_SB01] = pr[P_BTA] - s01; pr[P_SB11] = pr[P_BAA] - s11; }
-  } else {
-    wg_cyclic_solve<1>(Z, D, O, F, Li, p, dp, nt, lds);
   }
   __syncthreads();
   // border:  rb = [rhs_tau, rhs_alpha] - U' z ;  db = Sb^-1 rb ;  dp = z - TU db

@@ -38,7 +38,7 @@ struct PhiStage {
 };
 __device__ __forceinline__ PhiStage phi_stage(const WS& w, const Dims& dm, size_t sid) {
   PhiStage s;
-  const int nc = w.ncnt ? w.ncnt[sid] : 0;
+  const int nc = stage_rows(w, dm, sid) - dm.ng;          // clamped to the room of the handle
   s.nrow = dm.ng + nc; s.na = 0;
   s.a0[0] = s.a0[1] = 0; s.am[0] = s.am[1] = 0;
   if (dm.constr) {
@@ -160,7 +160,7 @@ constexpr int PHI_PRE_LDS = 4 * MS + NRM * NMAX + 4 * NRM * NMAX + 4 * NRM * NRM
 // scalars are left alone.
 __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
@@ -343,73 +343,10 @@ __device__ __forceinline__ double phi_bvec(const double* pvec, const Dims& dm, s
   return (a == c) ? v : 2.0 * v;
 }
 
-// after k_schur, before k_factor: rank-nrow corrections of D_k (lower triangle + pivot reference) and of the coupling block
-__global__ void __launch_bounds__(256) k_phi_schur(WS w, Dims dm) {
-  const int sid = blockIdx.x;
-  const int b = sid / dm.p, k = sid - b * dm.p;
-  const int* ip = w.iprob + (size_t)b * IS;
-  if (ip[I_PHASE] == PH_DONE) return;
-  const int tid = threadIdx.x, nx = dm.nx, d = dm.d, dp = dm.dp, nzs = dm.nz;
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int km = (k == 0) ? dm.p - 1 : k - 1;
-  const size_t sm1 = (size_t)b * dm.p + km;
-  const int ng = stage_rows(w, dm, sid), ngm = stage_rows(w, dm, sm1);
-  double* av = sm; double* Kav = av + dm.nr * d; double* bm = Kav + dm.nr * d; double* Kbm = bm + dm.nr * d; double* Kbv = Kbm + dm.nr * d;
-  double* qk = psm_at(w.psm, dm, sid); double* qm = psm_at(w.psm, dm, sm1);
-  // enumerate idx -> (a, c)
-  for (int idx = tid; idx < d; idx += 256) {
-    int a = 0, rem = idx;
-    while (rem >= nx - a) { rem -= nx - a; ++a; }
-    const int c = a + rem;
-    for (int i = 0; i < ng; ++i) { av[i * d + idx] = phi_avec(w.pvec, dm, sid, i, a, c); Kbv[i * d + idx] = phi_bvec(w.pvec, dm, sid, i, a, c); }
-    for (int i = 0; i < ngm; ++i) bm[i * d + idx] = phi_bvec(w.pvec, dm, sm1, i, a, c);
-  }
-  __syncthreads();
-  // K a, K b (this stage) and K b (previous stage); Kbv holds b on entry
-  for (int idx = tid; idx < d; idx += 256) {
-    double ka[NRM], kb[NRM];
-    for (int i = 0; i < ng; ++i) {
-      double x = 0.0, y = 0.0;
-      for (int j = 0; j < ng; ++j) { x = fma(PSM_K(qk)[i * nzs + j], av[j * d + idx], x); y = fma(PSM_K(qk)[i * nzs + j], Kbv[j * d + idx], y); }
-      ka[i] = x; kb[i] = y;
-    }
-    for (int i = 0; i < ng; ++i) { Kav[i * d + idx] = ka[i]; Kbv[i * d + idx] = kb[i]; }
-    for (int i = 0; i < ngm; ++i) {
-      double x = 0.0;
-      for (int j = 0; j < ngm; ++j) x = fma(PSM_K(qm)[i * nzs + j], bm[j * d + idx], x);
-      Kbm[i * d + idx] = x;
-    }
-  }
-  __syncthreads();
-  double* Dg = w.D + (size_t)sid * dp * dp;
-  const bool corner = (k == dm.p - 1);
-  double* Cg = corner ? (w.F + (size_t)(b * dm.p) * dp * dp) : (w.O + (size_t)sid * dp * dp);
-  double* dd = w.Ddiag + (size_t)sid * dp;
-  for (int e = tid; e < d * d; e += 256) {
-    const int row = e / d, col = e - row * d;
-    const size_t o = (size_t)row * dp + col;
-    // coupling block C_k[x][y] -= sum_i a_i[x] (K b)_i[y]; stored entry (row, col) is C_k[row][col] for the corner, C_k[col][row] otherwise
-    {
-      const int x = corner ? row : col, y = corner ? col : row;
-      double cv = 0.0;
-      for (int i = 0; i < ng; ++i) cv = fma(av[i * d + x], Kbv[i * d + y], cv);
-      Cg[o] -= cv;
-    }
-    if (col <= row) {
-      double dv = 0.0;
-      for (int i = 0; i < ng; ++i) dv = fma(av[i * d + row], Kav[i * d + col], dv);
-      for (int i = 0; i < ngm; ++i) dv = fma(bm[i * d + row], Kbm[i * d + col], dv);
-      const double nv = Dg[o] - dv;
-      Dg[o] = nv;
-      if (row == col) dd[row] = nv;
-    }
-  }
-}
-
 // after k_stage_rhs, before k_gather / k_solve: r_loc, K r_loc, and the eliminated part of the border right-hand sides
 __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -461,50 +398,11 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug
   }
 }
 
-// after k_gather, before k_solve: eliminated part of the P-block right-hand side and of the two border columns
-__global__ void __launch_bounds__(64) k_phi_gather(WS w, Dims dm, int pass) {
-  const int sid = blockIdx.x, lane = threadIdx.x;
-  const int b = sid / dm.p, k = sid - b * dm.p;
-  const int* ip = w.iprob + (size_t)b * IS;
-  const int phase = ip[I_PHASE];
-  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
-  const bool three = (pass == 1) || (phase != PH_MAIN);
-  const int nx = dm.nx, dp = dm.dp, nzs = dm.nz;
-  const int km = (k == 0) ? dm.p - 1 : k - 1;
-  const size_t sm1 = (size_t)b * dm.p + km;
-  const int ng = stage_rows(w, dm, sid), ngm = stage_rows(w, dm, sm1);
-  double* qk = psm_at(w.psm, dm, sid); double* qm = psm_at(w.psm, dm, sm1);
-  int e = 0;
-  for (int a = 0; a < nx; ++a) {
-    for (int c = a + lane; c < nx; c += 64) {
-      const int idx = e + (c - a);
-      double g = 0.0, ut = 0.0, ua = 0.0;
-      for (int i = 0; i < ng; ++i) {
-        const double ai = phi_avec(w.pvec, dm, sid, i, a, c);
-        g += ai * PSM_KR(qk, nzs)[i]; ut += ai * PSM_KCT(qk, nzs)[i]; ua += ai * PSM_KCA(qk, nzs)[i];
-      }
-      for (int i = 0; i < ngm; ++i) {
-        const double bi = phi_bvec(w.pvec, dm, sm1, i, a, c);
-        g += bi * PSM_KR(qm, nzs)[i]; ut += bi * PSM_KCT(qm, nzs)[i]; ua += bi * PSM_KCA(qm, nzs)[i];
-      }
-      if (three) {
-        double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3;
-        w3[0] -= g; w3[1] -= ut; w3[2] -= ua;
-        double* u = w.U + ((size_t)sid * dp + idx) * 2;
-        u[0] -= ut; u[1] -= ua;
-      } else {
-        w.Z[(size_t)sid * dp + idx] -= g;
-      }
-    }
-    e += nx - a;
-  }
-}
-
 // after k_solve, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
 // Mehrotra second-order terms in pass 1
 __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -636,7 +534,7 @@ __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
 //   D_{k+1}[d+i][0..d) = b_k,i   D_{k+1}[d+i][d+j] = T_loc,loc[i][j]   coupling block [block k+1][block k]: row d+i = a_k,i
 // after k_schur (which writes identity there), before k_factor
 __global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
-  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
@@ -646,8 +544,8 @@ __global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
   const size_t bs = (size_t)dp * dp;
   double* Dn = w.D + ((size_t)b * p + kn) * bs;
   double* ddn = w.Ddiag + ((size_t)b * p + kn) * dp;
-  const bool corner = (k == p - 1);
-  double* Cg = corner ? (w.F + (size_t)(b * p) * bs) : (w.O + (size_t)sid * bs);
+  const bool corner = (w.cr_orient[k] != 0);        // coupling block stored as T[P_k,P_{k+1}] (rows = block k) instead of T[P_{k+1},P_k]
+  double* Cg = w.O + (size_t)sid * bs;
   const double* q = psm_at(w.psm, dm, sid);
   for (int i = 0; i < nz; ++i) {
     double* drow = Dn + (size_t)(d + i) * dp;
@@ -662,8 +560,8 @@ __global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
         const double av = phi_avec(w.pvec, dm, sid, i, a, c), bv = phi_bvec(w.pvec, dm, sid, i, a, c);
         if (p == 1) { drow[idx] = av + bv; continue; }          // both couplings land in the one P block
         drow[idx] = bv;
-        if (corner) Cg[(size_t)idx * dp + d + i] = av;          // [block p-1][block 0]
-        else Cg[(size_t)(d + i) * dp + idx] = av;               // [block k+1][block k]
+        if (corner) Cg[(size_t)idx * dp + d + i] = av;          // stored [block k][block k+1]
+        else Cg[(size_t)(d + i) * dp + idx] = av;               // stored [block k+1][block k]
       }
       e += nx - a;
     }
@@ -672,7 +570,7 @@ __global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
 
 // after k_gather (which zero-pads the tails): right-hand side and border-column entries of y_loc in the vectors of block k+1
 __global__ void __launch_bounds__(64) k_aug_gather(WS w, Dims dm, int pass) {
-  const int sid = blockIdx.x, lane = threadIdx.x;
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];

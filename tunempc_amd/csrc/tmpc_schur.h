@@ -26,7 +26,7 @@ __device__ __forceinline__ double hkm_entry(const double* __restrict__ Lx, const
 // (stored transposed as the sub-diagonal block O_k = T[P_{k+1},P_k], or, for k = p-1, untransposed as the
 // cyclic corner F_0 = T[P_{p-1}, P_0]).
 __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
-  const int sid = blockIdx.x;
+  const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
@@ -59,8 +59,10 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   }
   __syncthreads();
   double* Dg = w.D + (size_t)sid * dp * dp;
-  const bool corner = (k == dm.p - 1);
-  double* Cg = corner ? (w.F + (size_t)(b * dm.p) * dp * dp) : (w.O + (size_t)sid * dp * dp);
+  // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
+  // reduction eliminates first.  `corner` = stored as C_k = T[P_k,P_{k+1}], otherwise transposed, O_k = T[P_{k+1},P_k]
+  const bool corner = (w.cr_orient[k] != 0);
+  double* Cg = w.O + (size_t)sid * dp * dp;
   double* dd = w.Ddiag + (size_t)sid * dp;
   const int tot = dp * dp;
   // Every store is coalesced along the fastest index of the STORED matrix: e -> (row, col) of the stored block.
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
 // Gather the adjoint pieces into svec right-hand sides:  v_j[(ab)] = w_ab * (adjV[j-1] - adjE[j])[a][b]
 // which: 0 -> Z (pass-2 rhs), 1 -> W3 (pass-1: rhs | u_tau | u_alpha) and U
 __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
-  const int sid = blockIdx.x;
+  const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -168,7 +170,7 @@ __device__ __forceinline__ double emin(const double* eigmin, int b, int p, int w
 
 // after k_stage_pre: mu, residual norms, phase logic (the same control flow as the CPU restatement used by the tests)
 __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
   double* pr = w.prob + (size_t)b * PS;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void raw_steps(const double* pr, double minx, double 
 
 // after the predictor direction (pass 1): Mehrotra centring parameter
 __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_MAIN) return;
   double* pr = w.prob + (size_t)b * PS;
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
 
 // after the final direction (pass 2): step lengths, scalar updates
 __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE) return;
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     else if (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     pr[P_PREVSTEPN] = full ? stepn : -1.0;
   }
-  if (ip[I_PHASE] != PH_DONE) atomicAdd(w.active, 1);
+  if (ip[I_PHASE] != PH_DONE) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; }
 }
 
 }  // namespace tmpc

@@ -7,8 +7,15 @@
 
 namespace tmpc {
 
+// index (b*p + k)*4 + which for k_eigmin: four workgroups per stage
+__device__ __forceinline__ int stage_id4(const WS& w, const Dims& dm) {
+  if (!w.alist) return blockIdx.x;
+  const int sb = blockIdx.x >> 2, bi = sb / dm.p;
+  return ((w.alist[bi] * dm.p + (sb - bi * dm.p)) << 2) | (blockIdx.x & 3);
+}
+
 #define TMPC_STAGE_PROLOGUE                                     \
-  const int sid = blockIdx.x;                                   \
+  const int sid = stage_id(w, dm);                              \
   const int b = sid / dm.p;                                     \
   const int k = sid - b * dm.p;                                 \
   const int lane = threadIdx.x;                                 \
@@ -86,7 +93,7 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
     ip[I_EARLY] = early;
     ip[I_PHASE] = early ? PH_DONE : PH_MAIN;
     ip[I_IPMSTATUS] = early ? IPM_OPTIMAL : IPM_MAXITER;
-    if (!early) atomicAdd(w.active, 1);
+    if (!early) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; }
   }
 }
 
@@ -133,7 +140,11 @@ __device__ __forceinline__ void adj_V(double* out, double* t, const double* sV, 
 }
 
 // rows of [G_k; C_k] present at stage sid
-__device__ __forceinline__ int stage_rows(const WS& w, const Dims& dm, size_t sid) { return dm.ng + (w.ncnt ? w.ncnt[sid] : 0); }
+__device__ __forceinline__ int stage_rows(const WS& w, const Dims& dm, size_t sid) {
+  int nc = w.ncnt ? w.ncnt[sid] : 0;                    // the device entry cannot range-check the caller's counts: clamp to the room of the handle
+  nc = nc < 0 ? 0 : (nc > dm.nr - dm.ng ? dm.nr - dm.ng : nc);
+  return dm.ng + nc;
+}
 // out (n x n LDS slot) += scale * sum_i coef[i] g_i g_i'   (equality-constraint term, G rows and coefficients in global memory)
 __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const double* coef, double scale, int ng, int n, int lane) {
   for (int e = lane; e < n * n; e += 64) {
@@ -393,7 +404,7 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
 // ------------------------------------------------------------------ smallest eigenvalue of one step-length matrix
 // one single-wave block per matrix (4 per stage): 8.9 KB of LDS each -> ~17 blocks (waves) resident per CU
 __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
-  const int mid = blockIdx.x;              // (b*p + k)*4 + which
+  const int mid = stage_id4(w, dm);        // (b*p + k)*4 + which
   const int b = (mid >> 2) / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
