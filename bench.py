@@ -49,31 +49,27 @@ def hbm_traffic_per_launch():
         return None
 
 
-def cpu_baseline(p_full, nx, mb, tol, budget_s=25.0):
-    """Oracle (numpy/LAPACK restatement of the same algorithm) timed on host cores, bounded sample."""
+def cpu_baseline(p, nx, mb, tol):
+    """The C++/OpenMP restatement of the same structured algorithm (oracle/cpu_ipm: LAPACK/BLAS on the d x d blocks, one problem
+    per OpenMP thread), timed on the host cores at the BENCH shape: one problem on one thread, then one problem per core on all
+    cores (bounded: about 10 + 15-25 s of CPU work).  Same seeded generator as the GPU batch.  Not PICOS+MOSEK."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import convexify_oracle as co
-    cores = min(os.cpu_count() or 1, 32)       # 300 x 300 blocks: more BLAS threads only add contention
-    try:
-        from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=cores)
-    except Exception:
-        cores = int(os.environ.get('OPENBLAS_NUM_THREADS', os.cpu_count() or 1))
-    p_s = min(p_full, 8)
-    A, B, H, _, _ = co.gen_problem(424242, p_s, nx, mb)
+    import cpu_ipm
+    from tunempc_amd import synthetic
+    cores = min(os.cpu_count() or 1, cpu_ipm.max_threads(), 64)
+    A, B, H = synthetic.gen_batch(100000, cores, p, nx, mb)
     t0 = time.perf_counter()
-    nprob = 0
-    while True:
-        r = co.convexify_arrays(A, B, H, dict(tol=tol))
-        nprob += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or el + el / nprob > 1.3 * budget_s:
-            break
-    el = time.perf_counter() - t0
-    return {"value": nprob * p_s / el, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/convexify_oracle.py (numpy + OpenBLAS, {cores} threads) on {nprob} problem(s) of nx={nx}, m={mb}, "
-                      f"p={p_s} (same stage size n={nx + mb} as the workload, shorter period; cost is linear in p), "
-                      f"{r['iters']} IPM iterations, {el:.1f} s"}
+    o1 = cpu_ipm.convexify_batch(A[:1], B[:1], H[:1], tol=tol, threads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oc = cpu_ipm.convexify_batch(A, B, H, tol=tol, threads=cores)
+    tc = time.perf_counter() - t0
+    return {"value": cores * p / tc, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+            "single_thread_value": p / t1,
+            "sample": f"oracle/cpu_ipm (C++/OpenMP restatement of the structured IPM, OpenBLAS on the {nx * (nx + 1) // 2}-wide blocks) at the bench "
+                      f"shape nx={nx}, m={mb}, p={p}: {cores} problems on {cores} threads in {tc:.1f} s ({int(oc['iters'].max())} IPM iterations max, "
+                      f"{int((oc['status'] == 0).sum())}/{cores} Optimal); 1 problem on 1 thread in {t1:.1f} s ({p / t1:.2f} stage-conv/s, "
+                      f"{int(o1['iters'][0])} iterations)"}
 
 
 def main():

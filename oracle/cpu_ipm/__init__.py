@@ -1,0 +1,51 @@
+"""ctypes loader of the C++/OpenMP CPU baseline (oracle/cpu_ipm/cpu_ipm.cpp)  --  TEST / MEASUREMENT INFRASTRUCTURE ONLY.
+Only tests/ and bench.py's cpu_baseline leg import this; the product (tunempc_amd) never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libcpu_ipm.so')
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, 'cpu_ipm.cpp')
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', HERE, '-s'] + (['-B'] if force else []))
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        lib = C.CDLL(LIB)
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)
+        lib.cpu_ipm_convexify_batch.restype = C.c_int
+        lib.cpu_ipm_convexify_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp, C.c_double, C.c_int, dp, dp, ip, ip]
+        lib.cpu_ipm_max_threads.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def convexify_batch(A, B, H, tol=0.0, threads=1):
+    """A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict(Hc, kappa, status, iters); `threads` OpenMP threads, one problem each."""
+    lib = load()
+    A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64); H = np.ascontiguousarray(H, dtype=np.float64)
+    nb, p, nx, _ = A.shape
+    mb = B.shape[3]
+    Hc = np.empty_like(H); kappa = np.empty(nb); status = np.empty(nb, np.int32); iters = np.empty(nb, np.int32)
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib.cpu_ipm_convexify_batch(nb, p, nx, mb, d(A), d(B), d(H), float(tol), int(threads), d(Hc), d(kappa), i(status), i(iters))
+    if rc != 0:
+        raise RuntimeError('cpu_ipm_convexify_batch failed: %d' % rc)
+    return dict(Hc=Hc, kappa=kappa, status=status, iters=iters)
+
+
+def max_threads():
+    return int(load().cpu_ipm_max_threads())
