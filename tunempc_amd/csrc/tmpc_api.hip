@@ -5,6 +5,8 @@
 #include <new>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/tunempc_hip.h"
@@ -37,23 +39,38 @@ struct DevBuf {
   template <typename T> T* as() const { return (T*)p; }
 };
 
-struct tmpc_handle {
-  Dims dm;          // dm.B = chunk capacity
-  Opts opt;
-  int flags;
+// A handle holds up to MAXL independent LANES: each owns a slice of the workspace, a stream and a host thread while a call runs.
+// A wave of problems is split over the lanes and their interior-point loops run concurrently: the matrix-core-bound kernels of the
+// block factorisation of one lane overlap with the LDS / latency-bound stage kernels and the HBM-bound triangular solves of the
+// other (the loops are independent: problems never interact).  Results do not depend on the number of lanes.
+constexpr int MAXL = 4;
+struct Lane {
   WS ws;
-  void* slab;
-  size_t slab_bytes;
-  // chunk-local copies of the user inputs when called with host pointers
-  double *dA, *dB, *dH;          // device staging for host API (chunk sized)
-  double* dG;                    // [chunk][p][nr][n] staging of the equality- / active-constraint Jacobians
-  int32_t* dncnt;                // [chunk][p] rows of C_k per stage (Step 2)
-  double* d_info;                // [chunk][16]
-  double* d_abk;                 // [chunk][3]
-  int32_t* d_si;                 // [chunk][2]
+  // lane-local copies of the user inputs when called with host pointers
+  double *dA, *dB, *dH;          // device staging for the host entries (lane capacity)
+  double* dG;                    // [cap][p][nr][n] staging of the equality- / active-constraint Jacobians
+  int32_t* dncnt;                // [cap][p] rows of C_k per stage (Step 2)
+  double* d_info;                // [cap][16]
+  double* d_abk;                 // [cap][3]
+  int32_t* d_si;                 // [cap][2]
+  hipStream_t st;                // the lane's own stream
   hipEvent_t ev[8];
   double prof[16];               // see tmpc_get_profile
   std::vector<hipEvent_t> kev;   // profile mode: event pairs around the launches of one factorisation (class = index % 3)
+  int last_nb;                   // problems this lane solved in the last wave (trace / multiplier read-back)
+  char err[512];                 // error text of the lane's worker thread
+};
+
+struct tmpc_handle {
+  Dims dm;          // dm.B = lane capacity (problems per lane and wave)
+  int chunk;        // problems per wave = nlanes * dm.B
+  int nlanes;
+  Opts opt;
+  int flags;
+  Lane lane[MAXL];
+  void* slab;
+  size_t slab_bytes;
+  hipEvent_t ev_in;              // inputs of a device-resident call are ready on the caller's stream
   int device;                    // HIP device the workspace lives on
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
@@ -100,7 +117,7 @@ struct Carver {
   }
 };
 
-static size_t carve(WS& w, const Dims& dm, char* base, tmpc_handle* h) {
+static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   Carver c{base, 0};
   const size_t BP = (size_t)dm.B * dm.p, nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
   const size_t bs = (size_t)dm.dp * dm.dp;
@@ -365,7 +382,7 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
 }
 
 // one chunk (nb = actual number of problems in this chunk, <= capacity); inputs already on device
-static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
+static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
                      const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0) {
   Dims dm = h->dm;
   dm.B = nb;
@@ -378,7 +395,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   dm.dp = (dm.d + (eq ? dm.nz : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
-  WS wall = h->ws;                       // view over ALL problems of the chunk (init / final kernels)
+  WS wall = ln->ws;                      // view over ALL problems of the chunk (init / final kernels)
   wall.A = dA; wall.Bm = dB; wall.H = dH; wall.G = dG; wall.ncnt = dncnt; wall.rho = rho;
   wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
   WS w = wall;                           // view over the problems still iterating (per-iteration kernels map blockIdx through alist)
@@ -403,17 +420,17 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
   int it = 0;
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
-    if (prof) HIPCHK(hipEventRecord(h->ev[0], st));
+    if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
-    if (prof) HIPCHK(hipEventRecord(h->ev[1], st));
+    if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
     if (eq) hipLaunchKernelGGL(k_aug_fill, dim3(BP), dim3(64), 0, st, w, dm);
-    if (prof) HIPCHK(hipEventRecord(h->ev[2], st));
+    if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
-    cr_factor(w, dm, h->sched, h->d_sched, alist, active, st, h->rs, h->mt, prof ? &h->kev : nullptr, &nkev);
-    if (prof) HIPCHK(hipEventRecord(h->ev[3], st));
+    cr_factor(w, dm, h->sched, h->d_sched, alist, active, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev);
+    if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
@@ -427,7 +444,7 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (pass == 1) {
         hipLaunchKernelGGL(k_ctrl_b, dim3(active), dim3(64), 0, st, w, dm);
-        if (prof) HIPCHK(hipEventRecord(h->ev[4], st));
+        if (prof) HIPCHK(hipEventRecord(ln->ev[4], st));
       } else {
         hipLaunchKernelGGL(k_ctrl_c, dim3(active), dim3(64), 0, st, w, dm);
       }
@@ -436,19 +453,19 @@ static int run_chunk(tmpc_handle* h, int nb, const double* dA, const double* dB,
     if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
-    if (prof) HIPCHK(hipEventRecord(h->ev[5], st));
+    if (prof) HIPCHK(hipEventRecord(ln->ev[5], st));
     HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (prof) {
       float ms;
-      for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1])); h->prof[i] += ms; }
-      h->prof[5] += 1.0;
-      h->prof[8] += (double)active;
-      for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1])); h->prof[9 + (i / 2) % 3] += ms; }
+      for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[i], ln->ev[i + 1])); ln->prof[i] += ms; }
+      ln->prof[5] += 1.0;
+      ln->prof[8] += (double)active;
+      for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, ln->kev[i], ln->kev[i + 1])); ln->prof[9 + (i / 2) % 3] += ms; }
     }
     ++it;
   }
-  h->prof[7] += it;
+  ln->prof[7] += it;
   hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
   hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, wall, dm);
   HIPCHK(hipGetLastError());
@@ -510,42 +527,60 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   }
   tmpc_handle* h = new (std::nothrow) tmpc_handle();
   if (!h) return TMPC_E_NOMEM;
-  memset(h->prof, 0, sizeof(h->prof)); h->slab = nullptr; h->d_sched = nullptr;
-  h->dA = h->dB = h->dH = h->dG = nullptr; h->dncnt = nullptr; h->d_info = h->d_abk = nullptr; h->d_si = nullptr;
+  h->slab = nullptr; h->d_sched = nullptr; h->ev_in = nullptr;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return TMPC_E_HIP; }
-  h->dm = make_dims(chunk, p, nx, mb, ng, nc);
+  // lanes: two concurrent half-waves once a wave holds enough problems (TMPC_LANES overrides; 1 = the plain sequential loop)
+  int nl = (chunk >= 16) ? 2 : 1;
+  { const char* e = getenv("TMPC_LANES"); if (e && atoi(e) >= 1) nl = std::min(atoi(e), MAXL); }
+  nl = std::max(1, std::min(nl, chunk));
+  h->nlanes = nl;
+  const int cap = (chunk + nl - 1) / nl;
+  h->chunk = cap * nl;
+  h->dm = make_dims(cap, p, nx, mb, ng, nc);
   h->sched = cr_build(p);
   { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
   { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->flags = 0;
-  h->slab_bytes = carve(h->ws, h->dm, nullptr, nullptr);
+  WS tmp;
+  const size_t lane_bytes = carve(tmp, h->dm, nullptr, nullptr);
+  h->slab_bytes = lane_bytes * nl;
   if (hipMalloc(&h->slab, h->slab_bytes) != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "hipMalloc(%zu bytes) failed", h->slab_bytes);
     delete h;
     return TMPC_E_NOMEM;
   }
-  carve(h->ws, h->dm, (char*)h->slab, h);
   int rc = cr_upload(h->sched, &h->d_sched);
-  if (rc != TMPC_OK) { hipFree(h->slab); delete h; return rc; }
-  for (int i = 0; i < 8; ++i) { if (hipEventCreate(&h->ev[i]) != hipSuccess) { hipFree(h->slab); hipFree(h->d_sched); delete h; return TMPC_E_HIP; } }
-  rc = set_lds_attrs(h->device);
-  if (rc != TMPC_OK) { hipFree(h->slab); hipFree(h->d_sched); delete h; return rc; }
+  bool ok = (rc == TMPC_OK) && hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
+  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
+  for (int l = 0; l < nl && ok; ++l) {
+    Lane& ln = h->lane[l];
+    carve(ln.ws, h->dm, (char*)h->slab + (size_t)l * lane_bytes, &ln);
+    ok = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&ln.ev[i]) == hipSuccess;
+  }
+  if (ok) { rc = set_lds_attrs(h->device); ok = (rc == TMPC_OK); }
+  if (!ok) { tmpc_destroy(h); return rc != TMPC_OK ? rc : TMPC_E_HIP; }
   *out = h;
   return TMPC_OK;
 }
 
 int tmpc_destroy(tmpc_handle* h) {
   if (!h) return TMPC_E_ARG;
-  for (int i = 0; i < 8; ++i) hipEventDestroy(h->ev[i]);
-  for (hipEvent_t e : h->kev) hipEventDestroy(e);
-  hipFree(h->slab);
-  hipFree(h->d_sched);
+  for (int l = 0; l < MAXL; ++l) {
+    Lane& ln = h->lane[l];
+    for (int i = 0; i < 8; ++i) if (ln.ev[i]) hipEventDestroy(ln.ev[i]);
+    for (hipEvent_t e : ln.kev) hipEventDestroy(e);
+    if (ln.st) hipStreamDestroy(ln.st);
+  }
+  if (h->ev_in) hipEventDestroy(h->ev_in);
+  if (h->slab) hipFree(h->slab);
+  if (h->d_sched) hipFree(h->d_sched);
   delete h;
   return TMPC_OK;
 }
 
-int tmpc_get_chunk(tmpc_handle* h) { return h ? h->dm.B : TMPC_E_ARG; }
+int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
@@ -557,33 +592,58 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
   return TMPC_OK;
 }
 
+}  // extern "C"
+
+// rows of the last wave live in the lanes that solved them: lane 0 first
+template <typename F> static int for_last_wave(tmpc_handle* h, int nb, F&& f) {
+  int done = 0;
+  for (int l = 0; l < h->nlanes && done < nb; ++l) {
+    const int m = std::min(h->lane[l].last_nb, nb - done);
+    if (m > 0) { int rc = f(h->lane[l], done, m); if (rc != TMPC_OK) return rc; }
+    done += m;
+  }
+  return done == nb ? TMPC_OK : TMPC_E_ARG;
+}
+
+extern "C" {
+
 int tmpc_get_trace(tmpc_handle* h, int nb, double* out) {
-  if (!h || !out || nb < 1 || nb > h->dm.B) return TMPC_E_ARG;
-  HIPCHK(hipMemcpy(out, h->ws.trace, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), hipMemcpyDeviceToHost));
-  return TMPC_OK;
+  if (!h || !out || nb < 1 || nb > h->chunk) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const size_t row = (size_t)TRACE_LEN * TRACE_W;
+  return for_last_wave(h, nb, [&](Lane& ln, int o, int m) {
+    HIPCHK(hipMemcpy(out + (size_t)o * row, ln.ws.trace, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+  });
 }
 
 int tmpc_debug_get_multipliers(tmpc_handle* h, int nb, int nr, double* phi, double* z, double* dphi, double* dz) {
-  if (!h || nb < 1 || nb > h->dm.B || nr < 1 || nr > h->dm.nr || !h->ws.phi) return TMPC_E_ARG;
-  const size_t cnt = (size_t)nb * h->dm.p * nr * sizeof(double);
-  if (phi) HIPCHK(hipMemcpy(phi, h->ws.phi, cnt, hipMemcpyDeviceToHost));
-  if (z) HIPCHK(hipMemcpy(z, h->ws.zph, cnt, hipMemcpyDeviceToHost));
-  if (dphi) HIPCHK(hipMemcpy(dphi, h->ws.dphi, cnt, hipMemcpyDeviceToHost));
-  if (dz) HIPCHK(hipMemcpy(dz, h->ws.dzph, cnt, hipMemcpyDeviceToHost));
-  return TMPC_OK;
+  if (!h || nb < 1 || nb > h->chunk || nr < 1 || nr > h->dm.nr || !h->lane[0].ws.phi) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const size_t row = (size_t)h->dm.p * nr;
+  return for_last_wave(h, nb, [&](Lane& ln, int o, int m) {
+    const size_t cnt = (size_t)m * row * sizeof(double);
+    if (phi) HIPCHK(hipMemcpy(phi + o * row, ln.ws.phi, cnt, hipMemcpyDeviceToHost));
+    if (z) HIPCHK(hipMemcpy(z + o * row, ln.ws.zph, cnt, hipMemcpyDeviceToHost));
+    if (dphi) HIPCHK(hipMemcpy(dphi + o * row, ln.ws.dphi, cnt, hipMemcpyDeviceToHost));
+    if (dz) HIPCHK(hipMemcpy(dz + o * row, ln.ws.dzph, cnt, hipMemcpyDeviceToHost));
+    return TMPC_OK;
+  });
 }
 
 int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t count, double* out) {
   if (!h || !out) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const WS& ws = h->lane[0].ws;                 // lane 0 (run with TMPC_LANES=1 to see a whole wave)
   const double* src = nullptr;
   switch (which) {
-    case 0: src = h->ws.psm; break;
-    case 1: src = h->ws.pvec; break;
-    case 2: src = h->ws.Ddiag; break;
-    case 3: src = h->ws.D; break;
-    case 4: src = h->ws.part; break;
-    case 5: src = h->ws.O; break;
-    case 6: src = h->ws.F; break;
+    case 0: src = ws.psm; break;
+    case 1: src = ws.pvec; break;
+    case 2: src = ws.Ddiag; break;
+    case 3: src = ws.D; break;
+    case 4: src = ws.part; break;
+    case 5: src = ws.O; break;
+    case 6: src = ws.F; break;
     default: return TMPC_E_ARG;
   }
   if (!src) return TMPC_E_ARG;
@@ -593,27 +653,92 @@ int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t co
 
 int tmpc_get_profile(tmpc_handle* h, double* out16) {
   if (!h || !out16) return TMPC_E_ARG;
-  for (int i = 0; i < 16; ++i) { out16[i] = h->prof[i]; h->prof[i] = 0.0; }
+  for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+  for (int l = 0; l < h->nlanes; ++l)
+    for (int i = 0; i < 16; ++i) {
+      if (i == 7) out16[i] = std::max(out16[i], h->lane[l].prof[i]); else out16[i] += h->lane[l].prof[i];
+      h->lane[l].prof[i] = 0.0;
+    }
+  out16[12] = (double)h->nlanes;
   return TMPC_OK;
 }
 
-static int copy_out(tmpc_handle* h, int nb, size_t off, double* Hc, double* dHc, double* P, double* alpha, double* beta,
-                    double* kappa, int32_t* status, int32_t* iters, double* info, hipMemcpyKind kind, hipStream_t st) {
+// ---- one call = inputs + outputs of nbt problems; a wave of up to `chunk` problems is split over the lanes
+struct Call {
+  int nbt;
+  const double *A, *B, *H, *J; const int32_t* ncnt; double rho;
+  double *Hc, *dHc, *P, *FgF, *alpha, *beta, *kappa; int32_t *status, *iters; double* info;
+  bool host;           // host pointers (staged through the lane's buffers) or device pointers
+  int jr;              // row stride of J / FgF in this call (0: no constraint rows)
+};
+
+static int lane_run(tmpc_handle* h, Lane* ln, const Call& c, int off, int nb) {
+  if (hipSetDevice(h->device) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipSetDevice(%d) failed", h->device); return TMPC_E_HIP; }
   const Dims& dm = h->dm;
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, BP = (size_t)nb * dm.p;
+  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)c.jr * dm.n;
+  const size_t so = (size_t)off * dm.p, BP = (size_t)nb * dm.p;
+  hipStream_t st = ln->st;
+  const double *dA = c.A + so * nxx, *dB = c.B ? c.B + so * nxm : nullptr, *dH = c.H + so * nn, *dJ = c.J ? c.J + so * gn : nullptr;
+  const int32_t* dn = c.ncnt ? c.ncnt + so : nullptr;
+  if (c.host) {
+    HIPCHK(hipMemcpyAsync(ln->dA, dA, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st)); dA = ln->dA;
+    if (dm.mb > 0) { HIPCHK(hipMemcpyAsync(ln->dB, dB, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st)); dB = ln->dB; }
+    HIPCHK(hipMemcpyAsync(ln->dH, dH, BP * nn * sizeof(double), hipMemcpyHostToDevice, st)); dH = ln->dH;
+    if (dJ) { HIPCHK(hipMemcpyAsync(ln->dG, dJ, BP * gn * sizeof(double), hipMemcpyHostToDevice, st)); dJ = ln->dG; }
+    if (dn) { HIPCHK(hipMemcpyAsync(ln->dncnt, dn, BP * sizeof(int32_t), hipMemcpyHostToDevice, st)); dn = ln->dncnt; }
+  }
+  int rc = run_chunk(h, ln, nb, dA, dB, dH, st, dJ, dn, c.rho);
+  if (rc != TMPC_OK) return rc;
+  ln->last_nb = nb;
+  const hipMemcpyKind kind = c.host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   Dims d2 = dm; d2.B = nb;
-  hipLaunchKernelGGL(k_output, dim3((nb + 63) / 64), dim3(64), 0, st, h->ws, d2, h->d_abk, h->d_abk + nb, h->d_abk + 2 * nb,
-                     h->d_si, h->d_si + nb, h->d_info);
-  if (Hc) HIPCHK(hipMemcpyAsync(Hc + off * dm.p * nn, h->ws.Hc, BP * nn * sizeof(double), kind, st));
-  if (dHc) HIPCHK(hipMemcpyAsync(dHc + off * dm.p * nn, h->ws.dHc, BP * nn * sizeof(double), kind, st));
-  if (P) HIPCHK(hipMemcpyAsync(P + off * dm.p * nxx, h->ws.Pout, BP * nxx * sizeof(double), kind, st));
-  if (alpha) HIPCHK(hipMemcpyAsync(alpha + off, h->d_abk, nb * sizeof(double), kind, st));
-  if (beta) HIPCHK(hipMemcpyAsync(beta + off, h->d_abk + nb, nb * sizeof(double), kind, st));
-  if (kappa) HIPCHK(hipMemcpyAsync(kappa + off, h->d_abk + 2 * nb, nb * sizeof(double), kind, st));
-  if (status) HIPCHK(hipMemcpyAsync(status + off, h->d_si, nb * sizeof(int32_t), kind, st));
-  if (iters) HIPCHK(hipMemcpyAsync(iters + off, h->d_si + nb, nb * sizeof(int32_t), kind, st));
-  if (info) HIPCHK(hipMemcpyAsync(info + off * TMPC_INFO_STRIDE, h->d_info, (size_t)nb * TMPC_INFO_STRIDE * sizeof(double), kind, st));
+  hipLaunchKernelGGL(k_output, dim3((nb + 63) / 64), dim3(64), 0, st, ln->ws, d2, ln->d_abk, ln->d_abk + nb, ln->d_abk + 2 * nb,
+                     ln->d_si, ln->d_si + nb, ln->d_info);
+  if (c.Hc) HIPCHK(hipMemcpyAsync(c.Hc + so * nn, ln->ws.Hc, BP * nn * sizeof(double), kind, st));
+  if (c.dHc) HIPCHK(hipMemcpyAsync(c.dHc + so * nn, ln->ws.dHc, BP * nn * sizeof(double), kind, st));
+  if (c.P) HIPCHK(hipMemcpyAsync(c.P + so * nxx, ln->ws.Pout, BP * nxx * sizeof(double), kind, st));
+  if (c.FgF && c.jr > 0) HIPCHK(hipMemcpyAsync(c.FgF + so * c.jr, ln->ws.Fg, BP * c.jr * sizeof(double), kind, st));
+  if (c.alpha) HIPCHK(hipMemcpyAsync(c.alpha + off, ln->d_abk, nb * sizeof(double), kind, st));
+  if (c.beta) HIPCHK(hipMemcpyAsync(c.beta + off, ln->d_abk + nb, nb * sizeof(double), kind, st));
+  if (c.kappa) HIPCHK(hipMemcpyAsync(c.kappa + off, ln->d_abk + 2 * nb, nb * sizeof(double), kind, st));
+  if (c.status) HIPCHK(hipMemcpyAsync(c.status + off, ln->d_si, nb * sizeof(int32_t), kind, st));
+  if (c.iters) HIPCHK(hipMemcpyAsync(c.iters + off, ln->d_si + nb, nb * sizeof(int32_t), kind, st));
+  if (c.info) HIPCHK(hipMemcpyAsync(c.info + (size_t)off * TMPC_INFO_STRIDE, ln->d_info, (size_t)nb * TMPC_INFO_STRIDE * sizeof(double), kind, st));
   HIPCHK(hipStreamSynchronize(st));
+  return TMPC_OK;
+}
+
+// Split the batch into waves of `chunk` problems and every wave over the lanes (contiguous slices, lane 0 first); lanes 1.. run
+// on their own host threads.  `user` = the caller's stream for device-resident calls: the lanes start after the work queued on
+// it so far, and the call returns with every result written (the lanes have been synchronised).
+static int dispatch(tmpc_handle* h, const Call& c, hipStream_t user, bool has_user) {
+  if (has_user) {
+    HIPCHK(hipEventRecord(h->ev_in, user));
+    for (int l = 0; l < h->nlanes; ++l) HIPCHK(hipStreamWaitEvent(h->lane[l].st, h->ev_in, 0));
+  }
+  const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
+  std::chrono::steady_clock::time_point t0;
+  if (prof) t0 = std::chrono::steady_clock::now();
+  for (int l = 0; l < h->nlanes; ++l) h->lane[l].last_nb = 0;
+  for (int off = 0; off < c.nbt; off += h->chunk) {
+    const int nw = std::min(h->chunk, c.nbt - off);
+    // balanced contiguous slices (a lane never gets more than its capacity dm.B)
+    const int nl = std::min(h->nlanes, nw);
+    int lo[MAXL + 1];
+    for (int l = 0; l <= nl; ++l) lo[l] = (int)((long)nw * l / nl);
+    int rcs[MAXL]; for (int l = 0; l < MAXL; ++l) { rcs[l] = TMPC_OK; h->lane[l].last_nb = 0; }
+    std::vector<std::thread> th;
+    for (int l = 1; l < nl; ++l)
+      th.emplace_back([&, l]() {
+        rcs[l] = lane_run(h, &h->lane[l], c, off + lo[l], lo[l + 1] - lo[l]);
+        if (rcs[l] != TMPC_OK) snprintf(h->lane[l].err, sizeof(h->lane[l].err), "%s", g_err);
+      });
+    rcs[0] = lane_run(h, &h->lane[0], c, off + lo[0], lo[1] - lo[0]);
+    for (auto& t : th) t.join();
+    for (int l = 0; l < nl; ++l)
+      if (rcs[l] != TMPC_OK) { if (l > 0) snprintf(g_err, sizeof(g_err), "%s", h->lane[l].err); return rcs[l]; }
+  }
+  if (prof) h->lane[0].prof[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return TMPC_OK;
 }
 
@@ -623,26 +748,8 @@ int tmpc_convexify_batch_device(tmpc_handle* h, int nbt, const double* dA, const
   if (h && nbt == 0) return TMPC_OK;           // empty shard
   if (!h || nbt < 1 || !dA || !dH || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
   ON_DEVICE(h);
-  hipStream_t st = (hipStream_t)stream;
-  const Dims& dm = h->dm;
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
-  hipEvent_t e0 = h->ev[6], e1 = h->ev[7];
-  const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
-  if (prof) HIPCHK(hipEventRecord(e0, st));
-  for (int off = 0; off < nbt; off += dm.B) {
-    const int nb = std::min(dm.B, nbt - off);
-    int rc = run_chunk(h, nb, dA + (size_t)off * dm.p * nxx, dB ? dB + (size_t)off * dm.p * dm.nx * dm.mb : nullptr,
-                       dH + (size_t)off * dm.p * nn, st);
-    if (rc != TMPC_OK) return rc;
-    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToDevice, st);
-    if (rc != TMPC_OK) return rc;
-  }
-  if (prof) {
-    HIPCHK(hipEventRecord(e1, st));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); h->prof[6] += ms;
-  }
-  return TMPC_OK;
+  Call c{nbt, dA, dB, dH, nullptr, nullptr, 0.0, Hc, dHc, P, nullptr, alpha, beta, kappa, status, iters, info, false, 0};
+  return dispatch(h, c, (hipStream_t)stream, true);
 }
 
 int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH, const double* dJ,
@@ -650,26 +757,14 @@ int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, c
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info, void* stream) {
   if (h && nbt == 0) return TMPC_OK;           // empty shard
   if (!h || nbt < 1 || !dA || !dH || !dJ || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
-  ON_DEVICE(h);
   const Dims& dm = h->dm;
   if (d_ncnt ? (dm.nz <= dm.nr || !(rho > 0.0)) : dm.ng < 1) {
     snprintf(g_err, sizeof(g_err), "handle has no room for this call (Step 2 needs tmpc_create_con with nc > 0 and rho > 0, Step 1 with G needs ng > 0)");
     return TMPC_E_ARG;
   }
-  hipStream_t st = (hipStream_t)stream;
-  const int nr = d_ncnt ? dm.nr : dm.ng;           // row stride of J and FgF in this call
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx;
-  for (int off = 0; off < nbt; off += dm.B) {
-    const int nb = std::min(dm.B, nbt - off);
-    const size_t o = (size_t)off * dm.p;
-    int rc = run_chunk(h, nb, dA + o * nxx, dB ? dB + o * dm.nx * dm.mb : nullptr, dH + o * nn, st, dJ + o * nr * dm.n,
-                       d_ncnt ? d_ncnt + o : nullptr, rho);
-    if (rc != TMPC_OK) return rc;
-    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToDevice, st);
-    if (rc != TMPC_OK) return rc;
-    if (FgF) HIPCHK(hipMemcpyAsync(FgF + o * nr, h->ws.Fg, (size_t)nb * dm.p * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
-  }
-  return TMPC_OK;
+  ON_DEVICE(h);
+  Call c{nbt, dA, dB, dH, dJ, d_ncnt, rho, Hc, dHc, P, FgF, alpha, beta, kappa, status, iters, info, false, d_ncnt ? dm.nr : dm.ng};
+  return dispatch(h, c, (hipStream_t)stream, true);
 }
 
 int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H,
@@ -678,51 +773,25 @@ int tmpc_convexify_batch_host(tmpc_handle* h, int nbt, const double* A, const do
   if (h && nbt == 0) return TMPC_OK;
   if (!h || nbt < 1 || !A || !H || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
   ON_DEVICE(h);
-  hipStream_t st = 0;
-  const Dims& dm = h->dm;
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
-  for (int off = 0; off < nbt; off += dm.B) {
-    const int nb = std::min(dm.B, nbt - off);
-    const size_t BP = (size_t)nb * dm.p;
-    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
-    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
-    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st);
-    if (rc != TMPC_OK) return rc;
-    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
-    if (rc != TMPC_OK) return rc;
-  }
-  return TMPC_OK;
+  Call c{nbt, A, B, H, nullptr, nullptr, 0.0, Hc, dHc, P, nullptr, alpha, beta, kappa, status, iters, info, true, 0};
+  return dispatch(h, c, nullptr, false);
 }
 
 int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, const double* G,
                                  double* Hc, double* dHc, double* P, double* Fg, double* alpha, double* beta, double* kappa,
                                  int32_t* status, int32_t* iters, double* info) {
+  if (h && nbt == 0) return TMPC_OK;
   if (!h || nbt < 1 || !A || !H || !G || !Fg || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
   if (h->dm.ng < 1) { snprintf(g_err, sizeof(g_err), "handle was created without equality-constraint rows (use tmpc_create_eq)"); return TMPC_E_ARG; }
   ON_DEVICE(h);
-  hipStream_t st = 0;
-  const Dims& dm = h->dm;
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.ng * dm.n;
-  for (int off = 0; off < nbt; off += dm.B) {
-    const int nb = std::min(dm.B, nbt - off);
-    const size_t BP = (size_t)nb * dm.p;
-    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
-    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dG, G + (size_t)off * dm.p * gn, BP * gn * sizeof(double), hipMemcpyHostToDevice, st));
-    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st, h->dG);
-    if (rc != TMPC_OK) return rc;
-    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
-    if (rc != TMPC_OK) return rc;
-    HIPCHK(hipMemcpy(Fg + (size_t)off * dm.p * dm.ng, h->ws.Fg, BP * dm.ng * sizeof(double), hipMemcpyDeviceToHost));
-  }
-  return TMPC_OK;
+  Call c{nbt, A, B, H, G, nullptr, 0.0, Hc, dHc, P, Fg, alpha, beta, kappa, status, iters, info, true, h->dm.ng};
+  return dispatch(h, c, nullptr, false);
 }
 
 int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, const double* J,
                                     const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info) {
+  if (h && nbt == 0) return TMPC_OK;
   if (!h || nbt < 1 || !A || !H || !J || !ncnt || !FgF || !(rho > 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
   const Dims& dm = h->dm;
   if (dm.nz <= dm.nr) { snprintf(g_err, sizeof(g_err), "handle was created without active-constraint rows (use tmpc_create_con with nc > 0)"); return TMPC_E_ARG; }
@@ -730,32 +799,18 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, co
   for (size_t i = 0; i < (size_t)nbt * dm.p; ++i)
     if (ncnt[i] < 0 || ncnt[i] > ncmax) { snprintf(g_err, sizeof(g_err), "ncnt[%zu]=%d outside 0..%d", i, ncnt[i], ncmax); return TMPC_E_ARG; }
   ON_DEVICE(h);
-  hipStream_t st = 0;
-  const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb, gn = (size_t)dm.nr * dm.n;
-  for (int off = 0; off < nbt; off += dm.B) {
-    const int nb = std::min(dm.B, nbt - off);
-    const size_t BP = (size_t)nb * dm.p;
-    HIPCHK(hipMemcpyAsync(h->dA, A + (size_t)off * dm.p * nxx, BP * nxx * sizeof(double), hipMemcpyHostToDevice, st));
-    if (dm.mb > 0) HIPCHK(hipMemcpyAsync(h->dB, B + (size_t)off * dm.p * nxm, BP * nxm * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dG, J + (size_t)off * dm.p * gn, BP * gn * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dncnt, ncnt + (size_t)off * dm.p, BP * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    int rc = run_chunk(h, nb, h->dA, h->dB, h->dH, st, h->dG, h->dncnt, rho);
-    if (rc != TMPC_OK) return rc;
-    rc = copy_out(h, nb, off, Hc, dHc, P, alpha, beta, kappa, status, iters, info, hipMemcpyDeviceToHost, st);
-    if (rc != TMPC_OK) return rc;
-    HIPCHK(hipMemcpy(FgF + (size_t)off * dm.p * dm.nr, h->ws.Fg, BP * dm.nr * sizeof(double), hipMemcpyDeviceToHost));
-  }
-  return TMPC_OK;
+  Call c{nbt, A, B, H, J, ncnt, rho, Hc, dHc, P, FgF, alpha, beta, kappa, status, iters, info, true, dm.nr};
+  return dispatch(h, c, nullptr, false);
 }
 
-int tmpc_supplement_terms_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* P, int nr,
+int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, const double* B, const double* P, int nr,
                                      const double* J, const double* wts, const double* T, double* dHc) {
-  if (!h || nbt < 1 || !A || !P || !dHc || (h->dm.mb > 0 && !B) || nr < 0 || ((J != nullptr) != (wts != nullptr)) || (J && nr < 1)) return TMPC_E_ARG;
+  if (!hh || nbt < 1 || !A || !P || !dHc || (hh->dm.mb > 0 && !B) || nr < 0 || ((J != nullptr) != (wts != nullptr)) || (J && nr < 1)) return TMPC_E_ARG;
   hipStream_t st = 0;
-  const Dims& dm = h->dm;
+  const Dims& dm = hh->dm;
+  Lane* h = &hh->lane[0];                               // lane 0's buffers (this entry is not on the hot path)
   const size_t nn = (size_t)dm.n * dm.n, nxx = (size_t)dm.nx * dm.nx, nxm = (size_t)dm.nx * dm.mb;
-  ON_DEVICE(h);
+  ON_DEVICE(hh);
   DevBuf bJ, bw;
   const size_t capst = (size_t)dm.B * dm.p;             // stages per chunk
   if (J) { HIPCHK(bJ.alloc(capst * nr * dm.n * 8)); HIPCHK(bw.alloc(capst * nr * 8)); }
@@ -784,11 +839,12 @@ int tmpc_supplement_batch_host(tmpc_handle* h, int nbt, const double* A, const d
   return tmpc_supplement_terms_batch_host(h, nbt, A, B, P, 0, nullptr, nullptr, nullptr, dHc);
 }
 
-int tmpc_eig_scan_host(tmpc_handle* h, int nbt, const double* H, double* out) {
-  if (!h || nbt < 1 || !H || !out) return TMPC_E_ARG;
-  ON_DEVICE(h);
+int tmpc_eig_scan_host(tmpc_handle* hh, int nbt, const double* H, double* out) {
+  if (!hh || nbt < 1 || !H || !out) return TMPC_E_ARG;
+  ON_DEVICE(hh);
+  Lane* h = &hh->lane[0];
+  const Dims& dm = hh->dm;
   hipStream_t st = 0;
-  const Dims& dm = h->dm;
   const size_t nn = (size_t)dm.n * dm.n;
   for (int off = 0; off < nbt; off += dm.B) {
     const int nb = std::min(dm.B, nbt - off);
