@@ -529,8 +529,10 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   if (!h) return TMPC_E_NOMEM;
   h->slab = nullptr; h->d_sched = nullptr; h->ev_in = nullptr;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return TMPC_E_HIP; }
-  // lanes: two concurrent half-waves once a wave holds enough problems (TMPC_LANES overrides; 1 = the plain sequential loop)
-  int nl = (chunk >= 16) ? 2 : 1;
+  // lanes: one by default -- measured on MI355X (profiles/r2b_lanes.txt), two or four concurrent half-waves gain nothing at the
+  // bench shape (6445 / 6526 / 6399 stage-conv/s with 1 / 2 / 4 lanes): every kernel of the loop already fills the chip, so the
+  // streams time-share instead of overlapping.  TMPC_LANES=n turns them on (latency-bound small batches may still profit).
+  int nl = 1;
   { const char* e = getenv("TMPC_LANES"); if (e && atoi(e) >= 1) nl = std::min(atoi(e), MAXL); }
   nl = std::max(1, std::min(nl, chunk));
   h->nlanes = nl;

@@ -1,6 +1,6 @@
 // Building blocks of the block factorisation of the HKM Schur matrix (tmpc_cr.h holds the kernels): the fp64 MFMA tile GEMM
-// C (+)= A B' (v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile = 2 x 2 MFMA
-// tiles, K staged through LDS in double-buffered 32-column slabs), the 64 x 64 tile Cholesky with its inverse, the
+// C (+)= A B' (v_mfma_f64_4x4x4_4b, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile = 2 x 8 fragments of 16 x 4,
+// K staged through LDS in double-buffered 32-column slabs), the 64 x 64 tile Cholesky with its inverse, the
 // left-looking blocked Cholesky of a d x d block, and the skinny MFMA GEMM that carries the triangular solves.
 #pragma once
 #include "tmpc_common.h"
@@ -48,19 +48,23 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv >> 1, wc = wv & 1;
   // slab loader: row (0..63); each thread moves two 32-byte pieces, k = lk..lk+3 and 16+lk..16+lk+3, into two
-  // 16-column sub-slabs of leading dimension 17 (the low-conflict layout of the single-buffered baseline)
+  // 16-column sub-slabs of leading dimension 17 (conflict-free for the fragment reads below)
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
   const int nks = (K + GK - 1) / GK;
-  const int fr = lane & 15, fk = lane >> 4;
-  // The MFMA is issued as C' = B_pi * A' with the columns of the B sub-tile permuted (pi(c) = 4*(c&3) + (c>>2)):
-  // lane (fr, fk) then owns C[row fr][cols 4*fk .. 4*fk+3] of every 16 x 16 sub-tile -- 32 contiguous bytes, i.e.
-  // two 16-byte accesses instead of four 8-byte ones for the C prefetch and the epilogue.
-  const int fp = 4 * (fr & 3) + (fr >> 2);
-  double4_t acc[2][2], cpre[2][2];
+  // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 products per instruction.  Operand lanes: A lane 16k + 4q + i holds A_q[i][k],
+  // B lane 16k + 4q + j holds B_q[k][j]; result lane 16i + 4q + j holds D_q[i][j] (profiles/r1_mfma_f64_4x4x4_lane_layout.txt).
+  // The four blocks q are four row groups of one 16-row A fragment and share one 4-column B fragment (replicated: the four
+  // lanes read the same LDS word), so one instruction is a 16 x 4 x 4 product.  A wave's 32 x 32 quadrant = 2 A fragments x
+  // 8 B fragments = 16 instructions per 4 columns of K from 10 LDS reads; LDS-fed this form issues 70-76 TFLOP/s where
+  // v_mfma_f64_16x16x4 stops at 45-48 (profiles/r2_mfma_f64_4x4x4_lds_fed_core.txt).
+  // Fragment cb covers the columns 16*(cb>>2) + 4*j + (cb&3): lane j then owns 4 adjacent columns of 4 fragments, i.e. 32
+  // contiguous bytes of C per (fragment row, half), two 16-byte accesses like the operand loads.
+  const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;     // as operand lane: k, block, row/col in block; as result lane: row fk, block fq, col fj
+  double acc[2][8], cpre[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0}; cpre[i][j] = acc[i][j]; }
+    for (int j = 0; j < 8; ++j) { acc[i][j] = 0.0; cpre[i][j] = 0.0; }
   double ra[8], rb[8];
   int m0 = 0, n0 = 0, ks = 0;            // current slab
   // ---- prologue: first slab -> LDS buffer 0
@@ -110,36 +114,33 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       for (int i = 0; i < 2; ++i) {
         const int rbase = m0 + wr * 32 + i * 16;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cbase = n0 + wc * 32 + j * 16;
+        for (int m = 0; m < 2; ++m) {
+          const int cbase = n0 + wc * 32 + m * 16;
           if (rbase < M && cbase < N) {
-            gcptr2 cp2 = (gcptr2)(C + (size_t)(rbase + fr) * ldc + cbase + 4 * fk);
+            gcptr2 cp2 = (gcptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + cbase + 4 * fj);
             const double2_t u0 = cp2[0], u1 = cp2[1];
-            cpre[i][j][0] = u0[0]; cpre[i][j][1] = u0[1]; cpre[i][j][2] = u1[0]; cpre[i][j][3] = u1[1];
+            cpre[i][4 * m + 0] = u0[0]; cpre[i][4 * m + 1] = u0[1]; cpre[i][4 * m + 2] = u1[0]; cpre[i][4 * m + 3] = u1[1];
           }
         }
       }
     }
     TMPC_T(1)
-    // ---- compute current slab.  (Skipping the 16 x 16 sub-tiles that lie outside M x N, above the diagonal of a
-    // symmetric update or under the zero half of a triangular B was measured: 20 % fewer MFMAs, no time gained --
-    // the per-MFMA branches cost what the skipped issue slots save -- so the MFMAs are unconditional.)
+    // ---- compute current slab (unconditional MFMAs: skipping fragments outside M x N or above the diagonal costs what it saves)
     {
       const double* As = lds + buf * (2 * SLABD);
       const double* Bs = As + SLABD;
       const int krem = K - ks * GK;
       if (USE_MFMA) {
-#define TMPC_MFMA_STEP(kk)                                                                  \
-  {                                                                                         \
-    const int so = ((kk) >> 2) * SUBD + ((kk) & 3) * 4 + fk;                                \
-    const double a0 = As[so + (wr * 32 + fr) * SLD];                                        \
-    const double a1 = As[so + (wr * 32 + 16 + fr) * SLD];                                   \
-    const double b0 = Bs[so + (wc * 32 + fp) * SLD];                                        \
-    const double b1 = Bs[so + (wc * 32 + 16 + fp) * SLD];                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);           \
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);           \
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);           \
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);           \
+#define TMPC_MFMA_STEP(kk)                                                                              \
+  {                                                                                                     \
+    const int so = ((kk) >> 2) * SUBD + ((kk) & 3) * 4 + fk;                                            \
+    const double a0 = As[so + (wr * 32 + 4 * fq + fj) * SLD];                                           \
+    const double a1 = As[so + (wr * 32 + 16 + 4 * fq + fj) * SLD];                                      \
+    _Pragma("unroll") for (int cb = 0; cb < 8; ++cb) {                                                  \
+      const double bv = Bs[so + (wc * 32 + 16 * (cb >> 2) + 4 * fj + (cb & 3)) * SLD];                  \
+      acc[0][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bv, acc[0][cb], 0, 0, 0);                     \
+      acc[1][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bv, acc[1][cb], 0, 0, 0);                     \
+    }                                                                                                   \
   }
         if (krem >= GK) {
 #pragma unroll
@@ -155,12 +156,10 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = wr * 32 + i * 16 + fr, col = wc * 32 + j * 16 + 4 * fk + r;
-                acc[i][j][r] = fma(As[(kk >> 4) * SUBD + row * SLD + (kk & 15)], Bs[(kk >> 4) * SUBD + col * SLD + (kk & 15)], acc[i][j][r]);
-              }
+            for (int cb = 0; cb < 8; ++cb) {
+              const int row = wr * 32 + i * 16 + 4 * fq + fk, col = wc * 32 + 16 * (cb >> 2) + 4 * fj + (cb & 3);
+              acc[i][cb] = fma(As[(kk >> 4) * SUBD + row * SLD + (kk & 15)], Bs[(kk >> 4) * SUBD + col * SLD + (kk & 15)], acc[i][cb]);
+            }
         }
       }
     }
@@ -175,22 +174,27 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
         for (int q = 0; q < 4; ++q) { An[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
     }
     TMPC_T(3)
-    // ---- tile finished: store its C fragment (reg r -> row lane&15, col 4*(lane>>4) + r)
+    // ---- tile finished: store its C fragment (row 4*fq + fk of each 16-row fragment, columns 16m + 4*fj .. + 3)
     if (ks == nks - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rbase = m0 + wr * 32 + i * 16;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cbase = n0 + wc * 32 + j * 16;
+        for (int m = 0; m < 2; ++m) {
+          const int cbase = n0 + wc * 32 + m * 16;
           if (rbase < M && cbase < N) {
-            double4_t v = acc[i][j];
-            if (mode == GM_SUB) v = cpre[i][j] - v; else if (mode == GM_NEG) v = -v;
+            double v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const double t = acc[i][4 * m + e];
+              v[e] = (mode == GM_SUB) ? cpre[i][4 * m + e] - t : ((mode == GM_NEG) ? -t : t);
+            }
             typedef double2_t __attribute__((address_space(1)))* gptr2;
-            gptr2 cp2 = (gptr2)(C + (size_t)(rbase + fr) * ldc + cbase + 4 * fk);
+            gptr2 cp2 = (gptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + cbase + 4 * fj);
             cp2[0] = (double2_t){v[0], v[1]}; cp2[1] = (double2_t){v[2], v[3]};
           }
-          acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][4 * m + e] = 0.0;
         }
       }
     }
