@@ -15,7 +15,8 @@ extern "C" {
 #endif
 
 /* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMM of the factorisation (one workgroup); mode 0: C -= AB',
- * 1: C = AB', 2: C = -AB'; lower != 0: only the 64 x 64 tiles on and below the diagonal.  All dims multiples of 16. */
+ * 1: C = AB', 2: C = -AB' (+16: the 128 x 128 / 512-thread shape of k_cr_update instead of 64 x 64 / 256); lower != 0: only the
+ * tiles on and below the diagonal, and inside diagonal tiles only the waves that reach it.  All dims multiples of 16. */
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
 
 /* Factor + solve one SPD block-cyclic-tridiagonal system with the cyclic-reduction kernels (tmpc_cr.h):

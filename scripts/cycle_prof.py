@@ -1,21 +1,29 @@
-import os, sys, ctypes as C
+"""In-kernel cycle split of the tile GEMM (wg_gemm_nt) inside the three kernel classes of the block factorisation: thread 0 of block 0
+of every launch accumulates __builtin_readcyclecounter() deltas per section; needs the -DTMPC_CYCLE_PROF build (libtunempc_hip_prof.so,
+built here when missing)."""
+import os, sys, subprocess, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tunempc_amd._lib as L
-L.library_path = lambda: os.path.join(ROOT, 'tunempc_amd', 'lib', 'libtunempc_hip_prof.so')
+PROF = os.path.join(ROOT, 'tunempc_amd', 'lib', 'libtunempc_hip_prof.so')
+if not os.path.exists(PROF):
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value', '-DTMPC_CYCLE_PROF',
+                           os.path.join(ROOT, 'tunempc_amd', 'csrc', 'tmpc_api.hip'), '-o', PROF])
+L.library_path = lambda: PROF
 from tunempc_amd._lib import HipConvexifier
 h = HipConvexifier(2, 3, 1)
 lib = h.lib
 lib.tmpc_debug_cycle_prof.argtypes = [C.POINTER(C.c_double)]
-out = np.zeros(16)
-for nb in (64, 512):
-    os.environ['TMPC_ABL'] = '6'
+out = np.zeros(64)
+names = ['issue next-slab loads', 'C prefetch issue', 'ds_read + MFMA', 'wait loads + LDS store', 'epilogue stores', 'barrier']
+for (nb, p) in ((512, 64), (64, 64)):
     lib.tmpc_debug_cycle_prof(out.ctypes.data_as(C.POINTER(C.c_double)))   # reset
-    ms = h.debug_factor_bench(nb, 8, 300, reps=1)
+    ms = h.debug_factor_bench(nb, p, 300, reps=1)
     lib.tmpc_debug_cycle_prof(out.ctypes.data_as(C.POINTER(C.c_double)))
-    tot = out[:6].sum()
-    names = ['issue next-slab loads', 'C prefetch issue', 'ds_read + MFMA', 'wait loads + LDS store', 'epilogue stores', 'barrier']
-    print(f"nb {nb}: kernel {ms} ms; block 0 thread 0 cycles in wg_gemm_nt (both variants' launches, 2 reps+warm): total {tot:.3e}")
-    for n_, v in zip(names, out[:6]):
-        print(f"    {n_:28s} {v:.3e}  {100*v/tot:5.1f} %")
+    print(f"nb {nb} p {p} d 300: factor {ms[0]:.2f} ms, solve {ms[1]:.2f} ms (profiled build)")
+    for cls, cn in ((1, 'k_cr_potrf'), (2, 'k_cr_trsm'), (3, 'k_cr_update')):
+        v = out[cls * 8: cls * 8 + 6]; tot = v.sum()
+        print(f"  {cn}: wave 0 of block 0, cycles inside wg_gemm_nt over all launches {tot:.3e}")
+        for n_, x in zip(names, v):
+            print(f"      {n_:28s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")

@@ -1,0 +1,13 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "block_cyclic or golden or parity_vs_oracle or full_size_c4" 2>&1 | tail -5 > gpurun_out/r2f_tests.log
+for MT in 64 128; do
+  TMPC_CR_MT=$MT timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r2f_bench_mt$MT.json 2> gpurun_out/r2f_bench_mt$MT.err
+done
+cat gpurun_out/r2f_tests.log
+for MT in 64 128; do python - <<PY
+import json
+j=json.load(open('gpurun_out/r2f_bench_mt$MT.json'))
+print('mt $MT', round(j['value'],1), 'ms/step', round(j['ms_per_step'],1), j['config']['ipm_iterations_max'], j['config']['status_optimal'], {k:round(v,1) for k,v in j['phase_ms'].items()}, {k:(round(v,2) if isinstance(v,float) else v) for k,v in j['roofline']['factorisation_phase'].items() if k!='kernels'}, 'upd TF', round(j['roofline']['achieved'],2))
+PY
+done

@@ -41,18 +41,36 @@ def test_library_loaded_in_tree():
 
 
 # ----------------------------------------------------------------------------- building blocks
-@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (128, 64, 48), (304, 48, 256), (304, 304, 304), (16, 16, 16), (48, 112, 80)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (128, 64, 48), (304, 48, 256), (304, 304, 304), (16, 16, 16), (48, 112, 80), (320, 128, 64)])
 @pytest.mark.parametrize('flags', [0, 1])
-def test_mfma_gemm_nt(hc, M, N, K, flags):
-    """v_mfma_f64_16x16x4 tile GEMM (and its scalar-FMA twin) vs numpy; asymmetric operands catch transposes."""
+@pytest.mark.parametrize('shape', [0, 16])
+def test_mfma_gemm_nt(hc, M, N, K, flags, shape):
+    """v_mfma_f64_4x4x4 tile GEMM (and its scalar-FMA twin) vs numpy, both workgroup shapes (64 x 64 / 256 threads, 128 x 128 / 512);
+    asymmetric operands catch transposes."""
     h = hc(2, 3, 1)
     h.set_options(flags=flags)
     rng = np.random.default_rng(M * 1000 + N + K)
     A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
     for mode, ref in [(0, C0 - A @ B.T), (1, A @ B.T), (2, -A @ B.T)]:
-        out = h.debug_gemm_nt(C0, A, B, mode)
+        out = h.debug_gemm_nt(C0, A, B, mode + shape)
         assert rel(out, ref) < 1e-14
     h.set_options(flags=0)
+
+
+@pytest.mark.parametrize('n,shape,T,W', [(304, 0, 64, 64), (304, 16, 128, 32), (320, 16, 128, 32), (496, 16, 128, 32)])
+def test_mfma_gemm_nt_lower(hc, n, shape, T, W):
+    """Lower-only symmetric update C -= A A': tiles strictly above the diagonal are skipped, inside diagonal tiles only the waves that
+    reach the diagonal compute and store (wave = (16 FA) x 32: 32 x 32 in the 64-shape, 64 x 32 in the 128-shape); the lower triangle is exact."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(n + shape)
+    A = rng.standard_normal((n, n)); C0 = rng.standard_normal((n, n))
+    out = h.debug_gemm_nt(C0, A, A, 0 + shape, lower=True)
+    ref = C0 - A @ A.T
+    low = np.tril(np.ones((n, n), bool))
+    assert np.abs(out - ref)[low].max() < 1e-12 * n
+    # everything above the block diagonal of T x T tiles is untouched
+    up = np.kron(np.triu(np.ones(((n + T - 1) // T,) * 2), 1), np.ones((T, T)))[:n, :n] > 0
+    assert np.abs(out - C0)[up].max() == 0.0
 
 
 def _spd_cyclic(rng, p, d):

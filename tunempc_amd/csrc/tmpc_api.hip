@@ -289,10 +289,16 @@ __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   wg_gemm_nt<USE_MFMA>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
 }
+template <bool USE_MFMA>      // the 128 x 128 shape of k_cr_update
+__global__ void __launch_bounds__(512, 1) k_debug_gemm512(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg_gemm_nt<USE_MFMA, 2, 4, 4>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
+}
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
 static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
+static size_t update_lds() { return (size_t)UPD_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 
 // kernels whose dynamic LDS exceeds the 64 KB default: the attribute is per device
@@ -314,6 +320,8 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm512<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm512<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -336,6 +344,9 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   int ke = 0;
   // profile mode: an event before and after every launch; pair i belongs to class i % 3 (potrf, trsm, update)
   auto mark = [&](int cls) {
+#ifdef TMPC_CYCLE_PROF
+    { static int cls_ids[4] = {0, 1, 2, 3}; hipMemcpyToSymbolAsync(HIP_SYMBOL(tmpc::g_prof_cls), &cls_ids[cls + 1], sizeof(int), 0, hipMemcpyHostToDevice, st); }
+#endif
     if (!kev) return;
     while ((int)kev->size() <= ke) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; kev->push_back(e); }
     (void)cls;
@@ -352,7 +363,8 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     if (lv.nupd == 0) { mark(1); mark(1); mark(2); mark(2); continue; }                  // last node: nothing left to update
     const long work64 = (long)count * lv.nelim * 2 * nt64;                 // 64-row strips of this level
     const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
-    const int mt = mt_opt > 0 ? mt_opt : (work64 >= 16384 ? 128 : 64);
+    const int mt = mt_opt > 0 ? mt_opt : 64;      // one 64 x 64 tile per workgroup: ~64 consecutive items per XCD span the tiles of 1-2 nodes, whose O blocks fit that L2
+                                                  // (the 128 x 128 / 512-thread shape of wg_gemm_nt was measured slower here: 102 vs 84.5 ms per phase)
     const int nstrip = (dm.dp + rs - 1) / rs, nm = (dm.dp + mt - 1) / mt;
     const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
@@ -885,7 +897,8 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
 
 // ---------------------------------------------------------------------------------- debug / unit-test entries (tunempc_hip_debug.h)
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
-  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16 || mode < 0 || mode > 2) return TMPC_E_ARG;
+  const int shape = mode >> 4; mode &= 15;             // mode + 16: the 128 x 128 / 512-thread shape
+  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16 || mode < 0 || mode > 2 || shape > 1) return TMPC_E_ARG;
   ON_DEVICE(h);
   DevBuf bC, bA, bB;
   HIPCHK(bC.alloc((size_t)M * N * 8)); HIPCHK(bA.alloc((size_t)M * K * 8)); HIPCHK(bB.alloc((size_t)N * K * 8));
@@ -893,7 +906,10 @@ int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double*
   HIPCHK(hipMemcpy(dC, C, (size_t)M * N * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dB, B, (size_t)N * K * 8, hipMemcpyHostToDevice));
-  if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  if (shape == 1) {
+    if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm512<false>, dim3(1), dim3(512), update_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+    else hipLaunchKernelGGL(k_debug_gemm512<true>, dim3(1), dim3(512), update_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  } else if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   else hipLaunchKernelGGL(k_debug_gemm<true>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(C, dC, (size_t)M * N * 8, hipMemcpyDeviceToHost));
@@ -1061,11 +1077,11 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
 }
 
 #ifdef TMPC_CYCLE_PROF
-int tmpc_debug_cycle_prof(double* out16) {
-  unsigned long long hh[16];
+int tmpc_debug_cycle_prof(double* out64) {
+  unsigned long long hh[64];
   HIPCHK(hipMemcpyFromSymbol(hh, HIP_SYMBOL(tmpc::g_prof), sizeof(hh)));
-  for (int i = 0; i < 16; ++i) out16[i] = (double)hh[i];
-  unsigned long long z[16] = {0};
+  for (int i = 0; i < 64; ++i) out64[i] = (double)hh[i];
+  unsigned long long z[64] = {0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tmpc::g_prof), z, sizeof(z)));
   return 0;
 }

@@ -7,8 +7,9 @@ namespace tmpc {
 
 // optional in-kernel cycle split (scripts/cycle_prof.py, scripts/gemm2_prof.py, scripts/stage_prof.py; -DTMPC_CYCLE_PROF builds only)
 #ifdef TMPC_CYCLE_PROF
-__device__ unsigned long long g_prof[16];
-#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[i] += t_ - tprev_; tprev_ = t_; } }
+__device__ unsigned long long g_prof[64];      // [class][8]: class set by the host before a launch (cr_factor: 1 potrf, 2 trsm, 3 update; 0: everything else)
+__device__ int g_prof_cls;
+#define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[(g_prof_cls & 7) * 8 + (i)] += t_ - tprev_; tprev_ = t_; } }
 #define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
 #else
 #define TMPC_T(i)

@@ -239,9 +239,25 @@ __global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, i
   int r = it % per;
   const int dp = dm.dp;
   const size_t bs = (size_t)dp * dp;
-  if (r < nupd * ntl) {
-    const int* ur = cr.upd + (size_t)(uoff + r / ntl) * CR_UW;
-    int t = r % ntl, tm = 0;
+  // Item order inside a problem: node by node along the cycle -- the fill tiles of eliminated node j, then the update tiles of
+  // the surviving node that follows it (update record j + 1): the O blocks of node j feed both, and the second operand of that
+  // update is the first O block of node j + 1, whose fill tiles come next.  Workgroups of one XCD run consecutive items, so each
+  // O block is fetched from HBM once and then served by that L2 (item order by kind re-fetched every block 3-4 times).
+  const int slot_items = ntf + ntl, nslot = nelim > nupd ? nelim : nupd;
+  int j = r / slot_items, rr = r - j * slot_items;
+  bool is_upd;
+  {
+    // slots j < min(nelim, nupd) hold ntf fill items and ntl update items; the longer list continues alone
+    const int nmin = nelim < nupd ? nelim : nupd;
+    const int full = nmin * slot_items;
+    if (r < full) { is_upd = rr >= ntf; if (is_upd) rr -= ntf; }
+    else if (nelim > nupd) { const int q = r - full; j = nmin + q / ntf; rr = q % ntf; is_upd = false; }
+    else { const int q = r - full; j = nmin + q / ntl; rr = q % ntl; is_upd = true; }
+    (void)nslot;
+  }
+  if (is_upd) {
+    const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
+    int t = rr, tm = 0;
     while (t > tm) { t -= tm + 1; ++tm; }               // t -> (tm, tn), tn <= tm
     const int tn = t;
     const int m0 = tm * mt, n0 = tn * mt;
@@ -254,10 +270,9 @@ __global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, i
       wg_gemm_nt<USE_MFMA>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
     }
   } else {
-    r -= nupd * ntl;
-    const int* er = cr.elim + (size_t)(eoff + r / ntf) * CR_EW;
+    const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
     if (er[CE_FILL] < 0) return;
-    const int t = r % ntf;
+    const int t = rr;
     const int tm = t / nm, tn = t - tm * nm;
     const int m0 = tm * mt, n0 = tn * mt;
     const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;

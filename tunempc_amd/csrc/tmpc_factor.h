@@ -11,7 +11,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GK = 32;             // K slab staged in LDS per step
 constexpr int GLD = GK + 2;        // LDS leading dim (doubles) of the A/B slabs: (2r + k) mod 32 is conflict-free for the MFMA fragment reads
-constexpr int FACT_LDS_DOUBLES = 4 * 2 * 64 * 17 + 64;   // two (A,B) slab pairs; the potrf tile + inverse + diag ref (2*64*65+72) alias the front
+constexpr int FACT_LDS_DOUBLES = 4 * 2 * 64 * 17 + 64;   // <2,2,2> shape: two (A,B) slab pairs; the potrf tile + inverse + diag ref (2*64*65+72) alias the front
+constexpr int UPD_LDS_DOUBLES = 4 * 2 * 128 * 17 + 64;   // <2,4,4> shape (128 x 128 tiles, k_cr_update)
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
 
@@ -41,156 +42,213 @@ typedef const double2_t __attribute__((address_space(1)))* gcptr2;
     dst[(off) + 0] = u0_[0]; dst[(off) + 1] = u0_[1]; dst[(off) + 2] = u1_[0]; dst[(off) + 3] = u1_[1]; \
   }
 typedef double __attribute__((address_space(1)))* gptr;
-template <bool USE_MFMA>
+// WM x WN waves per workgroup (blockDim.x = 64 WM WN), FA fragments of 16 rows per wave: a wave owns (16 FA) x 32 of C, the
+// workgroup tile is TM x TN = (16 FA WM) x (32 WN).  Two shapes are used: <2,2,2> = 64 x 64 with 256 threads (two workgroups per
+// CU; inside the block Cholesky and the triangular solves) and <2,4,4> = 128 x 128 with 512 threads (one workgroup per CU, the
+// same eight waves; half the global -> LDS traffic, LDS stores and barriers per flop) for the batched symmetric updates.
+// Waves whose part of the tile lies outside M x N -- or, on a diagonal tile of a lower-only update, entirely above the
+// diagonal -- skip their MFMAs and stores (they still help to load), so 304 = 128 + 128 + 48 costs like 128 + 128 + 64.
+template <int WM, int WN, int FA>
+struct GemmCfg {
+  static constexpr int TM = 16 * FA * WM, TN = 32 * WN, NTH = 64 * WM * WN, RP = NTH / 4;      // RP: slab rows covered by one pass of the loader
+  static constexpr int ARP = (TM + RP - 1) / RP, BRP = (TN + RP - 1) / RP;                       // loader passes over the A / B slab
+  static constexpr int ASUB = TM * 17, BSUB = TN * 17, BUFD = 2 * ASUB + 2 * BSUB;               // doubles: 16-column sub-slab of A / B, one (A,B) buffer
+  static constexpr int LDS_DOUBLES = 2 * BUFD;
+};
+
+template <bool USE_MFMA, int WM = 2, int WN = 2, int FA = 2>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
                                            double* lds) {
+  typedef GemmCfg<WM, WN, FA> G;
+  constexpr int TM = G::TM, TN = G::TN, RP = G::RP, ARP = G::ARP, BRP = G::BRP, ASUB = G::ASUB, BSUB = G::BSUB, BUFD = G::BUFD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr = wv >> 1, wc = wv & 1;
-  // slab loader: row (0..63); each thread moves two 32-byte pieces, k = lk..lk+3 and 16+lk..16+lk+3, into two
-  // 16-column sub-slabs of leading dimension 17 (conflict-free for the fragment reads below)
+  const int wr = wv / WN, wc = wv % WN;
+  // slab loader: row lrow (+ RP per pass); each thread moves two 32-byte pieces per pass and operand, k = lk..lk+3 and
+  // 16+lk..16+lk+3, into two 16-column sub-slabs of leading dimension 17 (conflict-free for the fragment reads below)
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
   const int nks = (K + GK - 1) / GK;
   // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 products per instruction.  Operand lanes: A lane 16k + 4q + i holds A_q[i][k],
   // B lane 16k + 4q + j holds B_q[k][j]; result lane 16i + 4q + j holds D_q[i][j] (profiles/r1_mfma_f64_4x4x4_lane_layout.txt).
   // The four blocks q are four row groups of one 16-row A fragment and share one 4-column B fragment (replicated: the four
-  // lanes read the same LDS word), so one instruction is a 16 x 4 x 4 product.  A wave's 32 x 32 quadrant = 2 A fragments x
-  // 8 B fragments = 16 instructions per 4 columns of K from 10 LDS reads; LDS-fed this form issues 70-76 TFLOP/s where
+  // lanes read the same LDS word), so one instruction is a 16 x 4 x 4 product.  A wave's (16 FA) x 32 part = FA A fragments x
+  // 8 B fragments = 8 FA instructions per 4 columns of K from FA + 8 LDS reads; LDS-fed this form issues 70-76 TFLOP/s where
   // v_mfma_f64_16x16x4 stops at 45-48 (profiles/r2_mfma_f64_4x4x4_lds_fed_core.txt).
   // Fragment cb covers the columns 16*(cb>>2) + 4*j + (cb&3): lane j then owns 4 adjacent columns of 4 fragments, i.e. 32
   // contiguous bytes of C per (fragment row, half), two 16-byte accesses like the operand loads.
   const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;     // as operand lane: k, block, row/col in block; as result lane: row fk, block fq, col fj
-  double acc[2][8], cpre[2][8];
+  const int wr0 = wr * 16 * FA, wc0 = wc * 32;                        // this wave's corner inside the tile
+  // the C fragment of a read-modify-write tile is prefetched at the tile's first slab in the small shape; the large shape (64
+  // accumulator registers per lane already) reads it in the epilogue instead -- once per 10 slabs of 256 MFMAs
+  constexpr bool CPRE = (FA <= 2);
+  double acc[FA][8], cpre[CPRE ? FA : 1][8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FA; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { acc[i][j] = 0.0; cpre[i][j] = 0.0; }
-  double ra[8], rb[8];
+    for (int j = 0; j < 8; ++j) { acc[i][j] = 0.0; if (CPRE) cpre[i][j] = 0.0; }
+  double ra[ARP * 8], rb[BRP * 8];
   int m0 = 0, n0 = 0, ks = 0;            // current slab
-  // ---- prologue: first slab -> LDS buffer 0
-  {
-    gcptr ap = (gcptr)(A + (size_t)lrow * lda + lk);
-    gcptr bp = (gcptr)(B + (size_t)lrow * ldb + lk);
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const bool kok = (h2 * 16 + lk) < K;
-      const bool aok = (lrow < M) && kok, bok = (lrow < N) && kok;
-      TMPC_LD4(ra, h2 * 4, ap + h2 * 16, aok)
-      TMPC_LD4(rb, h2 * 4, bp + h2 * 16, bok)
-    }
-    __syncthreads();                       // LDS free (previous user)
-    double* As = lds; double* Bs = lds + SLABD;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { As[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bs[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
-    __syncthreads();
+  // Slab loads go through raw buffer resources: the address is an SGPR base + a per-thread 32-bit offset that never changes
+  // + a scalar slab offset, and rows beyond M (N) fall outside the resource and read as zero -- no 64-bit address arithmetic, no
+  // predicates, no zero-fill moves.  (On this part the fp64 MFMA and the vector ALU share the issue slots of a SIMD: every
+  // VALU instruction of the loader is taken from the other wave's MFMA stream, profiles/r2_mfma_valu_mix_issue_rate.txt.)
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((unsigned)(M - 1) * (unsigned)lda + (unsigned)K) * 8u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((unsigned)(N - 1) * (unsigned)ldb + (unsigned)K) * 8u), 0x00020000);
+  const unsigned avo = (unsigned)(lrow * lda + lk) * 8u, bvo = (unsigned)(lrow * ldb + lk) * 8u;     // per-thread byte offsets (pass 0)
+  typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+#define TMPC_BLD4(dst, off, rsrc, vo, so)                                                                   \
+  {                                                                                                         \
+    const double2_t u0_ = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (vo), (so), 0));          \
+    const double2_t u1_ = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (vo) + 16u, (so), 0));    \
+    dst[(off) + 0] = u0_[0]; dst[(off) + 1] = u0_[1]; dst[(off) + 2] = u1_[0]; dst[(off) + 3] = u1_[1];    \
   }
+#define TMPC_SLAB_LOAD(M0, N0, KN)                                                                          \
+  {                                                                                                         \
+    const unsigned aso = (unsigned)((M0) * lda + (KN) - lk) * 8u, bso = (unsigned)((N0) * ldb + (KN) - lk) * 8u;   /* wave-uniform */ \
+    _Pragma("unroll") for (int rp = 0; rp < ARP; ++rp) {                                                    \
+      if (RP * ARP == TM || lrow + rp * RP < TM) {                                                          \
+        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+          TMPC_BLD4(ra, rp * 8 + h2 * 4, arsrc, avo + (unsigned)(rp * RP * lda + h2 * 16) * 8u, aso)        \
+      }                                                                                                     \
+    }                                                                                                       \
+    _Pragma("unroll") for (int rp = 0; rp < BRP; ++rp) {                                                    \
+      if (RP * BRP == TN || lrow + rp * RP < TN) {                                                          \
+        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+          TMPC_BLD4(rb, rp * 8 + h2 * 4, brsrc, bvo + (unsigned)(rp * RP * ldb + h2 * 16) * 8u, bso)        \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+#define TMPC_SLAB_STORE(BUF)                                                                                \
+  {                                                                                                         \
+    double* An_ = lds + (BUF) * BUFD;                                                                       \
+    double* Bn_ = An_ + 2 * ASUB;                                                                           \
+    _Pragma("unroll") for (int rp = 0; rp < ARP; ++rp) {                                                    \
+      const int row = lrow + rp * RP;                                                                       \
+      if (RP * ARP == TM || row < TM) {                                                                     \
+        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+          _Pragma("unroll") for (int q = 0; q < 4; ++q) An_[h2 * ASUB + row * SLD + lk + q] = ra[rp * 8 + h2 * 4 + q]; \
+      }                                                                                                     \
+    }                                                                                                       \
+    _Pragma("unroll") for (int rp = 0; rp < BRP; ++rp) {                                                    \
+      const int row = lrow + rp * RP;                                                                       \
+      if (RP * BRP == TN || row < TN) {                                                                     \
+        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+          _Pragma("unroll") for (int q = 0; q < 4; ++q) Bn_[h2 * BSUB + row * SLD + lk + q] = rb[rp * 8 + h2 * 4 + q]; \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+  // ---- prologue: first slab -> LDS buffer 0
+  TMPC_SLAB_LOAD(0, 0, lk)
+  __syncthreads();                         // LDS free (previous user)
+  TMPC_SLAB_STORE(0)
+  __syncthreads();
   int buf = 0;
   TMPC_T0()
   while (m0 < M) {
     // ---- next slab of the stream
     int nm0 = m0, nn0 = n0, nks_ = ks + 1;
     if (nks_ == nks) {
-      nks_ = 0; nn0 = n0 + 64;
-      if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + 64; }
+      nks_ = 0; nn0 = n0 + TN;
+      if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + TM; }
     }
     const bool more = nm0 < M;
-    if (more) {
-      const int kn = nks_ * GK + lk;
-      gcptr ap = (gcptr)(A + (size_t)(nm0 + lrow) * lda + kn);
-      gcptr bp = (gcptr)(B + (size_t)(nn0 + lrow) * ldb + kn);
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const bool kok = (kn + h2 * 16) < K;
-        const bool aok = (nm0 + lrow < M) && kok, bok = (nn0 + lrow < N) && kok;
-        TMPC_LD4(ra, h2 * 4, ap + h2 * 16, aok)
-        TMPC_LD4(rb, h2 * 4, bp + h2 * 16, bok)
-      }
-    }
+    if (more) TMPC_SLAB_LOAD(nm0, nn0, nks_ * GK + lk)
     TMPC_T(0)
-    if (ks == 0 && mode == GM_SUB) {       // prefetch the C fragment of this tile
+    // does this wave own anything of the current tile?  (outside M x N, or above the diagonal of a lower-only diagonal tile)
+    const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA);
+    if (CPRE && ks == 0 && mode == GM_SUB && wave_on) {       // prefetch the C fragment of this tile
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + wr * 32 + i * 16;
+      for (int i = 0; i < FA; ++i) {
+        const int rbase = m0 + wr0 + i * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const int cbase = n0 + wc * 32 + m * 16;
+          const int cbase = n0 + wc0 + m * 16;
           if (rbase < M && cbase < N) {
             gcptr2 cp2 = (gcptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + cbase + 4 * fj);
             const double2_t u0 = cp2[0], u1 = cp2[1];
-            cpre[i][4 * m + 0] = u0[0]; cpre[i][4 * m + 1] = u0[1]; cpre[i][4 * m + 2] = u1[0]; cpre[i][4 * m + 3] = u1[1];
+            cpre[CPRE ? i : 0][4 * m + 0] = u0[0]; cpre[CPRE ? i : 0][4 * m + 1] = u0[1]; cpre[CPRE ? i : 0][4 * m + 2] = u1[0]; cpre[CPRE ? i : 0][4 * m + 3] = u1[1];
           }
         }
       }
     }
     TMPC_T(1)
-    // ---- compute current slab (unconditional MFMAs: skipping fragments outside M x N or above the diagonal costs what it saves)
-    {
-      const double* As = lds + buf * (2 * SLABD);
-      const double* Bs = As + SLABD;
+    // ---- compute current slab
+    if (wave_on) {
+      const double* As = lds + buf * BUFD;
+      const double* Bs = As + 2 * ASUB;
       const int krem = K - ks * GK;
       if (USE_MFMA) {
 #define TMPC_MFMA_STEP(kk)                                                                              \
   {                                                                                                     \
-    const int so = ((kk) >> 2) * SUBD + ((kk) & 3) * 4 + fk;                                            \
-    const double a0 = As[so + (wr * 32 + 4 * fq + fj) * SLD];                                           \
-    const double a1 = As[so + (wr * 32 + 16 + 4 * fq + fj) * SLD];                                      \
+    const int so = ((kk) & 3) * 4 + fk;                                                                 \
+    const double* Ak = As + ((kk) >> 2) * ASUB + so;                                                    \
+    const double* Bk = Bs + ((kk) >> 2) * BSUB + so;                                                    \
+    double av[FA];                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < FA; ++i) av[i] = Ak[(wr0 + 16 * i + 4 * fq + fj) * SLD];       \
     _Pragma("unroll") for (int cb = 0; cb < 8; ++cb) {                                                  \
-      const double bv = Bs[so + (wc * 32 + 16 * (cb >> 2) + 4 * fj + (cb & 3)) * SLD];                  \
-      acc[0][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bv, acc[0][cb], 0, 0, 0);                     \
-      acc[1][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bv, acc[1][cb], 0, 0, 0);                     \
+      const double bv = Bk[(wc0 + 16 * (cb >> 2) + 4 * fj + (cb & 3)) * SLD];                           \
+      _Pragma("unroll") for (int i = 0; i < FA; ++i)                                                    \
+        acc[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i], bv, acc[i][cb], 0, 0, 0);                \
     }                                                                                                   \
   }
+        // (the large shape is unrolled by two only: a full unroll makes the compiler fetch all eight steps' fragments up front and spill)
         if (krem >= GK) {
+          if (FA <= 2) {
 #pragma unroll
-          for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+          } else {
+#pragma unroll 2
+            for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+          }
         } else {
+          if (FA <= 2) {
 #pragma unroll
-          for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+          } else {
+#pragma unroll 2
+            for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+          }
         }
 #undef TMPC_MFMA_STEP
       } else {   // debug path: same fragment ownership, scalar FMAs
         const int kmax = (krem >= GK) ? GK : krem;
         for (int kk = 0; kk < kmax; ++kk) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < FA; ++i)
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
-              const int row = wr * 32 + i * 16 + 4 * fq + fk, col = wc * 32 + 16 * (cb >> 2) + 4 * fj + (cb & 3);
-              acc[i][cb] = fma(As[(kk >> 4) * SUBD + row * SLD + (kk & 15)], Bs[(kk >> 4) * SUBD + col * SLD + (kk & 15)], acc[i][cb]);
+              const int row = wr0 + i * 16 + 4 * fq + fk, col = wc0 + 16 * (cb >> 2) + 4 * fj + (cb & 3);
+              acc[i][cb] = fma(As[(kk >> 4) * ASUB + row * SLD + (kk & 15)], Bs[(kk >> 4) * BSUB + col * SLD + (kk & 15)], acc[i][cb]);
             }
         }
       }
     }
     TMPC_T(2)
     // ---- stage the next slab into the other buffer
-    if (more) {
-      double* An = lds + (buf ^ 1) * (2 * SLABD);
-      double* Bn = An + SLABD;
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { An[h2 * SUBD + lrow * SLD + lk + q] = ra[h2 * 4 + q]; Bn[h2 * SUBD + lrow * SLD + lk + q] = rb[h2 * 4 + q]; }
-    }
+    if (more) TMPC_SLAB_STORE(buf ^ 1)
     TMPC_T(3)
     // ---- tile finished: store its C fragment (row 4*fq + fk of each 16-row fragment, columns 16m + 4*fj .. + 3)
-    if (ks == nks - 1) {
+    if (ks == nks - 1 && wave_on) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbase = m0 + wr * 32 + i * 16;
+      for (int i = 0; i < FA; ++i) {
+        const int rbase = m0 + wr0 + i * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const int cbase = n0 + wc * 32 + m * 16;
+          const int cbase = n0 + wc0 + m * 16;
           if (rbase < M && cbase < N) {
+            typedef double2_t __attribute__((address_space(1)))* gptr2;
+            gptr2 cp2 = (gptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + cbase + 4 * fj);
+            double c0[4] = {0.0, 0.0, 0.0, 0.0};
+            if (mode == GM_SUB) {
+              if (CPRE) { c0[0] = cpre[CPRE ? i : 0][4 * m]; c0[1] = cpre[CPRE ? i : 0][4 * m + 1]; c0[2] = cpre[CPRE ? i : 0][4 * m + 2]; c0[3] = cpre[CPRE ? i : 0][4 * m + 3]; }
+              else { const double2_t u0 = ((gcptr2)cp2)[0], u1 = ((gcptr2)cp2)[1]; c0[0] = u0[0]; c0[1] = u0[1]; c0[2] = u1[0]; c0[3] = u1[1]; }
+            }
             double v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const double t = acc[i][4 * m + e];
-              v[e] = (mode == GM_SUB) ? cpre[i][4 * m + e] - t : ((mode == GM_NEG) ? -t : t);
+              v[e] = (mode == GM_SUB) ? c0[e] - t : ((mode == GM_NEG) ? -t : t);
             }
-            typedef double2_t __attribute__((address_space(1)))* gptr2;
-            gptr2 cp2 = (gptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + cbase + 4 * fj);
             cp2[0] = (double2_t){v[0], v[1]}; cp2[1] = (double2_t){v[2], v[3]};
           }
 #pragma unroll
@@ -204,6 +262,9 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     buf ^= 1;
     m0 = nm0; n0 = nn0; ks = nks_;
   }
+#undef TMPC_SLAB_LOAD
+#undef TMPC_SLAB_STORE
+#undef TMPC_BLD4
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
