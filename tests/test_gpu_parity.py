@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import scipy.linalg as sla
+import torch  # noqa: F401  (before the HIP library is loaded: torch ships its own HIP runtime and fails to find the GPU when it initialises second)
 
 pytestmark = pytest.mark.gpu
 

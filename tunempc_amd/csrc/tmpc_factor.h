@@ -11,7 +11,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GK = 32;             // K slab staged in LDS per step
 constexpr int GLD = GK + 2;        // LDS leading dim (doubles) of the A/B slabs: (2r + k) mod 32 is conflict-free for the MFMA fragment reads
-constexpr int FACT_LDS_DOUBLES = 4 * 2 * 64 * 17 + 64;   // <2,2,2> shape: two (A,B) slab pairs; the potrf tile + inverse + diag ref (2*64*65+72) alias the front
+constexpr int FACT_LDS_DOUBLES = 2 * 64 * 65 + 72 + 4 * 16 * 17 + 8;   // the tile Cholesky (tile + inverse + pivot refs + one 16 x 17 scratch per wave); the <2,2,2> GEMM slabs (4*2*64*17) alias the front
 constexpr int UPD_LDS_DOUBLES = 4 * 2 * 128 * 17 + 64;   // <2,4,4> shape (128 x 128 tiles, k_cr_update)
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
@@ -267,82 +267,135 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 #undef TMPC_BLD4
 }
 
-// Cholesky of the nb x nb diagonal tile at T (ld = ldt) + its inverse into Ti (nb x nb, ld = TB).
-// dref: assembled diagonal entries (pivot reference).  Returns number of shifted pivots (thread-uniform).
-// Both loops are organised so that all 256 threads work: four lanes share every dot product (k strided by 4,
-// two xor-shuffles to combine), i.e. column-Crout for L and row-wise forward substitution for L^-1.
-__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
-  const int tid = threadIdx.x;
-  double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
-  double* Si = S + 64 * 65;                // 64 x 65
-  double* dr = Si + 64 * 65;               // 64 pivot references, then [64] = current pivot, [65] = shift counter
-  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * 65 + j] = T[(size_t)i * ldt + j]; }
-  if (tid < nb) dr[tid] = dref[tid];
-  if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }          // shift counter, smallest pivot / reference diagonal of this tile
-  __syncthreads();
-  const int row = tid >> 2, seg = tid & 3;
-  // ---- L: column Crout.  s_i = A[i][j] - sum_{k<j} L[i][k] L[j][k]
-  for (int j = 0; j < nb; ++j) {
-    double acc = 0.0;
-    if (row >= j && row < nb) {
-      const double* li = S + row * 65;
-      const double* lj = S + j * 65;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int k = seg;
-      for (; k + 12 < j; k += 16) {          // four independent chains: the LDS loads of a group issue back to back
-        a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 4], lj[k + 4], a1);
-        a2 = fma(li[k + 8], lj[k + 8], a2); a3 = fma(li[k + 12], lj[k + 12], a3);
-      }
-      for (; k < j; k += 4) a0 = fma(li[k], lj[k], a0);
-      acc = (a0 + a1) + (a2 + a3);
+// ---------------------------------------------------------------- 64 x 64 tile Cholesky + inverse, blocked by 16
+// The tile is factored in four 16-column steps: one wave factors and inverts the 16 x 16 diagonal block in LDS (16 short
+// column steps without workgroup barriers), the rows below are multiplied by that inverse and the trailing blocks updated with
+// v_mfma_f64_16x16x4 on LDS operands (one 16 x 16 block per wave); the inverse of the whole tile is then assembled block row by
+// block row from the diagonal inverses.  ~20 workgroup barriers per tile instead of the ~200 of a column-by-column sweep
+// (the tile factorisations were 20 % of the factorisation phase, all of it barrier latency).
+constexpr int LDP = 65;                                  // leading dimension of the tile images in LDS
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // LDS ops of one wave complete in order: this keeps the compiler from reordering across it
+
+// D (16 x 16 in registers, acc[r] = D[(lane >> 4) + 4 r][lane & 15]) += sgn * A B  with A[r][k] = Ap[r * lda + k], B[k][c] = Bp[k * bk + c * bc]
+__device__ __forceinline__ double4_t mm16(const double* Ap, int lda, const double* Bp, int bk, int bc, double4_t acc, double sgn, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < 16; k0 += 4) {
+    const double a = sgn * Ap[fr * lda + k0 + fk];
+    const double bv = Bp[(k0 + fk) * bk + fr * bc];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ double4_t load_d16(const double* Cp, int ldc, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  return (double4_t){Cp[fk * ldc + fr], Cp[(fk + 4) * ldc + fr], Cp[(fk + 8) * ldc + fr], Cp[(fk + 12) * ldc + fr]};
+}
+__device__ __forceinline__ void store_d16(double* Cp, int ldc, double4_t v, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  Cp[fk * ldc + fr] = v[0]; Cp[(fk + 4) * ldc + fr] = v[1]; Cp[(fk + 8) * ldc + fr] = v[2]; Cp[(fk + 12) * ldc + fr] = v[3];
+}
+
+// One wave: Cholesky (lower, in place) of the 16 x 16 block at S and its inverse into Si (same position; upper part zero).
+// dr: the 16 pivot references; stat[0] counts frozen pivots, stat[1] tracks the smallest pivot / reference (Cholesky-with-shift,
+// same rule as before: a pivot below 1e-15 of its reference is frozen at 1e20 * reference).
+__device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double* dr, double* stat, int lane) {
+  for (int j = 0; j < 16; ++j) {
+    double piv = S[j * LDP + j];
+    const double ref = fabs(dr[j]);
+    const bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
+    if (lane == 0) {
+      if (piv < 1e-8 * ref) stat[1] = fmin(stat[1], fmax(piv, 0.0) / ref);      // (division only on the rare small pivots)
+      if (bad) stat[0] += 1.0;
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    double sij = 0.0;
-    if (row >= j && row < nb) sij = S[row * 65 + j] - acc;
-    if (row == j && seg == 0) {
-      double piv = sij;
-      const double ref = fabs(dr[j]);
-      if (piv < 1e-8 * ref) dr[66] = fmin(dr[66], fmax(piv, 0.0) / ref);    // (division only on the rare small pivots)
-      if (!(piv > 1e-15 * ref) || !(piv > 0.0)) { piv = (ref > 0.0 ? ref : 1.0) * 1e20; dr[65] += 1.0; }   // Cholesky-with-shift
-      dr[64] = sqrt(piv);
+    if (bad) piv = (ref > 0.0 ? ref : 1.0) * 1e20;
+    const double dj = sqrt(piv);
+    if (lane < 16) {
+      if (lane > j) S[lane * LDP + j] = S[lane * LDP + j] / dj;
+      else if (lane == j) S[j * LDP + j] = dj;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                       // rank-1 update of the trailing lower triangle, four entries per lane
+      const int e = lane + 64 * t, i = e >> 4, k = e & 15;
+      if (k > j && k <= i) S[i * LDP + k] -= S[i * LDP + j] * S[k * LDP + j];
+    }
+    wave_lds_sync();
+  }
+  // inverse by rows:  Si[i][c] = (delta_ic - sum_{c<=k<i} L[i][k] Si[k][c]) / L[i][i]
+  for (int i = 0; i < 16; ++i) {
+    if (lane < 16) {
+      const int c = lane;
+      const double lii = S[i * LDP + i];
+      double v = 0.0;
+      if (c < i) {
+        double acc = 0.0;
+        for (int k = c; k < i; ++k) acc = fma(S[i * LDP + k], Si[k * LDP + c], acc);
+        v = -acc / lii;
+      } else if (c == i) v = 1.0 / lii;
+      Si[i * LDP + c] = v;
+    }
+    wave_lds_sync();
+  }
+}
+
+// Cholesky of the nb x nb diagonal tile at T (ld = ldt; nb a multiple of 16, <= 64) + its inverse into Ti (nb x nb, ld = TB).
+// dref: assembled diagonal entries (pivot reference).  Returns the number of frozen pivots (thread-uniform).
+__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
+  double* Si = S + 64 * LDP;               // 64 x 65
+  double* dr = Si + 64 * LDP;              // 64 pivot references, [65] = shift counter, [66] = smallest pivot / reference
+  double* tmp = dr + 72 + wv * (16 * 17);  // one 16 x 17 scratch block per wave
+  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * LDP + j] = T[(size_t)i * ldt + j]; Si[i * LDP + j] = 0.0; }
+  if (tid < nb) dr[tid] = dref[tid];
+  if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }
+  __syncthreads();
+  const int nbk = nb >> 4;
+  for (int jb = 0; jb < nbk; ++jb) {
+    const int o = 16 * jb;
+    if (wv == 0) wave_potrf16(S + o * LDP + o, Si + o * LDP + o, dr + o, dr + 65, lane);
+    __syncthreads();
+    {                                      // rows below: P <- P L11^-T, one 16-row block per wave
+      const int bi = jb + 1 + wv;
+      if (bi < nbk) {
+        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+        acc = mm16(S + 16 * bi * LDP + o, LDP, Si + o * LDP + o, 1, LDP, acc, 1.0, lane);     // B[k][c] = Linv11[c][k]
+        store_d16(S + 16 * bi * LDP + o, LDP, acc, lane);
+      }
     }
     __syncthreads();
-    if (seg == 0 && row >= j && row < nb) {
-      const double dj = dr[64];
-      S[row * 65 + j] = (row == j) ? dj : sij / dj;
+    {                                      // trailing blocks (bi, bj), jb < bj <= bi:  S -= P_bi P_bj'
+      int q = 0;
+      for (int bi = jb + 1; bi < nbk; ++bi)
+        for (int bj = jb + 1; bj <= bi; ++bj, ++q)
+          if ((q & 3) == wv) {
+            double* Cp = S + 16 * bi * LDP + 16 * bj;
+            double4_t acc = load_d16(Cp, LDP, lane);
+            acc = mm16(S + 16 * bi * LDP + o, LDP, S + 16 * bj * LDP + o, 1, LDP, acc, -1.0, lane);     // B[k][c] = P_bj[c][k]
+            store_d16(Cp, LDP, acc, lane);
+          }
     }
     __syncthreads();
   }
-  // ---- L^-1 by rows:  Ti[i][c] = (delta_ic - sum_{c<=k<i} L[i][k] Ti[k][c]) / L[i][i]
-  const int col = tid >> 2;
-  for (int i = 0; i < nb; ++i) {
-    double acc = 0.0;
-    if (col < i) {
-      const double* li = S + i * 65;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int k = col + seg;
-      for (; k + 12 < i; k += 16) {
-        a0 = fma(li[k], Si[k * 65 + col], a0); a1 = fma(li[k + 4], Si[(k + 4) * 65 + col], a1);
-        a2 = fma(li[k + 8], Si[(k + 8) * 65 + col], a2); a3 = fma(li[k + 12], Si[(k + 12) * 65 + col], a3);
-      }
-      for (; k < i; k += 4) a0 = fma(li[k], Si[k * 65 + col], a0);
-      acc = (a0 + a1) + (a2 + a3);
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (seg == 0 && col < nb) {
-      const double lii = S[i * 65 + i];
-      double v;
-      if (col < i) v = -acc / lii; else if (col == i) v = 1.0 / lii; else v = 0.0;
-      Si[i * 65 + col] = v;
+  // inverse of the tile, block row by block row:  Linv[bi][bj] = -Linv[bi][bi] * sum_{k=bj}^{bi-1} L[bi][k] Linv[k][bj]
+  for (int bi = 1; bi < nbk; ++bi) {
+    const int bj = wv;
+    if (bj < bi) {
+      double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int k = bj; k < bi; ++k) acc = mm16(S + 16 * bi * LDP + 16 * k, LDP, Si + 16 * k * LDP + 16 * bj, LDP, 1, acc, 1.0, lane);
+      store_d16(tmp, 17, acc, lane);
+      wave_lds_sync();
+      double4_t r = (double4_t){0.0, 0.0, 0.0, 0.0};
+      r = mm16(Si + 16 * bi * LDP + 16 * bi, LDP, tmp, 17, 1, r, -1.0, lane);
+      store_d16(Si + 16 * bi * LDP + 16 * bj, LDP, r, lane);
     }
     __syncthreads();
   }
   for (int e = tid; e < nb * nb; e += 256) {
     const int i = e / nb, j = e - i * nb;
-    if (j <= i) T[(size_t)i * ldt + j] = S[i * 65 + j];
-    Ti[i * TB + j] = Si[i * 65 + j];
+    if (j <= i) T[(size_t)i * ldt + j] = S[i * LDP + j];
+    Ti[i * TB + j] = Si[i * LDP + j];
   }
   __syncthreads();
   const int nb_bad = (int)dr[65];
