@@ -151,6 +151,16 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
  * the problems still iterating), [9] / [10] / [11] ms inside k_cr_potrf / k_cr_trsm / k_cr_update, [12..15] reserved. */
 int tmpc_get_profile(tmpc_handle* h, double* out16);
 
+/* Optimality certificate of the LAST wave solved (nb <= chunk, plain Step 1 model): the DUAL iterate of the interior-point method,
+ * i.e. the multipliers of the 2p LMIs of convexifier.py:304-306 in the scaled problem
+ *     min tau  s.t.  S1_k = M_k - I >= 0,  S2_k = tau I - M_k >= 0,  alpha - 1e-8 >= 0,   M_k = alpha s H_k + calH_k(Pbar):
+ * X1, X2 [nb][p][n][n] (>= 0) and scal [nb][4] = (x0, tau, alpha, mu_target).  For a dual-feasible triple (sum_k tr X2_k = 1,
+ * sum_k <s H_k, X1_k - X2_k> + x0 = 0, calH*(X1 - X2) = 0) weak duality gives  sum_k tr X1_k + 1e-8 x0  <=  kappa* (the optimal
+ * max condition number), so together with the primal point (P, alpha, kappa outputs: cond(Hc_k) <= kappa) a caller can bound the
+ * optimality gap of kappa without trusting this solver (tests/test_gpu_parity.py::test_dual_certificate does it in numpy).
+ * Any pointer may be NULL.  Early-exit members (already convex) hold no meaningful dual. */
+int tmpc_get_dual_host(tmpc_handle* h, int nb, double* X1, double* X2, double* scal);
+
 /* Per-iteration diagnostics of the LAST chunk solved: out[nb][80][10] = (iteration, phase, mu, tau, pinf, dinf,
  * primal step, dual step, relative output change of the step, cumulative shifted pivots); nb <= chunk. */
 int tmpc_get_trace(tmpc_handle* h, int nb, double* out);

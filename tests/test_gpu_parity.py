@@ -615,6 +615,55 @@ def test_sharded_path_with_hip_handle_and_nccl(hc):
             dist.destroy_process_group()
 
 
+def _certificate(A, B, H, out, dual, b):
+    """Solver-independent optimality certificate of member b, in numpy only (no oracle): the primal point returned by the library
+    (P, alpha, kappa) is feasible for the scaled SDP of convexifier.py:304-306 with objective kappa; the exported dual iterate is
+    feasible up to tiny residuals and its objective is a lower bound of the optimal kappa* (weak duality).  Returns
+    (kappa, dual objective, slack from the dual residuals, N * mu_target)."""
+    p, nx, _ = A.shape
+    n = H.shape[1]
+    s = out['info'][b, 0]
+    alpha = out['alpha'][b]; kappa = out['kappa'][b]
+    Hb = s * 0.5 * (H + H.transpose(0, 2, 1))
+    V = np.concatenate([A, B], axis=2)
+    Pbar = out['P'][b] * (s * alpha)                                        # un-scaling of convexifier.py:406 undone
+    M = alpha * Hb + V.transpose(0, 2, 1) @ np.roll(Pbar, -1, axis=0) @ V
+    M[:, :nx, :nx] -= Pbar
+    ev = np.linalg.eigvalsh(M)
+    assert ev.min() >= 1.0 - 1e-9 and ev.max() <= kappa * (1 + 1e-9) and alpha > 1e-8       # primal feasible, objective kappa
+    X1, X2, x0 = dual['X1'][b], dual['X2'][b], dual['x0'][b]
+    assert np.linalg.eigvalsh(X1).min() > 0 and np.linalg.eigvalsh(X2).min() > 0 and x0 > 0
+    Y = X1 - X2
+    r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
+    r_alpha = -np.sum(Hb * Y) - x0
+    W = V @ Y @ V.transpose(0, 2, 1)
+    r_P = -(np.roll(W, 1, axis=0) - Y[:, :nx, :nx])
+    dobj = np.trace(X1, axis1=1, axis2=2).sum() + 1e-8 * x0
+    # Lagrangian at any primal-feasible (tau, alpha, P):  tau >= dobj + tau r_tau + alpha r_alpha + <r_P, P>
+    slack = 2.0 * (abs(r_tau) * kappa + abs(r_alpha) * alpha + np.sqrt(np.sum(r_P ** 2)) * np.sqrt(np.sum(Pbar ** 2)))
+    return kappa, dobj, slack, (2 * p * n + 1) * dual['mu_target'][b]
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(0, 3, 3, 3, 2), (13, 2, 30, 4, 1), (11, 2, 6, 12, 4), (12, 2, 4, 24, 8), (777, 2, 64, 24, 8)])
+def test_dual_certificate(hc, seed, nb, p, nx, mb):
+    """kappa* is pinned from both sides without the oracle and without trusting the solver: the returned primal point is feasible
+    with value kappa (upper bound), the exported dual iterate gives a lower bound, and the two differ by the complementarity gap
+    N * mu_target the solver stops at (relative gap N * tol <= 1.3e-4 at the benchmark shape)."""
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    h = hc(p, nx, mb)
+    out = h.convexify_batch(A, B, H)
+    dual = h.dual(nb)
+    for b in range(nb):
+        if out['info'][b, 13] != 0.0:
+            continue                                  # already convex: no SDP was solved
+        assert int(out['status'][b]) == 0
+        kappa, dobj, slack, gap = _certificate(A[b], B[b], H[b], out, dual, b)
+        assert dobj - slack <= kappa                  # weak duality: lower bound <= attained value
+        assert kappa - dobj <= 1.05 * gap + slack     # ... and they are as close as the barrier parameter says
+        assert gap / kappa <= (2 * p * (nx + mb) + 1) * 2.0 ** -25 * 1.5
+        assert abs(dual['tau'][b] - kappa) <= 1e-12 * kappa
+
+
 # ----------------------------------------------------------------------------- consumer row: tracking reference
 @pytest.mark.parametrize('n,ns', [(4, 1), (5, 30), (15, 40), (32, 257)])
 def test_tracking_reference_parity(hc, n, ns):

@@ -20,7 +20,7 @@ EXPORTS = [
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
-    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace',
+    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 # ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
@@ -89,6 +89,8 @@ def load_library():
     lib.tmpc_get_profile.argtypes = [vp, dp]
     lib.tmpc_get_trace.restype = C.c_int
     lib.tmpc_get_trace.argtypes = [vp, C.c_int, dp]
+    lib.tmpc_get_dual_host.restype = C.c_int
+    lib.tmpc_get_dual_host.argtypes = [vp, C.c_int, dp, dp, dp]
     lib.tmpc_debug_gemm_nt.restype = C.c_int
     lib.tmpc_debug_gemm_nt.argtypes = [vp, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_debug_block_solve.restype = C.c_int
@@ -314,6 +316,13 @@ class HipConvexifier:
         keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters',
                 'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms']
         return dict(zip(keys, out.tolist()))
+
+    def dual(self, nb):
+        """Dual iterate of the last wave solved (plain Step 1 model, scaled problem): dict(X1, X2 [nb,p,n,n], x0, tau, alpha, mu_target [nb]);
+        see tmpc_get_dual_host -- the data for a solver-independent bound on the optimality gap of kappa."""
+        X1 = np.empty((nb, self.p, self.n, self.n)); X2 = np.empty_like(X1); sc = np.empty((nb, 4))
+        _check(self.lib, self.lib.tmpc_get_dual_host(self._h, int(nb), _dptr(X1), _dptr(X2), _dptr(sc)), 'tmpc_get_dual_host')
+        return dict(X1=X1, X2=X2, x0=sc[:, 0].copy(), tau=sc[:, 1].copy(), alpha=sc[:, 2].copy(), mu_target=sc[:, 3].copy())
 
     def trace(self, nb):
         """[nb, 80, 10] per-iteration diagnostics of the last chunk (it, phase, mu, tau, pinf, dinf, ap, ad, step, shifts)."""

@@ -139,6 +139,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.Z = c.take<double>(BP * dm.dp);
   w.active = c.take<int>(64);
   w.alist = c.take<int>((size_t)dm.B);
+  w.flist = c.take<int>((size_t)dm.B);
   w.cr_orient = nullptr;
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
@@ -412,11 +413,14 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
   WS w = wall;                           // view over the problems still iterating (per-iteration kernels map blockIdx through alist)
   int* alist = wall.alist;
+  int* flist = wall.flist;
   wall.alist = nullptr;
-  const Opts o = h->opt;
+  Opts o = h->opt;
+  if (eq) o.chord_step = 0.0;             // chord steps: plain model only (the stage-local multipliers keep fresh factorisations)
+  WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
-  HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
   {
@@ -425,9 +429,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   }
   hipLaunchKernelGGL(k_init_state, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BPall), dim3(64), 0, st, wall, dm);
-  int active = 0;
-  HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+  int cnt[2] = {0, 0};                    // problems still iterating / of which need a factorisation
+  HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  int active = cnt[0], nfac = cnt[0];
   const int cap = o.max_iter + o.center_iter + 2;
   int it = 0;
   while (active > 0 && it < cap) {
@@ -463,16 +468,18 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
-    HIPCHK(hipMemsetAsync(w.active, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[5], st));
-    HIPCHK(hipMemcpyAsync(&active, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+    const int nfac_done = nfac;
+    HIPCHK(hipMemcpyAsync(cnt, w.active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    active = cnt[0]; nfac = cnt[1];
     if (prof) {
       float ms;
       for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[i], ln->ev[i + 1])); ln->prof[i] += ms; }
-      ln->prof[5] += 1.0;
-      ln->prof[8] += (double)active;
+      if (nfac_done > 0) ln->prof[5] += 1.0;
+      ln->prof[8] += (double)nfac_done;
       for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, ln->kev[i], ln->kev[i + 1])); ln->prof[9 + (i / 2) % 3] += ms; }
     }
     ++it;
@@ -555,6 +562,8 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
   { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
+  h->opt.chord_step = 0.0;
+  { const char* e = getenv("TMPC_CHORD"); if (e) h->opt.chord_step = atof(e); }
   h->flags = 0;
   WS tmp;
   const size_t lane_bytes = carve(tmp, h->dm, nullptr, nullptr);
@@ -627,6 +636,30 @@ int tmpc_get_trace(tmpc_handle* h, int nb, double* out) {
   const size_t row = (size_t)TRACE_LEN * TRACE_W;
   return for_last_wave(h, nb, [&](Lane& ln, int o, int m) {
     HIPCHK(hipMemcpy(out + (size_t)o * row, ln.ws.trace, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+  });
+}
+
+// dual iterate of the LAST wave solved (see tunempc_hip.h)
+__global__ void k_dual_scalars(WS w, int nb, double* out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  double* o = out + (size_t)b * 4;
+  o[0] = pr[P_X0]; o[1] = pr[P_TAU]; o[2] = pr[P_ALPHA]; o[3] = pr[P_MUT];
+}
+
+int tmpc_get_dual_host(tmpc_handle* h, int nb, double* X1, double* X2, double* scal) {
+  if (!h || nb < 1 || nb > h->chunk) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const size_t row = (size_t)h->dm.p * h->dm.n * h->dm.n;
+  return for_last_wave(h, nb, [&](Lane& ln, int o, int m) {
+    if (X1) HIPCHK(hipMemcpy(X1 + (size_t)o * row, ln.ws.X1, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    if (X2) HIPCHK(hipMemcpy(X2 + (size_t)o * row, ln.ws.X2, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    if (scal) {
+      hipLaunchKernelGGL(k_dual_scalars, dim3((m + 63) / 64), dim3(64), 0, 0, ln.ws, m, ln.d_info);      // d_info: [cap][16] scratch, free between calls
+      HIPCHK(hipMemcpy(scal + (size_t)o * 4, ln.d_info, (size_t)m * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return TMPC_OK;
   });
 }

@@ -27,10 +27,11 @@ enum {
   P_TAU = 0, P_ALPHA, P_S0, P_X0, P_MU, P_MUT, P_SIGMU, P_AP, P_AD, P_S, P_SBETA, P_PINF, P_DINF, P_RELGAP,
   P_STEPN, P_PREVSTEPN, P_DTAU, P_DALPHA, P_DS0, P_DX0, P_RD0, P_CORR0, P_MINEIG_H, P_BTT, P_BTA, P_BAA,
   P_SB00, P_SB01, P_SB11, P_RHS_TAU, P_RHS_ALPHA, P_SXS, P_MINEIG_HC, P_MAXCOND, P_KAPPA, P_BETA, P_ALPHA_OUT,
-  P_MAXEIG_HC, P_MU0, P_MINPIV, PS = 48
+  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
-enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, IS = 16 };   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
+enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, IS = 16 };   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
+//   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
 // phases
 enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2 };
@@ -79,6 +80,8 @@ struct Opts {
   double center_tol;   // relative Newton step that ends the centering phase
   int max_iter;
   int center_iter;
+  double chord_step;   // centering: once a full Newton step could have been this many times longer before leaving the cone (i.e. the
+                       // iterate moved by < 1/chord_step in the local norm), the next steps re-use the factorisation; 0 = never
 };
 
 // Device workspace (all pointers device memory, fp64 row-major)
@@ -115,6 +118,7 @@ struct WS {
   double* TU;      // [B,p,dp,2]    T^-1 U
   double* Z;       // [B,p,dp]      rhs / solution
   int* active;     // [1] number of problems still iterating
+  int* flist;      // [B] the problems that need a new factorisation this iteration (count in active[1]); the others take a chord step
   int* alist;      // [B] their indices, compacted (written by k_init_prob / k_ctrl_d).  The per-iteration kernels are launched over
                    // `active` problems and map blockIdx through this list; nullptr = identity (init / final kernels, all problems)
   const int* cr_orient;  // [p] storage orientation of the coupling block of stage k (tmpc_cr.h): 0: T[P_{k+1},P_k], 1: T[P_k,P_{k+1}]

@@ -294,7 +294,7 @@ constexpr int cr_solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (
 __device__ __forceinline__ int cr_nc(const WS& w, int b, int pass) {
   const int phase = w.iprob[(size_t)b * IS + I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
-  return ((pass == 1) || (phase != PH_MAIN)) ? 3 : 1;
+  return ((pass == 1) || (phase != PH_MAIN && !w.iprob[(size_t)b * IS + I_CHORD])) ? 3 : 1;     // chord step: rhs only
 }
 __device__ __forceinline__ double* cr_rhs(const WS& w, const Dims& dm, int b, int node, int nc) {
   return ((nc == 3) ? w.W3 : w.Z) + ((size_t)b * dm.p + node) * dm.dp * nc;

@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* 
   double* TU = w.TU + (size_t)b * vl * 2;
   const double* U = w.U + (size_t)b * vl * 2;
   if (pass == 1 && phase != PH_MAIN) return;           // centering: everything happens in pass 2
-  const bool three = (pass == 1) || (phase != PH_MAIN);
+  const bool three = (pass == 1) || (phase != PH_MAIN && !ip[I_CHORD]);    // chord step: TU and the 2 x 2 border Schur complement of the last factorisation stay
   if (three) {
     double s00 = 0.0, s01 = 0.0, s11 = 0.0;
     for (size_t e = tid; e < vl; e += 256) {

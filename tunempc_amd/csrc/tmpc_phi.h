@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(64) k_aug_gather(WS w, Dims dm, int pass) {
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
-  const bool three = (pass == 1) || (phase != PH_MAIN);
+  const bool three = (pass == 1) || (phase != PH_MAIN && !ip[I_CHORD]);
   const PhiStage ps = phi_stage(w, dm, sid);
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   const int nzs = dm.nz;

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
   // main phase: pass 1 solves [predictor rhs | u_tau | u_alpha], pass 2 the corrector rhs alone;
   // centering phase: no predictor, so pass 1 is skipped and pass 2 solves [rhs | u_tau | u_alpha] in one sweep
   if (pass == 1 && phase != PH_MAIN) return;
-  const bool three = (pass == 1) || (phase != PH_MAIN);
+  const bool three = (pass == 1) || (phase != PH_MAIN && !ip[I_CHORD]);     // chord step: the border columns of the last factorisation stay
   const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* av = w.adjV + (size_t)(b * dm.p + km) * NADJ * nxx;
@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
   const double dx0 = pr[P_SIGMU] / s0 - x0 - x0 * ds0 / s0 - pr[P_CORR0];
   double ap, ad;
   raw_steps(pr, minx, mins, dx0, ds0, &ap, &ad);
+  pr[P_RAWSTEP] = fmin(ap, ad);               // how many times longer the step could be: 1 / (size of the step in the local norm of the cone)
   if (phase == PH_MAIN) {
     const double mn = fmin(ap, ad);
     const double gam = 0.9 + 0.09 * fmin(mn, 1.0);
@@ -334,8 +335,8 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
   pr[P_AP] = ap; pr[P_AD] = ad;
   if (w.trace && ip[I_ITERS] >= 1 && ip[I_ITERS] <= TRACE_LEN) {
     double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
-    t[0] = (double)ip[I_ITERS]; t[1] = (double)phase; t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
-    t[6] = ap; t[7] = ad; t[8] = pr[P_STEPN]; t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
+    t[0] = (double)ip[I_ITERS]; t[1] = (double)phase + 0.25 * ip[I_CHORD];    // x.25: a chord step (factorisation re-used) t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
+    t[6] = ap; t[7] = (phase == PH_CENTER) ? pr[P_RAWSTEP] : ad; t[8] = pr[P_STEPN];     // centering: ap = ad = 1 on full steps; slot 7 holds the raw step length instead t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
   }
   if (!stopped) {        // (0 * NaN would poison the kept iterate)
     pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
@@ -352,18 +353,35 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
   double* pr = w.prob + (size_t)b * PS;
   if (ip[I_PHASE] == PH_CENTER) {
     const bool full = (pr[P_AP] == 1.0 && pr[P_AD] == 1.0);
+    const bool was_chord = ip[I_CHORD] != 0;
     const double stepn = pr[P_STEPN], prev = pr[P_PREVSTEPN];
     const double rr = (prev >= 0.0) ? fmin(1.0, stepn / prev) : 1.0;                 // contraction of the last two full steps
-    const double est = stepn * rr * sqrt(rr);     // extrapolated next step: between linear (r) and quadratic (r^2) convergence
-    if (full && (stepn < o.center_tol || est < 0.1 * o.center_tol)) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
-    else if (full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    // extrapolated next step: between linear (r) and quadratic (r^2) convergence for Newton steps; a chord step (frozen
+    // factorisation) converges linearly, its remaining error is ~ stepn * r / (1 - r) <= stepn for r <= 1/2
+    const double est = was_chord ? stepn : stepn * rr * sqrt(rr);
+    bool chord_next = false;
+    if (full && (stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    else if (!was_chord && full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting there is
     // nothing more to gain (and the rest of a lockstep batch is waiting)
     else if (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+    else if (o.chord_step > 0.0 && full && ip[I_REG] == 0) {
+      // Chord steps: the last step moved the iterate by less than 1/chord_step in the local norm, so the Schur matrix at the new
+      // iterate differs from the factored one by about that much and Newton with the OLD factorisation still contracts by that
+      // factor per step -- at a fifth of the cost.  A chord step that contracts by less than 1/4 goes back to a fresh factorisation.
+      if (!was_chord) chord_next = pr[P_RAWSTEP] >= o.chord_step;
+      else chord_next = (prev < 0.0) || (stepn <= 0.25 * prev);
+    }
+    ip[I_CHORD] = (ip[I_PHASE] != PH_DONE && chord_next) ? 1 : 0;
+    if (ip[I_CHORD]) ip[I_NCHORD] += 1;
+    if (ip[I_PHASE] == PH_CENTER && ip[I_CHORD] == 0 && was_chord) ip[I_NCENT] -= 0;   // (a rejected chord step still counts as a centering iteration)
     pr[P_PREVSTEPN] = full ? stepn : -1.0;
   }
-  if (ip[I_PHASE] != PH_DONE) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; }
+  if (ip[I_PHASE] != PH_DONE) {
+    const int slot = atomicAdd(w.active, 1); w.alist[slot] = b;
+    if (!ip[I_CHORD]) { const int fs = atomicAdd(w.active + 1, 1); w.flist[fs] = b; }
+  }
 }
 
 }  // namespace tmpc

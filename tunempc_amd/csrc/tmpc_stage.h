@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
     ip[I_EARLY] = early;
     ip[I_PHASE] = early ? PH_DONE : PH_MAIN;
     ip[I_IPMSTATUS] = early ? IPM_OPTIMAL : IPM_MAXITER;
-    if (!early) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; }
+    if (!early) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; w.flist[slot] = b; }
   }
 }
 
