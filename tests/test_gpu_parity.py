@@ -664,6 +664,39 @@ def test_dual_certificate(hc, seed, nb, p, nx, mb):
         assert abs(dual['tau'][b] - kappa) <= 1e-12 * kappa
 
 
+# ----------------------------------------------------------------------------- producer row: sensitivities -> batched inputs
+@pytest.mark.parametrize('nb,p,nx,mb,nh', [(2, 3, 3, 2, 5), (3, 40, 9, 6, 7), (1, 4, 24, 8, 70), (2, 5, 2, 2, 1)])
+def test_producer_packing_on_device(hc, nb, p, nx, mb, nh):
+    """tmpc_pack_sensitivities_host vs the host mirror of pocp.py:322-361 (tunempc_amd.pocp): active rows in order (threshold :73), ragged
+    counts incl. stages with no active row, q = -mu' C, stage blocks of the Lagrangian Hessian; exact (pure selection / one dot product)."""
+    from tunempc_amd import pocp
+    n = nx + mb
+    rng = np.random.default_rng(nb * 100 + p + nh)
+    C = rng.standard_normal((nb, p, nh, n)); mu = rng.standard_normal((nb, p, nh))
+    mu[rng.random((nb, p, nh)) < 0.6] = 0.0                      # inactive constraints: exact zero multipliers
+    mu[0, 0] = 0.0                                               # a stage without any active constraint -> None in the reference
+    mu[-1, -1, :] = 1e-16                                        # below the threshold 1e-15
+    Hbig = rng.standard_normal((nb, p * n, p * n))
+    h = hc(p, nx, mb)
+    out = pocp.pack_batch_device(h, C=C, mu=mu, Hbig=Hbig)
+    for b in range(nb):
+        C_As, idx = pocp.active_set(list(C[b]), list(mu[b]))
+        qs = pocp.cost_gradient(list(mu[b]), list(C[b]))
+        Hs = pocp.stage_hessians(Hbig[b], n, p)
+        for k in range(p):
+            nc = 0 if C_As[k] is None else C_As[k].shape[0]
+            assert int(out['nc'][b, k]) == nc
+            if nc:
+                assert np.array_equal(out['C_As'][b, k, :nc], C_As[k]) and list(out['idx'][b, k, :nc]) == idx[k]
+            assert not out['C_As'][b, k, nc:].any() and (out['idx'][b, k, nc:] == -1).all()
+            assert np.abs(out['q'][b, k] - qs[k].ravel()).max() <= 1e-14 * max(1.0, np.abs(qs[k]).max())
+            assert np.array_equal(out['H'][b, k], Hs[k])
+    assert (out['nc'][0, 0] == 0) and (out['nc'][-1, -1] == 0)
+    # no path constraints: q = zeros (pocp.py:361)
+    o2 = pocp.pack_batch_device(h, Hbig=Hbig)
+    assert not o2['q'].any() and np.array_equal(o2['H'], out['H'])
+
+
 # ----------------------------------------------------------------------------- consumer row: tracking reference
 @pytest.mark.parametrize('n,ns', [(4, 1), (5, 30), (15, 40), (32, 257)])
 def test_tracking_reference_parity(hc, n, ns):

@@ -20,7 +20,7 @@ EXPORTS = [
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
-    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host',
+    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 # ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
@@ -89,6 +89,8 @@ def load_library():
     lib.tmpc_get_profile.argtypes = [vp, dp]
     lib.tmpc_get_trace.restype = C.c_int
     lib.tmpc_get_trace.argtypes = [vp, C.c_int, dp]
+    lib.tmpc_pack_sensitivities_host.restype = C.c_int
+    lib.tmpc_pack_sensitivities_host.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_double, C.c_int, dp, ip, ip, dp, dp]
     lib.tmpc_get_dual_host.restype = C.c_int
     lib.tmpc_get_dual_host.argtypes = [vp, C.c_int, dp, dp, dp]
     lib.tmpc_debug_gemm_nt.restype = C.c_int
@@ -316,6 +318,33 @@ class HipConvexifier:
         keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters',
                 'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms']
         return dict(zip(keys, out.tolist()))
+
+    def pack_sensitivities(self, C=None, mu=None, Hbig=None, thr=1e-15, ncmax=None, nb=None):
+        """GPU form of the array post-processing of Pocp.get_sensitivities (pocp.py:322-361): C [nb,p,nh,n], mu [nb,p,nh] -> C_As
+        [nb,p,ncmax,n] (active rows in order, zero-padded), nc [nb,p], idx [nb,p,nh] (-1 padded), q [nb,p,n]; Hbig [nb,p*n,p*n] ->
+        H [nb,p,n,n].  Without C: q = zeros (pass nb)."""
+        out = {}
+        p, n = self.p, self.n
+        if C is not None:
+            C = np.ascontiguousarray(C, dtype=np.float64); mu = np.ascontiguousarray(mu, dtype=np.float64)
+            nb, nh = C.shape[0], C.shape[2]
+            assert C.shape == (nb, p, nh, n) and mu.shape == (nb, p, nh), (C.shape, mu.shape)
+            ncmax = int(ncmax or nh)
+            out.update(C_As=np.empty((nb, p, ncmax, n)), nc=np.empty((nb, p), np.int32), idx=np.empty((nb, p, nh), np.int32))
+        else:
+            nh, ncmax = 0, 0
+            nb = int(nb if nb is not None else Hbig.shape[0])
+        out['q'] = np.empty((nb, p, n))
+        if Hbig is not None:
+            Hbig = np.ascontiguousarray(Hbig, dtype=np.float64)
+            assert Hbig.shape == (nb, p * n, p * n), Hbig.shape
+            out['H'] = np.empty((nb, p, n, n))
+        _check(self.lib, self.lib.tmpc_pack_sensitivities_host(self._h, nb, nh, _dptr(C), _dptr(mu), _dptr(Hbig), float(thr), ncmax,
+                                                               _dptr(out.get('C_As')), _iptr(out.get('nc')), _iptr(out.get('idx')),
+                                                               _dptr(out['q']), _dptr(out.get('H'))), 'tmpc_pack_sensitivities_host')
+        if 'nc' in out and (out['nc'] > ncmax).any():
+            raise ValueError('pack_sensitivities: a stage has %d active rows, more than ncmax = %d' % (int(out['nc'].max()), ncmax))
+        return out
 
     def dual(self, nb):
         """Dual iterate of the last wave solved (plain Step 1 model, scaled problem): dict(X1, X2 [nb,p,n,n], x0, tau, alpha, mu_target [nb]);

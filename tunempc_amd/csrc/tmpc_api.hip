@@ -273,6 +273,46 @@ __global__ void __launch_bounds__(64) k_tracking_ref(const double* Hc, const dou
   if (info && lane == 0) info[sid] = nbad;
 }
 
+// Producer side (pocp.py:322-361): one wave per stage.  Active-set extraction = order-preserving compaction of the rows of C_k with
+// |mu_k,i| > thr (wave ballot + prefix count), q_k = -mu_k' C_k, and the diagonal n x n block of the Lagrangian Hessian.
+__global__ void __launch_bounds__(64) k_pack_sens(const double* C, const double* mu, const double* Hbig, double thr, int nh, int ncmax, int p, int n,
+                                                  double* CAs, int32_t* ncnt, int32_t* idx, double* q, double* Hst) {
+  const size_t sid = blockIdx.x;
+  const int lane = threadIdx.x;
+  const size_t b = sid / p; const int k = (int)(sid - b * p);
+  if (C) {
+    const double* Ck = C + sid * nh * n; const double* mk = mu + sid * nh;
+    double* out = CAs + sid * (size_t)ncmax * n;
+    int cnt = 0;
+    for (int i0 = 0; i0 < nh; i0 += 64) {
+      const int i = i0 + lane;
+      const bool act = (i < nh) && (fabs(mk[i]) > thr);
+      const unsigned long long m = __ballot(act);
+      const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+      if (act) {
+        if (idx) idx[sid * nh + pos] = i;
+        if (pos < ncmax) for (int c = 0; c < n; ++c) out[(size_t)pos * n + c] = Ck[(size_t)i * n + c];
+      }
+      cnt += __popcll(m);
+    }
+    for (int e = lane + (cnt < ncmax ? cnt : ncmax) * n; e < ncmax * n; e += 64) out[e] = 0.0;      // zero padding
+    if (idx) for (int i = cnt + lane; i < nh; i += 64) idx[sid * nh + i] = -1;
+    if (lane == 0) ncnt[sid] = cnt;                                                                  // (> ncmax: the caller's padding was too small)
+    if (q) for (int c = lane; c < n; c += 64) {
+      double acc = 0.0;
+      for (int i = 0; i < nh; ++i) acc = fma(mk[i], Ck[(size_t)i * n + c], acc);
+      q[sid * n + c] = -acc;
+    }
+  } else if (q) {
+    for (int c = lane; c < n; c += 64) q[sid * n + c] = 0.0;                                         // pocp.py:361: zeros without path constraints
+  }
+  if (Hbig) {
+    const size_t ld = (size_t)p * n;
+    const double* Hb = Hbig + b * ld * ld + ((size_t)k * n) * ld + (size_t)k * n;
+    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; Hst[sid * n * n + e] = Hb[(size_t)i * ld + j]; }
+  }
+}
+
 // ---------------------------------------------------------------------------------- debug kernels
 __global__ void __launch_bounds__(64) k_debug_min_eig(const double* W, double* out, int n) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -879,6 +919,32 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, 
     HIPCHK(hipMemcpyAsync(dHc + so * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
+  return TMPC_OK;
+}
+
+int tmpc_pack_sensitivities_host(tmpc_handle* h, int nb, int nh, const double* C, const double* mu, const double* Hbig, double thr, int ncmax,
+                                 double* C_As, int32_t* ncnt, int32_t* idx, double* q, double* Hst) {
+  if (!h || nb < 1 || nh < 0 || ncmax < 0 || ((C != nullptr) != (mu != nullptr)) || (C && (nh < 1 || ncmax < 1 || !C_As || !ncnt)) || (Hbig && !Hst)) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const int p = h->dm.p, n = h->dm.n;
+  const size_t BP = (size_t)nb * p, ld = (size_t)p * n;
+  DevBuf bC, bmu, bH, bCA, bnc, bidx, bq, bHs;
+  if (C) {
+    HIPCHK(bC.alloc(BP * nh * n * 8)); HIPCHK(bmu.alloc(BP * nh * 8)); HIPCHK(bCA.alloc(BP * ncmax * n * 8)); HIPCHK(bnc.alloc(BP * 4)); HIPCHK(bidx.alloc(BP * nh * 4));
+    HIPCHK(hipMemcpy(bC.p, C, BP * nh * n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(bmu.p, mu, BP * nh * 8, hipMemcpyHostToDevice));
+  }
+  if (q) HIPCHK(bq.alloc(BP * n * 8));
+  if (Hbig) { HIPCHK(bH.alloc((size_t)nb * ld * ld * 8)); HIPCHK(bHs.alloc(BP * n * n * 8)); HIPCHK(hipMemcpy(bH.p, Hbig, (size_t)nb * ld * ld * 8, hipMemcpyHostToDevice)); }
+  hipLaunchKernelGGL(k_pack_sens, dim3((unsigned)BP), dim3(64), 0, 0, C ? bC.as<double>() : nullptr, C ? bmu.as<double>() : nullptr,
+                     Hbig ? bH.as<double>() : nullptr, thr, nh, ncmax, p, n, C ? bCA.as<double>() : nullptr, C ? bnc.as<int32_t>() : nullptr,
+                     (C && idx) ? bidx.as<int32_t>() : nullptr, q ? bq.as<double>() : nullptr, Hbig ? bHs.as<double>() : nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  if (C) {
+    HIPCHK(hipMemcpy(C_As, bCA.p, BP * ncmax * n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(ncnt, bnc.p, BP * 4, hipMemcpyDeviceToHost));
+    if (idx) HIPCHK(hipMemcpy(idx, bidx.p, BP * nh * 4, hipMemcpyDeviceToHost));
+  }
+  if (q) HIPCHK(hipMemcpy(q, bq.p, BP * n * 8, hipMemcpyDeviceToHost));
+  if (Hbig) HIPCHK(hipMemcpy(Hst, bHs.p, BP * n * n * 8, hipMemcpyDeviceToHost));
   return TMPC_OK;
 }
 

@@ -94,3 +94,11 @@ def pack_batch(S_list, nx):
             raise AssertionError('Input arguments should be of same type!')
         out['G'] = np.ascontiguousarray(np.stack([np.stack([_full(g) for g in S['G']]) for S in S_list]), dtype=np.float64)
     return out
+
+
+def pack_batch_device(handle, C=None, mu=None, Hbig=None, mu_tresh=MU_TRESH, ncmax=None, nb=None):
+    """The same post-processing on the GPU for a whole batch (tmpc_pack_sensitivities_host through `handle`, a HipConvexifier of the
+    problem shape): dense inputs C [nb,p,nh,n], mu [nb,p,nh], Hbig [nb,p*n,p*n] as the CasADi `.full()` calls deliver them, outputs in
+    the batched layout of the C ABI (C_As zero-padded with counts `nc`, q, H).  Bit-identical to `active_set` / `cost_gradient` /
+    `stage_hessians` (tests/test_gpu_parity.py::test_producer_packing_on_device)."""
+    return handle.pack_sensitivities(C=C, mu=mu, Hbig=Hbig, thr=mu_tresh, ncmax=ncmax, nb=nb)
