@@ -198,8 +198,9 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, in
 }
 
 // ---- phase 2: O_x <- T[x,i] L_i^-T for the (up to) two neighbours, `rs` rows per workgroup
-template <bool USE_MFMA>
-__global__ void __launch_bounds__(256, 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int rs) {
+// NS = 2: 32-column K slabs, 70 KB of LDS, two workgroups per CU; NS = 1: 16-column slabs, 35 KB, three per CU
+template <bool USE_MFMA, int NS>
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int rs) {
   const int nstrip = (dm.dp + rs - 1) / rs;
   const int per = 2 * nstrip;
   const int it = cr_item(count * nelim * per);
@@ -221,14 +222,14 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int
   int jt = 0;
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
-    if (j0 > 0) wg_gemm_nt<USE_MFMA>(X + j0, dp, X, dp, Dk + (size_t)j0 * dp, dp, rows, nb, j0, GM_SUB, false, lds);
-    wg_gemm_nt<USE_MFMA>(X + j0, dp, X + j0, dp, Li + (size_t)jt * TB * TB, TB, rows, nb, nb, GM_SET, false, lds);
+    if (j0 > 0) wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(X + j0, dp, X, dp, Dk + (size_t)j0 * dp, dp, rows, nb, j0, GM_SUB, false, lds);
+    wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(X + j0, dp, X + j0, dp, Li + (size_t)jt * TB * TB, TB, rows, nb, nb, GM_SET, false, lds);
   }
 }
 
 // ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, `mt` x `mt` output per workgroup
-template <bool USE_MFMA>
-__global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int mt) {
+template <bool USE_MFMA, int NS>
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) k_cr_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int mt) {
   const int nm = (dm.dp + mt - 1) / mt;
   const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
   const int per = nupd * ntl + nelim * ntf;
@@ -264,10 +265,10 @@ __global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, i
     const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;
     double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
     const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
-    wg_gemm_nt<USE_MFMA>(C, dp, O0 + (size_t)m0 * dp, dp, O0 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
+    wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, O0 + (size_t)m0 * dp, dp, O0 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
     if (ur[CU_E1] >= 0) {
       const double* O1 = cr_edge(w, dm, b, ur[CU_E1]);
-      wg_gemm_nt<USE_MFMA>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
+      wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
     }
   } else {
     const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, i
     const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
     const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
     double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
-    wg_gemm_nt<USE_MFMA>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
+    wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
   }
 }
 

@@ -48,26 +48,29 @@ typedef double __attribute__((address_space(1)))* gptr;
 // same eight waves; half the global -> LDS traffic, LDS stores and barriers per flop) for the batched symmetric updates.
 // Waves whose part of the tile lies outside M x N -- or, on a diagonal tile of a lower-only update, entirely above the
 // diagonal -- skip their MFMAs and stores (they still help to load), so 304 = 128 + 128 + 48 costs like 128 + 128 + 64.
-template <int WM, int WN, int FA>
+// NS: 16-column sub-slabs per K slab (slab = 16 NS columns of K): 2 in the block Cholesky; 1 halves the LDS of a workgroup
+// (35 KB for the 64 x 64 shape) so that three workgroups share a CU.
+template <int WM, int WN, int FA, int NS = 2>
 struct GemmCfg {
   static constexpr int TM = 16 * FA * WM, TN = 32 * WN, NTH = 64 * WM * WN, RP = NTH / 4;      // RP: slab rows covered by one pass of the loader
   static constexpr int ARP = (TM + RP - 1) / RP, BRP = (TN + RP - 1) / RP;                       // loader passes over the A / B slab
-  static constexpr int ASUB = TM * 17, BSUB = TN * 17, BUFD = 2 * ASUB + 2 * BSUB;               // doubles: 16-column sub-slab of A / B, one (A,B) buffer
+  static constexpr int ASUB = TM * 17, BSUB = TN * 17, BUFD = NS * ASUB + NS * BSUB;             // doubles: 16-column sub-slab of A / B, one (A,B) buffer
   static constexpr int LDS_DOUBLES = 2 * BUFD;
 };
 
-template <bool USE_MFMA, int WM = 2, int WN = 2, int FA = 2>
+template <bool USE_MFMA, int WM = 2, int WN = 2, int FA = 2, int NS = 2>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
                                            double* lds) {
-  typedef GemmCfg<WM, WN, FA> G;
+  typedef GemmCfg<WM, WN, FA, NS> G;
+  constexpr int GKT = 16 * NS;                          // K slab of this instantiation
   constexpr int TM = G::TM, TN = G::TN, RP = G::RP, ARP = G::ARP, BRP = G::BRP, ASUB = G::ASUB, BSUB = G::BSUB, BUFD = G::BUFD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wr = wv / WN, wc = wv % WN;
   // slab loader: row lrow (+ RP per pass); each thread moves two 32-byte pieces per pass and operand, k = lk..lk+3 and
   // 16+lk..16+lk+3, into two 16-column sub-slabs of leading dimension 17 (conflict-free for the fragment reads below)
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
-  const int nks = (K + GK - 1) / GK;
+  const int nks = (K + GKT - 1) / GKT;
   // v_mfma_f64_4x4x4_4b: four independent 4 x 4 x 4 products per instruction.  Operand lanes: A lane 16k + 4q + i holds A_q[i][k],
   // B lane 16k + 4q + j holds B_q[k][j]; result lane 16i + 4q + j holds D_q[i][j] (profiles/r1_mfma_f64_4x4x4_lane_layout.txt).
   // The four blocks q are four row groups of one 16-row A fragment and share one 4-column B fragment (replicated: the four
@@ -80,7 +83,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
   const int wr0 = wr * 16 * FA, wc0 = wc * 32;                        // this wave's corner inside the tile
   // the C fragment of a read-modify-write tile is prefetched at the tile's first slab in the small shape; the large shape (64
   // accumulator registers per lane already) reads it in the epilogue instead -- once per 10 slabs of 256 MFMAs
-  constexpr bool CPRE = (FA <= 2);
+  constexpr bool CPRE = (FA <= 2) && (NS == 2);       // (the 16-column-slab shape keeps its registers for a fourth workgroup per CU)
   double acc[FA][8], cpre[CPRE ? FA : 1][8];
 #pragma unroll
   for (int i = 0; i < FA; ++i)
@@ -107,13 +110,13 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     const unsigned aso = (unsigned)((M0) * lda + (KN) - lk) * 8u, bso = (unsigned)((N0) * ldb + (KN) - lk) * 8u;   /* wave-uniform */ \
     _Pragma("unroll") for (int rp = 0; rp < ARP; ++rp) {                                                    \
       if (RP * ARP == TM || lrow + rp * RP < TM) {                                                          \
-        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+        _Pragma("unroll") for (int h2 = 0; h2 < NS; ++h2)                                                   \
           TMPC_BLD4(ra, rp * 8 + h2 * 4, arsrc, avo + (unsigned)(rp * RP * lda + h2 * 16) * 8u, aso)        \
       }                                                                                                     \
     }                                                                                                       \
     _Pragma("unroll") for (int rp = 0; rp < BRP; ++rp) {                                                    \
       if (RP * BRP == TN || lrow + rp * RP < TN) {                                                          \
-        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+        _Pragma("unroll") for (int h2 = 0; h2 < NS; ++h2)                                                   \
           TMPC_BLD4(rb, rp * 8 + h2 * 4, brsrc, bvo + (unsigned)(rp * RP * ldb + h2 * 16) * 8u, bso)        \
       }                                                                                                     \
     }                                                                                                       \
@@ -121,18 +124,18 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 #define TMPC_SLAB_STORE(BUF)                                                                                \
   {                                                                                                         \
     double* An_ = lds + (BUF) * BUFD;                                                                       \
-    double* Bn_ = An_ + 2 * ASUB;                                                                           \
+    double* Bn_ = An_ + NS * ASUB;                                                                           \
     _Pragma("unroll") for (int rp = 0; rp < ARP; ++rp) {                                                    \
       const int row = lrow + rp * RP;                                                                       \
       if (RP * ARP == TM || row < TM) {                                                                     \
-        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+        _Pragma("unroll") for (int h2 = 0; h2 < NS; ++h2)                                                   \
           _Pragma("unroll") for (int q = 0; q < 4; ++q) An_[h2 * ASUB + row * SLD + lk + q] = ra[rp * 8 + h2 * 4 + q]; \
       }                                                                                                     \
     }                                                                                                       \
     _Pragma("unroll") for (int rp = 0; rp < BRP; ++rp) {                                                    \
       const int row = lrow + rp * RP;                                                                       \
       if (RP * BRP == TN || row < TN) {                                                                     \
-        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                                                    \
+        _Pragma("unroll") for (int h2 = 0; h2 < NS; ++h2)                                                   \
           _Pragma("unroll") for (int q = 0; q < 4; ++q) Bn_[h2 * BSUB + row * SLD + lk + q] = rb[rp * 8 + h2 * 4 + q]; \
       }                                                                                                     \
     }                                                                                                       \
@@ -152,7 +155,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
       if (nn0 >= N || (lower && nn0 > nm0)) { nn0 = 0; nm0 = m0 + TM; }
     }
     const bool more = nm0 < M;
-    if (more) TMPC_SLAB_LOAD(nm0, nn0, nks_ * GK + lk)
+    if (more) TMPC_SLAB_LOAD(nm0, nn0, nks_ * GKT + lk)
     TMPC_T(0)
     // does this wave own anything of the current tile?  (outside M x N, or above the diagonal of a lower-only diagonal tile)
     const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA);
@@ -175,8 +178,8 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     // ---- compute current slab
     if (wave_on) {
       const double* As = lds + buf * BUFD;
-      const double* Bs = As + 2 * ASUB;
-      const int krem = K - ks * GK;
+      const double* Bs = As + NS * ASUB;
+      const int krem = K - ks * GKT;
       if (USE_MFMA) {
 #define TMPC_MFMA_STEP(kk)                                                                              \
   {                                                                                                     \
@@ -192,26 +195,26 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     }                                                                                                   \
   }
         // (the large shape is unrolled by two only: a full unroll makes the compiler fetch all eight steps' fragments up front and spill)
-        if (krem >= GK) {
+        if (NS == 1 || krem >= GKT) {
           if (FA <= 2) {
 #pragma unroll
-            for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GKT / 4; ++kk) TMPC_MFMA_STEP(kk)
           } else {
 #pragma unroll 2
-            for (int kk = 0; kk < GK / 4; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GKT / 4; ++kk) TMPC_MFMA_STEP(kk)
           }
-        } else {
+        } else {                 // half slab (K = 16 mod 32)
           if (FA <= 2) {
 #pragma unroll
-            for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GKT / 8; ++kk) TMPC_MFMA_STEP(kk)
           } else {
 #pragma unroll 2
-            for (int kk = 0; kk < GK / 8; ++kk) TMPC_MFMA_STEP(kk)
+            for (int kk = 0; kk < GKT / 8; ++kk) TMPC_MFMA_STEP(kk)
           }
         }
 #undef TMPC_MFMA_STEP
       } else {   // debug path: same fragment ownership, scalar FMAs
-        const int kmax = (krem >= GK) ? GK : krem;
+        const int kmax = (krem >= GKT) ? GKT : krem;
         for (int kk = 0; kk < kmax; ++kk) {
 #pragma unroll
           for (int i = 0; i < FA; ++i)
