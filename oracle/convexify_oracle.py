@@ -334,6 +334,16 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     X2 = X1.copy()
     s0 = alpha
     x0 = o.get('init_x', 1.0) / (p * n)
+    if o.get('warm') is not None:
+        # experiment hook (scripts/warm_start_probe.py): start from a strictly feasible dual point (P, alpha, tau given in the scaled
+        # problem) with the primal blocks on its central path, X = mu0 S^-1
+        wm = o['warm']
+        P = np.array(wm['P'], dtype=float); alpha = float(wm['alpha']); tau = float(wm['tau'])
+        Mw = alpha * Hb + calH(A, B, P)
+        S1 = symmetrize(Mw - I); S2 = symmetrize(tau * I - Mw)
+        mu0w = float(wm.get('mu0', 1e-2))
+        X1 = mu0w * np.linalg.inv(S1); X2 = mu0w * np.linalg.inv(S2)
+        s0 = alpha - ALPHA_MIN; x0 = mu0w / s0
     ng = 0                                                 # rows of [G_k; C_k] per stage (padded to the longest stage, `mask` = real rows)
     ng0 = 0                                                # of which equality-constraint rows
     constr = C is not None and rho is not None
