@@ -117,6 +117,17 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nb, const double* A, con
                                     const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);
 
+/* The model of Step 3 (convexifier.py:137-147: setUpModelPicos with force=True, :269-273 T_k symmetric with every entry > 0, :284-285
+ * objective + sum rho*||T_k||_F, :352-353 term s_T*T_k, :422-423 un-scaling), here for the plain model (no G / C rows in the same solve):
+ * handle from tmpc_create_step3; T [nb][p][n][n] out; dHc includes T_k (convexifier.py:202-203).  The caller decides when to take
+ * this step (after the earlier steps came back Infeasible and with the 'force' option, as convexify() does).  The norm term is a
+ * second-order cone handled natively (tunempc_amd/csrc/tmpc_t3.h); the blocks of the factorisation grow to d + n(n+1)/2 + 1. */
+uint64_t tmpc_workspace_bytes_step3(int chunk, int p, int nx, int mb);
+int tmpc_create_step3(tmpc_handle** out, int chunk, int p, int nx, int mb);
+int tmpc_convexify_step3_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, double rho,
+                                    double* Hc, double* dHc, double* P, double* T, double* alpha, double* beta, double* kappa,
+                                    int32_t* status, int32_t* iters, double* info);
+
 /* Device-resident form of the two entries above (inputs and outputs in HBM, work queued on `stream`): d_ncnt == NULL is Step 1
  * with G (dJ = G [nb][p][ng][n], FgF [nb][p][ng]); otherwise the Step 2 model (dJ [nb][p][ng+nc][n], d_ncnt [nb][p] with
  * 0 <= ncnt <= nc -- not checked here --, FgF [nb][p][ng+nc]). */

@@ -295,6 +295,78 @@ def _arrow_start(a, m, mu):
     return a + 0.5 * (lo + hi)
 
 
+# ------------------------------------------------------------ second-order cone block (the norm term of Step 3)
+# rho*||T_k||_F <= t as the Lorentz cone (t; w c o theta) in Q^{m+1} (m = n(n+1)/2 entries of T_k; PICOS hands abs() to the solver
+# as a quadratic cone as well).  Jordan algebra of Q: u o v = (u'v; u0 v1 + v0 u1), identity e = (1; 0), det u = u0^2 - |u1|^2,
+# central path x o s = mu e (degree 1 per cone).  Nesterov-Todd scaling W (symmetric, W x = W^-1 s = lambda), closed forms as in
+# the CVXOPT cone-programming documentation: W = beta (2 v v' - J), W^-1 = (2 J v v' J - J)/beta, J = diag(1, -I).
+def _soc_det(u):
+    return u[0] * u[0] - u[1:] @ u[1:]
+
+
+def _soc_inv(u):
+    return np.concatenate([[u[0]], -u[1:]]) / _soc_det(u)
+
+
+def _soc_prod(u, v):
+    return np.concatenate([[u @ v], u[0] * v[1:] + v[0] * u[1:]])
+
+
+def _soc_div(lam, r):
+    """solve lam o u = r"""
+    dl = _soc_det(lam)
+    u0 = (lam[0] * r[0] - lam[1:] @ r[1:]) / dl
+    u1 = (-r[0] * lam[1:] + (dl * r[1:] + (lam[1:] @ r[1:]) * lam[1:]) / lam[0]) / dl
+    return np.concatenate([[u0], u1])
+
+
+def _soc_scaling(s, x):
+    """NT scaling of the pair (slack s, multiplier x): returns (beta, v) with W = beta (2 v v' - J)."""
+    ds_, dx_ = _soc_det(s), _soc_det(x)
+    sb = s / np.sqrt(ds_); xb = x / np.sqrt(dx_)
+    gam = np.sqrt((1.0 + xb @ sb) / 2.0)
+    wb = (sb + np.concatenate([[xb[0]], -xb[1:]])) / (2.0 * gam)
+    v = wb.copy(); v[0] += 1.0
+    v /= np.sqrt(2.0 * (wb[0] + 1.0))
+    return (ds_ / dx_) ** 0.25, v
+
+
+def _soc_W(beta, v, u, inverse=False):
+    """W u or W^-1 u"""
+    if inverse:
+        Jv = np.concatenate([[v[0]], -v[1:]])
+        return (2.0 * Jv * (Jv @ u) - np.concatenate([[u[0]], -u[1:]])) / beta
+    return beta * (2.0 * v * (v @ u) - np.concatenate([[u[0]], -u[1:]]))
+
+
+def _soc_W2inv(beta, v):
+    """W^-2 as a dense matrix (identity plus rank two)"""
+    Jv = np.concatenate([[v[0]], -v[1:]])
+    return (np.eye(len(v)) + 4.0 * (v @ v) * np.outer(Jv, Jv) - 2.0 * (np.outer(Jv, v) + np.outer(v, Jv))) / (beta * beta)
+
+
+def _soc_max_step(u, du):
+    """largest theta with u + theta du in Q (u in int Q)"""
+    a = du[0] * du[0] - du[1:] @ du[1:]
+    b = u[0] * du[0] - u[1:] @ du[1:]
+    c = _soc_det(u)
+    # c + 2 b th + a th^2 >= 0 and u0 + th du0 >= 0: smallest positive root
+    cand = [np.inf]
+    if du[0] < 0:
+        cand.append(-u[0] / du[0])
+    if abs(a) < 1e-300:
+        if b < 0:
+            cand.append(-c / (2.0 * b))
+    else:
+        disc = b * b - a * c
+        if disc >= 0:
+            sq = np.sqrt(disc)
+            for r in ((-b - sq) / a, (-b + sq) / a):
+                if r > 0:
+                    cand.append(r)
+    return min(cand)
+
+
 def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None, force=False):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
     constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
@@ -335,7 +407,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     s0 = alpha
     x0 = o.get('init_x', 1.0) / (p * n)
     if o.get('warm') is not None:
-        # experiment hook (scripts/warm_start_probe.py): start from a strictly feasible dual point (P, alpha, tau given in the scaled
+        # experiment hook (tests/tools/warm_start_probe.py): start from a strictly feasible dual point (P, alpha, tau given in the scaled
         # problem) with the primal blocks on its central path, X = mu0 S^-1
         wm = o['warm']
         P = np.array(wm['P'], dtype=float); alpha = float(wm['alpha']); tau = float(wm['tau'])
@@ -389,8 +461,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     blocks = ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else [])
                 if nT:
                     blocks.append(nJ + np.arange(nT))
-                for idx in blocks:
+                for bi_, idx in enumerate(blocks):
                     m = len(idx)
+                    soc = bool(nT) and bi_ == len(blocks) - 1             # the block of the entries of T_k: second-order cone
                     w2 = float(np.sum(cw[idx] ** 2))               # = m for the unweighted norms of Step 2
                     # start ON the central path of the norm term: multipliers z_i = w/sqrt(m) (the gradient of w||phi|| at equal
                     # phi_i: their stationarity residual vanishes), phi_i = x0/z_i (<= 1), X = x0 S^-1 with tr X = 1 (the cost of t),
@@ -398,8 +471,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     # term; with 2p terms the first Newton steps blow mu up by three orders of magnitude and the iteration diverges.)
                     ph = min(1.0, x0 * np.sqrt(w2) / wr)
                     phi[k, idx] = ph; z[k, idx] = x0 / ph
+                    if soc:
+                        a_ = wr * ph * np.sqrt(w2)                        # |s_1|; s = (t, w c o phi), x = x0 s^-1 with x_0 = 1 (the cost of t)
+                        t0 = 0.5 * (x0 + np.sqrt(x0 * x0 + 4.0 * a_ * a_))
+                        s_ = np.concatenate([[t0], wr * cw[idx] * phi[k, idx]])
+                        arrows.append(dict(k=k, idx=idx, t=t0, soc=True, x=x0 * _soc_inv(s_)))
+                        N = N + 1
+                        continue
                     t0 = _arrow_start(wr * ph * np.sqrt(w2), m, x0)
-                    arrows.append(dict(k=k, idx=idx, t=t0, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
+                    arrows.append(dict(k=k, idx=idx, t=t0, soc=False, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
     phase = 0
@@ -419,8 +499,12 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         Rd2 = (tau * I - M) - S2
         rd0 = (alpha - ALPHA_MIN) - s0
         for a in arrows:
-            a['S'] = _arrow(a['t'], cw[a['idx']] * phi[a['k'], a['idx']], wr)
-        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0) + sum(np.sum(a['X'] * a['S']) for a in arrows)) / N
+            if a['soc']:
+                a['s'] = np.concatenate([[a['t']], wr * cw[a['idx']] * phi[a['k'], a['idx']]])
+            else:
+                a['S'] = _arrow(a['t'], cw[a['idx']] * phi[a['k'], a['idx']], wr)
+        mu = (np.sum(X1 * S1) + np.sum(X2 * S2) + x0 * s0 + (np.sum(phi * z) if ng else 0.0)
+              + sum((a['x'] @ a['s']) if a['soc'] else np.sum(a['X'] * a['S']) for a in arrows)) / N
         Y = X1 - X2
         r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
         r_alpha = -np.sum(Hb * Y) - x0
@@ -429,6 +513,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         if ng:
             r_phi = -np.einsum('kiab,kab->ki', GG, Y) - z
             for a in arrows:                                   # the arrow LMI holds 2 w phi_i off the diagonal; its own variable t has cost 1
+                if a['soc']:
+                    r_phi[a['k'], a['idx']] -= wr * cw[a['idx']] * a['x'][1:]
+                    r_phi2 += (1.0 - a['x'][0]) ** 2
+                    continue
                 r_phi[a['k'], a['idx']] -= 2.0 * wr * cw[a['idx']] * a['X'][0, 1:]
                 r_phi2 += (1.0 - np.trace(a['X'])) ** 2
             r_phi2 += np.sum((r_phi * mask) ** 2)
@@ -505,6 +593,17 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                   Bfull[1, sl] = c_alpha[k]; Bfull[sl, 1] = c_alpha[k]
               for e, a in enumerate(arrows):
                   te = 2 + p * ng + e
+                  if a['soc']:
+                      cols = 2 + a['k'] * ng + a['idx']
+                      a['beta'], a['v'] = _soc_scaling(a['s'], a['x'])
+                      a['lam'] = _soc_W(a['beta'], a['v'], a['x'])
+                      W2 = _soc_W2inv(a['beta'], a['v'])
+                      a['W2'] = W2
+                      wc_ = wr * cw[a['idx']]
+                      Bfull[te, te] = W2[0, 0]
+                      Bfull[cols, te] = wc_ * W2[0, 1:]; Bfull[te, cols] = wc_ * W2[0, 1:]
+                      Bfull[np.ix_(cols, cols)] += np.outer(wc_, wc_) * W2[1:, 1:]
+                      continue
                   a['Si'] = np.linalg.inv(a['S'])
                   Pe = symmetrize(a['X'] @ a['Si'])
                   Bfull[te, te] = np.trace(Pe)
@@ -536,6 +635,11 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 rph = np.einsum('kiab,kab->ki', GG, T1 - T2) + tphi
                 rt = np.zeros(len(arrows))
                 for e, a in enumerate(arrows):
+                    if a['soc']:
+                        a['g'] = sig_mu * _soc_inv(a['s']) - a['x'] - (corre[e] if corre is not None else 0.0)     # dx = g - W^-2 ds
+                        rph[a['k'], a['idx']] += wr * cw[a['idx']] * (a['g'][1:] + a['x'][1:])
+                        rt[e] = (a['g'][0] + a['x'][0]) - 1.0
+                        continue
                     a['T'] = sig_mu * a['Si'] - (corre[e] if corre is not None else 0.0)
                     rph[a['k'], a['idx']] += 2.0 * wr * cw[a['idx']] * a['T'][0, 1:]
                     rt[e] = np.trace(a['T']) - 1.0
@@ -551,6 +655,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
                 for e, a in enumerate(arrows):
                     a['dt'] = db[2 + p * ng + e]
+                    if a['soc']:
+                        a['ds'] = np.concatenate([[a['dt']], wr * cw[a['idx']] * dphi[a['k'], a['idx']]])
+                        a['dx'] = a['g'] - a['W2'] @ a['ds']
+                        continue
                     a['dS'] = _arrow(a['dt'], cw[a['idx']] * dphi[a['k'], a['idx']], wr)
                     a['dX'] = sig_mu * a['Si'] - a['X'] - symmetrize(a['X'] @ a['dS'] @ a['Si']) - (corre[e] if corre is not None else 0.0)
             dS1 = dM + Rd1
@@ -576,6 +684,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 if (dz < 0).any(): ap = min(ap, (-z[dz < 0] / dz[dz < 0]).min())
                 if (dphi < 0).any(): ad = min(ad, (-phi[dphi < 0] / dphi[dphi < 0]).min())
             for a in arrows:
+                if a['soc']:
+                    ap = min(ap, _soc_max_step(a['x'], a['dx'])); ad = min(ad, _soc_max_step(a['s'], a['ds']))
+                    continue
                 ap = min(ap, _max_step(np.linalg.inv(np.linalg.cholesky(a['X']))[None], a['dX'][None]))
                 ad = min(ad, _max_step(np.linalg.inv(np.linalg.cholesky(a['S']))[None], a['dS'][None]))
             return ap, ad
@@ -586,7 +697,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             ap = min(1.0, ap); ad = min(1.0, ad)
             mu_aff = (np.sum((X1 + ap * dX1) * (S1 + ad * dS1)) + np.sum((X2 + ap * dX2) * (S2 + ad * dS2))
                       + (x0 + ap * dx0) * (s0 + ad * ds0) + (np.sum((z + ap * dz) * (phi + ad * dphi)) if ng else 0.0)
-                      + sum(np.sum((a['X'] + ap * a['dX']) * (a['S'] + ad * a['dS'])) for a in arrows)) / N
+                      + sum(((a['x'] + ap * a['dx']) @ (a['s'] + ad * a['ds'])) if a['soc'] else np.sum((a['X'] + ap * a['dX']) * (a['S'] + ad * a['dS']))
+                            for a in arrows)) / N
             sigma = min(max((mu_aff / mu) ** 2, 1e-6), 1.0)     # exponent 2: ~10 % fewer iterations than Mehrotra's 3 on this SDP family
             sig_mu = sigma * mu
             if mu_t is not None:
@@ -594,7 +706,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             corr1 = symmetrize(dX1 @ dS1 @ S1i); corr2 = symmetrize(dX2 @ dS2 @ S2i)
             corr0 = dx0 * ds0 / s0
             corrp = dz * dphi / phi if ng else None
-            corre = [symmetrize(a['dX'] @ a['dS'] @ a['Si']) for a in arrows]
+            corre = [_soc_W(a['beta'], a['v'], _soc_div(a['lam'], _soc_prod(_soc_W(a['beta'], a['v'], a['dx']), _soc_W(a['beta'], a['v'], a['ds'], inverse=True))), inverse=True)
+                     if a['soc'] else symmetrize(a['dX'] @ a['dS'] @ a['Si']) for a in arrows]
             dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(sig_mu, corr1, corr2, corr0, corrp, corre)
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             mn = min(ap, ad)
@@ -621,6 +734,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         if ng:
             z = z + ap * dz; phi = phi + ad * dphi
         for a in arrows:
+            if a['soc']:
+                a['x'] = a['x'] + ap * a['dx']; a['t'] += ad * a['dt']
+                continue
             a['X'] = symmetrize(a['X'] + ap * a['dX']); a['t'] += ad * a['dt']
         if phase == 1:
             # pure Newton centering on the central path at mu_t; stop on a tiny step, on stagnation

@@ -428,7 +428,7 @@ def test_step_logic_for_a_batch(golden_dir):
 
 def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
     """convexify(..., C=...) on the dense model's vector (B = 0, R < 0): Step 1 infeasible -> Step 2 -> EQUIVALENCE TYPE B;
-    without C the reference's ValueError; force asks for Step 3, which this build does not have."""
+    without C the reference's ValueError."""
     from tunempc_amd import convexifier
     g = np.load(os.path.join(golden_dir, 'n1_step2_active_constraints.npz'))
     p = g['A'].shape[0]
@@ -436,8 +436,8 @@ def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
     args = (lst(g['A']), lst(g['B']), lst(g['Q']), lst(g['R']), lst(g['N']))
     with pytest.raises(ValueError, match='Convexification is not possible'):
         convexifier.convexify(*args)
-    with pytest.raises(NotImplementedError):
-        convexifier.convexify(*args, opts={'rho': 1e-3, 'force': True})
+    forced = convexifier.convexify(*args, opts={'rho': 1e-3, 'force': True})          # no constraints given: Step 3 on the plain model
+    assert all(np.linalg.eigvalsh(co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) + forced[0][k]).min() > 0 for k in range(p))
     dHc, dQc, dRc, dNc = convexifier.convexify(*args, C=lst(g['Cu']), opts={'rho': float(g['rho'])})
     ref = co.convexify(*args, C=lst(g['Cu']), opts={'rho': float(g['rho'])})
     H = np.stack([co.build_hessian(g['Q'][k], g['R'][k], g['N'][k]) for k in range(p)])
@@ -488,6 +488,56 @@ def test_dropin_tuner_convexify_list_inputs():
     Hc = tuner_convexify(S, nx=4, p=30)
     r = co.convexify_arrays(A[0], B[0], H[0])
     assert len(Hc) == 30 and rel(np.stack(Hc), r['Hc']) < PARITY
+
+
+# ----------------------------------------------------------------------------- Step 3: forced regularisation T (plain model + T)
+@pytest.mark.parametrize('seed,nb,p,nx,mb,rho', [(0, 2, 2, 2, 1, 1e-3), (1, 2, 3, 3, 2, 1e-2), (2, 2, 1, 3, 1, 1e-3), (6, 1, 4, 4, 3, 1.0), (4, 1, 2, 9, 6, 1e-3),
+                                                 (5, 1, 5, 2, 2, 1e-1)])
+def test_step3_parity_vs_oracle(hc, seed, nb, p, nx, mb, rho):
+    """The Step 3 model (convexifier.py:137-147: T_k symmetric, every entry > 0, rho*||T_k||_F in the objective) through the HIP path
+    and the structured oracle (same model, norm term as a second-order cone), solved directly on seeded problems."""
+    A, B, H = co.gen_batch(300 + seed, nb, p, nx, mb)
+    h = hc(p, nx, mb, step3=True)
+    out = h.convexify_step3_batch(A, B, H, rho)
+    convex = [min(np.linalg.eigvalsh(co.symmetrize(H[b, k])).min() for k in range(p)) > 0 for b in range(nb)]
+    assert [bool(v != 0.0) for v in out['info'][:, 13]] == convex and not all(convex)     # members convex already are returned untouched
+    for b in range(nb):
+        if convex[b]:
+            assert rel(out['Hc'][b], H[b]) < 1e-15
+            continue
+        r = co.sdp_step1(A[b], B[b], H[b], rho=rho, force=True)
+        st, dHc = co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], T=r['T'])[:2]
+        assert int(out['status'][b]) == st == 0
+        assert rel(out['Hc'][b], H[b] + dHc) < PARITY
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        assert rel(out['T'][b], r['T']) < 1e-6 and (out['T'][b] > 0).all()
+        # structure of the supplement: Hc - H = sym(calH(P)) + T exactly
+        ref = co.convex_hessian_suppl(A[b], B[b], out['P'][b], T=out['T'][b])[0]
+        assert rel(out['Hc'][b] - H[b], ref) < 1e-12
+
+
+def test_step3_rescues_the_infeasible_vector(golden_dir):
+    """The dense model's vector (B = 0, R < 0, no constraints): Steps 1 and 2 cannot help, force -> Step 3 (convexifier.py:137-147).
+    The drop-in logs the reference's warnings, takes Step 3 on the GPU and returns a positive definite result; its optimal value
+    agrees with the dense restatement's (the minimiser is not unique in T beyond the objective)."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(golden_dir, 'n1_step3_force.npz'))
+    A, B, Q, R, N = ([m for m in g[k]] for k in ('A', 'B', 'Q', 'R', 'N'))
+    with pytest.raises(ValueError):
+        convexifier.convexify(A, B, Q, R, N, opts={'rho': float(g['rho']), 'solver': 'hip', 'force': False})
+    dHc, dQc, dRc, dNc = convexifier.convexify(A, B, Q, R, N, opts={'rho': float(g['rho']), 'solver': 'hip', 'force': True})
+    H = [co.build_hessian(q, r, n_) for q, r, n_ in zip(Q, R, N)]
+    for k in range(len(A)):
+        assert np.linalg.eigvalsh(H[k] + dHc[k]).min() > 0
+    out = convexifier.convexify_step3_batch(np.stack(A)[None], np.stack(B)[None], np.stack(H)[None], float(g['rho']))
+    assert int(out['status'][0]) == 0 and abs(out['kappa'][0] - float(g['kappa'])) < 1e-5 * float(g['kappa'])
+
+
+def test_step3_handle_serves_the_plain_model(hc):
+    A, B, H = co.gen_batch(5, 2, 4, 3, 2)
+    o1 = hc(4, 3, 2).convexify_batch(A, B, H)
+    o2 = hc(4, 3, 2, step3=True).convexify_batch(A, B, H)
+    assert np.array_equal(o1['Hc'], o2['Hc'])
 
 
 # ----------------------------------------------------------------------------- full-size properties (no oracle)

@@ -3,7 +3,7 @@ hidden feasible point (P_hat, which no real warm start knows) with perfectly cen
 parameters, and count iterations against the cold start."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import convexify_oracle as co
 for (p, nx, mb) in [(8, 12, 4), (16, 6, 2), (4, 24, 8)]:

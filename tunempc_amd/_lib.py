@@ -19,7 +19,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
-    'tmpc_convexify_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
+    'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host',
     'tmpc_last_error', 'tmpc_version',
 ]
@@ -63,6 +63,12 @@ def load_library():
     lib.tmpc_create_con.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_convexify_step2_batch_host.restype = C.c_int
     lib.tmpc_convexify_step2_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, C.c_double, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
+    lib.tmpc_workspace_bytes_step3.restype = C.c_uint64
+    lib.tmpc_workspace_bytes_step3.argtypes = [C.c_int] * 4
+    lib.tmpc_create_step3.restype = C.c_int
+    lib.tmpc_create_step3.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_convexify_step3_batch_host.restype = C.c_int
+    lib.tmpc_convexify_step3_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
     lib.tmpc_debug_get_multipliers.restype = C.c_int
     lib.tmpc_debug_get_multipliers.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     lib.tmpc_debug_get_array.restype = C.c_int
@@ -129,7 +135,7 @@ def _check(lib, rc, what):
 class HipConvexifier:
     """Handle for batched convexification of problems of one shape (p, nx, mb) on the current HIP device."""
 
-    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0, nc=0):
+    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0, nc=0, step3=False):
         self.lib = load_library()
         if self.lib.tmpc_device_count() < 1:
             raise RuntimeError("tunempc_amd: no HIP device visible; the convexify hot path has no CPU fallback")
@@ -137,7 +143,13 @@ class HipConvexifier:
         self._h = C.c_void_p()
         self.ng = int(ng)     # rows of the equality-constraint Jacobian per stage (convexifier.py:249-255), 0: none
         self.nc = int(nc)     # room for active-constraint rows per stage (Step 2, convexifier.py:258-266), 0: none
-        _check(self.lib, self.lib.tmpc_create_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_con')
+        self.step3 = bool(step3)      # room for the regularisation T_k of Step 3 (convexifier.py:137-147); such a handle also serves the plain model
+        if self.step3:
+            if self.ng or self.nc:
+                raise NotImplementedError('Step 3 on the GPU covers the plain model (no G / C rows in the same solve)')
+            _check(self.lib, self.lib.tmpc_create_step3(C.byref(self._h), int(chunk), self.p, self.nx, self.mb), 'tmpc_create_step3')
+        else:
+            _check(self.lib, self.lib.tmpc_create_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_con')
         self.chunk = int(self.lib.tmpc_get_chunk(self._h))
         self.flags = int(flags)
         self.set_options(tol, center_tol, max_iter, center_iter, flags)
@@ -232,6 +244,23 @@ class HipConvexifier:
                                                       _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
                                                       _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
         _check(self.lib, rc, 'tmpc_convexify_step2_batch_host')
+        return out
+
+    def convexify_step3_batch(self, A, B, H, rho):
+        """The Step 3 model (convexifier.py:137-147), plain model + T: outputs of convexify_batch + T [nb,p,n,n] (every entry > 0)."""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        nb = A.shape[0]
+        assert self.step3, 'handle created without step3=True'
+        assert A.shape == (nb, self.p, self.nx, self.nx) and B.shape == (nb, self.p, self.nx, self.mb) and H.shape == (nb, self.p, self.n, self.n)
+        out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), T=np.empty_like(H), alpha=np.empty(nb), beta=np.empty(nb),
+                   kappa=np.empty(nb), status=np.empty(nb, np.int32), iters=np.empty(nb, np.int32), info=np.empty((nb, INFO_STRIDE)))
+        if nb == 0:
+            return out
+        rc = self.lib.tmpc_convexify_step3_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), float(rho), _dptr(out['Hc']), _dptr(out['dHc']),
+                                                      _dptr(out['P']), _dptr(out['T']), _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
+                                                      _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
+        _check(self.lib, rc, 'tmpc_convexify_step3_batch_host')
         return out
 
     # ------------------------------------------------------------------ device-resident entry (torch tensors)

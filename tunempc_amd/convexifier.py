@@ -29,12 +29,12 @@ NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (t
 NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
-def _handle(p, nx, mb, ng=0, nc=0, nb=1):
+def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):
     """One cached handle per problem shape.  Its workspace is sized for the batch actually asked for (next power of two of nb,
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
     pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
     of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk."""
-    key = (p, nx, mb, ng)       # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
+    key = (p, nx, mb, ng, bool(step3))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
     want = 1
     while want < min(max(int(nb), 1), _MAX_CHUNK):
         want *= 2
@@ -46,7 +46,7 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1):
     if h is None:
         while len(_HANDLES) >= _MAX_HANDLES:
             _HANDLES.pop(next(iter(_HANDLES))).close()
-        h = HipConvexifier(p, nx, mb, chunk=want, ng=ng, nc=nc)
+        h = HipConvexifier(p, nx, mb, chunk=want, ng=ng, nc=nc, step3=step3)
     _HANDLES[key] = h           # most recently used last
     return h
 
@@ -121,6 +121,17 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     if ng:
         out['Fg'] = FgF[:, :, :ng]
     return out
+
+
+def convexify_step3_batch(A, B, H, rho, tol=None, handle=None):
+    """Batched Step 3 model (convexifier.py:137-147, setUpModelPicos with force=True) for the plain model: A, B, H as in convexify_batch.
+    Returns the dict of convexify_batch plus 'T' [nb,p,n,n] (every entry > 0); dHc includes T (convexifier.py:202-203)."""
+    A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
+    nb, p, nx, _ = A.shape
+    h = handle or _handle(p, nx, B.shape[3], 0, 0, nb, step3=True)
+    if handle is None or tol is not None:
+        h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
+    return h.convexify_step3_batch(A, B, H, rho)
 
 
 def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None):
@@ -270,7 +281,13 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         if (opts or {}).get('force', False):                                  # convexifier.py:137-147
             Logger.logger.info('Step 3: (η_F = 1), (η_T = 1)')
             Logger.logger.info('Enforcing convexification...')
-            raise NotImplementedError('Step 3 of the convexifier (forced regularisation T, convexifier.py:137-147) is not built yet')
+            if Gs is not None or 'C' in arg:
+                raise NotImplementedError('Step 3 on the GPU covers the plain model so far: the regularisation T together with the '
+                                          'multipliers of G / C in one solve (convexifier.py:144) is not built yet')
+            Logger.logger.info('solving SDP...')
+            res = convexify_step3_batch(As[None], Bs[None], Hs[None], (opts or {}).get('rho', 1e-3))
+            status = _log_solution(res)
+            Logger.logger.warning(50 * '*')
         else:
             Logger.logger.warning('Consider operating the system at another orbit of different period p')
             Logger.logger.warning('Convexification and stabilization of the MPC scheme can be enforced by enabling "force"-flag.')

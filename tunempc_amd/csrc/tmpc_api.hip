@@ -18,6 +18,7 @@
 #include "tmpc_factor.h"
 #include "tmpc_cr.h"
 #include "tmpc_phi.h"
+#include "tmpc_t3.h"
 
 using namespace tmpc;
 
@@ -95,13 +96,14 @@ static CrDev cr_dev(const CrSched& sc, const int* d_sched, const int* alist) {
 // ---------------------------------------------------------------------------------- sizes
 static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
 
-static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0) {
+static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0, int step3 = 0) {
   Dims d;
   d.ng = ng; d.nr = ng + nc; d.constr = 0;
+  d.nT = step3 ? (nx + mb) * (nx + mb + 1) / 2 : 0;
   d.nz = d.nr + (nc > 0 ? 2 : 0);          // room for the two epigraph variables of Step 2
   d.B = chunk; d.p = p; d.nx = nx; d.mb = mb; d.n = nx + mb;
   d.d = nx * (nx + 1) / 2;
-  d.dp = (d.d + d.nz + 15) / 16 * 16;      // room for the stage-local multipliers inside the blocks (run_chunk narrows it when unused)
+  d.dp = (d.d + d.nz + (d.nT ? d.nT + 1 : 0) + 15) / 16 * 16;      // room for the stage-local variables inside the blocks (run_chunk narrows it when unused)
   d.nt = (d.dp + TB - 1) / TB;
   d.flags = 0;
   return d;
@@ -160,6 +162,16 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
       w.aX = c.take<double>(BP * 2 * AE); w.adX = c.take<double>(BP * 2 * AE); w.acor = c.take<double>(BP * 2 * AE);
       w.aSi = c.take<double>(BP * 2 * AE); w.aLi = c.take<double>(BP * 2 * AE); w.aLXi = c.take<double>(BP * 2 * AE);
     }
+  }
+  w.t3th = w.t3z = w.t3dth = w.t3dz = w.t3cth = w.t3x = w.t3dx = w.t3cq = w.t3g = w.t3v = w.t3lam = nullptr;
+  w.t3t = w.t3dt = w.t3beta = w.t3psi = w.t3phi = w.Tout = nullptr;
+  if (dm.nT > 0) {
+    const size_t m = dm.nT, m1 = m + 1;
+    w.t3th = c.take<double>(BP * m); w.t3z = c.take<double>(BP * m); w.t3dth = c.take<double>(BP * m); w.t3dz = c.take<double>(BP * m); w.t3cth = c.take<double>(BP * m);
+    w.t3x = c.take<double>(BP * m1); w.t3dx = c.take<double>(BP * m1); w.t3cq = c.take<double>(BP * m1); w.t3g = c.take<double>(BP * m1);
+    w.t3v = c.take<double>(BP * m1); w.t3lam = c.take<double>(BP * m1);
+    w.t3t = c.take<double>(BP); w.t3dt = c.take<double>(BP); w.t3beta = c.take<double>(BP);
+    w.t3psi = c.take<double>(BP * nn); w.t3phi = c.take<double>(BP * nn); w.Tout = c.take<double>(BP * nn);
   }
   if (h) {
     h->dA = c.take<double>(BP * nxx); h->dB = c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); h->dH = c.take<double>(BP * nn);
@@ -369,6 +381,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   if (device >= 0 && device < 64) done[device] = true;
   return TMPC_OK;
 }
@@ -440,18 +453,22 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
 
 // one chunk (nb = actual number of problems in this chunk, <= capacity); inputs already on device
 static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
-                     const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0) {
+                     const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0, bool step3 = false) {
   Dims dm = h->dm;
   dm.B = nb;
+  if (!step3) dm.nT = 0;                  // a handle with room for T also serves the other models
   // a handle created with room for G / C rows also serves calls without them; Step 2 (constr) when the C counts are given
   if (!dG) { dm.ng = 0; dm.nr = 0; dm.nz = 0; }
   dm.constr = (dG && dncnt) ? 1 : 0;
   if (dG && !dncnt) { dm.nr = dm.ng; dm.nz = dm.ng; }
   // stage-local multipliers ride inside the blocks (block size d + nz)
   const bool eq = dm.nr > 0;
-  dm.dp = (dm.d + (eq ? dm.nz : 0) + 15) / 16 * 16;
+  const bool t3 = dm.nT > 0;
+  dm.dp = (dm.d + (eq ? dm.nz : 0) + (t3 ? dm.nT + 1 : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
   dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
+  const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
+  const size_t t3_schur_lds = (size_t)(10 * 32 * T3_LD + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
   WS wall = ln->ws;                      // view over ALL problems of the chunk (init / final kernels)
   wall.A = dA; wall.Bm = dB; wall.H = dH; wall.G = dG; wall.ncnt = dncnt; wall.rho = rho;
   wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
@@ -460,7 +477,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   int* flist = wall.flist;
   wall.alist = nullptr;
   Opts o = h->opt;
-  if (eq) o.chord_step = 0.0;             // chord steps: plain model only (the stage-local multipliers keep fresh factorisations)
+  if (eq || t3) o.chord_step = 0.0;       // chord steps: plain model only (the stage-local variables keep fresh factorisations)
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
@@ -473,6 +490,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   }
   hipLaunchKernelGGL(k_init_state, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BPall), dim3(64), 0, st, wall, dm);
+  if (t3) hipLaunchKernelGGL(k_t3_init, dim3(BPall), dim3(64), 0, st, wall, dm);
   int cnt[2] = {0, 0};                    // problems still iterating / of which need a factorisation
   HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -484,25 +502,41 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
     hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
+    if (t3) hipLaunchKernelGGL(k_t3_pre, dim3(BP), dim3(64), t3_lds, st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
-    hipLaunchKernelGGL(k_schur, dim3(BP), dim3(256), schur_lds(dm), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_aug_fill, dim3(BP), dim3(64), 0, st, w, dm);
+    // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
+    if (nfac > 0) hipLaunchKernelGGL(k_schur, dim3(nfac * dm.p), dim3(256), schur_lds(dm), st, wf, dm);
+    if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
+    if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
+    if (h->flags & 8) {                     // debug (tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
+      hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, 1);
+      hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
+      if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipGetLastError());
+      return TMPC_OK;
+    }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
-    cr_factor(w, dm, h->sched, h->d_sched, alist, active, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev);
+    if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
+      if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass);
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
+      if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
+      if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (pass == 1) {
         hipLaunchKernelGGL(k_ctrl_b, dim3(active), dim3(64), 0, st, w, dm);
         if (prof) HIPCHK(hipEventRecord(ln->ev[4], st));
@@ -512,6 +546,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
+    if (t3) hipLaunchKernelGGL(k_t3_update, dim3(BP), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[5], st));
@@ -558,12 +593,14 @@ static bool rows_ok(int nx, int ng, int nc) {
   (void)nx;
   return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM;
 }
-uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) {
+static uint64_t workspace_bytes(int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
   if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
   WS w;
-  Dims dm = make_dims(chunk, p, nx, mb, ng, nc);
+  Dims dm = make_dims(chunk, p, nx, mb, ng, nc, step3);
   return (uint64_t)carve(w, dm, nullptr, nullptr);
 }
+uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) { return workspace_bytes(chunk, p, nx, mb, ng, nc, 0); }
+uint64_t tmpc_workspace_bytes_step3(int chunk, int p, int nx, int mb) { return workspace_bytes(chunk, p, nx, mb, 0, 0, 1); }
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng) { return tmpc_workspace_bytes_con(chunk, p, nx, mb, ng, 0); }
 uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) { return tmpc_workspace_bytes_eq(chunk, p, nx, mb, 0); }
 
@@ -571,7 +608,11 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) { return tm
 
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) { return tmpc_create_con(out, chunk, p, nx, mb, ng, 0); }
 
-int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) {
+static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3);
+int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) { return create_handle(out, chunk, p, nx, mb, ng, nc, 0); }
+int tmpc_create_step3(tmpc_handle** out, int chunk, int p, int nx, int mb) { return create_handle(out, chunk, p, nx, mb, 0, 0, 1); }
+
+static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
   if (!out) return TMPC_E_ARG;
   *out = nullptr;
   if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
@@ -584,7 +625,7 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   if (chunk <= 0) {
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    const uint64_t per = tmpc_workspace_bytes_con(1, p, nx, mb, ng, nc);
+    const uint64_t per = workspace_bytes(1, p, nx, mb, ng, nc, step3);
     uint64_t fit = (uint64_t)(0.6 * (double)fr) / std::max<uint64_t>(per, 1);
     chunk = (int)std::max<uint64_t>(1, std::min<uint64_t>(512, fit));
   }
@@ -601,7 +642,7 @@ int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng,
   h->nlanes = nl;
   const int cap = (chunk + nl - 1) / nl;
   h->chunk = cap * nl;
-  h->dm = make_dims(cap, p, nx, mb, ng, nc);
+  h->dm = make_dims(cap, p, nx, mb, ng, nc, step3);
   h->sched = cr_build(p);
   { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
   { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
@@ -735,6 +776,8 @@ int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t co
     case 4: src = ws.part; break;
     case 5: src = ws.O; break;
     case 6: src = ws.F; break;
+    case 7: src = ws.W3; break;
+    case 8: src = ws.U; break;
     default: return TMPC_E_ARG;
   }
   if (!src) return TMPC_E_ARG;
@@ -761,6 +804,8 @@ struct Call {
   double *Hc, *dHc, *P, *FgF, *alpha, *beta, *kappa; int32_t *status, *iters; double* info;
   bool host;           // host pointers (staged through the lane's buffers) or device pointers
   int jr;              // row stride of J / FgF in this call (0: no constraint rows)
+  bool step3 = false;  // Step 3 model (plain + T)
+  double* T = nullptr; // [nbt][p][n][n] output of Step 3
 };
 
 static int lane_run(tmpc_handle* h, Lane* ln, const Call& c, int off, int nb) {
@@ -778,7 +823,7 @@ static int lane_run(tmpc_handle* h, Lane* ln, const Call& c, int off, int nb) {
     if (dJ) { HIPCHK(hipMemcpyAsync(ln->dG, dJ, BP * gn * sizeof(double), hipMemcpyHostToDevice, st)); dJ = ln->dG; }
     if (dn) { HIPCHK(hipMemcpyAsync(ln->dncnt, dn, BP * sizeof(int32_t), hipMemcpyHostToDevice, st)); dn = ln->dncnt; }
   }
-  int rc = run_chunk(h, ln, nb, dA, dB, dH, st, dJ, dn, c.rho);
+  int rc = run_chunk(h, ln, nb, dA, dB, dH, st, dJ, dn, c.rho, c.step3);
   if (rc != TMPC_OK) return rc;
   ln->last_nb = nb;
   const hipMemcpyKind kind = c.host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -789,6 +834,7 @@ static int lane_run(tmpc_handle* h, Lane* ln, const Call& c, int off, int nb) {
   if (c.dHc) HIPCHK(hipMemcpyAsync(c.dHc + so * nn, ln->ws.dHc, BP * nn * sizeof(double), kind, st));
   if (c.P) HIPCHK(hipMemcpyAsync(c.P + so * nxx, ln->ws.Pout, BP * nxx * sizeof(double), kind, st));
   if (c.FgF && c.jr > 0) HIPCHK(hipMemcpyAsync(c.FgF + so * c.jr, ln->ws.Fg, BP * c.jr * sizeof(double), kind, st));
+  if (c.T && c.step3) HIPCHK(hipMemcpyAsync(c.T + so * nn, ln->ws.Tout, BP * nn * sizeof(double), kind, st));
   if (c.alpha) HIPCHK(hipMemcpyAsync(c.alpha + off, ln->d_abk, nb * sizeof(double), kind, st));
   if (c.beta) HIPCHK(hipMemcpyAsync(c.beta + off, ln->d_abk + nb, nb * sizeof(double), kind, st));
   if (c.kappa) HIPCHK(hipMemcpyAsync(c.kappa + off, ln->d_abk + 2 * nb, nb * sizeof(double), kind, st));
@@ -891,6 +937,18 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, co
     if (ncnt[i] < 0 || ncnt[i] > ncmax) { snprintf(g_err, sizeof(g_err), "ncnt[%zu]=%d outside 0..%d", i, ncnt[i], ncmax); return TMPC_E_ARG; }
   ON_DEVICE(h);
   Call c{nbt, A, B, H, J, ncnt, rho, Hc, dHc, P, FgF, alpha, beta, kappa, status, iters, info, true, dm.nr};
+  return dispatch(h, c, nullptr, false);
+}
+
+int tmpc_convexify_step3_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, double rho,
+                                    double* Hc, double* dHc, double* P, double* T, double* alpha, double* beta, double* kappa,
+                                    int32_t* status, int32_t* iters, double* info) {
+  if (h && nbt == 0) return TMPC_OK;
+  if (!h || nbt < 1 || !A || !H || !(rho > 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  if (h->dm.nT < 1) { snprintf(g_err, sizeof(g_err), "handle was created without room for Step 3 (use tmpc_create_step3)"); return TMPC_E_ARG; }
+  ON_DEVICE(h);
+  Call c{nbt, A, B, H, nullptr, nullptr, rho, Hc, dHc, P, nullptr, alpha, beta, kappa, status, iters, info, true, 0};
+  c.step3 = true; c.T = T;
   return dispatch(h, c, nullptr, false);
 }
 

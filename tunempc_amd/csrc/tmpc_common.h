@@ -68,6 +68,7 @@ struct Dims {
   int nr;       // row stride of the stage-local multipliers: ng + (max rows of the active-constraint Jacobians C_k, Step 2), <= NRM
   int nz;       // stride of the stage-local variable vector: nr (+ 2 epigraph variables of the norm terms in Step 2)
   int constr;   // 1: Step 2 model (convexifier.py:116-131): multipliers of C_k and the rho-norm terms
+  int nT;       // Step 3 (convexifier.py:137-147): n(n+1)/2 entries of the regularisation T_k per stage (0: none); + 1 epigraph variable (tmpc_t3.h)
 };
 constexpr int NGM = 16;  // max ng
 constexpr int NCM = 16;  // max rows of C_k
@@ -141,6 +142,12 @@ struct WS {
   double* aX; double* adX; double* acor; // [B,p,2,AE] primal blocks, directions, Mehrotra term
   double* aSi; double* aLi; double* aLXi; // [B,p,2,AE] S^-1, L_S^-1, L_X^-1
   double* asum;    // [B,p,5]   <dX,S>, <X,dS>, <dX,dS>, min eig dual, min eig primal of the arrow blocks (joined in k_phi_steps)
+  // Step 3 (tmpc_t3.h): entries theta of T_k (linear cone, dual z) and the norm cone (t; w c o theta) with multiplier x
+  double* t3th; double* t3z; double* t3dth; double* t3dz; double* t3cth;          // [B,p,nT]
+  double* t3x; double* t3dx; double* t3cq; double* t3g; double* t3v; double* t3lam;   // [B,p,nT+1]
+  double* t3t; double* t3dt; double* t3beta;                                      // [B,p]
+  double* t3psi; double* t3phi;   // [B,p,n,n] full Psi = sym(X2 S2^-1) and Phi(Hb) of the stage (border entries of the theta rows)
+  double* Tout;    // [B,p,n,n] output T_k
 };
 
 // (problem, stage) of this workgroup for kernels with one workgroup per stage: blockIdx.x = (index in the active list) * p + k

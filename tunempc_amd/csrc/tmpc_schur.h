@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   }
   rp2 = wave_sum(rp2);
   double ncone = 0.0;
-  if (dm.nr > 0) { rp2 += psum(w.part, b, p, Q_RPHI2, lane); ncone = psum(w.part, b, p, Q_NCONE, lane); }   // stage-local multipliers: stationarity residual, cone dimension
+  if (dm.nr > 0 || dm.nT > 0) { rp2 += psum(w.part, b, p, Q_RPHI2, lane); ncone = psum(w.part, b, p, Q_NCONE, lane); }   // stage-local multipliers: stationarity residual, cone dimension
   if (lane != 0) return;
   const double N = 2.0 * p * dm.n + 1.0 + ncone;     // cone dimension
   const double tau = pr[P_TAU], alpha = pr[P_ALPHA], s0 = pr[P_S0], x0 = pr[P_X0];
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
   const double minx = emin(w.eigmin, b, p, 1, lane), mins = emin(w.eigmin, b, p, 0, lane);
   const double dxs = psum(w.part, b, p, Q_DXS, lane), xds = psum(w.part, b, p, Q_XDS, lane);
   const double dxds = psum(w.part, b, p, Q_DXDS, lane);
-  const double ncone = (dm.nr > 0) ? psum(w.part, b, p, Q_NCONE, lane) : 0.0;
+  const double ncone = (dm.nr > 0 || dm.nT > 0) ? psum(w.part, b, p, Q_NCONE, lane) : 0.0;
   if (lane != 0) return;
   const double N = 2.0 * p * dm.n + 1.0 + ncone;     // cone dimension
   const double s0 = pr[P_S0], x0 = pr[P_X0], mu = pr[P_MU];
@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
   pr[P_AP] = ap; pr[P_AD] = ad;
   if (w.trace && ip[I_ITERS] >= 1 && ip[I_ITERS] <= TRACE_LEN) {
     double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
-    t[0] = (double)ip[I_ITERS]; t[1] = (double)phase + 0.25 * ip[I_CHORD];    // x.25: a chord step (factorisation re-used) t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
+    t[0] = (double)ip[I_ITERS]; t[1] = (double)phase + 0.25 * ip[I_CHORD];    // x.25: a chord step (factorisation re-used)
+    t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
     t[6] = ap; t[7] = (phase == PH_CENTER) ? pr[P_RAWSTEP] : ad; t[8] = pr[P_STEPN];     // centering: ap = ad = 1 on full steps; slot 7 holds the raw step length instead t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
   }
   if (!stopped) {        // (0 * NaN would poison the kept iterate)

@@ -156,6 +156,16 @@ __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const dou
   wsync();
 }
 
+// out (n x n LDS slot) += scale * smat(theta): the regularisation T_k of Step 3 (tmpc_t3.h), theta = its entries (a <= b), row-major upper triangle
+__device__ __forceinline__ void add_smat_t3(double* out, const double* th, double scale, int n, int lane) {
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    out[i * LD + j] += scale * th[a * n - a * (a - 1) / 2 + (b - a)];
+  }
+  wsync();
+}
+
 constexpr int PRE_SLOTS = 9;     // 76 KB of LDS: two single-wave blocks per CU
 // ------------------------------------------------------------------ stage_pre
 __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
@@ -176,6 +186,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   TMPC_T(8)
   build_M(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
   if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
+  if (dm.nT > 0) add_smat_t3(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
   TMPC_T(9)
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
   int nbad = 0;
@@ -248,6 +259,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
       mm(t0, sX, LD, 1, sSi, LD, 1, n, n, n, 0, lane);                   // Psi = sym(X2 S2i)
       s_sym(t0, n, lane);
       trpsi = trace_s(t0, n, lane);
+      if (dm.nT > 0) s2g(w.t3psi + (size_t)sid * nn, t0, n, n, n, lane);
       adj_V(t1, t2, sV, t0, n, nx, lane);
       s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t1, nx, nx, nx, lane);
       s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx, lane);
@@ -255,6 +267,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   }
   TMPC_T(15)
   const double hbphi = dot_ss(sHb, sPhi, n, lane);
+  if (dm.nT > 0) s2g(w.t3phi + (size_t)sid * nn, sPhi, n, n, n, lane);
   adj_V(t1, t2, sV, sPhi, n, nx, lane);
   s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
   s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, sPhi, nx, nx, nx, lane);
@@ -330,6 +343,7 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   const double* dPk = w.dP + (size_t)sid * nxx;
   build_M(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
   if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
+  if (dm.nT > 0) add_smat_t3(sM, w.t3dth + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + dT_k
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
@@ -475,6 +489,14 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
     const int nrow = stage_rows(w, dm, sid);
     if (lane < dm.nr) w.Fg[(size_t)sid * dm.nr + lane] = (lane < nrow) ? sc * w.phi[(size_t)sid * dm.nr + lane] : 0.0;
     add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, sc, nrow, n, lane);
+  }
+  if (dm.nT > 0) {                          // T_k = s_T theta / (s_alpha alpha) (convexifier.py:422-423) and its term of the supplement (:202-203)
+    add_smat_t3(sM, w.t3th + (size_t)sid * dm.nT, sc, n, lane);
+    for (int e = lane; e < nn; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const int a = i < j ? i : j, bq = i < j ? j : i;
+      w.Tout[(size_t)sid * nn + e] = sc * w.t3th[(size_t)sid * dm.nT + a * n - a * (a - 1) / 2 + (bq - a)];
+    }
   }
   s_sym(sM, n, lane);
   double* dHg = w.dHc + (size_t)sid * nn;
