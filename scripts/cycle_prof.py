@@ -22,8 +22,21 @@ for (nb, p) in ((512, 64), (64, 64)):
     ms = h.debug_factor_bench(nb, p, 300, reps=1)
     lib.tmpc_debug_cycle_prof(out.ctypes.data_as(C.POINTER(C.c_double)))
     print(f"nb {nb} p {p} d 300: factor {ms[0]:.2f} ms, solve {ms[1]:.2f} ms (profiled build)")
+    v = out[32:35]; tot = v.sum()
+    print(f"  k_cr_potrf block column (wave 0 of block 0): {tot:.3e} cycles")
+    for n_, x in zip(['left-looking GEMM update', '64 x 64 tile Cholesky + inverse', 'panel multiply by the tile inverse'], v):
+        print(f"      {n_:42s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")
+    v = out[40:45]; tot = v.sum()
+    print(f"  inside the tile Cholesky: {tot:.3e} cycles")
+    for n_, x in zip(['load tile into LDS', 'wave_potrf16 (16 x 16 Cholesky + inverse, one wave)', 'panel + trailing update (MFMA 16x16x4)', 'inverse assembly', 'store tile + inverse'], v):
+        print(f"      {n_:52s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")
     for cls, cn in ((1, 'k_cr_potrf'), (2, 'k_cr_trsm'), (3, 'k_cr_update')):
         v = out[cls * 8: cls * 8 + 6]; tot = v.sum()
+        if cls == 2 and os.environ.get('TMPC_TRSM_RR', '1') != '0':
+            print(f"  k_cr_trsm_rr: wave 0 of block 0, cycles in the step loop over all launches {tot:.3e}")
+            for n_, x in zip(['issue B loads', 'ds_read + MFMA', 'tile transitions (store X, park, load E)', 'wait loads + LDS store', 'barrier'], v):
+                print(f"      {n_:42s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")
+            continue
         print(f"  {cn}: wave 0 of block 0, cycles inside wg_gemm_nt over all launches {tot:.3e}")
         for n_, x in zip(names, v):
             print(f"      {n_:28s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")

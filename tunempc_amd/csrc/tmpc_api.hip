@@ -368,7 +368,9 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_rr, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)(k_cr_update<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -419,18 +421,25 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
     const int mt = mt_opt > 0 ? mt_opt : 64;      // one 64 x 64 tile per workgroup: ~64 consecutive items per XCD span the tiles of 1-2 nodes, whose O blocks fit that L2
                                                   // (the 128 x 128 / 512-thread shape of wg_gemm_nt was measured slower here: 102 vs 84.5 ms per phase)
-    const int nstrip = (dm.dp + rs - 1) / rs, nm = (dm.dp + mt - 1) / mt;
-    const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
-    const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
+    const int nstrip = (dm.dp + rs - 1) / rs;
     static const int gemm_ns = [] { const char* e = getenv("TMPC_GEMM_NS"); return (e && atoi(e) == 2) ? 2 : 1; }();     // K-slab depth of the batched GEMM kernels
+    static const int upd_fa = [] { const char* e = getenv("TMPC_UPD_FA"); return (e && atoi(e) == 4) ? 4 : 2; }();        // rows of the update tile / 32 (128 x 64 tiles measured slower at dp = 304: 81 vs 68 ms per phase, the third row tile is 5/8 empty)
+    const int rt = (mf && gemm_ns == 1 && upd_fa == 4) ? 128 : 64;
+    const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
+    const long it_upd = (long)count * ((long)lv.nupd * cr_ntl(dm.dp, rt) + (long)lv.nelim * ((dm.dp + rt - 1) / rt) * ((dm.dp + 63) / 64));
     const size_t lds1 = (size_t)GemmCfg<2, 2, 2, 1>::LDS_DOUBLES * sizeof(double);
+    const size_t lds14 = (size_t)GemmCfg<2, 2, 4, 1>::LDS_DOUBLES * sizeof(double);
+    static const int trsm_rr = [] { const char* e = getenv("TMPC_TRSM_RR"); return e ? atoi(e) : 1; }();     // 0: the left-looking strip kernel
     mark(1);
-    if (!mf) hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
+    if (mf && trsm_rr && dm.nt <= TRR_NT)
+      hipLaunchKernelGGL(k_cr_trsm_rr, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRR_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    else if (!mf) hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else hipLaunchKernelGGL((k_cr_trsm<true, 1>), dim3(cr_grid(it_trsm)), dim3(256), lds1, st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     mark(1); mark(2);
     if (!mf) hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
+    else if (rt == 128) hipLaunchKernelGGL((k_cr_update<true, 1, 4>), dim3(cr_grid(it_upd)), dim3(256), lds14, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else hipLaunchKernelGGL((k_cr_update<true, 1>), dim3(cr_grid(it_upd)), dim3(256), lds1, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     mark(2);
   }

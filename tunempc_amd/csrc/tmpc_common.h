@@ -11,7 +11,11 @@ __device__ unsigned long long g_prof[64];      // [class][8]: class set by the h
 __device__ int g_prof_cls;
 #define TMPC_T(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[(g_prof_cls & 7) * 8 + (i)] += t_ - tprev_; tprev_ = t_; } }
 #define TMPC_T0() unsigned long long tprev_ = __builtin_readcyclecounter();
+#define TMPC_TC(c, i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_prof[(c) * 8 + (i)] += t_ - tprevc_; tprevc_ = t_; } }
+#define TMPC_TC0() unsigned long long tprevc_ = __builtin_readcyclecounter();
 #else
+#define TMPC_TC(c, i)
+#define TMPC_TC0()
 #define TMPC_T(i)
 #define TMPC_T0()
 #endif

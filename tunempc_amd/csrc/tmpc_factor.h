@@ -15,6 +15,9 @@ constexpr int FACT_LDS_DOUBLES = 2 * 64 * 65 + 72 + 4 * 16 * 17 + 8;   // the ti
 constexpr int UPD_LDS_DOUBLES = 4 * 2 * 128 * 17 + 64;   // <2,4,4> shape (128 x 128 tiles, k_cr_update)
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
+constexpr int GM_NOTRI = -(1 << 30);
+// tri (single-tile calls of a lower-only update with a rectangular tile): column minus row index of C's origin in the symmetric block;
+// waves whose part lies entirely above the diagonal skip their work (the square-tile form of this is `lower`)
 
 // C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
 // Workgroup tile 64 x 64 (each wave a 32 x 32 quadrant = 2 x 2 MFMA tiles).  The K slabs (GK = 32 columns) of ALL
@@ -61,7 +64,7 @@ struct GemmCfg {
 template <bool USE_MFMA, int WM = 2, int WN = 2, int FA = 2, int NS = 2>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
-                                           double* lds) {
+                                           double* lds, int tri = GM_NOTRI) {
   typedef GemmCfg<WM, WN, FA, NS> G;
   constexpr int GKT = 16 * NS;                          // K slab of this instantiation
   constexpr int TM = G::TM, TN = G::TN, RP = G::RP, ARP = G::ARP, BRP = G::BRP, ASUB = G::ASUB, BSUB = G::BSUB, BUFD = G::BUFD;
@@ -158,7 +161,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     if (more) TMPC_SLAB_LOAD(nm0, nn0, nks_ * GKT + lk)
     TMPC_T(0)
     // does this wave own anything of the current tile?  (outside M x N, or above the diagonal of a lower-only diagonal tile)
-    const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA);
+    const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA) && !(tri != GM_NOTRI && tri + n0 + wc0 >= m0 + wr0 + 16 * FA);
     if (CPRE && ks == 0 && mode == GM_SUB && wave_on) {       // prefetch the C fragment of this tile
 #pragma unroll
       for (int i = 0; i < FA; ++i) {
@@ -302,50 +305,62 @@ __device__ __forceinline__ void store_d16(double* Cp, int ldc, double4_t v, int 
 // One wave: Cholesky (lower, in place) of the 16 x 16 block at S and its inverse into Si (same position; upper part zero).
 // dr: the 16 pivot references; stat[0] counts frozen pivots, stat[1] tracks the smallest pivot / reference (Cholesky-with-shift,
 // same rule as before: a pivot below 1e-15 of its reference is frozen at 1e20 * reference).
+// The block lives in registers, row r in lane r (the other three lane groups mirror it): column step j takes the pivot and
+// the column entries of the other rows by v_readlane (wave-uniform operands of the rank-1 update), no LDS round trip inside
+// the 16 dependent steps; the inverse is then solved column by column (lane c owns column c, 16 registers) against the factor
+// read back from LDS through wave-uniform addresses, all loops unrolled.  (The LDS version spent 39 k cycles per block in
+// divergent dependent loops -- half of the whole k_cr_potrf kernel: profiles/r2v_cycle_prof_potrf.txt.)
+__device__ __forceinline__ double wave_bcast(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double* dr, double* stat, int lane) {
-  for (int j = 0; j < 16; ++j) {
-    double piv = S[j * LDP + j];
-    const double ref = fabs(dr[j]);
-    const bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
-    if (lane == 0) {
-      if (piv < 1e-8 * ref) stat[1] = fmin(stat[1], fmax(piv, 0.0) / ref);      // (division only on the rare small pivots)
-      if (bad) stat[0] += 1.0;
-    }
-    if (bad) piv = (ref > 0.0 ? ref : 1.0) * 1e20;
-    const double dj = sqrt(piv);
-    if (lane < 16) {
-      if (lane > j) S[lane * LDP + j] = S[lane * LDP + j] / dj;
-      else if (lane == j) S[j * LDP + j] = dj;
-    }
-    wave_lds_sync();
+  const int r = lane & 15;
+  double a[16], ri[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {                       // rank-1 update of the trailing lower triangle, four entries per lane
-      const int e = lane + 64 * t, i = e >> 4, k = e & 15;
-      if (k > j && k <= i) S[i * LDP + k] -= S[i * LDP + j] * S[k * LDP + j];
-    }
-    wave_lds_sync();
+  for (int k = 0; k < 16; ++k) a[k] = S[r * LDP + k];
+  const double myref = fabs(dr[r]);
+  double nbad = 0.0, minr = 1.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double piv = wave_bcast(a[j], j);
+    const double ref = wave_bcast(myref, j);
+    const bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
+    if (piv < 1e-8 * ref) minr = fmin(minr, fmax(piv, 0.0) / ref);      // (division only on the rare small pivots)
+    if (bad) { nbad += 1.0; piv = (ref > 0.0 ? ref : 1.0) * 1e20; }
+    const double dj = sqrt(piv), rinv = 1.0 / dj;
+    ri[j] = rinv;
+    a[j] = (r == j) ? dj : a[j] * rinv;              // rows above the diagonal carry unused values
+#pragma unroll
+    for (int k = j + 1; k < 16; ++k) a[k] = fma(-a[j], wave_bcast(a[j], k), a[k]);
   }
-  // inverse by rows:  Si[i][c] = (delta_ic - sum_{c<=k<i} L[i][k] Si[k][c]) / L[i][i]
+  if (lane < 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k <= r) S[r * LDP + k] = a[k];
+  }
+  if (lane == 0) { stat[0] += nbad; stat[1] = fmin(stat[1], minr); }
+  wave_lds_sync();
+  // inverse, column c = r:  x_i = (delta_ic - sum_{k<i} L[i][k] x_k) / L[i][i]   (x_k = 0 for k < c comes out by itself)
+  double x[16];
+#pragma unroll
   for (int i = 0; i < 16; ++i) {
-    if (lane < 16) {
-      const int c = lane;
-      const double lii = S[i * LDP + i];
-      double v = 0.0;
-      if (c < i) {
-        double acc = 0.0;
-        for (int k = c; k < i; ++k) acc = fma(S[i * LDP + k], Si[k * LDP + c], acc);
-        v = -acc / lii;
-      } else if (c == i) v = 1.0 / lii;
-      Si[i * LDP + c] = v;
-    }
-    wave_lds_sync();
+    double sacc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sacc = fma(-S[i * LDP + k], x[k], sacc);
+    x[i] = sacc * ri[i];
   }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Si[i * LDP + r] = (i >= r) ? x[i] : 0.0;
+  }
+  wave_lds_sync();
 }
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt; nb a multiple of 16, <= 64) + its inverse into Ti (nb x nb, ld = TB).
 // dref: assembled diagonal entries (pivot reference).  Returns the number of frozen pivots (thread-uniform).
-__device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
+__device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  TMPC_TC0()
   double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
   double* Si = S + 64 * LDP;               // 64 x 65
   double* dr = Si + 64 * LDP;              // 64 pivot references, [65] = shift counter, [66] = smallest pivot / reference
@@ -355,10 +370,12 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
   if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }
   __syncthreads();
   const int nbk = nb >> 4;
+  TMPC_TC(5, 0)
   for (int jb = 0; jb < nbk; ++jb) {
     const int o = 16 * jb;
     if (wv == 0) wave_potrf16(S + o * LDP + o, Si + o * LDP + o, dr + o, dr + 65, lane);
     __syncthreads();
+    TMPC_TC(5, 1)
     {                                      // rows below: P <- P L11^-T, one 16-row block per wave
       const int bi = jb + 1 + wv;
       if (bi < nbk) {
@@ -380,6 +397,7 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
           }
     }
     __syncthreads();
+    TMPC_TC(5, 2)
   }
   // inverse of the tile, block row by block row:  Linv[bi][bj] = -Linv[bi][bi] * sum_{k=bj}^{bi-1} L[bi][k] Linv[k][bj]
   for (int bi = 1; bi < nbk; ++bi) {
@@ -395,12 +413,14 @@ __device__ __forceinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, cons
     }
     __syncthreads();
   }
+  TMPC_TC(5, 3)
   for (int e = tid; e < nb * nb; e += 256) {
     const int i = e / nb, j = e - i * nb;
     if (j <= i) T[(size_t)i * ldt + j] = S[i * LDP + j];
     Ti[i * TB + j] = Si[i * LDP + j];
   }
   __syncthreads();
+  TMPC_TC(5, 4)
   const int nb_bad = (int)dr[65];
   *minr = fmin(*minr, dr[66]);
   __syncthreads();
@@ -414,6 +434,7 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
                                                int dp, double* lds, double* minr) {
   int nbad = 0;
   int jt = 0;
+  TMPC_TC0()
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     if (j0 > 0) {
@@ -421,13 +442,16 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
       if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
       if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
+    TMPC_TC(4, 0)
     double* Ti = Linv_k + (size_t)jt * TB * TB;
     nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds, minr);
+    TMPC_TC(4, 1)
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
       wg_gemm_nt<USE_MFMA>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
     if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
     if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
+    TMPC_TC(4, 2)
   }
   return nbad;
 }
