@@ -22,11 +22,11 @@ for (nb, p) in ((512, 64), (64, 64)):
     ms = h.debug_factor_bench(nb, p, 300, reps=1)
     lib.tmpc_debug_cycle_prof(out.ctypes.data_as(C.POINTER(C.c_double)))
     print(f"nb {nb} p {p} d 300: factor {ms[0]:.2f} ms, solve {ms[1]:.2f} ms (profiled build)")
-    v = out[32:35]; tot = v.sum()
+    v = out[48:51]; tot = v.sum()
     print(f"  k_cr_potrf block column (wave 0 of block 0): {tot:.3e} cycles")
     for n_, x in zip(['left-looking GEMM update', '64 x 64 tile Cholesky + inverse', 'panel multiply by the tile inverse'], v):
         print(f"      {n_:42s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")
-    v = out[40:45]; tot = v.sum()
+    v = out[56:61]; tot = v.sum()
     print(f"  inside the tile Cholesky: {tot:.3e} cycles")
     for n_, x in zip(['load tile into LDS', 'wave_potrf16 (16 x 16 Cholesky + inverse, one wave)', 'panel + trailing update (MFMA 16x16x4)', 'inverse assembly', 'store tile + inverse'], v):
         print(f"      {n_:52s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")

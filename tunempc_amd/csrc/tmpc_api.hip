@@ -437,6 +437,12 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else hipLaunchKernelGGL((k_cr_trsm<true, 1>), dim3(cr_grid(it_trsm)), dim3(256), lds1, st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     mark(1); mark(2);
+    static const int upd_dma = [] { const char* e = getenv("TMPC_UPD_DMA"); return e ? atoi(e) : 1; }();     // 0: the register-staged core
+    if (mf && upd_dma) {
+      const int nm64 = (dm.dp + 63) / 64;
+      const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
+      hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
+    } else
     if (!mf) hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else if (rt == 128) hipLaunchKernelGGL((k_cr_update<true, 1, 4>), dim3(cr_grid(it_upd)), dim3(256), lds14, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);

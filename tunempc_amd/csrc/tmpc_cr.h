@@ -26,6 +26,7 @@
 
 #include "tmpc_common.h"
 #include "tmpc_factor.h"
+#include "tmpc_gemm_dma.h"
 
 namespace tmpc {
 
@@ -480,6 +481,54 @@ __global__ void __launch_bounds__(256, (NS == 1 && FA == 2) ? 4 : ((NS == 1) ? 3
     const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
     double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
     wg_gemm_nt<USE_MFMA, 2, 2, FA, NS>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
+  }
+}
+
+// The same items on the LDS-DMA core (tmpc_gemm_dma.h): 64 x 64 tiles, the two edges of a doubly updated node as ONE K stream.
+constexpr int UPD_DMA_DEPTH = 2;
+__global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
+  const int dp = dm.dp;
+  const int nm = (dp + 63) / 64;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
+  const int per = nupd * ntl + nelim * ntf;
+  const int it = cr_item(count * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / per];
+  const int r = it % per;
+  const size_t bs = (size_t)dp * dp;
+  const int slot_items = ntf + ntl;
+  int j = r / slot_items, rr = r - j * slot_items;
+  bool is_upd;
+  {
+    const int nmin = nelim < nupd ? nelim : nupd;
+    const int full = nmin * slot_items;
+    if (r < full) { is_upd = rr >= ntf; if (is_upd) rr -= ntf; }
+    else if (nelim > nupd) { const int q = r - full; j = nmin + q / ntf; rr = q % ntf; is_upd = false; }
+    else { const int q = r - full; j = nmin + q / ntl; rr = q % ntl; is_upd = true; }
+  }
+  if (is_upd) {
+    const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
+    int t = rr, tm = 0;
+    while (t > tm) { t -= tm + 1; ++tm; }
+    const int tn = t;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
+    const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
+    const double* O1 = ur[CU_E1] >= 0 ? cr_edge(w, dm, b, ur[CU_E1]) : nullptr;
+    wg_tile_dma<UPD_DMA_DEPTH>(C, dp, O0 + (size_t)m0 * dp, O0 + (size_t)n0 * dp, O1 ? O1 + (size_t)m0 * dp : nullptr, O1 ? O1 + (size_t)n0 * dp : nullptr,
+                               dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds);
+  } else {
+    const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
+    if (er[CE_FILL] < 0) return;
+    const int tm = rr / nm, tn = rr - tm * nm;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
+    const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
+    double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
+    wg_tile_dma<UPD_DMA_DEPTH>(C, dp, Ox + (size_t)m0 * dp, Oy + (size_t)n0 * dp, nullptr, nullptr, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, GM_NOTRI, it, lds);
   }
 }
 

@@ -370,12 +370,12 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
   if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }
   __syncthreads();
   const int nbk = nb >> 4;
-  TMPC_TC(5, 0)
+  TMPC_TC(7, 0)
   for (int jb = 0; jb < nbk; ++jb) {
     const int o = 16 * jb;
     if (wv == 0) wave_potrf16(S + o * LDP + o, Si + o * LDP + o, dr + o, dr + 65, lane);
     __syncthreads();
-    TMPC_TC(5, 1)
+    TMPC_TC(7, 1)
     {                                      // rows below: P <- P L11^-T, one 16-row block per wave
       const int bi = jb + 1 + wv;
       if (bi < nbk) {
@@ -397,7 +397,7 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
           }
     }
     __syncthreads();
-    TMPC_TC(5, 2)
+    TMPC_TC(7, 2)
   }
   // inverse of the tile, block row by block row:  Linv[bi][bj] = -Linv[bi][bi] * sum_{k=bj}^{bi-1} L[bi][k] Linv[k][bj]
   for (int bi = 1; bi < nbk; ++bi) {
@@ -413,14 +413,14 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
     }
     __syncthreads();
   }
-  TMPC_TC(5, 3)
+  TMPC_TC(7, 3)
   for (int e = tid; e < nb * nb; e += 256) {
     const int i = e / nb, j = e - i * nb;
     if (j <= i) T[(size_t)i * ldt + j] = S[i * LDP + j];
     Ti[i * TB + j] = Si[i * LDP + j];
   }
   __syncthreads();
-  TMPC_TC(5, 4)
+  TMPC_TC(7, 4)
   const int nb_bad = (int)dr[65];
   *minr = fmin(*minr, dr[66]);
   __syncthreads();
@@ -442,16 +442,16 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
       if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
       if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2, dp, Dk + (size_t)j0 * dp, dp, dp, nb, j0, GM_SUB, false, lds);
     }
-    TMPC_TC(4, 0)
+    TMPC_TC(6, 0)
     double* Ti = Linv_k + (size_t)jt * TB * TB;
     nbad += wg_potrf_inv(Dk + (size_t)j0 * dp + j0, dp, Ti, dref + j0, nb, lds, minr);
-    TMPC_TC(4, 1)
+    TMPC_TC(6, 1)
     // panel below / beside the diagonal tile:  X <- X * Ti'   (in place, K = nb)
     if (dp - j0 - nb > 0)
       wg_gemm_nt<USE_MFMA>(Dk + (size_t)(j0 + nb) * dp + j0, dp, Dk + (size_t)(j0 + nb) * dp + j0, dp, Ti, TB, dp - j0 - nb, nb, nb, GM_SET, false, lds);
     if (R1) wg_gemm_nt<USE_MFMA>(R1 + j0, dp, R1 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
     if (R2) wg_gemm_nt<USE_MFMA>(R2 + j0, dp, R2 + j0, dp, Ti, TB, dp, nb, nb, GM_SET, false, lds);
-    TMPC_TC(4, 2)
+    TMPC_TC(6, 2)
   }
   return nbad;
 }

@@ -1,0 +1,142 @@
+// fp64 tile GEMM fed by LDS-DMA: C (M x N <= 64 x 64) {-=, = -} sum_q A_q B_q'   (K columns each, up to two operand pairs as one stream)
+//
+// The K slabs (64 rows x 16 columns per operand) go global -> LDS by buffer_load_dwordx4 ... lds: no staging registers, no
+// ds_write, and the slab after next is in flight while the current one is multiplied (DEPTH buffers, s_waitcnt vmcnt(N) with
+// N > 0, raw s_barrier).  The DMA writes lane-linear -- 8 lanes = one 128-byte row -- so the LDS image is unpadded
+// [row][8 granules of 16 B]; bank conflicts are avoided by a swizzle that lives in the per-lane GLOBAL address: granule c of row
+// r holds the K pair c ^ s(r), s(r) = (r & 7) ^ 2 ((r >> 3) & 1).  Fragment reads are ds_read_b128, one K pair per lane,
+// conflict-free for the A fragments (8 consecutive rows per LDS cycle) and the B fragments (4 rows, stride 4).
+// v_mfma_f64_4x4x4_4b consumes 4 k per instruction, one per 16-lane group: instruction 1 takes the even k of the group's
+// pairs (the lanes' .x), instruction 2 the odd ones (.y) -- A and B agree on the assignment, so the product is the same.
+// Each wave owns a 16-column strip of the tile and all (up to four) 16-row fragments of it: 4 + 4 fragment reads per 32
+// MFMAs, and on tiles that cross the diagonal of a symmetric update, or end at the edge of the block, a wave skips exactly
+// the 16 x 16 blocks that are not needed (executed / algorithmic flops of the lower triangle of a 304-block: 1.05 instead of
+// 1.22 with 32 x 32 wave quadrants).  The strip of wave w is (w + rot) & 3 so that the short strips of diagonal tiles do
+// not always land on the same SIMD.   Measured against the register-staged core: scripts/micro/dma_gemm.hip,
+// profiles/r2v_pmc_gemm_core_micro.txt.
+#pragma once
+#include "tmpc_common.h"
+#include "tmpc_factor.h"
+
+namespace tmpc {
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+constexpr int DMA_SLAB = 2048;                 // doubles per LDS buffer: A slab (64 x 16) + B slab
+template <int DEPTH>
+constexpr int dma_lds_doubles() { return DEPTH * DMA_SLAB; }
+
+// swizzle of row r
+__device__ __forceinline__ int dma_sw(int r) { return (r & 7) ^ (((r >> 3) & 1) << 1); }
+
+template <int DEPTH>
+__device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0, const double* B0, const double* A1, const double* B1, int ld,
+                                            int M, int N, int K, int mode, int tri, int rot, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc0 = ((wv + rot) & 3) * 16;
+  const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
+  const bool wave_on = wc0 < N;
+  int i0 = 0;
+  if (tri != GM_NOTRI) { i0 = (tri + wc0) >> 4; if (i0 < 0) i0 = 0; }        // row fragments above the strip's first column are not needed
+  const int i1 = (M + 15) >> 4;
+  const unsigned abytes = ((unsigned)(M - 1) * (unsigned)ld + (unsigned)K) * 8u, bbytes = ((unsigned)(N - 1) * (unsigned)ld + (unsigned)K) * 8u;
+  const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)A0, 0, (int)abytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc((void*)B0, 0, (int)bbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(A1 ? A1 : A0), 0, (int)abytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)(B1 ? B1 : B0), 0, (int)bbytes, 0x00020000);
+  // DMA: wave wv moves rows 16 wv .. 16 wv + 15 of both operands, two instructions of 8 rows each
+  unsigned vo[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = wv * 16 + 8 * h + (lane >> 3), c = lane & 7;
+    vo[h] = (unsigned)(row * ld + 2 * (c ^ dma_sw(row))) * 8u;
+  }
+  // fragment read offsets (doubles) inside a slab, one per half hh of the 16-column slab (K pairs 4 hh + fk)
+  int oa[2], ob[4][2];
+  {
+    const int swa = dma_sw(4 * fq + fj);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) oa[hh] = (4 * fq + fj) * 16 + 2 * ((4 * hh + fk) ^ swa);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int swb = dma_sw(wc0 + 4 * fj + e);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (wc0 + 4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
+    }
+  }
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = 0.0;
+  const int nks = K >> 4, nst = A1 ? 2 * nks : nks;
+  const bool full = wave_on && i0 == 0 && i1 == 4;
+#define TMPC_DMA_ISSUE(S, Q)                                                                              \
+  {                                                                                                       \
+    double* As_ = lds + (Q) * DMA_SLAB;                                                                   \
+    const bool second_ = (S) >= nks;                                                                      \
+    const int so_ = ((S) - (second_ ? nks : 0)) * 128;                                                    \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                       \
+      if (second_) {                                                                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (lds_vptr)(As_ + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb1, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0); \
+      } else {                                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (lds_vptr)(As_ + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb0, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+#define TMPC_DMA_MMA(PRED)                                                                                \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                      \
+    double2_t a[4];                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = *(const double2_t*)(As_ + oa[hh] + i * 256);     \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                    \
+      const double2_t bv = *(const double2_t*)(Bs_ + ob[cb][hh]);                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        if (!(PRED) || (i >= i0 && i < i1)) {                                                             \
+          acc[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][0], bv[0], acc[i][cb], 0, 0, 0);           \
+          acc[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][1], bv[1], acc[i][cb], 0, 0, 0);           \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+#define TMPC_DMA_STEP(S, Q)                                                                               \
+  {                                                                                                       \
+    if ((S) + DEPTH - 2 < nst - 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 2)) : "memory"); } \
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                             \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    if ((S) + DEPTH - 1 < nst) TMPC_DMA_ISSUE((S) + DEPTH - 1, ((Q) + DEPTH - 1) % DEPTH)                 \
+    const double* As_ = lds + (Q) * DMA_SLAB;                                                             \
+    const double* Bs_ = As_ + 1024;                                                                       \
+    if (full) TMPC_DMA_MMA(false)                                                                         \
+    else if (wave_on) TMPC_DMA_MMA(true)                                                                  \
+  }
+  __syncthreads();                                          // LDS free (previous user)
+#pragma unroll
+  for (int s = 0; s < DEPTH - 1; ++s)
+    if (s < nst) TMPC_DMA_ISSUE(s, s)
+  for (int s = 0; s < nst; s += DEPTH) {
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q)
+      if (s + q < nst) TMPC_DMA_STEP(s + q, q)
+  }
+#undef TMPC_DMA_STEP
+#undef TMPC_DMA_MMA
+#undef TMPC_DMA_ISSUE
+  if (wave_on) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = 16 * i;
+      if (i >= i0 && i < i1) {
+        typedef double2_t __attribute__((address_space(1)))* gptr2;
+        gptr2 cp = (gptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + wc0 + 4 * fj);
+        double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;
+        if (mode == GM_SUB) { u0 = cp[0]; u1 = cp[1]; }
+        if (mode == GM_SET) { u0[0] = acc[i][0]; u0[1] = acc[i][1]; u1[0] = acc[i][2]; u1[1] = acc[i][3]; }
+        else { u0[0] -= acc[i][0]; u0[1] -= acc[i][1]; u1[0] -= acc[i][2]; u1[1] -= acc[i][3]; }
+        cp[0] = u0; cp[1] = u1;
+      }
+    }
+  }
+}
+
+}  // namespace tmpc
