@@ -369,6 +369,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_rr, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)(k_cr_update<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -429,9 +430,11 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const long it_upd = (long)count * ((long)lv.nupd * cr_ntl(dm.dp, rt) + (long)lv.nelim * ((dm.dp + rt - 1) / rt) * ((dm.dp + 63) / 64));
     const size_t lds1 = (size_t)GemmCfg<2, 2, 2, 1>::LDS_DOUBLES * sizeof(double);
     const size_t lds14 = (size_t)GemmCfg<2, 2, 4, 1>::LDS_DOUBLES * sizeof(double);
-    static const int trsm_rr = [] { const char* e = getenv("TMPC_TRSM_RR"); return e ? atoi(e) : 1; }();     // 0: the left-looking strip kernel
+    static const int trsm_rr = [] { const char* e = getenv("TMPC_TRSM_RR"); return e ? atoi(e) : 2; }();     // 2: LDS-DMA strips, 1: register-staged, 0: the left-looking strip kernel
     mark(1);
-    if (mf && trsm_rr && dm.nt <= TRR_NT)
+    if (mf && trsm_rr == 2 && dm.nt <= TRR_NT)
+      hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRD_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    else if (mf && trsm_rr && dm.nt <= TRR_NT)
       hipLaunchKernelGGL(k_cr_trsm_rr, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRR_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else if (!mf) hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);

@@ -414,6 +414,200 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_rr(WS w, Dims dm, CrDev cr, 
 #undef TRR_ACC
 }
 
+// ---- phase 2 on the LDS-DMA core: the register-resident right-looking solve above with (a) the sub-slabs of L streaming in by
+// buffer_load ... lds, three deep, (b) each wave owning a 16-column strip of every column tile (tmpc_gemm_dma.h), so that the
+// product with the lower-triangular tile inverse skips the K slabs beyond the strip (10 of 16 strip-slabs) and the 48-wide last
+// tile and 48-row last strip cost what they hold.
+constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
+constexpr int TRD_LDS_DOUBLES = 4 * 1024 + TRD_DEPTH * 2048;       // X_i / T_i as the A operand (four 64 x 16 slabs) + the B steps in flight
+__global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int dp = dm.dp, nt = dm.nt;
+  const int per = 2 * nt;
+  const int it = cr_item(count * nelim * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int g = it / per, r = it - g * per;
+  const int b = cr.alist[g / nelim];
+  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
+  const int which = r / nt, strip = r - which * nt;
+  const int slot = which ? er[CE_EB] : er[CE_EA];
+  if (slot < 0) return;
+  const int node = er[CE_NODE];
+  const size_t bs = (size_t)dp * dp;
+  const double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
+  const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const int r0 = strip * 64;
+  const int rows = (dp - r0 < 64) ? dp - r0 : 64;
+  double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ws = (wv + it) & 3, wc0 = ws * 16;              // this wave's 16-column strip of every tile
+  const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
+  const int i1 = (rows + 15) >> 4;                          // 16-row fragments of the strip
+  double* At = lds;
+  double* Bs = lds + 4 * 1024;
+  unsigned voT[2], voL[2];                                  // DMA: wave wv moves rows 16 wv .. + 15 of a B slab, two pieces of 8 rows
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = wv * 16 + 8 * h + (lane >> 3), c = lane & 7;
+    voT[h] = (unsigned)(row * TB + 2 * (c ^ dma_sw(row))) * 8u;
+    voL[h] = (unsigned)(row * dp + 2 * (c ^ dma_sw(row))) * 8u;
+  }
+  int oa[2], ob[4][2];
+  {
+    const int swa = dma_sw(4 * fq + fj);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) oa[hh] = (4 * fq + fj) * 16 + 2 * ((4 * hh + fk) ^ swa);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int swb = dma_sw(wc0 + 4 * fj + e);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (wc0 + 4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
+    }
+  }
+  double acc1[4][4], acc2[4][4], acc3[4][4], acc4[4][4], xa[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { acc1[i][c] = 0.0; acc2[i][c] = 0.0; acc3[i][c] = 0.0; acc4[i][c] = 0.0; xa[i][c] = 0.0; }
+#define TRD_ACC(k) ((k) == 1 ? acc1 : (k) == 2 ? acc2 : (k) == 3 ? acc3 : acc4)
+#define TRD_NB(T) ((dp - 64 * (T) < 64) ? dp - 64 * (T) : 64)
+  // lane <-> memory: rows 16 i + 4 fq + fk of the four fragments, columns wc0 + 4 fj .. + 3 of the tile
+#define TRD_LOAD_E(I)                                                                                       \
+  {                                                                                                         \
+    const bool on_ = wc0 < TRD_NB(I);                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;                                                        \
+      if (on_ && i < i1) {                                                                                  \
+        gcptr2 cp = (gcptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (I) + wc0 + 4 * fj);            \
+        u0 = cp[0]; u1 = cp[1];                                                                             \
+      }                                                                                                     \
+      xa[i][0] = u0[0]; xa[i][1] = u0[1]; xa[i][2] = u1[0]; xa[i][3] = u1[1];                               \
+    }                                                                                                       \
+  }
+#define TRD_PARK()          /* xa -> A operand: slab = this strip, K pairs 2 fj and 2 fj + 1 of every row */ \
+  {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      const int row = 16 * i + 4 * fq + fk, sw_ = dma_sw(row);                                              \
+      double* q = At + ws * 1024 + row * 16;                                                                \
+      *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){xa[i][0], xa[i][1]};                            \
+      *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){xa[i][2], xa[i][3]};                        \
+    }                                                                                                       \
+  }
+#define TRD_ZERO_XA()                                                                                       \
+  {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] = 0.0;                                         \
+  }
+  // B stream: for every column tile i the slabs of Linv_i (K = nb_i), then those of L_ji, j > i (K = 64).  (ii, ij, is) = next slab to issue.
+  int ii = 0, ij = 0, is = 0, nissued = 0, ndone = 0, ylast = 0;       // ylast: DMA pieces per wave of the step issued last
+#define TRD_ISSUE()          /* one step = the slabs 2 is and 2 is + 1 (if the K range has it) of the pair (ii, ij) */ \
+  {                                                                                                         \
+    if (ii < nt) {                                                                                          \
+      double* dst_ = Bs + (nissued % TRD_DEPTH) * 2048 + wv * 256;                                          \
+      const int nsl_ = (ij == ii) ? (TRD_NB(ii) >> 4) : 4;                                                  \
+      const bool two_ = 2 * is + 1 < nsl_;                                                                  \
+      if (ij == ii) {                                                                                       \
+        const int nb_ = TRD_NB(ii);                                                                         \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(Li + (size_t)ii * TB * TB), 0, (int)(((unsigned)(nb_ - 1) * TB + (unsigned)nb_) * 8u), 0x00020000); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_), 16, voT[0], is * 256, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 128), 16, voT[1], is * 256, 0, 0);  \
+        if (two_) {                                                                                         \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024), 16, voT[0], is * 256 + 128, 0, 0);       \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024 + 128), 16, voT[1], is * 256 + 128, 0, 0); \
+        }                                                                                                   \
+      } else {                                                                                              \
+        const int nb_ = TRD_NB(ij);                                                                         \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(Dk + (size_t)(64 * ij) * dp + 64 * ii), 0, (int)(((unsigned)(nb_ - 1) * (unsigned)dp + 64u) * 8u), 0x00020000); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_), 16, voL[0], is * 256, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 128), 16, voL[1], is * 256, 0, 0);  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024), 16, voL[0], is * 256 + 128, 0, 0);         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024 + 128), 16, voL[1], is * 256 + 128, 0, 0);   \
+      }                                                                                                     \
+      ++nissued; ylast = (ij == ii && !two_) ? 2 : 4;                                                       \
+      if (++is == ((nsl_ + 1) >> 1)) { is = 0; if (++ij >= nt) { ++ii; ij = ii; } }                         \
+    }                                                                                                       \
+  }
+#define TRD_MMA2(TGT, AS, BS)                                                                               \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                        \
+    double2_t a_[4], b_[4];                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *(const double2_t*)((AS) + oa[hh] + i * 256);     \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) b_[cb] = *(const double2_t*)((BS) + ob[cb][hh]);       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      if (i < i1) {                                                                                         \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                  \
+          TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][0], b_[cb][0], TGT[i][cb], 0, 0, 0);        \
+          TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][1], b_[cb][1], TGT[i][cb], 0, 0, 0);        \
+        }                                                                                                   \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+  // the slab steps of the pair (CI, CJ), literal indices: TGT = xa on the diagonal, the partial sums of tile CJ otherwise
+#define TRD_PAIR(CI, CJ, TGT)                                                                               \
+  if ((CJ) < nt) {                                                                                          \
+    const int nbi = TRD_NB(CI), nbj = TRD_NB(CJ);                                                           \
+    const int nsl = ((CJ) == (CI)) ? (nbi >> 4) : 4;                  /* 16-column slabs of this pair */ \
+    const int nsub = (nsl + 1) >> 1;                                  /* steps of two */                     \
+    for (int cs = 0; cs < nsub; ++cs) {                                                                     \
+      /* step ndone has landed once at most the (younger) step issued after it is outstanding */            \
+      if (nissued - ndone - 1 >= 1 && ylast == 4) { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }        \
+      else if (nissued - ndone - 1 >= 1) { asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }    \
+      else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }                                  \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      TRD_ISSUE()                                                                                           \
+      const double* Bc_ = Bs + (ndone % TRD_DEPTH) * 2048;                                                  \
+      if (wc0 < nbj) {                                                                                      \
+        if (!((CJ) == (CI) && 2 * cs > ws)) TRD_MMA2(TGT, At + 2 * cs * 1024, Bc_)                          \
+        if (2 * cs + 1 < nsl && !((CJ) == (CI) && 2 * cs + 1 > ws)) TRD_MMA2(TGT, At + (2 * cs + 1) * 1024, Bc_ + 1024) \
+      }                                                                                                     \
+      ++ndone;                                                                                              \
+      const bool last_sub = (cs == nsub - 1);                                                               \
+      if ((CJ) == (CI) && last_sub) {          /* X_i complete: out to memory, and into LDS as the operand of the updates */ \
+        if (wc0 < nbi) {                                                                                    \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+            if (i < i1) {                                                                                   \
+              typedef double2_t __attribute__((address_space(1)))* gptr2;                                   \
+              gptr2 cp = (gptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (CI) + wc0 + 4 * fj);       \
+              cp[0] = (double2_t){xa[i][0], xa[i][1]}; cp[1] = (double2_t){xa[i][2], xa[i][3]};             \
+            }                                                                                               \
+          }                                                                                                 \
+        }                                                                                                   \
+        if ((CI) + 1 < nt) {                                                                                \
+          __builtin_amdgcn_s_barrier();        /* every wave is done with T_i */                            \
+          TRD_PARK()                                                                                        \
+          TRD_LOAD_E((CI) + 1)                 /* in flight during the updates */                           \
+        }                                                                                                   \
+      }                                                                                                     \
+      if ((CI) + 1 < TRR_NT && last_sub && (CJ) == nt - 1 && (CI) + 1 < nt) {     /* block i finished: T_{i+1} = E_{i+1} - partial sums of tile i+1 */ \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] -= TRD_ACC((CI) + 1)[i][c];                \
+        __builtin_amdgcn_s_barrier();          /* every wave is done with X_i */                            \
+        TRD_PARK()                                                                                          \
+        TRD_ZERO_XA()                                                                                       \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+
+  __syncthreads();
+  TRD_ISSUE()
+  TRD_LOAD_E(0)
+  TRD_PARK()                                                // T_0 = E_0
+  TRD_ZERO_XA()
+  TRD_PAIR(0, 0, xa) TRD_PAIR(0, 1, acc1) TRD_PAIR(0, 2, acc2) TRD_PAIR(0, 3, acc3) TRD_PAIR(0, 4, acc4)
+  if (nt > 1) { TRD_PAIR(1, 1, xa) TRD_PAIR(1, 2, acc2) TRD_PAIR(1, 3, acc3) TRD_PAIR(1, 4, acc4) }
+  if (nt > 2) { TRD_PAIR(2, 2, xa) TRD_PAIR(2, 3, acc3) TRD_PAIR(2, 4, acc4) }
+  if (nt > 3) { TRD_PAIR(3, 3, xa) TRD_PAIR(3, 4, acc4) }
+  if (nt > 4) { TRD_PAIR(4, 4, xa) }
+#undef TRD_PAIR
+#undef TRD_MMA2
+#undef TRD_ISSUE
+#undef TRD_ZERO_XA
+#undef TRD_PARK
+#undef TRD_LOAD_E
+#undef TRD_NB
+#undef TRD_ACC
+}
+
 // ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one (32 FA) x 64 output tile per workgroup
 // FA = 2: 64 x 64 tiles (35 KB of LDS with NS = 1, four workgroups per CU); FA = 4: 128 x 64 tiles, each wave a 64 x 32 part -- twice the
 // MFMAs per loaded operand byte, LDS store and barrier (52 KB, three workgroups per CU)
