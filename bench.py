@@ -34,7 +34,7 @@ def factor_flops_per_problem(p, d):
 
 
 TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
-KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_factor.h')]
+KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h')]
 
 
 def hbm_traffic_per_launch():
@@ -182,7 +182,7 @@ def main():
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                          "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r2_traffic.json)",
-                         "kernel": "k_cr_update<true> (symmetric updates and fill edges of the cyclic-reduction block Cholesky, v_mfma_f64_16x16x4_f64)",
+                         "kernel": "k_cr_update_dma (symmetric updates and fill edges of the cyclic-reduction block Cholesky: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles)",
                          "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
                          "algorithmic_flops_per_launch": upd_flops / upd_launches,
                          "factorisation_phase": {"kernels": "k_cr_potrf + k_cr_trsm + k_cr_update, all levels", "tflops": phase_tf,
@@ -190,8 +190,8 @@ def main():
                                                  "problems_per_phase": nfac / phases,
                                                  "potrf_ms": prof['potrf_ms'] / phases, "trsm_ms": prof['trsm_ms'] / phases,
                                                  "update_ms": upd_ms / phases},
-                         "peak_note": "datasheet FP64 matrix peak; measured register-only issue rate of v_mfma_f64_16x16x4 on this part: "
-                                      "36 (1 wave/SIMD) / 48 (2+) TFLOP/s, of v_mfma_f64_4x4x4: 71-75 (profiles/r1_mfma_f64_issue_rate.txt)"},
+                         "peak_note": "datasheet FP64 matrix peak at 2.4 GHz; under this kernel the chip holds 1.8-1.9 GHz (GRBM_GUI_ACTIVE / wall time, "
+                                      "profiles/r2v_pmc_gemm_core_micro.txt), i.e. 59-62 TFLOP/s at the sustained clock"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         if not args.no_cpu_baseline and world == 1:

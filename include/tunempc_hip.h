@@ -167,6 +167,13 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
  * out[b*p+k][0..3] = min eig, max eig, min |eig| (zeros excluded), max |eig| of sym(H[b][k]). */
 int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
 
+/* Eigenvalue clip of general-size symmetric matrices (reference: tunempc/sqp_method.py:327-403, `Sqp.__regularize_hessian`: the
+ * eigenvalues of the (reduced) Hessian below `regularization_tol` are lifted to it, H += evec diag(evmod - eva) evec^-1):
+ *   out[b] = sym(A[b]) + V diag(max(tol - lambda_i, 0)) V',   A, out [nb][n][n], any n >= 1 (no handle, current device).
+ * evals [nb][n] (optional): the eigenvalues lambda_i of A[b] (unordered); reg [nb] (optional): the largest lift max_i(tol - lambda_i, 0)
+ * (the reference's `self.__reg`); sweeps [nb] (optional): Jacobi sweeps taken. */
+int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, double* evals, double* reg, int32_t* sweeps);
+
 /* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set, 16 doubles:
  * out[0] stage_pre+ctrl, [1] schur assembly, [2] block factorisation (all kernels of tmpc_cr.h's factor phase), [3] predictor
  * pass, [4] corrector pass + update, [5] number of factorisation phases (= IPM iterations of the chunks), [6] total ms of the

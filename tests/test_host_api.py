@@ -64,7 +64,7 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith(('.py', '.h', '.hip')):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert 'convexify_oracle' not in txt and 'proto_dense' not in txt and 'tracking_oracle' not in txt and 'reference_sdp' not in txt, (dirpath, f)
+                assert 'convexify_oracle' not in txt and 'proto_dense' not in txt and 'tracking_oracle' not in txt and 'reference_sdp' not in txt and 'sqp_oracle' not in txt and 'cpu_ipm' not in txt, (dirpath, f)
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), (dirpath, f)
 
 

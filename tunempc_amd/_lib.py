@@ -20,7 +20,7 @@ EXPORTS = [
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
-    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host',
+    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 # ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
@@ -91,6 +91,8 @@ def load_library():
     lib.tmpc_supplement_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp]
     lib.tmpc_eig_scan_host.restype = C.c_int
     lib.tmpc_eig_scan_host.argtypes = [vp, C.c_int, dp, dp]
+    lib.tmpc_eig_clip_host.restype = C.c_int
+    lib.tmpc_eig_clip_host.argtypes = [C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int32)]
     lib.tmpc_get_profile.restype = C.c_int
     lib.tmpc_get_profile.argtypes = [vp, dp]
     lib.tmpc_get_trace.restype = C.c_int
@@ -430,6 +432,23 @@ class HipConvexifier:
         x = np.empty((p, d)); ns = np.zeros(1, np.int32)
         _check(self.lib, self.lib.tmpc_debug_block_solve(self._h, p, d, _dptr(D), _dptr(Ccpl), _dptr(rhs), _dptr(x), _iptr(ns)), 'tmpc_debug_block_solve')
         return x, int(ns[0])
+
+
+def eig_clip(A, tol):
+    """out = sym(A) + V diag(max(tol - lambda, 0)) V' for one (n x n) or a batch ([nb, n, n]) of symmetric matrices, any n
+    (tmpc_eig_clip_host; reference sqp_method.py:327-403).  Returns dict(out, evals, reg, sweeps)."""
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    single = A.ndim == 2
+    A3 = A[None] if single else A
+    nb, n, n2 = A3.shape
+    if n != n2:
+        raise ValueError('square matrices expected')
+    out = np.empty_like(A3); ev = np.empty((nb, n)); reg = np.empty(nb); sw = np.zeros(nb, dtype=np.int32)
+    _check(lib, lib.tmpc_eig_clip_host(nb, n, _dptr(A3), float(tol), _dptr(out), _dptr(ev), _dptr(reg), _iptr(sw)), 'tmpc_eig_clip_host')
+    if single:
+        return dict(out=out[0], evals=ev[0], reg=float(reg[0]), sweeps=int(sw[0]))
+    return dict(out=out, evals=ev, reg=reg, sweeps=sw)
 
 
 def cr_schedule(p):

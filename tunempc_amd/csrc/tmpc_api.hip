@@ -19,6 +19,7 @@
 #include "tmpc_cr.h"
 #include "tmpc_phi.h"
 #include "tmpc_t3.h"
+#include "tmpc_eig.h"
 
 using namespace tmpc;
 
@@ -1047,6 +1048,42 @@ int tmpc_eig_scan_host(tmpc_handle* hh, int nbt, const double* H, double* out) {
     HIPCHK(hipMemcpyAsync(out + (size_t)off * dm.p * 4, h->ws.part, BP * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
+  return TMPC_OK;
+}
+
+// out = A + V diag(max(tol - lambda, 0)) V' for nb symmetric n x n matrices (tmpc_eig.h; reference: sqp_method.py:327-403).
+// No handle: any n >= 1; the device is the current one.
+int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, double* evals, double* reg, int32_t* sweeps) {
+  if (nb < 1 || n < 1 || !A || !out) return TMPC_E_ARG;
+  const size_t nn = (size_t)n * n;
+  DevBuf bA, bU, bV, bO, bs;                                // bs: shift | evals | lift | reg | offmax
+  HIPCHK(bA.alloc((size_t)nb * nn * 8)); HIPCHK(bU.alloc((size_t)nb * nn * 8)); HIPCHK(bV.alloc((size_t)nb * nn * 8)); HIPCHK(bO.alloc((size_t)nb * nn * 8));
+  HIPCHK(bs.alloc(((size_t)nb * (3 + 2 * (size_t)n)) * 8));
+  double* dA = bA.as<double>(); double* dU = bU.as<double>(); double* dV = bV.as<double>(); double* dO = bO.as<double>();
+  double* dshift = bs.as<double>(); double* dev = dshift + nb; double* dlift = dev + (size_t)nb * n; double* dreg = dlift + (size_t)nb * n; double* doff = dreg + nb;
+  HIPCHK(hipMemcpy(dA, A, (size_t)nb * nn * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_eig_init, dim3(nb), dim3(256), 0, 0, dA, dU, dV, dshift, n);
+  const int m = (n + 1) & ~1;
+  int sw = 0;
+  std::vector<double> off(nb);
+  if (n > 1) {
+    for (; sw < 40; ++sw) {
+      HIPCHK(hipMemsetAsync(doff, 0, (size_t)nb * 8, 0));
+      for (int r = 0; r < m - 1; ++r) hipLaunchKernelGGL(k_eig_round, dim3(m / 2, nb), dim3(256), 0, 0, dU, dV, n, m, r, doff);
+      HIPCHK(hipMemcpy(off.data(), doff, (size_t)nb * 8, hipMemcpyDeviceToHost));
+      double worst = 0.0;
+      for (double v : off) worst = std::max(worst, v);
+      if (!(worst > 1e-15)) { ++sw; break; }                // a full sweep without a rotation
+    }
+  }
+  HIPCHK(hipMemsetAsync(dreg, 0, (size_t)nb * 8, 0));
+  hipLaunchKernelGGL(k_eig_values, dim3(n, nb), dim3(256), 0, 0, dU, dshift, dev, dlift, dreg, n, tol);
+  hipLaunchKernelGGL(k_eig_apply, dim3((unsigned)((nn + 255) / 256), nb), dim3(256), 0, 0, dA, dV, dlift, dO, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, dO, (size_t)nb * nn * 8, hipMemcpyDeviceToHost));
+  if (evals) HIPCHK(hipMemcpy(evals, dev, (size_t)nb * n * 8, hipMemcpyDeviceToHost));
+  if (reg) HIPCHK(hipMemcpy(reg, dreg, (size_t)nb * 8, hipMemcpyDeviceToHost));
+  if (sweeps) for (int b = 0; b < nb; ++b) sweeps[b] = sw;
   return TMPC_OK;
 }
 
