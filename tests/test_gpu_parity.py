@@ -470,6 +470,23 @@ def test_dropin_convexify_lqr_example():
     assert rel(np.asarray(dHc[0]) + co.build_hessian(Qn, Rn, Nn), g['Hc'][0, 0]) < PARITY
 
 
+def test_dropin_solver_log_at_debug_level(caplog):
+    """convexifier.py:87-91: below INFO level the solver is verbose -- here the iteration log of the device IPM goes to the logger."""
+    import logging
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c1_convex_lqr.npz'))
+    args = (g['A'][0, 0], g['B'][0, 0], g['Q'], g['R'], g['N'])
+    with caplog.at_level(logging.INFO, logger='tunempc'):
+        convexifier.convexify(*args)
+    assert not any('rel.step' in r.message for r in caplog.records) and any('Optimal solution found.' in r.message for r in caplog.records)
+    caplog.clear()
+    with caplog.at_level(logging.DEBUG, logger='tunempc'):
+        convexifier.convexify(*args)
+    msgs = [r.message for r in caplog.records]
+    its = [m for m in msgs if m.split() and m.split()[0].isdigit()]
+    assert any('rel.step' in m for m in msgs) and len(its) >= 5 and any('center' in m for m in its)
+
+
 def test_dropin_early_exit_and_infeasible():
     from tunempc_amd import convexifier
     rng = np.random.default_rng(3)

@@ -85,6 +85,8 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0):
         if ng > NG_MAX:
             raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
     h = handle or _handle(p, nx, mb, ng, nc_hint, nb)      # nc_hint: room for the C rows of a Step 2 that may follow (same handle)
+    global _LAST_HANDLE
+    _LAST_HANDLE = h
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)      # per call: a cached handle never keeps an earlier caller's tolerance
     if ng > 0:
@@ -115,6 +117,8 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     if ng:
         J[:, :, :ng] = np.asarray(G, dtype=np.float64)
     J[:, :, h.ng:h.ng + nc] = C
+    global _LAST_HANDLE
+    _LAST_HANDLE = h
     out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
     FgF = out.pop('FgF')
     out['F'] = FgF[:, :, h.ng:h.ng + nc]
@@ -131,6 +135,8 @@ def convexify_step3_batch(A, B, H, rho, tol=None, handle=None):
     h = handle or _handle(p, nx, B.shape[3], 0, 0, nb, step3=True)
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
+    global _LAST_HANDLE
+    _LAST_HANDLE = h
     return h.convexify_step3_batch(A, B, H, rho)
 
 
@@ -159,6 +165,9 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
     return out
 
 
+_LAST_HANDLE = None      # handle of the most recent batch call (its iteration trace is the solver log of convexify())
+
+
 _IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged'}     # info[10]; plays the role of M.status (convexifier.py:365, :443)
 
 
@@ -166,6 +175,13 @@ def _log_solution(res):
     """The log lines of solveSDP (convexifier.py:365-370) and check_convergence (:441-453) for one solved problem."""
     status = STATUS_NAMES[int(res['status'][0])]
     ipm = _IPM_STATUS.get(int(res['info'][0, 10]), 'unknown')
+    # solver verbosity (convexifier.py:87-91: opts['verbose'] = 1 below INFO level): the iteration log of the device IPM
+    if Logger.logger.getEffectiveLevel() < 20 and _LAST_HANDLE is not None:
+        Logger.logger.debug(' it  phase        mu       kappa       pinf       dinf   step_p   step_d  rel.step')
+        for r in _LAST_HANDLE.trace(1)[0]:
+            if r[0] > 0:
+                Logger.logger.debug('{:3d} {:>6s} {:9.2e} {:11.4e} {:10.2e} {:10.2e} {:8.4f} {:8.4f} {:9.2e}'.format(
+                    int(r[0]), 'main' if r[1] < 1 else ('chord' if r[1] % 1 else 'center'), r[2], r[3], r[4], r[5], min(r[6], 1.0), min(r[7], 1.0), r[8]))
     if ipm == 'optimal':
         Logger.logger.debug('SDP solution:')
         Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
