@@ -40,6 +40,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 # tol: complementarity tolerance relative to the optimal value, mu_target = tol * kappa (per unit of cone
 # dimension; the relative duality gap on kappa is then N*tol with N = 2*p*n + 1).  2^-25 keeps the HKM Schur
 # complement a factor >= 10 away from the fp64 breakdown observed at mu ~ 1e-8.
+MUT_BACKOFF_MAX = 10      # mu_t back-offs per problem (hard targets)
 DEFAULT_OPTS = dict(tol=2.0 ** -25, max_iter=50, center_iter=12, center_tol=1e-9)
 
 
@@ -486,12 +487,13 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     ncent = 0
     njam = 0
     nshiftrun = 0
+    nbackoff = 0
     status = 'max_iter'
     it = 0
     shift_used = 0.0
     prev_stepn = None
     stepn = np.inf
-    for it in range(o['max_iter'] + o['center_iter'] + 1):
+    for it in range(o['max_iter'] + o['center_iter'] * (MUT_BACKOFF_MAX + 1) + 1):
         M = alpha * Hb + calH(A, B, P)
         if ng:
             M = M + np.einsum('ki,kiab->kab', phi, GG)
@@ -563,8 +565,13 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
           chol = _CyclicBlockChol(D, C)
           shift_used = max(shift_used, chol.shift)
           nshiftrun = nshiftrun + 1 if chol.shift > 0.0 else 0
+          if phase == 1 and chol.shift > 0.0 and nbackoff < MUT_BACKOFF_MAX:
+              # hard target (cond(T) ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the central-path point one
+              # power of two earlier and repeat the iteration from the same iterate (the HIP path: k_ctrl_c, tmpc_schur.h)
+              mu_t *= 2.0; nbackoff += 1; ncent = 0; prev_stepn = None; nshiftrun = 0
+              continue
           if (phase == 1 and chol.shift > 0.0) or nshiftrun >= 2:
-              # numerical breakdown of the Schur factorisation while centering (cond(T) ~ (tau/mu)^2): keep the last
+              # numerical breakdown of the Schur factorisation while centering: keep the last
               # iterate, strictly feasible and close to the central path at ~2 mu_t, and report it as inaccurate
               status = 'optimal_inaccurate'
               break
@@ -753,6 +760,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 status = 'optimal'        # rounding floor reached
                 break
             if ncent >= o['center_iter']:
+                if nbackoff < MUT_BACKOFF_MAX:
+                    mu_t *= 2.0; nbackoff += 1; ncent = 0; prev_stepn = None
+                    continue
                 status = 'optimal_inaccurate'
                 break
             prev_stepn = stepn if full else None

@@ -11,6 +11,8 @@
 
 namespace tmpc {
 
+constexpr int MUT_BACKOFF_MAX = 10;      // mu_t back-offs per problem (2^10: relative gap <= ~1e-4 * default at the worst)
+
 // HKM block entry 0.5*(T(Lx,Ls)+T(Ls,Lx))[(ab),(cd)] with T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>; the two T's
 // consist of the same four products, so the entry is T(Lx,Ls)[(ab),(cd)].
 __device__ __forceinline__ double hkm_entry(const double* __restrict__ Lx, const double* __restrict__ Ls, int ldk,
@@ -324,6 +326,12 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
       // (Larger lifts were tried: they damp the weakest eigen-direction, centering turns linear and a lockstep batch waits.)
       ip[I_REG] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
       ap = 0.0; ad = 0.0; retry = true;
+    } else if (phase == PH_CENTER && (froze || nonfin) && ip[I_BACKOFF] < MUT_BACKOFF_MAX) {
+      // hard target (cond(H) >~ 1e3: cond of the Schur matrix ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the
+      // central-path point one power of two earlier instead of giving up -- the problem then ends Optimal at the gap
+      // N * mu_t it reports in info[6] (the default is tol * kappa), not Feasible at an uncontrolled one
+      pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0;
+      ap = 0.0; ad = 0.0; retry = true;
     } else if ((phase == PH_CENTER && froze) || ip[I_SHIFTRUN] >= 2 || ip[I_JAM] >= 2 || nonfin) {
       ap = 0.0; ad = 0.0;
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
@@ -337,7 +345,8 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
     t[0] = (double)ip[I_ITERS]; t[1] = (double)phase + 0.25 * ip[I_CHORD];    // x.25: a chord step (factorisation re-used)
     t[2] = pr[P_MU]; t[3] = pr[P_TAU]; t[4] = pr[P_PINF]; t[5] = pr[P_DINF];
-    t[6] = ap; t[7] = (phase == PH_CENTER) ? pr[P_RAWSTEP] : ad; t[8] = pr[P_STEPN];     // centering: ap = ad = 1 on full steps; slot 7 holds the raw step length instead t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
+    t[6] = ap; t[7] = (phase == PH_CENTER) ? pr[P_RAWSTEP] : ad; t[8] = pr[P_STEPN];     // centering: ap = ad = 1 on full steps; slot 7 holds the raw step length instead
+    t[9] = (double)(ip[I_NSHIFT] + ip[I_CHOLBAD]);
   }
   if (!stopped) {        // (0 * NaN would poison the kept iterate)
     pr[P_X0] = x0 + ap * dx0; pr[P_S0] = s0 + ad * ds0;
@@ -360,13 +369,15 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     // extrapolated next step: between linear (r) and quadratic (r^2) convergence for Newton steps; a chord step (frozen
     // factorisation) converges linearly, its remaining error is ~ stepn * r / (1 - r) <= stepn for r <= 1/2
     const double est = was_chord ? stepn : stepn * rr * sqrt(rr);
-    bool chord_next = false;
+    bool chord_next = false, full_reset = false;
     if (full && (stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (!was_chord && full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
-    else if (ip[I_NCENT] >= o.center_iter) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
-    // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting there is
-    // nothing more to gain (and the rest of a lockstep batch is waiting)
-    else if (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+    // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting -- or the centering
+    // budget is spent -- there is nothing more to gain at this mu_t: back off to the next power of two (hard target), or stop
+    else if (ip[I_NCENT] >= o.center_iter || (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev)) {
+      if (ip[I_BACKOFF] < MUT_BACKOFF_MAX) { pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; full_reset = true; }
+      else { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+    }
     else if (o.chord_step > 0.0 && full && ip[I_REG] == 0) {
       // Chord steps: the last step moved the iterate by less than 1/chord_step in the local norm, so the Schur matrix at the new
       // iterate differs from the factored one by about that much and Newton with the OLD factorisation still contracts by that
@@ -377,7 +388,7 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     ip[I_CHORD] = (ip[I_PHASE] != PH_DONE && chord_next) ? 1 : 0;
     if (ip[I_CHORD]) ip[I_NCHORD] += 1;
     if (ip[I_PHASE] == PH_CENTER && ip[I_CHORD] == 0 && was_chord) ip[I_NCENT] -= 0;   // (a rejected chord step still counts as a centering iteration)
-    pr[P_PREVSTEPN] = full ? stepn : -1.0;
+    pr[P_PREVSTEPN] = (full && !full_reset) ? stepn : -1.0;
   }
   if (ip[I_PHASE] != PH_DONE) {
     const int slot = atomicAdd(w.active, 1); w.alist[slot] = b;
