@@ -360,9 +360,12 @@ static int set_lds_attrs(int device) {
   static bool done[64] = {false};
   if (device >= 0 && device < 64 && done[device]) return TMPC_OK;
   const int big = 160 * 1024;
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
+  HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
   HIPCHK(hipFuncSetAttribute((const void*)k_final_stage, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -470,6 +473,14 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
   }
 }
 
+// the per-stage kernels of the plain model run with four waves per stage (TMPC_STAGE_NT=64: one wave, the original form)
+static const int g_stage_nt = [] { const char* e = getenv("TMPC_STAGE_NT"); return (e && atoi(e) == 64) ? 64 : 256; }();
+#define TMPC_STAGE_LAUNCH(K, LDSB, ST, ...)                                                          \
+  do {                                                                                               \
+    if (g_stage_nt == 256) hipLaunchKernelGGL((K<256>), dim3(BP), dim3(256), LDSB, ST, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((K<64>), dim3(BP), dim3(64), LDSB, ST, __VA_ARGS__);                      \
+  } while (0)
+
 // one chunk (nb = actual number of problems in this chunk, <= capacity); inputs already on device
 static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const double* dB, const double* dH, hipStream_t st,
                      const double* dG = nullptr, const int32_t* dncnt = nullptr, double rho = 0.0, bool step3 = false) {
@@ -519,7 +530,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
-    hipLaunchKernelGGL(k_stage_pre, dim3(BP), dim3(64), slots_bytes(PRE_SLOTS), st, w, dm);
+    TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
     if (t3) hipLaunchKernelGGL(k_t3_pre, dim3(BP), dim3(64), t3_lds, st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
@@ -529,7 +540,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (h->flags & 8) {                     // debug (tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
-      hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
@@ -542,7 +553,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
-      hipLaunchKernelGGL(k_stage_rhs, dim3(BP), dim3(64), slots_bytes(RHS_SLOTS), st, w, dm, pass);
+      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
@@ -552,7 +563,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
-      hipLaunchKernelGGL(k_stage_dir, dim3(BP), dim3(64), slots_bytes(DIR_SLOTS), st, w, dm, pass);
+      TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
       hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
@@ -563,7 +574,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
         hipLaunchKernelGGL(k_ctrl_c, dim3(active), dim3(64), 0, st, w, dm);
       }
     }
-    hipLaunchKernelGGL(k_update, dim3(BP), dim3(64), 0, st, w, dm);
+    TMPC_STAGE_LAUNCH(k_update, 0, st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
     if (t3) hipLaunchKernelGGL(k_t3_update, dim3(BP), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));

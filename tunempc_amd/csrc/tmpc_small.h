@@ -29,45 +29,69 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// sum over the NT threads of the block (NT = 64: one wave, shuffles only; NT = 256: four wave sums joined through LDS).
+// Every thread gets the result.  Ends with a barrier for NT > 64.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v) {
+  v = wave_sum(v);
+  if (NT > 64) {
+    __shared__ double red_[NT / 64];
+    __syncthreads();                                  // (previous use of red_)
+    if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = 0.0;
+#pragma unroll
+    for (int q = 0; q < NT / 64; ++q) v += red_[q];
+  }
+  return v;
+}
+
+// The helpers below take the thread index `lane` in [0, NT) of a block of NT threads (NT = 64: one wave per stage, the original
+// form; NT = 256: four waves share the stage's matrices -- the same LDS, four times the loads in flight and a quarter of the
+// dependent work per wave; the stage kernels are latency-bound with one wave per SIMD).
 // global (rows x cols, row-major, ld = ldg) -> LDS slot (LD).  Coalesced along rows.
+template <int NT = 64>
 __device__ __forceinline__ void g2s(double* __restrict__ s, const double* __restrict__ g, int rows, int cols,
                                     int ldg, int lane) {
   const int tot = rows * cols;
   int e = lane;
-  for (; e + 192 < tot; e += 256) {            // four loads in flight per lane: one exposed memory latency per 256 elements
+  for (; e + 3 * NT < tot; e += 4 * NT) {      // four loads in flight per thread: one exposed memory latency per 4 NT elements
     int i[4], j[4]; double v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int eu = e + 64 * u; i[u] = eu / cols; j[u] = eu - i[u] * cols; v[u] = g[(size_t)i[u] * ldg + j[u]]; }
+    for (int u = 0; u < 4; ++u) { const int eu = e + NT * u; i[u] = eu / cols; j[u] = eu - i[u] * cols; v[u] = g[(size_t)i[u] * ldg + j[u]]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[i[u] * LD + j[u]] = v[u];
   }
-  for (; e < tot; e += 64) {
+  for (; e < tot; e += NT) {
     const int i = e / cols, j = e - i * cols;
     s[i * LD + j] = g[(size_t)i * ldg + j];
   }
   wsync();
 }
+template <int NT = 64>
 __device__ __forceinline__ void s2g(double* __restrict__ g, const double* __restrict__ s, int rows, int cols,
                                     int ldg, int lane) {
   const int tot = rows * cols;
-  for (int e = lane; e < tot; e += 64) {
+  for (int e = lane; e < tot; e += NT) {
     const int i = e / cols, j = e - i * cols;
     g[(size_t)i * ldg + j] = s[i * LD + j];
   }
   wsync();
 }
 // symmetrised store: g = (s + s')/2
+template <int NT = 64>
 __device__ __forceinline__ void s2g_sym(double* __restrict__ g, const double* __restrict__ s, int n, int lane) {
   const int tot = n * n;
-  for (int e = lane; e < tot; e += 64) {
+  for (int e = lane; e < tot; e += NT) {
     const int i = e / n, j = e - i * n;
     g[(size_t)i * n + j] = 0.5 * (s[i * LD + j] + s[j * LD + i]);
   }
   wsync();
 }
+template <int NT = 64>
 __device__ __forceinline__ void s_sym(double* s, int n, int lane) {   // in place (s+s')/2
   const int tot = n * n;
-  for (int e = lane; e < tot; e += 64) {
+  for (int e = lane; e < tot; e += NT) {
     const int i = e / n, j = e - i * n;
     if (j < i) {
       const double v = 0.5 * (s[i * LD + j] + s[j * LD + i]);
@@ -82,9 +106,9 @@ __device__ __forceinline__ void s_sym(double* s, int n, int lane) {   // in plac
 // B[k*brs + j*bcs]; C row-major with LD.  mode 0: '=', 1: '+=', 2: '-='.  M,N,K <= 32.
 // Lane (li,lj) = (lane>>3, lane&7) owns the 4x4 block rows 4li.., cols 4lj..; out-of-range rows/cols read
 // in-slot garbage that only reaches outputs which are never stored.
-__device__ __forceinline__ void mm(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
-                                   const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
-                                   int lane) {
+__device__ __forceinline__ void mm64(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
+                                     const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
+                                     int lane) {
   const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
   double acc[4][4];
 #pragma unroll
@@ -120,6 +144,48 @@ __device__ __forceinline__ void mm(double* __restrict__ C, const double* __restr
       }
   }
   wsync();
+}
+
+// the same product by 256 threads: thread (ti, tj) = (tid >> 4, tid & 15) owns the 2 x 2 block rows 2 ti.., cols 2 tj..
+__device__ __forceinline__ void mm256(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
+                                      const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
+                                      int tid) {
+  const int i0 = (tid >> 4) * 2, j0 = (tid & 15) * 2;
+  double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+  if (i0 < M && j0 < N) {
+    const double* ap = A + i0 * ars;
+    const double* bp = B + j0 * bcs;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const double x0 = ap[k * acs], x1 = ap[ars + k * acs];
+      const double y0 = bp[k * brs], y1 = bp[bcs + k * brs];
+      a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
+    }
+  }
+  wsync();   // all reads of A/B done before C (which may alias a consumed operand slot) is written
+  if (i0 < M && j0 < N) {
+    const double v[2][2] = {{a00, a01}, {a10, a11}};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int i = i0 + r, j = j0 + c;
+        if (i < M && j < N) {
+          double* p = &C[i * LD + j];
+          if (mode == 0) *p = v[r][c];
+          else if (mode == 1) *p += v[r][c];
+          else *p -= v[r][c];
+        }
+      }
+  }
+  wsync();
+}
+template <int NT = 64>
+__device__ __forceinline__ void mm(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
+                                   const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
+                                   int lane) {
+  if (NT == 256) mm256(C, A, ars, acs, B, brs, bcs, M, N, K, mode, lane);
+  else mm64(C, A, ars, acs, B, brs, bcs, M, N, K, mode, lane);
 }
 
 // 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps
@@ -193,9 +259,9 @@ __device__ __forceinline__ void tri_inv_lower(double* __restrict__ Li, const dou
 // by v_readlane) -- the two dependency chains share every barrier and every latency, so the pair costs what one costs.
 __device__ __forceinline__ int chol_lower_pair(double* A, double* B, int n, int lane) {
   int nbad = 0;
-  const int row = lane & 31, half = lane >> 5;
+  const int row = lane & 31, half = (lane >> 5) & 1;
   double* Mx = half ? B : A;
-  const bool mine = row < n;
+  const bool mine = row < n && lane < 64;        // (blocks of more than one wave: the first wave works, the others keep the barriers)
   for (int j = 0; j < n; ++j) {
     double sij = 0.0;
     if (mine && row >= j) {
@@ -221,7 +287,8 @@ __device__ __forceinline__ int chol_lower_pair(double* A, double* B, int n, int 
 // LiA = LA^-1 (lanes 0..31) and LiB = LB^-1 (lanes 32..63), one lane per column
 __device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, const double* __restrict__ LA,
                                                    double* __restrict__ LiB, const double* __restrict__ LB, int n, int lane) {
-  const int c = lane & 31, half = lane >> 5;
+  const int c = lane & 31, half = (lane >> 5) & 1;
+  const bool first = lane < 64;                  // (blocks of more than one wave: the first wave works, the others keep the barriers)
   const double* L = half ? LB : LA;
   double* Li = half ? LiB : LiA;
   double rdl = 1.0;
@@ -230,7 +297,7 @@ __device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, con
     const double ra = __shfl(rdl, i, 64), rb = __shfl(rdl, 32 + i, 64);
     const double rdi = half ? rb : ra;
     double acc = 0.0;
-    if (c < i) {
+    if (c < i && first) {
       const double* li = L + i * LD;
       double a0 = 0.0, a1 = 0.0;
       int k = c;
@@ -238,7 +305,7 @@ __device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, con
       if (k < i) a0 = fma(li[k], Li[k * LD + c], a0);
       acc = a0 + a1;
     }
-    if (c < n) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
+    if (c < n && first) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
     wsync();
   }
 }
@@ -405,14 +472,16 @@ __device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, do
 }
 
 // <A, B> over the n x n leading block (both LDS)
+template <int NT = 64>
 __device__ __forceinline__ double dot_ss(const double* A, const double* B, int n, int lane) {
   double acc = 0.0;
-  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; acc = fma(A[i * LD + j], B[i * LD + j], acc); }
-  return wave_sum(acc);
+  for (int e = lane; e < n * n; e += NT) { const int i = e / n, j = e - i * n; acc = fma(A[i * LD + j], B[i * LD + j], acc); }
+  return block_sum<NT>(acc);
 }
+template <int NT = 64>
 __device__ __forceinline__ double trace_s(const double* A, int n, int lane) {
   double acc = (lane < n) ? A[lane * LD + lane] : 0.0;
-  return wave_sum(acc);
+  return block_sum<NT>(acc);
 }
 
 }  // namespace tmpc

@@ -25,9 +25,10 @@ __device__ __forceinline__ int stage_id4(const WS& w, const Dims& dm) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
 
 // transposed store of the leading rows x cols block: g[j*ldg + i] = s[i][j]
+template <int NT = 64>
 __device__ __forceinline__ void s2g_T(double* g, const double* s, int rows, int cols, int ldg, int lane) {
   const int tot = rows * cols;
-  for (int e = lane; e < tot; e += 64) {
+  for (int e = lane; e < tot; e += NT) {
     const int j = e / rows, i = e - j * rows;
     g[(size_t)j * ldg + i] = s[i * LD + j];
   }
@@ -118,13 +119,14 @@ __global__ void __launch_bounds__(64) k_init_state(WS w, Dims dm) {
 
 // ------------------------------------------------------------------ M_k (or dM_k) into an LDS slot
 // out = coef*Hb_k + V' Pn V - E' Pk E ; uses sV (already loaded), scratch slots t0,t1,sHb
+template <int NT = 64>
 __device__ __forceinline__ void build_M(double* out, const double* sV, double* t0, double* t1, const double* sHb,
                                         const double* Pk, const double* Pn, double coef, int n, int nx, int lane) {
-  g2s(t0, Pn, nx, nx, nx, lane);
-  mm(t1, sV, 1, LD, t0, LD, 1, n, nx, nx, 0, lane);        // V' Pn   (n x nx)
-  mm(out, t1, LD, 1, sV, LD, 1, n, n, nx, 0, lane);        // (V' Pn) V
-  g2s(t0, Pk, nx, nx, nx, lane);
-  for (int e = lane; e < n * n; e += 64) {
+  g2s<NT>(t0, Pn, nx, nx, nx, lane);
+  mm<NT>(t1, sV, 1, LD, t0, LD, 1, n, nx, nx, 0, lane);        // V' Pn   (n x nx)
+  mm<NT>(out, t1, LD, 1, sV, LD, 1, n, n, nx, 0, lane);        // (V' Pn) V
+  g2s<NT>(t0, Pk, nx, nx, nx, lane);
+  for (int e = lane; e < n * n; e += NT) {
     const int i = e / n, j = e - i * n;
     double v = out[i * LD + j] + coef * sHb[i * LD + j];
     if (i < nx && j < nx) v -= t0[i * LD + j];
@@ -134,9 +136,10 @@ __device__ __forceinline__ void build_M(double* out, const double* sV, double* t
 }
 
 // V G V' (nx x nx) into `out`, scratch t
+template <int NT = 64>
 __device__ __forceinline__ void adj_V(double* out, double* t, const double* sV, const double* G, int n, int nx, int lane) {
-  mm(t, sV, LD, 1, G, LD, 1, nx, n, n, 0, lane);           // V G    (nx x n)
-  mm(out, t, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);        // (V G) V'
+  mm<NT>(t, sV, LD, 1, G, LD, 1, nx, n, n, 0, lane);           // V G    (nx x n)
+  mm<NT>(out, t, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);        // (V G) V'
 }
 
 // rows of [G_k; C_k] present at stage sid
@@ -146,8 +149,9 @@ __device__ __forceinline__ int stage_rows(const WS& w, const Dims& dm, size_t si
   return dm.ng + nc;
 }
 // out (n x n LDS slot) += scale * sum_i coef[i] g_i g_i'   (equality-constraint term, G rows and coefficients in global memory)
+template <int NT = 64>
 __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const double* coef, double scale, int ng, int n, int lane) {
-  for (int e = lane; e < n * n; e += 64) {
+  for (int e = lane; e < n * n; e += NT) {
     const int i = e / n, j = e - i * n;
     double acc = 0.0;
     for (int r = 0; r < ng; ++r) acc = fma(scale * coef[r] * Gg[r * n + i], Gg[r * n + j], acc);
@@ -157,8 +161,9 @@ __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const dou
 }
 
 // out (n x n LDS slot) += scale * smat(theta): the regularisation T_k of Step 3 (tmpc_t3.h), theta = its entries (a <= b), row-major upper triangle
+template <int NT = 64>
 __device__ __forceinline__ void add_smat_t3(double* out, const double* th, double scale, int n, int lane) {
-  for (int e = lane; e < n * n; e += 64) {
+  for (int e = lane; e < n * n; e += NT) {
     const int i = e / n, j = e - i * n;
     const int a = i < j ? i : j, b = i < j ? j : i;
     out[i * LD + j] += scale * th[a * n - a * (a - 1) / 2 + (b - a)];
@@ -168,7 +173,8 @@ __device__ __forceinline__ void add_smat_t3(double* out, const double* th, doubl
 
 constexpr int PRE_SLOTS = 9;     // 76 KB of LDS: two single-wave blocks per CU
 // ------------------------------------------------------------------ stage_pre
-__global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
@@ -181,12 +187,12 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   double* t2 = sS;        // the S slot is free once L^-1 has been formed
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   TMPC_T0()
-  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   TMPC_T(8)
-  build_M(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
-  if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
-  if (dm.nT > 0) add_smat_t3(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
+  build_M<NT>(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
+  if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
+  if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
   TMPC_T(9)
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0;
   int nbad = 0;
@@ -195,7 +201,7 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   for (int r = 0; r < 2; ++r) {
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
     double* Rdg = (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += 64) {
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       const double m = sM[i * LD + j], sv = Sg[e];
       const double dg = (i == j) ? 1.0 : 0.0;
@@ -209,46 +215,46 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
-    g2s(sX, Xg, n, n, n, lane);
-    g2s(sS, Sg, n, n, n, lane);
+    g2s<NT>(sX, Xg, n, n, n, lane);
+    g2s<NT>(sS, Sg, n, n, n, lane);
     TMPC_T(8)
-    for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
+    for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
-      const double hx = dot_ss(sHb, sX, n, lane);
-      if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s(sX, n, lane); }
+      const double hx = dot_ss<NT>(sHb, sX, n, lane);
+      if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s<NT>(sX, n, lane); }
     }
     // S_r = L L', X_r = Lx Lx' (for the primal step length) and both inverses, the two matrices side by side in one wave
-    for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
+    for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
     wsync();
     TMPC_T(10)
     nbad += chol_lower_pair(sS, t0, n, lane);
     TMPC_T(11)
     tri_inv_lower_pair(sLi, sS, t1, t0, n, lane);
     TMPC_T(12)
-    s2g((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
-    s2g((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
+    s2g<NT>((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
+    s2g<NT>((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
     TMPC_T(13)
-    mm(sSi, sLi, 1, LD, sLi, LD, 1, n, n, n, 0, lane);                   // Li' Li
+    mm<NT>(sSi, sLi, 1, LD, sLi, LD, 1, n, n, n, 0, lane);                   // Li' Li
     TMPC_T(14)
-    s_sym(sSi, n, lane);
-    s2g((r ? w.S2i : w.S1i) + (size_t)sid * nn, sSi, n, n, n, lane);
+    s_sym<NT>(sSi, n, lane);
+    s2g<NT>((r ? w.S2i : w.S1i) + (size_t)sid * nn, sSi, n, n, n, lane);
     TMPC_T(13)
     // Kronecker factors of the HKM Schur blocks
     double* kfr = kf + (size_t)r * KF_PER_LMI * nxx;
-    mm(t0, sV, LD, 1, sX, LD, 1, nx, n, n, 0, lane);                     // V X     (nx x n)
-    mm(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);                    // V X V'
-    s2g(kfr + KF_KX * nxx, t1, nx, nx, nx, lane);
-    s2g_T(kfr + KF_FX * nxx, t0, nx, nx, nx, lane);                      // Fx = X[:nx,:] V' = ((VX)[:, :nx])'
-    s2g(kfr + KF_XXX * nxx, sX, nx, nx, nx, lane);
-    mm(t0, sV, LD, 1, sSi, LD, 1, nx, n, n, 0, lane);                    // V Si
-    mm(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);
-    s2g(kfr + KF_KS * nxx, t1, nx, nx, nx, lane);
-    s2g_T(kfr + KF_FS * nxx, t0, nx, nx, nx, lane);
-    s2g(kfr + KF_SIXX * nxx, sSi, nx, nx, nx, lane);
+    mm<NT>(t0, sV, LD, 1, sX, LD, 1, nx, n, n, 0, lane);                     // V X     (nx x n)
+    mm<NT>(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);                    // V X V'
+    s2g<NT>(kfr + KF_KX * nxx, t1, nx, nx, nx, lane);
+    s2g_T<NT>(kfr + KF_FX * nxx, t0, nx, nx, nx, lane);                      // Fx = X[:nx,:] V' = ((VX)[:, :nx])'
+    s2g<NT>(kfr + KF_XXX * nxx, sX, nx, nx, nx, lane);
+    mm<NT>(t0, sV, LD, 1, sSi, LD, 1, nx, n, n, 0, lane);                    // V Si
+    mm<NT>(t1, t0, LD, 1, sV, 1, LD, nx, nx, n, 0, lane);
+    s2g<NT>(kfr + KF_KS * nxx, t1, nx, nx, nx, lane);
+    s2g_T<NT>(kfr + KF_FS * nxx, t0, nx, nx, nx, lane);
+    s2g<NT>(kfr + KF_SIXX * nxx, sSi, nx, nx, nx, lane);
     // Phi_r(Hb) = sym(X Hb Si)
-    mm(t0, sX, LD, 1, sHb, LD, 1, n, n, n, 0, lane);
-    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
-    for (int e = lane; e < nn; e += 64) {
+    mm<NT>(t0, sX, LD, 1, sHb, LD, 1, n, n, n, 0, lane);
+    mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       const double phi = 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
       if (r == 0) sPhi[i * LD + j] = phi; else sPhi[i * LD + j] += phi;
@@ -256,22 +262,22 @@ __global__ void __launch_bounds__(64) k_stage_pre(WS w, Dims dm) {
     }
     wsync();
     if (r == 1) {
-      mm(t0, sX, LD, 1, sSi, LD, 1, n, n, n, 0, lane);                   // Psi = sym(X2 S2i)
-      s_sym(t0, n, lane);
-      trpsi = trace_s(t0, n, lane);
-      if (dm.nT > 0) s2g(w.t3psi + (size_t)sid * nn, t0, n, n, n, lane);
-      adj_V(t1, t2, sV, t0, n, nx, lane);
-      s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t1, nx, nx, nx, lane);
-      s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx, lane);
+      mm<NT>(t0, sX, LD, 1, sSi, LD, 1, n, n, n, 0, lane);                   // Psi = sym(X2 S2i)
+      s_sym<NT>(t0, n, lane);
+      trpsi = trace_s<NT>(t0, n, lane);
+      if (dm.nT > 0) s2g<NT>(w.t3psi + (size_t)sid * nn, t0, n, n, n, lane);
+      adj_V<NT>(t1, t2, sV, t0, n, nx, lane);
+      s2g<NT>(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t1, nx, nx, nx, lane);
+      s2g<NT>(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx, lane);
     }
   }
   TMPC_T(15)
-  const double hbphi = dot_ss(sHb, sPhi, n, lane);
-  if (dm.nT > 0) s2g(w.t3phi + (size_t)sid * nn, sPhi, n, n, n, lane);
-  adj_V(t1, t2, sV, sPhi, n, nx, lane);
-  s2g(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
-  s2g(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, sPhi, nx, nx, nx, lane);
-  rd2 = wave_sum(rd2); s2 = wave_sum(s2); xs = wave_sum(xs); trphi2 = wave_sum(trphi2);
+  const double hbphi = dot_ss<NT>(sHb, sPhi, n, lane);
+  if (dm.nT > 0) s2g<NT>(w.t3phi + (size_t)sid * nn, sPhi, n, n, n, lane);
+  adj_V<NT>(t1, t2, sV, sPhi, n, nx, lane);
+  s2g<NT>(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
+  s2g<NT>(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, sPhi, nx, nx, nx, lane);
+  rd2 = block_sum<NT>(rd2); s2 = block_sum<NT>(s2); xs = block_sum<NT>(xs); trphi2 = block_sum<NT>(trphi2);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
     q[Q_XS] = xs; q[Q_RD2] = rd2; q[Q_S2] = s2; q[Q_TRX2] = trx2; q[Q_HBY] = hby;
@@ -283,7 +289,8 @@ constexpr int RHS_SLOTS = 8;
 // ------------------------------------------------------------------ stage_rhs: T_r and the adjoint of G = T1 - T2
 // pass 1 = predictor (sigma*mu = 0, no corrector term; main-phase problems only)
 // pass 2 = corrector (main phase) or pure centering step (centering phase)
-__global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_stage_rhs(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -293,17 +300,17 @@ __global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
   const bool use_corr = (pass == 2 && phase == PH_MAIN);
   double* sV = sm; double* sX = sm + MS; double* sSi = sm + 2 * MS; double* sRd = sm + 3 * MS;
   double* t0 = sm + 4 * MS; double* t1 = sm + 5 * MS; double* sG = sm + 6 * MS; double* sHb = sm + 7 * MS;
-  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   double trt2 = 0.0;
   for (int r = 0; r < 2; ++r) {
-    g2s(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
-    g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
-    g2s(sRd, (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn, n, n, n, lane);
-    mm(t0, sX, LD, 1, sRd, LD, 1, n, n, n, 0, lane);
-    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    g2s<NT>(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
+    g2s<NT>(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    g2s<NT>(sRd, (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn, n, n, n, lane);
+    mm<NT>(t0, sX, LD, 1, sRd, LD, 1, n, n, n, 0, lane);
+    mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
     double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
     const double* cg = (r ? w.c2 : w.c1) + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += 64) {
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       double t = sig * sSi[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
       if (use_corr) t -= cg[e];
@@ -312,12 +319,12 @@ __global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
     }
     wsync();
   }
-  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
-  const double hbg = dot_ss(sHb, sG, n, lane);
-  adj_V(t1, t0, sV, sG, n, nx, lane);
-  s2g(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx, lane);
-  s2g(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, sG, nx, nx, nx, lane);
-  trt2 = wave_sum(trt2);
+  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  const double hbg = dot_ss<NT>(sHb, sG, n, lane);
+  adj_V<NT>(t1, t0, sV, sG, n, nx, lane);
+  s2g<NT>(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx, lane);
+  s2g<NT>(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, sG, nx, nx, nx, lane);
+  trt2 = block_sum<NT>(trt2);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
     q[Q_TRT2] = trt2; q[Q_HBG] = hbg;
@@ -326,7 +333,8 @@ __global__ void __launch_bounds__(64) k_stage_rhs(WS w, Dims dm, int pass) {
 
 constexpr int DIR_SLOTS = 9;      // 76 KB of LDS: two single-wave blocks per CU
 // ------------------------------------------------------------------ stage_dir: dS, dX, step-length eigenvalues, corrector term
-__global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_stage_dir(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -338,12 +346,12 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   double* sHb = sm + 8 * MS;
   double* sL = sHb;       // Hb is only needed to build dM
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
-  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   const double* dPk = w.dP + (size_t)sid * nxx;
-  build_M(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
-  if (dm.nr > 0) add_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
-  if (dm.nT > 0) add_smat_t3(sM, w.t3dth + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + dT_k
+  build_M<NT>(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
+  if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
+  if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3dth + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + dT_k
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
@@ -352,10 +360,10 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
     const double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
     double* dSg = (r ? w.dS2 : w.dS1) + (size_t)sid * nn;
     double* dXg = (r ? w.dX2 : w.dX1) + (size_t)sid * nn;
-    g2s(sX, Xg, n, n, n, lane);
-    g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    g2s<NT>(sX, Xg, n, n, n, lane);
+    g2s<NT>(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
     // sDX := Ldy = dS - Rd   (linear part of the slack direction)
-    for (int e = lane; e < nn; e += 64) {
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       const double dm_ = sM[i * LD + j];
       const double ldy = (r == 0) ? dm_ : ((i == j ? dtau : 0.0) - dm_);
@@ -365,9 +373,9 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
       dSg[e] = ds;
     }
     wsync();
-    mm(t0, sX, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
-    mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
-    for (int e = lane; e < nn; e += 64) {
+    mm<NT>(t0, sX, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
+    mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       const double dx = Tg[e] - sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
       sDX[i * LD + j] = dx;
@@ -378,18 +386,18 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
     wsync();
     // step-length matrices  W_S = L^-1 dS L^-T  and  W_X = LX^-1 dX LX^-T ; their smallest eigenvalues are
     // computed by k_eigmin (one wave per matrix, 16 waves per CU) -- slots 2r (dual) and 2r+1 (primal)
-    g2s(sL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
-    mm(t0, sL, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
-    mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
-    s2g_sym(w.Wm + ((size_t)sid * 4 + 2 * r) * nn, t1, n, lane);
-    g2s(sL, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
-    mm(t0, sL, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
-    mm(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
-    s2g_sym(w.Wm + ((size_t)sid * 4 + 2 * r + 1) * nn, t1, n, lane);
+    g2s<NT>(sL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
+    mm<NT>(t0, sL, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
+    mm<NT>(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
+    s2g_sym<NT>(w.Wm + ((size_t)sid * 4 + 2 * r) * nn, t1, n, lane);
+    g2s<NT>(sL, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
+    mm<NT>(t0, sL, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
+    mm<NT>(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
+    s2g_sym<NT>(w.Wm + ((size_t)sid * 4 + 2 * r + 1) * nn, t1, n, lane);
     if (pass == 1) {   // Mehrotra second-order term  sym(dX dS S^-1)
-      mm(t0, sDX, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
-      mm(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
-      s2g_sym((r ? w.c2 : w.c1) + (size_t)sid * nn, t1, n, lane);
+      mm<NT>(t0, sDX, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
+      mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
+      s2g_sym<NT>((r ? w.c2 : w.c1) + (size_t)sid * nn, t1, n, lane);
     }
   }
   // first-order relative change of the output Hc_k = M_k/(s*alpha):  dM_k - (dalpha/alpha) M_k,  M_k = S1 + Rd1 + I
@@ -397,18 +405,18 @@ __global__ void __launch_bounds__(64) k_stage_dir(WS w, Dims dm, int pass) {
   {
     const double ra = dalpha / pr[P_ALPHA];
     const double* S1g = w.S1 + (size_t)sid * nn; const double* R1g = w.Rd1 + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += 64) {
+    for (int e = lane; e < nn; e += NT) {
       const int i = e / n, j = e - i * n;
       const double m = S1g[e] + R1g[e] + (i == j ? 1.0 : 0.0);
       const double dh = sM[i * LD + j] - ra * m;
       dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
     }
-    dh2 = wave_sum(dh2); m2 = wave_sum(m2);
+    dh2 = block_sum<NT>(dh2); m2 = block_sum<NT>(m2);
   }
   double dp2 = 0.0, p2 = 0.0;
   const double* Pk = w.P + (size_t)sid * nxx;
-  for (int e = lane; e < nxx; e += 64) { dp2 = fma(dPk[e], dPk[e], dp2); p2 = fma(Pk[e], Pk[e], p2); }
-  dxs = wave_sum(dxs); xds = wave_sum(xds); dxds = wave_sum(dxds); dp2 = wave_sum(dp2); p2 = wave_sum(p2);
+  for (int e = lane; e < nxx; e += NT) { dp2 = fma(dPk[e], dPk[e], dp2); p2 = fma(Pk[e], Pk[e], p2); }
+  dxs = block_sum<NT>(dxs); xds = block_sum<NT>(xds); dxds = block_sum<NT>(dxds); dp2 = block_sum<NT>(dp2); p2 = block_sum<NT>(p2);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
     q[Q_DXS] = dxs; q[Q_XDS] = xds; q[Q_DXDS] = dxds; q[Q_DP2] = dp2; q[Q_P2] = p2; q[Q_DH2] = dh2; q[Q_M2] = m2;
@@ -435,7 +443,8 @@ __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
 }
 
 // ------------------------------------------------------------------ update: X += ap dX, S += ad dS, P += ad dP
-__global__ void __launch_bounds__(64) k_update(WS w, Dims dm) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_update(WS w, Dims dm) {
   TMPC_STAGE_PROLOGUE
   (void)sm;
   const int* ip = w.iprob + (size_t)b * IS;
@@ -444,7 +453,7 @@ __global__ void __launch_bounds__(64) k_update(WS w, Dims dm) {
   const double ap = pr[P_AP], ad = pr[P_AD];
   if (ap == 0.0 && ad == 0.0) return;      // discarded direction (it may hold NaN: 0 * NaN would poison the iterate)
   const size_t o = (size_t)sid * nn;
-  for (int e = lane; e < nn; e += 64) {
+  for (int e = lane; e < nn; e += NT) {
     const int i = e / n, j = e - i * n;
     const int et = j * n + i;
     if (j <= i) {
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(64) k_update(WS w, Dims dm) {
       w.S1[o + e] = s1; w.S1[o + et] = s1; w.S2[o + e] = s2; w.S2[o + et] = s2;
     }
   }
-  for (int e = lane; e < nxx; e += 64) w.P[(size_t)sid * nxx + e] += ad * w.dP[(size_t)sid * nxx + e];
+  for (int e = lane; e < nxx; e += NT) w.P[(size_t)sid * nxx + e] += ad * w.dP[(size_t)sid * nxx + e];
 }
 
 constexpr int FIN_SLOTS = 6;
