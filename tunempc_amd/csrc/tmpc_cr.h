@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, in
   }
 }
 
+constexpr int UPD_DMA_DEPTH = 2;                       // LDS buffers of the LDS-DMA tile GEMM in the batched kernels
 // ---- phase 2: O_x <- T[x,i] L_i^-T for the (up to) two neighbours, `rs` rows per workgroup
 // NS = 2: 32-column K slabs, 70 KB of LDS, two workgroups per CU; NS = 1: 16-column slabs, 35 KB, three per CU
 template <bool USE_MFMA, int NS>
@@ -679,7 +680,6 @@ __global__ void __launch_bounds__(256, (NS == 1 && FA == 2) ? 4 : ((NS == 1) ? 3
 }
 
 // The same items on the LDS-DMA core (tmpc_gemm_dma.h): 64 x 64 tiles, the two edges of a doubly updated node as ONE K stream.
-constexpr int UPD_DMA_DEPTH = 2;
 __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
   const int dp = dm.dp;
   const int nm = (dp + 63) / 64;

@@ -310,6 +310,13 @@ __device__ __forceinline__ void store_d16(double* Cp, int ldc, double4_t v, int 
 // the 16 dependent steps; the inverse is then solved column by column (lane c owns column c, 16 registers) against the factor
 // read back from LDS through wave-uniform addresses, all loops unrolled.  (The LDS version spent 39 k cycles per block in
 // divergent dependent loops -- half of the whole k_cr_potrf kernel: profiles/r2v_cycle_prof_potrf.txt.)
+// 1/sqrt(x), x > 0: v_rsq_f64 (~2^-26) + two Newton steps (full double precision)
+__device__ __forceinline__ double potrf_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
 __device__ __forceinline__ double wave_bcast(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
@@ -328,7 +335,7 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
     const bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
     if (piv < 1e-8 * ref) minr = fmin(minr, fmax(piv, 0.0) / ref);      // (division only on the rare small pivots)
     if (bad) { nbad += 1.0; piv = (ref > 0.0 ? ref : 1.0) * 1e20; }
-    const double dj = sqrt(piv), rinv = 1.0 / dj;
+    const double rinv = potrf_rsqrt(piv), dj = piv * rinv;          // (sqrt + division were half of the dependent chain of a step)
     ri[j] = rinv;
     a[j] = (r == j) ? dj : a[j] * rinv;              // rows above the diagonal carry unused values
 #pragma unroll
@@ -365,7 +372,18 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
   double* Si = S + 64 * LDP;               // 64 x 65
   double* dr = Si + 64 * LDP;              // 64 pivot references, [65] = shift counter, [66] = smallest pivot / reference
   double* tmp = dr + 72 + wv * (16 * 17);  // one 16 x 17 scratch block per wave
-  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; S[i * LDP + j] = T[(size_t)i * ldt + j]; Si[i * LDP + j] = 0.0; }
+  {                                        // thread -> row tid >> 2, 16 consecutive columns: eight 16-byte loads in flight, then the LDS stores
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+    double2_t v[8];
+    const bool on = i < nb && j0 < nb;
+    if (on) {
+      gcptr2 src = (gcptr2)(T + (size_t)i * ldt + j0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { S[i * LDP + j0 + 2 * q] = v[q][0]; S[i * LDP + j0 + 2 * q + 1] = v[q][1]; Si[i * LDP + j0 + 2 * q] = 0.0; Si[i * LDP + j0 + 2 * q + 1] = 0.0; }
+    }
+  }
   if (tid < nb) dr[tid] = dref[tid];
   if (tid == 0) { dr[65] = 0.0; dr[66] = 1.0; }
   __syncthreads();
@@ -414,10 +432,20 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
     __syncthreads();
   }
   TMPC_TC(7, 3)
-  for (int e = tid; e < nb * nb; e += 256) {
-    const int i = e / nb, j = e - i * nb;
-    if (j <= i) T[(size_t)i * ldt + j] = S[i * LDP + j];
-    Ti[i * TB + j] = Si[i * LDP + j];
+  {
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+    if (i < nb && j0 < nb) {
+      typedef double2_t __attribute__((address_space(1)))* gptr2;
+      gptr2 dt = (gptr2)(T + (size_t)i * ldt + j0);
+      gptr2 di = (gptr2)(Ti + i * TB + j0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + 2 * q;
+        di[q] = (double2_t){Si[i * LDP + j], Si[i * LDP + j + 1]};
+        if (j + 1 <= i) dt[q] = (double2_t){S[i * LDP + j], S[i * LDP + j + 1]};
+        else if (j <= i) T[(size_t)i * ldt + j] = S[i * LDP + j];
+      }
+    }
   }
   __syncthreads();
   TMPC_TC(7, 4)

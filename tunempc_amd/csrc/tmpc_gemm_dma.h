@@ -30,7 +30,8 @@ __device__ __forceinline__ int dma_sw(int r) { return (r & 7) ^ (((r >> 3) & 1) 
 
 template <int DEPTH>
 __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0, const double* B0, const double* A1, const double* B1, int ld,
-                                            int M, int N, int K, int mode, int tri, int rot, double* lds) {
+                                            int M, int N, int K, int mode, int tri, int rot, double* lds, int ldb = 0) {
+  if (ldb == 0) ldb = ld;                                   // leading dimension of the B operands (default: as A)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wc0 = ((wv + rot) & 3) * 16;
   const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
@@ -38,17 +39,18 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
   int i0 = 0;
   if (tri != GM_NOTRI) { i0 = (tri + wc0) >> 4; if (i0 < 0) i0 = 0; }        // row fragments above the strip's first column are not needed
   const int i1 = (M + 15) >> 4;
-  const unsigned abytes = ((unsigned)(M - 1) * (unsigned)ld + (unsigned)K) * 8u, bbytes = ((unsigned)(N - 1) * (unsigned)ld + (unsigned)K) * 8u;
+  const unsigned abytes = ((unsigned)(M - 1) * (unsigned)ld + (unsigned)K) * 8u, bbytes = ((unsigned)(N - 1) * (unsigned)ldb + (unsigned)K) * 8u;
   const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)A0, 0, (int)abytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc((void*)B0, 0, (int)bbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(A1 ? A1 : A0), 0, (int)abytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)(B1 ? B1 : B0), 0, (int)bbytes, 0x00020000);
   // DMA: wave wv moves rows 16 wv .. 16 wv + 15 of both operands, two instructions of 8 rows each
-  unsigned vo[2];
+  unsigned vo[2], vob[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = wv * 16 + 8 * h + (lane >> 3), c = lane & 7;
     vo[h] = (unsigned)(row * ld + 2 * (c ^ dma_sw(row))) * 8u;
+    vob[h] = (unsigned)(row * ldb + 2 * (c ^ dma_sw(row))) * 8u;
   }
   // fragment read offsets (doubles) inside a slab, one per half hh of the 16-column slab (K pairs 4 hh + fk)
   int oa[2], ob[4][2];
@@ -78,10 +80,10 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                       \
       if (second_) {                                                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, (lds_vptr)(As_ + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb1, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb1, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vob[h], so_, 0, 0); \
       } else {                                                                                            \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, (lds_vptr)(As_ + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb0, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vo[h], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb0, (lds_vptr)(As_ + 1024 + (wv * 16 + 8 * h) * 16), 16, vob[h], so_, 0, 0); \
       }                                                                                                   \
     }                                                                                                     \
   }
