@@ -422,10 +422,14 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
     wsync();
     if (lane < m) vv[96 + lane] = pi - kk * vv[lane];     // w
     wsync();
-    // A22 -= v w' + w v'
-    for (int e = lane; e < m * m; e += 64) {
-      const int r = e / m, c = e - r * m;
-      A[(j + 1 + r) * LD + j + 1 + c] -= vv[r] * vv[96 + c] + vv[96 + r] * vv[c];
+    // A22 -= v w' + w v'   (two lanes per row, alternate columns: no index division, v_r and w_r stay in registers)
+    {
+      const int r = lane & 31, c0 = lane >> 5;
+      if (r < m) {
+        const double vr = vv[r], wr = vv[96 + r];
+        double* ar = A + (j + 1 + r) * LD + j + 1;
+        for (int c = c0; c < m; c += 2) ar[c] -= vr * vv[96 + c] + wr * vv[c];
+      }
     }
     wsync();
   }
@@ -445,14 +449,20 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
   for (int round = 0; round < 7 && (hi - lo) > 4e-16 * fmax(scale, 1e-300); ++round) {
     const double h = (hi - lo) / 65.0;
     const double sig = lo + h * (double)(lane + 1);
+    // Sturm count without divisions: p_i = (d_{i-1} - sigma) p_{i-1} - e_{i-2}^2 p_{i-2}; the number of sign changes of p_0 .. p_n is
+    // the number of eigenvalues below sigma (a zero takes the sign opposite to its predecessor); rescaled against overflow
     int cnt = 0;
-    double q = dd[0] - sig;
-    if (q < 0.0) ++cnt;
+    double pm = 1.0, pc = dd[0] - sig;
+    if (pc == 0.0) pc = -1e-300;
+    if (pc < 0.0) ++cnt;
     for (int i = 1; i < n; ++i) {
-      if (fabs(q) < 1e-300) q = (q < 0.0) ? -1e-300 : 1e-300;
       const double e2 = ee[i - 1] * ee[i - 1];
-      q = dd[i] - sig - e2 / q;
-      if (q < 0.0) ++cnt;
+      double pn = fma(dd[i] - sig, pc, -e2 * pm);
+      if (pn == 0.0) pn = (pc < 0.0) ? 1e-300 : -1e-300;
+      if ((pn < 0.0) != (pc < 0.0)) ++cnt;
+      const double big = fmax(fabs(pn), fabs(pc));
+      const double sc = (big > 1e100) ? 1e-100 : ((big < 1e-100) ? 1e100 : 1.0);
+      pm = pc * sc; pc = pn * sc;
     }
     // number of shifts with zero eigenvalues below them
     const unsigned long long mask = __ballot(cnt == 0);
