@@ -373,7 +373,8 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_rr, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)(k_cr_update<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -437,7 +438,11 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     static const int trsm_rr = [] { const char* e = getenv("TMPC_TRSM_RR"); return e ? atoi(e) : 2; }();     // 2: LDS-DMA strips, 1: register-staged, 0: the left-looking strip kernel
     mark(1);
     if (mf && trsm_rr == 2 && dm.nt <= TRR_NT)
-      hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRD_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    {
+      static const int trd_fr = [] { const char* e = getenv("TMPC_TRSM_FR"); return (e && atoi(e) == 2) ? 2 : 4; }();     // 16-row fragments per strip (32-row strips, three workgroups per CU: measured equal, 140.4 vs 139.1 ms per factorisation)
+      if (trd_fr == 2) hipLaunchKernelGGL(k_cr_trsm_dma<2>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 31) / 32))), dim3(256), (size_t)trd_lds_doubles<2>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+      else hipLaunchKernelGGL(k_cr_trsm_dma<4>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 63) / 64))), dim3(256), (size_t)trd_lds_doubles<4>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    }
     else if (mf && trsm_rr && dm.nt <= TRR_NT)
       hipLaunchKernelGGL(k_cr_trsm_rr, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRR_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else if (!mf) hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);

@@ -420,25 +420,30 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_rr(WS w, Dims dm, CrDev cr, 
 // product with the lower-triangular tile inverse skips the K slabs beyond the strip (10 of 16 strip-slabs) and the 48-wide last
 // tile and 48-row last strip cost what they hold.
 constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
-constexpr int TRD_LDS_DOUBLES = 4 * 1024 + TRD_DEPTH * 2048;       // X_i / T_i as the A operand (four 64 x 16 slabs) + the B steps in flight
-__global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+// FR = 16-row fragments per strip: 4 (64-row strips, 80 accumulator doubles per lane, two workgroups per CU) or 2 (32-row strips: half the
+// accumulators, three workgroups per CU, L streamed twice as often from L2)
+template <int FR> constexpr int trd_lds_doubles() { return 4 * FR * 256 + TRD_DEPTH * 2048; }       // X_i / T_i as the A operand (four (16 FR) x 16 slabs) + the B steps in flight
+template <int FR>
+__global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  constexpr int RS = 16 * FR, ASL = RS * 16;                // rows per strip, doubles per A slab
   const int dp = dm.dp, nt = dm.nt;
-  const int per = 2 * nt;
+  const int nst = (dp + RS - 1) / RS;                       // strips per edge
+  const int per = 2 * nst;
   const int it = cr_item(count * nelim * per);
   if (it < 0) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int g = it / per, r = it - g * per;
   const int b = cr.alist[g / nelim];
   const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
-  const int which = r / nt, strip = r - which * nt;
+  const int which = r / nst, strip = r - which * nst;
   const int slot = which ? er[CE_EB] : er[CE_EA];
   if (slot < 0) return;
   const int node = er[CE_NODE];
   const size_t bs = (size_t)dp * dp;
   const double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
   const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
-  const int r0 = strip * 64;
-  const int rows = (dp - r0 < 64) ? dp - r0 : 64;
+  const int r0 = strip * RS;
+  const int rows = (dp - r0 < RS) ? dp - r0 : RS;
   double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
   const int i1 = (rows + 15) >> 4;                          // 16-row fragments of the strip
   double* At = lds;
-  double* Bs = lds + 4 * 1024;
+  double* Bs = lds + 4 * ASL;
   unsigned voT[2], voL[2];                                  // DMA: wave wv moves rows 16 wv .. + 15 of a B slab, two pieces of 8 rows
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -466,9 +471,9 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
       for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (wc0 + 4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
     }
   }
-  double acc1[4][4], acc2[4][4], acc3[4][4], acc4[4][4], xa[4][4];
+  double acc1[FR][4], acc2[FR][4], acc3[FR][4], acc4[FR][4], xa[FR][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FR; ++i)
 #pragma unroll
     for (int c = 0; c < 4; ++c) { acc1[i][c] = 0.0; acc2[i][c] = 0.0; acc3[i][c] = 0.0; acc4[i][c] = 0.0; xa[i][c] = 0.0; }
 #define TRD_ACC(k) ((k) == 1 ? acc1 : (k) == 2 ? acc2 : (k) == 3 ? acc3 : acc4)
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
 #define TRD_LOAD_E(I)                                                                                       \
   {                                                                                                         \
     const bool on_ = wc0 < TRD_NB(I);                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
       double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;                                                        \
       if (on_ && i < i1) {                                                                                  \
         gcptr2 cp = (gcptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (I) + wc0 + 4 * fj);            \
@@ -488,16 +493,16 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   }
 #define TRD_PARK()          /* xa -> A operand: slab = this strip, K pairs 2 fj and 2 fj + 1 of every row */ \
   {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
       const int row = 16 * i + 4 * fq + fk, sw_ = dma_sw(row);                                              \
-      double* q = At + ws * 1024 + row * 16;                                                                \
+      double* q = At + ws * ASL + row * 16;                                                                \
       *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){xa[i][0], xa[i][1]};                            \
       *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){xa[i][2], xa[i][3]};                        \
     }                                                                                                       \
   }
 #define TRD_ZERO_XA()                                                                                       \
   {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+    _Pragma("unroll") for (int i = 0; i < FR; ++i)                                                           \
       _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] = 0.0;                                         \
   }
   // B stream: for every column tile i the slabs of Linv_i (K = nb_i), then those of L_ji, j > i (K = 64).  (ii, ij, is) = next slab to issue.
@@ -531,10 +536,10 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   }
 #define TRD_MMA2(TGT, AS, BS)                                                                               \
   _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                        \
-    double2_t a_[4], b_[4];                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *(const double2_t*)((AS) + oa[hh] + i * 256);     \
+    double2_t a_[FR], b_[4];                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < FR; ++i) a_[i] = *(const double2_t*)((AS) + oa[hh] + i * 256);     \
     _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) b_[cb] = *(const double2_t*)((BS) + ob[cb][hh]);       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
       if (i < i1) {                                                                                         \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                  \
           TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][0], b_[cb][0], TGT[i][cb], 0, 0, 0);        \
@@ -558,14 +563,14 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
       TRD_ISSUE()                                                                                           \
       const double* Bc_ = Bs + (ndone % TRD_DEPTH) * 2048;                                                  \
       if (wc0 < nbj) {                                                                                      \
-        if (!((CJ) == (CI) && 2 * cs > ws)) TRD_MMA2(TGT, At + 2 * cs * 1024, Bc_)                          \
-        if (2 * cs + 1 < nsl && !((CJ) == (CI) && 2 * cs + 1 > ws)) TRD_MMA2(TGT, At + (2 * cs + 1) * 1024, Bc_ + 1024) \
+        if (!((CJ) == (CI) && 2 * cs > ws)) TRD_MMA2(TGT, At + 2 * cs * ASL, Bc_)                          \
+        if (2 * cs + 1 < nsl && !((CJ) == (CI) && 2 * cs + 1 > ws)) TRD_MMA2(TGT, At + (2 * cs + 1) * ASL, Bc_ + 1024) \
       }                                                                                                     \
       ++ndone;                                                                                              \
       const bool last_sub = (cs == nsub - 1);                                                               \
       if ((CJ) == (CI) && last_sub) {          /* X_i complete: out to memory, and into LDS as the operand of the updates */ \
         if (wc0 < nbi) {                                                                                    \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+          _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                   \
             if (i < i1) {                                                                                   \
               typedef double2_t __attribute__((address_space(1)))* gptr2;                                   \
               gptr2 cp = (gptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (CI) + wc0 + 4 * fj);       \
@@ -580,7 +585,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
         }                                                                                                   \
       }                                                                                                     \
       if ((CI) + 1 < TRR_NT && last_sub && (CJ) == nt - 1 && (CI) + 1 < nt) {     /* block i finished: T_{i+1} = E_{i+1} - partial sums of tile i+1 */ \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int i = 0; i < FR; ++i)                                                       \
           _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] -= TRD_ACC((CI) + 1)[i][c];                \
         __builtin_amdgcn_s_barrier();          /* every wave is done with X_i */                            \
         TRD_PARK()                                                                                          \
