@@ -14,9 +14,11 @@
 extern "C" {
 #endif
 
-/* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMM of the factorisation (one workgroup); mode 0: C -= AB',
- * 1: C = AB', 2: C = -AB' (+16: the 128 x 128 / 512-thread shape of k_cr_update instead of 64 x 64 / 256); lower != 0: only the
- * tiles on and below the diagonal, and inside diagonal tiles only the waves that reach it.  All dims multiples of 16. */
+/* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMMs of the factorisation; mode 0: C -= AB', 1: C = AB', 2: C = -AB'.
+ * mode + 0: the register-staged core (tmpc_factor.h, one workgroup walks all tiles); + 16: the LDS-DMA tile core (tmpc_gemm_dma.h, one
+ * workgroup per 64 x 64 tile); + 32: the LDS-DMA core with K split into two operand pairs of K/2 as one stream.  lower != 0: only the
+ * part on and below the diagonal (register-staged: 64 x 64 tiles and the waves that reach the diagonal; LDS-DMA: 16 x 16 blocks).
+ * All dims multiples of 16 (K of 32 for + 32). */
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower);
 
 /* Factor + solve one SPD block-cyclic-tridiagonal system with the cyclic-reduction kernels (tmpc_cr.h):

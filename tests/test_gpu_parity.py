@@ -44,33 +44,45 @@ def test_library_loaded_in_tree():
 # ----------------------------------------------------------------------------- building blocks
 @pytest.mark.parametrize('M,N,K', [(64, 64, 16), (128, 64, 48), (304, 48, 256), (304, 304, 304), (16, 16, 16), (48, 112, 80), (320, 128, 64)])
 @pytest.mark.parametrize('flags', [0, 1])
-@pytest.mark.parametrize('shape', [0, 16])
-def test_mfma_gemm_nt(hc, M, N, K, flags, shape):
-    """v_mfma_f64_4x4x4 tile GEMM (and its scalar-FMA twin) vs numpy, both workgroup shapes (64 x 64 / 256 threads, 128 x 128 / 512);
-    asymmetric operands catch transposes."""
+def test_mfma_gemm_nt(hc, M, N, K, flags):
+    """Register-staged v_mfma_f64_4x4x4 tile GEMM (and its scalar-FMA twin) vs numpy; asymmetric operands catch transposes."""
     h = hc(2, 3, 1)
     h.set_options(flags=flags)
     rng = np.random.default_rng(M * 1000 + N + K)
     A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
     for mode, ref in [(0, C0 - A @ B.T), (1, A @ B.T), (2, -A @ B.T)]:
-        out = h.debug_gemm_nt(C0, A, B, mode + shape)
+        out = h.debug_gemm_nt(C0, A, B, mode)
         assert rel(out, ref) < 1e-14
     h.set_options(flags=0)
 
 
-@pytest.mark.parametrize('n,shape,T,W', [(304, 0, 64, 64), (304, 16, 128, 32), (320, 16, 128, 32), (496, 16, 128, 32)])
-def test_mfma_gemm_nt_lower(hc, n, shape, T, W):
-    """Lower-only symmetric update C -= A A': tiles strictly above the diagonal are skipped, inside diagonal tiles only the waves that
-    reach the diagonal compute and store (wave = (16 FA) x 32: 32 x 32 in the 64-shape, 64 x 32 in the 128-shape); the lower triangle is exact."""
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (128, 64, 48), (304, 48, 256), (304, 304, 304), (16, 16, 16), (48, 112, 80), (320, 128, 64), (64, 64, 32)])
+@pytest.mark.parametrize('shape', [16, 32])
+def test_dma_tile_gemm(hc, M, N, K, shape):
+    """The LDS-DMA tile core of the batched factorisation kernels (tmpc_gemm_dma.h: source-side swizzle, b128 fragment reads, K pairs
+    split over two MFMAs, 16-column wave strips) vs numpy, every mode; shape 32: K as two operand pairs in one stream."""
+    if shape == 32 and K % 32:
+        pytest.skip('two equal operand pairs need K % 32 == 0')
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(M * 1000 + N + K + shape)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K)); C0 = rng.standard_normal((M, N))
+    for mode, ref in [(0, C0 - A @ B.T), (1, A @ B.T), (2, -A @ B.T)]:
+        out = h.debug_gemm_nt(C0, A, B, mode + shape)
+        assert rel(out, ref) < 1e-14
+
+
+@pytest.mark.parametrize('n,shape,G', [(304, 0, 64), (304, 16, 16), (320, 16, 16), (496, 16, 16), (304, 32, 16)])
+def test_gemm_nt_lower(hc, n, shape, G):
+    """Lower-only symmetric update C -= A A': the lower triangle is exact; everything above the block diagonal of G x G blocks is untouched
+    (register-staged core: 64 x 64 tiles above the diagonal are skipped; LDS-DMA core: every 16 x 16 block above it)."""
     h = hc(2, 3, 1)
     rng = np.random.default_rng(n + shape)
-    A = rng.standard_normal((n, n)); C0 = rng.standard_normal((n, n))
+    A = rng.standard_normal((n, n if shape != 32 else 320)); C0 = rng.standard_normal((n, n))
     out = h.debug_gemm_nt(C0, A, A, 0 + shape, lower=True)
     ref = C0 - A @ A.T
     low = np.tril(np.ones((n, n), bool))
     assert np.abs(out - ref)[low].max() < 1e-12 * n
-    # everything above the block diagonal of T x T tiles is untouched
-    up = np.kron(np.triu(np.ones(((n + T - 1) // T,) * 2), 1), np.ones((T, T)))[:n, :n] > 0
+    up = np.kron(np.triu(np.ones(((n + G - 1) // G,) * 2), 1), np.ones((G, G)))[:n, :n] > 0
     assert np.abs(out - C0)[up].max() == 0.0
 
 

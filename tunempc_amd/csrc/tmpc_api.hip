@@ -343,16 +343,25 @@ __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   wg_gemm_nt<USE_MFMA>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
 }
-template <bool USE_MFMA>      // the 128 x 128 shape of k_cr_update
-__global__ void __launch_bounds__(512, 1) k_debug_gemm512(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
+// the LDS-DMA tile core of the batched factorisation kernels (tmpc_gemm_dma.h): one workgroup per 64 x 64 tile, optional second operand
+// pair as one K stream (A2 = A, B2 = B shifted by K2 columns: the caller passes K = K1 + K2 and the split)
+__global__ void __launch_bounds__(256, 4) k_debug_gemm_dma(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower, int k1) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg_gemm_nt<USE_MFMA, 2, 4, 4>(C, N, A, K, B, K, M, N, K, mode, lower != 0, lds);
+  const int nmc = (N + 63) / 64;
+  const int tm = blockIdx.x / nmc, tn = blockIdx.x - tm * nmc;
+  if (lower && tn > tm) return;
+  const int m0 = 64 * tm, n0 = 64 * tn;
+  const int Mt = M - m0 < 64 ? M - m0 : 64, Nt = N - n0 < 64 ? N - n0 : 64;
+  const double* A0 = A + (size_t)m0 * K; const double* B0 = B + (size_t)n0 * K;
+  if (k1 > 0 && k1 < K && 2 * k1 == K)          // two operand pairs of equal K as ONE stream
+    wg_tile_dma<UPD_DMA_DEPTH>(C + (size_t)m0 * N + n0, N, A0, B0, A0 + k1, B0 + k1, K, Mt, Nt, k1, mode, (lower && tm == tn) ? 0 : GM_NOTRI, blockIdx.x, lds);
+  else
+    wg_tile_dma<UPD_DMA_DEPTH>(C + (size_t)m0 * N + n0, N, A0, B0, nullptr, nullptr, K, Mt, Nt, K, mode, (lower && tm == tn) ? 0 : GM_NOTRI, blockIdx.x, lds);
 }
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
 static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
-static size_t update_lds() { return (size_t)UPD_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 
 // kernels whose dynamic LDS exceeds the 64 KB default: the attribute is per device
@@ -372,17 +381,13 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_rr, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)(k_cr_update<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm512<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm512<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -427,38 +432,27 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
     const int mt = mt_opt > 0 ? mt_opt : 64;      // one 64 x 64 tile per workgroup: ~64 consecutive items per XCD span the tiles of 1-2 nodes, whose O blocks fit that L2
                                                   // (the 128 x 128 / 512-thread shape of wg_gemm_nt was measured slower here: 102 vs 84.5 ms per phase)
-    const int nstrip = (dm.dp + rs - 1) / rs;
-    static const int gemm_ns = [] { const char* e = getenv("TMPC_GEMM_NS"); return (e && atoi(e) == 2) ? 2 : 1; }();     // K-slab depth of the batched GEMM kernels
-    static const int upd_fa = [] { const char* e = getenv("TMPC_UPD_FA"); return (e && atoi(e) == 4) ? 4 : 2; }();        // rows of the update tile / 32 (128 x 64 tiles measured slower at dp = 304: 81 vs 68 ms per phase, the third row tile is 5/8 empty)
-    const int rt = (mf && gemm_ns == 1 && upd_fa == 4) ? 128 : 64;
+    const int nstrip = (dm.dp + rs - 1) / rs, nm = (dm.dp + mt - 1) / mt;
     const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
-    const long it_upd = (long)count * ((long)lv.nupd * cr_ntl(dm.dp, rt) + (long)lv.nelim * ((dm.dp + rt - 1) / rt) * ((dm.dp + 63) / 64));
-    const size_t lds1 = (size_t)GemmCfg<2, 2, 2, 1>::LDS_DOUBLES * sizeof(double);
-    const size_t lds14 = (size_t)GemmCfg<2, 2, 4, 1>::LDS_DOUBLES * sizeof(double);
-    static const int trsm_rr = [] { const char* e = getenv("TMPC_TRSM_RR"); return e ? atoi(e) : 2; }();     // 2: LDS-DMA strips, 1: register-staged, 0: the left-looking strip kernel
+    const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
+    // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
+    static const int use_dma = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();
+    static const int trd_fr = [] { const char* e = getenv("TMPC_TRSM_FR"); return (e && atoi(e) == 2) ? 2 : 4; }();     // 16-row fragments per strip (32-row strips, three workgroups per CU: measured equal, 140.4 vs 139.1 ms per factorisation)
     mark(1);
-    if (mf && trsm_rr == 2 && dm.nt <= TRR_NT)
-    {
-      static const int trd_fr = [] { const char* e = getenv("TMPC_TRSM_FR"); return (e && atoi(e) == 2) ? 2 : 4; }();     // 16-row fragments per strip (32-row strips, three workgroups per CU: measured equal, 140.4 vs 139.1 ms per factorisation)
+    if (mf && use_dma && dm.nt <= TRR_NT) {
       if (trd_fr == 2) hipLaunchKernelGGL(k_cr_trsm_dma<2>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 31) / 32))), dim3(256), (size_t)trd_lds_doubles<2>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
       else hipLaunchKernelGGL(k_cr_trsm_dma<4>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 63) / 64))), dim3(256), (size_t)trd_lds_doubles<4>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
     }
-    else if (mf && trsm_rr && dm.nt <= TRR_NT)
-      hipLaunchKernelGGL(k_cr_trsm_rr, dim3(cr_grid((long)count * lv.nelim * 2 * dm.nt)), dim3(256), (size_t)TRR_LDS_DOUBLES * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
-    else if (!mf) hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
-    else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
-    else hipLaunchKernelGGL((k_cr_trsm<true, 1>), dim3(cr_grid(it_trsm)), dim3(256), lds1, st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
+    else if (mf) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
+    else hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     mark(1); mark(2);
-    static const int upd_dma = [] { const char* e = getenv("TMPC_UPD_DMA"); return e ? atoi(e) : 1; }();     // 0: the register-staged core
-    if (mf && upd_dma) {
+    if (mf && use_dma) {
       const int nm64 = (dm.dp + 63) / 64;
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
       hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
-    } else
-    if (!mf) hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
-    else if (gemm_ns == 2) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
-    else if (rt == 128) hipLaunchKernelGGL((k_cr_update<true, 1, 4>), dim3(cr_grid(it_upd)), dim3(256), lds14, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
-    else hipLaunchKernelGGL((k_cr_update<true, 1>), dim3(cr_grid(it_upd)), dim3(256), lds1, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
+    }
+    else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
+    else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     mark(2);
   }
   if (nkev) *nkev = ke;
@@ -1129,8 +1123,8 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
 
 // ---------------------------------------------------------------------------------- debug / unit-test entries (tunempc_hip_debug.h)
 int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
-  const int shape = mode >> 4; mode &= 15;             // mode + 16: the 128 x 128 / 512-thread shape
-  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16 || mode < 0 || mode > 2 || shape > 1) return TMPC_E_ARG;
+  const int shape = mode >> 4; mode &= 15;             // mode + 16: the LDS-DMA tile core (one workgroup per tile); + 32: the same with K split into two operand pairs
+  if (!h || !C || !A || !B || M % 16 || N % 16 || K % 16 || K < 16 || mode < 0 || mode > 2 || shape > 2 || (shape == 2 && K % 32)) return TMPC_E_ARG;
   ON_DEVICE(h);
   DevBuf bC, bA, bB;
   HIPCHK(bC.alloc((size_t)M * N * 8)); HIPCHK(bA.alloc((size_t)M * K * 8)); HIPCHK(bB.alloc((size_t)N * K * 8));
@@ -1138,9 +1132,9 @@ int tmpc_debug_gemm_nt(tmpc_handle* h, double* C, const double* A, const double*
   HIPCHK(hipMemcpy(dC, C, (size_t)M * N * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dA, A, (size_t)M * K * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dB, B, (size_t)N * K * 8, hipMemcpyHostToDevice));
-  if (shape == 1) {
-    if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm512<false>, dim3(1), dim3(512), update_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
-    else hipLaunchKernelGGL(k_debug_gemm512<true>, dim3(1), dim3(512), update_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
+  if (shape >= 1) {
+    hipLaunchKernelGGL(k_debug_gemm_dma, dim3(((M + 63) / 64) * ((N + 63) / 64)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), 0,
+                       dC, dA, dB, M, N, K, mode, lower, shape == 2 ? K / 2 : 0);
   } else if (h->flags & TMPC_FLAG_NO_MFMA) hipLaunchKernelGGL(k_debug_gemm<false>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   else hipLaunchKernelGGL(k_debug_gemm<true>, dim3(1), dim3(256), factor_lds(), 0, dC, dA, dB, M, N, K, mode, lower);
   HIPCHK(hipDeviceSynchronize());

@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, in
 
 constexpr int UPD_DMA_DEPTH = 2;                       // LDS buffers of the LDS-DMA tile GEMM in the batched kernels
 // ---- phase 2: O_x <- T[x,i] L_i^-T for the (up to) two neighbours, `rs` rows per workgroup
-// NS = 2: 32-column K slabs, 70 KB of LDS, two workgroups per CU; NS = 1: 16-column slabs, 35 KB, three per CU
+// (left-looking strips on the register-staged core: the path for blocks wider than 320 and for the no-MFMA debug flag)
 template <bool USE_MFMA, int NS>
-__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int rs) {
+__global__ void __launch_bounds__(256, 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int rs) {
   const int nstrip = (dm.dp + rs - 1) / rs;
   const int per = 2 * nstrip;
   const int it = cr_item(count * nelim * per);
@@ -229,196 +229,15 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) k_cr_trsm(WS w, Dims dm,
   }
 }
 
-// ---- phase 2, register-resident form: one workgroup owns a 64-row strip of an edge block and walks its column tiles once.
-// X_i = (E_i - sum_{k<i} X_k L_ik') L_ii^-T is evaluated right-looking with the partial sums of ALL column tiles in accumulator
-// registers (NT tiles x 16 doubles per lane): as soon as X_i is known it is parked in LDS as the A operand and pushed into the
-// accumulators of the tiles j > i, with the 64 x 16 sub-slabs of L_ji streaming through a double-buffered LDS slab.  Every element
-// of E is read once and every element of X written once; only L (shared by the 2 x 5 strips of a node, served by L2) is re-read.
-// The left-looking kernel above re-reads its own X strips from memory (3 x the traffic, 4.7 TB/s: profiles/r2e_pmc_*.txt).
-#ifndef TRR_UNROLL
-#define TRR_UNROLL 2
-#endif
-constexpr int TRR_ASUB = 64 * SLD;                         // one 16-column sub-slab of the 64-row A operand
-constexpr int TRR_LDS_DOUBLES = 4 * TRR_ASUB + 2 * 2 * TRR_ASUB;   // A tile (64 x 64) + double-buffered B slab of two 16-column sub-slabs
-
-__device__ __forceinline__ void trr_mfma(double (*acc)[8], const double* As, const double* Bs, int wr0, int wc0, int fk, int fq, int fj) {
-#pragma unroll TRR_UNROLL
-  for (int kk = 0; kk < 4; ++kk) {
-    const int so = kk * 4 + fk;
-    double av[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) av[i] = As[(wr0 + 16 * i + 4 * fq + fj) * SLD + so];
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      const double bv = Bs[(wc0 + 16 * (cb >> 2) + 4 * fj + (cb & 3)) * SLD + so];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[i], bv, acc[i][cb], 0, 0, 0);
-    }
-  }
-}
-
-constexpr int TRR_NT = 5;                                  // column tiles held in registers (dp <= 320)
-__global__ void __launch_bounds__(256, 2) k_cr_trsm_rr(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
-  const int dp = dm.dp, nt = dm.nt;
-  const int per = 2 * nt;                                  // 64-row strips of the two edges of a node
-  const int it = cr_item(count * nelim * per);
-  if (it < 0) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int g = it / per, r = it - g * per;
-  const int b = cr.alist[g / nelim];
-  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
-  const int which = r / nt, strip = r - which * nt;
-  const int slot = which ? er[CE_EB] : er[CE_EA];
-  if (slot < 0) return;
-  const int node = er[CE_NODE];
-  const size_t bs = (size_t)dp * dp;
-  const double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
-  const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
-  const int r0 = strip * 64;
-  const int rows = (dp - r0 < 64) ? dp - r0 : 64;
-  double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wr0 = (wv >> 1) * 32, wc0 = (wv & 1) * 32;
-  const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
-  const int lrow = tid >> 2, lk = (tid & 3) * 4;            // B sub-slab loader: row, first of four k
-  double* At = lds;
-  double* Bs = lds + 4 * TRR_ASUB;                         // [buffer][sub-slab][64][17]
-
-  // partial sums of the column tiles 1..4 (tile 0 has none) and the tile being finished; separate arrays with literal indices
-  // only, so that every one of them stays in registers
-  double acc1[2][8], acc2[2][8], acc3[2][8], acc4[2][8], xa[2][8];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { acc1[i][c] = 0.0; acc2[i][c] = 0.0; acc3[i][c] = 0.0; acc4[i][c] = 0.0; xa[i][c] = 0.0; }
-#define TRR_ACC(k) ((k) == 1 ? acc1 : (k) == 2 ? acc2 : (k) == 3 ? acc3 : acc4)
-
-  // fragment <-> memory: lane owns rows rb + 4 fq + fk of the two 16-row fragments and columns cb + 4 fj .. + 3 of the two 16-column halves
-#define TRR_LOAD_E(I)                                                                                       \
-  {                                                                                                         \
-    const int nbe_ = (dp - 64 * (I) < 64) ? dp - 64 * (I) : 64;                                             \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                           \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                       \
-        const int rb = wr0 + 16 * f, cb = wc0 + 16 * m;                                                     \
-        double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;                                                      \
-        if (rb < rows && cb < nbe_) {                                                                       \
-          gcptr2 cp = (gcptr2)(X + (size_t)(rb + 4 * fq + fk) * dp + 64 * (I) + cb + 4 * fj);               \
-          u0 = cp[0]; u1 = cp[1];                                                                           \
-        }                                                                                                   \
-        xa[f][4 * m] = u0[0]; xa[f][4 * m + 1] = u0[1]; xa[f][4 * m + 2] = u1[0]; xa[f][4 * m + 3] = u1[1]; \
-      }                                                                                                     \
-  }
-#define TRR_PARK()          /* xa -> A operand in LDS ([sub-slab][row][17]) */                              \
-  {                                                                                                         \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                           \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                       \
-        double* q = At + ((wc0 >> 4) + m) * TRR_ASUB + (wr0 + 16 * f + 4 * fq + fk) * SLD + 4 * fj;         \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) q[e] = xa[f][4 * m + e];                              \
-      }                                                                                                     \
-  }
-#define TRR_ZERO_XA()                                                                                       \
-  {                                                                                                         \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                           \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) xa[f][c] = 0.0;                                         \
-  }
-  // B stream: for every column tile i the sub-slabs of Linv_i (K = nb_i), then those of L_ji for j > i (K = 64)
-  double rbv[8];
-#define TRR_LOAD_B(I, J, S)          /* slab S = sub-slabs 2S, 2S+1 (the second one only if the K range has it) */ \
-  {                                                                                                         \
-    const double* base; int ld, nbr, kk_;                                                                   \
-    if ((J) == (I)) { base = Li + (size_t)(I) * TB * TB; ld = TB; nbr = (dp - 64 * (I) < 64) ? dp - 64 * (I) : 64; kk_ = nbr; } \
-    else { base = Dk + (size_t)(64 * (J)) * dp + 64 * (I); ld = dp; nbr = (dp - 64 * (J) < 64) ? dp - 64 * (J) : 64; kk_ = 64; } \
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((unsigned)(nbr - 1) * (unsigned)ld + (unsigned)kk_) * 8u), 0x00020000); \
-    const unsigned vo = (unsigned)(lrow * ld + 32 * (S) + lk) * 8u;                                         \
-    const double2_t u0 = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0)); \
-    const double2_t u1 = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16u, 0, 0)); \
-    rbv[0] = u0[0]; rbv[1] = u0[1]; rbv[2] = u1[0]; rbv[3] = u1[1];                                         \
-    if (32 * (S) + 16 < kk_) {                                                                              \
-      const double2_t u2 = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 128u, 0, 0)); \
-      const double2_t u3 = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 144u, 0, 0)); \
-      rbv[4] = u2[0]; rbv[5] = u2[1]; rbv[6] = u3[0]; rbv[7] = u3[1];                                       \
-    }                                                                                                       \
-  }
-#define TRR_STORE_B(BUF)                                                                                    \
-  {                                                                                                         \
-    double* q = Bs + (BUF) * 2 * TRR_ASUB + lrow * SLD + lk;                                                \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) { q[e] = rbv[e]; q[TRR_ASUB + e] = rbv[4 + e]; }          \
-  }
-  // the sub-slab steps of the pair (CI, CJ), literal indices: TGT = xa on the diagonal, the partial sums of tile CJ otherwise
-#define TRR_PAIR(CI, CJ, TGT)                                                                               \
-  if ((CJ) < nt) {                                                                                          \
-    const int nbi = (dp - 64 * (CI) < 64) ? dp - 64 * (CI) : 64;                                            \
-    const int nsb = ((CJ) == (CI)) ? (nbi >> 4) : 4;                  /* 16-column sub-slabs of this pair */ \
-    const int nsub = (nsb + 1) >> 1;                                  /* steps of two */                     \
-    for (int cs = 0; cs < nsub; ++cs) {                                                                     \
-      int ni = (CI), nj = (CJ), ns = cs + 1;                                                                \
-      if (ns == nsub) { ns = 0; nj = (CJ) + 1; if (nj >= nt) { ni = (CI) + 1; nj = ni; } }                  \
-      const bool more = ni < nt;                                                                            \
-      if (more) TRR_LOAD_B(ni, nj, ns)                                                                      \
-      TMPC_T(0)                                                                                             \
-      trr_mfma(TGT, At + 2 * cs * TRR_ASUB, Bs + buf * 2 * TRR_ASUB, wr0, wc0, fk, fq, fj);                 \
-      if (2 * cs + 1 < nsb) trr_mfma(TGT, At + (2 * cs + 1) * TRR_ASUB, Bs + (buf * 2 + 1) * TRR_ASUB, wr0, wc0, fk, fq, fj); \
-      TMPC_T(1)                                                                                             \
-      const bool last_sub = (cs == nsub - 1);                                                               \
-      if ((CJ) == (CI) && last_sub) {          /* X_i complete: out to memory, and into LDS as the operand of the updates */ \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                       \
-          _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
-            const int rb = wr0 + 16 * f, cb = wc0 + 16 * m;                                                 \
-            if (rb < rows && cb < nbi) {                                                                    \
-              typedef double2_t __attribute__((address_space(1)))* gptr2;                                   \
-              gptr2 cp = (gptr2)(X + (size_t)(rb + 4 * fq + fk) * dp + 64 * (CI) + cb + 4 * fj);            \
-              cp[0] = (double2_t){xa[f][4 * m], xa[f][4 * m + 1]}; cp[1] = (double2_t){xa[f][4 * m + 2], xa[f][4 * m + 3]}; \
-            }                                                                                               \
-          }                                                                                                 \
-        if ((CI) + 1 < nt) {                                                                                \
-          __syncthreads();                     /* every wave is done with T_i */                            \
-          TRR_PARK()                                                                                        \
-          TRR_LOAD_E((CI) + 1)                 /* in flight during the updates */                           \
-        }                                                                                                   \
-      }                                                                                                     \
-      if ((CI) + 1 < TRR_NT && last_sub && ni != (CI) && more) {     /* block i finished: T_{i+1} = E_{i+1} - partial sums of tile i+1 */ \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                       \
-          _Pragma("unroll") for (int c = 0; c < 8; ++c) xa[f][c] -= TRR_ACC((CI) + 1)[f][c];                \
-        __syncthreads();                       /* every wave is done with X_i */                            \
-        TRR_PARK()                                                                                          \
-        TRR_ZERO_XA()                                                                                       \
-      }                                                                                                     \
-      TMPC_T(2)                                                                                          \
-      if (more) TRR_STORE_B(buf ^ 1)                                                                        \
-      TMPC_T(3)                                                                                             \
-      __syncthreads();                                                                                      \
-      TMPC_T(4)                                                                                             \
-      buf ^= 1;                                                                                             \
-    }                                                                                                       \
-  }
-
-  int buf = 0;
-  TRR_LOAD_B(0, 0, 0)
-  TRR_LOAD_E(0)
-  TRR_STORE_B(0)
-  TRR_PARK()                                                // T_0 = E_0
-  TRR_ZERO_XA()
-  __syncthreads();
-  TMPC_T0()
-  TRR_PAIR(0, 0, xa) TRR_PAIR(0, 1, acc1) TRR_PAIR(0, 2, acc2) TRR_PAIR(0, 3, acc3) TRR_PAIR(0, 4, acc4)
-  if (nt > 1) { TRR_PAIR(1, 1, xa) TRR_PAIR(1, 2, acc2) TRR_PAIR(1, 3, acc3) TRR_PAIR(1, 4, acc4) }
-  if (nt > 2) { TRR_PAIR(2, 2, xa) TRR_PAIR(2, 3, acc3) TRR_PAIR(2, 4, acc4) }
-  if (nt > 3) { TRR_PAIR(3, 3, xa) TRR_PAIR(3, 4, acc4) }
-  if (nt > 4) { TRR_PAIR(4, 4, xa) }
-#undef TRR_PAIR
-#undef TRR_STORE_B
-#undef TRR_LOAD_B
-#undef TRR_ZERO_XA
-#undef TRR_PARK
-#undef TRR_LOAD_E
-#undef TRR_ACC
-}
-
-// ---- phase 2 on the LDS-DMA core: the register-resident right-looking solve above with (a) the sub-slabs of L streaming in by
-// buffer_load ... lds, three deep, (b) each wave owning a 16-column strip of every column tile (tmpc_gemm_dma.h), so that the
-// product with the lower-triangular tile inverse skips the K slabs beyond the strip (10 of 16 strip-slabs) and the 48-wide last
-// tile and 48-row last strip cost what they hold.
+constexpr int TRR_NT = 5;                                  // column tiles whose partial sums fit the registers of k_cr_trsm_dma (dp <= 320)
+// ---- phase 2, register-resident form on the LDS-DMA core: one workgroup owns a 64-row strip of an edge block and walks its column
+// tiles once.  X_i = (E_i - sum_{k<i} X_k L_ik') L_ii^-T is evaluated right-looking with the partial sums of ALL column tiles in
+// accumulator registers: as soon as X_i is known it is parked in LDS as the A operand and pushed into the accumulators of the
+// tiles j > i, while the 64 x 16 slabs of L_ji stream in by buffer_load ... lds.  Every element of E is read once and every element
+// of X written once; only L (shared by the 2 x 5 strips of a node, served by L2) is re-read -- the left-looking kernel above
+// re-reads its own X strips from memory (3 x the traffic: profiles/r2e_pmc_*.txt).  Each wave owns a 16-column strip of every
+// column tile (tmpc_gemm_dma.h), so the product with the lower-triangular tile inverse skips the K slabs beyond the strip (10 of
+// 16 strip-slabs) and the 48-wide last tile and 48-row last strip cost what they hold.
 constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
 // FR = 16-row fragments per strip: 4 (64-row strips, 80 accumulator doubles per lane, two workgroups per CU) or 2 (32-row strips: half the
 // accumulators, three workgroups per CU, L streamed twice as often from L2)
@@ -614,28 +433,20 @@ __global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims
 #undef TRD_ACC
 }
 
-// ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one (32 FA) x 64 output tile per workgroup
-// FA = 2: 64 x 64 tiles (35 KB of LDS with NS = 1, four workgroups per CU); FA = 4: 128 x 64 tiles, each wave a 64 x 32 part -- twice the
-// MFMAs per loaded operand byte, LDS store and barrier (52 KB, three workgroups per CU)
-__host__ __device__ __forceinline__ int cr_ntl(int dp, int rt) {           // tiles of the lower triangle (incl. those crossing the diagonal)
-  int n = 0;
-  for (int m0 = 0; m0 < dp; m0 += rt) { const int last = (m0 + rt < dp ? m0 + rt : dp) - 1; n += last / 64 + 1; }
-  return n;
-}
-template <bool USE_MFMA, int NS, int FA = 2>
-__global__ void __launch_bounds__(256, (NS == 1 && FA == 2) ? 4 : ((NS == 1) ? 3 : 2)) k_cr_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int mt) {
-  constexpr int RT = 32 * FA;                               // tile rows
-  const int dp = dm.dp;
-  const int nmr = (dp + RT - 1) / RT, nmc = (dp + 63) / 64;
-  const int ntl = cr_ntl(dp, RT), ntf = nmr * nmc;
+// ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one 64 x 64 output tile per workgroup
+// (register-staged core of tmpc_factor.h: the fallback / debug path; the product path is k_cr_update_dma below)
+template <bool USE_MFMA, int NS>
+__global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int mt) {
+  const int nm = (dm.dp + mt - 1) / mt;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
   const int per = nupd * ntl + nelim * ntf;
   const int it = cr_item(count * per);
   if (it < 0) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = cr.alist[it / per];
   int r = it % per;
+  const int dp = dm.dp;
   const size_t bs = (size_t)dp * dp;
-  (void)mt;
   // Item order inside a problem: node by node along the cycle -- the fill tiles of eliminated node j, then the update tiles of
   // the surviving node that follows it (update record j + 1): the O blocks of node j feed both, and the second operand of that
   // update is the first O block of node j + 1, whose fill tiles come next.  Workgroups of one XCD run consecutive items, so each
@@ -654,33 +465,28 @@ __global__ void __launch_bounds__(256, (NS == 1 && FA == 2) ? 4 : ((NS == 1) ? 3
   if (is_upd) {
     const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
     int t = rr, tm = 0;
-    for (;; ++tm) {                                         // t -> (tm, tn): row tile tm has the column tiles 0 .. (last row)/64
-      const int last = ((tm + 1) * RT < dp ? (tm + 1) * RT : dp) - 1;
-      const int nrow = last / 64 + 1;
-      if (t < nrow) break;
-      t -= nrow;
-    }
+    while (t > tm) { t -= tm + 1; ++tm; }               // t -> (tm, tn), tn <= tm
     const int tn = t;
-    const int m0 = tm * RT, n0 = tn * 64;
-    const int M = (dp - m0 < RT) ? dp - m0 : RT, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const int m0 = tm * mt, n0 = tn * mt;
+    const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;
     double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
     const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
-    wg_gemm_nt<USE_MFMA, 2, 2, FA, NS>(C, dp, O0 + (size_t)m0 * dp, dp, O0 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, false, lds, n0 - m0);
+    wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, O0 + (size_t)m0 * dp, dp, O0 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
     if (ur[CU_E1] >= 0) {
       const double* O1 = cr_edge(w, dm, b, ur[CU_E1]);
-      wg_gemm_nt<USE_MFMA, 2, 2, FA, NS>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, false, lds, n0 - m0);
+      wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, O1 + (size_t)m0 * dp, dp, O1 + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, tm == tn, lds);
     }
   } else {
     const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
     if (er[CE_FILL] < 0) return;
     const int t = rr;
-    const int tm = t / nmc, tn = t - tm * nmc;
-    const int m0 = tm * RT, n0 = tn * 64;
-    const int M = (dp - m0 < RT) ? dp - m0 : RT, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const int tm = t / nm, tn = t - tm * nm;
+    const int m0 = tm * mt, n0 = tn * mt;
+    const int M = (dp - m0 < mt) ? dp - m0 : mt, N = (dp - n0 < mt) ? dp - n0 : mt;
     const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
     const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
     double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
-    wg_gemm_nt<USE_MFMA, 2, 2, FA, NS>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
+    wg_gemm_nt<USE_MFMA, 2, 2, 2, NS>(C, dp, Ox + (size_t)m0 * dp, dp, Oy + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, false, lds);
   }
 }
 

@@ -9,15 +9,10 @@ namespace tmpc {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GK = 32;             // K slab staged in LDS per step
-constexpr int GLD = GK + 2;        // LDS leading dim (doubles) of the A/B slabs: (2r + k) mod 32 is conflict-free for the MFMA fragment reads
 constexpr int FACT_LDS_DOUBLES = 2 * 64 * 65 + 72 + 4 * 16 * 17 + 8;   // the tile Cholesky (tile + inverse + pivot refs + one 16 x 17 scratch per wave); the <2,2,2> GEMM slabs (4*2*64*17) alias the front
-constexpr int UPD_LDS_DOUBLES = 4 * 2 * 128 * 17 + 64;   // <2,4,4> shape (128 x 128 tiles, k_cr_update)
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
-constexpr int GM_NOTRI = -(1 << 30);
-// tri (single-tile calls of a lower-only update with a rectangular tile): column minus row index of C's origin in the symmetric block;
-// waves whose part lies entirely above the diagonal skip their work (the square-tile form of this is `lower`)
+constexpr int GM_NOTRI = -(1 << 30);       // tmpc_gemm_dma.h: `tri` of a tile that does not touch the diagonal of a symmetric update
 
 // C (M x N, ldc) <op> A (M x K, lda) * B (N x K, ldb)'   — all dims multiples of 16, K >= 16.
 // Workgroup tile 64 x 64 (each wave a 32 x 32 quadrant = 2 x 2 MFMA tiles).  The K slabs (GK = 32 columns) of ALL
@@ -64,7 +59,7 @@ struct GemmCfg {
 template <bool USE_MFMA, int WM = 2, int WN = 2, int FA = 2, int NS = 2>
 __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, int lda,
                                            const double* B, int ldb, int M, int N, int K, int mode, bool lower,
-                                           double* lds, int tri = GM_NOTRI) {
+                                           double* lds) {
   typedef GemmCfg<WM, WN, FA, NS> G;
   constexpr int GKT = 16 * NS;                          // K slab of this instantiation
   constexpr int TM = G::TM, TN = G::TN, RP = G::RP, ARP = G::ARP, BRP = G::BRP, ASUB = G::ASUB, BSUB = G::BSUB, BUFD = G::BUFD;
@@ -161,7 +156,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
     if (more) TMPC_SLAB_LOAD(nm0, nn0, nks_ * GKT + lk)
     TMPC_T(0)
     // does this wave own anything of the current tile?  (outside M x N, or above the diagonal of a lower-only diagonal tile)
-    const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA) && !(tri != GM_NOTRI && tri + n0 + wc0 >= m0 + wr0 + 16 * FA);
+    const bool wave_on = (m0 + wr0 < M) && (n0 + wc0 < N) && !(lower && n0 == m0 && wc0 >= wr0 + 16 * FA);
     if (CPRE && ks == 0 && mode == GM_SUB && wave_on) {       // prefetch the C fragment of this tile
 #pragma unroll
       for (int i = 0; i < FA; ++i) {
