@@ -37,14 +37,24 @@ TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
 KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h')]
 
 
+def kernel_sources_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic_per_launch():
-    """HBM bytes per k_cr_update launch from the committed PMC passes (profiles/r2_traffic.json, written by
+    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r2_traffic.json, written by
     scripts/pmc_traffic.py from separate rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from
-    inside this process).  None when the file is missing or OLDER than the kernel sources: a stale number is not reported."""
+    inside this process).  None when the file is missing or was measured on OTHER kernel sources (content hash): a stale number is
+    not reported."""
     try:
-        if any(os.path.getmtime(f) > os.path.getmtime(TRAFFIC_JSON) for f in KERNEL_SOURCES):
+        j = json.load(open(TRAFFIC_JSON))
+        if j.get('sources_sha') != kernel_sources_sha():
             return None
-        return float(json.load(open(TRAFFIC_JSON))['hbm_bytes_per_launch'])
+        return float(j['hbm_bytes_per_launch'])
     except Exception:
         return None
 

@@ -15,6 +15,14 @@ def per_launch(path, counter, kernel):
     return sum(v for _, v in rows) / max(len(rows), 1), len(rows)
 
 
+def sources_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h'):
+        h.update(open(os.path.join(ROOT, 'tunempc_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main():
     kernel = sys.argv[3] if len(sys.argv) > 3 else 'k_cr_update_dma'
     f, nf = per_launch(sys.argv[1], 'FETCH_SIZE', kernel)
@@ -28,6 +36,7 @@ def main():
         "fetch_correction": "x2: gfx950 FETCH_SIZE counts 128-byte requests as 64 B (MI355X_MICROARCH.md, HBM section)",
         "write_size_kb_per_launch": w,
         "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+        "sources_sha": sources_sha(),
         "note": "average over all launches of the kernel (7 levels per factorisation phase, shrinking active sets)",
     }
     json.dump(out, open(os.path.join(ROOT, 'profiles', 'r2_traffic.json'), 'w'), indent=1)
