@@ -128,6 +128,16 @@ int tmpc_convexify_step3_batch_host(tmpc_handle* h, int nb, const double* A, con
                                     double* Hc, double* dHc, double* P, double* T, double* alpha, double* beta, double* kappa,
                                     int32_t* status, int32_t* iters, double* info);
 
+/* Step 3 with the multipliers of G and C in the same solve (convexifier.py:144: setUpModelPicos(..., constr = constraint_contribution,
+ * force = True)): handle from tmpc_create_step3_con (ng, nc as in tmpc_create_con); J, ncnt, FgF as in tmpc_convexify_step2_batch_host;
+ * ncnt == NULL: no C rows -- J holds the ng rows of G only, cost-free multipliers as in tmpc_convexify_eq_batch_host (the reference's
+ * constr = False).  T [nb][p][n][n] out; dHc includes the constraint terms and T_k. */
+uint64_t tmpc_workspace_bytes_step3_con(int chunk, int p, int nx, int mb, int ng, int nc);
+int tmpc_create_step3_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc);
+int tmpc_convexify_step3_con_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* J,
+                                        const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* T,
+                                        double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);
+
 /* Device-resident form of the two entries above (inputs and outputs in HBM, work queued on `stream`): d_ncnt == NULL is Step 1
  * with G (dJ = G [nb][p][ng][n], FgF [nb][p][ng]); otherwise the Step 2 model (dJ [nb][p][ng+nc][n], d_ncnt [nb][p] with
  * 0 <= ncnt <= nc -- not checked here --, FgF [nb][p][ng+nc]). */

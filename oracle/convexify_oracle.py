@@ -706,7 +706,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                       + (x0 + ap * dx0) * (s0 + ad * ds0) + (np.sum((z + ap * dz) * (phi + ad * dphi)) if ng else 0.0)
                       + sum(((a['x'] + ap * a['dx']) @ (a['s'] + ad * a['ds'])) if a['soc'] else np.sum((a['X'] + ap * a['dX']) * (a['S'] + ad * a['dS']))
                             for a in arrows)) / N
-            sigma = min(max((mu_aff / mu) ** 2, 1e-6), 1.0)     # exponent 2: ~10 % fewer iterations than Mehrotra's 3 on this SDP family
+            sigma = min(max((mu_aff / mu) ** o.get('sig_exp', 2), 1e-6), 1.0)     # exponent 2: ~10 % fewer iterations than Mehrotra's 3 on this SDP family (sig_exp / gam0 / gam1: experiment hooks)
             sig_mu = sigma * mu
             if mu_t is not None:
                 sig_mu = max(sig_mu, mu_t)
@@ -718,7 +718,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(sig_mu, corr1, corr2, corr0, corrp, corre)
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
             mn = min(ap, ad)
-            gam = 0.9 + 0.09 * min(mn, 1.0)
+            gam = o.get('gam0', 0.9) + o.get('gam1', 0.09) * min(mn, 1.0)
             ap = min(1.0, gam * ap); ad = min(1.0, gam * ad)
         else:
             ncent += 1

@@ -545,6 +545,43 @@ def test_step3_parity_vs_oracle(hc, seed, nb, p, nx, mb, rho):
         assert rel(out['Hc'][b] - H[b], ref) < 1e-12
 
 
+@pytest.mark.parametrize('seed,p,nx,mb,ng,ncs,rho', [(4, 2, 2, 1, 1, None, 1e-2), (1, 3, 3, 2, 1, [2, 0, 1], 1e-2), (3, 1, 3, 1, 0, [2], 1e-1),
+                                                    (3, 4, 4, 2, 2, [1, 3, 0, 2], 1e-3), (4, 2, 6, 3, 1, [2, 2], 1e-2)])
+def test_step3_with_constraint_rows_parity(hc, seed, p, nx, mb, ng, ncs, rho):
+    """Step 3 with the multipliers of G / C in the same solve (convexifier.py:144: constr = constraint_contribution, force = True) against
+    the structured oracle: Hc, the multipliers Fg / F, T and the objective; ncs None: G only (the reference's constr = False)."""
+    n = nx + mb
+    A, B, H = co.gen_batch(700 + seed, 1, p, nx, mb)
+    rng = np.random.default_rng(900 + seed)
+    G = rng.standard_normal((1, p, ng, n)) if ng else None
+    nc = max(ncs) if ncs else 0
+    h = hc(p, nx, mb, ng=ng, nc=nc, step3=True)
+    if ncs is None:
+        out = h.convexify_step3_con_batch(A, B, H, G, None, rho)
+        r = co.sdp_step1(A[0], B[0], H[0], G=G[0], rho=rho, force=True)
+        Cl = None
+    else:
+        C = np.zeros((1, p, nc, n))
+        for k in range(p):
+            C[0, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+        J = C if not ng else np.concatenate([G, C], axis=2)
+        out = h.convexify_step3_con_batch(A, B, H, J, np.asarray([ncs], np.int32), rho)
+        Cl = [C[0, k, :ncs[k]] if ncs[k] else None for k in range(p)]
+        r = co.sdp_step1(A[0], B[0], H[0], G=None if G is None else G[0], C=Cl, rho=rho, force=True)
+    assert out['info'][0, 13] == 0.0                     # (not already convex: an SDP was solved)
+    assert int(out['status'][0]) == 0 and r['ipm_status'] == 'optimal'
+    dHc = co.convex_hessian_suppl(A[0], B[0], r['P'], G=None if G is None else G[0], Fg=r.get('Fg'), C=Cl, F=r.get('F'), T=r['T'])[0]
+    assert rel(out['Hc'][0], H[0] + dHc) < PARITY
+    assert abs(out['kappa'][0] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+    assert rel(out['T'][0], r['T']) < 1e-6 and (out['T'][0] > 0).all()
+    if ng:
+        assert np.abs(out['FgF'][0, :, :ng] - r['Fg']).max() < 1e-7 * max(1.0, np.abs(r['Fg']).max())
+    if ncs:
+        for k in range(p):
+            if ncs[k]:
+                assert np.abs(out['FgF'][0, k, ng:ng + ncs[k]] - r['F'][k]).max() < 1e-7 * max(1.0, np.abs(r['F'][k]).max())
+
+
 def test_step3_rescues_the_infeasible_vector(golden_dir):
     """The dense model's vector (B = 0, R < 0, no constraints): Steps 1 and 2 cannot help, force -> Step 3 (convexifier.py:137-147).
     The drop-in logs the reference's warnings, takes Step 3 on the GPU and returns a positive definite result; its optimal value
@@ -560,6 +597,23 @@ def test_step3_rescues_the_infeasible_vector(golden_dir):
         assert np.linalg.eigvalsh(H[k] + dHc[k]).min() > 0
     out = convexifier.convexify_step3_batch(np.stack(A)[None], np.stack(B)[None], np.stack(H)[None], float(g['rho']))
     assert int(out['status'][0]) == 0 and abs(out['kappa'][0] - float(g['kappa'])) < 1e-5 * float(g['kappa'])
+
+
+def test_step3_dropin_with_constraint_rows(golden_dir):
+    """The same vector through convexify(..., G=, C=, opts={'force': True}): Steps 1 and 2 stay infeasible (the Jacobian rows do not reach
+    the negative R block), Step 3 takes the multipliers along (convexifier.py:144) and returns a positive definite result."""
+    from tunempc_amd import convexifier
+    g = np.load(os.path.join(golden_dir, 'n1_step3_force.npz'))
+    A, B, Q, R, N = ([m for m in g[k]] for k in ('A', 'B', 'Q', 'R', 'N'))
+    p, nx, nu = len(A), A[0].shape[0], B[0].shape[1]
+    rng = np.random.default_rng(5)
+    G = [np.hstack([rng.standard_normal((1, nx)), np.zeros((1, nu))]) for _ in range(p)]          # rows without an input part: no help for R < 0
+    C = [np.hstack([rng.standard_normal((2, nx)), np.zeros((2, nu))]) if k % 2 == 0 else None for k in range(p)]
+    with pytest.raises(ValueError):
+        convexifier.convexify(A, B, Q, R, N, G=G, C=C, opts={'rho': float(g['rho']), 'solver': 'hip', 'force': False})
+    dHc, dQc, dRc, dNc = convexifier.convexify(A, B, Q, R, N, G=G, C=C, opts={'rho': float(g['rho']), 'solver': 'hip', 'force': True})
+    for k in range(p):
+        assert np.linalg.eigvalsh(co.build_hessian(Q[k], R[k], N[k]) + dHc[k]).min() > 0
 
 
 def test_step3_handle_serves_the_plain_model(hc):

@@ -19,7 +19,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
-    'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
+    'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
     'tmpc_last_error', 'tmpc_version',
 ]
@@ -67,6 +67,12 @@ def load_library():
     lib.tmpc_workspace_bytes_step3.argtypes = [C.c_int] * 4
     lib.tmpc_create_step3.restype = C.c_int
     lib.tmpc_create_step3.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_workspace_bytes_step3_con.restype = C.c_uint64
+    lib.tmpc_workspace_bytes_step3_con.argtypes = [C.c_int] * 6
+    lib.tmpc_create_step3_con.restype = C.c_int
+    lib.tmpc_create_step3_con.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tmpc_convexify_step3_con_batch_host.restype = C.c_int
+    lib.tmpc_convexify_step3_con_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, ip, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
     lib.tmpc_convexify_step3_batch_host.restype = C.c_int
     lib.tmpc_convexify_step3_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp]
     lib.tmpc_debug_get_multipliers.restype = C.c_int
@@ -146,9 +152,9 @@ class HipConvexifier:
         self.ng = int(ng)     # rows of the equality-constraint Jacobian per stage (convexifier.py:249-255), 0: none
         self.nc = int(nc)     # room for active-constraint rows per stage (Step 2, convexifier.py:258-266), 0: none
         self.step3 = bool(step3)      # room for the regularisation T_k of Step 3 (convexifier.py:137-147); such a handle also serves the plain model
-        if self.step3:
-            if self.ng or self.nc:
-                raise NotImplementedError('Step 3 on the GPU covers the plain model (no G / C rows in the same solve)')
+        if self.step3 and (self.ng or self.nc):
+            _check(self.lib, self.lib.tmpc_create_step3_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_step3_con')
+        elif self.step3:
             _check(self.lib, self.lib.tmpc_create_step3(C.byref(self._h), int(chunk), self.p, self.nx, self.mb), 'tmpc_create_step3')
         else:
             _check(self.lib, self.lib.tmpc_create_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_con')
@@ -263,6 +269,28 @@ class HipConvexifier:
                                                       _dptr(out['P']), _dptr(out['T']), _dptr(out['alpha']), _dptr(out['beta']), _dptr(out['kappa']),
                                                       _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
         _check(self.lib, rc, 'tmpc_convexify_step3_batch_host')
+        return out
+
+    def convexify_step3_con_batch(self, A, B, H, J, ncnt, rho):
+        """Step 3 with the multipliers of G / C in the same solve (convexifier.py:144): J [nb,p,ng+nc,n] and ncnt [nb,p] as in
+        convexify_step2_batch, or J [nb,p,ng,n] with ncnt=None (G only, cost-free multipliers).  Outputs of convexify_batch + FgF + T."""
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        H = np.ascontiguousarray(H, dtype=np.float64); J = np.ascontiguousarray(J, dtype=np.float64)
+        nb = A.shape[0]
+        assert self.step3 and self.ng + self.nc > 0, 'handle created without step3=True and constraint rows'
+        nr = self.ng + (self.nc if ncnt is not None else 0)
+        assert J.shape == (nb, self.p, nr, self.n), (J.shape, (nb, self.p, nr, self.n))
+        if ncnt is not None:
+            ncnt = np.ascontiguousarray(ncnt, dtype=np.int32)
+            assert ncnt.shape == (nb, self.p)
+        out = dict(Hc=np.empty_like(H), dHc=np.empty_like(H), P=np.empty_like(A), T=np.empty_like(H), FgF=np.zeros((nb, self.p, nr)), alpha=np.empty(nb),
+                   beta=np.empty(nb), kappa=np.empty(nb), status=np.empty(nb, np.int32), iters=np.empty(nb, np.int32), info=np.empty((nb, INFO_STRIDE)))
+        if nb == 0:
+            return out
+        rc = self.lib.tmpc_convexify_step3_con_batch_host(self._h, nb, _dptr(A), _dptr(B), _dptr(H), _dptr(J), _iptr(ncnt), float(rho), _dptr(out['Hc']),
+                                                          _dptr(out['dHc']), _dptr(out['P']), _dptr(out['FgF']), _dptr(out['T']), _dptr(out['alpha']),
+                                                          _dptr(out['beta']), _dptr(out['kappa']), _iptr(out['status']), _iptr(out['iters']), _dptr(out['info']))
+        _check(self.lib, rc, 'tmpc_convexify_step3_con_batch_host')
         return out
 
     # ------------------------------------------------------------------ device-resident entry (torch tensors)

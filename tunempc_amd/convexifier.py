@@ -9,8 +9,9 @@ stack).  There is no CPU path in this package.
 
 Scope: Step 1 (eta_F = 0, eta_T = 0), with the equality-constraint multipliers Fg
 (convexifier.py:249-255) when G is given (up to NG_MAX rows per stage), and Step 2 (eta_F = 1: multipliers F of the
-active constraints C and the rho-norm terms, convexifier.py:116-131) when Step 1 is infeasible and C is given.
-Step 3 (forced regularisation T, convexifier.py:137-147) raises NotImplementedError.
+active constraints C and the rho-norm terms, convexifier.py:116-131) when Step 1 is infeasible and C is given, and
+Step 3 (opts['force']: the regularisation T with rho*||T_k||_F, convexifier.py:137-147, together with the multipliers of G / C
+when they are given) when the earlier steps stay infeasible.
 """
 import numpy as np
 
@@ -127,17 +128,49 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     return out
 
 
-def convexify_step3_batch(A, B, H, rho, tol=None, handle=None):
-    """Batched Step 3 model (convexifier.py:137-147, setUpModelPicos with force=True) for the plain model: A, B, H as in convexify_batch.
-    Returns the dict of convexify_batch plus 'T' [nb,p,n,n] (every entry > 0); dHc includes T (convexifier.py:202-203)."""
+def convexify_step3_batch(A, B, H, rho, tol=None, handle=None, G=None, C=None, ncnt=None):
+    """Batched Step 3 model (convexifier.py:137-147, setUpModelPicos with force=True): A, B, H as in convexify_batch.
+    Returns the dict of convexify_batch plus 'T' [nb,p,n,n] (every entry > 0); dHc includes T (convexifier.py:202-203).
+    With G [nb,p,ng,n] and / or C [nb,p,nc,n] + ncnt [nb,p] (as in convexify_step2_batch) their multipliers join the same solve
+    (convexifier.py:144 passes constr = constraint_contribution): 'Fg' / 'F' are returned as well and dHc includes their terms."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
-    h = handle or _handle(p, nx, B.shape[3], 0, 0, nb, step3=True)
+    mb = B.shape[3]
+    ng = 0 if G is None else np.shape(G)[2]
+    nc = 0 if C is None else np.shape(C)[2]
+    global _LAST_HANDLE
+    if ng == 0 and nc == 0:
+        h = handle or _handle(p, nx, mb, 0, 0, nb, step3=True)
+        if handle is None or tol is not None:
+            h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
+        _LAST_HANDLE = h
+        return h.convexify_step3_batch(A, B, H, rho)
+    if not _rows_supported(nx, ng, nc):
+        raise NotImplementedError('the HIP path handles up to {} equality- and {} active-constraint rows per stage (got ng={}, nc={})'.format(NG_MAX, NC_MAX, ng, nc))
+    if nc:
+        if ncnt is None:
+            raise ValueError('convexify_step3_batch: C needs ncnt [nb, p], the rows of C_k present per stage (0 where C_k is None)')
+        ncnt = np.asarray(ncnt, dtype=np.int32)
+        if ncnt.shape != (nb, p) or (ncnt < 0).any() or (ncnt > nc).any():
+            raise ValueError('ncnt must be an int array [nb, p] with 0 <= ncnt <= C.shape[2] = {}'.format(nc))
+    h = handle or _handle(p, nx, mb, ng, nc, nb, step3=True)
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
-    global _LAST_HANDLE
     _LAST_HANDLE = h
-    return h.convexify_step3_batch(A, B, H, rho)
+    if nc:
+        J = np.zeros((nb, p, h.ng + h.nc, nx + mb))
+        if ng:
+            J[:, :, :ng] = np.asarray(G, dtype=np.float64)
+        J[:, :, h.ng:h.ng + nc] = np.asarray(C, dtype=np.float64)
+        out = h.convexify_step3_con_batch(A, B, H, J, ncnt, rho)
+    else:
+        out = h.convexify_step3_con_batch(A, B, H, np.asarray(G, dtype=np.float64), None, rho)
+    FgF = out.pop('FgF')
+    if nc:
+        out['F'] = FgF[:, :, h.ng:h.ng + nc]
+    if ng:
+        out['Fg'] = FgF[:, :, :ng]
+    return out
 
 
 def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None):
@@ -297,11 +330,16 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         if (opts or {}).get('force', False):                                  # convexifier.py:137-147
             Logger.logger.info('Step 3: (η_F = 1), (η_T = 1)')
             Logger.logger.info('Enforcing convexification...')
-            if Gs is not None or 'C' in arg:
-                raise NotImplementedError('Step 3 on the GPU covers the plain model so far: the regularisation T together with the '
-                                          'multipliers of G / C in one solve (convexifier.py:144) is not built yet')
             Logger.logger.info('solving SDP...')
-            res = convexify_step3_batch(As[None], Bs[None], Hs[None], (opts or {}).get('rho', 1e-3))
+            if 'C' in arg:                                                    # convexifier.py:144: constr = constraint_contribution
+                Cp = np.zeros((period, nc, nx + nu))
+                for k, c in enumerate(Cl):
+                    if rows[k]:
+                        Cp[k, :rows[k]] = c
+                res = convexify_step3_batch(As[None], Bs[None], Hs[None], (opts or {}).get('rho', 1e-3), G=None if Gs is None else Gs[None],
+                                            C=Cp[None], ncnt=np.asarray(rows, np.int32)[None])
+            else:
+                res = convexify_step3_batch(As[None], Bs[None], Hs[None], (opts or {}).get('rho', 1e-3), G=None if Gs is None else Gs[None])
             status = _log_solution(res)
             Logger.logger.warning(50 * '*')
         else:

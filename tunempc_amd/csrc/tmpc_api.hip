@@ -538,6 +538,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (nfac > 0) hipLaunchKernelGGL(k_schur, dim3(nfac * dm.p), dim3(256), schur_lds(dm), st, wf, dm);
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
+    if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (h->flags & 8) {                     // debug (tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, 1);
@@ -630,6 +631,7 @@ static uint64_t workspace_bytes(int chunk, int p, int nx, int mb, int ng, int nc
 }
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) { return workspace_bytes(chunk, p, nx, mb, ng, nc, 0); }
 uint64_t tmpc_workspace_bytes_step3(int chunk, int p, int nx, int mb) { return workspace_bytes(chunk, p, nx, mb, 0, 0, 1); }
+uint64_t tmpc_workspace_bytes_step3_con(int chunk, int p, int nx, int mb, int ng, int nc) { return workspace_bytes(chunk, p, nx, mb, ng, nc, 1); }
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng) { return tmpc_workspace_bytes_con(chunk, p, nx, mb, ng, 0); }
 uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb) { return tmpc_workspace_bytes_eq(chunk, p, nx, mb, 0); }
 
@@ -640,6 +642,7 @@ int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) 
 static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3);
 int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) { return create_handle(out, chunk, p, nx, mb, ng, nc, 0); }
 int tmpc_create_step3(tmpc_handle** out, int chunk, int p, int nx, int mb) { return create_handle(out, chunk, p, nx, mb, 0, 0, 1); }
+int tmpc_create_step3_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) { return create_handle(out, chunk, p, nx, mb, ng, nc, 1); }
 
 static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
   if (!out) return TMPC_E_ARG;
@@ -977,6 +980,28 @@ int tmpc_convexify_step3_batch_host(tmpc_handle* h, int nbt, const double* A, co
   if (h->dm.nT < 1) { snprintf(g_err, sizeof(g_err), "handle was created without room for Step 3 (use tmpc_create_step3)"); return TMPC_E_ARG; }
   ON_DEVICE(h);
   Call c{nbt, A, B, H, nullptr, nullptr, rho, Hc, dHc, P, nullptr, alpha, beta, kappa, status, iters, info, true, 0};
+  c.step3 = true; c.T = T;
+  return dispatch(h, c, nullptr, false);
+}
+
+// Step 3 with the multipliers of G (and, with ncnt, of C and the norm terms of Step 2) in the same solve (convexifier.py:144:
+// setUpModelPicos(..., constr = constraint_contribution, force = True)).  J, ncnt, FgF as in tmpc_convexify_step2_batch_host
+// (ncnt NULL: J holds only the ng rows of G, cost-free multipliers as in tmpc_convexify_eq_batch_host).
+int tmpc_convexify_step3_con_batch_host(tmpc_handle* h, int nbt, const double* A, const double* B, const double* H, const double* J,
+                                        const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* T,
+                                        double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters, double* info) {
+  if (h && nbt == 0) return TMPC_OK;
+  if (!h || nbt < 1 || !A || !H || !J || !FgF || !(rho > 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  const Dims& dm = h->dm;
+  if (dm.nT < 1 || dm.nr < 1) { snprintf(g_err, sizeof(g_err), "handle was created without room for Step 3 and constraint rows (use tmpc_create_step3_con)"); return TMPC_E_ARG; }
+  if (ncnt) {
+    if (dm.nz <= dm.nr) { snprintf(g_err, sizeof(g_err), "handle was created without active-constraint rows (nc > 0)"); return TMPC_E_ARG; }
+    const int ncmax = dm.nr - dm.ng;
+    for (size_t i = 0; i < (size_t)nbt * dm.p; ++i)
+      if (ncnt[i] < 0 || ncnt[i] > ncmax) { snprintf(g_err, sizeof(g_err), "ncnt[%zu]=%d outside 0..%d", i, ncnt[i], ncmax); return TMPC_E_ARG; }
+  }
+  ON_DEVICE(h);
+  Call c{nbt, A, B, H, J, ncnt, rho, Hc, dHc, P, FgF, alpha, beta, kappa, status, iters, info, true, ncnt ? dm.nr : dm.ng};
   c.step3 = true; c.T = T;
   return dispatch(h, c, nullptr, false);
 }

@@ -134,8 +134,9 @@ __global__ void __launch_bounds__(64) k_t3_pre(WS w, Dims dm) {
   if (lane == 0) {
     double* pq = w.part + (size_t)sid * NPART;
     pq[Q_XS] += tz + xs;
-    pq[Q_RPHI2] = r2 + (1.0 - q.x[0]) * (1.0 - q.x[0]);
-    pq[Q_NCONE] = (double)(m + 1);
+    const double rt3 = r2 + (1.0 - q.x[0]) * (1.0 - q.x[0]);
+    if (dm.nr > 0) { pq[Q_RPHI2] += rt3; pq[Q_NCONE] += (double)(m + 1); }      // after k_phi_pre: the multipliers of G / C are there already
+    else { pq[Q_RPHI2] = rt3; pq[Q_NCONE] = (double)(m + 1); }
   }
 }
 
@@ -415,6 +416,34 @@ __global__ void __launch_bounds__(64) k_t3_update(WS w, Dims dm) {
   for (int e = lane; e < m; e += 64) { q.th[e] += ad * q.dth[e]; q.z[e] += ap * q.dz[e]; }
   for (int i = lane; i <= m; i += 64) q.x[i] += ap * q.dx[i];
   if (lane == 0) q.t[0] += ad * q.dt[0];
+}
+
+// ---------------------------------------------------------------- Step 3 together with the multipliers of G / C (convexifier.py:144 passes both):
+// the block between the entries theta of T_k and the multipliers phi_k,i (direction g_i g_i') in D_{k+1}:
+//   <E_ab, Phi(g g')> = sum_r (w_a u_b + w_b u_a)   (a < b),   w_a u_a   (a = b),     w = X_r g, u = S_r^-1 g  (pvec of tmpc_phi.h)
+// rows oT + e (after the multipliers, which sit at d .. d + nz), columns d + i; after k_aug_fill and k_t3_schur.
+__global__ void __launch_bounds__(64) k_t3_cross(WS w, Dims dm) {
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] == PH_DONE) return;
+  const int n = dm.n, m = dm.nT, d = dm.d, dp = dm.dp, oT = d + dm.nz;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  double* Dn = w.D + ((size_t)b * dm.p + kn) * dp * dp;
+  const int rows = stage_rows(w, dm, sid);
+  const int pvl = 2 * n + 2 * dm.nx;
+  for (int e = lane; e < m; e += 64) {
+    int a, bb; t3_ab(e, n, &a, &bb);
+    for (int i = 0; i < rows; ++i) {
+      double v = 0.0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double* pv = w.pvec + (((size_t)sid * 2 + r) * dm.nr + i) * (size_t)pvl;      // w = pv[0..n), u = pv[n..2n)
+        v += (a == bb) ? pv[a] * pv[n + a] : pv[a] * pv[n + bb] + pv[bb] * pv[n + a];
+      }
+      Dn[(size_t)(oT + e) * dp + d + i] = v;
+    }
+  }
 }
 
 }  // namespace tmpc
