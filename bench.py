@@ -82,6 +82,12 @@ def cpu_baseline(p, nx, mb, tol):
                       f"{int(o1['iters'][0])} iterations)"}
 
 
+# Everything that libraries print on stdout while the bench runs (RCCL prints its version banner there at communicator creation) goes
+# to stderr: stdout carries exactly one line, the JSON record.
+REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -208,7 +214,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 2.0 ** -25)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps(line) + '\n').encode())      # the ONE line on stdout (libraries' banners went to stderr)
     if use_dist:
         dist.destroy_process_group()
 
