@@ -384,6 +384,47 @@ __device__ __forceinline__ void jacobi_impl(double* A, int n, double* cs, int la
 }
 __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int lane) { jacobi_impl(A, n, cs, lane, 1e-31); }
 
+// smallest eigenvalue of the symmetric tridiagonal matrix (dd, ee) in LDS: Sturm-count multisection over 64 shifts per round (wave-uniform result)
+__device__ __forceinline__ double tridiag_lmin(const double* dd, const double* ee, int n, int lane) {
+  // Gershgorin lower bound, min-diagonal upper bound of lambda_min
+  double glo = 1e300, ghi = 1e300;
+  if (lane < n) {
+    const double el = (lane > 0) ? fabs(ee[lane - 1]) : 0.0, er = (lane < n - 1) ? fabs(ee[lane]) : 0.0;
+    glo = dd[lane] - el - er; ghi = dd[lane];
+  }
+  double lo = wave_min(glo), hi = wave_min(ghi);
+  const double scale = fmax(fabs(lo), fabs(hi));
+  lo -= 1e-14 * scale + 1e-300;
+  // multisection: lane l counts eigenvalues below sigma_l; lambda_min lies in the last interval with count 0
+  for (int round = 0; round < 7 && (hi - lo) > 4e-16 * fmax(scale, 1e-300); ++round) {
+    const double h = (hi - lo) / 65.0;
+    const double sig = lo + h * (double)(lane + 1);
+    // Sturm count without divisions: p_i = (d_{i-1} - sigma) p_{i-1} - e_{i-2}^2 p_{i-2}; the number of sign changes of p_0 .. p_n is
+    // the number of eigenvalues below sigma (a zero takes the sign opposite to its predecessor); rescaled against overflow
+    int cnt = 0;
+    double pm = 1.0, pc = dd[0] - sig;
+    if (pc == 0.0) pc = -1e-300;
+    if (pc < 0.0) ++cnt;
+    for (int i = 1; i < n; ++i) {
+      const double e2 = ee[i - 1] * ee[i - 1];
+      double pn = fma(dd[i] - sig, pc, -e2 * pm);
+      if (pn == 0.0) pn = (pc < 0.0) ? 1e-300 : -1e-300;
+      if ((pn < 0.0) != (pc < 0.0)) ++cnt;
+      const double big = fmax(fabs(pn), fabs(pc));
+      const double sc = (big > 1e100) ? 1e-100 : ((big < 1e-100) ? 1e100 : 1.0);
+      pm = pc * sc; pc = pn * sc;
+    }
+    // number of shifts with zero eigenvalues below them
+    const unsigned long long mask = __ballot(cnt == 0);
+    const int nz = __popcll(mask);            // counts are monotone in sigma: the first nz shifts have count 0
+    const double nlo = lo + h * (double)nz;   // sigma_{nz-1} (or lo)
+    const double nhi = (nz < 64) ? lo + h * (double)(nz + 1) : hi;
+    lo = nlo; hi = nhi;
+  }
+  return 0.5 * (lo + hi);
+}
+
+
 // Smallest eigenvalue of the symmetric n x n LDS matrix A (destroyed): Householder tridiagonalisation
 // (backward stable, ~4/3 n^3 flops, a quarter of the LDS traffic of a converged Jacobi) followed by Sturm-count
 // multisection over 64 shifts per round.  One single-wave block; vv: LDS scratch of >= 3*32 doubles.
@@ -391,7 +432,7 @@ __device__ __forceinline__ void jacobi_eigvals(double* A, int n, double* cs, int
 __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, int lane) {
   double* dd = vv + 32;       // diagonal
   double* ee = vv + 64;       // off-diagonal: ee[i] couples i and i+1
-  if (n == 1) return A[0];
+  if (n == 1) { const double a00 = A[0]; if (lane == 0) dd[0] = a00; wsync(); return a00; }
   for (int j = 0; j + 2 < n; ++j) {
     const int m = n - j - 1;                 // length of the column below the diagonal
     const double xi = (lane < m) ? A[(j + 1 + lane) * LD + j] : 0.0;
@@ -436,44 +477,16 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
   if (lane < n) dd[lane] = A[lane * LD + lane];
   if (lane == 0) ee[n - 2] = A[(n - 1) * LD + n - 2];
   wsync();
-  // Gershgorin lower bound, min-diagonal upper bound of lambda_min
-  double glo = 1e300, ghi = 1e300;
-  if (lane < n) {
-    const double el = (lane > 0) ? fabs(ee[lane - 1]) : 0.0, er = (lane < n - 1) ? fabs(ee[lane]) : 0.0;
-    glo = dd[lane] - el - er; ghi = dd[lane];
-  }
-  double lo = wave_min(glo), hi = wave_min(ghi);
-  const double scale = fmax(fabs(lo), fabs(hi));
-  lo -= 1e-14 * scale + 1e-300;
-  // multisection: lane l counts eigenvalues below sigma_l; lambda_min lies in the last interval with count 0
-  for (int round = 0; round < 7 && (hi - lo) > 4e-16 * fmax(scale, 1e-300); ++round) {
-    const double h = (hi - lo) / 65.0;
-    const double sig = lo + h * (double)(lane + 1);
-    // Sturm count without divisions: p_i = (d_{i-1} - sigma) p_{i-1} - e_{i-2}^2 p_{i-2}; the number of sign changes of p_0 .. p_n is
-    // the number of eigenvalues below sigma (a zero takes the sign opposite to its predecessor); rescaled against overflow
-    int cnt = 0;
-    double pm = 1.0, pc = dd[0] - sig;
-    if (pc == 0.0) pc = -1e-300;
-    if (pc < 0.0) ++cnt;
-    for (int i = 1; i < n; ++i) {
-      const double e2 = ee[i - 1] * ee[i - 1];
-      double pn = fma(dd[i] - sig, pc, -e2 * pm);
-      if (pn == 0.0) pn = (pc < 0.0) ? 1e-300 : -1e-300;
-      if ((pn < 0.0) != (pc < 0.0)) ++cnt;
-      const double big = fmax(fabs(pn), fabs(pc));
-      const double sc = (big > 1e100) ? 1e-100 : ((big < 1e-100) ? 1e100 : 1.0);
-      pm = pc * sc; pc = pn * sc;
-    }
-    // number of shifts with zero eigenvalues below them
-    const unsigned long long mask = __ballot(cnt == 0);
-    const int nz = __popcll(mask);            // counts are monotone in sigma: the first nz shifts have count 0
-    const double nlo = lo + h * (double)nz;   // sigma_{nz-1} (or lo)
-    const double nhi = (nz < 64) ? lo + h * (double)(nz + 1) : hi;
-    lo = nlo; hi = nhi;
-  }
-  return 0.5 * (lo + hi);
+  return tridiag_lmin(dd, ee, n, lane);
 }
-
+// largest eigenvalue of the tridiagonal matrix that the last tridiag_min_eig call left in vv (lambda_max(T) = -lambda_min(-T))
+__device__ __forceinline__ double tridiag_max_after(double* vv, int n, int lane) {
+  double* dd = vv + 32; double* ee = vv + 64;
+  if (n == 1) return dd[0];
+  if (lane < n) dd[lane] = -dd[lane];
+  wsync();
+  return -tridiag_lmin(dd, ee, n, lane);
+}
 // min / max of the diagonal after jacobi_eigvals (wave-uniform result)
 __device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, double* mn, double* mx) {
   double lo = 1e300, hi = -1e300;

@@ -519,9 +519,10 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
     t0[i * LD + j] = hc;
   }
   wsync();
-  jacobi_eigvals(t0, n, cs, lane);
-  double lo, hi;
-  diag_minmax(t0, n, lane, &lo, &hi);
+  // extreme eigenvalues of Hc_k for the status rule (convexifier.py:438-451): Householder tridiagonalisation + Sturm multisection at
+  // both ends (a full Jacobi diagonalisation cost 3/4 of this kernel)
+  const double lo = tridiag_min_eig(t0, n, cs, lane);
+  const double hi = tridiag_max_after(cs, n, lane);
   if (lane == 0) {
     double* q = w.part + (size_t)sid * NPART;
     q[Q_MINEIG] = lo; q[Q_MAXEIG] = hi;
