@@ -310,6 +310,67 @@ __device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, con
   }
 }
 
+// Block-size generic forms of the pair routines.  NT = 64: the single-wave pair above.  NT = 256: matrix A on wave 0 and matrix B
+// on wave 1, two lanes per row (column) each -- the dot products are half as long as in the one-lane-per-row pair form -- and the
+// other two waves only keep the barriers.  The returned count of non-positive pivots is the same in every thread.
+template <int NT>
+__device__ __forceinline__ int chol_lower_pair_t(double* A, double* B, int n, int tid) {
+  if (NT == 64) return chol_lower_pair(A, B, n, tid);
+  const int wv = tid >> 6, lane = tid & 63;
+  const int row = lane & 31, half = lane >> 5;
+  double* Mx = wv ? B : A;
+  const bool mine = (wv < 2) && row < n;
+  int nbad = 0;
+  for (int j = 0; j < n; ++j) {
+    double acc = 0.0;
+    if (mine && row >= j) {
+      const double* li = Mx + row * LD;
+      const double* lj = Mx + j * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = half;
+      for (; k + 2 < j; k += 4) { a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 2], lj[k + 2], a1); }
+      for (; k < j; k += 2) a0 = fma(li[k], lj[k], a0);
+      acc = a0 + a1;
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    double sij = 0.0;
+    if (mine && row >= j) sij = Mx[row * LD + j] - acc;
+    double piv = __shfl(sij, j, 64);
+    if (!(piv > 0.0)) { piv = 1e-300; if (wv < 2) ++nbad; }
+    const double rinv = rsqrt_nr(piv);
+    if (half == 0 && mine && row >= j) Mx[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
+    wsync();
+  }
+  return (int)block_sum<NT>((lane == 0 && wv < 2) ? (double)nbad : 0.0);
+}
+template <int NT>
+__device__ __forceinline__ void tri_inv_lower_pair_t(double* __restrict__ LiA, const double* __restrict__ LA,
+                                                     double* __restrict__ LiB, const double* __restrict__ LB, int n, int tid) {
+  if (NT == 64) { tri_inv_lower_pair(LiA, LA, LiB, LB, n, tid); return; }
+  const int wv = tid >> 6, lane = tid & 63;
+  const int c = lane & 31, half = lane >> 5;
+  const double* L = wv ? LB : LA;
+  double* Li = wv ? LiB : LiA;
+  const bool on = wv < 2;
+  double rdl = 1.0;
+  if (on && lane < n) rdl = 1.0 / L[lane * LD + lane];
+  for (int i = 0; i < n; ++i) {
+    const double rdi = __shfl(rdl, i, 64);
+    double acc = 0.0;
+    if (on && c < i) {
+      const double* li = L + i * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = c + half;
+      for (; k + 2 < i; k += 4) { a0 = fma(li[k], Li[k * LD + c], a0); a1 = fma(li[k + 2], Li[(k + 2) * LD + c], a1); }
+      for (; k < i; k += 2) a0 = fma(li[k], Li[k * LD + c], a0);
+      acc = a0 + a1;
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (on && half == 0 && c < n) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
+    wsync();
+  }
+}
+
 // Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and
 // leaves its eigenvalues on the diagonal.  cs: LDS scratch of >= 4*16 doubles.  One single-wave block works
 // on one matrix (the block barrier is then a wave-local barrier).

@@ -227,9 +227,9 @@ __global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
     for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
     wsync();
     TMPC_T(10)
-    nbad += chol_lower_pair(sS, t0, n, lane);
+    nbad += chol_lower_pair_t<NT>(sS, t0, n, lane);
     TMPC_T(11)
-    tri_inv_lower_pair(sLi, sS, t1, t0, n, lane);
+    tri_inv_lower_pair_t<NT>(sLi, sS, t1, t0, n, lane);
     TMPC_T(12)
     s2g<NT>((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
     s2g<NT>((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
