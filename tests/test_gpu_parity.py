@@ -623,6 +623,23 @@ def test_step3_handle_serves_the_plain_model(hc):
     assert np.array_equal(o1['Hc'], o2['Hc'])
 
 
+# ----------------------------------------------------------------------------- full-size parity against the compiled CPU port of the oracle
+@pytest.mark.parametrize('name,p,nx,mb,nb', [('c4 bench shape', 64, 24, 8, 2), ('c5 AWE-shaped synthetic', 200, 20, 10, 1)])
+def test_full_size_parity_vs_cpu_port(hc, name, p, nx, mb, nb):
+    """BASELINE configs[3] / configs[4] at their FULL stage size and period, against oracle/cpu_ipm -- the C++/OpenMP restatement of the
+    structured oracle (tests/test_cpu_ipm.py ties it to the numpy oracle at <= 1.6e-9) -- which solves such a problem in seconds where
+    the numpy oracle needs minutes: the same 1e-8 bar as every other parity test, on the headline workload itself."""
+    import cpu_ipm
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_batch(424242, nb, p, nx, mb)
+    out = hc(p, nx, mb).convexify_batch(A, B, H)
+    ref = cpu_ipm.convexify_batch(A, B, H, threads=min(nb, 4))
+    for b in range(nb):
+        assert int(out['status'][b]) == int(ref['status'][b]) == 0
+        assert rel(out['Hc'][b], ref['Hc'][b]) < PARITY
+        assert abs(out['kappa'][b] - ref['kappa'][b]) < 1e-9 * max(1.0, ref['kappa'][b])
+
+
 # ----------------------------------------------------------------------------- full-size properties (no oracle)
 def test_full_size_c4_properties(hc):
     """BASELINE configs[3] stage size and period (nx=24, m=8, p=64), a small batch: size-independent properties --
