@@ -11,18 +11,16 @@
 // system its rows reach P_k, P_{k+1}, tau and alpha only:
 //     a_k,i = -svec(W_i[:nx,:nx]) (P_k),   b_k,i = svec(V_k W_i V_k') (P_{k+1}),   W_i = sum_r sym(X_r g_i g_i' S_r^-1) = sum_r sym(w_ri u_ri'),
 //     c_tau, c_alpha (border), T_loc,loc (own block; zero coupling for the epigraph entries).
-// DEFAULT (block form): y_loc of stage k rides in block k+1 of the block-cyclic-tridiagonal system, behind P_{k+1} (block size
+// y_loc of stage k rides in block k+1 of the block-cyclic-tridiagonal system, behind P_{k+1} (block size
 // d + nz instead of d): rows d.. of D_{k+1} hold b_k and T_loc,loc, the same rows of the coupling block hold a_k (k_aug_fill), the
 // tails of the right-hand side / border vectors hold r_loc, c_tau, c_alpha (k_aug_gather), and dy_loc is the tail of the block
-// solution.  y_loc is then pivoted AFTER the two P blocks it couples to -- the order of the oracle's border solve -- and k_schur,
-// k_factor, k_solve run unchanged on the larger blocks.
-// TMPC_FLAG_ELIM (first design, kept for A/B): y_loc is eliminated stage by stage BEFORE the factorisation with K_k = T_loc,loc^-1:
-//     D_k -= a_k K_k a_k' + b_{k-1} K_{k-1} b_{k-1}',  C_k -= a_k K_k b_k',  border columns, 2 x 2 border and right-hand sides likewise,
-//     dy_loc = K_k (r_loc - T_loc,y dy).
-// It loses digits whenever a multiplier is active (z/phi << T_phiphi) and its direction g g' is nearly reachable by calH(dP): D - aKa'
-// then cancels to ~ (z/phi)/T_phiphi of D; replayed in numpy the direction error reaches 1e-6 .. 0.4 on such problems while the
-// block form stays at rounding level.
-// Every kernel here is one single-wave workgroup per stage (k_phi_schur: 256 threads) and only runs when dm.nr > 0.
+// solution.  y_loc is then pivoted AFTER the two P blocks it couples to -- the order of the oracle's border solve -- and k_schur and
+// the factorisation / substitution kernels of tmpc_cr.h run unchanged on the larger blocks.
+// (The first design eliminated y_loc stage by stage BEFORE the factorisation, D_k -= a_k K_k a_k' + ... with K_k = T_loc,loc^-1.  It lost
+// digits whenever a multiplier is active (z/phi << T_phiphi) and its direction g g' is nearly reachable by calH(dP): D - aKa' then
+// cancels to ~ (z/phi)/T_phiphi of D; replayed in numpy the direction error reached 1e-6 .. 0.4 on such problems while the block
+// form stays at rounding level.  Removed in round 2.)
+// Every kernel here is one single-wave workgroup per stage and only runs when dm.nr > 0.
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_small.h"
@@ -343,7 +341,7 @@ __device__ __forceinline__ double phi_bvec(const double* pvec, const Dims& dm, s
   return (a == c) ? v : 2.0 * v;
 }
 
-// after k_stage_rhs, before k_gather / k_solve: r_loc, K r_loc, and the eliminated part of the border right-hand sides
+// after k_stage_rhs, before k_gather / the substitutions: r_loc, K r_loc, and the eliminated part of the border right-hand sides
 __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), lane = threadIdx.x;
@@ -398,7 +396,7 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug
   }
 }
 
-// after k_solve, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
+// after the substitutions, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
 // Mehrotra second-order terms in pass 1
 __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -532,7 +530,7 @@ __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
 // ---- augmented-block form: y_loc of stage k rides in block k+1 behind P_{k+1}, i.e. it is pivoted AFTER the two P blocks it
 // couples to (the order of the oracle's border solve).  Rows d .. d+nz-1 of block k+1:
 //   D_{k+1}[d+i][0..d) = b_k,i   D_{k+1}[d+i][d+j] = T_loc,loc[i][j]   coupling block [block k+1][block k]: row d+i = a_k,i
-// after k_schur (which writes identity there), before k_factor
+// after k_schur (which writes identity there), before the factorisation
 __global__ void __launch_bounds__(64) k_aug_fill(WS w, Dims dm) {
   const int sid = stage_id(w, dm), lane = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
