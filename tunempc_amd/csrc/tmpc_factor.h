@@ -1,7 +1,8 @@
-// Building blocks of the block factorisation of the HKM Schur matrix (tmpc_cr.h holds the kernels): the fp64 MFMA tile GEMM
-// C (+)= A B' (v_mfma_f64_4x4x4_4b, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile = 2 x 8 fragments of 16 x 4,
-// K staged through LDS in double-buffered 32-column slabs), the 64 x 64 tile Cholesky with its inverse, the
-// left-looking blocked Cholesky of a d x d block, and the skinny MFMA GEMM that carries the triangular solves.
+// Building blocks of the block factorisation of the HKM Schur matrix (tmpc_cr.h holds the kernels): the register-staged fp64 MFMA
+// tile GEMM C (+)= A B' (v_mfma_f64_4x4x4_4b, 64 x 64 output tile per workgroup step, each wave a 32 x 32 sub-tile = 2 x 8 fragments of
+// 16 x 4, K staged global -> VGPR -> LDS in double-buffered 32-column slabs; it carries the block Cholesky of k_cr_potrf, blocks wider
+// than 320 and the scalar-FMA debug path -- the batched solves and updates run on the LDS-DMA core of tmpc_gemm_dma.h), the 64 x 64
+// tile Cholesky with its inverse, the left-looking blocked Cholesky of a d x d block, and the skinny MFMA GEMM of the substitutions.
 #pragma once
 #include "tmpc_common.h"
 
