@@ -37,11 +37,19 @@ TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
 KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h')]
 
 
+def _normalised(path):
+    """source text without // comments and whitespace: comment edits do not make a measurement stale, code edits do"""
+    import re
+    txt = open(path).read()
+    txt = re.sub(r'//[^\n]*', '', txt)
+    return re.sub(r'\s+', '', txt).encode()
+
+
 def kernel_sources_sha():
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(open(f, 'rb').read())
+        h.update(_normalised(f))
     return h.hexdigest()[:16]
 
 

@@ -15,11 +15,19 @@ def per_launch(path, counter, kernel):
     return sum(v for _, v in rows) / max(len(rows), 1), len(rows)
 
 
+def _normalised(path):
+    """source text without // comments and whitespace: comment edits do not make a measurement stale, code edits do"""
+    import re
+    txt = open(path).read()
+    txt = re.sub(r'//[^\n]*', '', txt)
+    return re.sub(r'\s+', '', txt).encode()
+
+
 def sources_sha():
     import hashlib
     h = hashlib.sha256()
     for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h'):
-        h.update(open(os.path.join(ROOT, 'tunempc_amd', 'csrc', f), 'rb').read())
+        h.update(_normalised(os.path.join(ROOT, 'tunempc_amd', 'csrc', f)))
     return h.hexdigest()[:16]
 
 
