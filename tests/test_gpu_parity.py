@@ -103,9 +103,10 @@ def _spd_cyclic(rng, p, d):
 
 
 @pytest.mark.parametrize('p,d', [(1, 6), (2, 10), (3, 10), (5, 21), (4, 78), (3, 136), (3, 300), (7, 45), (2, 3), (6, 20), (8, 33), (9, 16), (13, 10),
-                                 (16, 70), (30, 10), (64, 24), (200, 5)])
+                                 (16, 70), (30, 10), (64, 24), (200, 5), (3, 330), (4, 410), (2, 500), (3, 320), (5, 250)])
 def test_block_cyclic_cholesky_solve(hc, p, d):
-    """Cyclic-reduction block factorisation + solves (tmpc_cr.h) vs a dense numpy solve of the same SPD block-cyclic-tridiagonal system."""
+    """Cyclic-reduction block factorisation + solves (tmpc_cr.h) vs a dense numpy solve of the same SPD block-cyclic-tridiagonal system
+    (d <= 320: the LDS-DMA solve kernel with up to five column tiles in registers; wider blocks: the left-looking strips)."""
     h = hc(2, 3, 1)
     rng = np.random.default_rng(p * 100 + d)
     D, Cc, T = _spd_cyclic(rng, p, d)
