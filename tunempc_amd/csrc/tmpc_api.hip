@@ -406,7 +406,7 @@ static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
 // rs / mt: rows per workgroup of the triangular solves / edge of the output tile of the updates; 0 = by the amount of work
 // (whole 128-wide pieces while every CU still gets several workgroups, 64 otherwise).  The result does not depend on them.
 static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st,
-                      int rs_opt, int mt_opt, std::vector<hipEvent_t>* kev = nullptr, int* nkev = nullptr) {
+                      int rs_opt, int mt_opt, std::vector<hipEvent_t>* kev = nullptr, int* nkev = nullptr, int fuse_fwd1 = 0) {
   const CrDev cd = cr_dev(sc, d_sched, alist);
   int ke = 0;
   // profile mode: an event before and after every launch; pair i belongs to class i % 3 (potrf, trsm, update)
@@ -427,6 +427,8 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     if (mf) hipLaunchKernelGGL(k_cr_potrf<true>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else hipLaunchKernelGGL(k_cr_potrf<false>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
     mark(0);
+    // fused forward substitution of pass 1 (see k_cr_update_dma): z_i <- L_i^-1 z_i for this level's nodes as soon as L_i exists
+    if (fuse_fwd1) hipLaunchKernelGGL(k_cr_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.eoff, lv.nelim, count, 1);
     if (lv.nupd == 0) { mark(1); mark(1); mark(2); mark(2); continue; }                  // last node: nothing left to update
     const long work64 = (long)count * lv.nelim * 2 * nt64;                 // 64-row strips of this level
     const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
@@ -449,7 +451,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     if (mf && use_dma) {
       const int nm64 = (dm.dp + 63) / 64;
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
-      hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
+      hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
@@ -459,10 +461,11 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
 }
 
 // forward and backward substitution with that factor for the right-hand sides of `pass` (W3 / Z, see cr_nc)
-static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st, int pass) {
+static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st, int pass, bool skip_fwd = false) {
   const CrDev cd = cr_dev(sc, d_sched, alist);
   const size_t lds = solve_lds(dm);
   for (const CrLevel& lv : sc.lev) {
+    if (skip_fwd) break;                 // the forward sweep ran inside the factorisation (cr_factor, fuse_fwd1)
     hipLaunchKernelGGL(k_cr_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
     if (lv.nupd) hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), lds, st, w, dm, cd, lv.uoff, lv.nupd, count, pass);
   }
@@ -548,18 +551,27 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       HIPCHK(hipGetLastError());
       return TMPC_OK;
     }
+    // plain model: the right-hand sides of the predictor pass are ready before the factorisation, and its forward substitution
+    // rides inside it (k_cr_update_dma reads the O blocks anyway): one read of every O block less per main-phase iteration
+    static const int fuse_env = [] { const char* e = getenv("TMPC_FUSE_FWD"); return e ? atoi(e) : 1; }();
+    const bool fuse1 = fuse_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1;
+    if (fuse1) {
+      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
+    }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
-    if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev);
+    if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
-      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
+      const bool fused = (pass == 1 && fuse1);
+      if (!fused) TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
-      hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (!fused) hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass);
+      cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, fused);
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);

@@ -491,8 +491,22 @@ __global__ void __launch_bounds__(256, 2) k_cr_update(WS w, Dims dm, CrDev cr, i
   }
 }
 
+// which right-hand sides a problem solves in this pass: pass 1 (main phase only) [rhs | u_tau | u_alpha] in W3; pass 2 the
+// corrector rhs alone in Z (main phase) or all three (centering: no predictor).  0: nothing to do.
+__device__ __forceinline__ int cr_nc(const WS& w, int b, int pass) {
+  const int phase = w.iprob[(size_t)b * IS + I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
+  return ((pass == 1) || (phase != PH_MAIN && !w.iprob[(size_t)b * IS + I_CHORD])) ? 3 : 1;     // chord step: rhs only
+}
+__device__ __forceinline__ double* cr_rhs(const WS& w, const Dims& dm, int b, int node, int nc) {
+  return ((nc == 3) ? w.W3 : w.Z) + ((size_t)b * dm.p + node) * dm.dp * nc;
+}
+
 // The same items on the LDS-DMA core (tmpc_gemm_dma.h): 64 x 64 tiles, the two edges of a doubly updated node as ONE K stream.
-__global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
+// fuse != 0: the forward substitution step of pass 1, z_s -= O_s z_i (k_cr_fwd_off), rides along in the first column tile of every row tile
+// of a surviving node -- the O blocks stream through this kernel anyway, so pass 1 reads them once less (the right-hand sides of pass 1
+// and k_cr_fwd_diag of this level must have run before; problems without a predictor pass are left alone).
+__global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int fuse) {
   const int dp = dm.dp;
   const int nm = (dp + 63) / 64;
   const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
@@ -523,8 +537,12 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
     double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
     const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
     const double* O1 = ur[CU_E1] >= 0 ? cr_edge(w, dm, b, ur[CU_E1]) : nullptr;
+    const bool fz = fuse && tn == 0 && cr_nc(w, b, 1) == 3;
+    const double* z0 = fz ? cr_rhs(w, dm, b, ur[CU_S0], 3) : nullptr;
+    const double* z1 = (fz && O1) ? cr_rhs(w, dm, b, ur[CU_S1], 3) : nullptr;
+    double* yz = fz ? cr_rhs(w, dm, b, ur[CU_NODE], 3) + (size_t)m0 * 3 : nullptr;
     wg_tile_dma<UPD_DMA_DEPTH>(C, dp, O0 + (size_t)m0 * dp, O0 + (size_t)n0 * dp, O1 ? O1 + (size_t)m0 * dp : nullptr, O1 ? O1 + (size_t)n0 * dp : nullptr,
-                               dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds);
+                               dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds, 0, z0, z1, yz, 3);
   } else {
     const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
     if (er[CE_FILL] < 0) return;
@@ -543,17 +561,6 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
 // then z_s -= O_s z_i for the surviving neighbours; backward in reverse: z_i <- L_i^-T (z_i - O_a' z_a - O_b' z_b).
 // The matrix-vector work is the skinny MFMA GEMM of tmpc_factor.h (wg_gemv16); every factor block is streamed once per sweep.
 constexpr int cr_solve_lds_doubles(int dp) { return 3 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
-
-// which right-hand sides a problem solves in this pass: pass 1 (main phase only) [rhs | u_tau | u_alpha] in W3; pass 2 the
-// corrector rhs alone in Z (main phase) or all three (centering: no predictor).  0: nothing to do.
-__device__ __forceinline__ int cr_nc(const WS& w, int b, int pass) {
-  const int phase = w.iprob[(size_t)b * IS + I_PHASE];
-  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
-  return ((pass == 1) || (phase != PH_MAIN && !w.iprob[(size_t)b * IS + I_CHORD])) ? 3 : 1;     // chord step: rhs only
-}
-__device__ __forceinline__ double* cr_rhs(const WS& w, const Dims& dm, int b, int node, int nc) {
-  return ((nc == 3) ? w.W3 : w.Z) + ((size_t)b * dm.p + node) * dm.dp * nc;
-}
 
 __global__ void __launch_bounds__(256) k_cr_fwd_diag(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
   const int it = cr_item(count * nelim);

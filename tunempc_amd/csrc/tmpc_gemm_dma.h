@@ -23,14 +23,18 @@ namespace tmpc {
 typedef __attribute__((address_space(3))) void* lds_vptr;
 constexpr int DMA_SLAB = 2048;                 // doubles per LDS buffer: A slab (64 x 16) + B slab
 template <int DEPTH>
-constexpr int dma_lds_doubles() { return DEPTH * DMA_SLAB; }
+constexpr int dma_lds_doubles() { return DEPTH * DMA_SLAB + 512; }       // + two mini slabs for fused right-hand sides
 
 // swizzle of row r
 __device__ __forceinline__ int dma_sw(int r) { return (r & 7) ^ (((r >> 3) & 1) << 1); }
 
 template <int DEPTH>
 __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0, const double* B0, const double* A1, const double* B1, int ld,
-                                            int M, int N, int K, int mode, int tri, int rot, double* lds, int ldb = 0) {
+                                            int M, int N, int K, int mode, int tri, int rot, double* lds, int ldb = 0,
+                                            const double* z0 = nullptr, const double* z1 = nullptr, double* yz = nullptr, int znc = 0) {
+  // z0 / z1 (optional, [K][znc], znc <= 4): right-hand sides that ride along as one more B fragment of the wave that owns the first strip,
+  //   yz[M][znc] -= A0 z0 (+ A1 z1)   -- the forward substitution step of the node this tile row belongs to, fused into its update
+  //   (the slab of z for the next step is fetched during the MFMAs of the current one and parked next to the operand buffers).
   if (ldb == 0) ldb = ld;                                   // leading dimension of the B operands (default: as A)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wc0 = ((wv + rot) & 3) * 16;
@@ -70,6 +74,14 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = 0.0;
+  const bool zf = (z0 != nullptr), zf0 = zf && wc0 == 0;   // (block-uniform / wave-uniform: the wave of the first strip, which always has work)
+  double* Zs = lds + DEPTH * DMA_SLAB;                      // [2][256]: rows 4 q of a mini slab hold right-hand side q
+  double accz[4] = {0.0, 0.0, 0.0, 0.0}, zreg = 0.0;
+  int obz[2], zpos = 0;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) obz[hh] = (4 * fj) * 16 + 2 * ((4 * hh + fk) ^ dma_sw(4 * fj));
+  const bool zld = zf && tid < 16 * znc;                    // this thread moves one entry of every z slab
+  if (zld) { const int k = tid / znc, q = tid - k * znc; zpos = (4 * q) * 16 + 2 * ((k >> 1) ^ dma_sw(4 * q)) + (k & 1); }
   const int nks = K >> 4, nst = A1 ? 2 * nks : nks;
   const bool full = wave_on && i0 == 0 && i1 == 4;
 #define TMPC_DMA_ISSUE(S, Q)                                                                              \
@@ -100,19 +112,33 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
         }                                                                                                 \
       }                                                                                                   \
     }                                                                                                     \
+    if (zf0) {                                                                                            \
+      const double2_t bz = *(const double2_t*)(Zc_ + obz[hh]);                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        if (i < i1) {                                                                                     \
+          accz[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][0], bz[0], accz[i], 0, 0, 0);                 \
+          accz[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i][1], bz[1], accz[i], 0, 0, 0);                 \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
   }
+#define TMPC_DMA_ZSRC(S) (((S) >= nks ? z1 : z0) + (size_t)((S) - ((S) >= nks ? nks : 0)) * 16 * znc + tid)
 #define TMPC_DMA_STEP(S, Q)                                                                               \
   {                                                                                                       \
-    if ((S) + DEPTH - 2 < nst - 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 2)) : "memory"); } \
-    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                             \
+    if ((S) + DEPTH - 2 < nst - 1) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (DEPTH - 2)) : "memory"); } \
+    else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }                                  \
     __builtin_amdgcn_s_barrier();                                                                         \
     if ((S) + DEPTH - 1 < nst) TMPC_DMA_ISSUE((S) + DEPTH - 1, ((Q) + DEPTH - 1) % DEPTH)                 \
+    if (zld && (S) + 1 < nst) zreg = *TMPC_DMA_ZSRC((S) + 1);                                             \
     const double* As_ = lds + (Q) * DMA_SLAB;                                                             \
     const double* Bs_ = As_ + 1024;                                                                       \
+    const double* Zc_ = Zs + ((S) & 1) * 256;                                                             \
     if (full) TMPC_DMA_MMA(false)                                                                         \
     else if (wave_on) TMPC_DMA_MMA(true)                                                                  \
+    if (zld && (S) + 1 < nst) Zs[(((S) + 1) & 1) * 256 + zpos] = zreg;                                    \
   }
   __syncthreads();                                          // LDS free (previous user)
+  if (zld) Zs[zpos] = *TMPC_DMA_ZSRC(0);
 #pragma unroll
   for (int s = 0; s < DEPTH - 1; ++s)
     if (s < nst) TMPC_DMA_ISSUE(s, s)
@@ -122,8 +148,14 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
       if (s + q < nst) TMPC_DMA_STEP(s + q, q)
   }
 #undef TMPC_DMA_STEP
+#undef TMPC_DMA_ZSRC
 #undef TMPC_DMA_MMA
 #undef TMPC_DMA_ISSUE
+  if (zf0 && fj < znc) {                                     // yz -= (rows of A) z: lane holds row 16 i + 4 fq + fk, right-hand side fj
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < i1) yz[(size_t)(16 * i + 4 * fq + fk) * znc + fj] -= accz[i];
+  }
   if (wave_on) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
