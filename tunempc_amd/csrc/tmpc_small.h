@@ -507,18 +507,23 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
     const double mu = sqrt(x0 * x0 + sigma);
     const double v0 = (x0 <= 0.0) ? (x0 - mu) : (-sigma / (x0 + mu));
     const double beta = 2.0 * v0 * v0 / (sigma + v0 * v0);
-    if (lane < m) vv[lane] = (lane == 0) ? 1.0 : xi / v0;
+    const double rv0 = 1.0 / v0;             // (one reciprocal, wave-uniform, instead of a division per lane)
+    if (lane < m) vv[lane] = (lane == 0) ? 1.0 : xi * rv0;
     if (lane == 0) ee[j] = mu;               // |H x| = mu e_1 (sign irrelevant for eigenvalues of the tridiagonal)
     wsync();
-    // p = beta * A22 v
+    // p = beta * A22 v: two lanes per row (alternate columns), joined by one shuffle
     double pi = 0.0;
-    if (lane < m) {
-      const double* ar = A + (j + 1 + lane) * LD + j + 1;
+    {
+      const int r = lane & 31, c0 = lane >> 5;
       double a0 = 0.0, a1 = 0.0;
-      int c = 0;
-      for (; c + 1 < m; c += 2) { a0 = fma(ar[c], vv[c], a0); a1 = fma(ar[c + 1], vv[c + 1], a1); }
-      if (c < m) a0 = fma(ar[c], vv[c], a0);
-      pi = beta * (a0 + a1);
+      if (r < m) {
+        const double* ar = A + (j + 1 + r) * LD + j + 1;
+        int c = c0;
+        for (; c + 2 < m; c += 4) { a0 = fma(ar[c], vv[c], a0); a1 = fma(ar[c + 2], vv[c + 2], a1); }
+        for (; c < m; c += 2) a0 = fma(ar[c], vv[c], a0);
+      }
+      const double part = a0 + a1;
+      pi = beta * (part + __shfl_xor(part, 32, 64));
     }
     const double kk = 0.5 * beta * wave_sum((lane < m) ? pi * vv[lane] : 0.0);
     wsync();
@@ -538,7 +543,14 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
   if (lane < n) dd[lane] = A[lane * LD + lane];
   if (lane == 0) ee[n - 2] = A[(n - 1) * LD + n - 2];
   wsync();
-  return tridiag_lmin(dd, ee, n, lane);
+#ifdef TMPC_CYCLE_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[5 * 8 + 1] += __builtin_readcyclecounter(); }
+#endif
+  const double lm_ = tridiag_lmin(dd, ee, n, lane);
+#ifdef TMPC_CYCLE_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[5 * 8 + 2] += __builtin_readcyclecounter(); }
+#endif
+  return lm_;
 }
 // largest eigenvalue of the tridiagonal matrix that the last tridiag_min_eig call left in vv (lambda_max(T) = -lambda_min(-T))
 __device__ __forceinline__ double tridiag_max_after(double* vv, int n, int lane) {

@@ -436,9 +436,11 @@ __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
   double* A = sm;
   double* cs = A + MS;
   const double* Wg = w.Wm + (size_t)mid * n * n;
-  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * LD + j] = Wg[e]; }
-  wsync();
+  TMPC_TC0()
+  g2s(A, Wg, n, n, n, lane);               // (four loads in flight per lane)
+  TMPC_TC(5, 0)
   const double lo = tridiag_min_eig(A, n, cs, lane);
+  TMPC_TC(5, 3)
   if (lane == 0) w.eigmin[mid] = lo;
 }
 
