@@ -33,8 +33,8 @@ for (nb, p) in ((512, 64), (64, 64)):
     for cls, cn in ((1, 'k_cr_potrf'), (2, 'k_cr_trsm'), (3, 'k_cr_update')):
         v = out[cls * 8: cls * 8 + 6]; tot = v.sum()
         if cls == 2 and os.environ.get('TMPC_TRSM_RR', '1') != '0':
-            print(f"  k_cr_trsm_rr: wave 0 of block 0, cycles in the step loop over all launches {tot:.3e}")
-            for n_, x in zip(['issue B loads', 'ds_read + MFMA', 'tile transitions (store X, park, load E)', 'wait loads + LDS store', 'barrier'], v):
+            print(f"  k_cr_trsm_dma: wave 0 of block 0, cycles in the step loop over all launches {tot:.3e}")
+            for n_, x in zip(['wait for the slab DMA', 'barrier', 'issue the next DMA', 'ds_read + MFMA', 'tile transitions (store X, park, load E)'], v):
                 print(f"      {n_:42s} {x:.3e}  {100 * x / max(tot, 1):5.1f} %")
             continue
         print(f"  {cn}: wave 0 of block 0, cycles inside wg_gemm_nt over all launches {tot:.3e}")

@@ -381,8 +381,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -439,11 +438,9 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
     // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
     static const int use_dma = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();
-    static const int trd_fr = [] { const char* e = getenv("TMPC_TRSM_FR"); return (e && atoi(e) == 2) ? 2 : 4; }();     // 16-row fragments per strip (32-row strips, three workgroups per CU: measured equal, 140.4 vs 139.1 ms per factorisation)
     mark(1);
     if (mf && use_dma && dm.nt <= TRR_NT) {
-      if (trd_fr == 2) hipLaunchKernelGGL(k_cr_trsm_dma<2>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 31) / 32))), dim3(256), (size_t)trd_lds_doubles<2>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
-      else hipLaunchKernelGGL(k_cr_trsm_dma<4>, dim3(cr_grid((long)count * lv.nelim * 2 * ((dm.dp + 63) / 64))), dim3(256), (size_t)trd_lds_doubles<4>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+      hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), (size_t)trd_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);

@@ -231,21 +231,33 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm(WS w, Dims dm, CrDev cr, int
 }
 
 constexpr int TRR_NT = 5;                                  // column tiles whose partial sums fit the registers of k_cr_trsm_dma (dp <= 320)
+// wait until at most n (even, wave-uniform) vector-memory operations of this wave are outstanding, and for LDS: the count is a run-time
+// value in k_cr_trsm_dma (stores of X and loads of E sit between the slab DMAs), the instruction takes an immediate
+__device__ __forceinline__ void vm_wait_le(int n) {
+#define TMPC_VMW(K) case K / 2: asm volatile("s_waitcnt vmcnt(" #K ") lgkmcnt(0)" ::: "memory"); break;
+  switch (n >> 1) {
+    TMPC_VMW(0) TMPC_VMW(2) TMPC_VMW(4) TMPC_VMW(6) TMPC_VMW(8) TMPC_VMW(10) TMPC_VMW(12) TMPC_VMW(14) TMPC_VMW(16) TMPC_VMW(18) TMPC_VMW(20) TMPC_VMW(22)
+    default: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); break;
+  }
+#undef TMPC_VMW
+}
 // ---- phase 2, register-resident form on the LDS-DMA core: one workgroup owns a 64-row strip of an edge block and walks its column
 // tiles once.  X_i = (E_i - sum_{k<i} X_k L_ik') L_ii^-T is evaluated right-looking with the partial sums of ALL column tiles in
 // accumulator registers: as soon as X_i is known it is parked in LDS as the A operand and pushed into the accumulators of the
 // tiles j > i, while the 64 x 16 slabs of L_ji stream in by buffer_load ... lds.  Every element of E is read once and every element
 // of X written once; only L (shared by the 2 x 5 strips of a node, served by L2) is re-read -- the left-looking kernel above
-// re-reads its own X strips from memory (3 x the traffic: profiles/r2e_pmc_*.txt).  Each wave owns a 16-column strip of every
-// column tile (tmpc_gemm_dma.h), so the product with the lower-triangular tile inverse skips the K slabs beyond the strip (10 of
-// 16 strip-slabs) and the 48-wide last tile and 48-row last strip cost what they hold.
+// re-reads its own X strips from memory (3 x the traffic: profiles/r2e_pmc_*.txt).
+// Work split over the four waves, chosen so that every step costs every wave the same:
+//   * full 64-wide tiles j (all but the last): wave s owns the 16-column strip s of the tile, all four 16-row fragments ("C" layout);
+//   * the product with the lower-triangular tile inverse and the last tile (48 wide at d = 300): wave s owns the 16-row fragment s
+//     and every 16-column strip ("R" layout) -- by columns the triangle would give the waves 1 : 2 : 3 : 4 slabs and the narrow last
+//     tile would leave one wave idle (in-kernel cycle split of the by-columns form: 58 % of wave 0's time outside the MFMA section).
+// One run-time loop over the slab steps with a branch per accumulator set: the unrolled form (one copy of the step per tile pair) was
+// 97 KB of code, more than the instruction cache.
 constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
-// FR = 16-row fragments per strip: 4 (64-row strips, 80 accumulator doubles per lane, two workgroups per CU) or 2 (32-row strips: half the
-// accumulators, three workgroups per CU, L streamed twice as often from L2)
-template <int FR> constexpr int trd_lds_doubles() { return 4 * FR * 256 + TRD_DEPTH * 2048; }       // X_i / T_i as the A operand (four (16 FR) x 16 slabs) + the B steps in flight
-template <int FR>
-__global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
-  constexpr int RS = 16 * FR, ASL = RS * 16;                // rows per strip, doubles per A slab
+constexpr int trd_lds_doubles() { return 4 * 1024 + TRD_DEPTH * 2048; }       // X_i / T_i as the A operand (four 64 x 16 slabs) + the B steps in flight
+__global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  constexpr int FR = 4, RS = 16 * FR, ASL = RS * 16, DP = TRD_DEPTH;          // fragments and rows per strip, doubles per A slab
   const int dp = dm.dp, nt = dm.nt;
   const int nst = (dp + RS - 1) / RS;                       // strips per edge
   const int per = 2 * nst;
@@ -259,17 +271,23 @@ __global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims
   const int slot = which ? er[CE_EB] : er[CE_EA];
   if (slot < 0) return;
   const int node = er[CE_NODE];
-  const size_t bs = (size_t)dp * dp;
-  const double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
+#ifdef TMPC_HACK_L0
+  const double* Dk = w.D;
+  const double* Li = w.Linv;
+#else
+  const double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
   const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+#endif
   const int r0 = strip * RS;
   const int rows = (dp - r0 < RS) ? dp - r0 : RS;
   double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ws = (wv + it) & 3, wc0 = ws * 16;              // this wave's 16-column strip of every tile
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the slab walk below branches on scalars
+  const int ws = (wv + it) & 3, wc0 = ws * 16;              // this wave's column strip ("C") or row fragment ("R")
   const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
   const int i1 = (rows + 15) >> 4;                          // 16-row fragments of the strip
+  const int nlast = nt - 1, nbl = dp - 64 * nlast, ncl = nbl >> 4;            // the last tile: index, width, 16-column strips
+  const bool rw = ws < i1;                                  // this wave has a row fragment
   double* At = lds;
   double* Bs = lds + 4 * ASL;
   unsigned voT[2], voL[2];                                  // DMA: wave wv moves rows 16 wv .. + 15 of a B slab, two pieces of 8 rows
@@ -279,58 +297,95 @@ __global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims
     voT[h] = (unsigned)(row * TB + 2 * (c ^ dma_sw(row))) * 8u;
     voL[h] = (unsigned)(row * dp + 2 * (c ^ dma_sw(row))) * 8u;
   }
-  int oa[2], ob[4][2];
+  int oa[2], ob[4][2];                                      // fragment offsets of A rows 4 fq + fj (+ 256 per fragment) and B rows 4 fj + e (+ 256 per strip)
   {
     const int swa = dma_sw(4 * fq + fj);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) oa[hh] = (4 * fq + fj) * 16 + 2 * ((4 * hh + fk) ^ swa);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int swb = dma_sw(wc0 + 4 * fj + e);
+      const int swb = dma_sw(4 * fj + e);
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (wc0 + 4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
+      for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
     }
   }
-  double acc1[FR][4], acc2[FR][4], acc3[FR][4], acc4[FR][4], xa[FR][4];
-#pragma unroll
-  for (int i = 0; i < FR; ++i)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { acc1[i][c] = 0.0; acc2[i][c] = 0.0; acc3[i][c] = 0.0; acc4[i][c] = 0.0; xa[i][c] = 0.0; }
-#define TRD_ACC(k) ((k) == 1 ? acc1 : (k) == 2 ? acc2 : (k) == 3 ? acc3 : acc4)
+  // Four register sets of 16 doubles hold E - (partial sums) of the column tiles: acc1 .. acc3 the full tiles 1 .. 3 (C layout), acc0
+  // tile 0 and, once X_0 is out, the last tile (R layout).  When the block row of tile i - 1 is done, set i holds T_i: it goes to LDS as
+  // the A operand, is cleared and collects T_i L_ii^-T (R layout) -- X_i, stored and parked NEGATED so that the updates accumulate
+  // E_j - sum_k X_k L_jk'.  E_1 .. E_3 are read at the start, E_last after X_0: no global load sits on the path between two tiles.
+  double acc0[4][4], acc1[4][4], acc2[4][4], acc3[4][4];
+  int vmtot = 0, vmk0 = 0, vmk1 = 0, vmk2 = 0;             // vector-memory operations issued so far; the count right after the DMA of step s (slot s % DP)
 #define TRD_NB(T) ((dp - 64 * (T) < 64) ? dp - 64 * (T) : 64)
-  // lane <-> memory: rows 16 i + 4 fq + fk of the four fragments, columns wc0 + 4 fj .. + 3 of the tile
-#define TRD_LOAD_E(I)                                                                                       \
+  // C layout, lane <-> memory: rows 16 i + 4 fq + fk of the four fragments, columns wc0 + 4 fj .. + 3 of the tile
+#define TRD_LOAD_C(I, SET)                                                                                  \
   {                                                                                                         \
     const bool on_ = wc0 < TRD_NB(I);                                                                       \
-    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
       double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;                                                        \
       if (on_ && i < i1) {                                                                                  \
         gcptr2 cp = (gcptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (I) + wc0 + 4 * fj);            \
         u0 = cp[0]; u1 = cp[1];                                                                             \
       }                                                                                                     \
-      xa[i][0] = u0[0]; xa[i][1] = u0[1]; xa[i][2] = u1[0]; xa[i][3] = u1[1];                               \
+      SET[i][0] = u0[0]; SET[i][1] = u0[1]; SET[i][2] = u1[0]; SET[i][3] = u1[1];                           \
     }                                                                                                       \
+    if (on_) vmtot += 2 * i1;                                                                               \
   }
-#define TRD_PARK()          /* xa -> A operand: slab = this strip, K pairs 2 fj and 2 fj + 1 of every row */ \
+  // R layout: rows wc0 + 4 fq + fk, columns 16 c + 4 fj .. + 3 of the strips c < NC of the tile
+#define TRD_LOAD_R(I, NC, SET)                                                                              \
   {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+      double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;                                                        \
+      if (rw && c < (NC)) {                                                                                 \
+        gcptr2 cp = (gcptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);            \
+        u0 = cp[0]; u1 = cp[1];                                                                             \
+      }                                                                                                     \
+      SET[c][0] = u0[0]; SET[c][1] = u0[1]; SET[c][2] = u1[0]; SET[c][3] = u1[1];                           \
+    }                                                                                                       \
+    if (rw) vmtot += 2 * (NC);                                                                              \
+  }
+#define TRD_STORE_R(I, NC, SET)                                                                             \
+  if (rw) {                                                                                                 \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+      if (c < (NC)) {                                                                                       \
+        typedef double2_t __attribute__((address_space(1)))* gptr2;                                         \
+        gptr2 cp = (gptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);              \
+        cp[0] = (double2_t){SET[c][0], SET[c][1]}; cp[1] = (double2_t){SET[c][2], SET[c][3]};               \
+      }                                                                                                     \
+    }                                                                                                       \
+    vmtot += 2 * (NC);                                                                                      \
+  }
+  // SG * set -> A operand.  C: slab = this wave's strip, K pairs 2 fj and 2 fj + 1 of every row; R: this wave's rows of the slabs c < NC
+#define TRD_PARK_C(SET)                                                                                     \
+  {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
       const int row = 16 * i + 4 * fq + fk, sw_ = dma_sw(row);                                              \
       double* q = At + ws * ASL + row * 16;                                                                \
-      *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){xa[i][0], xa[i][1]};                            \
-      *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){xa[i][2], xa[i][3]};                        \
+      *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){SET[i][0], SET[i][1]};                          \
+      *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){SET[i][2], SET[i][3]};                      \
     }                                                                                                       \
   }
-#define TRD_ZERO_XA()                                                                                       \
+#define TRD_PARK_R(NC, SET, SG)                                                                             \
+  if (rw) {                                                                                                 \
+    const int row = wc0 + 4 * fq + fk, sw_ = dma_sw(row);                                                   \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+      if (c < (NC)) {                                                                                       \
+        double* q = At + c * ASL + row * 16;                                                               \
+        *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){SG SET[c][0], SG SET[c][1]};                  \
+        *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){SG SET[c][2], SG SET[c][3]};              \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+#define TRD_ZERO(SET)                                                                                       \
   {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < FR; ++i)                                                           \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] = 0.0;                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) SET[i][c] = 0.0;                                        \
   }
   // B stream: for every column tile i the slabs of Linv_i (K = nb_i), then those of L_ji, j > i (K = 64).  (ii, ij, is) = next slab to issue.
-  int ii = 0, ij = 0, is = 0, nissued = 0, ndone = 0, ylast = 0;       // ylast: DMA pieces per wave of the step issued last
+  int ii = 0, ij = 0, is = 0, nissued = 0, ndone = 0;
 #define TRD_ISSUE()          /* one step = the slabs 2 is and 2 is + 1 (if the K range has it) of the pair (ii, ij) */ \
   {                                                                                                         \
     if (ii < nt) {                                                                                          \
-      double* dst_ = Bs + (nissued % TRD_DEPTH) * 2048 + wv * 256;                                          \
+      double* dst_ = Bs + (nissued % DP) * 2048 + wv * 256;                                                 \
       const int nsl_ = (ij == ii) ? (TRD_NB(ii) >> 4) : 4;                                                  \
       const bool two_ = 2 * is + 1 < nsl_;                                                                  \
       if (ij == ii) {                                                                                       \
@@ -350,88 +405,146 @@ __global__ void __launch_bounds__(256, FR == 2 ? 3 : 2) k_cr_trsm_dma(WS w, Dims
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024), 16, voL[0], is * 256 + 128, 0, 0);         \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_vptr)(dst_ + 1024 + 128), 16, voL[1], is * 256 + 128, 0, 0);   \
       }                                                                                                     \
-      ++nissued; ylast = (ij == ii && !two_) ? 2 : 4;                                                       \
+      vmtot += (ij == ii && !two_) ? 2 : 4;                                                                 \
+      { const int k_ = nissued % DP; if (k_ == 0) vmk0 = vmtot; else if (k_ == 1) vmk1 = vmtot; else vmk2 = vmtot; }  \
+      ++nissued;                                                                                            \
       if (++is == ((nsl_ + 1) >> 1)) { is = 0; if (++ij >= nt) { ++ii; ij = ii; } }                         \
     }                                                                                                       \
   }
-#define TRD_MMA2(TGT, AS, BS)                                                                               \
+  // one 16-deep slab into TGT.  C: the four fragments x this wave's strip; R: this wave's fragment x the strips C0 <= c < NC.
+  // No run-time condition inside (conditional updates of single accumulators made the register allocator keep copies of the sets and
+  // spill; a reload from scratch in turn forces vmcnt(0), i.e. waits for the slab DMA just issued): the fragments beyond the rows of a
+  // short last strip are computed and never stored (a row of the result depends on the same row of the operand only), and the strip
+  // ranges of R are literals -- the dispatch on the run-time shapes sits outside, one uniform branch per step.
+#define TRD_MMA_C(TGT, AS, BS)                                                                              \
   _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                        \
-    double2_t a_[FR], b_[4];                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < FR; ++i) a_[i] = *(const double2_t*)((AS) + oa[hh] + i * 256);     \
-    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) b_[cb] = *(const double2_t*)((BS) + ob[cb][hh]);       \
-    _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                         \
-      if (i < i1) {                                                                                         \
+    double2_t a_[4], b_[4];                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *(const double2_t*)((AS) + oa[hh] + i * 256);      \
+    _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) b_[cb] = *(const double2_t*)((BS) + wc0 * 16 + ob[cb][hh]); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+      _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                    \
+        TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][0], b_[cb][0], TGT[i][cb], 0, 0, 0);          \
+        TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][1], b_[cb][1], TGT[i][cb], 0, 0, 0);          \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+#define TRD_MMA_R(TGT, AS, BS, C0, NC)                                                                      \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                        \
+    const double2_t a_ = *(const double2_t*)((AS) + oa[hh] + wc0 * 16);                                     \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+      if (c >= (C0) && c < (NC)) {                                                                          \
+        double2_t b_[4];                                                                                     \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) b_[cb] = *(const double2_t*)((BS) + c * 256 + ob[cb][hh]); \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                  \
-          TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][0], b_[cb][0], TGT[i][cb], 0, 0, 0);        \
-          TGT[i][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[i][1], b_[cb][1], TGT[i][cb], 0, 0, 0);        \
+          TGT[c][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[0], b_[cb][0], TGT[c][cb], 0, 0, 0);           \
+          TGT[c][cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_[1], b_[cb][1], TGT[c][cb], 0, 0, 0);           \
         }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
   }
-  // the slab steps of the pair (CI, CJ), literal indices: TGT = xa on the diagonal, the partial sums of tile CJ otherwise
-#define TRD_PAIR(CI, CJ, TGT)                                                                               \
-  if ((CJ) < nt) {                                                                                          \
-    const int nbi = TRD_NB(CI), nbj = TRD_NB(CJ);                                                           \
-    const int nsl = ((CJ) == (CI)) ? (nbi >> 4) : 4;                  /* 16-column slabs of this pair */ \
-    const int nsub = (nsl + 1) >> 1;                                  /* steps of two */                     \
-    for (int cs = 0; cs < nsub; ++cs) {                                                                     \
-      /* step ndone has landed once at most the (younger) step issued after it is outstanding */            \
-      if (nissued - ndone - 1 >= 1 && ylast == 4) { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }        \
-      else if (nissued - ndone - 1 >= 1) { asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }    \
-      else { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }                                  \
-      __builtin_amdgcn_s_barrier();                                                                         \
-      TRD_ISSUE()                                                                                           \
-      const double* Bc_ = Bs + (ndone % TRD_DEPTH) * 2048;                                                  \
-      if (wc0 < nbj) {                                                                                      \
-        if (!((CJ) == (CI) && 2 * cs > ws)) TRD_MMA2(TGT, At + 2 * cs * ASL, Bc_)                          \
-        if (2 * cs + 1 < nsl && !((CJ) == (CI) && 2 * cs + 1 > ws)) TRD_MMA2(TGT, At + (2 * cs + 1) * ASL, Bc_ + 1024) \
-      }                                                                                                     \
-      ++ndone;                                                                                              \
-      const bool last_sub = (cs == nsub - 1);                                                               \
-      if ((CJ) == (CI) && last_sub) {          /* X_i complete: out to memory, and into LDS as the operand of the updates */ \
-        if (wc0 < nbi) {                                                                                    \
-          _Pragma("unroll") for (int i = 0; i < FR; ++i) {                                                   \
-            if (i < i1) {                                                                                   \
-              typedef double2_t __attribute__((address_space(1)))* gptr2;                                   \
-              gptr2 cp = (gptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (CI) + wc0 + 4 * fj);       \
-              cp[0] = (double2_t){xa[i][0], xa[i][1]}; cp[1] = (double2_t){xa[i][2], xa[i][3]};             \
-            }                                                                                               \
-          }                                                                                                 \
-        }                                                                                                   \
-        if ((CI) + 1 < nt) {                                                                                \
-          __builtin_amdgcn_s_barrier();        /* every wave is done with T_i */                            \
-          TRD_PARK()                                                                                        \
-          TRD_LOAD_E((CI) + 1)                 /* in flight during the updates */                           \
-        }                                                                                                   \
-      }                                                                                                     \
-      if ((CI) + 1 < TRR_NT && last_sub && (CJ) == nt - 1 && (CI) + 1 < nt) {     /* block i finished: T_{i+1} = E_{i+1} - partial sums of tile i+1 */ \
-        _Pragma("unroll") for (int i = 0; i < FR; ++i)                                                       \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c) xa[i][c] -= TRD_ACC((CI) + 1)[i][c];                \
-        __builtin_amdgcn_s_barrier();          /* every wave is done with X_i */                            \
-        TRD_PARK()                                                                                          \
-        TRD_ZERO_XA()                                                                                       \
-      }                                                                                                     \
-    }                                                                                                       \
-  }
+  // the two slabs of a step into one set: C; the triangular product of a full tile, first and second step; the last tile, N strips wide
+#define TRD_STEP_C(TGT) { TRD_MMA_C(TGT, A0, Bc) TRD_MMA_C(TGT, A0 + ASL, Bc + 1024) }
+#define TRD_STEP_D0(TGT) { TRD_MMA_R(TGT, At, Bc, 0, 4) TRD_MMA_R(TGT, At + ASL, Bc + 1024, 1, 4) }
+#define TRD_STEP_D1(TGT) { TRD_MMA_R(TGT, At + 2 * ASL, Bc, 2, 4) TRD_MMA_R(TGT, At + 3 * ASL, Bc + 1024, 3, 4) }
+#define TRD_STEP_RL(N) { TRD_MMA_R(acc0, A0, Bc, 0, N) TRD_MMA_R(acc0, A0 + ASL, Bc + 1024, 0, N) }
 
   __syncthreads();
+  TMPC_TC0()
   TRD_ISSUE()
-  TRD_LOAD_E(0)
-  TRD_PARK()                                                // T_0 = E_0
-  TRD_ZERO_XA()
-  TRD_PAIR(0, 0, xa) TRD_PAIR(0, 1, acc1) TRD_PAIR(0, 2, acc2) TRD_PAIR(0, 3, acc3) TRD_PAIR(0, 4, acc4)
-  if (nt > 1) { TRD_PAIR(1, 1, xa) TRD_PAIR(1, 2, acc2) TRD_PAIR(1, 3, acc3) TRD_PAIR(1, 4, acc4) }
-  if (nt > 2) { TRD_PAIR(2, 2, xa) TRD_PAIR(2, 3, acc3) TRD_PAIR(2, 4, acc4) }
-  if (nt > 3) { TRD_PAIR(3, 3, xa) TRD_PAIR(3, 4, acc4) }
-  if (nt > 4) { TRD_PAIR(4, 4, xa) }
-#undef TRD_PAIR
-#undef TRD_MMA2
+  if (DP > 2) TRD_ISSUE()
+  TRD_LOAD_C(0, acc0)
+  if (nt > 2) TRD_LOAD_C(1, acc1) else TRD_ZERO(acc1)
+  if (nt > 3) TRD_LOAD_C(2, acc2) else TRD_ZERO(acc2)
+  if (nt > 4) TRD_LOAD_C(3, acc3) else TRD_ZERO(acc3)
+  TRD_PARK_C(acc0)                                          // T_0 = E_0
+  TRD_ZERO(acc0)
+  // a step: wait for its slabs, let every wave arrive (the buffer of the step before is free then), start the DMA of the next step
+#define TRD_STEP_BEGIN()                                                                                    \
+    { const int k_ = ndone % DP; vm_wait_le(vmtot - (k_ == 0 ? vmk0 : k_ == 1 ? vmk1 : vmk2)); }            \
+    TMPC_TC(2, 0)                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    TMPC_TC(2, 1)                                                                                           \
+    TRD_ISSUE()                                                                                             \
+    TMPC_TC(2, 2)                                                                                           \
+    const double* Bc = Bs + (ndone % DP) * 2048;                                                            \
+    ++ndone;
+  // the two steps of the update of a full tile (C layout) / of the last tile (R layout, set 0) by X_i
+#define TRD_PAIR_C(TGT)                                                                                     \
+  _Pragma("unroll 1") for (int cs = 0; cs < 2; ++cs) {                                                                          \
+    TRD_STEP_BEGIN()                                                                                        \
+    const double* A0 = At + 2 * cs * ASL;                                                                   \
+    TRD_STEP_C(TGT)                                                                                         \
+    TMPC_TC(2, 3)                                                                                           \
+  }
+#define TRD_PAIR_RL(N)                                                                                      \
+  _Pragma("unroll 1") for (int cs = 0; cs < 2; ++cs) {                                                                          \
+    TRD_STEP_BEGIN()                                                                                        \
+    const double* A0 = At + 2 * cs * ASL;                                                                   \
+    if (rw) TRD_STEP_RL(N)                                                                                  \
+    TMPC_TC(2, 3)                                                                                           \
+  }
+  // the triangular product of a full tile in set TGT, X_i out and (negated) into LDS
+#define TRD_DIAG(TGT)                                                                                       \
+  {                                                                                                         \
+    { TRD_STEP_BEGIN() if (rw) TRD_STEP_D0(TGT) TMPC_TC(2, 3) }                                             \
+    { TRD_STEP_BEGIN() if (rw) TRD_STEP_D1(TGT) TMPC_TC(2, 3) }                                             \
+    TRD_STORE_R(ci, 4, TGT)                                                                                 \
+    if (ci + 1 < nt) {                                                                                      \
+      __builtin_amdgcn_s_barrier();                         /* every wave is done with T_i */               \
+      TRD_PARK_R(4, TGT, -)                                                                                 \
+    }                                                                                                       \
+  }
+  for (int ci = 0; ci < nt; ++ci) {
+    const int nci = TRD_NB(ci) >> 4;
+    // T_i times the lower-triangular inverse: strip c needs the slabs <= c
+    if (nci == 4) {
+      if (ci == 0 || ci == nlast) TRD_DIAG(acc0) else if (ci == 1) TRD_DIAG(acc1) else if (ci == 2) TRD_DIAG(acc2) else TRD_DIAG(acc3)
+    } else {                                                // a narrow last tile (always set 0): run-time strip range
+      for (int cs = 0; cs < ((nci + 1) >> 1); ++cs) {
+        TRD_STEP_BEGIN()
+        const double* A0 = At + 2 * cs * ASL;
+        if (rw) {
+          TRD_MMA_R(acc0, A0, Bc, 2 * cs, nci)
+          if (2 * cs + 1 < nci) TRD_MMA_R(acc0, A0 + ASL, Bc + 1024, 2 * cs + 1, nci)
+        }
+        TMPC_TC(2, 3)
+      }
+      TRD_STORE_R(ci, nci, acc0)
+    }
+    if (ci == 0 && nt > 1) TRD_LOAD_R(nlast, ncl, acc0)     // E_last: lands during the updates of the tiles before it
+    if (ci + 1 >= nt) break;
+    // X_i into the tiles to its right
+    if (ci < 1 && 1 < nlast) TRD_PAIR_C(acc1)
+    if (ci < 2 && 2 < nlast) TRD_PAIR_C(acc2)
+    if (ci < 3 && 3 < nlast) TRD_PAIR_C(acc3)
+    if (ncl == 3) TRD_PAIR_RL(3) else if (ncl == 4) TRD_PAIR_RL(4) else if (ncl == 2) TRD_PAIR_RL(2) else TRD_PAIR_RL(1)
+    // block row i finished: set i + 1 holds T_{i+1}
+    const int t = ci + 1;
+    __builtin_amdgcn_s_barrier();                           // every wave is done with X_i
+    if (t == nlast) { TRD_PARK_R(ncl, acc0, +) TRD_ZERO(acc0) }
+    else if (t == 1) { TRD_PARK_C(acc1) TRD_ZERO(acc1) }
+    else if (t == 2) { TRD_PARK_C(acc2) TRD_ZERO(acc2) }
+    else { TRD_PARK_C(acc3) TRD_ZERO(acc3) }
+    TMPC_TC(2, 4)
+  }
+#undef TRD_DIAG
+#undef TRD_PAIR_RL
+#undef TRD_PAIR_C
+#undef TRD_STEP_BEGIN
+#undef TRD_STEP_RL
+#undef TRD_STEP_D1
+#undef TRD_STEP_D0
+#undef TRD_STEP_C
+#undef TRD_MMA_R
+#undef TRD_MMA_C
 #undef TRD_ISSUE
-#undef TRD_ZERO_XA
-#undef TRD_PARK
-#undef TRD_LOAD_E
+#undef TRD_ZERO
+#undef TRD_PARK_R
+#undef TRD_PARK_C
+#undef TRD_STORE_R
+#undef TRD_LOAD_R
+#undef TRD_LOAD_C
 #undef TRD_NB
-#undef TRD_ACC
 }
 
 // ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one 64 x 64 output tile per workgroup
