@@ -382,6 +382,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -422,8 +423,13 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   if (sc.prep) hipLaunchKernelGGL(k_cr_prep, dim3(count), dim3(256), 0, st, w, dm, cd, sc.prep);
   const int nt64 = (dm.dp + 63) / 64;
   for (const CrLevel& lv : sc.lev) {
+    // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
+    static const int use_dma = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();
+    static const int potrf_dma = [] { const char* e = getenv("TMPC_POTRF_DMA"); return e ? atoi(e) : 1; }();
     mark(0);
-    if (mf) hipLaunchKernelGGL(k_cr_potrf<true>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    if (mf && use_dma && potrf_dma && dm.nt <= TRR_NT)
+      hipLaunchKernelGGL(k_cr_potrf_dma, dim3(cr_grid((long)count * lv.nelim)), dim3(256), (size_t)potrf_dma_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    else if (mf) hipLaunchKernelGGL(k_cr_potrf<true>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else hipLaunchKernelGGL(k_cr_potrf<false>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
     mark(0);
     // fused forward substitution of pass 1 (see k_cr_update_dma): z_i <- L_i^-1 z_i for this level's nodes as soon as L_i exists
@@ -436,8 +442,6 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const int nstrip = (dm.dp + rs - 1) / rs, nm = (dm.dp + mt - 1) / mt;
     const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
-    // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
-    static const int use_dma = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();
     mark(1);
     if (mf && use_dma && dm.nt <= TRR_NT) {
       hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), (size_t)trd_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);

@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(256) k_cr_prep(WS w, Dims dm, CrDev cr, int pr
   }
 }
 
-// ---- phase 1: Cholesky of the diagonal blocks of this level's eliminated nodes
+constexpr int UPD_DMA_DEPTH = 2;                       // LDS buffers of the LDS-DMA tile GEMM in the batched kernels
+// ---- phase 1: Cholesky of the diagonal blocks of this level's eliminated nodes (left-looking on the register-staged core: blocks wider
+// than 320 and the no-MFMA debug flag; the product path is k_cr_potrf_dma below)
 template <bool USE_MFMA>
 __global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
   const int it = cr_item(count * nelim);
@@ -199,7 +201,6 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf(WS w, Dims dm, CrDev cr, in
   }
 }
 
-constexpr int UPD_DMA_DEPTH = 2;                       // LDS buffers of the LDS-DMA tile GEMM in the batched kernels
 // ---- phase 2: O_x <- T[x,i] L_i^-T for the (up to) two neighbours, `rs` rows per workgroup
 // (left-looking strips on the register-staged core: the path for blocks wider than 320 and for the no-MFMA debug flag)
 template <bool USE_MFMA, int NS>
@@ -256,37 +257,20 @@ __device__ __forceinline__ void vm_wait_le(int n) {
 // 97 KB of code, more than the instruction cache.
 constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
 constexpr int trd_lds_doubles() { return 4 * 1024 + TRD_DEPTH * 2048; }       // X_i / T_i as the A operand (four 64 x 16 slabs) + the B steps in flight
-__global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+// POTRF: the same sweep as one block row of the Cholesky factorisation of the block itself (k_cr_potrf_dma): X = the row strip r of D,
+// nt = r + 1 tiles, the last one the diagonal tile, whose updates take X_i itself as the second operand (from LDS: no slab stream), and
+// which leaves as D_rr - sum_i X_i X_i' for the tile Cholesky instead of being multiplied by an inverse.
+template <bool POTRF>
+__device__ __forceinline__ void trd_strip(double* X, const double* Dk, const double* Li, int rows, int nt, int dp, int it, double* lds) {
   constexpr int FR = 4, RS = 16 * FR, ASL = RS * 16, DP = TRD_DEPTH;          // fragments and rows per strip, doubles per A slab
-  const int dp = dm.dp, nt = dm.nt;
-  const int nst = (dp + RS - 1) / RS;                       // strips per edge
-  const int per = 2 * nst;
-  const int it = cr_item(count * nelim * per);
-  if (it < 0) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int g = it / per, r = it - g * per;
-  const int b = cr.alist[g / nelim];
-  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
-  const int which = r / nst, strip = r - which * nst;
-  const int slot = which ? er[CE_EB] : er[CE_EA];
-  if (slot < 0) return;
-  const int node = er[CE_NODE];
-#ifdef TMPC_HACK_L0
-  const double* Dk = w.D;
-  const double* Li = w.Linv;
-#else
-  const double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
-  const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
-#endif
-  const int r0 = strip * RS;
-  const int rows = (dp - r0 < RS) ? dp - r0 : RS;
-  double* X = cr_edge(w, dm, b, slot) + (size_t)r0 * dp;
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the slab walk below branches on scalars
+  int tid = threadIdx.x;
+  if (POTRF) asm volatile("" : "+v"(tid));                  // per-lane constants are rebuilt for every block row instead of living (spilled) across the tile Cholesky
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the slab walk below branches on scalars
   const int ws = (wv + it) & 3, wc0 = ws * 16;              // this wave's column strip ("C") or row fragment ("R")
   const int fk = lane >> 4, fq = (lane >> 2) & 3, fj = lane & 3;
   const int i1 = (rows + 15) >> 4;                          // 16-row fragments of the strip
-  const int nlast = nt - 1, nbl = dp - 64 * nlast, ncl = nbl >> 4;            // the last tile: index, width, 16-column strips
+  const int nlast = nt - 1, nbl = (dp - 64 * nlast < 64) ? dp - 64 * nlast : 64, ncl = nbl >> 4;      // the last tile: index, width, 16-column strips
+  const int ntd = POTRF ? nt - 1 : nt;                      // tiles with a triangular product and a slab stream
   const bool rw = ws < i1;                                  // this wave has a row fragment
   double* At = lds;
   double* Bs = lds + 4 * ASL;
@@ -309,10 +293,11 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
       for (int hh = 0; hh < 2; ++hh) ob[e][hh] = (4 * fj + e) * 16 + 2 * ((4 * hh + fk) ^ swb);
     }
   }
-  // Four register sets of 16 doubles hold E - (partial sums) of the column tiles: acc1 .. acc3 the full tiles 1 .. 3 (C layout), acc0
-  // tile 0 and, once X_0 is out, the last tile (R layout).  When the block row of tile i - 1 is done, set i holds T_i: it goes to LDS as
-  // the A operand, is cleared and collects T_i L_ii^-T (R layout) -- X_i, stored and parked NEGATED so that the updates accumulate
-  // E_j - sum_k X_k L_jk'.  E_1 .. E_3 are read at the start, E_last after X_0: no global load sits on the path between two tiles.
+  // Four register sets of 16 doubles hold (partial sums) - E of the column tiles: acc1 .. acc3 the full tiles 1 .. 3 (C layout), acc0
+  // tile 0 and, once X_0 is out, the last tile (R layout).  E is loaded negated and the products X_k L_jk' add up on it, so when the
+  // block row of tile i - 1 is done set i holds -T_i: it goes to LDS negated as the A operand, is cleared and collects T_i L_ii^-T
+  // (R layout) -- X_i, stored and parked for the updates.  E_1 .. E_3 are read at the start, E_last after X_0: no global load sits
+  // on the path between two tiles.
   double acc0[4][4], acc1[4][4], acc2[4][4], acc3[4][4];
   int vmtot = 0, vmk0 = 0, vmk1 = 0, vmk2 = 0;             // vector-memory operations issued so far; the count right after the DMA of step s (slot s % DP)
 #define TRD_NB(T) ((dp - 64 * (T) < 64) ? dp - 64 * (T) : 64)
@@ -326,7 +311,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
         gcptr2 cp = (gcptr2)(X + (size_t)(16 * i + 4 * fq + fk) * dp + 64 * (I) + wc0 + 4 * fj);            \
         u0 = cp[0]; u1 = cp[1];                                                                             \
       }                                                                                                     \
-      SET[i][0] = u0[0]; SET[i][1] = u0[1]; SET[i][2] = u1[0]; SET[i][3] = u1[1];                           \
+      SET[i][0] = -u0[0]; SET[i][1] = -u0[1]; SET[i][2] = -u1[0]; SET[i][3] = -u1[1];                       \
     }                                                                                                       \
     if (on_) vmtot += 2 * i1;                                                                               \
   }
@@ -339,29 +324,29 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
         gcptr2 cp = (gcptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);            \
         u0 = cp[0]; u1 = cp[1];                                                                             \
       }                                                                                                     \
-      SET[c][0] = u0[0]; SET[c][1] = u0[1]; SET[c][2] = u1[0]; SET[c][3] = u1[1];                           \
+      SET[c][0] = -u0[0]; SET[c][1] = -u0[1]; SET[c][2] = -u1[0]; SET[c][3] = -u1[1];                       \
     }                                                                                                       \
     if (rw) vmtot += 2 * (NC);                                                                              \
   }
-#define TRD_STORE_R(I, NC, SET)                                                                             \
+#define TRD_STORE_R(I, NC, SET, SG)                                                                         \
   if (rw) {                                                                                                 \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
       if (c < (NC)) {                                                                                       \
         typedef double2_t __attribute__((address_space(1)))* gptr2;                                         \
         gptr2 cp = (gptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);              \
-        cp[0] = (double2_t){SET[c][0], SET[c][1]}; cp[1] = (double2_t){SET[c][2], SET[c][3]};               \
+        cp[0] = (double2_t){SG SET[c][0], SG SET[c][1]}; cp[1] = (double2_t){SG SET[c][2], SG SET[c][3]};   \
       }                                                                                                     \
     }                                                                                                       \
     vmtot += 2 * (NC);                                                                                      \
   }
-  // SG * set -> A operand.  C: slab = this wave's strip, K pairs 2 fj and 2 fj + 1 of every row; R: this wave's rows of the slabs c < NC
-#define TRD_PARK_C(SET)                                                                                     \
+  // (+-) set -> A operand.  C: slab = this wave's strip, K pairs 2 fj and 2 fj + 1 of every row; R: this wave's rows of the slabs c < NC
+#define TRD_PARK_C(SET)      /* negated */                                                                  \
   {                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
       const int row = 16 * i + 4 * fq + fk, sw_ = dma_sw(row);                                              \
       double* q = At + ws * ASL + row * 16;                                                                \
-      *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){SET[i][0], SET[i][1]};                          \
-      *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){SET[i][2], SET[i][3]};                      \
+      *(double2_t*)(q + 2 * ((2 * fj) ^ sw_)) = (double2_t){-SET[i][0], -SET[i][1]};                        \
+      *(double2_t*)(q + 2 * ((2 * fj + 1) ^ sw_)) = (double2_t){-SET[i][2], -SET[i][3]};                    \
     }                                                                                                       \
   }
 #define TRD_PARK_R(NC, SET, SG)                                                                             \
@@ -384,7 +369,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   int ii = 0, ij = 0, is = 0, nissued = 0, ndone = 0;
 #define TRD_ISSUE()          /* one step = the slabs 2 is and 2 is + 1 (if the K range has it) of the pair (ii, ij) */ \
   {                                                                                                         \
-    if (ii < nt) {                                                                                          \
+    if (ii < ntd) {                                                                                         \
       double* dst_ = Bs + (nissued % DP) * 2048 + wv * 256;                                                 \
       const int nsl_ = (ij == ii) ? (TRD_NB(ii) >> 4) : 4;                                                  \
       const bool two_ = 2 * is + 1 < nsl_;                                                                  \
@@ -408,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
       vmtot += (ij == ii && !two_) ? 2 : 4;                                                                 \
       { const int k_ = nissued % DP; if (k_ == 0) vmk0 = vmtot; else if (k_ == 1) vmk1 = vmtot; else vmk2 = vmtot; }  \
       ++nissued;                                                                                            \
-      if (++is == ((nsl_ + 1) >> 1)) { is = 0; if (++ij >= nt) { ++ii; ij = ii; } }                         \
+      if (++is == ((nsl_ + 1) >> 1)) { is = 0; if (++ij >= ntd) { ++ii; ij = ii; } }                        \
     }                                                                                                       \
   }
   // one 16-deep slab into TGT.  C: the four fragments x this wave's strip; R: this wave's fragment x the strips C0 <= c < NC.
@@ -456,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   if (nt > 2) TRD_LOAD_C(1, acc1) else TRD_ZERO(acc1)
   if (nt > 3) TRD_LOAD_C(2, acc2) else TRD_ZERO(acc2)
   if (nt > 4) TRD_LOAD_C(3, acc3) else TRD_ZERO(acc3)
-  TRD_PARK_C(acc0)                                          // T_0 = E_0
+  TRD_PARK_C(acc0)                                          // T_0 = E_0 (the set holds -E_0)
   TRD_ZERO(acc0)
   // a step: wait for its slabs, let every wave arrive (the buffer of the step before is free then), start the DMA of the next step
 #define TRD_STEP_BEGIN()                                                                                    \
@@ -477,24 +462,31 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
     TMPC_TC(2, 3)                                                                                           \
   }
 #define TRD_PAIR_RL(N)                                                                                      \
-  _Pragma("unroll 1") for (int cs = 0; cs < 2; ++cs) {                                                                          \
-    TRD_STEP_BEGIN()                                                                                        \
-    const double* A0 = At + 2 * cs * ASL;                                                                   \
-    if (rw) TRD_STEP_RL(N)                                                                                  \
-    TMPC_TC(2, 3)                                                                                           \
+  if (POTRF) {                       /* the diagonal tile: X_i X_i', both operands in LDS already */          \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    if (rw) {                                                                                               \
+      _Pragma("unroll 1") for (int sl = 0; sl < 4; ++sl) { const double* As_ = At + sl * ASL; TRD_MMA_R(acc0, As_, As_, 0, N) } \
+    }                                                                                                       \
+  } else {                                                                                                  \
+    _Pragma("unroll 1") for (int cs = 0; cs < 2; ++cs) {                                                    \
+      TRD_STEP_BEGIN()                                                                                      \
+      const double* A0 = At + 2 * cs * ASL;                                                                 \
+      if (rw) TRD_STEP_RL(N)                                                                                \
+      TMPC_TC(2, 3)                                                                                         \
+    }                                                                                                       \
   }
   // the triangular product of a full tile in set TGT, X_i out and (negated) into LDS
 #define TRD_DIAG(TGT)                                                                                       \
   {                                                                                                         \
     { TRD_STEP_BEGIN() if (rw) TRD_STEP_D0(TGT) TMPC_TC(2, 3) }                                             \
     { TRD_STEP_BEGIN() if (rw) TRD_STEP_D1(TGT) TMPC_TC(2, 3) }                                             \
-    TRD_STORE_R(ci, 4, TGT)                                                                                 \
+    TRD_STORE_R(ci, 4, TGT, +)                                                                              \
     if (ci + 1 < nt) {                                                                                      \
       __builtin_amdgcn_s_barrier();                         /* every wave is done with T_i */               \
-      TRD_PARK_R(4, TGT, -)                                                                                 \
+      TRD_PARK_R(4, TGT, +)                                                                                 \
     }                                                                                                       \
   }
-  for (int ci = 0; ci < nt; ++ci) {
+  for (int ci = 0; ci < ntd; ++ci) {
     const int nci = TRD_NB(ci) >> 4;
     // T_i times the lower-triangular inverse: strip c needs the slabs <= c
     if (nci == 4) {
@@ -509,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
         }
         TMPC_TC(2, 3)
       }
-      TRD_STORE_R(ci, nci, acc0)
+      TRD_STORE_R(ci, nci, acc0, +)
     }
     if (ci == 0 && nt > 1) TRD_LOAD_R(nlast, ncl, acc0)     // E_last: lands during the updates of the tiles before it
     if (ci + 1 >= nt) break;
@@ -521,11 +513,15 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
     // block row i finished: set i + 1 holds T_{i+1}
     const int t = ci + 1;
     __builtin_amdgcn_s_barrier();                           // every wave is done with X_i
-    if (t == nlast) { TRD_PARK_R(ncl, acc0, +) TRD_ZERO(acc0) }
+    if (POTRF && t == nlast) break;                         // the diagonal tile stays in its set
+    if (t == nlast) { TRD_PARK_R(ncl, acc0, -) TRD_ZERO(acc0) }
     else if (t == 1) { TRD_PARK_C(acc1) TRD_ZERO(acc1) }
     else if (t == 2) { TRD_PARK_C(acc2) TRD_ZERO(acc2) }
     else { TRD_PARK_C(acc3) TRD_ZERO(acc3) }
     TMPC_TC(2, 4)
+  }
+  if (POTRF) {                                              // D_rr - sum_i X_i X_i' back in place (set 0 holds its negative)
+    TRD_STORE_R(nlast, ncl, acc0, -)
   }
 #undef TRD_DIAG
 #undef TRD_PAIR_RL
@@ -545,6 +541,58 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
 #undef TRD_LOAD_R
 #undef TRD_LOAD_C
 #undef TRD_NB
+}
+
+__global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int dp = dm.dp;
+  const int nst = (dp + 63) / 64;                           // strips per edge
+  const int per = 2 * nst;
+  const int it = cr_item(count * nelim * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int g = it / per, r = it - g * per;
+  const int b = cr.alist[g / nelim];
+  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
+  const int which = r / nst, strip = r - which * nst;
+  const int slot = which ? er[CE_EB] : er[CE_EA];
+  if (slot < 0) return;
+  const int node = er[CE_NODE];
+  const double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
+  const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const int r0 = strip * 64;
+  trd_strip<false>(cr_edge(w, dm, b, slot) + (size_t)r0 * dp, Dk, Li, (dp - r0 < 64) ? dp - r0 : 64, dm.nt, dp, it, lds);
+}
+
+// ---- phase 1 on the same sweep: block row r of the factor is the triangular solve of the row strip r of D against the rows above it,
+// its diagonal tile D_rr - sum_i X_i X_i' comes out of the same accumulators and goes through the 64 x 64 tile Cholesky + inverse.
+// One workgroup per block, the block rows one after the other (each needs the finished rows above).
+constexpr int potrf_dma_lds_doubles() { return FACT_LDS_DOUBLES > trd_lds_doubles() ? FACT_LDS_DOUBLES : trd_lds_doubles(); }
+__global__ void __launch_bounds__(256, 2) k_cr_potrf_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp;
+  double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
+  double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const double* dref = w.Ddiag + ((size_t)b * dm.p + node) * dp;
+  double* stat = lds + FACT_LDS_DOUBLES - 8;                // frozen pivots / smallest pivot ratio of the block so far (kept in LDS: the sweep needs every register)
+  if (threadIdx.x == 0) { stat[0] = 0.0; stat[1] = 1.0; }
+  for (int r = 0; r < dm.nt; ++r) {
+    const int r0 = 64 * r, nb = (dp - r0 < 64) ? dp - r0 : 64;
+    if (r > 0) {
+      trd_strip<true>(Dk + (size_t)r0 * dp, Dk, Li, nb, r + 1, dp, it, lds);
+      __syncthreads();                                      // the tile is in memory, every wave is done with the slabs in LDS
+    }
+    wg_potrf_inv(Dk + (size_t)r0 * dp + r0, dp, Li + (size_t)r * TB * TB, dref + r0, nb, lds, nullptr, stat, (it >> 5) & 3);
+  }
+  if (threadIdx.x == 0) {
+    const int nbad = (int)stat[0];
+    const double minr = stat[1];
+    if (nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
+    if (w.prob && minr < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, minr);
+  }
 }
 
 // ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one 64 x 64 output tile per workgroup

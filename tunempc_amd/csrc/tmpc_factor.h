@@ -361,7 +361,9 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
 
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt; nb a multiple of 16, <= 64) + its inverse into Ti (nb x nb, ld = TB).
 // dref: assembled diagonal entries (pivot reference).  Returns the number of frozen pivots (thread-uniform).
-__device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr) {
+// stat (optional, LDS): [0] += frozen pivots, [1] = min(itself, smallest pivot ratio) instead of *minr
+__device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr, double* stat = nullptr, int sw = 0) {
+  // sw: the wave that runs the serial 16 x 16 steps
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   TMPC_TC0()
   double* S = lds;                         // 64 x 65 (aliases the GEMM slabs, never live at the same time)
@@ -387,7 +389,7 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
   TMPC_TC(7, 0)
   for (int jb = 0; jb < nbk; ++jb) {
     const int o = 16 * jb;
-    if (wv == 0) wave_potrf16(S + o * LDP + o, Si + o * LDP + o, dr + o, dr + 65, lane);
+    if (wv == sw) wave_potrf16(S + o * LDP + o, Si + o * LDP + o, dr + o, dr + 65, lane);
     __syncthreads();
     TMPC_TC(7, 1)
     {                                      // rows below: P <- P L11^-T, one 16-row block per wave
@@ -446,7 +448,8 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
   __syncthreads();
   TMPC_TC(7, 4)
   const int nb_bad = (int)dr[65];
-  *minr = fmin(*minr, dr[66]);
+  if (stat) { if (tid == 0) { stat[0] += dr[65]; stat[1] = fmin(stat[1], dr[66]); } }
+  else *minr = fmin(*minr, dr[66]);
   __syncthreads();
   return nb_bad;
 }
