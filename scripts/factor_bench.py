@@ -2,10 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import tunempc_amd._lib as L
-if os.environ.get('TMPC_LIB'):
-    L.library_path = lambda: os.environ['TMPC_LIB']          # an experimental build of the library
-from tunempc_amd._lib import HipConvexifier
+from tunempc_amd._lib import HipConvexifier          # (TMPC_LIB=path: an experimental build of the library)
 h = HipConvexifier(2, 3, 1)
 cases = [(512, 8, 300), (64, 8, 300), (8, 8, 300), (512, 64, 300), (64, 64, 300), (8, 64, 300), (1, 64, 300), (64, 200, 210), (1, 30, 10)]
 if len(sys.argv) > 1:

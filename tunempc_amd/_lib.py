@@ -31,7 +31,8 @@ DEBUG_EXPORTS = [
 
 
 def library_path():
-    return os.path.join(_HERE, 'lib', 'libtunempc_hip.so')
+    """The in-tree build; TMPC_LIB names another build of the same library (A/B measurements of two builds on one box)."""
+    return os.environ.get('TMPC_LIB') or os.path.join(_HERE, 'lib', 'libtunempc_hip.so')
 
 
 def load_library():

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, 4) k_debug_gemm_dma(double* C, const doub
 }
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
-static size_t schur_lds(const Dims& dm) { return (size_t)12 * dm.nx * (dm.nx + 1) * sizeof(double) + (size_t)2 * dm.d * sizeof(short) + 64; }
+static size_t schur_lds(const Dims& dm) { return (size_t)SCH_REC * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 

@@ -56,6 +56,8 @@ enum {
 };
 
 // Kronecker-factor slots per stage (KF[((b*p+k)*12 + slot) * nx*nx])
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
 enum { KF_XXX = 0, KF_SIXX, KF_KX, KF_KS, KF_FX, KF_FS, KF_PER_LMI = 6 };
 // adjoint slots per stage: 0: G = T1-T2 (rhs), 1: Psi (tau column), 2: PhiH (alpha column)
 enum { ADJ_G = 0, ADJ_PSI, ADJ_PHI, NADJ = 3 };

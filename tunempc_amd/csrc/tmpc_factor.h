@@ -8,7 +8,6 @@
 
 namespace tmpc {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int FACT_LDS_DOUBLES = 2 * 64 * 65 + 72 + 4 * 16 * 17 + 8;   // the tile Cholesky (tile + inverse + pivot refs + one 16 x 17 scratch per wave); the <2,2,2> GEMM slabs (4*2*64*17) alias the front
 
@@ -31,7 +30,6 @@ constexpr int SLD = 17, SUBD = 64 * SLD, SLABD = 2 * SUBD;   // sub-slab leading
 #define TMPC_LD(p) (*(p))
 #endif
 typedef const double __attribute__((address_space(1)))* gcptr;
-typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef const double2_t __attribute__((address_space(1)))* gcptr2;
 // 32-byte piece (4 doubles, 32-byte aligned) as two 16-byte loads
 #define TMPC_LD4(dst, off, p, ok)                                                       \

@@ -14,19 +14,19 @@ namespace tmpc {
 constexpr int MUT_BACKOFF_MAX = 10;      // mu_t back-offs per problem (2^10: relative gap <= ~1e-4 * default at the worst)
 
 // HKM block entry 0.5*(T(Lx,Ls)+T(Ls,Lx))[(ab),(cd)] with T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>; the two T's
-// consist of the same four products, so the entry is T(Lx,Ls)[(ab),(cd)].
-__device__ __forceinline__ double hkm_entry(const double* __restrict__ Lx, const double* __restrict__ Ls, int ldk,
-                                            int a, int b, int c, int d_) {
-  const double xac = Lx[a * ldk + c], xad = Lx[a * ldk + d_], xbc = Lx[b * ldk + c], xbd = Lx[b * ldk + d_];
-  const double sac = Ls[a * ldk + c], sad = Ls[a * ldk + d_], sbc = Ls[b * ldk + c], sbd = Ls[b * ldk + d_];
-  const double t = (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
-  const double wr = (a == b) ? 0.5 : 1.0, wc = (c == d_) ? 0.5 : 1.0;
-  return wr * wc * t;
-}
-
+// consist of the same four products, so the entry is T(Lx,Ls)[(ab),(cd)] = w_ab w_cd hkm_t(...), w = 1/2 on the diagonal pairs.
 // One 256-thread workgroup per (problem, stage): D_k, and the coupling block C_k = T[P_k, P_{k+1}]
 // (stored transposed as the sub-diagonal block O_k = T[P_{k+1},P_k], or, for k = p-1, untransposed as the
 // cyclic corner F_0 = T[P_{p-1}, P_0]).
+// The kernel issues instructions, not flops: an entry needs the elements (a,c), (a,d), (b,c), (b,d) of twelve nx x nx Kronecker
+// factors.  They sit interleaved in LDS -- one record of 12 doubles per (i, j): XXX, SIXX, KX, KS of both LMIs, then FX, FS of both --
+// so the four records come in by ds_read_b128 from four addresses (the first form read 48 separate doubles from 12 matrix images
+// and spent two thirds of its issue slots on integer address work: profiles/r2_final_pmc.txt, 96 % issue-bound with 41 % of the LDS
+// cycles busy).  SCH_REC = 14: a record stride of 112 bytes keeps the 16-byte reads of 16 different columns on different banks.
+constexpr int SCH_REC = 14;
+__device__ __forceinline__ double hkm_t(double xac, double xad, double xbc, double xbd, double sac, double sad, double sbc, double sbd) {
+  return (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
+}
 __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
@@ -34,77 +34,80 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   if (ip[I_PHASE] == PH_DONE) return;
   const int tid = threadIdx.x;
   const int nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
-  const int ldk = nx + 1;
   // relative lift of the diagonal after an iteration whose factorisation froze pivots (k_ctrl_c): 1e-12
   const int reg = ip[I_REG];
   const double regf = (reg <= 0) ? 1.0 : 1.0 + 1e-13 * ((reg == 1) ? 10.0 : (reg == 2) ? 100.0 : 1000.0);
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  // 12 matrices: [r][0..5] = Xxx, Sixx (stage k), Kx, Ks (stage k-1), Fx, Fs (stage k)
-  double* mats = sm;
-  const int msz = nx * ldk;
-  short* ia = (short*)(sm + 12 * msz);
-  short* ib = ia + d;
+  double* mats = sm;                                        // [nx][nx][SCH_REC]
+  unsigned* pair = (unsigned*)(sm + (size_t)nxx * SCH_REC); // [d]: a | b << 16 of the packed index (ab), a <= b
+  // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
+  // reduction eliminates first.  `corner` = stored as C_k = T[P_k,P_{k+1}], otherwise transposed, O_k = T[P_{k+1},P_k]:
+  // stored entry (row, col) = C_k[col][row], i.e. the same expression on the TRANSPOSED factors F', so those go into LDS
+  // transposed and every block uses the pair of the stored row as (ab) and the pair of the stored column as (cd).
+  const bool corner = (w.cr_orient[k] != 0);
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* kfk = w.KF + (size_t)sid * 12 * nxx;
   const double* kfm = w.KF + (size_t)(b * dm.p + km) * 12 * nxx;
   for (int e = tid; e < 12 * nxx; e += 256) {
     const int m = e / nxx, r = e - m * nxx;
-    const int slot = m % KF_PER_LMI;
+    const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
     const double v = (slot == KF_KX || slot == KF_KS) ? kfm[e] : kfk[e];
-    const int i = r / nx, j = r - i * nx;
-    mats[m * msz + i * ldk + j] = v;
+    int i = r / nx, j = r - i * nx;
+    const bool fmat = (slot == KF_FX || slot == KF_FS);
+    if (fmat && !corner) { const int t_ = i; i = j; j = t_; }
+    const int q = fmat ? 8 + 2 * lmi + (slot - KF_FX) : 4 * lmi + slot;
+    mats[(size_t)(i * nx + j) * SCH_REC + q] = v;
   }
-  if (tid == 0) {
-    int e = 0;
-    for (int a = 0; a < nx; ++a)
-      for (int c = a; c < nx; ++c) { ia[e] = (short)a; ib[e] = (short)c; ++e; }
+  if (tid < nx) {
+    int e = tid * nx - (tid * (tid - 1)) / 2;
+    for (int c = tid; c < nx; ++c) pair[e++] = (unsigned)tid | ((unsigned)c << 16);
   }
   __syncthreads();
   double* Dg = w.D + (size_t)sid * dp * dp;
-  // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
-  // reduction eliminates first.  `corner` = stored as C_k = T[P_k,P_{k+1}], otherwise transposed, O_k = T[P_{k+1},P_k]
-  const bool corner = (w.cr_orient[k] != 0);
   double* Cg = w.O + (size_t)sid * dp * dp;
   double* dd = w.Ddiag + (size_t)sid * dp;
   const int tot = dp * dp;
   // Every store is coalesced along the fastest index of the STORED matrix: e -> (row, col) of the stored block.
-  // D_k: only the lower triangle is ever read (left-looking panels + the lower half of the diagonal tiles), so
-  // only col <= row is computed and written.  The coupling block is stored transposed (O_k = C_k') except for
-  // the cyclic corner, so the roles of (ab) and (cd) are swapped instead of transposing the store.
+  // D_k: only the lower triangle is ever read (the row strips of the block Cholesky stop at the diagonal tile, whose lower half is
+  // used), so only col <= row is computed and written.
+  const int qs = 256 / dp, rs = 256 - qs * dp;              // e += 256 as (row, col) += (qs, rs)
+  int row = tid / dp, col = tid - row * dp;
   for (int e = tid; e < tot; e += 256) {
-    const int row = e / dp, col = e - row * dp;
     if (row >= d || col >= d) {
       if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0;
       Cg[e] = 0.0;
       if (row == col) dd[row] = 1.0;
-      continue;
-    }
-    // coupling block: C_k[(ab),(cd)] with (ab) in P_k, (cd) in P_{k+1}; stored entry (row, col) is C_k[row][col]
-    // for the corner and C_k[col][row] otherwise
-    {
-      const int ra = corner ? row : col, rc = corner ? col : row;
-      const int a = ia[ra], bb = ib[ra], c = ia[rc], d_ = ib[rc];
-      double cv = 0.0;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
-        cv -= hkm_entry(mr + KF_FX * msz, mr + KF_FS * msz, ldk, a, bb, c, d_);
+    } else {
+      const unsigned pr_ = pair[row], pc_ = pair[col];
+      const int a = (int)(pr_ & 0xffffu), bb = (int)(pr_ >> 16), c = (int)(pc_ & 0xffffu), d_ = (int)(pc_ >> 16);
+      const double wgt = ((a == bb) ? 0.5 : 1.0) * ((c == d_) ? 0.5 : 1.0);
+      const double2_t* pac = (const double2_t*)(mats + (size_t)(a * nx + c) * SCH_REC);
+      const double2_t* pad = (const double2_t*)(mats + (size_t)(a * nx + d_) * SCH_REC);
+      const double2_t* pbc = (const double2_t*)(mats + (size_t)(bb * nx + c) * SCH_REC);
+      const double2_t* pbd = (const double2_t*)(mats + (size_t)(bb * nx + d_) * SCH_REC);
+      {                                                     // coupling block: -(T(FX_0, FS_0) + T(FX_1, FS_1))
+        const double2_t ac0 = pac[4], ad0 = pad[4], bc0 = pbc[4], bd0 = pbd[4];
+        const double2_t ac1 = pac[5], ad1 = pad[5], bc1 = pbc[5], bd1 = pbd[5];
+        double cv = 0.0;
+        cv -= wgt * hkm_t(ac0[0], ad0[0], bc0[0], bd0[0], ac0[1], ad0[1], bc0[1], bd0[1]);
+        cv -= wgt * hkm_t(ac1[0], ad1[0], bc1[0], bd1[0], ac1[1], ad1[1], bc1[1], bd1[1]);
+        Cg[e] = cv;
       }
-      Cg[e] = cv;
-    }
-    if (col <= row) {
-      const int a = ia[row], bb = ib[row], c = ia[col], d_ = ib[col];
-      double dv = 0.0;
+      if (col <= row) {
+        double dv = 0.0;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const double* mr = mats + (size_t)r * KF_PER_LMI * msz;
-        dv += hkm_entry(mr + KF_XXX * msz, mr + KF_SIXX * msz, ldk, a, bb, c, d_);
-        dv += hkm_entry(mr + KF_KX * msz, mr + KF_KS * msz, ldk, a, bb, c, d_);
+        for (int r = 0; r < 2; ++r) {
+          const double2_t ac0 = pac[2 * r], ad0 = pad[2 * r], bc0 = pbc[2 * r], bd0 = pbd[2 * r];                          // XXX, SIXX
+          const double2_t ac1 = pac[2 * r + 1], ad1 = pad[2 * r + 1], bc1 = pbc[2 * r + 1], bd1 = pbd[2 * r + 1];          // KX, KS
+          dv += wgt * hkm_t(ac0[0], ad0[0], bc0[0], bd0[0], ac0[1], ad0[1], bc0[1], bd0[1]);
+          dv += wgt * hkm_t(ac1[0], ad1[0], bc1[0], bd1[0], ac1[1], ad1[1], bc1[1], bd1[1]);
+        }
+        if (row == col) { dv *= regf; dd[row] = dv; }
+        Dg[e] = dv;
       }
-      if (row == col) dv *= regf;
-      Dg[e] = dv;
-      if (row == col) dd[row] = dv;
     }
+    row += qs; col += rs;
+    if (col >= dp) { col -= dp; ++row; }
   }
 }
 
