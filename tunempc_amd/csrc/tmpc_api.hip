@@ -539,7 +539,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
-    if (nfac > 0) hipLaunchKernelGGL(k_schur, dim3(nfac * dm.p), dim3(256), schur_lds(dm), st, wf, dm);
+    if (nfac > 0) hipLaunchKernelGGL(k_schur, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds(dm), st, wf, dm);
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);

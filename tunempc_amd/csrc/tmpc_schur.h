@@ -15,19 +15,25 @@ constexpr int MUT_BACKOFF_MAX = 10;      // mu_t back-offs per problem (2^10: re
 
 // HKM block entry 0.5*(T(Lx,Ls)+T(Ls,Lx))[(ab),(cd)] with T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>; the two T's
 // consist of the same four products, so the entry is T(Lx,Ls)[(ab),(cd)] = w_ab w_cd hkm_t(...), w = 1/2 on the diagonal pairs.
-// One 256-thread workgroup per (problem, stage): D_k, and the coupling block C_k = T[P_k, P_{k+1}]
+// One workgroup per (problem, stage): D_k, and the coupling block C_k = T[P_k, P_{k+1}]
 // (stored transposed as the sub-diagonal block O_k = T[P_{k+1},P_k], or, for k = p-1, untransposed as the
 // cyclic corner F_0 = T[P_{p-1}, P_0]).
-// The kernel issues instructions, not flops: an entry needs the elements (a,c), (a,d), (b,c), (b,d) of twelve nx x nx Kronecker
-// factors.  They sit interleaved in LDS -- one record of 12 doubles per (i, j): XXX, SIXX, KX, KS of both LMIs, then FX, FS of both --
-// so the four records come in by ds_read_b128 from four addresses (the first form read 48 separate doubles from 12 matrix images
-// and spent two thirds of its issue slots on integer address work: profiles/r2_final_pmc.txt, 96 % issue-bound with 41 % of the LDS
-// cycles busy).  SCH_REC = 14: a record stride of 112 bytes keeps the 16-byte reads of 16 different columns on different banks.
+// An entry needs the elements (a,c), (a,d), (b,c), (b,d) of twelve nx x nx Kronecker factors and a handful of flops: the kernel is
+// bound by instruction issue and LDS bytes, then by the HBM writes (1.08 MB per stage).  Layout and walk are chosen for that:
+//   * the factors sit interleaved in LDS, one record of 12 doubles per (i, j): XXX, SIXX, KX, KS of both LMIs, then FX, FS of both;
+//     a record comes in by ds_read_b128 (the first form read 48 separate doubles from 12 matrix images and spent two thirds of its
+//     issue slots on integer address work: profiles/r2_final_pmc.txt, 96 % issue-bound).  SCH_REC = 14: a record stride of
+//     112 bytes keeps the 16-byte reads of 16 different columns on different banks;
+//   * a thread owns one stored COLUMN (its pair (cd) and weights stay in registers) and the workgroup walks the stored rows
+//     together: the pair (ab) of the row is wave-uniform, the records (a, c), (a, d) stay in registers for the 24 - a rows that share a,
+//     only (b, c) and (b, d) are fetched per entry (half the LDS bytes of an entry-by-entry walk), and every store is 64 consecutive
+//     doubles of one row.  320 threads cover the 304 columns of the bench shape in one pass.
 constexpr int SCH_REC = 14;
+constexpr int SCH_NT = 320;
 __device__ __forceinline__ double hkm_t(double xac, double xad, double xbc, double xbd, double sac, double sad, double sbc, double sbd) {
   return (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
 }
-__global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
+__global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
@@ -48,7 +54,7 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* kfk = w.KF + (size_t)sid * 12 * nxx;
   const double* kfm = w.KF + (size_t)(b * dm.p + km) * 12 * nxx;
-  for (int e = tid; e < 12 * nxx; e += 256) {
+  for (int e = tid; e < 12 * nxx; e += SCH_NT) {
     const int m = e / nxx, r = e - m * nxx;
     const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
     const double v = (slot == KF_KX || slot == KF_KS) ? kfm[e] : kfk[e];
@@ -66,48 +72,54 @@ __global__ void __launch_bounds__(256) k_schur(WS w, Dims dm) {
   double* Dg = w.D + (size_t)sid * dp * dp;
   double* Cg = w.O + (size_t)sid * dp * dp;
   double* dd = w.Ddiag + (size_t)sid * dp;
-  const int tot = dp * dp;
-  // Every store is coalesced along the fastest index of the STORED matrix: e -> (row, col) of the stored block.
   // D_k: only the lower triangle is ever read (the row strips of the block Cholesky stop at the diagonal tile, whose lower half is
-  // used), so only col <= row is computed and written.
-  const int qs = 256 / dp, rs = 256 - qs * dp;              // e += 256 as (row, col) += (qs, rs)
-  int row = tid / dp, col = tid - row * dp;
-  for (int e = tid; e < tot; e += 256) {
-    if (row >= d || col >= d) {
-      if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0;
-      Cg[e] = 0.0;
-      if (row == col) dd[row] = 1.0;
-    } else {
-      const unsigned pr_ = pair[row], pc_ = pair[col];
-      const int a = (int)(pr_ & 0xffffu), bb = (int)(pr_ >> 16), c = (int)(pc_ & 0xffffu), d_ = (int)(pc_ >> 16);
-      const double wgt = ((a == bb) ? 0.5 : 1.0) * ((c == d_) ? 0.5 : 1.0);
-      const double2_t* pac = (const double2_t*)(mats + (size_t)(a * nx + c) * SCH_REC);
-      const double2_t* pad = (const double2_t*)(mats + (size_t)(a * nx + d_) * SCH_REC);
-      const double2_t* pbc = (const double2_t*)(mats + (size_t)(bb * nx + c) * SCH_REC);
-      const double2_t* pbd = (const double2_t*)(mats + (size_t)(bb * nx + d_) * SCH_REC);
+  // used), so only col <= row is computed and written.  Rows and columns beyond d: identity / zero padding.
+  for (int col = tid; col < dp; col += SCH_NT) {
+    const bool cin = col < d;
+    const unsigned pc_ = cin ? pair[col] : 0u;
+    const int c = (int)(pc_ & 0xffffu), d_ = (int)(pc_ >> 16);
+    const double wc = (c == d_) ? 0.5 : 1.0;
+    const double2_t* rc = (const double2_t*)(mats + (size_t)c * SCH_REC);        // + i * nx * SCH_REC: record (i, c)
+    const double2_t* rd = (const double2_t*)(mats + (size_t)d_ * SCH_REC);
+    double2_t ac[6], ad[6];
+    int a_prev = -1;
+    for (int row = 0; row < dp; ++row) {
+      const size_t e = (size_t)row * dp + col;
+      if (row >= d || !cin) {
+        if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0;
+        Cg[e] = 0.0;
+        if (row == col) dd[row] = 1.0;
+        continue;
+      }
+      const unsigned pr_ = (unsigned)__builtin_amdgcn_readfirstlane((int)pair[row]);
+      const int a = (int)(pr_ & 0xffffu), bb = (int)(pr_ >> 16);
+      const int ro = nx * (SCH_REC / 2);                    // double2 per row of records
+      if (a != a_prev) {
+        a_prev = a;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { ac[q] = rc[a * ro + q]; ad[q] = rd[a * ro + q]; }
+      }
+      const double wgt = ((a == bb) ? 0.5 : 1.0) * wc;
       {                                                     // coupling block: -(T(FX_0, FS_0) + T(FX_1, FS_1))
-        const double2_t ac0 = pac[4], ad0 = pad[4], bc0 = pbc[4], bd0 = pbd[4];
-        const double2_t ac1 = pac[5], ad1 = pad[5], bc1 = pbc[5], bd1 = pbd[5];
+        const double2_t bc0 = rc[bb * ro + 4], bd0 = rd[bb * ro + 4], bc1 = rc[bb * ro + 5], bd1 = rd[bb * ro + 5];
         double cv = 0.0;
-        cv -= wgt * hkm_t(ac0[0], ad0[0], bc0[0], bd0[0], ac0[1], ad0[1], bc0[1], bd0[1]);
-        cv -= wgt * hkm_t(ac1[0], ad1[0], bc1[0], bd1[0], ac1[1], ad1[1], bc1[1], bd1[1]);
+        cv -= wgt * hkm_t(ac[4][0], ad[4][0], bc0[0], bd0[0], ac[4][1], ad[4][1], bc0[1], bd0[1]);
+        cv -= wgt * hkm_t(ac[5][0], ad[5][0], bc1[0], bd1[0], ac[5][1], ad[5][1], bc1[1], bd1[1]);
         Cg[e] = cv;
       }
       if (col <= row) {
         double dv = 0.0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const double2_t ac0 = pac[2 * r], ad0 = pad[2 * r], bc0 = pbc[2 * r], bd0 = pbd[2 * r];                          // XXX, SIXX
-          const double2_t ac1 = pac[2 * r + 1], ad1 = pad[2 * r + 1], bc1 = pbc[2 * r + 1], bd1 = pbd[2 * r + 1];          // KX, KS
-          dv += wgt * hkm_t(ac0[0], ad0[0], bc0[0], bd0[0], ac0[1], ad0[1], bc0[1], bd0[1]);
-          dv += wgt * hkm_t(ac1[0], ad1[0], bc1[0], bd1[0], ac1[1], ad1[1], bc1[1], bd1[1]);
+          const double2_t bc0 = rc[bb * ro + 2 * r], bd0 = rd[bb * ro + 2 * r];                  // XXX, SIXX
+          const double2_t bc1 = rc[bb * ro + 2 * r + 1], bd1 = rd[bb * ro + 2 * r + 1];          // KX, KS
+          dv += wgt * hkm_t(ac[2 * r][0], ad[2 * r][0], bc0[0], bd0[0], ac[2 * r][1], ad[2 * r][1], bc0[1], bd0[1]);
+          dv += wgt * hkm_t(ac[2 * r + 1][0], ad[2 * r + 1][0], bc1[0], bd1[0], ac[2 * r + 1][1], ad[2 * r + 1][1], bc1[1], bd1[1]);
         }
         if (row == col) { dv *= regf; dd[row] = dv; }
         Dg[e] = dv;
       }
     }
-    row += qs; col += rs;
-    if (col >= dp) { col -= dp; ++row; }
   }
 }
 
