@@ -339,8 +339,9 @@ __device__ __forceinline__ int chol_lower_pair_t(double* A, double* B, int n, in
     if (!(piv > 0.0)) { piv = 1e-300; if (wv < 2) ++nbad; }
     const double rinv = rsqrt_nr(piv);
     if (half == 0 && mine && row >= j) Mx[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
-    wsync();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // each wave touches its own matrix only: in-order LDS, no workgroup barrier per column
   }
+  wsync();
   return (int)block_sum<NT>((lane == 0 && wv < 2) ? (double)nbad : 0.0);
 }
 template <int NT>
@@ -367,8 +368,9 @@ __device__ __forceinline__ void tri_inv_lower_pair_t(double* __restrict__ LiA, c
     }
     acc += __shfl_xor(acc, 32, 64);
     if (on && half == 0 && c < n) Li[i * LD + c] = (c < i) ? -acc * rdi : ((c == i) ? rdi : 0.0);
-    wsync();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (as above)
   }
+  wsync();
 }
 
 // Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and
