@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, 4) k_debug_gemm_dma(double* C, const doub
 }
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
-static size_t schur_lds(const Dims& dm) { return (size_t)SCH_REC * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
+template <int PART> static size_t schur_lds(const Dims& dm) { return (size_t)sch_rec<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 
@@ -376,7 +376,8 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
   HIPCHK(hipFuncSetAttribute((const void*)k_final_stage, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -539,7 +540,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
-    if (nfac > 0) hipLaunchKernelGGL(k_schur, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds(dm), st, wf, dm);
+    if (nfac > 0) {
+      hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
+      hipLaunchKernelGGL(k_schur<1>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
+    }
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);

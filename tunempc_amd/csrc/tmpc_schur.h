@@ -22,18 +22,22 @@ constexpr int MUT_BACKOFF_MAX = 10;      // mu_t back-offs per problem (2^10: re
 // bound by instruction issue and LDS bytes, then by the HBM writes (1.08 MB per stage).  Layout and walk are chosen for that:
 //   * the factors sit interleaved in LDS, one record of 12 doubles per (i, j): XXX, SIXX, KX, KS of both LMIs, then FX, FS of both;
 //     a record comes in by ds_read_b128 (the first form read 48 separate doubles from 12 matrix images and spent two thirds of its
-//     issue slots on integer address work: profiles/r2_final_pmc.txt, 96 % issue-bound).  SCH_REC = 14: a record stride of
-//     112 bytes keeps the 16-byte reads of 16 different columns on different banks;
+//     issue slots on integer address work: profiles/r2_final_pmc.txt, 96 % issue-bound);
 //   * a thread owns one stored COLUMN (its pair (cd) and weights stay in registers) and the workgroup walks the stored rows
 //     together: the pair (ab) of the row is wave-uniform, the records (a, c), (a, d) stay in registers for the 24 - a rows that share a,
 //     only (b, c) and (b, d) are fetched per entry (half the LDS bytes of an entry-by-entry walk), and every store is 64 consecutive
 //     doubles of one row.  320 threads cover the 304 columns of the bench shape in one pass.
-constexpr int SCH_REC = 14;
+//   * two launches, one per block (PART 0: D_k, records of the eight D factors; PART 1: C_k, records of the four F factors): the LDS
+//     image of one part is 46 KB / 28 KB instead of 65 KB, three / five workgroups per CU instead of two.  Record strides of 80 and
+//     48 bytes keep the 16-byte reads of 16 different columns on different banks.
 constexpr int SCH_NT = 320;
+template <int PART> constexpr int sch_rec() { return PART == 0 ? 10 : 6; }      // doubles per record (8 / 4 used)
 __device__ __forceinline__ double hkm_t(double xac, double xad, double xbc, double xbd, double sac, double sad, double sbc, double sbd) {
   return (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
 }
+template <int PART>
 __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
+  constexpr int REC = sch_rec<PART>();
   const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
@@ -44,8 +48,8 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   const int reg = ip[I_REG];
   const double regf = (reg <= 0) ? 1.0 : 1.0 + 1e-13 * ((reg == 1) ? 10.0 : (reg == 2) ? 100.0 : 1000.0);
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* mats = sm;                                        // [nx][nx][SCH_REC]
-  unsigned* pair = (unsigned*)(sm + (size_t)nxx * SCH_REC); // [d]: a | b << 16 of the packed index (ab), a <= b
+  double* mats = sm;                                        // [nx][nx][REC]
+  unsigned* pair = (unsigned*)(sm + (size_t)nxx * REC);     // [d]: a | b << 16 of the packed index (ab), a <= b
   // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
   // reduction eliminates first.  `corner` = stored as C_k = T[P_k,P_{k+1}], otherwise transposed, O_k = T[P_{k+1},P_k]:
   // stored entry (row, col) = C_k[col][row], i.e. the same expression on the TRANSPOSED factors F', so those go into LDS
@@ -57,12 +61,13 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   for (int e = tid; e < 12 * nxx; e += SCH_NT) {
     const int m = e / nxx, r = e - m * nxx;
     const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
+    const bool fmat = (slot == KF_FX || slot == KF_FS);
+    if (fmat != (PART == 1)) continue;
     const double v = (slot == KF_KX || slot == KF_KS) ? kfm[e] : kfk[e];
     int i = r / nx, j = r - i * nx;
-    const bool fmat = (slot == KF_FX || slot == KF_FS);
     if (fmat && !corner) { const int t_ = i; i = j; j = t_; }
-    const int q = fmat ? 8 + 2 * lmi + (slot - KF_FX) : 4 * lmi + slot;
-    mats[(size_t)(i * nx + j) * SCH_REC + q] = v;
+    const int q = fmat ? 2 * lmi + (slot - KF_FX) : 4 * lmi + slot;
+    mats[(size_t)(i * nx + j) * REC + q] = v;
   }
   if (tid < nx) {
     int e = tid * nx - (tid * (tid - 1)) / 2;
@@ -79,35 +84,35 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
     const unsigned pc_ = cin ? pair[col] : 0u;
     const int c = (int)(pc_ & 0xffffu), d_ = (int)(pc_ >> 16);
     const double wc = (c == d_) ? 0.5 : 1.0;
-    const double2_t* rc = (const double2_t*)(mats + (size_t)c * SCH_REC);        // + i * nx * SCH_REC: record (i, c)
-    const double2_t* rd = (const double2_t*)(mats + (size_t)d_ * SCH_REC);
-    double2_t ac[6], ad[6];
+    const double2_t* rc = (const double2_t*)(mats + (size_t)c * REC);           // + i * nx * REC: record (i, c)
+    const double2_t* rd = (const double2_t*)(mats + (size_t)d_ * REC);
+    constexpr int NQ = PART == 0 ? 4 : 2;                   // double2 per record
+    double2_t ac[NQ], ad[NQ];
     int a_prev = -1;
-    for (int row = 0; row < dp; ++row) {
+    const int row0 = (PART == 0) ? (col / 64) * 64 : 0;     // D: rows above the wave's first column have nothing to write
+    for (int row = row0; row < dp; ++row) {
       const size_t e = (size_t)row * dp + col;
       if (row >= d || !cin) {
-        if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0;
-        Cg[e] = 0.0;
-        if (row == col) dd[row] = 1.0;
+        if (PART == 0) { if (col <= row) Dg[e] = (row == col) ? 1.0 : 0.0; if (row == col) dd[row] = 1.0; }
+        else Cg[e] = 0.0;
         continue;
       }
       const unsigned pr_ = (unsigned)__builtin_amdgcn_readfirstlane((int)pair[row]);
       const int a = (int)(pr_ & 0xffffu), bb = (int)(pr_ >> 16);
-      const int ro = nx * (SCH_REC / 2);                    // double2 per row of records
+      const int ro = nx * (REC / 2);                        // double2 per row of records
       if (a != a_prev) {
         a_prev = a;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { ac[q] = rc[a * ro + q]; ad[q] = rd[a * ro + q]; }
+        for (int q = 0; q < NQ; ++q) { ac[q] = rc[a * ro + q]; ad[q] = rd[a * ro + q]; }
       }
       const double wgt = ((a == bb) ? 0.5 : 1.0) * wc;
-      {                                                     // coupling block: -(T(FX_0, FS_0) + T(FX_1, FS_1))
-        const double2_t bc0 = rc[bb * ro + 4], bd0 = rd[bb * ro + 4], bc1 = rc[bb * ro + 5], bd1 = rd[bb * ro + 5];
+      if (PART == 1) {                                      // coupling block: -(T(FX_0, FS_0) + T(FX_1, FS_1))
+        const double2_t bc0 = rc[bb * ro], bd0 = rd[bb * ro], bc1 = rc[bb * ro + 1], bd1 = rd[bb * ro + 1];
         double cv = 0.0;
-        cv -= wgt * hkm_t(ac[4][0], ad[4][0], bc0[0], bd0[0], ac[4][1], ad[4][1], bc0[1], bd0[1]);
-        cv -= wgt * hkm_t(ac[5][0], ad[5][0], bc1[0], bd1[0], ac[5][1], ad[5][1], bc1[1], bd1[1]);
+        cv -= wgt * hkm_t(ac[0][0], ad[0][0], bc0[0], bd0[0], ac[0][1], ad[0][1], bc0[1], bd0[1]);
+        cv -= wgt * hkm_t(ac[1][0], ad[1][0], bc1[0], bd1[0], ac[1][1], ad[1][1], bc1[1], bd1[1]);
         Cg[e] = cv;
-      }
-      if (col <= row) {
+      } else if (col <= row) {
         double dv = 0.0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
