@@ -209,7 +209,7 @@ def main():
                          "kernel": "k_cr_update_dma (symmetric updates and fill edges of the cyclic-reduction block Cholesky: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles)",
                          "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
                          "algorithmic_flops_per_launch": upd_flops / upd_launches,
-                         "factorisation_phase": {"kernels": "k_cr_potrf + k_cr_trsm_dma + k_cr_update_dma (+ the fused forward sweep of the predictor pass), all levels", "tflops": phase_tf,
+                         "factorisation_phase": {"kernels": "k_cr_potrf_dma + k_cr_trsm_dma + k_cr_update_dma (+ the fused forward sweep of the predictor pass), all levels", "tflops": phase_tf,
                                                  "frac": phase_tf / PEAK_F64_MFMA_TFLOPS, "avg_ms": prof['factor_ms'] / phases,
                                                  "problems_per_phase": nfac / phases,
                                                  "potrf_ms": prof['potrf_ms'] / phases, "trsm_ms": prof['trsm_ms'] / phases,
