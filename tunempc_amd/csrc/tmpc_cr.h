@@ -7,11 +7,11 @@
 // costs no extra flops but exposes p/2, p/4, ... independent eliminations per level, and every phase of a level is a
 // batched tile kernel over (active problem, node, tile):
 //
-//   k_cr_potrf        one workgroup per eliminated node      D_i = L_i L_i'  (64 x 64 tile Cholesky + inverted diagonal tiles)
+//   k_cr_potrf_dma    one workgroup per eliminated node      D_i = L_i L_i'  (block rows on the sweep of the triangular solve, 64 x 64 tile Cholesky + inverted diagonal tiles)
 //   k_cr_trsm_dma     per node, neighbour, 64-row strip      O_x <- T[x,i] L_i^-T        (x = the two neighbours a, b of i)
 //   k_cr_update_dma   per surviving node: lower tiles        D_s -= O_s O_s' (one or two eliminated neighbours, one K stream)
 //                     per eliminated node: all tiles         T[x,y] (=|-=) -O_x O_y'     (the fill edge, x,y = a,b)
-// (k_cr_trsm / k_cr_update: the same phases on the register-staged GEMM core of tmpc_factor.h -- blocks wider than 320, debug flag.)
+// (k_cr_potrf / k_cr_trsm / k_cr_update: the same phases on the register-staged GEMM core of tmpc_factor.h -- blocks wider than 320, debug flag.)
 //
 // Grids are sized by the number of problems still iterating (compacted list), so the tail of a lockstep batch and
 // small batches of long-period problems keep the chip busy; workgroups working on the same node are placed on one XCD
