@@ -171,25 +171,32 @@ __device__ __forceinline__ void add_smat_t3(double* out, const double* th, doubl
   wsync();
 }
 
-constexpr int PRE_SLOTS = 9;     // 76 KB of LDS: two single-wave blocks per CU
+constexpr int PRE_SLOTS = 6;     // 51 KB of LDS: three blocks per CU (the kernel is latency-bound: 268 / 155 ms per step at one / two blocks per CU).
+                                 // Hb and the accumulated Phi live in registers (element e = lane + q NT of the n x n matrix), slots are re-used.
 // ------------------------------------------------------------------ stage_pre
 template <int NT>
-__global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims dm) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
   const double* pr = w.prob + (size_t)b * PS;
   const double alpha = pr[P_ALPHA], tau = pr[P_TAU];
-  double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sS = sm + 3 * MS;
-  double* sLi = sm + 4 * MS; double* sSi = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
-  double* sHb = sm + 8 * MS;
-  double* sPhi = sM;      // M is consumed by the residuals below, then its slot accumulates Phi(Hb)
-  double* t2 = sS;        // the S slot is free once L^-1 has been formed
+  // slot 0: V.  First phase: Hb (1), M (2), scratch (3, 4).  Per LMI: X (1), S then S^-1 (2), scratch (3, 4), L^-1 then scratch (5).  End: Phi (1).
+  double* sV = sm; double* sX = sm + MS; double* sS = sm + 2 * MS; double* t0 = sm + 3 * MS; double* t1 = sm + 4 * MS; double* sLi = sm + 5 * MS;
+  double* sHb = sX;       // only until M is built; afterwards Hb is in registers (hbr) or re-read into a scratch slot
+  double* sM = sS;        // consumed by the residuals before S is loaded
+  double* sSi = sS;       // S^-1 = Li' Li takes the slot of the factor once L^-1 has been formed
+  double* t2 = sLi;       // free once S^-1 has been formed
+  double* sPhi = sX;      // the accumulated Phi(Hb) goes to LDS after the last use of X
+  constexpr int EPT = NMAX * NMAX / NT;                     // elements of an n x n matrix per thread
+  double hbr[EPT], phir[EPT];
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   TMPC_T0()
   g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   TMPC_T(8)
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; hbr[q] = (e < nn) ? sHb[i * LD + j] : 0.0; phir[q] = 0.0; }
   build_M<NT>(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
   if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
@@ -220,7 +227,10 @@ __global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
     TMPC_T(8)
     for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
-      const double hx = dot_ss<NT>(sHb, sX, n, lane);
+      double hx = 0.0;
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; if (e < nn) hx = fma(hbr[q], sX[i * LD + j], hx); }
+      hx = block_sum<NT>(hx);
       if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s<NT>(sX, n, lane); }
     }
     // S_r = L L', X_r = Lx Lx' (for the primal step length) and both inverses, the two matrices side by side in one wave
@@ -252,13 +262,18 @@ __global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
     s2g_T<NT>(kfr + KF_FS * nxx, t0, nx, nx, nx, lane);
     s2g<NT>(kfr + KF_SIXX * nxx, sSi, nx, nx, nx, lane);
     // Phi_r(Hb) = sym(X Hb Si)
-    mm<NT>(t0, sX, LD, 1, sHb, LD, 1, n, n, n, 0, lane);
+    g2s<NT>(t1, w.Hb + (size_t)sid * nn, n, n, n, lane);
+    mm<NT>(t0, sX, LD, 1, t1, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
-    for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
-      const double phi = 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
-      if (r == 0) sPhi[i * LD + j] = phi; else sPhi[i * LD + j] += phi;
-      if (r == 1 && i == j) trphi2 += phi;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = lane + q * NT;
+      if (e < nn) {
+        const int i = e / n, j = e - i * n;
+        const double phi = 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
+        phir[q] += phi;
+        if (r == 1 && i == j) trphi2 += phi;
+      }
     }
     wsync();
     if (r == 1) {
@@ -272,7 +287,14 @@ __global__ void __launch_bounds__(NT) k_stage_pre(WS w, Dims dm) {
     }
   }
   TMPC_T(15)
-  const double hbphi = dot_ss<NT>(sHb, sPhi, n, lane);
+  double hbphi = 0.0;
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = lane + q * NT;
+    if (e < nn) { const int i = e / n, j = e - i * n; sPhi[i * LD + j] = phir[q]; hbphi = fma(hbr[q], phir[q], hbphi); }
+  }
+  wsync();
+  hbphi = block_sum<NT>(hbphi);
   if (dm.nT > 0) s2g<NT>(w.t3phi + (size_t)sid * nn, sPhi, n, n, n, lane);
   adj_V<NT>(t1, t2, sV, sPhi, n, nx, lane);
   s2g<NT>(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx, lane);
