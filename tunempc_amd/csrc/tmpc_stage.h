@@ -307,12 +307,12 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
   }
 }
 
-constexpr int RHS_SLOTS = 8;
+constexpr int RHS_SLOTS = 6;      // three blocks per CU (see PRE_SLOTS): G = T1 - T2 accumulates in registers, Hb is read elementwise from memory
 // ------------------------------------------------------------------ stage_rhs: T_r and the adjoint of G = T1 - T2
 // pass 1 = predictor (sigma*mu = 0, no corrector term; main-phase problems only)
 // pass 2 = corrector (main phase) or pure centering step (centering phase)
 template <int NT>
-__global__ void __launch_bounds__(NT) k_stage_rhs(WS w, Dims dm, int pass) {
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_rhs(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -321,7 +321,12 @@ __global__ void __launch_bounds__(NT) k_stage_rhs(WS w, Dims dm, int pass) {
   const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
   const bool use_corr = (pass == 2 && phase == PH_MAIN);
   double* sV = sm; double* sX = sm + MS; double* sSi = sm + 2 * MS; double* sRd = sm + 3 * MS;
-  double* t0 = sm + 4 * MS; double* t1 = sm + 5 * MS; double* sG = sm + 6 * MS; double* sHb = sm + 7 * MS;
+  double* t0 = sm + 4 * MS; double* t1 = sm + 5 * MS;
+  double* sG = sRd;       // G goes to LDS after the last use of Rd
+  constexpr int EPT = NMAX * NMAX / NT;                     // elements of an n x n matrix per thread (element e = lane + q NT)
+  double gr[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) gr[q] = 0.0;
   g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   double trt2 = 0.0;
   for (int r = 0; r < 2; ++r) {
@@ -332,17 +337,30 @@ __global__ void __launch_bounds__(NT) k_stage_rhs(WS w, Dims dm, int pass) {
     mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
     double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
     const double* cg = (r ? w.c2 : w.c1) + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
-      double t = sig * sSi[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
-      if (use_corr) t -= cg[e];
-      Tg[e] = t;
-      if (r == 0) sG[i * LD + j] = t; else { sG[i * LD + j] -= t; if (i == j) trt2 += t; }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = lane + q * NT;
+      if (e < nn) {
+        const int i = e / n, j = e - i * n;
+        double t = sig * sSi[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
+        if (use_corr) t -= cg[e];
+        Tg[e] = t;
+        if (r == 0) gr[q] = t; else { gr[q] -= t; if (i == j) trt2 += t; }
+      }
     }
     wsync();
   }
-  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
-  const double hbg = dot_ss<NT>(sHb, sG, n, lane);
+  double hbg = 0.0;
+  {
+    const double* Hbg = w.Hb + (size_t)sid * nn;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = lane + q * NT;
+      if (e < nn) { const int i = e / n, j = e - i * n; sG[i * LD + j] = gr[q]; hbg = fma(Hbg[e], gr[q], hbg); }
+    }
+  }
+  wsync();
+  hbg = block_sum<NT>(hbg);
   adj_V<NT>(t1, t0, sV, sG, n, nx, lane);
   s2g<NT>(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx, lane);
   s2g<NT>(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, sG, nx, nx, nx, lane);
@@ -353,20 +371,21 @@ __global__ void __launch_bounds__(NT) k_stage_rhs(WS w, Dims dm, int pass) {
   }
 }
 
-constexpr int DIR_SLOTS = 9;      // 76 KB of LDS: two single-wave blocks per CU
+constexpr int DIR_SLOTS = 6;      // three blocks per CU (see PRE_SLOTS): dM in registers after it is built, V / Hb / L^-1 share slots with X, S^-1, dS
 // ------------------------------------------------------------------ stage_dir: dS, dX, step-length eigenvalues, corrector term
 template <int NT>
-__global__ void __launch_bounds__(NT) k_stage_dir(WS w, Dims dm, int pass) {
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims dm, int pass) {
   TMPC_STAGE_PROLOGUE
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
   const double* pr = w.prob + (size_t)b * PS;
   const double dtau = pr[P_DTAU], dalpha = pr[P_DALPHA];
-  double* sV = sm; double* sM = sm + MS; double* sX = sm + 2 * MS; double* sSi = sm + 3 * MS;
-  double* sDS = sm + 4 * MS; double* sDX = sm + 5 * MS; double* t0 = sm + 6 * MS; double* t1 = sm + 7 * MS;
-  double* sHb = sm + 8 * MS;
-  double* sL = sHb;       // Hb is only needed to build dM
+  double* sX = sm; double* sSi = sm + MS; double* sDS = sm + 2 * MS; double* sDX = sm + 3 * MS; double* t0 = sm + 4 * MS; double* t1 = sm + 5 * MS;
+  double* sV = sX; double* sHb = sSi; double* sM = sDS;    // V, Hb and the slot of dM are only needed to build dM (kept in registers: dmr)
+  double* sL = sX;        // X is dead once dX is known
+  constexpr int EPT = NMAX * NMAX / NT;                     // elements of an n x n matrix per thread (element e = lane + q NT)
+  double dmr[EPT];
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
@@ -374,6 +393,9 @@ __global__ void __launch_bounds__(NT) k_stage_dir(WS w, Dims dm, int pass) {
   build_M<NT>(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
   if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3dth + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + dT_k
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; dmr[q] = (e < nn) ? sM[i * LD + j] : 0.0; }
+  wsync();
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
@@ -385,14 +407,18 @@ __global__ void __launch_bounds__(NT) k_stage_dir(WS w, Dims dm, int pass) {
     g2s<NT>(sX, Xg, n, n, n, lane);
     g2s<NT>(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
     // sDX := Ldy = dS - Rd   (linear part of the slack direction)
-    for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
-      const double dm_ = sM[i * LD + j];
-      const double ldy = (r == 0) ? dm_ : ((i == j ? dtau : 0.0) - dm_);
-      sDX[i * LD + j] = ldy;
-      const double ds = ldy + Rdg[e];
-      sDS[i * LD + j] = ds;
-      dSg[e] = ds;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = lane + q * NT;
+      if (e < nn) {
+        const int i = e / n, j = e - i * n;
+        const double dm_ = dmr[q];
+        const double ldy = (r == 0) ? dm_ : ((i == j ? dtau : 0.0) - dm_);
+        sDX[i * LD + j] = ldy;
+        const double ds = ldy + Rdg[e];
+        sDS[i * LD + j] = ds;
+        dSg[e] = ds;
+      }
     }
     wsync();
     mm<NT>(t0, sX, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
@@ -427,11 +453,15 @@ __global__ void __launch_bounds__(NT) k_stage_dir(WS w, Dims dm, int pass) {
   {
     const double ra = dalpha / pr[P_ALPHA];
     const double* S1g = w.S1 + (size_t)sid * nn; const double* R1g = w.Rd1 + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
-      const double m = S1g[e] + R1g[e] + (i == j ? 1.0 : 0.0);
-      const double dh = sM[i * LD + j] - ra * m;
-      dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = lane + q * NT;
+      if (e < nn) {
+        const int i = e / n, j = e - i * n;
+        const double m = S1g[e] + R1g[e] + (i == j ? 1.0 : 0.0);
+        const double dh = dmr[q] - ra * m;
+        dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
+      }
     }
     dh2 = block_sum<NT>(dh2); m2 = block_sum<NT>(m2);
   }
