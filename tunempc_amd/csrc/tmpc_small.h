@@ -488,6 +488,73 @@ __device__ __forceinline__ double tridiag_lmin(const double* dd, const double* e
 }
 
 
+// The n = 32 form of the tridiagonalisation below with the matrix in REGISTERS: lane (r, h) = (lane & 31, lane >> 5) holds the 16 entries
+// A[r][16 h .. 16 h + 15]; the Householder steps are unrolled 16-fold, so column j is a literal register.  Per step only v and w go
+// through LDS (one store and eight 16-byte broadcast reads each) instead of two reads and one write of the whole trailing matrix:
+// k_eigmin was LDS-bound (72 % of the LDS cycles busy at 16 waves per CU, Householder 148 k of its 197 k cycles per matrix).
+// The vectors carry zeros outside the trailing block, so every step runs the same 48 FMAs per lane on the full rows.
+// Leaves diagonal and off-diagonal in vv + 32 / vv + 64 like tridiag_min_eig.  vv: >= 128 doubles, 16-byte aligned.
+__device__ __forceinline__ void tridiag_reduce32(const double* A, double* vv, int lane) {
+  double* dd = vv + 32;
+  double* ee = vv + 64;
+  double* vb = vv;            // v (32)
+  double* wb = vv + 96;       // w (32)
+  const int r = lane & 31, h = lane >> 5;
+  double a[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q] = A[r * LD + 16 * h + q];
+  wsync();
+#pragma unroll 1
+  for (int hj = 0; hj < 2; ++hj)            // (only the register index must be a literal: half the code of a 30-fold unroll, which was 66 KB)
+#pragma unroll
+  for (int qj = 0; qj < 16; ++qj) {
+    const int j = 16 * hj + qj;
+    if (j >= 30) break;
+    // x_r = A[r][j], r > j (both halves of a row get it)
+    const double xo = a[qj];
+    const double xx = __shfl_xor(xo, 32, 64);
+    const double xi = (r > j) ? ((h == hj) ? xo : xx) : 0.0;
+    const double x0 = __shfl(xi, j + 1, 64);
+    const double sigma = wave_sum((h == 0 && r > j + 1) ? xi * xi : 0.0);
+    if (sigma == 0.0) {                      // already tridiagonal in this column
+      if (lane == 0) ee[j] = x0;
+      continue;
+    }
+    const double mu = sqrt(x0 * x0 + sigma);
+    const double v0 = (x0 <= 0.0) ? (x0 - mu) : (-sigma / (x0 + mu));
+    const double beta = 2.0 * v0 * v0 / (sigma + v0 * v0);
+    const double rv0 = 1.0 / v0;
+    const double vr = (r == j + 1) ? 1.0 : ((r > j + 1) ? xi * rv0 : 0.0);
+    if (h == 0) vb[r] = vr;
+    if (lane == 0) ee[j] = mu;               // |H x| = mu e_1 (sign irrelevant for eigenvalues of the tridiagonal)
+    wsync();
+    double vc[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const double2_t u = *(const double2_t*)(vb + 16 * h + 2 * t); vc[2 * t] = u[0]; vc[2 * t + 1] = u[1]; }
+    // p = beta * A v over the row (v vanishes outside the trailing block)
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) { a0 = fma(a[q], vc[q], a0); a1 = fma(a[q + 1], vc[q + 1], a1); }
+    const double part = a0 + a1;
+    const double pi = (r > j) ? beta * (part + __shfl_xor(part, 32, 64)) : 0.0;
+    const double kk = 0.5 * beta * wave_sum((h == 0) ? pi * vr : 0.0);
+    const double wr = (r > j) ? pi - kk * vr : 0.0;
+    if (h == 0) wb[r] = wr;
+    wsync();
+    // A -= v w' + w v'
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const double2_t u = *(const double2_t*)(wb + 16 * h + 2 * t);
+      a[2 * t] -= vr * u[0] + wr * vc[2 * t];
+      a[2 * t + 1] -= vr * u[1] + wr * vc[2 * t + 1];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) if (16 * h + q == r) dd[r] = a[q];
+  if (lane == 63) ee[30] = a[14];            // A[31][30]
+  wsync();
+}
+
 // Smallest eigenvalue of the symmetric n x n LDS matrix A (destroyed): Householder tridiagonalisation
 // (backward stable, ~4/3 n^3 flops, a quarter of the LDS traffic of a converged Jacobi) followed by Sturm-count
 // multisection over 64 shifts per round.  One single-wave block; vv: LDS scratch of >= 3*32 doubles.
@@ -496,6 +563,17 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
   double* dd = vv + 32;       // diagonal
   double* ee = vv + 64;       // off-diagonal: ee[i] couples i and i+1
   if (n == 1) { const double a00 = A[0]; if (lane == 0) dd[0] = a00; wsync(); return a00; }
+  if (n == 32) {
+    tridiag_reduce32(A, vv, lane);
+#ifdef TMPC_CYCLE_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[5 * 8 + 1] += __builtin_readcyclecounter(); }
+#endif
+    const double l32 = tridiag_lmin(dd, ee, n, lane);
+#ifdef TMPC_CYCLE_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[5 * 8 + 2] += __builtin_readcyclecounter(); }
+#endif
+    return l32;
+  }
   for (int j = 0; j + 2 < n; ++j) {
     const int m = n - j - 1;                 // length of the column below the diagonal
     const double xi = (lane < m) ? A[(j + 1 + lane) * LD + j] : 0.0;
