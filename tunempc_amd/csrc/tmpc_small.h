@@ -46,6 +46,12 @@ __device__ __forceinline__ double block_sum(double v) {
   return v;
 }
 
+// e -> (i, j) = (e / n, e % n): the element loops of the per-stage kernels run this for every element; the benchmark shape has
+// n = 32 (and the n x n matrices of every shape have n <= 32), where a shift replaces the ~20-instruction integer division
+__device__ __forceinline__ void ediv(int e, int n, int& i, int& j) {
+  if (n == 32) { i = e >> 5; j = e & 31; } else { i = e / n; j = e - i * n; }
+}
+
 // The helpers below take the thread index `lane` in [0, NT) of a block of NT threads (NT = 64: one wave per stage, the original
 // form; NT = 256: four waves share the stage's matrices -- the same LDS, four times the loads in flight and a quarter of the
 // dependent work per wave; the stage kernels are latency-bound with one wave per SIMD).
@@ -63,7 +69,7 @@ __device__ __forceinline__ void g2s(double* __restrict__ s, const double* __rest
     for (int u = 0; u < 4; ++u) s[i[u] * LD + j[u]] = v[u];
   }
   for (; e < tot; e += NT) {
-    const int i = e / cols, j = e - i * cols;
+    int i, j; ediv(e, cols, i, j);
     s[i * LD + j] = g[(size_t)i * ldg + j];
   }
   wsync();
@@ -73,7 +79,7 @@ __device__ __forceinline__ void s2g(double* __restrict__ g, const double* __rest
                                     int ldg, int lane) {
   const int tot = rows * cols;
   for (int e = lane; e < tot; e += NT) {
-    const int i = e / cols, j = e - i * cols;
+    int i, j; ediv(e, cols, i, j);
     g[(size_t)i * ldg + j] = s[i * LD + j];
   }
   wsync();
@@ -83,7 +89,7 @@ template <int NT = 64>
 __device__ __forceinline__ void s2g_sym(double* __restrict__ g, const double* __restrict__ s, int n, int lane) {
   const int tot = n * n;
   for (int e = lane; e < tot; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     g[(size_t)i * n + j] = 0.5 * (s[i * LD + j] + s[j * LD + i]);
   }
   wsync();
@@ -92,7 +98,7 @@ template <int NT = 64>
 __device__ __forceinline__ void s_sym(double* s, int n, int lane) {   // in place (s+s')/2
   const int tot = n * n;
   for (int e = lane; e < tot; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     if (j < i) {
       const double v = 0.5 * (s[i * LD + j] + s[j * LD + i]);
       s[i * LD + j] = v;
@@ -387,7 +393,7 @@ __device__ __forceinline__ void jacobi_impl(double* A, int n, double* cs, int la
     // convergence test: off-diagonal mass vs total
     double off = 0.0, dia = 0.0;
     for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e - i * n;
+      int i, j; ediv(e, n, i, j);
       const double v = A[i * LD + j];
       if (i == j) dia += v * v; else off += v * v;
     }
@@ -651,7 +657,7 @@ __device__ __forceinline__ void diag_minmax(const double* A, int n, int lane, do
 template <int NT = 64>
 __device__ __forceinline__ double dot_ss(const double* A, const double* B, int n, int lane) {
   double acc = 0.0;
-  for (int e = lane; e < n * n; e += NT) { const int i = e / n, j = e - i * n; acc = fma(A[i * LD + j], B[i * LD + j], acc); }
+  for (int e = lane; e < n * n; e += NT) { int i, j; ediv(e, n, i, j); acc = fma(A[i * LD + j], B[i * LD + j], acc); }
   return block_sum<NT>(acc);
 }
 template <int NT = 64>

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) k_init_stage(WS w, Dims dm) {
   double* sH = sm; double* cs = sm + MS;
   const double* Hg = w.H + (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     sH[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]);
   }
   wsync();
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64) k_init_stage(WS w, Dims dm) {
   const double* Ag = w.A + (size_t)sid * nxx;
   const double* Bg = w.Bm + (size_t)sid * nx * mb;
   for (int e = lane; e < nx * n; e += 64) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     Vg[e] = (j < nx) ? Ag[i * nx + j] : Bg[i * mb + (j - nx)];
   }
 }
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64) k_init_state(WS w, Dims dm) {
   const double x0 = 1.0 / (double)(dm.p * n);
   double* Hb = w.Hb + (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     const double hb = s * Hb[e];
     Hb[e] = hb;
     const double dg = (i == j) ? 1.0 : 0.0;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void build_M(double* out, const double* sV, double* t
   mm<NT>(out, t1, LD, 1, sV, LD, 1, n, n, nx, 0, lane);        // (V' Pn) V
   g2s<NT>(t0, Pk, nx, nx, nx, lane);
   for (int e = lane; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     double v = out[i * LD + j] + coef * sHb[i * LD + j];
     if (i < nx && j < nx) v -= t0[i * LD + j];
     out[i * LD + j] = v;
@@ -152,7 +152,7 @@ __device__ __forceinline__ int stage_rows(const WS& w, const Dims& dm, size_t si
 template <int NT = 64>
 __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const double* coef, double scale, int ng, int n, int lane) {
   for (int e = lane; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     double acc = 0.0;
     for (int r = 0; r < ng; ++r) acc = fma(scale * coef[r] * Gg[r * n + i], Gg[r * n + j], acc);
     out[i * LD + j] += acc;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void add_gtg(double* out, const double* Gg, const dou
 template <int NT = 64>
 __device__ __forceinline__ void add_smat_t3(double* out, const double* th, double scale, int n, int lane) {
   for (int e = lane; e < n * n; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     const int a = i < j ? i : j, b = i < j ? j : i;
     out[i * LD + j] += scale * th[a * n - a * (a - 1) / 2 + (b - a)];
   }
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
   g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   TMPC_T(8)
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; hbr[q] = (e < nn) ? sHb[i * LD + j] : 0.0; phir[q] = 0.0; }
+  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; int i, j; ediv(e, n, i, j); hbr[q] = (e < nn) ? sHb[i * LD + j] : 0.0; phir[q] = 0.0; }
   build_M<NT>(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
   if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
     double* Rdg = (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn;
     for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
+      int i, j; ediv(e, n, i, j);
       const double m = sM[i * LD + j], sv = Sg[e];
       const double dg = (i == j) ? 1.0 : 0.0;
       const double rd = (r == 0 ? (m - dg) : (tau * dg - m)) - sv;
@@ -225,16 +225,16 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
     g2s<NT>(sX, Xg, n, n, n, lane);
     g2s<NT>(sS, Sg, n, n, n, lane);
     TMPC_T(8)
-    for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
+    for (int e = lane; e < nn; e += NT) { int i, j; ediv(e, n, i, j); xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
       double hx = 0.0;
 #pragma unroll
-      for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; if (e < nn) hx = fma(hbr[q], sX[i * LD + j], hx); }
+      for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; int i, j; ediv(e, n, i, j); if (e < nn) hx = fma(hbr[q], sX[i * LD + j], hx); }
       hx = block_sum<NT>(hx);
       if (r == 0) hby += hx; else { hby -= hx; trx2 = trace_s<NT>(sX, n, lane); }
     }
     // S_r = L L', X_r = Lx Lx' (for the primal step length) and both inverses, the two matrices side by side in one wave
-    for (int e = lane; e < nn; e += NT) { const int i = e / n, j = e - i * n; t0[i * LD + j] = sX[i * LD + j]; }
+    for (int e = lane; e < nn; e += NT) { int i, j; ediv(e, n, i, j); t0[i * LD + j] = sX[i * LD + j]; }
     wsync();
     TMPC_T(10)
     nbad += chol_lower_pair_t<NT>(sS, t0, n, lane);
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
     for (int q = 0; q < EPT; ++q) {
       const int e = lane + q * NT;
       if (e < nn) {
-        const int i = e / n, j = e - i * n;
+        int i, j; ediv(e, n, i, j);
         const double phi = 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
         phir[q] += phi;
         if (r == 1 && i == j) trphi2 += phi;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     const int e = lane + q * NT;
-    if (e < nn) { const int i = e / n, j = e - i * n; sPhi[i * LD + j] = phir[q]; hbphi = fma(hbr[q], phir[q], hbphi); }
+    if (e < nn) { int i, j; ediv(e, n, i, j); sPhi[i * LD + j] = phir[q]; hbphi = fma(hbr[q], phir[q], hbphi); }
   }
   wsync();
   hbphi = block_sum<NT>(hbphi);
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_rhs(WS w, Dims 
     for (int q = 0; q < EPT; ++q) {
       const int e = lane + q * NT;
       if (e < nn) {
-        const int i = e / n, j = e - i * n;
+        int i, j; ediv(e, n, i, j);
         double t = sig * sSi[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
         if (use_corr) t -= cg[e];
         Tg[e] = t;
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_rhs(WS w, Dims 
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int e = lane + q * NT;
-      if (e < nn) { const int i = e / n, j = e - i * n; sG[i * LD + j] = gr[q]; hbg = fma(Hbg[e], gr[q], hbg); }
+      if (e < nn) { int i, j; ediv(e, n, i, j); sG[i * LD + j] = gr[q]; hbg = fma(Hbg[e], gr[q], hbg); }
     }
   }
   wsync();
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
   if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3dth + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + dT_k
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; const int i = e / n, j = e - i * n; dmr[q] = (e < nn) ? sM[i * LD + j] : 0.0; }
+  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; int i, j; ediv(e, n, i, j); dmr[q] = (e < nn) ? sM[i * LD + j] : 0.0; }
   wsync();
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
     for (int q = 0; q < EPT; ++q) {
       const int e = lane + q * NT;
       if (e < nn) {
-        const int i = e / n, j = e - i * n;
+        int i, j; ediv(e, n, i, j);
         const double dm_ = dmr[q];
         const double ldy = (r == 0) ? dm_ : ((i == j ? dtau : 0.0) - dm_);
         sDX[i * LD + j] = ldy;
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
     mm<NT>(t0, sX, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
     for (int e = lane; e < nn; e += NT) {
-      const int i = e / n, j = e - i * n;
+      int i, j; ediv(e, n, i, j);
       const double dx = Tg[e] - sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]);
       sDX[i * LD + j] = dx;
       dXg[e] = dx;
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
     for (int q = 0; q < EPT; ++q) {
       const int e = lane + q * NT;
       if (e < nn) {
-        const int i = e / n, j = e - i * n;
+        int i, j; ediv(e, n, i, j);
         const double m = S1g[e] + R1g[e] + (i == j ? 1.0 : 0.0);
         const double dh = dmr[q] - ra * m;
         dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(NT) k_update(WS w, Dims dm) {
   if (ap == 0.0 && ad == 0.0) return;      // discarded direction (it may hold NaN: 0 * NaN would poison the iterate)
   const size_t o = (size_t)sid * nn;
   for (int e = lane; e < nn; e += NT) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     const int et = j * n + i;
     if (j <= i) {
       const double x1 = 0.5 * ((w.X1[o + e] + ap * w.dX1[o + e]) + (w.X1[o + et] + ap * w.dX1[o + et]));
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
   g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   // H (unscaled, symmetrised as in k_init_stage)
   const double* Hg = w.H + (size_t)sid * nn;
-  for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; sHb[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
+  for (int e = lane; e < nn; e += 64) { int i, j; ediv(e, n, i, j); sHb[i * LD + j] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
   wsync();
   // dH = V' Pst+ V - E' Pst E  (coef 0: no Hb term), then symmetrise (mtools.symmetrize, convexifier.py:206)
   build_M(sM, sV, t0, t1, sHb, Po, Pon, 0.0, n, nx, lane);
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
   if (dm.nT > 0) {                          // T_k = s_T theta / (s_alpha alpha) (convexifier.py:422-423) and its term of the supplement (:202-203)
     add_smat_t3(sM, w.t3th + (size_t)sid * dm.nT, sc, n, lane);
     for (int e = lane; e < nn; e += 64) {
-      const int i = e / n, j = e - i * n;
+      int i, j; ediv(e, n, i, j);
       const int a = i < j ? i : j, bq = i < j ? j : i;
       w.Tout[(size_t)sid * nn + e] = sc * w.t3th[(size_t)sid * dm.nT + a * n - a * (a - 1) / 2 + (bq - a)];
     }
@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(64) k_final_stage(WS w, Dims dm) {
   double* dHg = w.dHc + (size_t)sid * nn;
   double* Hcg = w.Hc + (size_t)sid * nn;
   for (int e = lane; e < nn; e += 64) {
-    const int i = e / n, j = e - i * n;
+    int i, j; ediv(e, n, i, j);
     const double dh = sM[i * LD + j];
     dHg[e] = dh;
     const double hc = sHb[i * LD + j] + dh;
