@@ -186,10 +186,52 @@ __device__ __forceinline__ void mm256(double* __restrict__ C, const double* __re
   }
   wsync();
 }
+// The same product on the matrix cores: wave w owns the 16 x 16 tile (w >> 1, w & 1) of C and runs K / 4 v_mfma_f64_16x16x4 on
+// operand fragments read straight from LDS -- 2 reads per lane and instruction, an eighth of the LDS traffic of the vector form above
+// (which reads one operand per FMA and leaves the per-stage kernels LDS-bound: pre 122 -> 108 ms per step; with one wave per stage
+// and two blocks per CU the same instruction was slower than the vector form).  Rows / columns beyond M / N are computed on whatever the
+// 32 x 33 slots hold and not stored; K is padded with zeros to a multiple of 4.
+__device__ __forceinline__ void mm256_mfma(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
+                                           const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
+                                           int tid) {
+  const int wv = tid >> 6, lane = tid & 63;
+  const int ti = (wv >> 1) * 16, tj = (wv & 1) * 16;
+  const int fr = lane & 15, fk = lane >> 4;
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+  const bool on = ti < M && tj < N;
+  if (on) {
+    const double* ap = A + (ti + fr) * ars + fk * acs;
+    const double* bp = B + fk * brs + (tj + fr) * bcs;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const bool kin = k0 + fk < K;
+      const double a = kin ? ap[k0 * acs] : 0.0;
+      const double b = kin ? bp[k0 * brs] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+  }
+  wsync();   // all reads of A/B done before C (which may alias a consumed operand slot) is written
+  if (on) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti + fk + 4 * r, j = tj + fr;
+      if (i < M && j < N) {
+        double* p = &C[i * LD + j];
+        if (mode == 0) *p = acc[r];
+        else if (mode == 1) *p += acc[r];
+        else *p -= acc[r];
+      }
+    }
+  }
+  wsync();
+}
 template <int NT = 64>
 __device__ __forceinline__ void mm(double* __restrict__ C, const double* __restrict__ A, int ars, int acs,
                                    const double* __restrict__ B, int brs, int bcs, int M, int N, int K, int mode,
                                    int lane) {
+#ifndef TMPC_MM_VALU                        // (-DTMPC_MM_VALU: the vector form, for comparison)
+  if (NT == 256) { mm256_mfma(C, A, ars, acs, B, brs, bcs, M, N, K, mode, lane); return; }
+#endif
   if (NT == 256) mm256(C, A, ars, acs, B, brs, bcs, M, N, K, mode, lane);
   else mm64(C, A, ars, acs, B, brs, bcs, M, N, K, mode, lane);
 }
