@@ -274,27 +274,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 // block row from the diagonal inverses.  ~20 workgroup barriers per tile instead of the ~200 of a column-by-column sweep
 // (the tile factorisations were 20 % of the factorisation phase, all of it barrier latency).
 constexpr int LDP = 65;                                  // leading dimension of the tile images in LDS
-__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // LDS ops of one wave complete in order: this keeps the compiler from reordering across it
-
-// D (16 x 16 in registers, acc[r] = D[(lane >> 4) + 4 r][lane & 15]) += sgn * A B  with A[r][k] = Ap[r * lda + k], B[k][c] = Bp[k * bk + c * bc]
-__device__ __forceinline__ double4_t mm16(const double* Ap, int lda, const double* Bp, int bk, int bc, double4_t acc, double sgn, int lane) {
-  const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-  for (int k0 = 0; k0 < 16; k0 += 4) {
-    const double a = sgn * Ap[fr * lda + k0 + fk];
-    const double bv = Bp[(k0 + fk) * bk + fr * bc];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
-  }
-  return acc;
-}
-__device__ __forceinline__ double4_t load_d16(const double* Cp, int ldc, int lane) {
-  const int fr = lane & 15, fk = lane >> 4;
-  return (double4_t){Cp[fk * ldc + fr], Cp[(fk + 4) * ldc + fr], Cp[(fk + 8) * ldc + fr], Cp[(fk + 12) * ldc + fr]};
-}
-__device__ __forceinline__ void store_d16(double* Cp, int ldc, double4_t v, int lane) {
-  const int fr = lane & 15, fk = lane >> 4;
-  Cp[fk * ldc + fr] = v[0]; Cp[(fk + 4) * ldc + fr] = v[1]; Cp[(fk + 8) * ldc + fr] = v[2]; Cp[(fk + 12) * ldc + fr] = v[3];
-}
+// (wave_lds_sync, mm16, load_d16, store_d16: tmpc_small.h)
 
 // One wave: Cholesky (lower, in place) of the 16 x 16 block at S and its inverse into Si (same position; upper part zero).
 // dr: the 16 pivot references; stat[0] counts frozen pivots, stat[1] tracks the smallest pivot / reference (Cholesky-with-shift,

@@ -421,6 +421,73 @@ __device__ __forceinline__ void tri_inv_lower_pair_t(double* __restrict__ LiA, c
   wsync();
 }
 
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // LDS ops of one wave complete in order: this keeps the compiler from reordering across it
+
+// D (16 x 16 in registers, acc[r] = D[(lane >> 4) + 4 r][lane & 15]) += sgn * A B  with A[r][k] = Ap[r * lda + k], B[k][c] = Bp[k * bk + c * bc]
+__device__ __forceinline__ double4_t mm16(const double* Ap, int lda, const double* Bp, int bk, int bc, double4_t acc, double sgn, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < 16; k0 += 4) {
+    const double a = sgn * Ap[fr * lda + k0 + fk];
+    const double bv = Bp[(k0 + fk) * bk + fr * bc];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ double4_t load_d16(const double* Cp, int ldc, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  return (double4_t){Cp[fk * ldc + fr], Cp[(fk + 4) * ldc + fr], Cp[(fk + 8) * ldc + fr], Cp[(fk + 12) * ldc + fr]};
+}
+__device__ __forceinline__ void store_d16(double* Cp, int ldc, double4_t v, int lane) {
+  const int fr = lane & 15, fk = lane >> 4;
+  Cp[fk * ldc + fr] = v[0]; Cp[(fk + 4) * ldc + fr] = v[1]; Cp[(fk + 8) * ldc + fr] = v[2]; Cp[(fk + 12) * ldc + fr] = v[3];
+}
+
+// n = 32, four waves: the Cholesky factors of A and B (lower triangles in place) and their inverses LiA, LiB (zeros above the diagonal),
+// blocked by 16.  The 32 dependent column steps of the pair routines above are the floor of k_stage_pre (each one an LDS round trip,
+// a dot product, two shuffles and a reciprocal square root: 41 k + 36 k cycles per pair); by blocks the dot products are half as
+// long and the off-diagonal work -- panel L21 = A21 Li11', update A22 -= L21 L21', Li21 = -Li22 (L21 Li11) -- runs on
+// v_mfma_f64_16x16x4 with LDS operands, wave 0 on A and wave 1 on B.  Returns the number of non-positive pivots (same in every thread).
+template <int NT>
+__device__ __forceinline__ int chol_inv_pair32(double* A, double* LiA, double* B, double* LiB, int tid) {
+  const int wv = tid >> 6, lane = tid & 63;
+  const int o22 = 16 * LD + 16;
+  int nbad = chol_lower_pair_t<NT>(A, B, 16, tid);
+  tri_inv_lower_pair_t<NT>(LiA, A, LiB, B, 16, tid);
+  if (wv < 2) {
+    double* M = wv ? B : A; double* Li = wv ? LiB : LiA;
+    double* M21 = M + 16 * LD;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    acc = mm16(M21, LD, Li, 1, LD, acc, 1.0, lane);         // L21 = A21 Li11'   (B[k][c] = Li11[c][k])
+    wave_lds_sync();
+    store_d16(M21, LD, acc, lane);
+    wave_lds_sync();
+    acc = load_d16(M + o22, LD, lane);
+    acc = mm16(M21, LD, M21, 1, LD, acc, -1.0, lane);       // A22 -= L21 L21'   (B[k][c] = L21[c][k])
+    wave_lds_sync();
+    store_d16(M + o22, LD, acc, lane);
+  }
+  wsync();
+  nbad += chol_lower_pair_t<NT>(A + o22, B + o22, 16, tid);
+  tri_inv_lower_pair_t<NT>(LiA + o22, A + o22, LiB + o22, B + o22, 16, tid);
+  if (wv < 2) {
+    double* M = wv ? B : A; double* Li = wv ? LiB : LiA;
+    double* M21 = M + 16 * LD; double* Li21 = Li + 16 * LD;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    acc = mm16(M21, LD, Li, LD, 1, acc, 1.0, lane);         // W = L21 Li11
+    wave_lds_sync();
+    store_d16(Li21, LD, acc, lane);                         // (parked in its final place)
+    wave_lds_sync();
+    acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    acc = mm16(Li + o22, LD, Li21, LD, 1, acc, -1.0, lane); // Li21 = -Li22 W
+    wave_lds_sync();
+    store_d16(Li21, LD, acc, lane);
+    store_d16(Li + 16, LD, (double4_t){0.0, 0.0, 0.0, 0.0}, lane);    // the block above the diagonal
+  }
+  wsync();
+  return nbad;
+}
+
 // Cyclic (round-robin parallel-ordered) two-sided Jacobi: destroys the symmetric n x n LDS matrix A and
 // leaves its eigenvalues on the diagonal.  cs: LDS scratch of >= 4*16 doubles.  One single-wave block works
 // on one matrix (the block barrier is then a wave-local barrier).

@@ -237,9 +237,14 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
     for (int e = lane; e < nn; e += NT) { int i, j; ediv(e, n, i, j); t0[i * LD + j] = sX[i * LD + j]; }
     wsync();
     TMPC_T(10)
-    nbad += chol_lower_pair_t<NT>(sS, t0, n, lane);
-    TMPC_T(11)
-    tri_inv_lower_pair_t<NT>(sLi, sS, t1, t0, n, lane);
+    if (NT == 256 && n == 32) {
+      nbad += chol_inv_pair32<NT>(sS, sLi, t0, t1, lane);
+      TMPC_T(11)
+    } else {
+      nbad += chol_lower_pair_t<NT>(sS, t0, n, lane);
+      TMPC_T(11)
+      tri_inv_lower_pair_t<NT>(sLi, sS, t1, t0, n, lane);
+    }
     TMPC_T(12)
     s2g<NT>((r ? w.L2i : w.L1i) + (size_t)sid * nn, sLi, n, n, n, lane);
     s2g<NT>((r ? w.LX2i : w.LX1i) + (size_t)sid * nn, t1, n, n, n, lane);
