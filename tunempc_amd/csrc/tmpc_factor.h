@@ -291,10 +291,7 @@ __device__ __forceinline__ double potrf_rsqrt(double x) {
   r = r * (1.5 - 0.5 * x * r * r);
   return r;
 }
-__device__ __forceinline__ double wave_bcast(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
+// (wave_bcast: tmpc_small.h)
 __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double* dr, double* stat, int lane) {
   const int r = lane & 15;
   double a[16], ri[16];

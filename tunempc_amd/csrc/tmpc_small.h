@@ -18,6 +18,11 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// value of lane l (wave-uniform l) in every lane: two v_readlane instead of the ds_bpermute pair of __shfl
+__device__ __forceinline__ double wave_bcast(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
@@ -269,7 +274,7 @@ __device__ __forceinline__ int chol_lower(double* A, int n, int lane) {
     acc += __shfl_xor(acc, 32, 64);
     double sij = 0.0;
     if (mine && row >= j) sij = A[row * LD + j] - acc;
-    double piv = __shfl(sij, j, 64);
+    double piv = wave_bcast(sij, j);
     if (!(piv > 0.0)) { piv = 1e-300; ++nbad; }
     const double rinv = rsqrt_nr(piv);
     if (half == 0 && mine && row >= j) A[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
@@ -287,7 +292,7 @@ __device__ __forceinline__ void tri_inv_lower(double* __restrict__ Li, const dou
   double rdl = 1.0;
   if (lane < n) rdl = 1.0 / L[lane * LD + lane];
   for (int i = 0; i < n; ++i) {
-    const double rdi = __shfl(rdl, i, 64);
+    const double rdi = wave_bcast(rdl, i);
     double acc = 0.0;
     if (c < i) {
       const double* li = L + i * LD;
@@ -321,7 +326,7 @@ __device__ __forceinline__ int chol_lower_pair(double* A, double* B, int n, int 
       if (k < j) a0 = fma(li[k], lj[k], a0);
       sij = li[j] - (a0 + a1);
     }
-    const double pa = __shfl(sij, j, 64), pb = __shfl(sij, 32 + j, 64);      // wave-uniform source lanes
+    const double pa = wave_bcast(sij, j), pb = wave_bcast(sij, 32 + j);      // wave-uniform source lanes
     if (!(pa > 0.0)) ++nbad;
     if (!(pb > 0.0)) ++nbad;
     double piv = half ? pb : pa;
@@ -342,7 +347,7 @@ __device__ __forceinline__ void tri_inv_lower_pair(double* __restrict__ LiA, con
   double rdl = 1.0;
   if (c < n) rdl = 1.0 / L[c * LD + c];
   for (int i = 0; i < n; ++i) {
-    const double ra = __shfl(rdl, i, 64), rb = __shfl(rdl, 32 + i, 64);
+    const double ra = wave_bcast(rdl, i), rb = wave_bcast(rdl, 32 + i);
     const double rdi = half ? rb : ra;
     double acc = 0.0;
     if (c < i && first) {
@@ -383,7 +388,7 @@ __device__ __forceinline__ int chol_lower_pair_t(double* A, double* B, int n, in
     acc += __shfl_xor(acc, 32, 64);
     double sij = 0.0;
     if (mine && row >= j) sij = Mx[row * LD + j] - acc;
-    double piv = __shfl(sij, j, 64);
+    double piv = wave_bcast(sij, j);
     if (!(piv > 0.0)) { piv = 1e-300; if (wv < 2) ++nbad; }
     const double rinv = rsqrt_nr(piv);
     if (half == 0 && mine && row >= j) Mx[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
@@ -404,7 +409,7 @@ __device__ __forceinline__ void tri_inv_lower_pair_t(double* __restrict__ LiA, c
   double rdl = 1.0;
   if (on && lane < n) rdl = 1.0 / L[lane * LD + lane];
   for (int i = 0; i < n; ++i) {
-    const double rdi = __shfl(rdl, i, 64);
+    const double rdi = wave_bcast(rdl, i);
     double acc = 0.0;
     if (on && c < i) {
       const double* li = L + i * LD;
@@ -629,7 +634,7 @@ __device__ __forceinline__ void tridiag_reduce32(const double* A, double* vv, in
     const double xo = a[qj];
     const double xx = __shfl_xor(xo, 32, 64);
     const double xi = (r > j) ? ((h == hj) ? xo : xx) : 0.0;
-    const double x0 = __shfl(xi, j + 1, 64);
+    const double x0 = wave_bcast(xi, j + 1);
     const double sigma = wave_sum((h == 0 && r > j + 1) ? xi * xi : 0.0);
     if (sigma == 0.0) {                      // already tridiagonal in this column
       if (lane == 0) ee[j] = x0;
@@ -692,7 +697,7 @@ __device__ __forceinline__ double tridiag_min_eig(double* A, int n, double* vv, 
   for (int j = 0; j + 2 < n; ++j) {
     const int m = n - j - 1;                 // length of the column below the diagonal
     const double xi = (lane < m) ? A[(j + 1 + lane) * LD + j] : 0.0;
-    const double x0 = __shfl(xi, 0, 64);
+    const double x0 = wave_bcast(xi, 0);
     const double sigma = wave_sum((lane >= 1 && lane < m) ? xi * xi : 0.0);
     if (sigma == 0.0) {                      // already tridiagonal in this column
       if (lane == 0) ee[j] = x0;
