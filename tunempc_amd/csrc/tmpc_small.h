@@ -60,6 +60,29 @@ __device__ __forceinline__ void ediv(int e, int n, int& i, int& j) {
 // The helpers below take the thread index `lane` in [0, NT) of a block of NT threads (NT = 64: one wave per stage, the original
 // form; NT = 256: four waves share the stage's matrices -- the same LDS, four times the loads in flight and a quarter of the
 // dependent work per wave; the stage kernels are latency-bound with one wave per SIMD).
+// The same copy in two halves, so that several matrices can be in flight before the first one is needed: g2r issues the loads of a
+// matrix of at most NMAX x NMAX elements into registers (element e = lane + q NT), r2s parks them in an LDS slot.
+template <int NT>
+__device__ __forceinline__ void g2r(double (&v)[NMAX * NMAX / NT], const double* __restrict__ g, int rows, int cols, int ldg, int lane) {
+  const int tot = rows * cols;
+#pragma unroll
+  for (int q = 0; q < NMAX * NMAX / NT; ++q) {
+    const int e = lane + q * NT;
+    int i, j; ediv(e, cols, i, j);
+    v[q] = (e < tot) ? g[(size_t)i * ldg + j] : 0.0;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void r2s(double* __restrict__ s, const double (&v)[NMAX * NMAX / NT], int rows, int cols, int lane) {
+  const int tot = rows * cols;
+#pragma unroll
+  for (int q = 0; q < NMAX * NMAX / NT; ++q) {
+    const int e = lane + q * NT;
+    int i, j; ediv(e, cols, i, j);
+    if (e < tot) s[i * LD + j] = v[q];
+  }
+  wsync();
+}
 // global (rows x cols, row-major, ld = ldg) -> LDS slot (LD).  Coalesced along rows.
 template <int NT = 64>
 __device__ __forceinline__ void g2s(double* __restrict__ s, const double* __restrict__ g, int rows, int cols,
@@ -69,7 +92,7 @@ __device__ __forceinline__ void g2s(double* __restrict__ s, const double* __rest
   for (; e + 3 * NT < tot; e += 4 * NT) {      // four loads in flight per thread: one exposed memory latency per 4 NT elements
     int i[4], j[4]; double v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int eu = e + NT * u; i[u] = eu / cols; j[u] = eu - i[u] * cols; v[u] = g[(size_t)i[u] * ldg + j[u]]; }
+    for (int u = 0; u < 4; ++u) { const int eu = e + NT * u; ediv(eu, cols, i[u], j[u]); v[u] = g[(size_t)i[u] * ldg + j[u]]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[i[u] * LD + j[u]] = v[u];
   }

@@ -192,11 +192,14 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
   double hbr[EPT], phir[EPT];
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   TMPC_T0()
-  g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  double ldA[EPT];                                          // loads in flight (g2r / r2s): one exposed memory latency per group of matrices
+  g2r<NT>(ldA, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2r<NT>(hbr, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  r2s<NT>(sV, ldA, nx, n, lane);
+  r2s<NT>(sHb, hbr, n, n, lane);
   TMPC_T(8)
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) { const int e = lane + q * NT; int i, j; ediv(e, n, i, j); hbr[q] = (e < nn) ? sHb[i * LD + j] : 0.0; phir[q] = 0.0; }
+  for (int q = 0; q < EPT; ++q) phir[q] = 0.0;
   build_M<NT>(sM, sV, t0, t1, sHb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx, lane);
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(phi) G
   if (dm.nT > 0) add_smat_t3<NT>(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n, lane);                                                       // + T_k
@@ -222,8 +225,13 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
   for (int r = 0; r < 2; ++r) {
     const double* Xg = (r ? w.X2 : w.X1) + (size_t)sid * nn;
     const double* Sg = (r ? w.S2 : w.S1) + (size_t)sid * nn;
-    g2s<NT>(sX, Xg, n, n, n, lane);
-    g2s<NT>(sS, Sg, n, n, n, lane);
+    {
+      double ldB[EPT];
+      g2r<NT>(ldA, Xg, n, n, n, lane);
+      g2r<NT>(ldB, Sg, n, n, n, lane);
+      r2s<NT>(sX, ldA, n, n, lane);
+      r2s<NT>(sS, ldB, n, n, lane);
+    }
     TMPC_T(8)
     for (int e = lane; e < nn; e += NT) { int i, j; ediv(e, n, i, j); xs = fma(sX[i * LD + j], sS[i * LD + j], xs); }
     {
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_pre(WS w, Dims 
     s2g_T<NT>(kfr + KF_FS * nxx, t0, nx, nx, nx, lane);
     s2g<NT>(kfr + KF_SIXX * nxx, sSi, nx, nx, nx, lane);
     // Phi_r(Hb) = sym(X Hb Si)
-    g2s<NT>(t1, w.Hb + (size_t)sid * nn, n, n, n, lane);
+    r2s<NT>(t1, hbr, n, n, lane);
     mm<NT>(t0, sX, LD, 1, t1, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
 #pragma unroll
