@@ -343,9 +343,13 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_rhs(WS w, Dims 
   g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   double trt2 = 0.0;
   for (int r = 0; r < 2; ++r) {
-    g2s<NT>(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
-    g2s<NT>(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
-    g2s<NT>(sRd, (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn, n, n, n, lane);
+    {                                        // the three operands in flight together (one exposed memory latency)
+      double l0[EPT], l1[EPT], l2[EPT];
+      g2r<NT>(l0, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
+      g2r<NT>(l1, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+      g2r<NT>(l2, (r ? w.Rd2 : w.Rd1) + (size_t)sid * nn, n, n, n, lane);
+      r2s<NT>(sX, l0, n, n, lane); r2s<NT>(sSi, l1, n, n, lane); r2s<NT>(sRd, l2, n, n, lane);
+    }
     mm<NT>(t0, sX, LD, 1, sRd, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sSi, LD, 1, n, n, n, 0, lane);
     double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
@@ -400,8 +404,12 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
   constexpr int EPT = NMAX * NMAX / NT;                     // elements of an n x n matrix per thread (element e = lane + q NT)
   double dmr[EPT];
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
-  g2s<NT>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  g2s<NT>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  {
+    double l0[EPT], l1[EPT];
+    g2r<NT>(l0, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+    g2r<NT>(l1, w.Hb + (size_t)sid * nn, n, n, n, lane);
+    r2s<NT>(sV, l0, nx, n, lane); r2s<NT>(sHb, l1, n, n, lane);
+  }
   const double* dPk = w.dP + (size_t)sid * nxx;
   build_M<NT>(sM, sV, t0, t1, sHb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dM
   if (dm.nr > 0) add_gtg<NT>(sM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n, lane);   // + G' diag(dphi) G
@@ -417,8 +425,15 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
     const double* Tg = (r ? w.T2 : w.T1) + (size_t)sid * nn;
     double* dSg = (r ? w.dS2 : w.dS1) + (size_t)sid * nn;
     double* dXg = (r ? w.dX2 : w.dX1) + (size_t)sid * nn;
-    g2s<NT>(sX, Xg, n, n, n, lane);
-    g2s<NT>(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    double lL[EPT], lLX[EPT];                // L_r^-1 and LX_r^-1: needed further down, fetched with X and S^-1 (one exposed memory latency)
+    {
+      double l0[EPT], l1[EPT];
+      g2r<NT>(l0, Xg, n, n, n, lane);
+      g2r<NT>(l1, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+      g2r<NT>(lL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
+      g2r<NT>(lLX, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
+      r2s<NT>(sX, l0, n, n, lane); r2s<NT>(sSi, l1, n, n, lane);
+    }
     // sDX := Ldy = dS - Rd   (linear part of the slack direction)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -447,11 +462,11 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
     wsync();
     // step-length matrices  W_S = L^-1 dS L^-T  and  W_X = LX^-1 dX LX^-T ; their smallest eigenvalues are
     // computed by k_eigmin (one wave per matrix, 16 waves per CU) -- slots 2r (dual) and 2r+1 (primal)
-    g2s<NT>(sL, (r ? w.L2i : w.L1i) + (size_t)sid * nn, n, n, n, lane);
+    r2s<NT>(sL, lL, n, n, lane);
     mm<NT>(t0, sL, LD, 1, sDS, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
     s2g_sym<NT>(w.Wm + ((size_t)sid * 4 + 2 * r) * nn, t1, n, lane);
-    g2s<NT>(sL, (r ? w.LX2i : w.LX1i) + (size_t)sid * nn, n, n, n, lane);
+    r2s<NT>(sL, lLX, n, n, lane);
     mm<NT>(t0, sL, LD, 1, sDX, LD, 1, n, n, n, 0, lane);
     mm<NT>(t1, t0, LD, 1, sL, 1, LD, n, n, n, 0, lane);
     s2g_sym<NT>(w.Wm + ((size_t)sid * 4 + 2 * r + 1) * nn, t1, n, lane);
