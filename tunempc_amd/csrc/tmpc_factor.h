@@ -467,7 +467,9 @@ __device__ __forceinline__ int wg_block_column(double* Dk, double* R1, double* R
 constexpr int NCP = 4;      // rows of the LDS vectors (>= max NC = 3)
 constexpr int GKV = 16, GLDV = GKV + 1;   // K slab of the skinny GEMM
 
-template <bool TRANS>
+// LOWER: M is a lower-triangular tile (an inverted diagonal tile): the 4-element pieces above the diagonal are zeros in memory and are
+// not fetched (3/8 of the tile: the substitutions are bound by the bytes they stream)
+template <bool TRANS, bool LOWER = false>
 __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, int xld, const double* M, int ldm,
                                           int rows, int cols, bool accumulate, double sgn, double* As, int nc) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -485,10 +487,11 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     // four slabs of loads in flight per thread (ra..rd, slab ks mod 4): the solve streams the factors once and is bound by
     // bytes in flight (512 workgroups x 8 KB with a single prefetch: 4.4 TB/s; two in flight: 5.2)
     double rb[4], rc[4], rd[4];
-    TMPC_LD4(ra, 0, src, ok)
-    if (nks > 1) { const double* s1 = src + kstep; TMPC_LD4(rb, 0, s1, ok) }
-    if (nks > 2) { const double* s1 = src + 2 * kstep; TMPC_LD4(rc, 0, s1, ok) }
-    if (nks > 3) { const double* s1 = src + 3 * kstep; TMPC_LD4(rd, 0, s1, ok) }
+#define TMPC_GEMV_OK(KS) (ok && (!LOWER || (TRANS ? (m0 + lcol <= GKV * (KS) + lrow) : (GKV * (KS) + lcol <= m0 + lrow))))
+    TMPC_LD4(ra, 0, src, TMPC_GEMV_OK(0))
+    if (nks > 1) { const double* s1 = src + kstep; TMPC_LD4(rb, 0, s1, TMPC_GEMV_OK(1)) }
+    if (nks > 2) { const double* s1 = src + 2 * kstep; TMPC_LD4(rc, 0, s1, TMPC_GEMV_OK(2)) }
+    if (nks > 3) { const double* s1 = src + 3 * kstep; TMPC_LD4(rd, 0, s1, TMPC_GEMV_OK(3)) }
 #define TMPC_GEMV_SLAB(RG, KS)                                                                                  \
     {                                                                                                             \
       __syncthreads();                                                                                            \
@@ -500,7 +503,7 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
       __syncthreads();                                                                                            \
       if ((KS) + 4 < nks) {                                                                                       \
         const double* s2 = src + (size_t)((KS) + 4) * kstep;                                                      \
-        TMPC_LD4(RG, 0, s2, ok)                                                                                   \
+        TMPC_LD4(RG, 0, s2, TMPC_GEMV_OK((KS) + 4))                                                              \
       }                                                                                                           \
       if (m0 + 16 * wv < rows) {                                                                                  \
         const int k0 = (KS) * GKV;                                                                                \
@@ -518,6 +521,7 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
       if (ks + 3 < nks) TMPC_GEMV_SLAB(rd, ks + 3)
     }
 #undef TMPC_GEMV_SLAB
+#undef TMPC_GEMV_OK
     if (m0 + 16 * wv < rows && fr < nc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -539,7 +543,7 @@ __device__ __forceinline__ void blk_fwd(double* z, int xld, double* tmp, int tld
   for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     const double* Ti = Lik + (size_t)jt * TB * TB;
-    wg_gemv16<false>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
+    wg_gemv16<false, true>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
     for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; z[q * xld + j0 + i] = tmp[q * tld + i]; }
     __syncthreads();
     const int rem = dp - j0 - nb;
@@ -554,7 +558,7 @@ __device__ __forceinline__ void blk_bwd(double* z, int xld, double* tmp, int tld
     const int j0 = jt * TB;
     const int nb = (dp - j0 < TB) ? dp - j0 : TB;
     const double* Ti = Lik + (size_t)jt * TB * TB;
-    wg_gemv16<true>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
+    wg_gemv16<true, true>(tmp, tld, z + j0, xld, Ti, TB, nb, nb, false, 1.0, As, nc);
     for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; z[q * xld + j0 + i] = tmp[q * tld + i]; }
     __syncthreads();
     if (j0 > 0) wg_gemv16<true>(z, xld, z + j0, xld, Dk + (size_t)j0 * dp, dp, j0, nb, true, -1.0, As, nc);
