@@ -559,7 +559,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     // plain model: the right-hand sides of the predictor pass are ready before the factorisation, and its forward substitution
     // rides inside it (k_cr_update_dma reads the O blocks anyway): one read of every O block less per main-phase iteration
     static const int fuse_env = [] { const char* e = getenv("TMPC_FUSE_FWD"); return e ? atoi(e) : 1; }();
-    const bool fuse1 = fuse_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1;
+    static const int dma_env = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();       // (the fused sweep lives in k_cr_update_dma)
+    const bool fuse1 = fuse_env && dma_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1;
     if (fuse1) {
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
