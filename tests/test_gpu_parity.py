@@ -903,3 +903,40 @@ def test_supplement_with_constraint_and_regularisation_terms(hc):
         assert rel(np.stack(dHc), ref[0]) < 1e-14, kw.keys()
         assert rel(np.stack(dQc), ref[1]) < 1e-14 and rel(np.stack(dRc), ref[2]) < 1e-14 and rel(np.stack(dNc), ref[3]) < 1e-14
         assert all(np.array_equal(d, d.T) for d in dHc)
+
+
+_FALLBACK_CODE = r'''
+import os, sys
+import numpy as np
+import torch  # noqa: F401  (first: see the note at the top of tests/test_gpu_parity.py)
+sys.path.insert(0, sys.argv[1])
+from tunempc_amd._lib import HipConvexifier
+worst = 0.0
+for name in sys.argv[3:]:
+    g = np.load(os.path.join(sys.argv[2], name + '.npz'))
+    A, B, H = g['A'], g['B'], g['H']
+    h = HipConvexifier(A.shape[1], A.shape[2], B.shape[3])
+    out = h.convexify_batch(A, B, H)
+    h.close()
+    for b in range(A.shape[0]):
+        assert int(out['status'][b]) == int(g['status'][b]), (name, b, out['status'][b], g['status'][b])
+        err = np.linalg.norm(out['Hc'][b] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b])
+        worst = max(worst, err)
+print('WORST %.3e' % worst)
+'''
+
+
+@pytest.mark.parametrize('env', [{'TMPC_FACTOR_DMA': '0'}, {'TMPC_POTRF_DMA': '0'}, {'TMPC_FUSE_FWD': '0', 'TMPC_CHORD': '0'},
+                                 {'TMPC_STAGE_NT': '64'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
+def test_kernel_variants_behind_environment_switches(golden_dir, env):
+    """The kernel variants behind the environment switches of libtunempc_hip (read once per process: register-staged factorisation
+    kernels, left-looking block Cholesky, separate forward sweep without chord steps, one wave per stage) against three golden
+    vectors, each variant in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _FALLBACK_CODE, root, golden_dir, 'c2_unicycle_shape', 'mid_n16', 'awe_shape_n15'],
+                       env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    worst = float(r.stdout.strip().split('WORST')[-1])
+    assert worst < PARITY, (env, worst)
