@@ -67,27 +67,92 @@ def hbm_traffic_per_launch():
         return None
 
 
+def host_cpu_info():
+    """What the host offers THIS process: the cores it may run on (affinity), the CPU-time quota of its cgroup, model and NUMA layout.
+    `os.cpu_count()` alone counts the machine's cores, whatever the container was given."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["affinity"] = info["os_cpu_count"]
+    quota = None
+    try:                                   # cgroup v2
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except Exception:
+        try:                               # cgroup v1
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    info["cgroup_cpu_quota"] = quota
+    model, sockets, numa = None, set(), None
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name') and model is None:
+                model = ln.split(':', 1)[1].strip()
+            if ln.startswith('physical id'):
+                sockets.add(ln.split(':', 1)[1].strip())
+        numa = len([d for d in os.listdir('/sys/devices/system/node') if d.startswith('node') and d[4:].isdigit()])
+    except Exception:
+        pass
+    info.update(model=model, sockets=len(sockets) or None, numa_nodes=numa)
+    eff = info["affinity"]
+    if quota:
+        eff = max(1, min(eff, int(quota + 0.5)))
+    info["effective_cores"] = eff
+    return info
+
+
 def cpu_baseline(p, nx, mb, tol):
     """The C++/OpenMP restatement of the same structured algorithm (oracle/cpu_ipm: LAPACK/BLAS on the d x d blocks, one problem
-    per OpenMP thread), timed on the host cores at the BENCH shape: one problem on one thread, then one problem per core on all
-    cores (bounded: about 10 + 15-25 s of CPU work).  Same seeded generator as the GPU batch.  Not PICOS+MOSEK."""
+    per OpenMP thread), timed on the host cores at the BENCH shape: one problem on one thread, a mid-point (8 threads), and one
+    problem per core on all cores this process may use (affinity and cgroup quota, not os.cpu_count()); bounded to about a minute of
+    wall time.  Same seeded generator as the GPU batch.  Not PICOS+MOSEK."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import cpu_ipm
     from tunempc_amd import synthetic
-    cores = min(os.cpu_count() or 1, cpu_ipm.max_threads(), 64)
+    hw = host_cpu_info()
+    cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
     A, B, H = synthetic.gen_batch(100000, cores, p, nx, mb)
-    t0 = time.perf_counter()
-    o1 = cpu_ipm.convexify_batch(A[:1], B[:1], H[:1], tol=tol, threads=1)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oc = cpu_ipm.convexify_batch(A, B, H, tol=tol, threads=cores)
-    tc = time.perf_counter() - t0
-    return {"value": cores * p / tc, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
-            "single_thread_value": p / t1,
-            "sample": f"oracle/cpu_ipm (C++/OpenMP restatement of the structured IPM, OpenBLAS on the {nx * (nx + 1) // 2}-wide blocks) at the bench "
-                      f"shape nx={nx}, m={mb}, p={p}: {cores} problems on {cores} threads in {tc:.1f} s ({int(oc['iters'].max())} IPM iterations max, "
-                      f"{int((oc['status'] == 0).sum())}/{cores} Optimal); 1 problem on 1 thread in {t1:.1f} s ({p / t1:.2f} stage-conv/s, "
-                      f"{int(o1['iters'][0])} iterations)"}
+
+    def run(nt):
+        t0 = time.perf_counter()
+        o = cpu_ipm.convexify_batch(A[:nt], B[:nt], H[:nt], tol=tol, threads=nt)
+        return time.perf_counter() - t0, o
+
+    t1, o1 = run(1)
+    points = {1: p / t1}
+    mid = 8 if cores >= 16 else None
+    if mid:
+        tm, _ = run(mid)
+        points[mid] = mid * p / tm
+    if cores > 1:
+        tc, oc = run(cores)
+    else:
+        tc, oc = t1, o1
+    points[cores] = cores * p / tc
+    eff = points[cores] / (cores * points[1])
+    d = nx * (nx + 1) // 2
+    ws_mb = 3 * p * ((d + 15) // 16 * 16) ** 2 * 8 / 1e6
+    note = ""
+    if eff < 0.5:
+        note = (f"; parallel efficiency {eff:.2f} < 0.5: every thread streams its own {ws_mb:.0f} MB of Schur blocks per factorisation "
+                f"({cores * ws_mb / 1e3:.1f} GB over {cores} threads against the shared L3 / memory channels)"
+                + (f", and os.cpu_count() = {hw['os_cpu_count']} exceeds what this process may use" if hw['os_cpu_count'] > cores else ""))
+    return {"value": points[cores], "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+            "single_thread_value": points[1], "parallel_efficiency": eff,
+            "by_threads": {str(k): v for k, v in sorted(points.items())},
+            "host": hw,
+            "sample": f"oracle/cpu_ipm (C++/OpenMP restatement of the structured IPM, OpenBLAS on the {d}-wide blocks) at the bench "
+                      f"shape nx={nx}, m={mb}, p={p} on {hw['model']} ({hw['sockets']} socket(s), {hw['numa_nodes']} NUMA node(s); "
+                      f"os.cpu_count {hw['os_cpu_count']}, affinity {hw['affinity']}, cgroup quota {hw['cgroup_cpu_quota']}): {cores} problems on "
+                      f"{cores} threads in {tc:.1f} s ({int(oc['iters'].max())} IPM iterations max, {int((oc['status'] == 0).sum())}/{cores} Optimal); "
+                      f"1 problem on 1 thread in {t1:.1f} s ({p / t1:.2f} stage-conv/s, {int(o1['iters'][0])} iterations)"
+                      + (f"; {mid} problems on {mid} threads: {points[mid]:.1f} stage-conv/s" if mid else "") + note}
 
 
 # Everything that libraries print on stdout while the bench runs (RCCL prints its version banner there at communicator creation) goes
@@ -107,6 +172,7 @@ def main():
     ap.add_argument('--mb', type=int, default=8)
     ap.add_argument('--tol', type=float, default=0.0, help='0 = library default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the unprofiled and host-buffer legs after the timed region')
     ap.add_argument('--distinct', type=int, default=512, help='distinct synthetic problems generated per rank (tiled to --batch when smaller)')
     args = ap.parse_args()
 
@@ -140,12 +206,13 @@ def main():
     if args.tol > 0:
         h.set_options(tol=args.tol, flags=FLAG_PROFILE)
     out = None
+    gather_cache = {}                      # the all-gather lands in the same buffers every step (tunempc_amd/dist.py)
 
     def step():
         nonlocal out
         out = h.convexify_batch_device(dA, dB, dH, out)
         if use_dist:
-            g = all_gather_results({k: out[k] for k in ('Hc', 'kappa', 'status')}, nbl * world)
+            g = all_gather_results({k: out[k] for k in ('Hc', 'kappa', 'status')}, nbl * world, cache=gather_cache)
             return g
         return out
 
@@ -170,6 +237,40 @@ def main():
     prof = h.profile()
     status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy()
     ok = int((status == 0).sum())
+    # load balance across ranks: the slowest member of every rank's shard sets that rank's step time
+    it_rank = torch.tensor([float(iters.max()), float(iters.mean())], dtype=torch.float64, device=dev)
+    if use_dist:
+        it_all = [torch.empty_like(it_rank) for _ in range(world)]
+        dist.all_gather(it_all, it_rank)
+        it_all = [t.cpu().tolist() for t in it_all]
+    else:
+        it_all = [it_rank.cpu().tolist()]
+
+    # the same solve WITHOUT the profiling events (the product default), and through the host-buffer entry (H2D + D2H inside), N = 1 only
+    extra_rates = {}
+    if world == 1 and not args.no_extra:
+        ne = max(1, min(args.steps, 3))
+        h.set_options(tol=args.tol if args.tol > 0 else None, flags=0)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(ne):
+            step()
+        torch.cuda.synchronize()
+        e0 = time.perf_counter() - t0
+        extra_rates["unprofiled"] = {"value": nbl * p * ne / e0, "ms_per_step": 1e3 * e0 / ne, "steps": ne,
+                                     "note": "same device-resident step without TMPC_FLAG_PROFILE (no hipEvent pairs around the launches): the product default"}
+        hA, hB, hH = (x.cpu().numpy() for x in (dA, dB, dH))
+        h.convexify_batch(hA[:8], hB[:8], hH[:8])
+        nh = max(1, min(args.steps, 2))
+        t0 = time.perf_counter()
+        for _ in range(nh):
+            oh = h.convexify_batch(hA, hB, hH)
+        e1 = time.perf_counter() - t0
+        extra_rates["host_buffer"] = {"value": nbl * p * nh / e1, "ms_per_step": 1e3 * e1 / nh, "steps": nh,
+                                      "note": "tmpc_convexify_batch_host: pageable numpy buffers in, numpy buffers out (H2D of A, B, H and D2H of Hc, dHc, P, "
+                                              "scalars inside the timed region); SURVEY.md 8d's host-buffer to host-buffer metric -- never `value`",
+                                      "status_optimal": int((oh['status'] == 0).sum())}
+        h.set_options(tol=args.tol if args.tol > 0 else None, flags=FLAG_PROFILE)
 
     if rank == 0:
         total_units = nbl * world * p * args.steps
@@ -199,6 +300,7 @@ def main():
                        "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
                        "distinct_problems_per_gpu": nd, "mu_tol": args.tol if args.tol > 0 else 2.0 ** -25,
                        "ipm_iterations_max": int(iters.max()), "ipm_iterations_mean": float(iters.mean()),
+                       "ipm_iterations_per_rank": [{"max": int(a), "mean": b} for a, b in it_all],
                        "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
@@ -218,8 +320,13 @@ def main():
                                       "profiles/r2v_pmc_gemm_core_micro.txt), i.e. 59-62 TFLOP/s at the sustained clock"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
+        line.update(extra_rates)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 2.0 ** -25)
+            try:                                                        # the checker's build or run must never cost the GPU measurement its line
+                line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 2.0 ** -25)
+            except Exception as e:      # noqa: BLE001
+                line["cpu_baseline"] = None
+                line["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
         else:
             line["cpu_baseline"] = None
         sys.stdout.flush()

@@ -46,6 +46,7 @@ extern "C" {
 #define TMPC_E_NOMEM (-3)      /* hipMalloc failed                                          */
 #define TMPC_E_HIP (-4)        /* HIP runtime error (see tmpc_last_error)                   */
 #define TMPC_E_NODEVICE (-5)   /* no gfx950 device visible                                  */
+#define TMPC_E_NOCONV (-6)     /* tmpc_eig_clip_host: Jacobi sweeps exhausted (outputs hold the last iterate) */
 
 #define TMPC_STATUS_OPTIMAL 0    /* convexifier.py:444 'Optimal'    */
 #define TMPC_STATUS_FEASIBLE 1   /* convexifier.py:446 'Feasible'   */
@@ -87,7 +88,8 @@ int tmpc_get_chunk(tmpc_handle* h);
  * (the relative duality gap on kappa, the max condition number, is then (2*p*n+1)*tol);
  * center_tol = relative Newton step ending the final centering phase, default 1e-9;
  * max_iter / center_iter = iteration caps (defaults 50 / 12); flags = TMPC_FLAG_*.  Values <= 0 keep
- * the current setting (flags is always applied). */
+ * the current setting (flags is always applied; bits other than the TMPC_FLAG_* above -- and the debug bit of
+ * tunempc_hip_debug.h -- are rejected with TMPC_E_ARG). */
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags);
 
 /* Step 1 of convexifier.convexify for `nb` independent problems.  Any output pointer may be NULL.
@@ -181,7 +183,8 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
  * eigenvalues of the (reduced) Hessian below `regularization_tol` are lifted to it, H += evec diag(evmod - eva) evec^-1):
  *   out[b] = sym(A[b]) + V diag(max(tol - lambda_i, 0)) V',   A, out [nb][n][n], any n >= 1 (no handle, current device).
  * evals [nb][n] (optional): the eigenvalues lambda_i of A[b] (unordered); reg [nb] (optional): the largest lift max_i(tol - lambda_i, 0)
- * (the reference's `self.__reg`); sweeps [nb] (optional): Jacobi sweeps taken. */
+ * (the reference's `self.__reg`); sweeps [nb] (optional): Jacobi sweeps taken.  Returns TMPC_E_NOCONV when 40 sweeps did not
+ * orthogonalise the vectors to the rounding level (~2 n eps); the outputs then hold the last iterate. */
 int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, double* evals, double* reg, int32_t* sweeps);
 
 /* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set, 16 doubles:

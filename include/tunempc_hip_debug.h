@@ -14,6 +14,11 @@
 extern "C" {
 #endif
 
+/* Debug bit for tmpc_set_options(flags): the solve stops after ASSEMBLING the Schur system of the first iteration, which then sits
+ * unfactored in the workspace for tmpc_debug_get_array (tests/tools/step3_asm_check.py).  The outputs of such a call are NOT a
+ * solution -- never set it in product code. */
+#define TMPC_DEBUG_FLAG_STOP_ASSEMBLED 8
+
 /* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMMs of the factorisation; mode 0: C -= AB', 1: C = AB', 2: C = -AB'.
  * mode + 0: the register-staged core (tmpc_factor.h, one workgroup walks all tiles); + 16: the LDS-DMA tile core (tmpc_gemm_dma.h, one
  * workgroup per 64 x 64 tile); + 32: the LDS-DMA core with K split into two operand pairs of K/2 as one stream.  lower != 0: only the

@@ -27,6 +27,7 @@ void scipy_dtrsm_(const char*, const char*, const char*, const char*, const int*
 void scipy_dpotrf_(const char*, const int*, double*, const int*, int*);
 void scipy_dsyev_(const char*, const char*, const int*, double*, const int*, double*, double*, const int*, int*);
 void scipy_openblas_set_num_threads(int);
+int scipy_openblas_get_num_threads(void);
 }
 
 namespace {
@@ -500,6 +501,7 @@ int cpu_ipm_convexify_batch(int nb, int p, int nx, int mb, const double* A, cons
   if (nb < 0 || p < 1 || nx < 1 || mb < 0 || !A || !H || !Hc) return -1;
   const int n = nx + mb;
   if (tol <= 0.0) tol = 0x1p-25;
+  const int blas_threads_before = scipy_openblas_get_num_threads();     // the process's scipy shares this OpenBLAS: put its setting back afterwards
   scipy_openblas_set_num_threads(1);
   if (threads < 1) threads = 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
@@ -510,6 +512,7 @@ int cpu_ipm_convexify_batch(int nb, int p, int nx, int mb, const double* A, cons
     if (status) status[b] = r.status;
     if (iters) iters[b] = r.iters;
   }
+  scipy_openblas_set_num_threads(blas_threads_before);
   return 0;
 }
 

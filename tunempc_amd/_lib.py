@@ -136,6 +136,13 @@ def _iptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
 
 
+class EigNotConverged(RuntimeError):
+    """tmpc_eig_clip_host returned TMPC_E_NOCONV: the Jacobi sweeps were exhausted; `.partial` holds the last iterate."""
+
+
+E_NOCONV = -6
+
+
 def _check(lib, rc, what):
     if rc != 0:
         raise RuntimeError(f"tunempc_amd: {what} failed with code {rc}: {lib.tmpc_last_error().decode()}")
@@ -474,7 +481,12 @@ def eig_clip(A, tol):
     if n != n2:
         raise ValueError('square matrices expected')
     out = np.empty_like(A3); ev = np.empty((nb, n)); reg = np.empty(nb); sw = np.zeros(nb, dtype=np.int32)
-    _check(lib, lib.tmpc_eig_clip_host(nb, n, _dptr(A3), float(tol), _dptr(out), _dptr(ev), _dptr(reg), _iptr(sw)), 'tmpc_eig_clip_host')
+    rc = lib.tmpc_eig_clip_host(nb, n, _dptr(A3), float(tol), _dptr(out), _dptr(ev), _dptr(reg), _iptr(sw))
+    if rc == E_NOCONV:
+        err = EigNotConverged(f"tunempc_amd: tmpc_eig_clip_host did not converge: {lib.tmpc_last_error().decode()}")
+        err.partial = dict(out=out, evals=ev, reg=reg, sweeps=sw)
+        raise err
+    _check(lib, rc, 'tmpc_eig_clip_host')
     if single:
         return dict(out=out[0], evals=ev[0], reg=float(reg[0]), sweeps=int(sw[0]))
     return dict(out=out, evals=ev, reg=reg, sweeps=sw)

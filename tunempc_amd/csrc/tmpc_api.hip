@@ -547,7 +547,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
-    if (h->flags & 8) {                     // debug (tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
+    if (h->flags & TMPC_DEBUG_FLAG_STOP_ASSEMBLED) {   // debug (tunempc_hip_debug.h; tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
@@ -742,6 +742,10 @@ int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
+  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) {
+    snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2)", flags);
+    return TMPC_E_ARG;
+  }
   if (tol > 0) h->opt.tol = tol;
   if (center_tol > 0) h->opt.center_tol = center_tol;
   if (max_iter > 0) h->opt.max_iter = max_iter;
@@ -1106,37 +1110,62 @@ int tmpc_eig_scan_host(tmpc_handle* hh, int nbt, const double* H, double* out) {
 
 // out = A + V diag(max(tol - lambda, 0)) V' for nb symmetric n x n matrices (tmpc_eig.h; reference: sqp_method.py:327-403).
 // No handle: any n >= 1; the device is the current one.
+// device scratch of tmpc_eig_clip_host, kept between calls (the reference calls this once per SQP iteration: no hipMalloc / hipFree
+// pair inside that loop); one per host thread and device, grown on demand
+struct EigScratch {
+  void* p = nullptr; size_t bytes = 0; int device = -1;
+  ~EigScratch() { if (p) hipFree(p); }
+  hipError_t reserve(size_t need) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (p && dev == device && bytes >= need) return hipSuccess;
+    if (p) { hipFree(p); p = nullptr; bytes = 0; }
+    e = hipMalloc(&p, need);
+    if (e == hipSuccess) { bytes = need; device = dev; }
+    return e;
+  }
+};
+static thread_local EigScratch g_eig_scratch;
+
 int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, double* evals, double* reg, int32_t* sweeps) {
   if (nb < 1 || n < 1 || !A || !out) return TMPC_E_ARG;
-  const size_t nn = (size_t)n * n;
-  DevBuf bA, bU, bV, bO, bs;                                // bs: shift | evals | lift | reg | offmax
-  HIPCHK(bA.alloc((size_t)nb * nn * 8)); HIPCHK(bU.alloc((size_t)nb * nn * 8)); HIPCHK(bV.alloc((size_t)nb * nn * 8)); HIPCHK(bO.alloc((size_t)nb * nn * 8));
-  HIPCHK(bs.alloc(((size_t)nb * (3 + 2 * (size_t)n)) * 8));
-  double* dA = bA.as<double>(); double* dU = bU.as<double>(); double* dV = bV.as<double>(); double* dO = bO.as<double>();
-  double* dshift = bs.as<double>(); double* dev = dshift + nb; double* dlift = dev + (size_t)nb * n; double* dreg = dlift + (size_t)nb * n; double* doff = dreg + nb;
-  HIPCHK(hipMemcpy(dA, A, (size_t)nb * nn * 8, hipMemcpyHostToDevice));
+  const size_t nn = (size_t)n * n, mat = (size_t)nb * nn;
+  const size_t small = (size_t)nb * (3 + 2 * (size_t)n);    // shift | evals | lift | reg | offmax
+  HIPCHK(g_eig_scratch.reserve((4 * mat + small) * 8));
+  double* dA = (double*)g_eig_scratch.p; double* dU = dA + mat; double* dV = dU + mat; double* dO = dV + mat;
+  double* dshift = dO + mat; double* dev = dshift + nb; double* dlift = dev + (size_t)nb * n; double* dreg = dlift + (size_t)nb * n; double* doff = dreg + nb;
+  HIPCHK(hipMemcpy(dA, A, mat * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_eig_init, dim3(nb), dim3(256), 0, 0, dA, dU, dV, dshift, n);
   const int m = (n + 1) & ~1;
+  const double thr = std::max(1e-15, 2.0 * n * 2.220446049250313e-16);     // rotations below the rounding level of an n-long dot product never settle
   int sw = 0;
+  bool converged = (n == 1);
   std::vector<double> off(nb);
   if (n > 1) {
-    for (; sw < 40; ++sw) {
+    for (; sw < EIG_MAX_SWEEPS; ++sw) {
       HIPCHK(hipMemsetAsync(doff, 0, (size_t)nb * 8, 0));
-      for (int r = 0; r < m - 1; ++r) hipLaunchKernelGGL(k_eig_round, dim3(m / 2, nb), dim3(256), 0, 0, dU, dV, n, m, r, doff);
+      for (int r = 0; r < m - 1; ++r) hipLaunchKernelGGL(k_eig_round, dim3(m / 2, nb), dim3(256), 0, 0, dU, dV, n, m, r, doff, thr);
       HIPCHK(hipMemcpy(off.data(), doff, (size_t)nb * 8, hipMemcpyDeviceToHost));
       double worst = 0.0;
-      for (double v : off) worst = std::max(worst, v);
-      if (!(worst > 1e-15)) { ++sw; break; }                // a full sweep without a rotation
+      for (double v : off) if (v > worst) worst = v;
+      if (!(worst > thr)) { ++sw; converged = true; break; }   // a full sweep without a rotation
     }
   }
   HIPCHK(hipMemsetAsync(dreg, 0, (size_t)nb * 8, 0));
   hipLaunchKernelGGL(k_eig_values, dim3(n, nb), dim3(256), 0, 0, dU, dshift, dev, dlift, dreg, n, tol);
   hipLaunchKernelGGL(k_eig_apply, dim3((unsigned)((nn + 255) / 256), nb), dim3(256), 0, 0, dA, dV, dlift, dO, n);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(out, dO, (size_t)nb * nn * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, dO, mat * 8, hipMemcpyDeviceToHost));
   if (evals) HIPCHK(hipMemcpy(evals, dev, (size_t)nb * n * 8, hipMemcpyDeviceToHost));
   if (reg) HIPCHK(hipMemcpy(reg, dreg, (size_t)nb * 8, hipMemcpyDeviceToHost));
   if (sweeps) for (int b = 0; b < nb; ++b) sweeps[b] = sw;
+  if (!converged) {                                            // outputs hold the last iterate; the caller must not take them for converged
+    double worst = 0.0;
+    for (double v : off) if (v > worst) worst = v;
+    snprintf(g_err, sizeof(g_err), "tmpc_eig_clip_host: %d Jacobi sweeps without convergence (largest relative off-diagonal %.3e, threshold %.3e)", sw, worst, thr);
+    return TMPC_E_NOCONV;
+  }
   return TMPC_OK;
 }
 

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_eig_init(const double* A, double* U, do
 }
 
 // one round of the tournament: workgroup k rotates the pair (pa, pb) of round r (m = n rounded up to even players, player m-1 fixed)
-__global__ void __launch_bounds__(256) k_eig_round(double* U, double* V, int n, int m, int r, double* offmax) {
+__global__ void __launch_bounds__(256) k_eig_round(double* U, double* V, int n, int m, int r, double* offmax, double thr) {
   __shared__ double red[4];
   const int k = blockIdx.x, b = blockIdx.y;
   int pa, pb;
@@ -56,9 +56,10 @@ __global__ void __launch_bounds__(256) k_eig_round(double* U, double* V, int n, 
   double al = 0.0, be = 0.0, ga = 0.0;
   for (int j = threadIdx.x; j < n; j += 256) { const double x = up[j], y = uq[j]; al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga); }
   al = eig_block_sum(al, red); be = eig_block_sum(be, red); ga = eig_block_sum(ga, red);
-  const double rel = fabs(ga) / sqrt(al * be);
+  const double den = sqrt(al) * sqrt(be);                        // (the product al * be itself underflows for tiny-norm inputs)
+  const double rel = (den > 0.0) ? fabs(ga) / den : 0.0;
   if (threadIdx.x == 0) atomicMax((unsigned long long*)(offmax + b), (unsigned long long)__double_as_longlong(rel));     // rel >= 0: ordered as integers
-  if (!(rel > 1e-15)) return;
+  if (!(rel > thr)) return;                                      // thr ~ n eps: the rounding level of the n-long dot products
   const double zeta = (be - al) / (2.0 * ga);
   const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
   const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;

@@ -255,7 +255,9 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   }
   ip[I_ITERS] += 1;
   ip[I_SHIFT0] = ip[I_NSHIFT];
-  if (phase == PH_CENTER) { ip[I_NCENT] += 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
+  // centering budget: a chord step (factorisation re-used, a fifth of the cost, linear convergence) counts a quarter -- spending the
+  // budget of Newton steps on chord steps would trigger the mu_t back-off below, i.e. change the answer, on slowly contracting members
+  if (phase == PH_CENTER) { ip[I_NCENT] += (ip[I_CHORD] && (ip[I_NCHORD] & 3)) ? 0 : 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
   else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
 }
 
@@ -407,7 +409,6 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     }
     ip[I_CHORD] = (ip[I_PHASE] != PH_DONE && chord_next) ? 1 : 0;
     if (ip[I_CHORD]) ip[I_NCHORD] += 1;
-    if (ip[I_PHASE] == PH_CENTER && ip[I_CHORD] == 0 && was_chord) ip[I_NCENT] -= 0;   // (a rejected chord step still counts as a centering iteration)
     pr[P_PREVSTEPN] = (full && !full_reset) ? stepn : -1.0;
   }
   if (ip[I_PHASE] != PH_DONE) {

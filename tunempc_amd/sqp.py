@@ -11,7 +11,10 @@
 The null space (an SVD of the active-constraint Jacobian, scipy.linalg.null_space as in the reference) and the two thin
 products with Z stay host numpy; the symmetric eigen-decomposition, clip and reconstruction of the r x r (or full) matrix are
 tmpc_eig_clip_host (include/tunempc_hip.h, tunempc_amd/csrc/tmpc_eig.h).  The reference calls the general `eig` on a matrix that is
-symmetric by construction; its eigenvalues are real and evec^-1 = evec', which is what the symmetric solver returns."""
+symmetric by construction; its eigenvalues are real and evec^-1 = evec', which is what the symmetric solver returns.
+
+A decomposition that did not converge (TMPC_E_NOCONV: 40 Jacobi sweeps exhausted) raises `_lib.EigNotConverged` out of
+regularize_hessian: a Hessian "regularised" with unconverged eigenvectors would silently hand the QP an indefinite matrix."""
 import numpy as np
 
 from tunempc_amd import _lib
