@@ -114,7 +114,12 @@ int tmpc_convexify_eq_batch_host(tmpc_handle* h, int nb, const double* A, const 
  * J [nb][p][ng+nc][n]: per stage the ng rows of G_k, then the rows of C_k, zero padding up to nc (ng, nc of tmpc_create_con);
  * ncnt int32 [nb][p]: rows of C_k actually present (0 for a stage whose C_k is None).  FgF [nb][p][ng+nc] out: Fg_k, then F_k,
  * zeros in the padding.  dHc includes both constraint terms.  The caller decides when to take this step (after Step 1 came
- * back Infeasible, as convexify() does). */
+ * back Infeasible, as convexify() does).
+ * rho = 0 selects the BETA-ONLY objective: the reference assembles the norm terms with `picos.sum(obj, abs(rho*F[i]))`
+ * (convexifier.py:276-283); whether PICOS 1.2.0 adds or drops that second argument cannot be checked here (the package is not installed,
+ * SURVEY.md 7.0).  If it drops it, the solver sees min beta with cost-free multipliers F_k, Fg_k >= 0 -- the rows of C_k then act exactly
+ * like rows of G_k -- which is what rho = 0 solves (no norm cones at all, not a zero-weight limit of them).  rho > 0 is the paper's
+ * objective (eq. 20a) and the default of the Python mirror. */
 int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* J,
                                     const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);

@@ -368,7 +368,7 @@ def _soc_max_step(u, du):
     return min(cand)
 
 
-def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None, force=False):
+def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho=None, force=False, cost_free=False):
     """Solve  min beta  s.t.  alpha>=1e-8, I <= M_k <= sbeta*beta*I  (convexifier.py:213-308 with
     constr=False, force=False) for one tuning problem.  Returns dict with P (= dP of
     convexifier.py:406), alpha, beta, kappa=sbeta*beta, iterations, ipm status flags.
@@ -381,7 +381,11 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     objective is tau = sbeta*beta plus the sum of the t).  All of them are stage-local border columns as well.
     force (with rho): Step 3 (convexifier.py:137-147): T_k symmetric with every entry > 0 (:269-273), term s_T*T_k in HcE_k
     (:352-353) and rho*||T_k||_F in the objective (:284-285).  The n(n+1)/2 free entries of T_k are further stage-local
-    multipliers whose "row" is the basis matrix E_ab instead of g g'; the Frobenius norm weighs off-diagonal entries by sqrt(2)."""
+    multipliers whose "row" is the basis matrix E_ab instead of g g'; the Frobenius norm weighs off-diagonal entries by sqrt(2).
+    cost_free (with C): the OTHER reading of convexifier.py:276-283.  The reference adds the norm terms with `picos.sum(obj, abs(rho*F[i]))`;
+    in PICOS 1.2.0 the second positional parameter of picos.sum was an iterator label, not a summand ([UNVERIFIED]: the
+    package is not installed), in which case the objective the solver sees is beta alone and F_k, Fg_k are cost-free multipliers -- the
+    rows of C_k then behave exactly like rows of G_k (ragged).  Same as rho = 0.  The paper's objective (eq. 20a) is the default."""
     o = dict(DEFAULT_OPTS)
     if opts:
         o.update(opts)
@@ -419,7 +423,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         s0 = alpha - ALPHA_MIN; x0 = mu0w / s0
     ng = 0                                                 # rows of [G_k; C_k] per stage (padded to the longest stage, `mask` = real rows)
     ng0 = 0                                                # of which equality-constraint rows
-    constr = C is not None and rho is not None
+    constr = C is not None and (rho is not None or cost_free)
+    cost_free = bool(cost_free) or (constr and rho == 0.0)
     force = bool(force) and rho is not None
     nT = n * (n + 1) // 2 if force else 0                  # free entries of T_k (Step 3)
     ncs = [0] * p
@@ -454,11 +459,11 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         phi = np.where(mask, np.minimum(1.0, 1.0 / g2), 1.0)
         z = np.where(mask, x0 / phi, 0.0)
         N = N + int(mask.sum())
-        if constr or force:
+        if (constr and not cost_free) or force:
             wr = rho * sbeta / s
             for k in range(p):
                 blocks = []
-                if constr:
+                if constr and not cost_free:
                     blocks = ([np.arange(ng0)] if ng0 else []) + ([ng0 + np.arange(ncs[k])] if ncs[k] else [])
                 if nT:
                     blocks.append(nJ + np.arange(nT))
@@ -777,7 +782,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         Tm = np.zeros((p, n, n))
         Tm[:, ta, tb] = phi[:, nJ:] / (s * alpha); Tm[:, tb, ta] = phi[:, nJ:] / (s * alpha)            # convexifier.py:422-423 (s_T = s_alpha = s)
         out['T'] = Tm
-    if constr or nT:
+    if (constr and not cost_free) or nT:
         out['objective'] = tau / sbeta + sum(a['t'] for a in arrows) / sbeta       # beta + sum rho ||F_k|| (+ rho ||Fg_k||) (+ rho ||T_k||_F)
     return out
 

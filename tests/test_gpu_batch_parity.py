@@ -1,0 +1,249 @@
+"""GPU parity of the BATCH path that bench.py measures (run with -m gpu on an MI355X; every call goes through the C ABI).
+
+tests/test_gpu_parity.py value-checks batches of at most five members.  The benchmarked path is different in kind: hundreds of
+members per wave, launches over the compacted list of members still iterating (`alist`) and of those that need a new factorisation
+(`flist`), chord steps for some members while others re-factor, waves (batch > chunk), stragglers and the mu_t back-off.  Here every
+member of such batches is compared with oracle/cpu_ipm (the compiled restatement of the structured oracle, tied to the numpy oracle
+in tests/test_cpu_ipm.py) to the same 1e-8 relative Frobenius bar, and the solver-independent answers (identity family, dual
+certificate) are asserted with the VALUES they reach.  VERDICT r2, "Next round" items 1a and 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before the HIP library is loaded, see tests/test_gpu_parity.py)
+
+pytestmark = pytest.mark.gpu
+
+import convexify_oracle as co  # noqa: E402
+import cpu_ipm  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARITY = 1e-8       # relative Frobenius norm, BASELINE.json: "H/q within 1e-8 of reference"
+HOST_THREADS = max(1, min(8, len(os.sched_getaffinity(0))))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def hc():
+    from tunempc_amd._lib import HipConvexifier
+    cache = {}
+
+    def get(p, nx, mb, **kw):
+        key = (p, nx, mb, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = HipConvexifier(p, nx, mb, **kw)
+        return cache[key]
+    yield get
+    for h in cache.values():
+        h.close()
+
+
+def _check_members(out, ref, members, what):
+    worst = 0.0
+    for b in members:
+        assert int(out['status'][b]) == int(ref['status'][b]), (what, b, out['status'][b], ref['status'][b])
+        e = rel(out['Hc'][b], ref['Hc'][b])
+        worst = max(worst, e)
+        assert e < PARITY, (what, b, e)
+        assert abs(out['kappa'][b] - ref['kappa'][b]) < 1e-9 * max(1.0, ref['kappa'][b]), (what, b)
+    return worst
+
+
+# ----------------------------------------------------------------------------- (i) whole batches, every member value-checked
+@pytest.mark.parametrize('name,seed,nb,p,nx,mb,chunk', [
+    ('n = 16, 96 members in one wave', 31000, 96, 16, 12, 4, 0),
+    ('n = 16, 70 members in waves of 32 (ragged last wave)', 32000, 70, 16, 12, 4, 32),
+    ('c4 bench shape, 16 members', 33000, 16, 64, 24, 8, 0),
+])
+def test_batch_parity_every_member(hc, name, seed, nb, p, nx, mb, chunk):
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
+    h = hc(p, nx, mb, chunk=chunk) if chunk else hc(p, nx, mb)
+    out = h.convexify_batch(A, B, H)
+    ref = cpu_ipm.convexify_batch(A, B, H, threads=HOST_THREADS)
+    assert (ref['status'] == 0).all()
+    worst = _check_members(out, ref, range(nb), name)
+    print(f'{name}: worst rel. Frobenius error over {nb} members {worst:.2e}; iterations {out["iters"].min()}..{out["iters"].max()}')
+
+
+# ----------------------------------------------------------------------------- (ii) the batch bench.py times
+def test_bench_batch_sampled_members(hc):
+    """The exact 512-problem batch of bench.py (`synthetic.gen_batch(100000, 512, 64, 24, 8)`, default chunk, device-resident entry): every
+    member Optimal, and 8 members drawn at random are compared with cpu_ipm on their own -- the values the benchmark produces, not just
+    its status column."""
+    import torch
+    from tunempc_amd import synthetic
+    p, nx, mb, nb = 64, 24, 8, 512
+    A, B, H = synthetic.gen_batch(100000, nb, p, nx, mb)
+    h = hc(p, nx, mb)
+    dev = torch.device('cuda', 0)
+    o = h.convexify_batch_device(*(torch.from_numpy(x).to(dev) for x in (A, B, H)))
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in o.items()}
+    assert (out['status'] == 0).all()
+    pick = np.sort(np.random.default_rng(20261002).choice(nb, size=8, replace=False))
+    ref = cpu_ipm.convexify_batch(A[pick], B[pick], H[pick], threads=HOST_THREADS)
+    sub = {k: out[k][pick] for k in ('Hc', 'kappa', 'status')}
+    worst = _check_members(sub, ref, range(len(pick)), 'bench batch')
+    # the slowest and the fastest member of the batch as well (the ones the compaction treats differently from the crowd)
+    ext = np.array([int(np.argmax(out['iters'])), int(np.argmin(out['iters']))])
+    ref2 = cpu_ipm.convexify_batch(A[ext], B[ext], H[ext], threads=2)
+    worst = max(worst, _check_members({k: out[k][ext] for k in ('Hc', 'kappa', 'status')}, ref2, range(2), 'bench batch extremes'))
+    print(f'bench batch: members {pick.tolist()} + extremes {ext.tolist()}: worst rel. Frobenius error {worst:.2e}; '
+          f'iterations {out["iters"].min()}..{out["iters"].max()} (mean {out["iters"].mean():.2f})')
+
+
+# ----------------------------------------------------------------------------- (iii) waves + a forced straggler
+def _hard_problem(seed, p, nx, mb, cond_exp):
+    """the generator of tunempc_amd.synthetic with cond(Hhat) = 10^cond_exp instead of 10"""
+    rng = np.random.default_rng(seed)
+    n = nx + mb
+    A = np.zeros((p, nx, nx)); B = np.zeros((p, nx, mb)); Phat = np.zeros((p, nx, nx)); Hhat = np.zeros((p, n, n))
+    for k in range(p):
+        a = rng.standard_normal((nx, nx)) / np.sqrt(nx)
+        A[k] = a * (0.9 / np.max(np.abs(np.linalg.eigvals(a))))
+        B[k] = rng.standard_normal((nx, mb)) / np.sqrt(nx)
+        W, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = 10.0 ** rng.uniform(0, cond_exp, n); lam[0] = 1.0; lam[1] = 10.0 ** cond_exp
+        Hhat[k] = (W * lam) @ W.T
+        pk = rng.standard_normal((nx, nx)); Phat[k] = (pk + pk.T) / 2
+    H = co.symmetrize(Hhat - co.calH(A, B, Phat))
+    return A, B, H
+
+
+def test_waves_with_stragglers(hc):
+    """Batch larger than the chunk, two hard members among ordinary ones -- cond(Hhat) = 1e3 (19 oracle iterations) and 10^4.5 (37 oracle
+    iterations, one mu_t back-off in the oracle): the crowd finishes early (compacted lists, chord steps) while the stragglers keep
+    iterating.  Every ordinary member must (a) equal the value it gets in a batch WITHOUT the stragglers bit for bit -- members never
+    interact --, (b) match cpu_ipm to 1e-8; the stragglers must end with the solver-independent invariants intact."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb, chunk = 16, 12, 4, 40, 16
+    A, B, H = synthetic.gen_batch(34000, nb, p, nx, mb)
+    hard = {21: 3.0, 33: 4.5}                             # second and third (last, ragged) wave
+    A2, B2, H2 = A.copy(), B.copy(), H.copy()
+    for b, ce in hard.items():
+        A2[b], B2[b], H2[b] = _hard_problem(99, p, nx, mb, ce)
+    h = hc(p, nx, mb, chunk=chunk)
+    base = h.convexify_batch(A, B, H)
+    out = h.convexify_batch(A2, B2, H2)
+    tr = h.trace(nb - 2 * chunk)                         # last wave only (diagnostics of the final chunk)
+    others = [b for b in range(nb) if b not in hard]
+    for b in others:
+        assert np.array_equal(out['Hc'][b], base['Hc'][b]) and out['iters'][b] == base['iters'][b], b
+    ref = cpu_ipm.convexify_batch(A, B, H, threads=HOST_THREADS)
+    worst = _check_members(out, ref, others, 'waves')
+    # chord steps were taken in the last wave (phase column x.25, tmpc_schur.h k_ctrl_c)
+    ph = tr[:, :, 1]
+    chord = int(np.sum(np.abs(ph - np.floor(ph) - 0.25) < 1e-9))
+    assert chord > 0
+    print(f'waves: worst rel. error of {len(others)} ordinary members {worst:.2e}; chord steps in the last wave: {chord}')
+    for b in hard:                                        # the stragglers: more iterations than the crowd, invariants hold
+        assert out['iters'][b] > np.median(out['iters'][others])
+        assert int(out['status'][b]) in (0, 1)
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-8)
+        dH = co.convex_hessian_suppl(A2[b], B2[b], out['P'][b])[0]
+        assert rel(out['Hc'][b] - H2[b], dH) < 1e-10
+        dflt = 2.0 ** np.round(np.log2(2.0 ** -25 * out['kappa'][b]))
+        print(f'  straggler {b} (cond 1e{hard[b]}): {out["iters"][b]} iterations (median of the crowd {np.median(out["iters"][others]):.0f}), '
+              f'mu_target / default = {out["info"][b, 6] / dflt:.0f}, status {out["status"][b]}, kappa {out["kappa"][b]:.1f}')
+
+
+# ----------------------------------------------------------------------------- (iv) BASELINE configs[2] at its batch
+def test_c3_batch_256_values(hc):
+    """BASELINE configs[2]: evaporation-shaped (nx = 2, m = 2), p = 50, batch = 256 random seeds -- every member against cpu_ipm."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb = 50, 2, 2, 256
+    A, B, H = synthetic.gen_batch(35000, nb, p, nx, mb)
+    out = hc(p, nx, mb).convexify_batch(A, B, H)
+    ref = cpu_ipm.convexify_batch(A, B, H, threads=HOST_THREADS)
+    worst = _check_members(out, ref, range(nb), 'c3 batch')
+    print(f'c3 batch 256: worst rel. Frobenius error {worst:.2e}; optimal {(out["status"] == 0).sum()}/{nb}; early exits {int(out["info"][:, 13].sum())}')
+
+
+# ----------------------------------------------------------------------------- (v) the HIP handle under two ranks
+_RANK_CODE = r'''
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]; out_path = sys.argv[2]
+sys.path.insert(0, ROOT)
+from tunempc_amd._lib import HipConvexifier
+from tunempc_amd import synthetic
+from tunempc_amd.dist import convexify_batch_sharded, shard_range
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)          # one GPU on this box: both ranks open cuda:0, the collective runs on the host
+torch.cuda.set_device(0)
+p, nx, mb, nb = 4, 3, 2, 5                                             # ragged: shards of 2 and 3
+A, B, H = synthetic.gen_batch(910, nb, p, nx, mb)
+h = HipConvexifier(p, nx, mb, chunk=4)
+def solve(a, b, c):
+    o = h.convexify_batch(a.numpy(), b.numpy(), c.numpy())            # the real handle, C ABI, this rank's slice only
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in o.items()}
+cache = {}
+g = convexify_batch_sharded(torch.from_numpy(A), torch.from_numpy(B), torch.from_numpy(H), solve)
+lo, hi = shard_range(nb, rank, world)
+np.savez(out_path + f'.rank{rank}.npz', Hc=g['Hc'].numpy(), kappa=g['kappa'].numpy(), status=g['status'].numpy(), lo=lo, hi=hi)
+dist.barrier()
+dist.destroy_process_group()
+h.close()
+'''
+
+
+def test_hip_handle_under_two_ranks(hc, tmp_path):
+    """Two child processes, each started fresh (no GPU call before the rank initialises), both on cuda:0, `gloo` collective, the REAL
+    HipConvexifier as solve_fn of tunempc_amd.dist.convexify_batch_sharded, ragged 5-problem batch: every rank ends with the full batch,
+    equal to the serial solve bit for bit.  (RCCL with more than one rank needs more than one GPU; the box has one.)"""
+    from tunempc_amd import synthetic
+    port = 29700 + os.getpid() % 200
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    outp = str(tmp_path / 'g')
+    procs = [subprocess.Popen([sys.executable, '-c', _RANK_CODE, ROOT, outp], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for pr in procs:
+        try:
+            so, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            pr.kill(); so, _ = pr.communicate()
+        logs.append(so)
+    assert all(pr.returncode == 0 for pr in procs), '\n'.join(logs)[-3000:]
+    A, B, H = synthetic.gen_batch(910, 5, 4, 3, 2)
+    ref = hc(4, 3, 2, chunk=4).convexify_batch(A, B, H)
+    shards = []
+    for r in range(2):
+        g = np.load(outp + f'.rank{r}.npz')
+        assert np.array_equal(g['Hc'], ref['Hc']) and np.array_equal(g['kappa'], ref['kappa']) and np.array_equal(g['status'], ref['status'])
+        shards.append((int(g['lo']), int(g['hi'])))
+    assert shards == [(0, 2), (2, 5)]
+
+
+# ----------------------------------------------------------------------------- solver-independent answers, with their values
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(77, 3, 5, 4, 2), (78, 3, 16, 12, 4), (79, 2, 64, 24, 8)])
+def test_identity_family_against_the_known_answer(hc, seed, nb, p, nx, mb):
+    """Hhat_k = I  =>  kappa* = 1 and Hc_k = I is the UNIQUE optimal point -- the one family whose answer does not depend
+    on any solver (ours or the reference's).  Compared with I itself, not with the oracle:
+      * Hc: the central path of this family runs through M_k = const * I, so the centred point the library returns already IS the
+        answer up to rounding: asserted <= 1e-9 (max-norm), measured ~1e-12;
+      * kappa - 1 = the duality gap N mu_t the solver stops at ((2pn+1) * 2^-25 relative; 1.2e-4 at the bench shape) -- the one output whose
+        distance to the optimum is set by the tolerance."""
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb, identity=True)
+    out = hc(p, nx, mb).convexify_batch(A, B, H)
+    n = nx + mb
+    N = 2 * p * n + 1
+    eye = np.broadcast_to(np.eye(n), (p, n, n))
+    for b in range(nb):
+        assert int(out['status'][b]) == 0
+        err = np.abs(out['Hc'][b] - eye).max()
+        gap = out['kappa'][b] - 1.0
+        print(f'identity family p={p} n={n} member {b}: max|Hc - I| = {err:.2e}, kappa - 1 = {gap:.3e} (N * 2^-25 = {N * 2.0 ** -25:.3e})')
+        assert err <= 1e-9
+        assert 0.0 <= gap <= 1.5 * N * 2.0 ** -25

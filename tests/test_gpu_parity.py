@@ -384,6 +384,29 @@ def test_step2_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng, ncs, rho):
         assert rel(out['dHc'][b], ref) < 1e-12
 
 
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng,ncs', [(20, 2, 3, 3, 2, 0, [2, 0, 1]), (7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3]), (11, 1, 4, 6, 3, 2, [4, 0, 8, 1]),
+                                                    (30, 1, 2, 3, 1, 1, [1, 1]), (12, 1, 3, 24, 8, 4, [8, 3, 0])])
+def test_step2_beta_only_objective_parity(hc, seed, nb, p, nx, mb, ng, ncs):
+    """The OTHER reading of convexifier.py:276-283 (`picos.sum(obj, abs(rho*F[i]))` may drop its second argument in PICOS 1.2.0, SURVEY.md
+    7.0): objective beta alone, multipliers F_k, Fg_k cost-free.  rho = 0 through the C ABI vs the oracle's cost_free model; ragged C_k."""
+    A, B, H, G, C, ncnt = _step2_inputs(seed, nb, p, nx, mb, ng, ncs)
+    J = np.concatenate([G, C], axis=2)
+    out = hc(p, nx, mb, ng=ng, nc=C.shape[2]).convexify_step2_batch(A, B, H, J, ncnt, 0.0)
+    for b in range(nb):
+        Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        Gb = G[b] if ng else None
+        r = co.sdp_step1(A[b], B[b], H[b], G=Gb, C=Cl, cost_free=True)
+        st, dHc = co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], G=Gb, Fg=r.get('Fg'), C=Cl, F=r['F'])[:2]
+        assert int(out['status'][b]) == int(st)
+        assert rel(out['Hc'][b], H[b] + dHc) < PARITY
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        Fo = out['FgF'][b]
+        assert (Fo >= 0).all() and all(not Fo[k, ng + ncnt[b, k]:].any() for k in range(p))
+        # cost-free multipliers can only lower kappa compared with the paper's objective at any rho > 0
+    paper = hc(p, nx, mb, ng=ng, nc=C.shape[2]).convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    assert (out['kappa'] <= paper['kappa'] * (1 + 1e-7)).all()
+
+
 @pytest.mark.parametrize('name', ['step2_ragged_n5', 'step2_with_g_n6', 'step2_p1'])
 def test_step2_golden_vectors(hc, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
@@ -813,6 +836,11 @@ def test_dual_certificate(hc, seed, nb, p, nx, mb):
         assert kappa - dobj <= 1.05 * gap + slack     # ... and they are as close as the barrier parameter says
         assert gap / kappa <= (2 * p * (nx + mb) + 1) * 2.0 ** -25 * 1.5
         assert abs(dual['tau'][b] - kappa) <= 1e-12 * kappa
+        # the VALUE of the certified gap: kappa* lies in [dobj - slack, kappa]; relative width = N tol (1.2e-4 at p = 64, n = 32) -- the
+        # distance of the returned kappa to the optimum that holds whatever solver produced the point (the reference's solver stops at ~1e-8)
+        width = (kappa - (dobj - slack)) / kappa
+        print(f'certified relative gap on kappa, p={p} n={nx + mb} member {b}: {width:.3e}  (N tol = {(2 * p * (nx + mb) + 1) * 2.0 ** -25:.3e})')
+        assert width <= 1.1 * (2 * p * (nx + mb) + 1) * 2.0 ** -25
 
 
 # ----------------------------------------------------------------------------- producer row: sensitivities -> batched inputs

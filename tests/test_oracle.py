@@ -196,3 +196,20 @@ def test_supplement_terms_restatement():
         Hs = (Hco + Hco.T) / 2
         assert np.allclose(dH[i], Hs, atol=1e-13)
         assert np.array_equal(dQ[i], dH[i][:nx, :nx]) and np.array_equal(dR[i], dH[i][nx:, nx:]) and np.array_equal(dN[i], dH[i][:nx, nx:])
+
+
+def test_cost_free_multipliers_equal_equality_rows():
+    """The beta-only reading of convexifier.py:276-283 (cost_free=True / rho = 0): with the same number of rows at every stage the
+    rows of C_k are indistinguishable from rows of G_k; with ragged rows kappa can only be lower than with the norm terms."""
+    A, B, H = co.gen_batch(7, 1, 5, 4, 2)
+    A, B, H = A[0], B[0], H[0]
+    rng = np.random.default_rng(3)
+    C = [rng.standard_normal((2, 6)) for _ in range(5)]
+    r1 = co.sdp_step1(A, B, H, C=C, cost_free=True)
+    r2 = co.sdp_step1(A, B, H, G=np.stack(C))
+    assert np.array_equal(r1['P'], r2['P']) and np.array_equal(np.stack(r1['F']), r2['Fg'])
+    Cr = [C[0], None, C[2][:1], C[3], None]
+    r3 = co.sdp_step1(A, B, H, C=Cr, rho=0.0)
+    r4 = co.sdp_step1(A, B, H, C=Cr, rho=1e-3)
+    assert r3['ipm_status'] == r4['ipm_status'] == 'optimal' and r3['kappa'] <= r4['kappa'] * (1 + 1e-7)
+    assert r3['F'][1] is None and r3['F'][4] is None and all((f >= 0).all() for f in r3['F'] if f is not None)

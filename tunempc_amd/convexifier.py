@@ -98,7 +98,8 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0):
 def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     """Batched Step 2 model (convexifier.py:116-131, setUpModelPicos with constr=True): A, B, H as in convexify_batch;
     C [nb,p,nc,n] active-constraint Jacobians zero-padded to nc rows, ncnt [nb,p] rows present per stage (0: C_k is None);
-    G [nb,p,ng,n] optional.  Returns the dict of convexify_batch plus 'F' [nb,p,nc] (zeros in the padding) and, with G, 'Fg'."""
+    G [nb,p,ng,n] optional.  Returns the dict of convexify_batch plus 'F' [nb,p,nc] (zeros in the padding) and, with G, 'Fg'.
+    rho = 0: the beta-only objective (cost-free multipliers; see `convexify`, opts['objective'])."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     C = np.asarray(C, dtype=np.float64); ncnt = np.asarray(ncnt, dtype=np.int32)
     nb, p, nx, _ = A.shape
@@ -244,7 +245,13 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     :param Q: weighting matrix Q (nx,nx)   :param R: (nu,nu)   :param N: (nx,nu)
     :param C: jacobian of active constraints at steady state (nc, nx+nu)
     :param G: jacobian of equality constraints at steady state (ng, nx+nu)
-    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91)
+    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); one more key,
+                 'objective': 'paper' (default) | 'beta'.  The reference assembles the Step 2/3 objective with
+                 `picos.sum(obj, abs(rho*F[i]))` (convexifier.py:276-285).  In PICOS 1.2.0 the second positional parameter of
+                 picos.sum may be an iterator label rather than a summand (unverifiable here, PICOS is not
+                 installed): then the solver minimises beta alone and the multipliers are cost-free.  'paper' is the objective
+                 of the paper (eq. 20a): beta + rho * sum(||F_k|| + ||Fg_k|| [+ ||T_k||]); 'beta' is the other reading, for
+                 Step 2 (the rows of C_k act like rows of G_k).  For Step 3 a cost-free T_k has no counterpart here.
     :return: Convexified Hessian supplement "dH": (dHc, dQc, dRc, dNc), lists of p arrays.
     """
     arg = {'A': A, 'B': B, 'Q': Q, 'R': R, 'N': N}
@@ -269,6 +276,10 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     solver = (opts or {}).get('solver', 'hip')
     if solver not in ('hip', 'mosek', 'cvxopt'):
         raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))
+    objective = (opts or {}).get('objective', 'paper')
+    if objective not in ('paper', 'beta'):
+        raise ValueError("unknown objective '{}' ('paper': beta + rho * norm terms, 'beta': beta alone)".format(objective))
+    rho2 = 0.0 if objective == 'beta' else (opts or {}).get('rho', 1e-3)      # Step 2: rho = 0 is the beta-only model
 
     Gs = None
     if 'G' in arg:        # the multipliers Fg_k >= 0 belong to every step, Step 1 included (convexifier.py:249-255)
@@ -317,7 +328,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
                 Cp[k, :rows[k]] = c
         Logger.logger.info('solving SDP...')
         res = convexify_step2_batch(As[None], Bs[None], Hs[None], Cp[None], np.asarray(rows, np.int32)[None],
-                                    (opts or {}).get('rho', 1e-3), G=None if Gs is None else Gs[None])
+                                    rho2, G=None if Gs is None else Gs[None])
         status = _log_solution(res)
         if status in ['Optimal', 'Feasible']:
             Logger.logger.info('EQUIVALENCE TYPE B')
@@ -328,6 +339,9 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         Logger.logger.warning('!! The provided indefinite LQ MPC problem is not stabilising !!')
         Logger.logger.warning(50 * '*')
         if (opts or {}).get('force', False):                                  # convexifier.py:137-147
+            if objective == 'beta':
+                raise NotImplementedError("opts['objective'] = 'beta' covers Step 2; Step 3 with a cost-free T_k (the beta-only reading of "
+                                          "convexifier.py:284-285) has no counterpart in the HIP path -- use the default objective")
             Logger.logger.info('Step 3: (η_F = 1), (η_T = 1)')
             Logger.logger.info('Enforcing convexification...')
             Logger.logger.info('solving SDP...')

@@ -493,8 +493,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   if (!step3) dm.nT = 0;                  // a handle with room for T also serves the other models
   // a handle created with room for G / C rows also serves calls without them; Step 2 (constr) when the C counts are given
   if (!dG) { dm.ng = 0; dm.nr = 0; dm.nz = 0; }
-  dm.constr = (dG && dncnt) ? 1 : 0;
+  // rho == 0 with C counts: the beta-only objective (the other reading of convexifier.py:276-283, see tunempc_hip.h): the rows of C_k are
+  // cost-free like those of G_k -- ragged rows, no norm terms (no arrow blocks, no epigraph variables)
+  dm.constr = (dG && dncnt && rho > 0.0) ? 1 : 0;
   if (dG && !dncnt) { dm.nr = dm.ng; dm.nz = dm.ng; }
+  if (dG && dncnt && !dm.constr) dm.nz = dm.nr;
   // stage-local multipliers ride inside the blocks (block size d + nz)
   const bool eq = dm.nr > 0;
   const bool t3 = dm.nT > 0;
@@ -949,8 +952,8 @@ int tmpc_convexify_con_batch_device(tmpc_handle* h, int nbt, const double* dA, c
   if (h && nbt == 0) return TMPC_OK;           // empty shard
   if (!h || nbt < 1 || !dA || !dH || !dJ || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
   const Dims& dm = h->dm;
-  if (d_ncnt ? (dm.nz <= dm.nr || !(rho > 0.0)) : dm.ng < 1) {
-    snprintf(g_err, sizeof(g_err), "handle has no room for this call (Step 2 needs tmpc_create_con with nc > 0 and rho > 0, Step 1 with G needs ng > 0)");
+  if (d_ncnt ? (dm.nz <= dm.nr || !(rho >= 0.0)) : dm.ng < 1) {
+    snprintf(g_err, sizeof(g_err), "handle has no room for this call (Step 2 needs tmpc_create_con with nc > 0 and rho >= 0, Step 1 with G needs ng > 0)");
     return TMPC_E_ARG;
   }
   ON_DEVICE(h);
@@ -983,7 +986,7 @@ int tmpc_convexify_step2_batch_host(tmpc_handle* h, int nbt, const double* A, co
                                     const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* alpha,
                                     double* beta, double* kappa, int32_t* status, int32_t* iters, double* info) {
   if (h && nbt == 0) return TMPC_OK;
-  if (!h || nbt < 1 || !A || !H || !J || !ncnt || !FgF || !(rho > 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;
+  if (!h || nbt < 1 || !A || !H || !J || !ncnt || !FgF || !(rho >= 0.0) || (h->dm.mb > 0 && !B)) return TMPC_E_ARG;      // rho = 0: beta-only objective
   const Dims& dm = h->dm;
   if (dm.nz <= dm.nr) { snprintf(g_err, sizeof(g_err), "handle was created without active-constraint rows (use tmpc_create_con with nc > 0)"); return TMPC_E_ARG; }
   const int ncmax = dm.nr - dm.ng;
