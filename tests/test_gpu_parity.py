@@ -185,7 +185,7 @@ def test_golden_vectors(hc, golden_dir, name):
         assert int(out['status'][b]) == int(g['status'][b])
         assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
         assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
-        assert rel(out['P'][b], g['P'][b]) < 1e-7
+        assert rel(out['P'][b], g['P'][b]) < PARITY          # P is as well determined as Hc (amplification <= 10: profiles/r3_secondary_outputs.txt)
 
 
 @pytest.mark.parametrize('seed,nb,p,nx,mb', [(0, 3, 3, 3, 2), (20, 4, 1, 3, 1), (30, 4, 2, 3, 1), (13, 2, 30, 4, 1), (5, 4, 16, 3, 2),
@@ -281,7 +281,7 @@ def test_equality_term_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng):
         if r['early_exit']:
             assert not out['Fg'][b].any() and not out['dHc'][b].any()
             continue
-        assert (out['Fg'][b] >= 0).all() and rel(out['Fg'][b], r['Fg']) < 1e-7
+        assert (out['Fg'][b] >= 0).all() and rel(out['Fg'][b], r['Fg']) < PARITY
         # the supplement is what convexHessianSuppl builds from (P, Fg): convexifier.py:196-197
         assert rel(out['dHc'][b], co.convex_hessian_suppl(A[b], B[b], out['P'][b], G=G[b], Fg=out['Fg'][b])[0]) < 1e-12
         ev = np.linalg.eigvalsh(out['Hc'][b])
@@ -298,7 +298,7 @@ def test_equality_term_golden_vectors(hc, golden_dir, name):
         assert int(out['status'][b]) == int(g['status'][b])
         assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
         assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
-        assert np.linalg.norm(out['Fg'][b] - g['Fg'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['Fg'][b]))
+        assert np.linalg.norm(out['Fg'][b] - g['Fg'][b]) <= PARITY * max(1.0, np.linalg.norm(g['Fg'][b]))
 
 
 def test_equality_term_handle_serves_plain_calls_and_chunks(hc):
@@ -374,9 +374,9 @@ def test_step2_parity_vs_oracle(hc, seed, nb, p, nx, mb, ng, ncs, rho):
         assert (Fo >= 0).all()
         for k in range(p):
             if ng:
-                assert np.linalg.norm(Fo[k, :ng] - r['Fg'][k]) <= 1e-7 * max(1.0, np.linalg.norm(r['Fg'][k]))
+                assert np.linalg.norm(Fo[k, :ng] - r['Fg'][k]) <= PARITY * max(1.0, np.linalg.norm(r['Fg'][k]))
             if ncnt[b, k]:
-                assert np.linalg.norm(Fo[k, ng:ng + ncnt[b, k]] - r['F'][k]) <= 1e-7 * max(1.0, np.linalg.norm(r['F'][k]))
+                assert np.linalg.norm(Fo[k, ng:ng + ncnt[b, k]] - r['F'][k]) <= PARITY * max(1.0, np.linalg.norm(r['F'][k]))
             assert not Fo[k, ng + ncnt[b, k]:].any()
         # the supplement is what convexHessianSuppl builds from (P, Fg, F): convexifier.py:196-201
         Fl = [Fo[k, ng:ng + ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
@@ -418,9 +418,9 @@ def test_step2_golden_vectors(hc, golden_dir, name):
         assert int(out['status'][b]) == int(g['status'][b])
         assert rel(out['Hc'][b], g['Hc'][b]) < PARITY
         assert abs(out['kappa'][b] - g['kappa'][b]) < 1e-9 * max(1.0, g['kappa'][b])
-        assert np.linalg.norm(out['FgF'][b][:, ng:] - g['F'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['F'][b]))
+        assert np.linalg.norm(out['FgF'][b][:, ng:] - g['F'][b]) <= PARITY * max(1.0, np.linalg.norm(g['F'][b]))
         if ng:
-            assert np.linalg.norm(out['FgF'][b][:, :ng] - g['Fg'][b]) <= 1e-7 * max(1.0, np.linalg.norm(g['Fg'][b]))
+            assert np.linalg.norm(out['FgF'][b][:, :ng] - g['Fg'][b]) <= PARITY * max(1.0, np.linalg.norm(g['Fg'][b]))
 
 
 def test_device_resident_constraint_entries_match_host_entries(hc):
@@ -563,7 +563,7 @@ def test_step3_parity_vs_oracle(hc, seed, nb, p, nx, mb, rho):
         assert int(out['status'][b]) == st == 0
         assert rel(out['Hc'][b], H[b] + dHc) < PARITY
         assert abs(out['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
-        assert rel(out['T'][b], r['T']) < 1e-6 and (out['T'][b] > 0).all()
+        assert rel(out['T'][b], r['T']) < PARITY and (out['T'][b] > 0).all()
         # structure of the supplement: Hc - H = sym(calH(P)) + T exactly
         ref = co.convex_hessian_suppl(A[b], B[b], out['P'][b], T=out['T'][b])[0]
         assert rel(out['Hc'][b] - H[b], ref) < 1e-12
@@ -597,13 +597,13 @@ def test_step3_with_constraint_rows_parity(hc, seed, p, nx, mb, ng, ncs, rho):
     dHc = co.convex_hessian_suppl(A[0], B[0], r['P'], G=None if G is None else G[0], Fg=r.get('Fg'), C=Cl, F=r.get('F'), T=r['T'])[0]
     assert rel(out['Hc'][0], H[0] + dHc) < PARITY
     assert abs(out['kappa'][0] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
-    assert rel(out['T'][0], r['T']) < 1e-6 and (out['T'][0] > 0).all()
+    assert rel(out['T'][0], r['T']) < PARITY and (out['T'][0] > 0).all()
     if ng:
-        assert np.abs(out['FgF'][0, :, :ng] - r['Fg']).max() < 1e-7 * max(1.0, np.abs(r['Fg']).max())
+        assert np.abs(out['FgF'][0, :, :ng] - r['Fg']).max() < PARITY * max(1.0, np.abs(r['Fg']).max())
     if ncs:
         for k in range(p):
             if ncs[k]:
-                assert np.abs(out['FgF'][0, k, ng:ng + ncs[k]] - r['F'][k]).max() < 1e-7 * max(1.0, np.abs(r['F'][k]).max())
+                assert np.abs(out['FgF'][0, k, ng:ng + ncs[k]] - r['F'][k]).max() < PARITY * max(1.0, np.abs(r['F'][k]).max())
 
 
 def test_step3_rescues_the_infeasible_vector(golden_dir):
@@ -840,7 +840,7 @@ def test_dual_certificate(hc, seed, nb, p, nx, mb):
         # distance of the returned kappa to the optimum that holds whatever solver produced the point (the reference's solver stops at ~1e-8)
         width = (kappa - (dobj - slack)) / kappa
         print(f'certified relative gap on kappa, p={p} n={nx + mb} member {b}: {width:.3e}  (N tol = {(2 * p * (nx + mb) + 1) * 2.0 ** -25:.3e})')
-        assert width <= 1.1 * (2 * p * (nx + mb) + 1) * 2.0 ** -25
+        assert width <= 1.5 * (2 * p * (nx + mb) + 1) * 2.0 ** -25      # (mu_t is tol * kappa rounded to a power of two: up to sqrt(2) above it)
 
 
 # ----------------------------------------------------------------------------- producer row: sensitivities -> batched inputs
