@@ -189,7 +189,7 @@ int tmpc_eig_scan_host(tmpc_handle* h, int nb, const double* H, double* out);
  *   out[b] = sym(A[b]) + V diag(max(tol - lambda_i, 0)) V',   A, out [nb][n][n], any n >= 1 (no handle, current device).
  * evals [nb][n] (optional): the eigenvalues lambda_i of A[b] (unordered); reg [nb] (optional): the largest lift max_i(tol - lambda_i, 0)
  * (the reference's `self.__reg`); sweeps [nb] (optional): Jacobi sweeps taken.  Returns TMPC_E_NOCONV when 40 sweeps did not
- * orthogonalise the vectors to the rounding level (~2 n eps); the outputs then hold the last iterate. */
+ * orthogonalise the vectors to the rounding level (~2 sqrt(n) eps); the outputs then hold the last iterate. */
 int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, double* evals, double* reg, int32_t* sweeps);
 
 /* Accumulated hipEvent timings since the last call (ms) when TMPC_FLAG_PROFILE is set, 16 doubles:

@@ -1141,7 +1141,8 @@ int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, 
   HIPCHK(hipMemcpy(dA, A, mat * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_eig_init, dim3(nb), dim3(256), 0, 0, dA, dU, dV, dshift, n);
   const int m = (n + 1) & ~1;
-  const double thr = std::max(1e-15, 2.0 * n * 2.220446049250313e-16);     // rotations below the rounding level of an n-long dot product never settle
+  const double thr = std::max(1e-15, 2.0 * sqrt((double)n) * 2.220446049250313e-16);     // ~ the rounding level of an n-long dot product (random-walk bound): smaller rotations never settle;
+                                                                                          // 2 n eps (the worst-case bound) left 2e-9 relative error in the clipped eigenvalues at n = 257
   int sw = 0;
   bool converged = (n == 1);
   std::vector<double> off(nb);
