@@ -255,7 +255,10 @@ __device__ __forceinline__ void vm_wait_le(int n) {
 //     tile would leave one wave idle (in-kernel cycle split of the by-columns form: 58 % of wave 0's time outside the MFMA section).
 // One run-time loop over the slab steps with a branch per accumulator set: the unrolled form (one copy of the step per tile pair) was
 // 97 KB of code, more than the instruction cache.
-constexpr int TRD_DEPTH = 2;                                      // B buffers, each one step = two 16-column slabs
+#ifndef TMPC_TRD_DEPTH
+#define TMPC_TRD_DEPTH 2
+#endif
+constexpr int TRD_DEPTH = TMPC_TRD_DEPTH;                        // B buffers, each one step = two 16-column slabs
 constexpr int trd_lds_doubles() { return 4 * 1024 + TRD_DEPTH * 2048; }       // X_i / T_i as the A operand (four 64 x 16 slabs) + the B steps in flight
 // POTRF: the same sweep as one block row of the Cholesky factorisation of the block itself (k_cr_potrf_dma): X = the row strip r of D,
 // nt = r + 1 tiles, the last one the diagonal tile, whose updates take X_i itself as the second operand (from LDS: no slab stream), and
