@@ -488,6 +488,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     arrows.append(dict(k=k, idx=idx, t=t0, soc=False, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
+    extrap_terms = None
     phase = 0
     ncent = 0
     njam = 0
@@ -703,6 +704,22 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 ad = min(ad, _max_step(np.linalg.inv(np.linalg.cholesky(a['S']))[None], a['dS'][None]))
             return ap, ad
 
+        if phase == 2:
+            # Taylor coefficients of the central path mu -> y(mu) at the centred point, parametrised by t: mu(t) = (1 - t) mu_t.  Order 1 is the
+            # affine-scaling direction; order k >= 2 solves the same system with the right-hand side -sum_{i<k} dX_i dS_{k-i} (the Mehrotra
+            # corrector is its k = 2 term).  One factorisation, one solve per order.  y(t = 1) = sum of the coefficients is the model's limit
+            # point mu -> 0.  Plain model only.  MEASUREMENT ONLY: the product returns the centred point itself.
+            assert not ng, 'extrap: plain model only'
+            terms = [direction(0.0)]
+            c1 = 0.0; c2 = 0.0; c0 = 0.0
+            for k in range(2, o['extrap'] + 1):
+                c1 = c1 + symmetrize(sum(terms[i][5] @ terms[k - 2 - i][3] for i in range(k - 1)) @ S1i)
+                c2 = c2 + symmetrize(sum(terms[i][6] @ terms[k - 2 - i][4] for i in range(k - 1)) @ S2i)
+                c0 = c0 + sum(terms[i][8] * terms[k - 2 - i][7] for i in range(k - 1)) / s0
+                tot = direction(0.0, c1, c2, c0)
+                terms.append(tuple(tot[j] - sum(tm[j] for tm in terms) for j in range(10)))
+            extrap_terms = [(tm[0], tm[1], tm[2]) for tm in terms]          # (dtau_k, dalpha_k, dP_k)
+            break
         if phase == 0:
             dtau, dalpha, dP, dS1, dS2, dX1, dX2, ds0, dx0, dM, dphi, dz = direction(0.0)
             ap, ad = steps(dS1, dS2, dX1, dX2, ds0, dx0, dphi, dz)
@@ -760,6 +777,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             est = stepn * min(1.0, stepn / prev_stepn) ** 1.5 if prev_stepn is not None else stepn
             if full and (stepn < o['center_tol'] or est < 0.1 * o['center_tol']):
                 status = 'optimal'
+                if o.get('extrap', 0):        # measurement hook (tests/tools/path_sensitivity.py): Taylor model of the central path at the returned point
+                    phase = 2
+                    continue
                 break
             if full and prev_stepn is not None and stepn > 0.5 * prev_stepn and stepn < 1e-6:
                 status = 'optimal'        # rounding floor reached
@@ -774,6 +794,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
     Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
     out = dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
                ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
+    if o.get('extrap', 0) and status == 'optimal':
+        out['extrap_terms'] = extrap_terms                  # scaled variables: y(t) = (tau, alpha, Pbar) + sum_k t^k terms[k-1]
+        out['Pbar'] = P
     if ng0:
         out['Fg'] = phi[:, :ng0] / (s * alpha)          # convexifier.py:410 (s_F = s_alpha = s)
     if constr:
