@@ -302,16 +302,16 @@ __device__ __forceinline__ void fmac_bcast16(double& acc, double x, double y) {
   asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(K));
 }
 // Round 3.  The serial 16 x 16 steps were 63 % of the tile Cholesky, which is all but ~30 us of a k_cr_potrf_dma workgroup
-// (profiles/r3_cycle_prof_before.txt), and they are bound by the NUMBER of fp64 VALU instructions the one wave issues (8 cycles each, behind the
-// MFMAs of the workgroup it shares the SIMD with), not by the dependent chain: the first rewrite of this round only removed the dependent
-// forward substitution of the inverse and changed nothing.  So:
+// (profiles/r3_cycle_prof_before.txt), and they are bound by the NUMBER of fp64 VALU instructions the one wave issues (every one of them behind the
+// MFMAs of the workgroup it shares the SIMD with) at least as much as by the dependent chain: the first rewrite of this round only removed
+// the dependent forward substitution of the inverse and changed nothing.  So:
 //  * the inverse is carried along the elimination: M starts as I and every column step applies to M the row operations it applies to A
 //    (rows i > j: M_i -= (l_ij / l_jj) M_j; row r is scaled by 1 / l_rr at the end), so M ends as L^-1 -- no second sweep, no LDS round trip;
 //  * row r of A sits in the lanes r, r + 16, r + 32, r + 48 (mirrored, as before); lane (r, g) holds M[r][4q + g], q = 0..3, so the four lane
 //    groups share the work on M;
 //  * every rank-1 update is ONE instruction, v_fmac_f64 with a DPP row broadcast as its first source (the value of row k of the same lane
 //    group), instead of two v_readlane and an FMA: ~480 instead of ~1100 VALU instructions per 16 x 16 block.
-struct Potrf16State { double a[16]; double m[4]; double nbad, minr, myref, myrinv; int r, g; };
+struct Potrf16State { double a[16]; double m[4]; double nbad, minr, myref, thr8; int r, g; };
 template <int J, int K>
 __device__ __forceinline__ void potrf16_arow(Potrf16State& st, double nlj, double lj) {        // a_rk -= l_rJ l_kJ, k = K .. 15
   if constexpr (K < 16) { fmac_bcast16<K>(st.a[K], nlj, lj); potrf16_arow<J, K + 1>(st, nlj, lj); }
@@ -320,17 +320,16 @@ template <int J, int Q>
 __device__ __forceinline__ void potrf16_mrow(Potrf16State& st, double fr) {                    // M_rc -= (l_rJ / l_JJ) M_Jc, c = 4 q + g <= J (row J is still unscaled)
   if constexpr (Q <= J / 4) { fmac_bcast16<J>(st.m[Q], st.m[Q], fr); potrf16_mrow<J, Q + 1>(st, fr); }
 }
+// One column step.  The wave issues every instruction of it behind the MFMAs of the workgroup it shares the SIMD with, so the step is
+// written for instruction count (the compiler's version of the straightforward code was 58 VALU instructions per step, this one is ~27):
+//  * one comparison against a pre-scaled threshold (1e-8 x reference) guards a wave-uniform slow path that holds everything rare: the
+//    smallest-pivot statistics and the frozen-pivot rule (pivot <= 1e-15 x reference or <= 0: frozen at 1e20 x reference, as in round 1);
+//  * 1/sqrt = v_rsq_f64 (~2^-26) + ONE third-order step r (1 + h/2 + 3 h^2/8), h = 1 - x r^2 (error ~ h^3: full double precision);
+//  * no select for the diagonal entry (a_JJ / sqrt(a_JJ) IS sqrt(a_JJ)), none for 1 / l_rr (read back once at the end).
 template <int J>
 __device__ __forceinline__ void potrf16_step(Potrf16State& st) {
-  // The dependent chain of a step (pivot -> 1/sqrt -> l_rJ -> first update -> next pivot) is what the wave waits on, every link behind the
-  // MFMAs of the workgroup that shares the SIMD: the frozen-pivot rule is evaluated beside the chain (the reciprocal root of the raw pivot is
-  // replaced afterwards by that of the substitute, one select), and 1/sqrt is v_rsq_f64 (~2^-26) + ONE third-order step
-  // r (1 + h/2 + 3 h^2/8), h = 1 - x r^2 (relative error ~ h^3: full double precision), five dependent operations instead of eight.
   const double piv = row_bcast16<J>(st.a[J]);
-  const double ref = row_bcast16<J>(st.myref);
-  const bool bad = !(piv > 1e-15 * ref) || !(piv > 0.0);
-  if (piv < 1e-8 * ref) st.minr = fmin(st.minr, fmax(piv, 0.0) / ref);      // (division only on the rare small pivots)
-  const double sub = (ref > 0.0 ? ref : 1.0) * 1e20;                         // frozen pivot: 1e20 * reference (Cholesky-with-shift, the rule of round 1)
+  const double th8 = row_bcast16<J>(st.thr8);
   double rinv;
   {
     const double r0 = __builtin_amdgcn_rsq(piv);
@@ -338,12 +337,19 @@ __device__ __forceinline__ void potrf16_step(Potrf16State& st) {
     const double c = fma(0.375, h, 0.5), hc = h * c;
     rinv = fma(r0, hc, r0);
   }
-  if (bad) { st.nbad += 1.0; rinv = potrf_rsqrt(sub); }                      // (wave-uniform, rare)
-  const double dj = (bad ? sub : piv) * rinv;
-  const double lj = st.a[J] * rinv;                                       // l_rJ (rows above the diagonal carry unused values)
-  const double nlj = st.a[J] * -rinv;
-  st.a[J] = (st.r == J) ? dj : lj;
-  st.myrinv = (st.r == J) ? rinv : st.myrinv;
+  double lj = st.a[J] * rinv;                                             // l_rJ (rows above the diagonal carry unused values); row J: sqrt(pivot)
+  if (__builtin_amdgcn_ballot_w64(!(piv > th8)) != 0) {                   // wave-uniform (the four lane groups mirror the block), rare
+    const double ref = row_bcast16<J>(st.myref);
+    if (piv < 1e-8 * ref) st.minr = fmin(st.minr, fmax(piv, 0.0) / ref);
+    if (!(piv > 1e-15 * ref) || !(piv > 0.0)) {
+      const double sub = (ref > 0.0 ? ref : 1.0) * 1e20;
+      st.nbad += 1.0;
+      rinv = potrf_rsqrt(sub);
+      lj = (st.r == J) ? sub * rinv : st.a[J] * rinv;
+    }
+  }
+  st.a[J] = lj;
+  const double nlj = -lj;
   const double fr = (st.r > J) ? nlj * rinv : 0.0;
   potrf16_arow<J, J + 1>(st, nlj, lj);
   potrf16_mrow<J, 0>(st, fr);
@@ -356,8 +362,8 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
   for (int k = 0; k < 16; ++k) st.a[k] = S[st.r * LDP + k];
 #pragma unroll
   for (int q = 0; q < 4; ++q) st.m[q] = (4 * q + st.g == st.r) ? 1.0 : 0.0;
-  st.myref = fabs(dr[st.r]);
-  st.nbad = 0.0; st.minr = 1.0; st.myrinv = 1.0;
+  st.myref = fabs(dr[st.r]); st.thr8 = 1e-8 * st.myref;
+  st.nbad = 0.0; st.minr = 1.0;
   __builtin_amdgcn_s_setprio(3);          // the one wave every other wave of the workgroup waits for: ahead of the co-resident workgroup's waves at the issue port
   potrf16_step<0>(st);
   __builtin_amdgcn_s_setprio(0);
@@ -365,8 +371,17 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
 #pragma unroll
     for (int k = 0; k < 16; ++k) if (k <= st.r) S[st.r * LDP + k] = st.a[k];
   }
+  wave_lds_sync();
+  double myrinv;                                                           // 1 / l_rr: v_rcp_f64 + two Newton steps
+  {
+    const double d = S[st.r * LDP + st.r];
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    myrinv = x;
+  }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int c = 4 * q + st.g; Si[st.r * LDP + c] = (c <= st.r) ? st.m[q] * st.myrinv : 0.0; }      // row r of L^-1 = row r of M / l_rr
+  for (int q = 0; q < 4; ++q) { const int c = 4 * q + st.g; Si[st.r * LDP + c] = (c <= st.r) ? st.m[q] * myrinv : 0.0; }      // row r of L^-1 = row r of M / l_rr
   if (lane == 0) { stat[0] += st.nbad; stat[1] = fmin(stat[1], st.minr); }
   wave_lds_sync();
 }
