@@ -121,3 +121,36 @@ def test_shard_range_partitions():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_cache(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tunempc_amd.dist import all_gather_results, shard_range
+    cache = {}
+    out = []
+    for step, nb in enumerate((6, 6, 5, 5)):              # even shards twice, ragged shards twice: the buffers of a shape are allocated once
+        lo, hi = shard_range(nb, rank, world)
+        loc = dict(Hc=(torch.arange(lo, hi, dtype=torch.float64)[:, None] + 100.0 * step).repeat(1, 3).contiguous(),
+                   status=torch.arange(lo, hi, dtype=torch.int32))
+        g = all_gather_results(loc, nb, cache=cache)
+        out.append((g['Hc'].clone().numpy(), g['status'].clone().numpy(), len(cache), [v.data_ptr() for v in cache.values()]))
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_all_gather_results_reuses_its_buffers():
+    """bench.py's serving loop gathers into the same buffers every step (dist.all_gather_results(cache=...)): same values as without a
+    cache, no new allocation for a repeated shape, ragged shards still trimmed."""
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_cache, args=(world, port, ret), nprocs=world, join=True)
+    for rank in range(world):
+        for step, (nb, (Hc, st, ncache, ptrs)) in enumerate(zip((6, 6, 5, 5), ret[rank])):
+            np.testing.assert_array_equal(Hc, (np.arange(nb, dtype=np.float64)[:, None] + 100.0 * step).repeat(3, axis=1))
+            np.testing.assert_array_equal(st, np.arange(nb))
+        assert ret[rank][0][3] == ret[rank][1][3][:len(ret[rank][0][3])]            # second even step: the same buffers
+        assert ret[rank][2][2] == ret[rank][3][2]                                   # second ragged step: nothing new allocated
