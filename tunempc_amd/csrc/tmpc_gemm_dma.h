@@ -152,19 +152,31 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
 #undef TMPC_DMA_MMA
 #undef TMPC_DMA_ISSUE
   if (zf0 && fj < znc) {                                     // yz -= (rows of A) z: lane holds row 16 i + 4 fq + fk, right-hand side fj
+    double yv[4];                                            // (all loads before the first store, as for C below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yv[i] = (i < i1) ? yz[(size_t)(16 * i + 4 * fq + fk) * znc + fj] : 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i < i1) yz[(size_t)(16 * i + 4 * fq + fk) * znc + fj] -= accz[i];
+      if (i < i1) yz[(size_t)(16 * i + 4 * fq + fk) * znc + fj] = yv[i] - accz[i];
   }
   if (wave_on) {
+    typedef double2_t __attribute__((address_space(1)))* gptr2;
+    // C -= ...: all (up to four) fragments of the tile are fetched before the first one is stored.  Written fragment by fragment the
+    // compiler must keep every load behind the previous fragment's store (they may alias): four exposed round trips per tile instead of one.
+    double2_t cu[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int rbase = 16 * i;
+      cu[i][0] = (double2_t){0.0, 0.0}; cu[i][1] = cu[i][0];
+      if (mode == GM_SUB && i >= i0 && i < i1) {
+        gcptr2 cq = (gcptr2)(C + (size_t)(16 * i + 4 * fq + fk) * ldc + wc0 + 4 * fj);
+        cu[i][0] = cq[0]; cu[i][1] = cq[1];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
       if (i >= i0 && i < i1) {
-        typedef double2_t __attribute__((address_space(1)))* gptr2;
-        gptr2 cp = (gptr2)(C + (size_t)(rbase + 4 * fq + fk) * ldc + wc0 + 4 * fj);
-        double2_t u0 = (double2_t){0.0, 0.0}, u1 = u0;
-        if (mode == GM_SUB) { u0 = cp[0]; u1 = cp[1]; }
+        gptr2 cp = (gptr2)(C + (size_t)(16 * i + 4 * fq + fk) * ldc + wc0 + 4 * fj);
+        double2_t u0 = cu[i][0], u1 = cu[i][1];
         if (mode == GM_SET) { u0[0] = acc[i][0]; u0[1] = acc[i][1]; u1[0] = acc[i][2]; u1[1] = acc[i][3]; }
         else { u0[0] -= acc[i][0]; u0[1] -= acc[i][1]; u1[0] -= acc[i][2]; u1[1] -= acc[i][3]; }
         cp[0] = u0; cp[1] = u1;
