@@ -270,6 +270,20 @@ def main():
                                       "note": "tmpc_convexify_batch_host: pageable numpy buffers in, numpy buffers out (H2D of A, B, H and D2H of Hc, dHc, P, "
                                               "scalars inside the timed region); SURVEY.md 8d's host-buffer to host-buffer metric -- never `value`",
                                       "status_optimal": int((oh['status'] == 0).sum())}
+        # the documented non-default option that trades the reproducible point for speed (include/tunempc_hip.h, TMPC_FLAG_FAST_EXIT)
+        from tunempc_amd._lib import FLAG_FAST_EXIT
+        h.set_options(tol=args.tol if args.tol > 0 else None, flags=FLAG_FAST_EXIT)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(ne):
+            step()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        st2 = out['status'].cpu().numpy(); it2 = out['iters'].cpu().numpy()
+        extra_rates["fast_exit_option"] = {"value": nbl * p * ne / e2, "ms_per_step": 1e3 * e2 / ne, "steps": ne,
+                                           "ipm_iterations_mean": float(it2.mean()), "status_optimal": int((st2 == 0).sum()),
+                                           "note": "NOT the headline setting: TMPC_FLAG_FAST_EXIT stops every member after its first full centering step -- feasible, "
+                                                   "kappa within the same gap, but not the converged central-path point (Hc ~1e-3..1e-2 off it, not reproducible to 1e-8)"}
         h.set_options(tol=args.tol if args.tol > 0 else None, flags=FLAG_PROFILE)
 
     if rank == 0:

@@ -54,6 +54,11 @@ extern "C" {
 
 #define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments instead of v_mfma_f64_16x16x4 */
 #define TMPC_FLAG_PROFILE 2      /* record hipEvent timings per phase (tmpc_get_profile)           */
+#define TMPC_FLAG_FAST_EXIT 4    /* stop every problem after its FIRST full centering step instead of converging to the central-path point
+                                    at mu_target: Hc is feasible (positive definite, cond <= kappa), kappa within the same gap N mu_target of
+                                    optimal, the linear residuals are gone -- but the point is within ~1e-2 (relative) of the centred one, not
+                                    at it, so two implementations agree on it to ~1e-3 only, not to 1e-8.  ~2 factorisations fewer per problem.
+                                    Off by default: the default answer is the reproducible one. */
 
 #define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,

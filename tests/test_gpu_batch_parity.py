@@ -247,3 +247,33 @@ def test_identity_family_against_the_known_answer(hc, seed, nb, p, nx, mb):
         print(f'identity family p={p} n={n} member {b}: max|Hc - I| = {err:.2e}, kappa - 1 = {gap:.3e} (N * 2^-25 = {N * 2.0 ** -25:.3e})')
         assert err <= 1e-9
         assert 0.0 <= gap <= 1.5 * N * 2.0 ** -25
+
+
+# ----------------------------------------------------------------------------- the fast-exit option
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(36000, 24, 16, 12, 4), (36100, 8, 64, 24, 8)])
+def test_fast_exit_option(hc, seed, nb, p, nx, mb):
+    """TMPC_FLAG_FAST_EXIT (off by default): every member stops after its first full centering step.  What still holds, asserted here: Optimal
+    status, Hc positive definite with cond(Hc_k) <= kappa, the supplement structure of eq. (18), kappa within the duality gap of the default
+    answer, fewer iterations.  What is given up, measured here: the point is NOT the converged central-path point (Hc differs from the
+    default answer by ~1e-3 .. 1e-2 relative), so it is not reproducible to 1e-8."""
+    from tunempc_amd import synthetic
+    from tunempc_amd._lib import HipConvexifier, FLAG_FAST_EXIT
+    A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
+    ref = hc(p, nx, mb).convexify_batch(A, B, H)
+    h = HipConvexifier(p, nx, mb, flags=FLAG_FAST_EXIT)
+    out = h.convexify_batch(A, B, H)
+    h.close()
+    N = 2 * p * (nx + mb) + 1
+    assert (out['status'] == 0).all() and (ref['status'] == 0).all()
+    assert (out['iters'] < ref['iters']).all()
+    dev = []
+    for b in range(nb):
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-9)
+        dH = co.convex_hessian_suppl(A[b], B[b], out['P'][b])[0]
+        assert rel(out['Hc'][b] - H[b], dH) < 1e-10
+        assert abs(out['kappa'][b] - ref['kappa'][b]) <= 4.0 * N * 2.0 ** -25 * ref['kappa'][b]
+        dev.append(rel(out['Hc'][b], ref['Hc'][b]))
+    assert max(dev) < 0.2
+    print(f'fast exit p={p} n={nx + mb}: iterations {out["iters"].mean():.2f} instead of {ref["iters"].mean():.2f}; Hc differs from the converged point by '
+          f'{min(dev):.1e} .. {max(dev):.1e} (relative Frobenius); kappa by {np.abs(out["kappa"] / ref["kappa"] - 1).max():.1e}')

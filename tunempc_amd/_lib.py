@@ -12,6 +12,7 @@ _LIB = None
 INFO_STRIDE = 16
 FLAG_NO_MFMA = 1
 FLAG_PROFILE = 2
+FLAG_FAST_EXIT = 4      # stop after the first full centering step (see include/tunempc_hip.h): faster, not reproducible to 1e-8
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
 # every symbol declared in include/tunempc_hip.h (the drop-in boundary) ...

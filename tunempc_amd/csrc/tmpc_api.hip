@@ -515,6 +515,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   wall.alist = nullptr;
   Opts o = h->opt;
   if (eq || t3) o.chord_step = 0.0;       // chord steps: plain model only (the stage-local variables keep fresh factorisations)
+  o.fast_exit = (h->flags & TMPC_FLAG_FAST_EXIT) ? 1 : 0;
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
@@ -700,6 +701,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
   { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
+  h->opt.fast_exit = 0;
   h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); TMPC_CHORD=0 disables
   { const char* e = getenv("TMPC_CHORD"); if (e) h->opt.chord_step = atof(e); }
   h->flags = 0;
@@ -745,8 +747,8 @@ int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
-  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) {
-    snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2)", flags);
+  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) {
+    snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2, TMPC_FLAG_FAST_EXIT = 4)", flags);
     return TMPC_E_ARG;
   }
   if (tol > 0) h->opt.tol = tol;

@@ -91,6 +91,8 @@ struct Opts {
   int center_iter;
   double chord_step;   // centering: once a full Newton step could have been this many times longer before leaving the cone (i.e. the
                        // iterate moved by < 1/chord_step in the local norm), the next steps re-use the factorisation; 0 = never
+  int fast_exit;       // TMPC_FLAG_FAST_EXIT: stop after the FIRST full centering step (feasible, kappa within the gap N mu_t of optimal, but
+                       // not the converged central-path point: not reproducible to 1e-8 between implementations)
 };
 
 // Device workspace (all pointers device memory, fp64 row-major)

@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     // factorisation) converges linearly, its remaining error is ~ stepn * r / (1 - r) <= stepn for r <= 1/2
     const double est = was_chord ? stepn : stepn * rr * sqrt(rr);
     bool chord_next = false, full_reset = false;
-    if (full && (stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    if (full && (o.fast_exit || stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     else if (!was_chord && full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting -- or the centering
     // budget is spent -- there is nothing more to gain at this mu_t: back off to the next power of two (hard target), or stop
