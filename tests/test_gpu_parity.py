@@ -117,6 +117,34 @@ def test_block_cyclic_cholesky_solve(hc, p, d):
     assert rel(x, xref) < 1e-12
 
 
+@pytest.mark.parametrize('p,d,dead', [(3, 10, [(0, 3)]), (4, 78, [(1, 0), (1, 77), (3, 40)]), (5, 40, [(2, 17), (2, 18)]), (3, 300, [(0, 150), (2, 299)])])
+def test_block_cholesky_frozen_pivots(hc, p, d, dead):
+    """Cholesky-with-shift of the 16 x 16 pivot blocks (wave_potrf16, the slow path of its column step): a variable whose row and column of
+    the matrix vanish has a zero pivot and a zero pivot reference; the rule of round 1 freezes it (pivot := 1e20), counts it, and leaves
+    the rest of the solve untouched -- the other unknowns equal the dense solve of the system without it, its own comes out ~ 0."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(7 * p + d)
+    D, Cc, T = _spd_cyclic(rng, p, d)
+    for (k, i) in dead:
+        D[k][i, :] = 0.0; D[k][:, i] = 0.0
+        Cc[k][i, :] = 0.0; Cc[(k - 1) % p][:, i] = 0.0
+    rhs = rng.standard_normal((p, d))
+    x, nshift = h.debug_block_solve(D, Cc, rhs)
+    keep = np.ones(p * d, bool)
+    for (k, i) in dead:
+        keep[k * d + i] = False
+    T2 = np.zeros((p * d, p * d))
+    for k in range(p):
+        kn = (k + 1) % p
+        T2[k*d:(k+1)*d, k*d:(k+1)*d] += D[k]
+        T2[k*d:(k+1)*d, kn*d:(kn+1)*d] += Cc[k]; T2[kn*d:(kn+1)*d, k*d:(k+1)*d] += Cc[k].T
+    xref = np.zeros(p * d)
+    xref[keep] = np.linalg.solve(T2[np.ix_(keep, keep)], rhs.ravel()[keep])
+    assert nshift == len(dead)
+    assert np.abs(x.ravel()[~keep]).max() < 1e-15
+    assert rel(x.ravel()[keep], xref[keep]) < 1e-11
+
+
 @pytest.mark.parametrize('n', [1, 2, 4, 5, 15, 30, 32])
 def test_jacobi_eig_scan(hc, n):
     """batched symmetric eigenvalue extremes (pre-check :82, autoScaling :374-401, status :438-440) vs LAPACK."""
