@@ -445,7 +445,8 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
     mark(1);
     if (mf && use_dma && dm.nt <= TRR_NT) {
-      hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), (size_t)trd_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+      static const size_t trsm_lds = [] { const char* e = getenv("TMPC_TRSM_LDS_KB"); const size_t b = (size_t)trd_lds_doubles() * sizeof(double); return (e && (size_t)atoi(e) * 1024 > b) ? (size_t)atoi(e) * 1024 : b; }();   // (experiment: occupancy of the sweep)
+      hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), trsm_lds, st, w, dm, cd, lv.eoff, lv.nelim, count);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
     else hipLaunchKernelGGL((k_cr_trsm<false, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
