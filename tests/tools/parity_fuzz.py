@@ -1,5 +1,5 @@
-"""Randomised parity run (outside pytest): random shapes and seeds, plain Step 1 / Step 1 with G / Step 2 model, HIP path vs the
-oracle.  Prints every member whose status differs or whose Hc differs by more than 1e-8, and the worst error per model.
+"""Randomised parity run (outside pytest): random shapes and seeds, plain Step 1 / Step 1 with G / Step 2 model / Step 2 with the beta-only
+objective (rho = 0) / Step 3 model (n <= 12), HIP path vs the oracle.  Prints every member whose status differs or whose Hc differs by more than 1e-8, and the worst error per model.
 Usage: python tests/tools/parity_fuzz.py [ncases] [seed] [pmax] [nxmax]"""
 import os, sys, json, time
 import numpy as np
@@ -12,7 +12,8 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 pmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 nxmax = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-worst = dict(plain=0.0, G=0.0, step2=0.0); bad = []; count = dict(plain=0, G=0, step2=0)
+MODELS = ('plain', 'G', 'step2', 'beta', 'step3')
+worst = {m: 0.0 for m in MODELS}; bad = []; count = {m: 0 for m in MODELS}
 t0 = time.time()
 for case in range(ncases):
     p = int(rng.integers(1, pmax + 1)); nx = int(rng.integers(1, nxmax + 1)); mb = int(rng.integers(1, 5))      # mb = 0 (a stage block without inputs) is degenerate: kappa* = 1 with both LMIs active everywhere
@@ -31,11 +32,19 @@ for case in range(ncases):
     h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
     outs = dict(plain=h.convexify_batch(A, B, H), G=h.convexify_eq_batch(A, B, H, G),
                 step2=h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, rho))
+    outs['beta'] = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, 0.0)
     h.close()
+    do3 = n <= 12
+    if do3:
+        h3 = HipConvexifier(p, nx, mb, step3=True)
+        outs['step3'] = h3.convexify_step3_batch(A, B, H, rho)
+        h3.close()
     for b in range(nb):
         early = np.linalg.eigvalsh(H[b])[:, 0].min() > 0
         Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
-        for model in ('plain', 'G', 'step2'):
+        for model in MODELS:
+            if model == 'step3' and not do3:
+                continue
             o = outs[model]
             if early:
                 ok = bool(o['info'][b, 13]) and not o['dHc'][b].any()
@@ -46,8 +55,12 @@ for case in range(ncases):
                     r = co.convexify_arrays(A[b], B[b], H[b]); Hc, st = r['Hc'], r['status']
                 elif model == 'G':
                     r = co.convexify_arrays(A[b], B[b], H[b], G=G[b]); Hc, st = r['Hc'], r['status']
+                elif model == 'step3':
+                    r = co.sdp_step1(A[b], B[b], H[b], rho=rho, force=True)
+                    st, dHc = co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], T=r['T'])[:2]
+                    Hc = H[b] + dHc
                 else:
-                    r = co.sdp_step1(A[b], B[b], H[b], G=G[b], C=Cl, rho=rho)
+                    r = co.sdp_step1(A[b], B[b], H[b], G=G[b], C=Cl, rho=rho, cost_free=(model == 'beta'))
                     st, dHc = co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], G=G[b], Fg=r['Fg'], C=Cl, F=r['F'])[:2]
                     Hc = H[b] + dHc
               except np.linalg.LinAlgError as e:
