@@ -17,6 +17,7 @@
 #include "tmpc_schur.h"
 #include "tmpc_factor.h"
 #include "tmpc_cr.h"
+#include "tmpc_cr_small.h"
 #include "tmpc_phi.h"
 #include "tmpc_t3.h"
 #include "tmpc_eig.h"
@@ -389,6 +390,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -402,6 +404,17 @@ static int set_lds_attrs(int device) {
 
 // ---------------------------------------------------------------------------------- block factorisation / solves (tmpc_cr.h)
 static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
+
+// Small blocks (dp = 16): one kernel per factorisation / per solve instead of a launch sequence per level (tmpc_cr_small.h); TMPC_SMALL=0: off
+static bool cr_small_levels(const Dims& dm, const CrSched& sc, CrLevs* out) {
+  static const int small_env = [] { const char* e = getenv("TMPC_SMALL"); return e ? atoi(e) : 1; }();
+  if (!small_env || dm.dp != 16 || (dm.flags & 1) || dm.p > CRS_PMAX || (int)sc.lev.size() > CRS_MAXLEV) return false;
+  if (out) {
+    out->n = (int)sc.lev.size();
+    for (int l = 0; l < out->n; ++l) { out->v[4 * l] = sc.lev[l].eoff; out->v[4 * l + 1] = sc.lev[l].nelim; out->v[4 * l + 2] = sc.lev[l].uoff; out->v[4 * l + 3] = sc.lev[l].nupd; }
+  }
+  return true;
+}
 
 // Cholesky of the block-cyclic-tridiagonal Schur matrices of the `count` problems listed in alist (device), level by level.
 // rs / mt: rows per workgroup of the triangular solves / edge of the output tile of the updates; 0 = by the amount of work
@@ -422,6 +435,16 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   };
   const bool mf = !(dm.flags & 1);
   if (sc.prep) hipLaunchKernelGGL(k_cr_prep, dim3(count), dim3(256), 0, st, w, dm, cd, sc.prep);
+  {
+    CrLevs lv;
+    if (!fuse_fwd1 && cr_small_levels(dm, sc, &lv)) {
+      mark(0);
+      hipLaunchKernelGGL(k_cr_small_factor, dim3(count), dim3(256), (size_t)crs_factor_lds_doubles() * sizeof(double), st, w, dm, cd, lv);
+      mark(0);
+      if (nkev) *nkev = ke;
+      return;
+    }
+  }
   const int nt64 = (dm.dp + 63) / 64;
   for (const CrLevel& lv : sc.lev) {
     // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
@@ -466,6 +489,13 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
 // forward and backward substitution with that factor for the right-hand sides of `pass` (W3 / Z, see cr_nc)
 static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st, int pass, bool skip_fwd = false) {
   const CrDev cd = cr_dev(sc, d_sched, alist);
+  {
+    CrLevs lv;
+    if (!skip_fwd && cr_small_levels(dm, sc, &lv)) {
+      hipLaunchKernelGGL(k_cr_small_solve, dim3(count), dim3(256), (size_t)crs_solve_lds_doubles(dm.p) * sizeof(double), st, w, dm, cd, lv, pass);
+      return;
+    }
+  }
   const size_t lds = solve_lds(dm);
   for (const CrLevel& lv : sc.lev) {
     if (skip_fwd) break;                 // the forward sweep ran inside the factorisation (cr_factor, fuse_fwd1)
@@ -565,7 +595,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     // rides inside it (k_cr_update_dma reads the O blocks anyway): one read of every O block less per main-phase iteration
     static const int fuse_env = [] { const char* e = getenv("TMPC_FUSE_FWD"); return e ? atoi(e) : 1; }();
     static const int dma_env = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();       // (the fused sweep lives in k_cr_update_dma)
-    const bool fuse1 = fuse_env && dma_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1;
+    const bool fuse1 = fuse_env && dma_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && !cr_small_levels(dm, h->sched, nullptr);
     if (fuse1) {
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
