@@ -983,7 +983,7 @@ print('WORST %.3e' % worst)
 
 
 @pytest.mark.parametrize('env', [{'TMPC_FACTOR_DMA': '0'}, {'TMPC_POTRF_DMA': '0'}, {'TMPC_FUSE_FWD': '0', 'TMPC_CHORD': '0'},
-                                 {'TMPC_STAGE_NT': '64'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
+                                 {'TMPC_STAGE_NT': '64'}, {'TMPC_SMALL': '0'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
 def test_kernel_variants_behind_environment_switches(golden_dir, env):
     """The kernel variants behind the environment switches of libtunempc_hip (read once per process: register-staged factorisation
     kernels, left-looking block Cholesky, separate forward sweep without chord steps, one wave per stage) against three golden
@@ -991,7 +991,7 @@ def test_kernel_variants_behind_environment_switches(golden_dir, env):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', _FALLBACK_CODE, root, golden_dir, 'c2_unicycle_shape', 'mid_n16', 'awe_shape_n15'],
+    r = subprocess.run([sys.executable, '-c', _FALLBACK_CODE, root, golden_dir, 'c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'awe_shape_n15'],
                        env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     worst = float(r.stdout.strip().split('WORST')[-1])
