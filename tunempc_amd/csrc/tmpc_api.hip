@@ -391,6 +391,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_small_factor, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -439,7 +440,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     CrLevs lv;
     if (!fuse_fwd1 && cr_small_levels(dm, sc, &lv)) {
       mark(0);
-      hipLaunchKernelGGL(k_cr_small_factor, dim3(count), dim3(256), (size_t)crs_factor_lds_doubles() * sizeof(double), st, w, dm, cd, lv);
+      hipLaunchKernelGGL(k_cr_small_factor, dim3(count), dim3(CRS_NT), (size_t)crs_factor_lds_doubles() * sizeof(double), st, w, dm, cd, lv);
       mark(0);
       if (nkev) *nkev = ke;
       return;
@@ -492,7 +493,7 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
   {
     CrLevs lv;
     if (!skip_fwd && cr_small_levels(dm, sc, &lv)) {
-      hipLaunchKernelGGL(k_cr_small_solve, dim3(count), dim3(256), (size_t)crs_solve_lds_doubles(dm.p) * sizeof(double), st, w, dm, cd, lv, pass);
+      hipLaunchKernelGGL(k_cr_small_solve, dim3(count), dim3(CRS_NT), (size_t)crs_solve_lds_doubles(dm.p) * sizeof(double), st, w, dm, cd, lv, pass);
       return;
     }
   }

@@ -5,7 +5,7 @@
 // microseconds of work, so the level-by-level launch sequence of the batched tile kernels (3 launches per level to factor, 3 to solve:
 // ~1500 launches per solve at p = 30) costs the unicycle-shaped problem 11 ms of launch latency for 7 ms of kernels that are themselves
 // mostly launch ramp (profiles/r3_small_config_kernel_stats.txt).  Here the levels are a loop inside the kernel with workgroup
-// barriers in between; the four waves of the workgroup take the eliminated nodes / update items of a level in turn.  The factor is stored
+// barriers in between; the sixteen waves of the workgroup take the eliminated nodes / update items of a level in turn.  The factor is stored
 // exactly as the batched kernels store it (L in the lower triangle of D, inverted diagonal tile in Linv, O and fill blocks in their
 // edge slots), so everything else -- chord steps, the border solve, the debug entries -- is unchanged, and a result computed on this path
 // differs from the batched one only by rounding (same operations, 16 x 16 MFMA products instead of 64 x 64 tiles).
@@ -20,33 +20,36 @@ constexpr int CRS_MAXLEV = 24;           // levels of the schedule passed by val
 constexpr int CRS_PMAX = 160;            // right-hand sides of a whole problem live in LDS (vectors + scratch: 2 * p * 16 * 3 doubles = 123 KB at p = 160)
 struct CrLevs { int n; int v[4 * CRS_MAXLEV]; };          // (eoff, nelim, uoff, nupd) per level
 
-constexpr int crs_factor_lds_doubles() { return 4 * (2 * 16 * LDP + 8); }      // per wave: S, Si (16 x LDP each), two statistics
-__global__ void __launch_bounds__(256) k_cr_small_factor(WS w, Dims dm, CrDev cr, CrLevs lv) {
+constexpr int CRS_NW = 16;               // waves per workgroup: a level of p = 30 (15 eliminated nodes) is one round; 1024 threads
+constexpr int CRS_NT = 64 * CRS_NW;
+constexpr int CRS_LD = 17;               // leading dimension of the 16 x 16 images in LDS
+constexpr int crs_factor_lds_doubles() { return CRS_NW * (2 * 16 * CRS_LD + 8); }      // per wave: S, Si, two statistics
+__global__ void __launch_bounds__(CRS_NT) k_cr_small_factor(WS w, Dims dm, CrDev cr, CrLevs lv) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = cr.alist[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int dp = 16;
   const size_t bs = (size_t)dp * dp;
-  double* S = lds + wv * (2 * 16 * LDP + 8);
-  double* Si = S + 16 * LDP;
-  double* stat = Si + 16 * LDP;                          // [0] frozen pivots, [1] smallest pivot / reference of this wave's nodes
+  double* S = lds + wv * (2 * 16 * CRS_LD + 8);
+  double* Si = S + 16 * CRS_LD;
+  double* stat = Si + 16 * CRS_LD;                          // [0] frozen pivots, [1] smallest pivot / reference of this wave's nodes
   if (lane == 0) { stat[0] = 0.0; stat[1] = 1.0; }
   for (int l = 0; l < lv.n; ++l) {
     const int eoff = lv.v[4 * l], nelim = lv.v[4 * l + 1], uoff = lv.v[4 * l + 2], nupd = lv.v[4 * l + 3];
     // ---- eliminated nodes: D_i = L_i L_i', L_i^-1, and O_x <- T[x,i] L_i^-T for the (up to) two neighbours; one wave per node
-    for (int j = wv; j < nelim; j += 4) {
+    for (int j = wv; j < nelim; j += CRS_NW) {
       const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
       const int node = er[CE_NODE];
       double* Dk = w.D + ((size_t)b * dm.p + node) * bs;
       double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
       const double* dref = w.Ddiag + ((size_t)b * dm.p + node) * dp;
-      for (int e = lane; e < 256; e += 64) { const int i = e >> 4, c = e & 15; S[i * LDP + c] = Dk[e]; Si[i * LDP + c] = 0.0; }
+      for (int e = lane; e < 256; e += 64) { const int i = e >> 4, c = e & 15; S[i * CRS_LD + c] = Dk[e]; Si[i * CRS_LD + c] = 0.0; }
       wave_lds_sync();
-      wave_potrf16(S, Si, dref, stat, lane);
+      wave_potrf16<CRS_LD>(S, Si, dref, stat, lane);
       for (int e = lane; e < 256; e += 64) {
         const int i = e >> 4, c = e & 15;
-        if (c <= i) Dk[e] = S[i * LDP + c];
-        Li[i * TB + c] = Si[i * LDP + c];
+        if (c <= i) Dk[e] = S[i * CRS_LD + c];
+        Li[i * TB + c] = Si[i * CRS_LD + c];
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -54,14 +57,14 @@ __global__ void __launch_bounds__(256) k_cr_small_factor(WS w, Dims dm, CrDev cr
         if (slot < 0) continue;
         double* X = cr_edge(w, dm, b, slot);
         double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-        acc = mm16(X, dp, Si, 1, LDP, acc, 1.0, lane);     // (X L^-T)[r][c] = sum_k X[r][k] Linv[c][k]
+        acc = mm16(X, dp, Si, 1, CRS_LD, acc, 1.0, lane);     // (X L^-T)[r][c] = sum_k X[r][k] Linv[c][k]
         store_d16(X, dp, acc, lane);
       }
     }
     __threadfence_block();
     __syncthreads();
     // ---- surviving neighbours D_s -= O_s O_s' (one or two eliminated neighbours) and the fill edges T[x,y] (=|-=) -O_x O_y'
-    for (int it = wv; it < nupd + nelim; it += 4) {
+    for (int it = wv; it < nupd + nelim; it += CRS_NW) {
       if (it < nupd) {
         const int* ur = cr.upd + (size_t)(uoff + it) * CR_UW;
         double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs;
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(256) k_cr_small_factor(WS w, Dims dm, CrDev cr
 // The vectors of the whole problem sit in LDS ([p][16][nc], as in memory); every (node, row, right-hand side) entry of a level is one
 // thread's 16-long dot product against a block read from L2.
 constexpr int crs_solve_lds_doubles(int p) { return 2 * p * 16 * 3 + 16; }
-__global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr, CrLevs lv, int pass) {
+__global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev cr, CrLevs lv, int pass) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = cr.alist[blockIdx.x];
   const int nc = cr_nc(w, b, pass);
@@ -106,12 +109,12 @@ __global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr,
   double* z = lds;                                        // [p][16][nc]
   double* t = lds + (size_t)p * dp * 3;                   // scratch of the same shape
   double* R = cr_rhs(w, dm, b, 0, nc);
-  for (int e = tid; e < nz; e += 256) z[e] = R[e];
+  for (int e = tid; e < nz; e += CRS_NT) z[e] = R[e];
   __syncthreads();
   // ---- forward, level by level: z_i <- L_i^-1 z_i for the eliminated nodes, then z_s -= O_s z_i for their surviving neighbours
   for (int l = 0; l < lv.n; ++l) {
     const int eoff = lv.v[4 * l], nelim = lv.v[4 * l + 1], uoff = lv.v[4 * l + 2], nupd = lv.v[4 * l + 3];
-    for (int e = tid; e < nelim * dp * nc; e += 256) {
+    for (int e = tid; e < nelim * dp * nc; e += CRS_NT) {
       const int j = e / (dp * nc), rq = e - j * (dp * nc), r = rq / nc, q = rq - r * nc;
       const int node = cr.elim[(size_t)(eoff + j) * CR_EW + CE_NODE];
       const double* Li = w.Linv + ((size_t)b * p + node) * dm.nt * TB * TB + r * TB;
@@ -121,13 +124,13 @@ __global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr,
       t[e] = acc;
     }
     __syncthreads();
-    for (int e = tid; e < nelim * dp * nc; e += 256) {
+    for (int e = tid; e < nelim * dp * nc; e += CRS_NT) {
       const int j = e / (dp * nc), rq = e - j * (dp * nc);
       const int node = cr.elim[(size_t)(eoff + j) * CR_EW + CE_NODE];
       z[(size_t)node * dp * nc + rq] = t[e];
     }
     __syncthreads();
-    for (int e = tid; e < nupd * dp * nc; e += 256) {
+    for (int e = tid; e < nupd * dp * nc; e += CRS_NT) {
       const int j = e / (dp * nc), rq = e - j * (dp * nc), r = rq / nc, q = rq - r * nc;
       const int* ur = cr.upd + (size_t)(uoff + j) * CR_UW;
       double acc = z[(size_t)ur[CU_NODE] * dp * nc + rq];
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr,
   // ---- backward, levels in reverse: z_i <- L_i^-T (z_i - O_a' z_a - O_b' z_b)
   for (int l = lv.n - 1; l >= 0; --l) {
     const int eoff = lv.v[4 * l], nelim = lv.v[4 * l + 1];
-    for (int e = tid; e < nelim * dp * nc; e += 256) {
+    for (int e = tid; e < nelim * dp * nc; e += CRS_NT) {
       const int j = e / (dp * nc), rq = e - j * (dp * nc), r = rq / nc, q = rq - r * nc;
       const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
       double acc = z[(size_t)er[CE_NODE] * dp * nc + rq];
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr,
       t[e] = acc;
     }
     __syncthreads();
-    for (int e = tid; e < nelim * dp * nc; e += 256) {
+    for (int e = tid; e < nelim * dp * nc; e += CRS_NT) {
       const int j = e / (dp * nc), rq = e - j * (dp * nc), r = rq / nc, q = rq - r * nc;
       const int node = cr.elim[(size_t)(eoff + j) * CR_EW + CE_NODE];
       const double* Li = w.Linv + ((size_t)b * p + node) * dm.nt * TB * TB + r;      // column r of L^-1
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(256) k_cr_small_solve(WS w, Dims dm, CrDev cr,
     }
     __syncthreads();
   }
-  for (int e = tid; e < nz; e += 256) R[e] = z[e];
+  for (int e = tid; e < nz; e += CRS_NT) R[e] = z[e];
 }
 
 }  // namespace tmpc

@@ -355,11 +355,12 @@ __device__ __forceinline__ void potrf16_step(Potrf16State& st) {
   potrf16_mrow<J, 0>(st, fr);
   if constexpr (J + 1 < 16) potrf16_step<J + 1>(st);
 }
+template <int LDQ = LDP>                                     // leading dimension of S and Si (tmpc_cr_small.h packs them tighter)
 __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double* dr, double* stat, int lane) {
   Potrf16State st;
   st.r = lane & 15; st.g = lane >> 4;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) st.a[k] = S[st.r * LDP + k];
+  for (int k = 0; k < 16; ++k) st.a[k] = S[st.r * LDQ + k];
 #pragma unroll
   for (int q = 0; q < 4; ++q) st.m[q] = (4 * q + st.g == st.r) ? 1.0 : 0.0;
   st.myref = fabs(dr[st.r]); st.thr8 = 1e-8 * st.myref;
@@ -369,19 +370,19 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
   __builtin_amdgcn_s_setprio(0);
   if (lane < 16) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (k <= st.r) S[st.r * LDP + k] = st.a[k];
+    for (int k = 0; k < 16; ++k) if (k <= st.r) S[st.r * LDQ + k] = st.a[k];
   }
   wave_lds_sync();
   double myrinv;                                                           // 1 / l_rr: v_rcp_f64 + two Newton steps
   {
-    const double d = S[st.r * LDP + st.r];
+    const double d = S[st.r * LDQ + st.r];
     double x = __builtin_amdgcn_rcp(d);
     x = fma(fma(-d, x, 1.0), x, x);
     x = fma(fma(-d, x, 1.0), x, x);
     myrinv = x;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int c = 4 * q + st.g; Si[st.r * LDP + c] = (c <= st.r) ? st.m[q] * myrinv : 0.0; }      // row r of L^-1 = row r of M / l_rr
+  for (int q = 0; q < 4; ++q) { const int c = 4 * q + st.g; Si[st.r * LDQ + c] = (c <= st.r) ? st.m[q] * myrinv : 0.0; }      // row r of L^-1 = row r of M / l_rr
   if (lane == 0) { stat[0] += st.nbad; stat[1] = fmin(stat[1], st.minr); }
   wave_lds_sync();
 }
