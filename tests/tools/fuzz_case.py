@@ -1,5 +1,5 @@
 """Replays one case of parity_fuzz.py (same random stream) and prints the GPU traces and the oracle's of one member/model.
-Usage: python tests/tools/fuzz_case.py <case> <member> <model> [seed]"""
+Usage: python tests/tools/fuzz_case.py <case> <member> <model> [seed] [pmax] [nxmax]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,8 +8,10 @@ import convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier
 want, bsel, model = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 rng = np.random.default_rng(int(sys.argv[4]) if len(sys.argv) > 4 else 2024)
+pmax = int(sys.argv[5]) if len(sys.argv) > 5 else 12
+nxmax = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 for case in range(want + 1):
-    p = int(rng.integers(1, 13)); nx = int(rng.integers(1, 9)); mb = int(rng.integers(1, 5))
+    p = int(rng.integers(1, pmax + 1)); nx = int(rng.integers(1, nxmax + 1)); mb = int(rng.integers(1, 5))
     n = nx + mb
     ng = int(rng.integers(1, 4)); nc = int(rng.integers(1, 5))
     seed = int(rng.integers(0, 10 ** 6))
@@ -41,5 +43,8 @@ t = []
 Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
 r = co.sdp_step1(A[b], B[b], H[b], trace=t, G=None if model == 'plain' else G[b], C=Cl if model == 'step2' else None, rho=rho if model == 'step2' else None)
 print('oracle', r['ipm_status'], 'iters', r['iters'], 'kappa', r['kappa'], 'shift', r['shift'])
+if model == 'plain':
+    Hco = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'])[0]
+    print('rel. Frobenius error of Hc, GPU vs oracle: %.3e' % (np.linalg.norm(o['Hc'][b] - Hco) / np.linalg.norm(Hco)))
 for x in t:
     print('  it %2d ph %d mu %.3e tau %.8f pinf %.2e dinf %.2e' % (x['it'] + 1, x['phase'], x['mu'], x['tau'], x['pinf'], x['dinf']))

@@ -32,7 +32,7 @@ enum {
   P_TAU = 0, P_ALPHA, P_S0, P_X0, P_MU, P_MUT, P_SIGMU, P_AP, P_AD, P_S, P_SBETA, P_PINF, P_DINF, P_RELGAP,
   P_STEPN, P_PREVSTEPN, P_DTAU, P_DALPHA, P_DS0, P_DX0, P_RD0, P_CORR0, P_MINEIG_H, P_BTT, P_BTA, P_BAA,
   P_SB00, P_SB01, P_SB11, P_RHS_TAU, P_RHS_ALPHA, P_SXS, P_MINEIG_HC, P_MAXCOND, P_KAPPA, P_BETA, P_ALPHA_OUT,
-  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, P_PREVCHORD, PS = 48
+  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
 enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF, IS = 16 };   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)

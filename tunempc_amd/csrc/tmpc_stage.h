@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
     pr[P_S] = s; pr[P_SBETA] = sbeta; pr[P_MINEIG_H] = lo;
     // everything O(1) from the start: alpha*Hb has eigenvalues in [-1, 1], S2 = tau*I - alpha*Hb in [1, 3]
     pr[P_TAU] = 2.0; pr[P_ALPHA] = 1.0 / sbeta; pr[P_S0] = 1.0 / sbeta; pr[P_X0] = 1.0 / (double)(dm.p * dm.n);
-    pr[P_MUT] = -1.0; pr[P_PREVSTEPN] = -1.0; pr[P_STEPN] = 1e300; pr[P_MINPIV] = 1.0; pr[P_PREVCHORD] = 0.0;
+    pr[P_MUT] = -1.0; pr[P_PREVSTEPN] = -1.0; pr[P_STEPN] = 1e300; pr[P_MINPIV] = 1.0;
     const int early = (lo > 0.0) ? 1 : 0;          // convexifier.py:83
     ip[I_EARLY] = early;
     ip[I_PHASE] = early ? PH_DONE : PH_MAIN;
