@@ -599,10 +599,14 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     // rides inside it (k_cr_update_dma reads the O blocks anyway): one read of every O block less per main-phase iteration
     static const int fuse_env = [] { const char* e = getenv("TMPC_FUSE_FWD"); return e ? atoi(e) : 1; }();
     static const int dma_env = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();       // (the fused sweep lives in k_cr_update_dma)
-    const bool fuse1 = fuse_env && dma_env && !eq && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && !cr_small_levels(dm, h->sched, nullptr);
+    // (round 3: also with the multipliers of G / C -- their right-hand side rows depend on the iterate only, like the others; not with Step 3)
+    static const int fuse_eq_env = [] { const char* e = getenv("TMPC_FUSE_FWD_EQ"); return e ? atoi(e) : 1; }();
+    const bool fuse1 = fuse_env && dma_env && (!eq || fuse_eq_env) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
     if (fuse1) {
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
+      if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
@@ -611,10 +615,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);
       if (!fused) TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
+      if (eq && !fused) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (!fused) hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
+      if (eq && !fused) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, fused);
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
