@@ -18,11 +18,18 @@ for name, nb, p, nx, mb in cfgs:
     h = HipConvexifier(p, nx, mb, flags=FLAG_PROFILE)
     h.convexify_batch(A, B, H)          # warm-up
     h.profile()
-    t = time.perf_counter(); o = h.convexify_batch(A, B, H); dt = time.perf_counter() - t
+    # short solves (tens of milliseconds) see the clock ramp of an idle part: repeat and keep the median (the minimum is printed as well)
+    reps = 1 if nb * p > 20000 else 7
+    dts = []
+    for _ in range(reps):
+        t = time.perf_counter(); o = h.convexify_batch(A, B, H); dts.append(time.perf_counter() - t)
+    dt = float(np.median(dts))
     pr = h.profile()
+    for k_ in ('factor_ms', 'factor_launches'):
+        pr[k_] = pr[k_] / reps
     ev = np.linalg.eigvalsh(o['Hc'])
     ok = bool((ev.min(-1) > 0).all() and ((ev[..., -1] / ev[..., 0]).max(-1) <= o['kappa'] * (1 + 1e-9)).all())
-    rec = dict(config=name, batch=nb, p=p, nx=nx, m=mb, seconds_host_to_host=dt, stage_conv_per_s=nb * p / dt,
+    rec = dict(config=name, batch=nb, p=p, nx=nx, m=mb, seconds_host_to_host=dt, seconds_min=float(min(dts)), repetitions=reps, stage_conv_per_s=nb * p / dt,
                iters_max=int(o['iters'].max()), iters_mean=float(o['iters'].mean()), status=np.bincount(o['status'], minlength=3).tolist(),
                invariants_ok=ok, factor_ms_per_iter=pr['factor_ms'] / max(pr['factor_launches'], 1))
     print(json.dumps(rec)); out.append(rec)

@@ -729,7 +729,10 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   // lanes: one by default -- measured on MI355X (profiles/r2b_lanes.txt), two or four concurrent half-waves gain nothing at the
   // bench shape (6445 / 6526 / 6399 stage-conv/s with 1 / 2 / 4 lanes): every kernel of the loop already fills the chip, so the
   // streams time-share instead of overlapping.  TMPC_LANES=n turns them on (latency-bound small batches may still profit).
-  int nl = 1;
+  // Round 3: problems whose Schur blocks are a single tile (dp <= 64: every example of the reference) are latency-bound per launch, and two
+  // lanes overlap the launch ramps of one half-wave with the kernels of the other: +8 ... +10 % at the AWE and evaporation shapes with
+  // batches of 64 / 256 (repeat-timed scripts/config_sweep.py), nothing to gain at batch 1.
+  int nl = (make_dims(1, p, nx, mb, ng, nc, step3).dp <= 64 && chunk >= 2) ? 2 : 1;
   { const char* e = getenv("TMPC_LANES"); if (e && atoi(e) >= 1) nl = std::min(atoi(e), MAXL); }
   nl = std::max(1, std::min(nl, chunk));
   h->nlanes = nl;
