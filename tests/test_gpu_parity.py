@@ -517,6 +517,36 @@ def test_step2_dropin_takes_over_when_step1_is_infeasible(golden_dir):
         convexifier.convexify(*args, C=Cr, opts={'rho': float(g['rho'])})        # stage 1 keeps R < 0 without its constraint
 
 
+@pytest.mark.parametrize('seed,p,nx,mb,gam', [(61, 3, 3, 2, 50.0), (62, 4, 4, 2, 50.0), (63, 2, 3, 1, 20.0)])
+def test_step2_dropin_beta_only_objective(seed, p, nx, mb, gam):
+    """opts={'objective': 'beta'}: the other reading of convexifier.py:276-285 through the drop-in.  The stage Hessians of a feasible problem
+    are made indefinite along ragged constraint rows, H_k -= gamma C_k' C_k, so that Step 1 is infeasible and Step 2 has to find
+    F_k ~ gamma: the drop-in with cost-free multipliers against the oracle's cost_free model; the paper's objective can only give a larger
+    condition number; with 'force' the drop-in refuses (a cost-free T_k has no counterpart); unknown values raise."""
+    from tunempc_amd import convexifier
+    A, B, H = co.gen_batch(seed, 1, p, nx, mb)
+    A, B, H = A[0], B[0], H[0].copy()
+    rng = np.random.default_rng(seed + 1)
+    C = [rng.standard_normal((1 if k % 2 else 2, nx + mb)) for k in range(p)]
+    for k in range(p):
+        H[k] -= gam * C[k].T @ C[k]
+    lst = lambda a: [a[k] for k in range(p)]
+    args = (lst(A), lst(B), [H[k][:nx, :nx] for k in range(p)], [H[k][nx:, nx:] for k in range(p)], [H[k][:nx, nx:] for k in range(p)])
+    with pytest.raises(ValueError, match='Convexification is not possible'):
+        convexifier.convexify(*args)                                           # Step 1 alone cannot do it
+    dHc = convexifier.convexify(*args, C=C, opts={'objective': 'beta'})[0]
+    r = co.sdp_step1(A, B, H, C=C, cost_free=True)
+    ref = co.convex_hessian_suppl(A, B, r['P'], C=C, F=r['F'])[0]
+    assert r['ipm_status'] == 'optimal' and rel(H + np.stack(dHc), H + ref) < PARITY
+    paper = convexifier.convexify(*args, C=C, opts={'rho': 1e-3})[0]
+    cond = lambda d: (lambda ev: (ev[:, -1] / ev[:, 0]).max())(np.linalg.eigvalsh(H + np.stack(d)))
+    assert cond(dHc) <= cond(paper) * (1 + 1e-6)
+    with pytest.raises(ValueError, match='unknown objective'):
+        convexifier.convexify(*args, C=C, opts={'objective': 'gamma'})
+    with pytest.raises(NotImplementedError, match='beta'):
+        convexifier.convexify(*args, C=[None] * p, opts={'objective': 'beta', 'force': True})    # no active rows at all: still infeasible after Step 2
+
+
 # ----------------------------------------------------------------------------- reference-compatible API
 def test_dropin_convexify_lqr_example():
     """examples/convex_lqr.py through the drop-in API: same call, same return structure, same assertion (:58)."""
