@@ -523,8 +523,21 @@ __device__ __forceinline__ void trd_strip(double* X, const double* Dk, const dou
     else { TRD_PARK_C(acc3) TRD_ZERO(acc3) }
     TMPC_TC(2, 4)
   }
-  if (POTRF) {                                              // D_rr - sum_i X_i X_i' back in place (set 0 holds its negative)
-    TRD_STORE_R(nlast, ncl, acc0, -)
+  if (POTRF) {                                              // D_rr - sum_i X_i X_i' (set 0 holds its negative) straight into the LDS image of the tile Cholesky
+    // (round 3: it used to go back to memory and be re-read by wg_potrf_inv one barrier later -- a store-to-load round trip through L2 per
+    // tile, ~10 k of the ~95 k cycles of a tile).  Every wave has passed the barrier behind the last product that read the A operand, the
+    // image (64 x LDP from the start of the LDS block) may overwrite it.
+    if (rw) {
+      double* Simg = lds;
+      const int row = wc0 + 4 * fq + fk;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < ncl) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Simg[row * LDP + 16 * c + 4 * fj + e] = -acc0[c][e];
+        }
+      }
+    }
   }
 #undef TRD_DIAG
 #undef TRD_PAIR_RL
@@ -586,9 +599,9 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf_dma(WS w, Dims dm, CrDev cr
     const int r0 = 64 * r, nb = (dp - r0 < 64) ? dp - r0 : 64;
     if (r > 0) {
       trd_strip<true>(Dk + (size_t)r0 * dp, Dk, Li, nb, r + 1, dp, it, lds);
-      __syncthreads();                                      // the tile is in memory, every wave is done with the slabs in LDS
+      __syncthreads();                                      // the tile is in its LDS image, every wave is done with the slabs in LDS
     }
-    wg_potrf_inv(Dk + (size_t)r0 * dp + r0, dp, Li + (size_t)r * TB * TB, dref + r0, nb, lds, nullptr, stat, (it >> 5) & 3);
+    wg_potrf_inv(Dk + (size_t)r0 * dp + r0, dp, Li + (size_t)r * TB * TB, dref + r0, nb, lds, nullptr, stat, (it >> 5) & 3, r > 0);
   }
   if (threadIdx.x == 0) {
     const int nbad = (int)stat[0];

@@ -390,7 +390,8 @@ __device__ __forceinline__ void wave_potrf16(double* S, double* Si, const double
 // Cholesky of the nb x nb diagonal tile at T (ld = ldt; nb a multiple of 16, <= 64) + its inverse into Ti (nb x nb, ld = TB).
 // dref: assembled diagonal entries (pivot reference).  Returns the number of frozen pivots (thread-uniform).
 // stat (optional, LDS): [0] += frozen pivots, [1] = min(itself, smallest pivot ratio) instead of *minr
-__device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr, double* stat = nullptr, int sw = 0) {
+// preloaded: the tile already sits in the LDS image S (k_cr_potrf_dma: the sweep of its block row leaves it there instead of sending it through memory)
+__device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const double* dref, int nb, double* lds, double* minr, double* stat = nullptr, int sw = 0, bool preloaded = false) {
   // sw: the wave that runs the serial 16 x 16 steps
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   TMPC_TC0()
@@ -402,12 +403,16 @@ __device__ __noinline__ int wg_potrf_inv(double* T, int ldt, double* Ti, const d
     const int i = tid >> 2, j0 = (tid & 3) * 16;
     double2_t v[8];
     const bool on = i < nb && j0 < nb;
-    if (on) {
+    if (on && !preloaded) {
       gcptr2 src = (gcptr2)(T + (size_t)i * ldt + j0);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = src[q];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { S[i * LDP + j0 + 2 * q] = v[q][0]; S[i * LDP + j0 + 2 * q + 1] = v[q][1]; Si[i * LDP + j0 + 2 * q] = 0.0; Si[i * LDP + j0 + 2 * q + 1] = 0.0; }
+      for (int q = 0; q < 8; ++q) { S[i * LDP + j0 + 2 * q] = v[q][0]; S[i * LDP + j0 + 2 * q + 1] = v[q][1]; }
+    }
+    if (on) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { Si[i * LDP + j0 + 2 * q] = 0.0; Si[i * LDP + j0 + 2 * q + 1] = 0.0; }
     }
   }
   if (tid < nb) dr[tid] = dref[tid];
