@@ -1013,10 +1013,10 @@ print('WORST %.3e' % worst)
 
 
 @pytest.mark.parametrize('env', [{'TMPC_FACTOR_DMA': '0'}, {'TMPC_POTRF_DMA': '0'}, {'TMPC_FUSE_FWD': '0', 'TMPC_CHORD': '0'},
-                                 {'TMPC_STAGE_NT': '64'}, {'TMPC_SMALL': '0'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
+                                 {'TMPC_STAGE_NT': '64'}, {'TMPC_SMALL': '0'}, {'TMPC_EIG_PRETEST': '0'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
 def test_kernel_variants_behind_environment_switches(golden_dir, env):
     """The kernel variants behind the environment switches of libtunempc_hip (read once per process: register-staged factorisation
-    kernels, left-looking block Cholesky, separate forward sweep without chord steps, one wave per stage) against three golden
+    kernels, left-looking block Cholesky, separate forward sweep without chord steps, one wave per stage, every step-length eigenvalue computed) against three golden
     vectors, each variant in a process of its own."""
     import subprocess
     import sys

@@ -509,6 +509,8 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
   }
 }
 
+// TMPC_EIG_PRETEST=0: k_eigmin computes every eigenvalue (round 2)
+static const int g_eig_pretest = [] { const char* e = getenv("TMPC_EIG_PRETEST"); return e ? atoi(e) : 1; }();
 // the per-stage kernels of the plain model run with four waves per stage (TMPC_STAGE_NT=64: one wave, the original form)
 static const int g_stage_nt = [] { const char* e = getenv("TMPC_STAGE_NT"); return (e && atoi(e) == 64) ? 64 : 256; }();
 #define TMPC_STAGE_LAUNCH(K, LDSB, ST, ...)                                                          \
@@ -625,7 +627,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
-      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass);
+      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, g_eig_pretest ? o.chord_step : -1.0);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (pass == 1) {
@@ -772,6 +774,11 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
 
 int tmpc_destroy(tmpc_handle* h) {
   if (!h) return TMPC_E_ARG;
+#ifdef TMPC_EIG_DEBUG
+  { int c[4]; double v[8]; hipDeviceSynchronize(); hipMemcpyFromSymbol(c, HIP_SYMBOL(g_eig_dbg), sizeof c); hipMemcpyFromSymbol(v, HIP_SYMBOL(g_eig_dbgv), sizeof v);
+    fprintf(stderr, "eig pretest: passed %d (wrong %d: lambda %.6e theta %.6f pass %g phase %g)  failed %d (wrong %d: lambda %.6e theta %.6f pass %g phase %g)\n",
+            c[0], c[1], v[0], v[1], v[2], v[3], c[2], c[3], v[4], v[5], v[6], v[7]); }
+#endif
   for (int l = 0; l < MAXL; ++l) {
     Lane& ln = h->lane[l];
     for (int i = 0; i < 8; ++i) if (ln.ev[i]) hipEventDestroy(ln.ev[i]);

@@ -25,6 +25,9 @@ __device__ int g_prof_cls;
 constexpr double ALPHA_MIN = 1e-8;     // reference: convexifier.py:245  (alpha > 1e-8)
 constexpr int TRACE_LEN = 80, TRACE_W = 10;
 constexpr int TB = 64;                 // tile size of the d x d block factorisation (potrf / trsm granularity)
+#ifndef TMPC_CENTER_DAMP
+#define TMPC_CENTER_DAMP 0.95      // damping of the raw step length in the centering phase (k_ctrl_c; k_eigmin's pre-test threshold)
+#endif
 constexpr int EIG_MAX_SWEEPS = 40;     // tmpc_eig_clip_host: Jacobi sweeps before TMPC_E_NOCONV
 
 // ---- per-problem double scalars (prob[b*PS + idx])

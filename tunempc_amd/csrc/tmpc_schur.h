@@ -323,9 +323,6 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     const double gam = 0.9 + 0.09 * fmin(mn, 1.0);
     ap = fmin(1.0, gam * ap); ad = fmin(1.0, gam * ad);
   } else {
-#ifndef TMPC_CENTER_DAMP
-#define TMPC_CENTER_DAMP 0.95
-#endif
     ap = fmin(1.0, TMPC_CENTER_DAMP * ap); ad = fmin(1.0, TMPC_CENTER_DAMP * ad);
   }
   bool retry = false;

@@ -306,6 +306,37 @@ __device__ __forceinline__ int chol_lower(double* A, int n, int lane) {
   return nbad;
 }
 
+// Is I + theta W positive definite?  (W symmetric n x n in LDS, destroyed; wave-uniform answer.)  The same Crout sweep as chol_lower on the
+// shifted matrix, leaving at the first non-positive pivot.  k_eigmin asks this before it computes an eigenvalue: a step length is
+// only needed exactly when the step is SHORT (lambda_min(W) <= -1 / theta); a long one is clipped to 1 anyway.
+__device__ __forceinline__ bool shifted_is_pd(double* A, double theta, int n, int lane) {
+  const int row = lane & 31, half = lane >> 5;
+  const bool mine = row < n;
+  for (int e = lane; e < n * n; e += 64) { int i, j; ediv(e, n, i, j); A[i * LD + j] = theta * A[i * LD + j] + (i == j ? 1.0 : 0.0); }
+  wsync();
+  for (int j = 0; j < n; ++j) {
+    double acc = 0.0;
+    if (mine && row >= j) {
+      const double* li = A + row * LD;
+      const double* lj = A + j * LD;
+      double a0 = 0.0, a1 = 0.0;
+      int k = half;
+      for (; k + 2 < j; k += 4) { a0 = fma(li[k], lj[k], a0); a1 = fma(li[k + 2], lj[k + 2], a1); }
+      for (; k < j; k += 2) a0 = fma(li[k], lj[k], a0);
+      acc = a0 + a1;
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    double sij = 0.0;
+    if (mine && row >= j) sij = A[row * LD + j] - acc;
+    const double piv = wave_bcast(sij, j);
+    if (!(piv > 0.0)) return false;                        // (wave-uniform: every lane holds the same pivot)
+    const double rinv = rsqrt_nr(piv);
+    if (half == 0 && mine && row >= j) A[row * LD + j] = (row == j) ? piv * rinv : sij * rinv;
+    wsync();
+  }
+  return true;
+}
+
 // Li = L^-1 for lower-triangular L (n x n, LDS).  Li gets explicit zeros above the diagonal.
 // Row-wise forward substitution: row i of L^-1 from the rows above, Li[i][c] = -(sum_{c<=k<i} L[i][k] Li[k][c]) / L[i][i];
 // two lanes per column share the sum, L[i][k] is a broadcast read, Li[k][c] runs along the lanes, the reciprocal

@@ -504,8 +504,21 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) k_stage_dir(WS w, Dims 
 }
 
 // ------------------------------------------------------------------ smallest eigenvalue of one step-length matrix
+#ifdef TMPC_EIG_DEBUG
+__device__ int g_eig_dbg[4]; __device__ double g_eig_dbgv[8];
+#endif
 // one single-wave block per matrix (4 per stage): 8.9 KB of LDS each -> ~17 blocks (waves) resident per CU
-__global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
+// The largest step theta* = -1 / lambda_min(W) that keeps a cone block positive definite is needed EXACTLY only when it is short: the
+// control kernels clip every step at 1 (k_ctrl_b: min(1, theta*); k_ctrl_c: min(1, gamma theta*), gamma >= 0.9, in the main phase, min(1, 0.95 theta*) while
+// centering) and ask one more thing, whether theta* >= chord_step (the chord decision).  So the wave first asks whether I + theta W is positive
+// definite at those thresholds -- a Cholesky sweep that stops at the first bad pivot, a fifth of the tridiagonalisation + Sturm search --
+// and reports -1 / theta (a bound that yields the same clipped step and the same decision as the exact value) when it is; the eigenvalue
+// is computed only for the blocks that fail.  Per problem the minimum over stages is exact whenever any block is short (a failing block has
+// lambda_min <= -1 / theta <= every reported bound).  Same iterates bit for bit; the raw step in the trace is the bound.  Pass 2 only: the
+// affine step of pass 1 is short in some block of most problems, and asking first cost more than it saved there.  On the bench batch 54 % of
+// the questions are answered by the sweep (no wrong answer in 4.05 M, checked against the eigenvalue with -DTMPC_EIG_DEBUG); pass 2 -4 %,
+// bench line +0.8 % (profiles/r3_eig_pretest_ab.txt).  (Round 3.)
+__global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass, double chord_step) {
   const int mid = stage_id4(w, dm);        // (b*p + k)*4 + which
   const int b = (mid >> 2) / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
@@ -519,6 +532,33 @@ __global__ void __launch_bounds__(64) k_eigmin(WS w, Dims dm, int pass) {
   TMPC_TC0()
   g2s(A, Wg, n, n, n, lane);               // (four loads in flight per lane)
   TMPC_TC(5, 0)
+  // thresholds, longest first: the chord decision (centering only), then "the clipped step is 1"
+  double th[2]; int nth = 0;
+  if (chord_step < 0.0) {}                                                      // TMPC_EIG_PRETEST=0: every eigenvalue
+  else if (pass == 1) {}                                                        // affine step: min(1, theta*) -- usually short in some block; asking first cost more than it saved (pass 1 +0.7 %)
+  else if (phase == PH_MAIN) th[nth++] = (1.0 / 0.9) * (1.0 + 1e-9);             // gamma in [0.9, 0.99] (the other cone may be the short one): gamma theta >= 1
+  else {
+    if (chord_step > 1.0 / TMPC_CENTER_DAMP) th[nth++] = chord_step * (1.0 + 1e-9);
+    th[nth++] = (1.0 / TMPC_CENTER_DAMP) * (1.0 + 1e-9);
+  }
+  for (int t = 0; t < nth; ++t) {
+    if (shifted_is_pd(A, th[t], n, lane)) {
+#ifdef TMPC_EIG_DEBUG
+      wsync(); g2s(A, Wg, n, n, n, lane);
+      const double ex = tridiag_min_eig(A, n, cs, lane);
+      if (lane == 0) { atomicAdd(&g_eig_dbg[0], 1); if (ex <= -1.0 / th[t]) { if (atomicAdd(&g_eig_dbg[1], 1) == 0) { g_eig_dbgv[0] = ex; g_eig_dbgv[1] = th[t]; g_eig_dbgv[2] = pass; g_eig_dbgv[3] = phase; } } }
+#endif
+      if (lane == 0) w.eigmin[mid] = -1.0 / th[t];
+      return;
+    }
+    wsync();
+    g2s(A, Wg, n, n, n, lane);             // the sweep destroyed its copy (L2-hot)
+#ifdef TMPC_EIG_DEBUG
+    { const double ex = tridiag_min_eig(A, n, cs, lane);
+      if (lane == 0) { atomicAdd(&g_eig_dbg[2], 1); if (ex > -1.0 / th[t]) { if (atomicAdd(&g_eig_dbg[3], 1) == 0) { g_eig_dbgv[4] = ex; g_eig_dbgv[5] = th[t]; g_eig_dbgv[6] = pass; g_eig_dbgv[7] = phase; } } }
+      wsync(); g2s(A, Wg, n, n, n, lane); }
+#endif
+  }
   const double lo = tridiag_min_eig(A, n, cs, lane);
   TMPC_TC(5, 3)
   if (lane == 0) w.eigmin[mid] = lo;
