@@ -545,6 +545,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         # (a full Newton step removes the linear residuals: centering may start with pinf well above the final accuracy)
         if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and pinf < 1e-3:
             phase = 1
+        if phase == 0 and nshiftrun >= 2:
+            # the wall met on the way down (the last two factorisations needed a shift before mu reached 2 mu_t): the path cannot be
+            # followed below the current mu -- centre at the power of two above it, if the back-off budget covers that (k_ctrl_a)
+            kb = max(0, int(np.ceil(np.log2(mu / mu_t))))
+            if dinf < 1e-6 and pinf < 1e-3 and nbackoff + kb <= MUT_BACKOFF_MAX:
+                mu_t *= 2.0 ** kb; nbackoff += kb; phase = 1; ncent = 0; prev_stepn = None; nshiftrun = 0
+            else:
+                status = 'optimal_inaccurate'
+                break
         if phase == 0 and it >= o['max_iter']:
             break
         L1, S1i, L1i = _chol_inv(S1)
@@ -572,13 +581,19 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
           shift_used = max(shift_used, chol.shift)
           nshiftrun = nshiftrun + 1 if chol.shift > 0.0 else 0
           if phase == 1 and chol.shift > 0.0 and nbackoff < MUT_BACKOFF_MAX:
-              # hard target (cond(T) ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the central-path point one
-              # power of two earlier and repeat the iteration from the same iterate (the HIP path: k_ctrl_c, tmpc_schur.h)
+              # hard target (cond(T) ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the central-path point one power of
+              # two earlier AND take the step the shifted factorisation gives towards it (the HIP path: k_ctrl_f, tmpc_schur.h).  Round 3:
+              # the iteration used to be repeated from the same iterate -- but the Schur matrix belongs to the iterate, not to the
+              # target, so ten back-offs in a row met the same singular matrix and the problem ended 'inaccurate' at 1024 mu_t.  A
+              # step towards the larger mu_t moves the iterate back up the path, where the matrix is definite again: the members
+              # of scripts/robustness_sweep.py at cond(H) = 1e5 that ended Feasible now end Optimal after 1-5 back-offs.
               mu_t *= 2.0; nbackoff += 1; ncent = 0; prev_stepn = None; nshiftrun = 0
-              continue
-          if (phase == 1 and chol.shift > 0.0) or nshiftrun >= 2:
-              # numerical breakdown of the Schur factorisation while centering: keep the last
-              # iterate, strictly feasible and close to the central path at ~2 mu_t, and report it as inaccurate
+              if not o.get('backoff_step', True):      # (experiment hook: the behaviour of rounds 1-2)
+                  continue
+          elif (phase == 1 and chol.shift > 0.0) or (nshiftrun >= 2 and (mu_t is None or nbackoff >= MUT_BACKOFF_MAX or not o.get('backoff_step', True))):
+              # numerical breakdown of the Schur factorisation that no back-off is left for: keep the last iterate, strictly feasible
+              # and close to the central path at ~2 mu_t, and report it as inaccurate.  (Two shifted factorisations in a row in the MAIN
+              # phase with back-offs left: the step is taken, the next iteration starts centering where it stands -- see above.)
               status = 'optimal_inaccurate'
               break
           U = np.stack([u_tau, u_alpha], axis=2)                  # [p,d,2]

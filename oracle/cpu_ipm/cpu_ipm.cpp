@@ -289,7 +289,8 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
   vec Kx(nxx), Ks(nxx), Fx(nxx), Fs(nxx), tx((size_t)nx * n), Xxx(nxx), Sxx(nxx);
   pr.D.resize((size_t)p * bs); pr.Csub.resize((size_t)p * bs);
   double mu_t = -1.0, mu = 0, mu0 = 0, pinf = 0, dinf = 0, stepn = 1e300, prev_stepn = -1.0;
-  int phase = 0, ncent = 0, njam = 0, nshiftrun = 0, it = 0;
+  int phase = 0, ncent = 0, njam = 0, nshiftrun = 0, nbackoff = 0, it = 0;
+  const int MUT_BACKOFF_MAX = 10;          // as the oracle and the HIP path
   enum { ST_MAXIT, ST_OPT, ST_INACC, ST_DIV } ipm = ST_MAXIT;
   auto dot = [&](const vec& a, const vec& b) { double v = 0; for (size_t e = 0; e < PN; ++e) v += a[e] * b[e]; return v; };
   auto trace_sum = [&](const vec& a) { double v = 0; for (int k = 0; k < p; ++k) for (int i = 0; i < n; ++i) v += a[((size_t)k * n + i) * n + i]; return v; };
@@ -303,7 +304,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     return lm >= 0.0 ? 1e300 : -1.0 / lm;
   };
   double dtau = 0, dalpha = 0, ds0 = 0, dx0 = 0;
-  for (it = 0; it < max_iter + center_iter + 1; ++it) {
+  for (it = 0; it < max_iter + center_iter * (MUT_BACKOFF_MAX + 1) + 1; ++it) {
     pr.calH(M, P, alpha);
     double rd2 = 0, s2 = 0;
     for (int k = 0; k < p; ++k) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
@@ -324,6 +325,11 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     if (!(mu > 0.0) || !std::isfinite(mu) || !std::isfinite(tau) || mu > 1e6 * mu0) { ipm = ST_DIV; break; }
     if (mu_t < 0.0 && relgap < 1e-2 && dinf < 1e-2) mu_t = exp2(rint(log2(tol * std::max(1.0, fabs(tau)))));
     if (phase == 0 && mu_t > 0.0 && mu <= 2.0 * mu_t && dinf < 1e-6 && pinf < 1e-3) phase = 1;
+    if (phase == 0 && nshiftrun >= 2) {      // the wall met on the way down: centre at the power of two above the current mu (convexify_oracle.py, k_ctrl_a)
+      const int kb = std::max(0, (int)ceil(log2(mu / mu_t)));
+      if (dinf < 1e-6 && pinf < 1e-3 && nbackoff + kb <= MUT_BACKOFF_MAX) { mu_t = ldexp(mu_t, kb); nbackoff += kb; phase = 1; ncent = 0; prev_stepn = -1.0; nshiftrun = 0; }
+      else { ipm = ST_INACC; break; }
+    }
     if (phase == 0 && it >= max_iter) break;
     bool ok = true;
     for (int k = 0; k < p && ok; ++k) {
@@ -377,7 +383,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     for (int k = 0; k < p; ++k) pr.svec_grad(&U[(size_t)(p + k) * d], &adjb[(size_t)k * nxx]);
     if (!pr.factor()) { ipm = ST_INACC; break; }
     nshiftrun = pr.shift > 0.0 ? nshiftrun + 1 : 0;
-    if ((phase == 1 && pr.shift > 0.0) || nshiftrun >= 2) { ipm = ST_INACC; break; }
+    if (phase == 1 && pr.shift > 0.0 && nbackoff < MUT_BACKOFF_MAX) {
+      // hard target: aim one power of two earlier and take the step of the shifted factorisation towards it (convexify_oracle.py, k_ctrl_f)
+      mu_t *= 2.0; ++nbackoff; ncent = 0; prev_stepn = -1.0; nshiftrun = 0;
+    } else if ((phase == 1 && pr.shift > 0.0) || (nshiftrun >= 2 && (mu_t < 0.0 || nbackoff >= MUT_BACKOFF_MAX))) { ipm = ST_INACC; break; }
     TU = U; pr.solve(TU.data(), 2);
     double sb00 = b_tt, sb01 = b_ta, sb11 = b_aa;
     for (size_t e = 0; e < (size_t)p * d; ++e) { sb00 -= U[e] * TU[e]; sb01 -= U[e] * TU[(size_t)p * d + e]; sb11 -= U[(size_t)p * d + e] * TU[(size_t)p * d + e]; }
@@ -469,7 +478,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       const double est = (prev_stepn >= 0.0) ? stepn * pow(std::min(1.0, stepn / prev_stepn), 1.5) : stepn;
       if (full && (stepn < center_tol || est < 0.1 * center_tol)) { ipm = ST_OPT; ++it; break; }
       if (full && prev_stepn >= 0.0 && stepn > 0.5 * prev_stepn && stepn < 1e-6) { ipm = ST_OPT; ++it; break; }
-      if (ncent >= center_iter) { ipm = ST_INACC; ++it; break; }
+      if (ncent >= center_iter) {
+        if (nbackoff < MUT_BACKOFF_MAX) { mu_t *= 2.0; ++nbackoff; ncent = 0; prev_stepn = -1.0; continue; }
+        ipm = ST_INACC; ++it; break;
+      }
       prev_stepn = full ? stepn : -1.0;
     }
   }

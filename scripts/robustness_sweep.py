@@ -11,22 +11,11 @@ if os.environ.get('TMPC_LIB'):
 from tunempc_amd._lib import HipConvexifier
 
 
+from tunempc_amd import synthetic
+
+
 def gen(seed, p, nx, mb, sigP, cond_exp, rad):
-    rng = np.random.default_rng(seed)
-    n = nx + mb
-    A = np.zeros((p, nx, nx)); B = np.zeros((p, nx, mb)); Phat = np.zeros((p, nx, nx)); Hhat = np.zeros((p, n, n))
-    for k in range(p):
-        a = rng.standard_normal((nx, nx)) / np.sqrt(nx)
-        A[k] = a * (rad / np.max(np.abs(np.linalg.eigvals(a))))
-        B[k] = rng.standard_normal((nx, mb)) / np.sqrt(nx)
-        W, _ = np.linalg.qr(rng.standard_normal((n, n)))
-        Hhat[k] = (W * 10.0 ** rng.uniform(0, cond_exp, n)) @ W.T
-        pk = rng.standard_normal((nx, nx)); Phat[k] = sigP * (pk + pk.T) / 2
-    V = np.concatenate([A, B], axis=2)
-    dH = np.swapaxes(V, 1, 2) @ np.roll(Phat, -1, axis=0) @ V
-    dH[:, :nx, :nx] -= Phat
-    H = Hhat - dH
-    return A, B, (H + np.swapaxes(H, 1, 2)) / 2
+    return synthetic.gen_problem(seed, p, nx, mb, sigP=sigP, cond_exp=cond_exp, rad=rad)
 
 
 def calH(A, B, P):

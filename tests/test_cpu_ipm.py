@@ -30,3 +30,15 @@ def test_cpu_ipm_infeasible_member():
     H[1] = co.build_hessian(np.eye(2), np.array([[-1.0]]), np.zeros((2, 1)))
     o = cpu_ipm.convexify_batch(A, B, H)
     assert int(o['status'][1]) == 2 and int(o['status'][0]) == 0
+
+
+def test_cpu_ipm_hard_targets_back_off_like_the_oracle():
+    """cond(Hhat) = 1e5 (scripts/robustness_sweep.py): the Schur matrix turns numerically singular before the default mu_t.  Both
+    restatements back mu_t off by powers of two, taking the step of the shifted factorisation, and end Optimal (round 3)."""
+    from tunempc_amd import synthetic
+    for b in (2, 5):
+        A, B, H = synthetic.gen_problem(7000 + 17 * b, 30, 4, 1, sigP=10.0, cond_exp=5, rad=0.5)
+        o = cpu_ipm.convexify_batch(A[None], B[None], H[None])
+        r = co.convexify_arrays(A, B, H)
+        assert int(o['status'][0]) == int(r['status']) == 0
+        assert abs(o['kappa'][0] - r['kappa']) <= 1e-4 * r['kappa']              # within N mu_t of each other whatever the back-off count

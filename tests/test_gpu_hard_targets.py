@@ -1,0 +1,63 @@
+"""Hard targets on the GPU (run with -m gpu): inputs outside the benchmark distribution whose Schur complement turns numerically singular
+before the default barrier parameter is reached (cond(Hhat) = 1e5; scripts/robustness_sweep.py is the wide sweep, 1440 members).
+
+Both the HIP path and the oracle then aim for the central-path point a power of two earlier, taking the step the safeguarded factorisation
+gives towards it (k_ctrl_f / k_ctrl_a in tmpc_schur.h; convexify_oracle.py), and end `Optimal` at the gap N * mu_t reported in info[6].
+Until round 3 the iteration was repeated from the same iterate instead: these members ended `Feasible` at 1024 mu_t.
+
+The two implementations guard the factorisation differently (frozen pivots + a diagonal lift vs a uniform relative shift), so they may need
+a different number of back-offs; a member is value-compared where the final mu_t agree (tests/tools/hard_target_probe.py: 17 of 32, Hc to
+<= 5.4e-7; one back-off apart the points differ by 1-4 %, as DESIGN.md section 2 measures for the central path in general).  The bound of
+the value comparison is 1e-5, not 1e-8: cond(H) = 1e5 amplifies the rounding of either side by that factor."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before the HIP library is loaded, see tests/test_gpu_parity.py)
+
+pytestmark = pytest.mark.gpu
+
+import convexify_oracle as co  # noqa: E402
+from tunempc_amd import synthetic  # noqa: E402
+
+
+def _calH(A, B, P):
+    V = np.concatenate([A, B], axis=2); nx = A.shape[1]
+    d = np.swapaxes(V, 1, 2) @ np.roll(P, -1, axis=0) @ V
+    d[:, :nx, :nx] -= P
+    return (d + np.swapaxes(d, 1, 2)) / 2
+
+
+@pytest.mark.parametrize('p,nx,mb,sigP,rad', [(30, 4, 1, 10.0, 0.5), (30, 4, 1, 100.0, 0.9), (8, 16, 4, 1.0, 0.5), (5, 9, 6, 100.0, 0.5)])
+def test_hard_targets_end_optimal_after_backoff(p, nx, mb, sigP, rad):
+    from tunempc_amd._lib import HipConvexifier
+    nb = 8
+    probs = [synthetic.gen_problem(7000 + 17 * b, p, nx, mb, sigP=sigP, cond_exp=5, rad=rad) for b in range(nb)]
+    A, B, H = (np.stack([q[i] for q in probs]) for i in range(3))
+    h = HipConvexifier(p, nx, mb)
+    out = h.convexify_batch(A, B, H)
+    h.close()
+    backoffs, compared, worst = [], 0, 0.0
+    for b in range(nb):
+        assert int(out['status'][b]) == 0, (b, out['status'][b], out['iters'][b])                  # 'Optimal' (rounds 1-2: up to 5 of 8 'Feasible')
+        # solver-independent: Hc > 0, cond(Hc_k) <= kappa, Hc - H = calH(P)
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0.0
+        if out['info'][b, 13]:                                                                    # H was convex already (convexifier.py:83)
+            continue
+        assert (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-7)
+        assert np.abs(out['Hc'][b] - H[b] - _calH(A[b], B[b], out['P'][b])).max() <= 1e-10 * max(1.0, np.abs(H[b]).max())
+        mut0 = 2.0 ** np.round(np.log2(2.0 ** -25 * max(1.0, out['kappa'][b])))
+        k = int(np.round(np.log2(out['info'][b, 6] / mut0)))
+        assert 0 <= k <= 6, (b, k)                                                                 # the gap stays within 64 x the default
+        backoffs.append(k)
+        r = co.sdp_step1(A[b], B[b], H[b])
+        assert r['ipm_status'] == 'optimal', (b, r['ipm_status'])
+        # kappa: both are within N mu_t of the optimum whatever the back-off count
+        assert abs(out['kappa'][b] - r['kappa']) <= 2.0 * (2 * p * (nx + mb) + 1) * max(out['info'][b, 6], r['mu_target'])
+        if r['mu_target'] == out['info'][b, 6]:
+            Hc = H[b] + co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'])[1]
+            e = np.linalg.norm(out['Hc'][b] - Hc) / np.linalg.norm(Hc)
+            worst = max(worst, e); compared += 1
+            assert e < 1e-5, (b, k, e)
+    assert max(backoffs) >= 1                        # the case does exercise the back-off
+    assert compared >= 2, (compared, backoffs)
+    print(f'back-offs {backoffs}, value-compared {compared} members, worst {worst:.2e}')

@@ -213,3 +213,21 @@ def test_cost_free_multipliers_equal_equality_rows():
     r4 = co.sdp_step1(A, B, H, C=Cr, rho=1e-3)
     assert r3['ipm_status'] == r4['ipm_status'] == 'optimal' and r3['kappa'] <= r4['kappa'] * (1 + 1e-7)
     assert r3['F'][1] is None and r3['F'][4] is None and all((f >= 0).all() for f in r3['F'] if f is not None)
+
+
+def test_hard_target_backs_off_and_ends_optimal():
+    """cond(Hhat) = 1e5: the Schur complement turns numerically singular at the default mu_t.  The solver aims one power of two
+    earlier AND takes the step of the shifted factorisation towards it (round 3) -- repeating the iteration from the same iterate
+    (rounds 1-2, opts['backoff_step'] = False) meets the same singular matrix ten times and ends inaccurate at 1024 mu_t."""
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_problem(7000 + 17 * 2, 30, 4, 1, sigP=10.0, cond_exp=5, rad=0.5)
+    r = co.sdp_step1(A, B, H)
+    k = np.log2(r['mu_target'] / 2.0 ** np.round(np.log2(2.0 ** -25 * r['kappa'])))
+    assert r['ipm_status'] == 'optimal' and 1 <= k <= 5 and r['shift'] > 0.0
+    assert co.check_convergence(A, B, H, r['P'], r['ipm_status'])[0] == co.STATUS_OPTIMAL
+    old = co.sdp_step1(A, B, H, opts=dict(backoff_step=False))
+    assert old['ipm_status'] == 'optimal_inaccurate'
+    # the wall met in the MAIN phase (two shifted factorisations in a row before mu reaches 2 mu_t): centre where the iterate stands
+    A, B, H = synthetic.gen_problem(7000 + 17 * 5, 30, 4, 1, sigP=10.0, cond_exp=5, rad=0.5)
+    r = co.sdp_step1(A, B, H)
+    assert r['ipm_status'] == 'optimal' and r['mu_target'] > 2.0 ** -25 * r['kappa'] * 1.5

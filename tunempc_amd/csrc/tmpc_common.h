@@ -28,6 +28,7 @@ constexpr int TB = 64;                 // tile size of the d x d block factorisa
 #ifndef TMPC_CENTER_DAMP
 #define TMPC_CENTER_DAMP 0.95      // damping of the raw step length in the centering phase (k_ctrl_c; k_eigmin's pre-test threshold)
 #endif
+constexpr int REG_MAX = 3;             // levels of the relative lift of the Schur diagonal after frozen pivots: 1e-12, 1e-11, 1e-10 (k_schur, k_ctrl_c)
 constexpr int EIG_MAX_SWEEPS = 40;     // tmpc_eig_clip_host: Jacobi sweeps before TMPC_E_NOCONV
 
 // ---- per-problem double scalars (prob[b*PS + idx])
@@ -38,7 +39,8 @@ enum {
   P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
-enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_PREVFULL, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF, IS = 16 };   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
+enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF, IS = 16 };   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
+//   // I_BOSTEP: 1 = k_ctrl_f backed mu_t off in this centering iteration (frozen pivots): the step of that factorisation is TAKEN (k_ctrl_c)
 //   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
 //   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots

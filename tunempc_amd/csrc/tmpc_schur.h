@@ -249,6 +249,19 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
     phase = PH_CENTER;
     ip[I_PHASE] = phase;
   }
+  if (phase == PH_MAIN && ip[I_SHIFTRUN] >= 2) {
+    // the wall met on the way down (frozen pivots in the last two factorisations before mu reached 2 mu_t; k_ctrl_c let the steps pass):
+    // the path cannot be followed below the current mu -- centre at the power of two above it, if the back-off budget covers that
+    // (convexify_oracle.py does the same).  Rounds 1-2 stopped here with an inaccurate point.
+    const int kb = (mut > 0.0 && mu > mut) ? (int)ceil(log2(mu / mut)) : 0;
+    if (mut > 0.0 && dinf < 1e-6 && pinf < 1e-3 && ip[I_BACKOFF] + kb <= MUT_BACKOFF_MAX) {
+      mut = ldexp(mut, kb); pr[P_MUT] = mut; ip[I_BACKOFF] += kb;
+      phase = PH_CENTER; ip[I_PHASE] = phase; ip[I_SHIFTRUN] = 0; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0;
+    } else {
+      ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
+      return;
+    }
+  }
   if (phase == PH_MAIN && ip[I_ITERS] >= o.max_iter) {
     ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_MAXITER;
     return;
@@ -259,6 +272,25 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   // budget of Newton steps on chord steps would trigger the mu_t back-off below, i.e. change the answer, on slowly contracting members
   if (phase == PH_CENTER) { ip[I_NCENT] += (ip[I_CHORD] && (ip[I_NCHORD] & 3)) ? 0 : 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
   else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
+}
+
+// after the factorisation of a centering iteration, before its right-hand side: hard target.  Frozen pivots while centering mean the Schur matrix
+// is numerically singular AT THIS ITERATE (cond ~ (tau/mu)^2 passes 1/eps before the default mu_t when cond(H) >~ 1e3).  Aim for the
+// central-path point one power of two earlier and TAKE the step this factorisation gives towards it (a frozen pivot leaves its component
+// of the direction at zero: Newton restricted to the subspace that can still be resolved); the step moves the iterate back up the path, where the
+// matrix is definite again.  The problem then ends Optimal at the gap N mu_t it reports in info[6].  (Rounds 1-2 doubled mu_t and REPEATED
+// the iteration from the same iterate -- the matrix belongs to the iterate, not to the target: ten back-offs in a row met the same singular
+// matrix, and the cond(H) = 1e5 members of scripts/robustness_sweep.py ended Feasible at 1024 mu_t instead of Optimal at 2-32 mu_t.)
+__global__ void __launch_bounds__(64) k_ctrl_f(WS w, Dims dm) {
+  const int b = prob_id(w);
+  if (threadIdx.x != 0) return;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_CENTER || ip[I_CHORD]) return;
+  if (ip[I_NSHIFT] == ip[I_SHIFT0] || ip[I_REG] < REG_MAX || ip[I_BACKOFF] >= MUT_BACKOFF_MAX) return;   // (frozen pivots first lift the diagonal, 1e-12 ... 1e-10, and repeat: k_ctrl_c)
+  double* pr = w.prob + (size_t)b * PS;
+  pr[P_MUT] *= 2.0; pr[P_SIGMU] = pr[P_MUT];
+  ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0; ip[I_BOSTEP] = 1;
+  ip[I_REG] = 0;                                  // the next factorisation tries without the lift (see k_ctrl_d)
 }
 
 // step lengths from the per-stage extreme eigenvalues + the scalar (alpha) block
@@ -338,20 +370,31 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     ip[I_SHIFTRUN] = froze ? ip[I_SHIFTRUN] + 1 : 0;
     // a direction that is not finite (a cascade of frozen pivots can overflow the fill row) is a breakdown as well
     const bool nonfin = !(fabs(dtau) < 1e300) || !(fabs(dalpha) < 1e300) || !(ap == ap) || !(ad == ad) || !(dh2 == dh2);
-    if ((froze || nonfin) && ip[I_REG] < 1) {
+    const bool bostep = ip[I_BOSTEP] != 0;       // k_ctrl_f backed mu_t off before this direction was computed
+    ip[I_BOSTEP] = 0;
+    // two main-phase iterations in a row with frozen pivots and back-offs left: let the step pass, k_ctrl_a starts centering where the iterate stands
+    const bool wall_next = (phase == PH_MAIN && !nonfin && ip[I_JAM] < 2 && pr[P_MUT] > 0.0 && ip[I_BACKOFF] < MUT_BACKOFF_MAX);
+    if ((froze || nonfin) && ip[I_REG] < REG_MAX) {
       // first answer to frozen pivots: discard this direction, lift the Schur diagonal by 1e-12 relative
       // from now on and repeat the iteration from the same iterate -- the matrix sits within ~1e-13 (diagonally scaled) of
       // singular near mu_t, and e.g. the stage-local elimination of an active multiplier (tmpc_phi.h) can use that margin up.
-      // (Larger lifts were tried: they damp the weakest eigen-direction, centering turns linear and a lockstep batch waits.)
+      // If pivots freeze again the lift grows to 1e-11, then 1e-10 (round 3; the oracle's Cholesky-with-shift escalates the same way):
+      // the block factorisation multiplies by explicitly inverted diagonal tiles, which costs ~sqrt(cond D_k) eps of accuracy against a
+      // substitution, so a matrix with scaled lambda_min = 1.3e-13 that LAPACK still factors freezes pivots here even at 1e-12
+      // (scripts/case93_factor_probe.py: a fuzz member of the benchmark distribution whose first centering iterate follows a 32-fold
+      // drop of mu; it ended Feasible after ten idle back-offs).  Larger lifts damp the weakest eigen-direction and centering turns
+      // linear -- k_ctrl_d then backs mu_t off and drops the lift.
       ip[I_REG] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
       ap = 0.0; ad = 0.0; retry = true;
+    } else if (bostep && !nonfin) {
+      ip[I_SHIFTRUN] = 0;                        // the step is taken (k_ctrl_f)
     } else if (phase == PH_CENTER && (froze || nonfin) && ip[I_BACKOFF] < MUT_BACKOFF_MAX) {
       // hard target (cond(H) >~ 1e3: cond of the Schur matrix ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the
       // central-path point one power of two earlier instead of giving up -- the problem then ends Optimal at the gap
       // N * mu_t it reports in info[6] (the default is tol * kappa), not Feasible at an uncontrolled one
       pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0;
       ap = 0.0; ad = 0.0; retry = true;
-    } else if ((phase == PH_CENTER && froze) || ip[I_SHIFTRUN] >= 2 || ip[I_JAM] >= 2 || nonfin) {
+    } else if ((phase == PH_CENTER && froze) || (ip[I_SHIFTRUN] >= 2 && !wall_next) || ip[I_JAM] >= 2 || nonfin) {
       ap = 0.0; ad = 0.0;
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
     }
@@ -394,11 +437,17 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     const double est = was_chord ? stepn : stepn * rr * sqrt(rr);
     bool chord_next = false, full_reset = false;
     if (full && (o.fast_exit || stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
-    else if (!was_chord && full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    // (rounding floor: the steps stopped contracting below 1e-6.  Not with a lifted diagonal: Newton is damped in the weakest directions then
+    // and small steps say nothing about the distance to the centred point -- a fuzz member stopped 1e-4 away with steps of 1e-7; the next
+    // branch backs mu_t off and drops the lift instead.)
+    else if (!was_chord && full && prev >= 0.0 && stepn > 0.5 * prev && stepn < 1e-6 && ip[I_REG] == 0) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
     // with a lifted Schur diagonal Newton is inexact in the weakest direction: once the steps stop contracting -- or the centering
     // budget is spent -- there is nothing more to gain at this mu_t: back off to the next power of two (hard target), or stop
     else if (ip[I_NCENT] >= o.center_iter || (ip[I_REG] > 0 && full && prev >= 0.0 && stepn > 0.5 * prev)) {
-      if (ip[I_BACKOFF] < MUT_BACKOFF_MAX) { pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; full_reset = true; }
+      // (the lift of the diagonal goes with the target it was needed for: with it Newton is inexact and converges linearly at ANY mu_t -- the
+      // Schur matrix of an ill-conditioned H has eigenvalues below 1e-12 relative all along the path -- while the plain factorisation may well
+      // succeed one power of two up; if it does not, the first frozen pivot brings the lift back at the price of one factorisation)
+      if (ip[I_BACKOFF] < MUT_BACKOFF_MAX) { pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; ip[I_REG] = 0; full_reset = true; }
       else { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     }
     else if (o.chord_step > 0.0 && full && ip[I_REG] == 0) {

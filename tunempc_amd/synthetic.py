@@ -5,17 +5,19 @@ indefinite, yet Step 1 of the convexifier is strictly feasible by construction."
 import numpy as np
 
 
-def gen_problem(seed, p, nx, mb, sigP=1.0, identity=False):
+def gen_problem(seed, p, nx, mb, sigP=1.0, identity=False, cond_exp=1.0, rad=0.9):
+    """cond_exp: cond(Hhat_k) <= 10**cond_exp; rad: spectral radius of A_k (the knobs of scripts/robustness_sweep.py: the defaults are the
+    benchmark distribution)."""
     rng = np.random.default_rng(seed)
     n = nx + mb
     A = np.zeros((p, nx, nx)); B = np.zeros((p, nx, mb)); Phat = np.zeros((p, nx, nx)); Hhat = np.zeros((p, n, n))
     for k in range(p):
         a = rng.standard_normal((nx, nx)) / np.sqrt(nx)
         rho = np.max(np.abs(np.linalg.eigvals(a)))
-        A[k] = a * (0.9 / rho)
+        A[k] = a * (rad / rho)
         B[k] = rng.standard_normal((nx, mb)) / np.sqrt(nx)
         W, _ = np.linalg.qr(rng.standard_normal((n, n)))
-        lam = np.ones(n) if identity else 10.0 ** rng.uniform(0, 1, n)
+        lam = np.ones(n) if identity else 10.0 ** rng.uniform(0, cond_exp, n)
         Hhat[k] = (W * lam) @ W.T
         pk = rng.standard_normal((nx, nx)); Phat[k] = sigP * (pk + pk.T) / 2
     V = np.concatenate([A, B], axis=2)
