@@ -25,12 +25,13 @@ def calH(A, B, P):
     return (d + np.swapaxes(d, 1, 2)) / 2
 
 
+CONDS = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 3, 5)      # exponents of cond(Hhat)
 rows = []
 nbad = 0
 for (p, nx, mb) in [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]:
     h = HipConvexifier(p, nx, mb)
     for sigP in (0.1, 1.0, 10.0, 100.0):
-        for cond_exp in (1, 3, 5):
+        for cond_exp in CONDS:
             for rad in (0.5, 0.9, 1.2):
                 nb = 8
                 ABH = [gen(7000 + 17 * b, p, nx, mb, sigP, cond_exp, rad) for b in range(nb)]
