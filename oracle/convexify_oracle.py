@@ -582,7 +582,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
           nshiftrun = nshiftrun + 1 if chol.shift > 0.0 else 0
           if phase == 1 and chol.shift > 0.0 and nbackoff < MUT_BACKOFF_MAX:
               # hard target (cond(T) ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the central-path point one power of
-              # two earlier AND take the step the shifted factorisation gives towards it (the HIP path: k_ctrl_f, tmpc_schur.h).  Round 3:
+              # two earlier AND take the step the shifted factorisation gives towards it (the HIP path: ctrl_backoff_before_rhs in k_ctrl_b, tmpc_schur.h).  Round 3:
               # the iteration used to be repeated from the same iterate -- but the Schur matrix belongs to the iterate, not to the
               # target, so ten back-offs in a row met the same singular matrix and the problem ended 'inaccurate' at 1024 mu_t.  A
               # step towards the larger mu_t moves the iterate back up the path, where the matrix is definite again: the members

@@ -384,7 +384,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     if (!pr.factor()) { ipm = ST_INACC; break; }
     nshiftrun = pr.shift > 0.0 ? nshiftrun + 1 : 0;
     if (phase == 1 && pr.shift > 0.0 && nbackoff < MUT_BACKOFF_MAX) {
-      // hard target: aim one power of two earlier and take the step of the shifted factorisation towards it (convexify_oracle.py, k_ctrl_f)
+      // hard target: aim one power of two earlier and take the step of the shifted factorisation towards it (convexify_oracle.py, k_ctrl_b)
       mu_t *= 2.0; ++nbackoff; ncent = 0; prev_stepn = -1.0; nshiftrun = 0;
     } else if ((phase == 1 && pr.shift > 0.0) || (nshiftrun >= 2 && (mu_t < 0.0 || nbackoff >= MUT_BACKOFF_MAX))) { ipm = ST_INACC; break; }
     TU = U; pr.solve(TU.data(), 2);

@@ -2,7 +2,7 @@
 before the default barrier parameter is reached (cond(Hhat) = 1e5; scripts/robustness_sweep.py is the wide sweep, 1440 members).
 
 Both the HIP path and the oracle then aim for the central-path point a power of two earlier, taking the step the safeguarded factorisation
-gives towards it (k_ctrl_f / k_ctrl_a in tmpc_schur.h; convexify_oracle.py), and end `Optimal` at the gap N * mu_t reported in info[6].
+gives towards it (k_ctrl_b / k_ctrl_a in tmpc_schur.h; convexify_oracle.py), and end `Optimal` at the gap N * mu_t reported in info[6].
 Until round 3 the iteration was repeated from the same iterate instead: these members ended `Feasible` at 1024 mu_t.
 
 The two implementations guard the factorisation differently (frozen pivots + a diagonal lift vs a uniform relative shift), so they may need

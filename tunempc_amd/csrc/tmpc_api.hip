@@ -613,7 +613,6 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
     if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
-    if (nfac > 0) hipLaunchKernelGGL(k_ctrl_f, dim3(active), dim3(64), 0, st, w, dm);      // hard targets: mu_t back-off BEFORE the right-hand side of a centering step
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);

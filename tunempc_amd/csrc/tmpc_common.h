@@ -40,7 +40,7 @@ enum {
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
 enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF, IS = 16 };   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
-//   // I_BOSTEP: 1 = k_ctrl_f backed mu_t off in this centering iteration (frozen pivots): the step of that factorisation is TAKEN (k_ctrl_c)
+//   // I_BOSTEP: 1 = k_ctrl_b (ctrl_backoff_before_rhs) backed mu_t off in this centering iteration (frozen pivots): the step of that factorisation is TAKEN (k_ctrl_c)
 //   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
 //   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots

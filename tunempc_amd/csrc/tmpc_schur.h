@@ -274,16 +274,16 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
 }
 
-// after the factorisation of a centering iteration, before its right-hand side: hard target.  Frozen pivots while centering mean the Schur matrix
+// After the factorisation of a centering iteration, before its right-hand side: hard target.  Frozen pivots while centering mean the Schur matrix
 // is numerically singular AT THIS ITERATE (cond ~ (tau/mu)^2 passes 1/eps before the default mu_t when cond(H) >~ 1e3).  Aim for the
 // central-path point one power of two earlier and TAKE the step this factorisation gives towards it (a frozen pivot leaves its component
 // of the direction at zero: Newton restricted to the subspace that can still be resolved); the step moves the iterate back up the path, where the
 // matrix is definite again.  The problem then ends Optimal at the gap N mu_t it reports in info[6].  (Rounds 1-2 doubled mu_t and REPEATED
 // the iteration from the same iterate -- the matrix belongs to the iterate, not to the target: ten back-offs in a row met the same singular
 // matrix, and the cond(H) = 1e5 members of scripts/robustness_sweep.py ended Feasible at 1024 mu_t instead of Optimal at 2-32 mu_t.)
-__global__ void __launch_bounds__(64) k_ctrl_f(WS w, Dims dm) {
-  const int b = prob_id(w);
-  if (threadIdx.x != 0) return;
+// (Runs at the top of k_ctrl_b -- after the factorisation and the predictor pass that centering problems skip, before the right-hand side of
+// pass 2 -- so it costs no launch of its own.)
+__device__ __forceinline__ void ctrl_backoff_before_rhs(WS& w, int b) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_CENTER || ip[I_CHORD]) return;
   if (ip[I_NSHIFT] == ip[I_SHIFT0] || ip[I_REG] < REG_MAX || ip[I_BACKOFF] >= MUT_BACKOFF_MAX) return;   // (frozen pivots first lift the diagonal, 1e-12 ... 1e-10, and repeat: k_ctrl_c)
@@ -307,7 +307,10 @@ __device__ __forceinline__ void raw_steps(const double* pr, double minx, double 
 __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
   const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
-  if (ip[I_PHASE] != PH_MAIN) return;
+  if (ip[I_PHASE] != PH_MAIN) {
+    if (lane == 0) ctrl_backoff_before_rhs(w, b);        // centering: hard-target back-off, see above
+    return;
+  }
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p;
   const double minx = emin(w.eigmin, b, p, 1, lane), mins = emin(w.eigmin, b, p, 0, lane);
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     ip[I_SHIFTRUN] = froze ? ip[I_SHIFTRUN] + 1 : 0;
     // a direction that is not finite (a cascade of frozen pivots can overflow the fill row) is a breakdown as well
     const bool nonfin = !(fabs(dtau) < 1e300) || !(fabs(dalpha) < 1e300) || !(ap == ap) || !(ad == ad) || !(dh2 == dh2);
-    const bool bostep = ip[I_BOSTEP] != 0;       // k_ctrl_f backed mu_t off before this direction was computed
+    const bool bostep = ip[I_BOSTEP] != 0;       // ctrl_backoff_before_rhs (k_ctrl_b) backed mu_t off before this direction was computed
     ip[I_BOSTEP] = 0;
     // two main-phase iterations in a row with frozen pivots and back-offs left: let the step pass, k_ctrl_a starts centering where the iterate stands
     const bool wall_next = (phase == PH_MAIN && !nonfin && ip[I_JAM] < 2 && pr[P_MUT] > 0.0 && ip[I_BACKOFF] < MUT_BACKOFF_MAX);
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
       ip[I_REG] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
       ap = 0.0; ad = 0.0; retry = true;
     } else if (bostep && !nonfin) {
-      ip[I_SHIFTRUN] = 0;                        // the step is taken (k_ctrl_f)
+      ip[I_SHIFTRUN] = 0;                        // the step is taken (ctrl_backoff_before_rhs)
     } else if (phase == PH_CENTER && (froze || nonfin) && ip[I_BACKOFF] < MUT_BACKOFF_MAX) {
       // hard target (cond(H) >~ 1e3: cond of the Schur matrix ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the
       // central-path point one power of two earlier instead of giving up -- the problem then ends Optimal at the gap
