@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   if (phase == PH_MAIN && ip[I_SHIFTRUN] >= 2) {
     // the wall met on the way down (frozen pivots in the last two factorisations before mu reached 2 mu_t; k_ctrl_c let the steps pass):
     // the path cannot be followed below the current mu -- centre at the power of two above it, if the back-off budget covers that
-    // (convexify_oracle.py does the same).  Rounds 1-2 stopped here with an inaccurate point.
+    // (the CPU restatement used by the tests does the same).  Rounds 1-2 stopped here with an inaccurate point.
     const int kb = (mut > 0.0 && mu > mut) ? (int)ceil(log2(mu / mut)) : 0;
     if (mut > 0.0 && dinf < 1e-6 && pinf < 1e-3 && ip[I_BACKOFF] + kb <= MUT_BACKOFF_MAX) {
       mut = ldexp(mut, kb); pr[P_MUT] = mut; ip[I_BACKOFF] += kb;
