@@ -61,3 +61,35 @@ def test_hard_targets_end_optimal_after_backoff(p, nx, mb, sigP, rad):
     assert max(backoffs) >= 1                        # the case does exercise the back-off
     assert compared >= 2, (compared, backoffs)
     print(f'back-offs {backoffs}, value-compared {compared} members, worst {worst:.2e}')
+
+
+def test_hard_targets_through_the_models_with_multipliers():
+    """The back-off through Step 1 with G, Step 2 and Step 3 (stage-local multipliers, norm cones): every member Optimal, finite, positive
+    definite, at most 6 back-offs (scripts/robustness_models.py is the wider run: 256 of 256)."""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb, ng, nc = 8, 6, 3, 8, 2, 2
+    n = nx + mb
+    probs = [synthetic.gen_problem(9000 + 13 * b, p, nx, mb, sigP=10.0, cond_exp=5, rad=0.5) for b in range(nb)]
+    A, B, H = (np.stack([q[i] for q in probs]) for i in range(3))
+    rng = np.random.default_rng(805)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
+    outs = dict(G=h.convexify_eq_batch(A, B, H, G), step2=h.convexify_step2_batch(A, B, H, np.concatenate([G, Cc], axis=2), ncnt, 1e-3))
+    h.close()
+    h3 = HipConvexifier(p, nx, mb, step3=True)
+    outs['step3'] = h3.convexify_step3_batch(A, B, H, 1e-3)
+    h3.close()
+    total = 0
+    for model, o in outs.items():
+        assert all(np.isfinite(o[k]).all() for k in ('Hc', 'P', 'kappa')), model
+        assert (o['status'] == 0).all(), (model, o['status'], o['iters'])
+        assert np.linalg.eigvalsh(o['Hc']).min() > 0.0, model
+        mut0 = 2.0 ** np.round(np.log2(2.0 ** -25 * np.maximum(1.0, o['kappa'])))
+        back = np.round(np.log2(o['info'][:, 6] / mut0)).astype(int)
+        assert back.min() >= 0 and back.max() <= 6, (model, back)
+        total += int(back.sum())
+    assert total > 0                                 # the case does exercise the back-off
