@@ -1,5 +1,5 @@
 """Replays one case of parity_fuzz.py (same random stream) and prints the GPU traces and the oracle's of one member/model.
-Usage: python tests/tools/fuzz_case.py <case> <member> <model> [seed] [pmax] [nxmax]"""
+Usage: python tests/tools/fuzz_case.py <case> <member> <plain|G|step2|beta|step3> [seed] [pmax] [nxmax]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,8 +31,12 @@ if model == 'plain':
     o = h.convexify_batch(A, B, H)
 elif model == 'G':
     o = h.convexify_eq_batch(A, B, H, G)
+elif model == 'step3':
+    h.close()
+    h = HipConvexifier(p, nx, mb, step3=True)
+    o = h.convexify_step3_batch(A, B, H, rho)
 else:
-    o = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, rho)
+    o = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, 0.0 if model == 'beta' else rho)
 tr = h.trace(nb)
 b = bsel
 print('gpu status', o['status'][b], 'iters', o['iters'][b], 'kappa', o['kappa'][b], 'info', o['info'][b, 10:16])
@@ -41,7 +45,11 @@ for row in tr[b]:
     print('  it %2d ph %d mu %.3e tau %.8f pinf %.2e dinf %.2e ap %.3f ad %.3f step %.2e shifts %d' % tuple(row))
 t = []
 Cl = [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
-r = co.sdp_step1(A[b], B[b], H[b], trace=t, G=None if model == 'plain' else G[b], C=Cl if model == 'step2' else None, rho=rho if model == 'step2' else None)
+if model == 'step3':
+    r = co.sdp_step1(A[b], B[b], H[b], trace=t, rho=rho, force=True)
+else:
+    r = co.sdp_step1(A[b], B[b], H[b], trace=t, G=None if model == 'plain' else G[b], C=Cl if model in ('step2', 'beta') else None,
+                     rho=rho if model in ('step2', 'beta') else None, cost_free=(model == 'beta'))
 print('oracle', r['ipm_status'], 'iters', r['iters'], 'kappa', r['kappa'], 'shift', r['shift'])
 if model == 'plain':
     Hco = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'])[0]

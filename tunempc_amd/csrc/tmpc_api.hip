@@ -570,7 +570,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   int active = cnt[0], nfac = cnt[0];
-  const int cap = o.max_iter + o.center_iter + 2;
+  // main-phase cap + a centering budget per target the back-off may visit (the CPU restatement's bound).  Only members that keep backing
+  // off get there -- a degenerate Step 3 member of the fuzz (kappa* = 1, damped centering steps at every target) needs ~110 iterations;
+  // until round 3 the wave stopped at max_iter + center_iter + 2 = 64 and such a member came back Feasible.
+  const int cap = o.max_iter + o.center_iter * (MUT_BACKOFF_MAX + 1) + 2;
   int it = 0;
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
