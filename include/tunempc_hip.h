@@ -92,7 +92,9 @@ int tmpc_get_chunk(tmpc_handle* h);
 /* Solver options: tol = complementarity tolerance mu_target/kappa per unit cone dimension, default 2^-25
  * (the relative duality gap on kappa, the max condition number, is then (2*p*n+1)*tol);
  * center_tol = relative Newton step ending the final centering phase, default 1e-9;
- * max_iter / center_iter = iteration caps (defaults 50 / 12); flags = TMPC_FLAG_*.  Values <= 0 keep
+ * max_iter / center_iter = iteration caps (defaults 50 / 12): max_iter bounds the main phase, center_iter the centering iterations
+ * per barrier target -- a hard target may visit up to 11 targets (ten back-offs by powers of two, reported in info[6]), so a problem ends
+ * after at most max_iter + 11 * center_iter + 2 iterations; flags = TMPC_FLAG_*.  Values <= 0 keep
  * the current setting (flags is always applied; bits other than the TMPC_FLAG_* above -- and the debug bit of
  * tunempc_hip_debug.h -- are rejected with TMPC_E_ARG). */
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags);
