@@ -245,7 +245,10 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   int phase = ip[I_PHASE];
   // (a full Newton step removes the linear residuals, so the centering phase may start with pinf well above the final
   // accuracy; waiting for pinf < 1e-6 cost the slowest problems of a batch three extra factorisations)
-  if (phase == PH_MAIN && mut > 0.0 && mu <= 2.0 * mut && dinf < 1e-6 && pinf < 1e-3) {
+  // (with a lifted diagonal the directions are inexact and pinf may sit at 1e-2 ... 1e-1 for good while mu has long arrived at mu_t -- a
+  // cond-1e6 member of the sweep spent its 50 main-phase iterations there: the centering phase, whose contraction test drops the lift and
+  // backs mu_t off, is the way out, and its full Newton steps remove the linear residual once the factorisation is exact again)
+  if (phase == PH_MAIN && mut > 0.0 && mu <= 2.0 * mut && dinf < 1e-6 && (pinf < 1e-3 || ip[I_REG] >= 1)) {
     phase = PH_CENTER;
     ip[I_PHASE] = phase;
   }
