@@ -543,13 +543,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
             mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau))))
         # (a full Newton step removes the linear residuals: centering may start with pinf well above the final accuracy)
-        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and pinf < 1e-3:
+        # (after a shifted factorisation the directions are inexact and pinf may sit at 1e-3 ... 1e-1 while mu has arrived: the centering
+        # phase -- back-off, steps of the exact factorisation one power of two up -- is the way out; the HIP path: k_ctrl_a)
+        if phase == 0 and mu_t is not None and mu <= 2.0 * mu_t and dinf < 1e-6 and (pinf < 1e-3 or nshiftrun >= 1):
             phase = 1
         if phase == 0 and nshiftrun >= 2:
             # the wall met on the way down (the last two factorisations needed a shift before mu reached 2 mu_t): the path cannot be
             # followed below the current mu -- centre at the power of two above it, if the back-off budget covers that (k_ctrl_a)
             kb = max(0, int(np.ceil(np.log2(mu / mu_t))))
-            if dinf < 1e-6 and pinf < 1e-3 and nbackoff + kb <= MUT_BACKOFF_MAX:
+            if dinf < 1e-6 and nbackoff + kb <= MUT_BACKOFF_MAX:
                 mu_t *= 2.0 ** kb; nbackoff += kb; phase = 1; ncent = 0; prev_stepn = None; nshiftrun = 0
             else:
                 status = 'optimal_inaccurate'

@@ -324,10 +324,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     if (it == 0) mu0 = mu;
     if (!(mu > 0.0) || !std::isfinite(mu) || !std::isfinite(tau) || mu > 1e6 * mu0) { ipm = ST_DIV; break; }
     if (mu_t < 0.0 && relgap < 1e-2 && dinf < 1e-2) mu_t = exp2(rint(log2(tol * std::max(1.0, fabs(tau)))));
-    if (phase == 0 && mu_t > 0.0 && mu <= 2.0 * mu_t && dinf < 1e-6 && pinf < 1e-3) phase = 1;
+    if (phase == 0 && mu_t > 0.0 && mu <= 2.0 * mu_t && dinf < 1e-6 && (pinf < 1e-3 || nshiftrun >= 1)) phase = 1;      // (after a shifted factorisation pinf is noise: convexify_oracle.py)
     if (phase == 0 && nshiftrun >= 2) {      // the wall met on the way down: centre at the power of two above the current mu (convexify_oracle.py, k_ctrl_a)
       const int kb = std::max(0, (int)ceil(log2(mu / mu_t)));
-      if (dinf < 1e-6 && pinf < 1e-3 && nbackoff + kb <= MUT_BACKOFF_MAX) { mu_t = ldexp(mu_t, kb); nbackoff += kb; phase = 1; ncent = 0; prev_stepn = -1.0; nshiftrun = 0; }
+      if (dinf < 1e-6 && nbackoff + kb <= MUT_BACKOFF_MAX) { mu_t = ldexp(mu_t, kb); nbackoff += kb; phase = 1; ncent = 0; prev_stepn = -1.0; nshiftrun = 0; }
       else { ipm = ST_INACC; break; }
     }
     if (phase == 0 && it >= max_iter) break;

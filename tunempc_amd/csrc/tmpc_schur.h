@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
     // the path cannot be followed below the current mu -- centre at the power of two above it, if the back-off budget covers that
     // (the CPU restatement used by the tests does the same).  Rounds 1-2 stopped here with an inaccurate point.
     const int kb = (mut > 0.0 && mu > mut) ? (int)ceil(log2(mu / mut)) : 0;
-    if (mut > 0.0 && dinf < 1e-6 && pinf < 1e-3 && ip[I_BACKOFF] + kb <= MUT_BACKOFF_MAX) {
+    if (mut > 0.0 && dinf < 1e-6 && ip[I_BACKOFF] + kb <= MUT_BACKOFF_MAX) {        // (pinf is noise after two safeguarded factorisations)
       mut = ldexp(mut, kb); pr[P_MUT] = mut; ip[I_BACKOFF] += kb;
       phase = PH_CENTER; ip[I_PHASE] = phase; ip[I_SHIFTRUN] = 0; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0;
     } else {
