@@ -231,3 +231,13 @@ def test_hard_target_backs_off_and_ends_optimal():
     A, B, H = synthetic.gen_problem(7000 + 17 * 5, 30, 4, 1, sigP=10.0, cond_exp=5, rad=0.5)
     r = co.sdp_step1(A, B, H)
     assert r['ipm_status'] == 'optimal' and r['mu_target'] > 2.0 ** -25 * r['kappa'] * 1.5
+
+
+def test_hard_target_wall_rule_ignores_pinf_after_a_shift():
+    """cond(Hhat) = 1e8: two shifted factorisations in a row leave pinf at ~7e-3 when mu arrives at mu_t; the centering phase starts
+    anyway (its steps one power of two up remove the residual) instead of ending 'inaccurate' (round 3; the HIP path: k_ctrl_a)."""
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_problem(7000 + 17 * 1, 8, 16, 4, sigP=10.0, cond_exp=8, rad=0.5)
+    r = co.sdp_step1(A, B, H)
+    assert r['ipm_status'] == 'optimal' and r['shift'] > 0.0 and r['pinf'] < 1e-6
+    assert co.check_convergence(A, B, H, r['P'], r['ipm_status'])[0] == co.STATUS_OPTIMAL
