@@ -119,8 +119,14 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev 
       const int node = cr.elim[(size_t)(eoff + j) * CR_EW + CE_NODE];
       const double* Li = w.Linv + ((size_t)b * p + node) * dm.nt * TB * TB + r * TB;
       const double* zi = z + (size_t)node * dp * nc + q;
+      // (all sixteen terms: the entries of L^-1 above the diagonal are exact zeros, and with a fixed trip count the sixteen loads of the
+      // row leave together instead of one L2 round trip per term -- the loop bound r made this the longest phase of the kernel)
+      double li[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) li[k] = Li[k];
       double acc = 0.0;
-      for (int k = 0; k <= r; ++k) acc = fma(Li[k], zi[k * nc], acc);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = fma(li[k], zi[k * nc], acc);
       t[e] = acc;
     }
     __syncthreads();
@@ -140,7 +146,11 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev 
         if (slot < 0) break;
         const double* O = cr_edge(w, dm, b, slot) + r * dp;
         const double* zi = z + (size_t)ur[s ? CU_S1 : CU_S0] * dp * nc + q;
-        for (int k = 0; k < dp; ++k) acc = fma(-O[k], zi[k * nc], acc);
+        double ov[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ov[k] = O[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(-ov[k], zi[k * nc], acc);
       }
       z[(size_t)ur[CU_NODE] * dp * nc + rq] = acc;         // (an entry of a surviving node: nobody else reads or writes it in this phase)
     }
@@ -159,7 +169,11 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev 
         if (slot < 0) continue;
         const double* O = cr_edge(w, dm, b, slot) + r;     // column r of O_x
         const double* zx = z + (size_t)er[s ? CE_NB : CE_NA] * dp * nc + q;
-        for (int k = 0; k < dp; ++k) acc = fma(-O[k * dp], zx[k * nc], acc);
+        double ov[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ov[k] = O[k * dp];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(-ov[k], zx[k * nc], acc);
       }
       t[e] = acc;
     }
@@ -169,8 +183,12 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev 
       const int node = cr.elim[(size_t)(eoff + j) * CR_EW + CE_NODE];
       const double* Li = w.Linv + ((size_t)b * p + node) * dm.nt * TB * TB + r;      // column r of L^-1
       const double* tj = t + (size_t)j * dp * nc + q;
+      double li[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) li[k] = Li[k * TB];       // (zeros for k < r, see the forward sweep)
       double acc = 0.0;
-      for (int k = r; k < dp; ++k) acc = fma(Li[k * TB], tj[k * nc], acc);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = fma(li[k], tj[k * nc], acc);
       z[(size_t)node * dp * nc + rq] = acc;
     }
     __syncthreads();
