@@ -184,3 +184,14 @@ def test_pack_batch_layout():
         pocp.pack_batch([S0, {**S1, 'A': S1['A'][:-1]}], nx)
     with pytest.raises(AssertionError, match='same size along trajectory'):
         pocp.pack_batch([{**S1, 'H': [S1['H'][0], np.eye(n + 1), S1['H'][2]]}], nx)
+
+
+def test_synthetic_generator_knobs():
+    """tunempc_amd.synthetic: the defaults are the benchmark distribution (test above);
+    cond_exp / rad are the knobs of scripts/robustness_sweep.py (conditioning of the hidden SPD target, spectral radius of A_k)."""
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_problem(7, 6, 4, 2, sigP=0.0, cond_exp=5, rad=0.5)          # sigP = 0: H is the hidden target itself
+    rho = [np.max(np.abs(np.linalg.eigvals(A[k]))) for k in range(6)]
+    assert np.allclose(rho, 0.5)
+    ev = np.linalg.eigvalsh(H)
+    assert ev.min() > 0 and 1e2 < (ev[:, -1] / ev[:, 0]).max() <= 1e5 * (1 + 1e-9)
