@@ -33,6 +33,11 @@ import numpy as np
 import scipy.linalg as sla
 from scipy.linalg.blas import dtrsm
 
+try:
+    from . import ddnum as dn
+except ImportError:                                   # tests put oracle/ itself on sys.path
+    import ddnum as dn
+
 ALPHA_MIN = 1e-8          # convexifier.py:245
 STATUS_OPTIMAL, STATUS_FEASIBLE, STATUS_INFEASIBLE = 0, 1, 2
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
@@ -255,6 +260,200 @@ class _CyclicBlockChol:
                 Z[k] -= F[k].T @ Z[p - 1]
             Z[k] = sla.solve_triangular(Lkk[k].T, Z[k], lower=False)
         return Z
+
+
+# ------------------------------------------------------------ the same system in double-double (tight-accuracy mode)
+DD_SWITCH = 2.0 ** -23    # tight mode: block linear algebra in double-double once mu <= DD_SWITCH * max(1, |tau|) (or after a shifted fp64 factorisation)
+
+
+def _T_dd(L, R, ia, ib):
+    """_T for stacked dd factors L, R [p, nx, nx] -> dd [p, d, d] (exact products of the dd entries, dd sums)."""
+    a = ia[:, None]; b = ib[:, None]; c = ia[None, :]; e = ib[None, :]
+    wab = (ia != ib).astype(np.float64)[:, None]; wce = (ia != ib).astype(np.float64)[None, :]
+    t = L[:, a, c] * R[:, b, e]
+    t = t + (L[:, a, e] * R[:, b, c]) * wce
+    t = t + (L[:, b, c] * R[:, a, e]) * wab
+    t = t + (L[:, b, e] * R[:, a, c]) * (wab * wce)
+    return t
+
+
+def _assemble_dd(X1, S1i, X2, S2i, V, nx, ia, ib):
+    """D_k, C_k of the HKM Schur matrix in double-double: the Kronecker-factor images V X V', V S^-1 V', X_E V', S^-1_E V' are formed in dd
+    from the fp64 X, S^-1, V (their fp64 rounding alone, eps |S^-1| ~ eps/mu against eigenvalues ~ mu, is the wall of the fp64 path)."""
+    p = X1.shape[0]
+    d = len(ia)
+    D = dn.zeros((p, d, d)); C = dn.zeros((p, d, d))
+    Vd = dn.DD(V)
+    for (X, Si) in ((X1, S1i), (X2, S2i)):
+        Xd = dn.DD(X); Sd = dn.DD(Si)
+        VX = dn.matmul(Vd, Xd); VS = dn.matmul(Vd, Sd)                  # [p, nx, n]
+        Kx = dn.matmul_nt(VX, Vd); Ks = dn.matmul_nt(VS, Vd)            # V X V'
+        Fx = dn.matmul_nt(Xd[:, :nx, :], Vd); Fs = dn.matmul_nt(Sd[:, :nx, :], Vd)
+        D = D + _T_dd(Xd[:, :nx, :nx], Sd[:, :nx, :nx], ia, ib)
+        Tk = _T_dd(Kx, Ks, ia, ib)
+        D = D + dn.DD(np.roll(Tk.hi, 1, axis=0), np.roll(Tk.lo, 1, axis=0))
+        C = C - _T_dd(Fx, Fs, ia, ib)
+    return D, C
+
+
+class _CyclicBlockCholDD:
+    """_CyclicBlockChol in double-double: same elimination order, no shift (a non-positive pivot raises LinAlgError).
+    solve() takes and returns fp64 right-hand sides / solutions; the substitutions run in dd."""
+    shift = 0.0
+
+    def __init__(self, D, C):
+        p, d, _ = D.shape
+        self.p, self.d = p, d
+        if p <= 2:
+            T = dn.zeros((p * d, p * d))
+            for k in range(p):
+                sl = slice(k * d, (k + 1) * d)
+                T[sl, sl] = T[sl, sl] + D[k]
+                kn = (k + 1) % p
+                sn = slice(kn * d, (kn + 1) * d)
+                if kn == k:
+                    T[sl, sl] = T[sl, sl] + C[k] + C[k].T
+                else:
+                    T[sl, sn] = T[sl, sn] + C[k]
+                    T[sn, sl] = T[sn, sl] + C[k].T
+            self.Ld = dn.cholesky(T)
+            return
+        self.Lkk = [None] * p; self.O = [None] * p; self.F = [None] * p
+        Dw = [D[k].copy() for k in range(p)]
+        Fpre = C[p - 1].copy()                  # block [p-1, 0]
+        for k in range(p - 1):
+            L = dn.cholesky(Dw[k]); self.Lkk[k] = L
+            sub = C[k].T.copy()                 # block [k+1, k]
+            if k == p - 2:
+                sub = sub + Fpre
+                self.O[k] = dn.solve_lower(L, sub.T).T                 # sub L^-T
+                Dw[p - 1] = Dw[p - 1] - dn.matmul_nt(self.O[k], self.O[k])
+            else:
+                self.O[k] = dn.solve_lower(L, sub.T).T
+                self.F[k] = dn.solve_lower(L, Fpre.T).T
+                Dw[k + 1] = Dw[k + 1] - dn.matmul_nt(self.O[k], self.O[k])
+                Dw[p - 1] = Dw[p - 1] - dn.matmul_nt(self.F[k], self.F[k])
+                Fpre = -dn.matmul_nt(self.F[k], self.O[k])
+        self.Lkk[p - 1] = dn.cholesky(Dw[p - 1])
+
+    def solve(self, R):
+        p, d = self.p, self.d
+        if p <= 2:
+            z = dn.solve_lower(self.Ld, R.reshape(p * d, -1))
+            z = dn.solve_lower(self.Ld, z, trans=True)
+            return z.to_float().reshape(R.shape)
+        Lkk, O, F = self.Lkk, self.O, self.F
+        Z = [dn.DD(R[k]) for k in range(p)]
+        for k in range(p - 1):
+            Z[k] = dn.solve_lower(Lkk[k], Z[k])
+            Z[k + 1] = Z[k + 1] - dn.matmul(O[k], Z[k])
+            if k < p - 2:
+                Z[p - 1] = Z[p - 1] - dn.matmul(F[k], Z[k])
+        Z[p - 1] = dn.solve_lower(Lkk[p - 1], Z[p - 1])
+        Z[p - 1] = dn.solve_lower(Lkk[p - 1], Z[p - 1], trans=True)
+        for k in range(p - 2, -1, -1):
+            Z[k] = Z[k] - dn.matmul(O[k].T, Z[k + 1])
+            if k < p - 2:
+                Z[k] = Z[k] - dn.matmul(F[k].T, Z[p - 1])
+            Z[k] = dn.solve_lower(Lkk[k], Z[k], trans=True)
+        return np.stack([z.to_float() for z in Z])
+
+
+POLISH_ENTER = 1e-4       # tight mode: the primal-dual centering phase hands over to the dd dual-Newton polish after a full step this small
+POLISH_MAX = 6
+
+
+def _inv_dd(S):
+    """S [p, n, n] dd, positive definite -> S^-1 (dd) by Cholesky and two substitutions; raises LinAlgError otherwise."""
+    L = dn.cholesky(S)
+    out = dn.zeros(S.shape)
+    eye = np.eye(S.shape[-1])
+    for k in range(S.shape[0]):
+        out[k] = dn.solve_lower(L[k], dn.solve_lower(L[k], eye), trans=True)
+    return out
+
+
+def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False):
+    """Tight mode, last phase: Newton's method on the DUAL barrier problem  min tau - mu (sum logdet S1_k + logdet S2_k + log(alpha - 1e-8))
+    in y = (tau, alpha, P) alone, with every stage quantity in double-double: S_r(y) is formed in dd from the fp64 y (no cancellation in
+    M - I), S_r^-1 in dd, X_r := mu S_r^-1 is not an iterate any more.  The primal-dual iteration stores X and S^-1 as fp64 matrices whose
+    large part (active x active, O(1) resp. 1/mu) buries the small one (~mu resp. O(1)) under an ABSOLUTE rounding error eps, and the
+    directions inside the optimal face are determined by the small part: its centred point is reproducible to ~eps/mu only (1e-7 at
+    mu = 2e-12, measured).  The minimiser of the barrier problem IS the central-path point at mu; two or three steps from the end of the
+    primal-dual centering phase reproduce it to ~1e-12 (two runs on inputs 1e-14 apart).  Returns (tau, alpha, P, X1, X2, ok, steps, stepn)."""
+    p, nx, _ = A.shape
+    n = Hb.shape[1]
+    d = nx * (nx + 1) // 2
+    ia, ib = _tri_idx(nx)
+    V = np.concatenate([A, B], axis=2)
+    Vd = dn.DD(V); Hd = dn.DD(Hb); I = np.eye(n)
+    wsv = np.where(ia == ib, 1.0, 2.0)
+    roll1 = lambda G: dn.DD(np.roll(G.hi, 1, axis=0), np.roll(G.lo, 1, axis=0))
+    sym = lambda G: (G + G.T) * 0.5
+    sv = lambda G: G[:, ia, ib] * wsv
+    adj = lambda G: roll1(dn.matmul_nt(dn.matmul(Vd, G), Vd)) - G[:, :nx, :nx]          # calH_adj in dd
+    tr = lambda G: np.trace(G.to_float(), axis1=1, axis2=2).sum()
+
+    def cones(tau_, alpha_, P_):
+        M = Hd * alpha_ + dn.matmul(dn.matmul(Vd.T, dn.DD(np.roll(P_, -1, axis=0))), Vd)
+        M[:, :nx, :nx] = M[:, :nx, :nx] - dn.DD(P_)
+        if not alpha_ - ALPHA_MIN > 0.0:
+            raise np.linalg.LinAlgError('alpha')
+        return M, _inv_dd(M - I), _inv_dd((-M) + tau_ * I)
+
+    stepn = np.inf
+    X1 = X2 = None
+    ok = False
+    steps = 0
+    try:
+        M, Z1, Z2 = cones(tau, alpha, P)
+    except np.linalg.LinAlgError:
+        return tau, alpha, P, None, None, False, 0, stepn
+    for steps in range(1, POLISH_MAX + 1):
+        s0 = alpha - ALPHA_MIN
+        X1 = Z1 * mu; X2 = Z2 * mu; x0 = mu / s0
+        Dm = dn.zeros((p, d, d)); Cm = dn.zeros((p, d, d))
+        for (X, Z) in ((X1, Z1), (X2, Z2)):
+            Kx = dn.matmul_nt(dn.matmul(Vd, X), Vd); Ks = dn.matmul_nt(dn.matmul(Vd, Z), Vd)
+            Fx = dn.matmul_nt(X[:, :nx, :], Vd); Fs = dn.matmul_nt(Z[:, :nx, :], Vd)
+            Dm = Dm + _T_dd(X[:, :nx, :nx], Z[:, :nx, :nx], ia, ib) + roll1(_T_dd(Kx, Ks, ia, ib))
+            Cm = Cm - _T_dd(Fx, Fs, ia, ib)
+        try:
+            chol = _CyclicBlockCholDD(Dm, Cm)
+        except np.linalg.LinAlgError:
+            break
+        Psi = sym(dn.matmul(X2, Z2)); Ph2 = sym(dn.matmul(dn.matmul(X2, Hd), Z2)); PhiH = sym(dn.matmul(dn.matmul(X1, Hd), Z1)) + Ph2
+        U = np.stack([(-sv(adj(Psi))).to_float(), sv(adj(PhiH)).to_float()], axis=2)
+        Bb = np.array([[tr(Psi), -tr(Ph2)], [-tr(Ph2), np.sum((Hd * PhiH).to_float()) + x0 / s0]])
+        Y = X1 - X2
+        g_tau = 1.0 - tr(X2); g_alpha = -np.sum((Hd * Y).to_float()) - x0
+        rhsP = sv(adj(Y)).to_float()                              # -gradient in P, rounded to fp64 AFTER the subtractions
+        TU = chol.solve(U)
+        Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
+        z = chol.solve(rhsP[:, :, None])[:, :, 0]
+        db = np.linalg.solve(Sb, np.array([-g_tau, -g_alpha]) - np.einsum('kdi,kd->i', U, z))
+        dp = z - TU @ db
+        dP = _smat(dp, nx, ia, ib)
+        Mf = M.to_float()
+        dM = db[1] * Hb + calH(A, B, dP)
+        stepn = np.sqrt(np.sum((dM - (db[1] / alpha) * Mf) ** 2) / np.sum(Mf ** 2))
+        th = 1.0
+        while True:                                               # damped only if the full step leaves the cone (not seen after the centering phase)
+            try:
+                M, Z1, Z2 = cones(tau + th * db[0], alpha + th * db[1], P + th * dP)
+                break
+            except np.linalg.LinAlgError:
+                th *= 0.5
+                if th < 1e-3:
+                    return tau, alpha, P, X1.to_float(), X2.to_float(), False, steps, stepn
+        tau += th * db[0]; alpha += th * db[1]; P = P + th * dP
+        if verbose:
+            print(f"      polish {steps}: |dy|rel={stepn:.3e} step={th:.3f}")
+        if th == 1.0 and stepn < center_tol:
+            ok = True
+            break
+    X1 = (Z1 * mu).to_float(); X2 = (Z2 * mu).to_float()
+    return tau, alpha, P, X1, X2, ok, steps, stepn
 
 
 # ------------------------------------------------------------ small batched helpers
@@ -488,6 +687,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     arrows.append(dict(k=k, idx=idx, t=t0, soc=False, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
+    tight = bool(o.get('tight', False))       # tight-accuracy mode (plain model): see DD_SWITCH
+    assert not (tight and ng), 'tight mode: plain Step 1 model only'
+    dd_on = False
+    ndd = 0
     extrap_terms = None
     phase = 0
     ncent = 0
@@ -564,13 +767,23 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
         # ---- Schur complement pieces
         # nx x nx Kronecker factors per LMI block
         if refactor:
-          D = np.zeros((p, d, d)); C = np.zeros((p, d, d))
-          for (X, Si) in ((X1, S1i), (X2, S2i)):
-            Kx = V @ X @ Vt; Ks = V @ Si @ Vt            # V-side (P_{k+1})
-            Fx = X[:, :nx, :] @ Vt; Fs = Si[:, :nx, :] @ Vt   # cross  (E . V')
-            D += _hkm_block(X[:, :nx, :nx], Si[:, :nx, :nx], ia, ib)
-            D += np.roll(_hkm_block(Kx, Ks, ia, ib), 1, axis=0)
-            C -= _hkm_block(Fx, Fs, ia, ib)
+          def _blocks64():
+              D_ = np.zeros((p, d, d)); C_ = np.zeros((p, d, d))
+              for (X, Si) in ((X1, S1i), (X2, S2i)):
+                  Kx = V @ X @ Vt; Ks = V @ Si @ Vt            # V-side (P_{k+1})
+                  Fx = X[:, :nx, :] @ Vt; Fs = Si[:, :nx, :] @ Vt   # cross  (E . V')
+                  D_ += _hkm_block(X[:, :nx, :nx], Si[:, :nx, :nx], ia, ib)
+                  D_ += np.roll(_hkm_block(Kx, Ks, ia, ib), 1, axis=0)
+                  C_ -= _hkm_block(Fx, Fs, ia, ib)
+              return D_, C_
+          # tight mode: the blocks, their factorisation and the substitutions in double-double once the iterate is within DD_SWITCH of the
+          # boundary (cond of the Schur matrix ~ (tau/mu)^2), or as soon as the fp64 factorisation needs a shift
+          if tight and not dd_on and mu <= DD_SWITCH * max(1.0, abs(tau)):
+              dd_on = True
+          if o.get('_assemble') is not None:            # (experiment hook of tests/tools/tight_probe.py: block assembly in extended precision)
+              D, C = o['_assemble'](X1, S1i, X2, S2i, V, nx, ia, ib)
+          elif not dd_on:
+              D, C = _blocks64()
           # border columns (tau, alpha)
           Psi = symmetrize(X2 @ S2i)                              # Phi2(I)
           PhiH = symmetrize(X1 @ Hb @ S1i) + symmetrize(X2 @ Hb @ S2i)
@@ -579,7 +792,17 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
           b_tt = np.trace(Psi, axis1=1, axis2=2).sum()
           b_ta = -np.trace(symmetrize(X2 @ Hb @ S2i), axis1=1, axis2=2).sum()
           b_aa = np.sum(Hb * PhiH) + x0 / s0
-          chol = _CyclicBlockChol(D, C)
+          if not dd_on:
+              chol = o.get('_chol_cls', _CyclicBlockChol)(D, C)
+              if tight and chol.shift > 0.0:
+                  dd_on = True
+          if dd_on:
+              ndd += 1
+              try:
+                  chol = _CyclicBlockCholDD(*_assemble_dd(X1, S1i, X2, S2i, V, nx, ia, ib))
+              except np.linalg.LinAlgError:
+                  status = 'optimal_inaccurate'
+                  break
           shift_used = max(shift_used, chol.shift)
           nshiftrun = nshiftrun + 1 if chol.shift > 0.0 else 0
           if phase == 1 and chol.shift > 0.0 and nbackoff < MUT_BACKOFF_MAX:
@@ -792,6 +1015,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             # linearly, r^2 * stepn in its quadratic regime; r^1.5 sits between the two and stops one iteration early
             # when the convergence is already super-linear
             est = stepn * min(1.0, stepn / prev_stepn) ** 1.5 if prev_stepn is not None else stepn
+            if tight and full and stepn < POLISH_ENTER:
+                status = 'polish'
+                break
             if full and (stepn < o['center_tol'] or est < 0.1 * o['center_tol']):
                 status = 'optimal'
                 if o.get('extrap', 0):        # measurement hook (tests/tools/path_sensitivity.py): Taylor model of the central path at the returned point
@@ -808,9 +1034,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                 status = 'optimal_inaccurate'
                 break
             prev_stepn = stepn if full else None
+    npolish = 0
+    if status == 'polish':
+        tau, alpha, P, Xp1, Xp2, okp, npolish, stepn = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose)
+        status = 'optimal' if okp else 'optimal_inaccurate'
+        if Xp1 is not None:
+            X1, X2 = Xp1, Xp2; s0 = alpha - ALPHA_MIN; x0 = mu_t / s0
     Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
     out = dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
-               ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used)
+               ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used, dd_iters=ndd, polish_steps=npolish, stepn=stepn, X1=X1, X2=X2, x0=x0)
     if o.get('extrap', 0) and status == 'optimal':
         out['extrap_terms'] = extrap_terms                  # scaled variables: y(t) = (tau, alpha, Pbar) + sum_k t^k terms[k-1]
         out['Pbar'] = P

@@ -27,13 +27,16 @@ def load():
         dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)
         lib.cpu_ipm_convexify_batch.restype = C.c_int
         lib.cpu_ipm_convexify_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp, C.c_double, C.c_int, dp, dp, ip, ip]
+        lib.cpu_ipm_convexify_batch2.restype = C.c_int
+        lib.cpu_ipm_convexify_batch2.argtypes = [C.c_int] * 4 + [dp, dp, dp, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip, dp]
         lib.cpu_ipm_max_threads.restype = C.c_int
         _lib = lib
     return _lib
 
 
-def convexify_batch(A, B, H, tol=0.0, threads=1):
-    """A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict(Hc, kappa, status, iters); `threads` OpenMP threads, one problem each."""
+def convexify_batch(A, B, H, tol=0.0, threads=1, tight=False):
+    """A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict(Hc, kappa, status, iters); `threads` OpenMP threads, one problem each.
+    tight: the tight-accuracy mode (double-double block linear algebra + dual-Newton polish; adds mu_t, dd_iters, polish_steps, stepn)."""
     lib = load()
     A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64); H = np.ascontiguousarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
@@ -41,6 +44,13 @@ def convexify_batch(A, B, H, tol=0.0, threads=1):
     Hc = np.empty_like(H); kappa = np.empty(nb); status = np.empty(nb, np.int32); iters = np.empty(nb, np.int32)
     d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    if tight:
+        info = np.zeros((nb, 4))
+        rc = lib.cpu_ipm_convexify_batch2(nb, p, nx, mb, d(A), d(B), d(H), float(tol), int(threads), 1, d(Hc), d(kappa), i(status), i(iters), d(info))
+        if rc != 0:
+            raise RuntimeError('cpu_ipm_convexify_batch2 failed: %d' % rc)
+        return dict(Hc=Hc, kappa=kappa, status=status, iters=iters, mu_t=info[:, 0], dd_iters=info[:, 1].astype(int),
+                    polish_steps=info[:, 2].astype(int), stepn=info[:, 3])
     rc = lib.cpu_ipm_convexify_batch(nb, p, nx, mb, d(A), d(B), d(H), float(tol), int(threads), d(Hc), d(kappa), i(status), i(iters))
     if rc != 0:
         raise RuntimeError('cpu_ipm_convexify_batch failed: %d' % rc)

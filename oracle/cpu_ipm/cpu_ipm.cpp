@@ -89,6 +89,120 @@ struct Small {
   }
 };
 
+// ---------------------------------------------------------------- double-double ("dd") arithmetic for the tight-accuracy mode
+// (oracle/ddnum.py is the numpy twin; algorithms: Dekker 1971, Knuth 4.2.2, Hida-Li-Bailey's QD).  A value is hi + lo, |lo| <= ulp(hi)/2.
+// Block kernels work on split arrays (hi[], lo[]) with branch-free inner loops over contiguous entries, which gcc vectorises (AVX2 + FMA).
+namespace ddk {
+struct dd { double h, l; };
+static inline dd qts(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+static inline dd ts(double a, double b) { const double s = a + b, v = s - a; return {s, (a - (s - v)) + (b - v)}; }
+static inline dd tp(double a, double b) { const double p = a * b; return {p, fma(a, b, -p)}; }
+static inline dd add(dd a, dd b) { dd s = ts(a.h, b.h); const dd t = ts(a.l, b.l); s.l += t.h; s = qts(s.h, s.l); s.l += t.l; return qts(s.h, s.l); }
+static inline dd neg(dd a) { return {-a.h, -a.l}; }
+static inline dd sub(dd a, dd b) { return add(a, neg(b)); }
+static inline dd mul(dd a, dd b) { dd p = tp(a.h, b.h); p.l += a.h * b.l + a.l * b.h; return qts(p.h, p.l); }
+static inline dd muld(dd a, double b) { dd p = tp(a.h, b); p.l += a.l * b; return qts(p.h, p.l); }
+static inline dd from(double a) { return {a, 0.0}; }
+static inline double val(dd a) { return a.h + a.l; }
+static inline dd div(dd a, dd b) {
+  const double q1 = a.h / b.h; dd r = sub(a, muld(b, q1));
+  const double q2 = r.h / b.h; r = sub(r, muld(b, q2));
+  const double q3 = r.h / b.h;
+  return add(qts(q1, q2), from(q3));
+}
+static inline dd sqrt_(dd a) { const double x = 1.0 / sqrt(a.h), ax = a.h * x; const double err = sub(a, tp(ax, ax)).h; return qts(ax, err * x * 0.5); }
+
+// c[0..n) -= a * b[0..n)   (dd scalar a, split dd vectors)
+static inline void axpy_sub(double* __restrict ch, double* __restrict cl, double ah, double al, const double* __restrict bh, const double* __restrict bl, int n) {
+#pragma omp simd
+  for (int j = 0; j < n; ++j) {
+    const double p = ah * bh[j];
+    double e = fma(ah, bh[j], -p); e = fma(ah, bl[j], e); e = fma(al, bh[j], e);
+    const double c0 = ch[j], s = c0 - p, v = s - c0;
+    double t = (c0 - (s - v)) + (-p - v);
+    t += cl[j] - e;
+    const double h = s + t;
+    cl[j] = t - (h - s); ch[j] = h;
+  }
+}
+// c[0..n) *= a
+static inline void scale(double* __restrict ch, double* __restrict cl, dd a, int n) {
+  for (int j = 0; j < n; ++j) { const dd r = mul(dd{ch[j], cl[j]}, a); ch[j] = r.h; cl[j] = r.l; }
+}
+// lower Cholesky in place (row-major n x n, leading dimension ld, lower part used / written); false on a non-positive pivot
+static bool potrf(double* Ah, double* Al, int n, int ld, std::vector<double>& tmp) {
+  tmp.resize(2 * (size_t)n);
+  double* colh = tmp.data(); double* coll = colh + n;
+  for (int j = 0; j < n; ++j) {
+    const dd piv{Ah[(size_t)j * ld + j], Al[(size_t)j * ld + j]};
+    if (!(piv.h > 0.0)) return false;
+    const dd r = sqrt_(piv);
+    Ah[(size_t)j * ld + j] = r.h; Al[(size_t)j * ld + j] = r.l;
+    const dd rinv = div(from(1.0), r);
+    for (int i = j + 1; i < n; ++i) {
+      const dd v = mul(dd{Ah[(size_t)i * ld + j], Al[(size_t)i * ld + j]}, rinv);
+      Ah[(size_t)i * ld + j] = v.h; Al[(size_t)i * ld + j] = v.l; colh[i] = v.h; coll[i] = v.l;
+    }
+    for (int i = j + 1; i < n; ++i)      // A[i][j+1..i] -= l_ij * l_{j+1..i, j}
+      axpy_sub(Ah + (size_t)i * ld + j + 1, Al + (size_t)i * ld + j + 1, colh[i], coll[i], colh + j + 1, coll + j + 1, i - j);
+  }
+  return true;
+}
+// Xt (n x m, row-major, rows = columns of X) <- solution of X L' = E given Et = E' in Xt:  Xt[j][:] = (Et[j][:] - sum_{k<j} L[j][k] Xt[k][:]) / L[j][j]
+static void trsm_t(double* Xh, double* Xl, int m, const double* Lh, const double* Ll, int n, int ld, bool par) {
+  const int nth = par ? omp_get_max_threads() : 1;
+#pragma omp parallel for schedule(static) num_threads(nth) if (par)
+  for (int c = 0; c < nth; ++c) {
+    const int i0 = (int)((long)m * c / nth), i1 = (int)((long)m * (c + 1) / nth), len = i1 - i0;
+    if (len <= 0) continue;
+    for (int j = 0; j < n; ++j) {
+      double* xh = Xh + (size_t)j * m + i0; double* xl = Xl + (size_t)j * m + i0;
+      for (int k = 0; k < j; ++k) axpy_sub(xh, xl, Lh[(size_t)j * ld + k], Ll[(size_t)j * ld + k], Xh + (size_t)k * m + i0, Xl + (size_t)k * m + i0, len);
+      scale(xh, xl, div(from(1.0), dd{Lh[(size_t)j * ld + j], Ll[(size_t)j * ld + j]}), len);
+    }
+  }
+}
+// C (n x n row-major) -= At' Bt  with At, Bt (k x n row-major); lower: only j <= i
+static void gemm_tn_sub(double* Ch, double* Cl, const double* Ath, const double* Atl, const double* Bth, const double* Btl, int n, int kk, bool lower, bool par) {
+#pragma omp parallel for schedule(dynamic, 4) if (par)
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < kk; ++k)
+      axpy_sub(Ch + (size_t)i * n, Cl + (size_t)i * n, Ath[(size_t)k * n + i], Atl[(size_t)k * n + i], Bth + (size_t)k * n, Btl + (size_t)k * n, lower ? i + 1 : n);
+}
+// small dense dd matrices (stage level, n <= 32): plain loops
+typedef std::vector<dd> mat;
+static void mm(mat& C, const mat& A, const mat& B, int m, int k, int n, bool bt) {      // C (m x n) = A (m x k) B (k x n), or A B' with B (n x k) when bt
+  C.assign((size_t)m * n, dd{0.0, 0.0});
+  for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+    dd s{0.0, 0.0};
+    for (int q = 0; q < k; ++q) s = add(s, mul(A[(size_t)i * k + q], bt ? B[(size_t)j * k + q] : B[(size_t)q * n + j]));
+    C[(size_t)i * n + j] = s;
+  }
+}
+static bool inv_spd(mat& Z, const mat& S, int n) {                       // Z = S^-1 by Cholesky and two substitutions per column
+  mat L(S);
+  for (int j = 0; j < n; ++j) {
+    dd s = L[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s = sub(s, mul(L[(size_t)j * n + k], L[(size_t)j * n + k]));
+    if (!(s.h > 0.0)) return false;
+    const dd r = sqrt_(s); L[(size_t)j * n + j] = r;
+    for (int i = j + 1; i < n; ++i) {
+      dd t = L[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) t = sub(t, mul(L[(size_t)i * n + k], L[(size_t)j * n + k]));
+      L[(size_t)i * n + j] = div(t, r);
+    }
+  }
+  Z.assign((size_t)n * n, dd{0.0, 0.0});
+  std::vector<dd> y(n);
+  for (int c = 0; c < n; ++c) {
+    for (int i = 0; i < n; ++i) { dd t = from(i == c ? 1.0 : 0.0); for (int k = 0; k < i; ++k) t = sub(t, mul(L[(size_t)i * n + k], y[k])); y[i] = div(t, L[(size_t)i * n + i]); }
+    for (int i = n - 1; i >= 0; --i) { dd t = y[i]; for (int k = i + 1; k < n; ++k) t = sub(t, mul(L[(size_t)k * n + i], y[k])); y[i] = div(t, L[(size_t)i * n + i]); }
+    for (int i = 0; i < n; ++i) Z[(size_t)i * n + c] = y[i];
+  }
+  return true;
+}
+}  // namespace ddk
+
 // ---------------------------------------------------------------- one tuning problem
 struct Problem {
   int p, nx, mb, n, d;
@@ -251,11 +365,161 @@ struct Problem {
   }
 };
 
-struct Result { double kappa, alpha; int status, iters, early; };
+// ---------------------------------------------------------------- the block-cyclic-tridiagonal system in double-double (tight mode)
+// Same elimination order as Problem::factor_once, no shift.  Row-major d x d blocks, split hi / lo arrays.  C_k = T[P_k, P_{k+1}] (rows P_k);
+// the factors O_k = [k+1][k] L_k^-T and F_k = [p-1][k] L_k^-T are kept TRANSPOSED (Ot_k: rows = index of stage k), which makes every inner
+// loop of the triangular solves, the updates and the forward substitution a contiguous dd axpy.
+struct DdSys {
+  int p = 0, d = 0; bool par = false;
+  std::vector<double> Dh, Dl, Ch, Cl, Oh, Ol, Fh, Fl, Nh, Nl, tmp, fph, fpl;
+  void init(int p_, int d_, bool par_) {
+    p = p_; d = d_; par = par_;
+    const size_t n = (size_t)p * d * d;
+    Dh.assign(n, 0.0); Dl.assign(n, 0.0); Ch.assign(n, 0.0); Cl.assign(n, 0.0);
+  }
+  // M[(ab)][(cd)] += sg * T(L, R)[(ab),(cd)]   (Problem::add_T in dd; L, R nx x nx dd, row-major block M)
+  static void add_T(double* Mh, double* Ml, const ddk::mat& L, const ddk::mat& R, double sg, int nx, int d, const std::vector<int>& ia, const std::vector<int>& ib) {
+    using namespace ddk;
+    for (int r = 0; r < d; ++r) {
+      const int a = ia[r], b = ib[r];
+      const double wr = (a == b) ? 0.5 : 1.0;
+      for (int c = 0; c < d; ++c) {
+        const int cc = ia[c], e = ib[c];
+        const double wgt = sg * wr * ((cc == e) ? 0.5 : 1.0);
+        dd t = add(add(mul(L[a * nx + cc], R[b * nx + e]), mul(L[a * nx + e], R[b * nx + cc])), add(mul(L[b * nx + cc], R[a * nx + e]), mul(L[b * nx + e], R[a * nx + cc])));
+        t = muld(t, wgt);                                                          // (a power of two: exact)
+        const dd v = add(dd{Mh[(size_t)r * d + c], Ml[(size_t)r * d + c]}, t);
+        Mh[(size_t)r * d + c] = v.h; Ml[(size_t)r * d + c] = v.l;
+      }
+    }
+  }
+  bool factor() {
+    const size_t bs = (size_t)d * d;
+    if (p <= 2) {
+      const int N = p * d;
+      Nh.assign((size_t)N * N, 0.0); Nl.assign((size_t)N * N, 0.0);
+      auto acc = [&](int r, int c, double h, double l) { const ddk::dd v = ddk::add(ddk::dd{Nh[(size_t)r * N + c], Nl[(size_t)r * N + c]}, ddk::dd{h, l}); Nh[(size_t)r * N + c] = v.h; Nl[(size_t)r * N + c] = v.l; };
+      for (int k = 0; k < p; ++k) {
+        const int kn = (k + 1) % p;
+        for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) {
+          acc(k * d + i, k * d + j, Dh[k * bs + (size_t)i * d + j], Dl[k * bs + (size_t)i * d + j]);
+          const double ch = Ch[k * bs + (size_t)i * d + j], cl = Cl[k * bs + (size_t)i * d + j];
+          if (kn == k) { acc(i, j, ch, cl); acc(j, i, ch, cl); }
+          else { acc(k * d + i, kn * d + j, ch, cl); acc(kn * d + j, k * d + i, ch, cl); }
+        }
+      }
+      return ddk::potrf(Nh.data(), Nl.data(), N, N, tmp);
+    }
+    Oh.assign((size_t)p * bs, 0.0); Ol.assign((size_t)p * bs, 0.0); Fh.assign((size_t)p * bs, 0.0); Fl.assign((size_t)p * bs, 0.0);
+    fph.assign(bs, 0.0); fpl.assign(bs, 0.0);                                       // Fpre' : block [k][p-1]
+    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) { fph[(size_t)j * d + i] = Ch[(p - 1) * bs + (size_t)i * d + j]; fpl[(size_t)j * d + i] = Cl[(p - 1) * bs + (size_t)i * d + j]; }
+    for (int k = 0; k < p - 1; ++k) {
+      double* Lh = &Dh[k * bs]; double* Ll = &Dl[k * bs];
+      if (!ddk::potrf(Lh, Ll, d, d, tmp)) return false;
+      double* oh = &Oh[k * bs]; double* ol = &Ol[k * bs];
+      memcpy(oh, &Ch[k * bs], bs * sizeof(double)); memcpy(ol, &Cl[k * bs], bs * sizeof(double));       // E' of O_k = C_k
+      if (k == p - 2) {
+        for (size_t e = 0; e < bs; ++e) { const ddk::dd v = ddk::add(ddk::dd{oh[e], ol[e]}, ddk::dd{fph[e], fpl[e]}); oh[e] = v.h; ol[e] = v.l; }
+        ddk::trsm_t(oh, ol, d, Lh, Ll, d, d, par);
+        ddk::gemm_tn_sub(&Dh[(size_t)(p - 1) * bs], &Dl[(size_t)(p - 1) * bs], oh, ol, oh, ol, d, d, true, par);
+      } else {
+        double* fh = &Fh[k * bs]; double* fl = &Fl[k * bs];
+        memcpy(fh, fph.data(), bs * sizeof(double)); memcpy(fl, fpl.data(), bs * sizeof(double));
+        ddk::trsm_t(oh, ol, d, Lh, Ll, d, d, par);
+        ddk::trsm_t(fh, fl, d, Lh, Ll, d, d, par);
+        ddk::gemm_tn_sub(&Dh[(size_t)(k + 1) * bs], &Dl[(size_t)(k + 1) * bs], oh, ol, oh, ol, d, d, true, par);
+        ddk::gemm_tn_sub(&Dh[(size_t)(p - 1) * bs], &Dl[(size_t)(p - 1) * bs], fh, fl, fh, fl, d, d, true, par);
+        std::fill(fph.begin(), fph.end(), 0.0); std::fill(fpl.begin(), fpl.end(), 0.0);
+        ddk::gemm_tn_sub(fph.data(), fpl.data(), oh, ol, fh, fl, d, d, false, par);       // ([p-1][k+1])' = -O_k F_k'
+      }
+    }
+    return ddk::potrf(&Dh[(size_t)(p - 1) * bs], &Dl[(size_t)(p - 1) * bs], d, d, tmp);
+  }
+  static void fwd(const double* Lh, const double* Ll, int n, int ld, ddk::dd* z) {
+    for (int i = 0; i < n; ++i) { ddk::dd t = z[i]; for (int j = 0; j < i; ++j) t = ddk::sub(t, ddk::mul(ddk::dd{Lh[(size_t)i * ld + j], Ll[(size_t)i * ld + j]}, z[j])); z[i] = ddk::div(t, ddk::dd{Lh[(size_t)i * ld + i], Ll[(size_t)i * ld + i]}); }
+  }
+  static void bwd(const double* Lh, const double* Ll, int n, int ld, ddk::dd* z) {
+    for (int i = n - 1; i >= 0; --i) { ddk::dd t = z[i]; for (int j = i + 1; j < n; ++j) t = ddk::sub(t, ddk::mul(ddk::dd{Lh[(size_t)j * ld + i], Ll[(size_t)j * ld + i]}, z[j])); z[i] = ddk::div(t, ddk::dd{Lh[(size_t)i * ld + i], Ll[(size_t)i * ld + i]}); }
+  }
+  // R: nrhs vectors [p][d] (fp64 in, fp64 out); substitutions in dd
+  void solve(double* R, int nrhs) const {
+    const size_t bs = (size_t)d * d;
+    std::vector<ddk::dd> z((size_t)p * d);
+    for (int q = 0; q < nrhs; ++q) {
+      double* r = R + (size_t)q * p * d;
+      for (size_t e = 0; e < z.size(); ++e) z[e] = ddk::from(r[e]);
+      if (p <= 2) { const int N = p * d; fwd(Nh.data(), Nl.data(), N, N, z.data()); bwd(Nh.data(), Nl.data(), N, N, z.data()); }
+      else {
+        auto sub_t = [&](ddk::dd* y, const double* Th, const double* Tl, const ddk::dd* x) {      // y -= T' x  (T = Ot: y_i -= sum_q Ot[q][i] x_q)
+          for (int qq = 0; qq < d; ++qq) for (int i = 0; i < d; ++i) y[i] = ddk::sub(y[i], ddk::mul(ddk::dd{Th[(size_t)qq * d + i], Tl[(size_t)qq * d + i]}, x[qq]));
+        };
+        auto sub_n = [&](ddk::dd* y, const double* Th, const double* Tl, const ddk::dd* x) {      // y -= T x   (y_q -= sum_i Ot[q][i] x_i)
+          for (int qq = 0; qq < d; ++qq) { ddk::dd t = y[qq]; for (int i = 0; i < d; ++i) t = ddk::sub(t, ddk::mul(ddk::dd{Th[(size_t)qq * d + i], Tl[(size_t)qq * d + i]}, x[i])); y[qq] = t; }
+        };
+        for (int k = 0; k < p - 1; ++k) {
+          fwd(&Dh[k * bs], &Dl[k * bs], d, d, &z[(size_t)k * d]);
+          sub_t(&z[(size_t)(k + 1) * d], &Oh[k * bs], &Ol[k * bs], &z[(size_t)k * d]);
+          if (k < p - 2) sub_t(&z[(size_t)(p - 1) * d], &Fh[k * bs], &Fl[k * bs], &z[(size_t)k * d]);
+        }
+        fwd(&Dh[(size_t)(p - 1) * bs], &Dl[(size_t)(p - 1) * bs], d, d, &z[(size_t)(p - 1) * d]);
+        bwd(&Dh[(size_t)(p - 1) * bs], &Dl[(size_t)(p - 1) * bs], d, d, &z[(size_t)(p - 1) * d]);
+        for (int k = p - 2; k >= 0; --k) {
+          sub_n(&z[(size_t)k * d], &Oh[k * bs], &Ol[k * bs], &z[(size_t)(k + 1) * d]);
+          if (k < p - 2) sub_n(&z[(size_t)k * d], &Fh[k * bs], &Fl[k * bs], &z[(size_t)(p - 1) * d]);
+          bwd(&Dh[k * bs], &Dl[k * bs], d, d, &z[(size_t)k * d]);
+        }
+      }
+      for (size_t e = 0; e < z.size(); ++e) r[e] = ddk::val(z[e]);
+    }
+  }
+};
+
+// blocks D_k, C_k in dd from the stage pairs (X_r, Z_r = S_r^-1), r = 1, 2, given as dd matrices (fp64 iterates: lo = 0)
+static void assemble_dd(DdSys& sys, const Problem& pr, const std::vector<ddk::mat>& X1, const std::vector<ddk::mat>& Z1, const std::vector<ddk::mat>& X2,
+                        const std::vector<ddk::mat>& Z2) {
+  using namespace ddk;
+  const int p = pr.p, nx = pr.nx, n = pr.n, d = pr.d;
+  sys.init(p, d, sys.par);
+  const size_t bs = (size_t)d * d;
+#pragma omp parallel for schedule(dynamic, 1) if (sys.par)
+  for (int k = 0; k < p; ++k) {
+    mat Vd((size_t)nx * n), Fx, Fs, Xe((size_t)nx * nx), Ze((size_t)nx * nx), Xr((size_t)nx * n), Zr((size_t)nx * n);
+    for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+    for (int r = 0; r < 2; ++r) {
+      const mat& X = r ? X2[k] : X1[k]; const mat& Z = r ? Z2[k] : Z1[k];
+      for (int a = 0; a < nx; ++a) for (int c = 0; c < n; ++c) { Xr[(size_t)a * n + c] = X[(size_t)a * n + c]; Zr[(size_t)a * n + c] = Z[(size_t)a * n + c]; }
+      mm(Fx, Xr, Vd, nx, n, nx, true); mm(Fs, Zr, Vd, nx, n, nx, true);
+      for (int a = 0; a < nx; ++a) for (int c = 0; c < nx; ++c) { Xe[a * nx + c] = X[(size_t)a * n + c]; Ze[a * nx + c] = Z[(size_t)a * n + c]; }
+      DdSys::add_T(&sys.Dh[k * bs], &sys.Dl[k * bs], Xe, Ze, 1.0, nx, d, pr.ia, pr.ib);
+      DdSys::add_T(&sys.Ch[k * bs], &sys.Cl[k * bs], Fx, Fs, -1.0, nx, d, pr.ia, pr.ib);
+    }
+  }
+  // second sweep for the V-side terms (a different block than the loop index: no races)
+  sys.Oh.assign((size_t)p * bs, 0.0); sys.Ol.assign((size_t)p * bs, 0.0);
+#pragma omp parallel for schedule(dynamic, 1) if (sys.par)
+  for (int k = 0; k < p; ++k) {
+    mat Vd((size_t)nx * n), t, Kx, Ks;
+    for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+    for (int r = 0; r < 2; ++r) {
+      const mat& X = r ? X2[k] : X1[k]; const mat& Z = r ? Z2[k] : Z1[k];
+      mm(t, Vd, X, nx, n, n, false); mm(Kx, t, Vd, nx, n, nx, true);
+      mm(t, Vd, Z, nx, n, n, false); mm(Ks, t, Vd, nx, n, nx, true);
+      DdSys::add_T(&sys.Oh[k * bs], &sys.Ol[k * bs], Kx, Ks, 1.0, nx, d, pr.ia, pr.ib);
+    }
+  }
+  for (int k = 0; k < p; ++k) {
+    const int kn = (k + 1) % p;
+    for (size_t e = 0; e < bs; ++e) { const dd v = add(dd{sys.Dh[kn * bs + e], sys.Dl[kn * bs + e]}, dd{sys.Oh[k * bs + e], sys.Ol[k * bs + e]}); sys.Dh[kn * bs + e] = v.h; sys.Dl[kn * bs + e] = v.l; }
+  }
+}
+
+struct Result { double kappa, alpha; int status, iters, early; double mu_t = 0, stepn = 0; int dd_iters = 0, polish = 0; };
+constexpr double DD_SWITCH = 0x1p-23, POLISH_ENTER = 1e-4;      // as oracle/convexify_oracle.py
+constexpr int POLISH_MAX = 6;
 
 // status codes as include/tunempc_hip.h: 0 Optimal, 1 Feasible, 2 Infeasible
 Result solve_problem(int p, int nx, int mb, const double* A, const double* B, const double* Hin, double tol, int max_iter, int center_iter,
-                     double center_tol, double* Hc_out) {
+                     double center_tol, double* Hc_out, bool tight = false, bool par = false) {
   const int n = nx + mb, nn = n * n, d = nx * (nx + 1) / 2, nxx = nx * nx;
   Small sm(n);
   Result res; res.kappa = 0; res.alpha = 1; res.status = 0; res.iters = 0; res.early = 0;
@@ -292,6 +556,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
   int phase = 0, ncent = 0, njam = 0, nshiftrun = 0, nbackoff = 0, it = 0;
   const int MUT_BACKOFF_MAX = 10;          // as the oracle and the HIP path
   enum { ST_MAXIT, ST_OPT, ST_INACC, ST_DIV } ipm = ST_MAXIT;
+  bool dd_on = false, polish = false; int ndd = 0;      // tight mode (convexify_oracle.py: DD_SWITCH, _polish_dd)
+  DdSys dsys; dsys.par = par;
+  std::vector<ddk::mat> qX1, qZ1, qX2, qZ2;
+  auto to_dd = [&](std::vector<ddk::mat>& out, const vec& src) { out.resize(p); for (int k = 0; k < p; ++k) { out[k].resize(nn); for (int e = 0; e < nn; ++e) out[k][e] = ddk::from(src[(size_t)k * nn + e]); } };
   auto dot = [&](const vec& a, const vec& b) { double v = 0; for (size_t e = 0; e < PN; ++e) v += a[e] * b[e]; return v; };
   auto trace_sum = [&](const vec& a) { double v = 0; for (int k = 0; k < p; ++k) for (int i = 0; i < n; ++i) v += a[((size_t)k * n + i) * n + i]; return v; };
   auto max_step = [&](const vec& Li, const vec& dXv) {
@@ -348,9 +616,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       }
     }
     if (!ok) { ipm = ST_DIV; break; }
+    if (tight && !dd_on && mu <= DD_SWITCH * std::max(1.0, fabs(tau))) dd_on = true;
     // ---- Schur complement blocks from the Kronecker factors
     std::fill(pr.D.begin(), pr.D.end(), 0.0); std::fill(pr.Csub.begin(), pr.Csub.end(), 0.0);
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 2 && !dd_on; ++r) {
       const vec& X = r ? X2 : X1; const vec& Si = r ? S2i : S1i;
       for (int k = 0; k < p; ++k) {
         const size_t o = (size_t)k * nn; const double* v = pr.Vk(k); const int kn = (k + 1) % p;
@@ -381,13 +650,24 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     for (int k = 0; k < p; ++k) { pr.svec_grad(&U[(size_t)k * d], &adjb[(size_t)k * nxx]); for (int e = 0; e < d; ++e) U[(size_t)k * d + e] = -U[(size_t)k * d + e]; }
     pr.adj(adjb, PhiH);
     for (int k = 0; k < p; ++k) pr.svec_grad(&U[(size_t)(p + k) * d], &adjb[(size_t)k * nxx]);
-    if (!pr.factor()) { ipm = ST_INACC; break; }
+    if (!dd_on) {
+      if (!pr.factor()) { ipm = ST_INACC; break; }
+      if (tight && pr.shift > 0.0) dd_on = true;
+    }
+    if (dd_on) {
+      ++ndd;
+      to_dd(qX1, X1); to_dd(qZ1, S1i); to_dd(qX2, X2); to_dd(qZ2, S2i);
+      assemble_dd(dsys, pr, qX1, qZ1, qX2, qZ2);
+      if (!dsys.factor()) { ipm = ST_INACC; break; }
+      pr.shift = 0.0;
+    }
+    auto bsolve = [&](double* R, int nrhs) { if (dd_on) dsys.solve(R, nrhs); else pr.solve(R, nrhs); };
     nshiftrun = pr.shift > 0.0 ? nshiftrun + 1 : 0;
     if (phase == 1 && pr.shift > 0.0 && nbackoff < MUT_BACKOFF_MAX) {
       // hard target: aim one power of two earlier and take the step of the shifted factorisation towards it (convexify_oracle.py, k_ctrl_b)
       mu_t *= 2.0; ++nbackoff; ncent = 0; prev_stepn = -1.0; nshiftrun = 0;
     } else if ((phase == 1 && pr.shift > 0.0) || (nshiftrun >= 2 && (mu_t < 0.0 || nbackoff >= MUT_BACKOFF_MAX))) { ipm = ST_INACC; break; }
-    TU = U; pr.solve(TU.data(), 2);
+    TU = U; bsolve(TU.data(), 2);
     double sb00 = b_tt, sb01 = b_ta, sb11 = b_aa;
     for (size_t e = 0; e < (size_t)p * d; ++e) { sb00 -= U[e] * TU[e]; sb01 -= U[e] * TU[(size_t)p * d + e]; sb11 -= U[(size_t)p * d + e] * TU[(size_t)p * d + e]; }
     auto direction = [&](double sig, bool corr, double corr0) {
@@ -402,7 +682,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       const double rhs_tau = trace_sum(T2) - 1.0, rhs_alpha = dot(Hb, G) + t0s;
       pr.adj(adjb, G);
       for (int k = 0; k < p; ++k) pr.svec_grad(&zs[(size_t)k * d], &adjb[(size_t)k * nxx]);
-      pr.solve(zs.data(), 1);
+      bsolve(zs.data(), 1);
       double u0 = 0, u1 = 0;
       for (size_t e = 0; e < (size_t)p * d; ++e) { u0 += U[e] * zs[e]; u1 += U[(size_t)p * d + e] * zs[e]; }
       const double rb0 = rhs_tau - u0, rb1 = rhs_alpha - u1, det = sb00 * sb11 - sb01 * sb01;
@@ -476,6 +756,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     if (phase == 1) {
       const bool full = (ap == 1.0 && ad == 1.0);
       const double est = (prev_stepn >= 0.0) ? stepn * pow(std::min(1.0, stepn / prev_stepn), 1.5) : stepn;
+      if (tight && full && stepn < POLISH_ENTER) { polish = true; ++it; break; }
       if (full && (stepn < center_tol || est < 0.1 * center_tol)) { ipm = ST_OPT; ++it; break; }
       if (full && prev_stepn >= 0.0 && stepn > 0.5 * prev_stepn && stepn < 1e-6) { ipm = ST_OPT; ++it; break; }
       if (ncent >= center_iter) {
@@ -484,6 +765,112 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       }
       prev_stepn = full ? stepn : -1.0;
     }
+  }
+  int npolish = 0;
+  if (polish) {
+    // dual-Newton polish in double-double (convexify_oracle._polish_dd): every stage quantity from the fp64 y = (tau, alpha, P)
+    using namespace ddk;
+    ipm = ST_INACC;
+    std::vector<mat> Mq(p), Z1q(p), Z2q(p), X1q(p), X2q(p), W1(p), W2(p), W3(p);
+    auto cones = [&](double tau_, double alpha_, const vec& P_) -> bool {
+      if (!(alpha_ - ALPHA_MIN > 0.0)) return false;
+      bool okc = true;
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+      for (int k = 0; k < p; ++k) {
+        const int kn = (k + 1) % p;
+        mat Vd((size_t)nx * n), Pn((size_t)nx * nx), t, M, S((size_t)nn);
+        for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+        for (int e = 0; e < nxx; ++e) Pn[e] = from(P_[(size_t)kn * nxx + e]);
+        mat Vt((size_t)n * nx); for (int a = 0; a < nx; ++a) for (int c = 0; c < n; ++c) Vt[(size_t)c * nx + a] = Vd[(size_t)a * n + c];
+        mm(t, Vt, Pn, n, nx, nx, false); mm(M, t, Vd, n, nx, n, false);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+          dd v = add(M[(size_t)i * n + j], muld(from(Hb[(size_t)k * nn + i * n + j]), alpha_));
+          if (i < nx && j < nx) v = sub(v, from(P_[(size_t)k * nxx + i * nx + j]));
+          M[(size_t)i * n + j] = v;
+        }
+        Mq[k] = M;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (i == j) ? sub(M[(size_t)i * n + j], from(1.0)) : M[(size_t)i * n + j];
+        if (!inv_spd(Z1q[k], S, n)) { okc = false; continue; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (i == j) ? sub(from(tau_), M[(size_t)i * n + j]) : neg(M[(size_t)i * n + j]);
+        if (!inv_spd(Z2q[k], S, n)) okc = false;
+      }
+      return okc;
+    };
+    // adjoint in dd, then svec (weights 1 / 2) rounded to fp64:  out[j] = svec(V_{j-1} G_{j-1} V_{j-1}' - G_j[:nx,:nx])
+    auto adj_sv = [&](double* out, const std::vector<mat>& G, double sg) {
+      std::vector<mat> W(p);
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+      for (int k = 0; k < p; ++k) {
+        mat Vd((size_t)nx * n), t;
+        for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+        mm(t, Vd, G[k], nx, n, n, false); mm(W[k], t, Vd, nx, n, nx, true);
+      }
+      for (int j = 0; j < p; ++j) {
+        const int jm = (j + p - 1) % p;
+        for (int e = 0; e < d; ++e) {
+          const int a = pr.ia[e], c = pr.ib[e];
+          const dd v = sub(W[jm][a * nx + c], G[j][(size_t)a * n + c]);
+          out[(size_t)j * d + e] = sg * val(v) * (a == c ? 1.0 : 2.0);
+        }
+      }
+    };
+    bool okp = cones(tau, alpha, P);
+    vec Pn_(P.size()), Mf(PN);
+    for (npolish = 1; okp && npolish <= POLISH_MAX; ++npolish) {
+      const double mu_p = mu_t;
+      s0 = alpha - ALPHA_MIN; x0 = mu_p / s0;
+      std::vector<mat> Psi(p), Ph(p), Ph2(p), Yq(p);
+      double b_tt = 0, b_ta = 0, b_aa = 0, g_tau = 1.0, g_alpha = -x0;
+      for (int k = 0; k < p; ++k) {
+        const size_t o = (size_t)k * nn;
+        X1q[k].resize(nn); X2q[k].resize(nn); Yq[k].resize(nn);
+        for (int e = 0; e < nn; ++e) { X1q[k][e] = muld(Z1q[k][e], mu_p); X2q[k][e] = muld(Z2q[k][e], mu_p); Yq[k][e] = sub(X1q[k][e], X2q[k][e]); }
+        mat Hd(nn), t; for (int e = 0; e < nn; ++e) Hd[e] = from(Hb[o + e]);
+        mm(Psi[k], X2q[k], Z2q[k], n, n, n, false);
+        mm(t, X2q[k], Hd, n, n, n, false); mm(Ph2[k], t, Z2q[k], n, n, n, false);
+        mm(t, X1q[k], Hd, n, n, n, false); mm(Ph[k], t, Z1q[k], n, n, n, false);
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) {       // symmetrise (exact up to rounding already)
+          auto sy = [&](mat& G) { const dd v = muld(add(G[(size_t)i * n + j], G[(size_t)j * n + i]), 0.5); G[(size_t)i * n + j] = v; G[(size_t)j * n + i] = v; };
+          sy(Psi[k]); sy(Ph2[k]); sy(Ph[k]);
+        }
+        for (int e = 0; e < nn; ++e) Ph[k][e] = add(Ph[k][e], Ph2[k][e]);
+        dd trp = from(0.0), trh = from(0.0), hp = from(0.0), trx = from(0.0), hy = from(0.0);
+        for (int i = 0; i < n; ++i) { trp = add(trp, Psi[k][(size_t)i * n + i]); trh = add(trh, Ph2[k][(size_t)i * n + i]); trx = add(trx, X2q[k][(size_t)i * n + i]); }
+        for (int e = 0; e < nn; ++e) { hp = add(hp, mul(Hd[e], Ph[k][e])); hy = add(hy, mul(Hd[e], Yq[k][e])); }
+        b_tt += val(trp); b_ta -= val(trh); b_aa += val(hp); g_tau -= val(trx); g_alpha -= val(hy);
+      }
+      b_aa += x0 / s0;
+      assemble_dd(dsys, pr, X1q, Z1q, X2q, Z2q);
+      if (!dsys.factor()) break;
+      adj_sv(&U[0], Psi, -1.0); adj_sv(&U[(size_t)p * d], Ph, 1.0); adj_sv(zs.data(), Yq, 1.0);
+      TU = U; dsys.solve(TU.data(), 2); dsys.solve(zs.data(), 1);
+      double sb00 = b_tt, sb01 = b_ta, sb11 = b_aa, u0 = 0, u1 = 0;
+      for (size_t e = 0; e < (size_t)p * d; ++e) {
+        sb00 -= U[e] * TU[e]; sb01 -= U[e] * TU[(size_t)p * d + e]; sb11 -= U[(size_t)p * d + e] * TU[(size_t)p * d + e];
+        u0 += U[e] * zs[e]; u1 += U[(size_t)p * d + e] * zs[e];
+      }
+      const double rb0 = -g_tau - u0, rb1 = -g_alpha - u1, det = sb00 * sb11 - sb01 * sb01;
+      dtau = (sb11 * rb0 - sb01 * rb1) / det; dalpha = (sb00 * rb1 - sb01 * rb0) / det;
+      for (int k = 0; k < p; ++k) for (int e = 0; e < d; ++e) {
+        const double v = zs[(size_t)k * d + e] - TU[(size_t)k * d + e] * dtau - TU[(size_t)(p + k) * d + e] * dalpha;
+        dP[(size_t)k * nxx + pr.ia[e] * nx + pr.ib[e]] = v; dP[(size_t)k * nxx + pr.ib[e] * nx + pr.ia[e]] = v;
+      }
+      pr.calH(dM, dP, dalpha);
+      double num = 0, den = 0; const double ra = dalpha / alpha;
+      for (int k = 0; k < p; ++k) for (int e = 0; e < nn; ++e) { const double mv = val(Mq[k][e]); const double dh = dM[(size_t)k * nn + e] - ra * mv; num += dh * dh; den += mv * mv; }
+      stepn = sqrt(num / den);
+      double th = 1.0;
+      for (;;) {
+        for (size_t e = 0; e < P.size(); ++e) Pn_[e] = P[e] + th * dP[e];
+        if (cones(tau + th * dtau, alpha + th * dalpha, Pn_)) break;
+        th *= 0.5;
+        if (th < 1e-3) { okp = false; break; }
+      }
+      if (!okp) break;
+      tau += th * dtau; alpha += th * dalpha; P = Pn_;
+      if (th == 1.0 && stepn < center_tol) { ipm = ST_OPT; break; }
+    }
+    if (npolish > POLISH_MAX) npolish = POLISH_MAX;
   }
   // un-scaling, supplement, status (convexifier.py:403-456)
   const double sc = 1.0 / (s * alpha);
@@ -497,7 +884,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Hc_out[o + i * n + j] = Hs[o + i * n + j] + 0.5 * (dM[o + i * n + j] + dM[o + j * n + i]);
     lo2 = std::min(lo2, sm.min_eig(&Hc_out[o], work.data()));
   }
-  res.kappa = tau; res.alpha = alpha; res.iters = it;
+  res.kappa = tau; res.alpha = alpha; res.iters = it; res.mu_t = mu_t; res.stepn = stepn; res.dd_iters = ndd; res.polish = npolish;
   res.status = (lo2 > 0.0) ? (ipm == ST_OPT ? 0 : 1) : 2;
   return res;
 }
@@ -524,6 +911,35 @@ int cpu_ipm_convexify_batch(int nb, int p, int nx, int mb, const double* A, cons
     if (status) status[b] = r.status;
     if (iters) iters[b] = r.iters;
   }
+  scipy_openblas_set_num_threads(blas_threads_before);
+  return 0;
+}
+
+// The same with the tight-accuracy mode (tight != 0: block linear algebra in double-double below DD_SWITCH, dual-Newton polish at the end;
+// tol down to 2^-41).  A batch smaller than the thread count runs its problems one after the other with the threads inside the block
+// kernels.  info [nb][4]: mu_t, dd iterations, polish steps, last relative step.
+int cpu_ipm_convexify_batch2(int nb, int p, int nx, int mb, const double* A, const double* B, const double* H, double tol, int threads, int tight,
+                             double* Hc, double* kappa, int32_t* status, int32_t* iters, double* info) {
+  if (nb < 0 || p < 1 || nx < 1 || mb < 0 || !A || !H || !Hc) return -1;
+  const int n = nx + mb;
+  if (tol <= 0.0) tol = 0x1p-25;
+  const int blas_threads_before = scipy_openblas_get_num_threads();
+  scipy_openblas_set_num_threads(1);
+  if (threads < 1) threads = 1;
+  const bool inner = tight && nb < threads;
+  omp_set_max_active_levels(1);
+  const int saved = omp_get_max_threads();
+  omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (!inner)
+  for (int b = 0; b < nb; ++b) {
+    const Result r = solve_problem(p, nx, mb, A + (size_t)b * p * nx * nx, B + (size_t)b * p * nx * mb, H + (size_t)b * p * n * n, tol, 50, 12, 1e-9,
+                                   Hc + (size_t)b * p * n * n, tight != 0, inner);
+    if (kappa) kappa[b] = r.kappa;
+    if (status) status[b] = r.status;
+    if (iters) iters[b] = r.iters;
+    if (info) { info[4 * b] = r.mu_t; info[4 * b + 1] = r.dd_iters; info[4 * b + 2] = r.polish; info[4 * b + 3] = r.stepn; }
+  }
+  omp_set_num_threads(saved);
   scipy_openblas_set_num_threads(blas_threads_before);
   return 0;
 }
