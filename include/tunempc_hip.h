@@ -99,6 +99,18 @@ int tmpc_get_chunk(tmpc_handle* h);
  * tunempc_hip_debug.h -- are rejected with TMPC_E_ARG). */
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags);
 
+/* Tight-accuracy mode (opt-in; plain Step 1 handles).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
+ * ~1e-8 (convexifier.py:363); the default solve above stops at tol = 2^-25, a certified gap of (2*p*n+1)*3e-8 on kappa, because the HKM
+ * Schur matrix (condition ~1/mu^2) cannot be factored in fp64 below mu ~ 1e-8.  With enable != 0 every problem that ended Optimal is
+ * continued from its centred point towards mu_target = tight_tol * kappa (default 2^-37 ~ 7.3e-12: gap (2*p*n+1)*7.3e-12; accepted range
+ * [2^-42, 1), every member of the test families converges down to 2^-37, most down to 2^-41) with the Kronecker-factor images, the
+ * assembly, the block Cholesky and the substitutions in double-double arithmetic, and finished by Newton steps on the dual barrier
+ * problem in which every stage quantity is double-double (the returned point is then reproducible to ~1e-12 instead of ~eps/mu).
+ * Outputs as before; info[6] = the mu_target reached, iters includes the extra iterations.  Costs one more workspace of about the size of
+ * the block storage (allocated at the first enable) and ~10 double-double factorisations per problem (vector ALU, no matrix cores).
+ * enable == 0 switches back to the default (the workspace stays).  TMPC_E_UNSUPPORTED for handles with G / C rows or Step 3. */
+int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol);
+
 /* Step 1 of convexifier.convexify for `nb` independent problems.  Any output pointer may be NULL.
  * status/iters are int32 [nb]; alpha/beta/kappa are double [nb]; info is double [nb][16]. */
 int tmpc_convexify_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H,

@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 # every symbol declared in include/tunempc_hip.h (the drop-in boundary) ...
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
-    'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options',
+    'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
@@ -89,6 +89,8 @@ def load_library():
     lib.tmpc_destroy.argtypes = [vp]
     lib.tmpc_get_chunk.restype = C.c_int
     lib.tmpc_get_chunk.argtypes = [vp]
+    lib.tmpc_set_tight.restype = C.c_int
+    lib.tmpc_set_tight.argtypes = [vp, C.c_int, C.c_double]
     lib.tmpc_set_options.restype = C.c_int
     lib.tmpc_set_options.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
     lib.tmpc_convexify_batch_host.restype = C.c_int
@@ -176,6 +178,11 @@ class HipConvexifier:
             self.flags = int(flags)
         _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
                                                    int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
+
+    def set_tight(self, enable=True, tight_tol=None):
+        """Tight-accuracy mode (include/tunempc_hip.h: tmpc_set_tight): continue every Optimal problem towards tight_tol * kappa (default 2^-37)
+        with double-double block linear algebra and a dd dual-Newton polish.  Plain Step 1 handles only."""
+        _check(self.lib, self.lib.tmpc_set_tight(self._h, 1 if enable else 0, float(tight_tol or 0.0)), 'tmpc_set_tight')
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:

@@ -21,6 +21,7 @@
 #include "tmpc_phi.h"
 #include "tmpc_t3.h"
 #include "tmpc_eig.h"
+#include "tmpc_dd.h"
 
 using namespace tmpc;
 
@@ -78,6 +79,10 @@ struct tmpc_handle {
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
   int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
+  void* dd_slab;                 // tight mode (tmpc_set_tight): low words of the double-double planes, allocated on first use
+  size_t dd_bytes;
+  int tight;                     // 1: the tight phase follows the default solve
+  double tight_tol;
 };
 
 // device copy of a schedule: [elim | upd | orient]
@@ -147,6 +152,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.cr_orient = nullptr;
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
+  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
@@ -183,6 +189,19 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
     c.take<double>(BP * nxx); c.take<double>(BP * dm.nx * std::max(dm.mb, 1)); c.take<double>(BP * nn);
     c.take<double>((size_t)dm.B * TMPC_INFO_STRIDE); c.take<double>((size_t)dm.B * 3); c.take<int32_t>((size_t)dm.B * 2);
   }
+  return (c.off + 255) & ~(size_t)255;
+}
+
+// low words of the double-double planes of the tight mode (tmpc_dd.h), one slice per lane
+static size_t carve_dd(WS& w, const Dims& dm, char* base) {
+  Carver c{base, 0};
+  const size_t BP = (size_t)dm.B * dm.p, nxx = (size_t)dm.nx * dm.nx, bs = (size_t)dm.dp * dm.dp;
+  w.Dl = c.take<double>(BP * bs); w.Ol = c.take<double>(BP * bs); w.Fl = c.take<double>(BP * bs);
+  w.Linvl = c.take<double>(BP * dm.nt * TB * TB);
+  w.KFl = c.take<double>(BP * 12 * nxx); w.adjVl = c.take<double>(BP * NADJ * nxx); w.adjEl = c.take<double>(BP * NADJ * nxx);
+  w.W3l = c.take<double>(BP * dm.dp * 3); w.Zl = c.take<double>(BP * dm.dp);
+  w.Pprev = c.take<double>(BP * nxx);
+  w.plist = c.take<int>((size_t)dm.B);
   return (c.off + 255) & ~(size_t)255;
 }
 
@@ -399,6 +418,17 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_update, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_fwd_off, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_images, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_polish_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));
+  HIPCHK(hipFuncSetAttribute((const void*)k_polish_step, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));
   if (device >= 0 && device < 64) done[device] = true;
   return TMPC_OK;
 }
@@ -509,6 +539,38 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
   }
 }
 
+// ---- the same in double-double (tight mode, tmpc_dd.h): one launch per phase and level, no small-block or fused forms
+template <int PART> static size_t ddschur_lds(const Dims& dm) { return (size_t)2 * ddsch_mats<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
+static void dd_factor(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st) {
+  const CrDev cd = cr_dev(sc, d_sched, alist);
+  const size_t lds = (size_t)DD_FACT_LDS * sizeof(double);
+  if (sc.prep) hipLaunchKernelGGL(k_dd_prep, dim3(count), dim3(256), 0, st, w, dm, cd, sc.prep);
+  const int nm = (dm.dp + 63) / 64;
+  for (const CrLevel& lv : sc.lev) {
+    hipLaunchKernelGGL(k_dd_potrf, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count);
+    if (lv.nupd == 0) continue;
+    hipLaunchKernelGGL(k_dd_trsm, dim3(cr_grid((long)count * lv.nelim * 2 * nm)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count);
+    const long items = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
+    hipLaunchKernelGGL(k_dd_update, dim3(cr_grid(items)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
+  }
+}
+static int dd_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st, int pass, int nb_all) {
+  const CrDev cd = cr_dev(sc, d_sched, alist);
+  const size_t lds = (size_t)dd_solve_lds_doubles(dm.dp) * sizeof(double);
+  // the right-hand sides arrive as fp64 numbers: low words zero
+  HIPCHK(hipMemsetAsync(w.W3l, 0, (size_t)nb_all * dm.p * dm.dp * 3 * sizeof(double), st));
+  HIPCHK(hipMemsetAsync(w.Zl, 0, (size_t)nb_all * dm.p * dm.dp * sizeof(double), st));
+  for (const CrLevel& lv : sc.lev) {
+    hipLaunchKernelGGL(k_dd_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
+    if (lv.nupd) hipLaunchKernelGGL(k_dd_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), lds, st, w, dm, cd, lv.uoff, lv.nupd, count, pass);
+  }
+  for (size_t l = sc.lev.size(); l-- > 0;) {
+    const CrLevel& lv = sc.lev[l];
+    hipLaunchKernelGGL(k_dd_bwd, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
+  }
+  return TMPC_OK;
+}
+
 // TMPC_EIG_PRETEST=0: k_eigmin computes every eigenvalue (round 2)
 static const int g_eig_pretest = [] { const char* e = getenv("TMPC_EIG_PRETEST"); return e ? atoi(e) : 1; }();
 // the per-stage kernels of the plain model run with four waves per stage (TMPC_STAGE_NT=64: one wave, the original form)
@@ -548,6 +610,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   int* flist = wall.flist;
   wall.alist = nullptr;
   Opts o = h->opt;
+  o.tight = 0; o.tight_tol = 0.0;
   // chord steps also with stage-local multipliers since round 3 (their rows are part of the frozen blocks like everything else; all parity
   // cases, goldens and the five-model fuzz agree to the same bar; Step 1 with G +4.7 %, Step 2 +3.9 %).  TMPC_EQ_CHORD=0: plain model only, as in round 2
   { static const int eqc = [] { const char* e = getenv("TMPC_EQ_CHORD"); return e ? atoi(e) : 1; }();
@@ -556,7 +619,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
-  HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
   {
@@ -566,7 +629,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   hipLaunchKernelGGL(k_init_state, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (t3) hipLaunchKernelGGL(k_t3_init, dim3(BPall), dim3(64), 0, st, wall, dm);
-  int cnt[2] = {0, 0};                    // problems still iterating / of which need a factorisation
+  int cnt[4] = {0, 0, 0, 0};              // problems still iterating / of which need a factorisation / handed to the polish / still polishing
   HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   int active = cnt[0], nfac = cnt[0];
@@ -575,6 +638,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   // until round 3 the wave stopped at max_iter + center_iter + 2 = 64 and such a member came back Feasible.
   const int cap = o.max_iter + o.center_iter * (MUT_BACKOFF_MAX + 1) + 2;
   int it = 0;
+  // one interior-point loop; ddm: the tight phase (tmpc_dd.h) -- assembly, factorisation and substitutions in double-double, every problem of the list
+  auto ipm_loop = [&](const Opts& o, bool ddm, int cap) -> int {
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
@@ -584,7 +649,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
-    if (nfac > 0) {
+    if (ddm) {
+      hipLaunchKernelGGL(k_dd_images, dim3(BP), dim3(256), slots_bytes(DD_IMG_SLOTS), st, w, dm);
+      hipLaunchKernelGGL(k_dd_schur<0>, dim3(BP), dim3(256), ddschur_lds<0>(dm), st, w, dm);
+      hipLaunchKernelGGL(k_dd_schur<1>, dim3(BP), dim3(256), ddschur_lds<1>(dm), st, w, dm);
+    } else if (nfac > 0) {
       hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
       hipLaunchKernelGGL(k_schur<1>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
     }
@@ -606,7 +675,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     static const int dma_env = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();       // (the fused sweep lives in k_cr_update_dma)
     // (round 3: also with the multipliers of G / C -- their right-hand side rows depend on the iterate only, like the others; not with Step 3)
     static const int fuse_eq_env = [] { const char* e = getenv("TMPC_FUSE_FWD_EQ"); return e ? atoi(e) : 1; }();
-    const bool fuse1 = fuse_env && dma_env && (!eq || fuse_eq_env) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
+    const bool fuse1 = !ddm && fuse_env && dma_env && (!eq || fuse_eq_env) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
     if (fuse1) {
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
@@ -615,7 +684,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     int nkev = 0;
-    if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
+    if (ddm) dd_factor(w, dm, h->sched, h->d_sched, alist, active, st);
+    else if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);
@@ -625,7 +695,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (!fused) hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (eq && !fused) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
-      cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, fused);
+      if (ddm) { const int rc_ = dd_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, nb); if (rc_ != TMPC_OK) return rc_; }
+      else cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, fused);
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
@@ -658,6 +729,48 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, ln->kev[i], ln->kev[i + 1])); ln->prof[9 + (i / 2) % 3] += ms; }
     }
     ++it;
+  }
+  return TMPC_OK;
+  };
+  { const int rc_ = ipm_loop(o, false, cap); if (rc_ != TMPC_OK) return rc_; }
+  // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
+  // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
+  if (h->tight && !eq && !t3 && wall.Dl) {
+    Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.chord_step = 0.0; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
+    HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
+    { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3((nb + 63) / 64), dim3(64), 0, st, wi, dm, ot); }
+    HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    active = cnt[0]; nfac = cnt[0];
+    { const int rc_ = ipm_loop(ot, true, it + cap); if (rc_ != TMPC_OK) return rc_; }
+    HIPCHK(hipMemcpyAsync(cnt, w.active, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int npol = cnt[2];
+    int* list = wall.plist; int* next = alist; int count = npol;
+    for (int step = 0; step < POLISH_MAX && count > 0; ++step) {
+      WS wp = wall; wp.alist = list;
+      hipLaunchKernelGGL(k_dd_polish_pre, dim3(count * dm.p), dim3(256), slots_bytes(DD_POL_SLOTS), st, wp, dm, 0);
+      hipLaunchKernelGGL(k_polish_ctrl_a, dim3(count), dim3(64), 0, st, wp, dm);
+      hipLaunchKernelGGL(k_dd_schur<0>, dim3(count * dm.p), dim3(256), ddschur_lds<0>(dm), st, wp, dm);
+      hipLaunchKernelGGL(k_dd_schur<1>, dim3(count * dm.p), dim3(256), ddschur_lds<1>(dm), st, wp, dm);
+      dd_factor(wp, dm, h->sched, h->d_sched, list, count, st);
+      hipLaunchKernelGGL(k_dd_gather, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
+      { const int rc_ = dd_solve(wp, dm, h->sched, h->d_sched, list, count, st, 2, nb); if (rc_ != TMPC_OK) return rc_; }
+      hipLaunchKernelGGL(k_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list, 2);
+      hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
+      HIPCHK(hipMemsetAsync(w.active + 3, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_polish_ctrl_b, dim3(count), dim3(64), 0, st, wp, dm, ot, (const int*)list, count, next, w.active + 3);
+      HIPCHK(hipMemcpyAsync(cnt + 3, w.active + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      count = cnt[3];
+      int* t_ = (list == wall.plist) ? flist : list; list = next; next = t_;
+      ++it;
+    }
+    if (npol > 0) {      // final iterate of every polished problem: cone check, X_r / S_r for the outputs and the dual export
+      WS wp = wall; wp.alist = wall.plist;
+      hipLaunchKernelGGL(k_dd_polish_pre, dim3(npol * dm.p), dim3(256), slots_bytes(DD_POL_SLOTS), st, wp, dm, 1);
+      hipLaunchKernelGGL(k_polish_final, dim3(npol), dim3(64), 0, st, wp, dm);
+    }
   }
   ln->prof[7] += it;
   hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
@@ -729,7 +842,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   }
   tmpc_handle* h = new (std::nothrow) tmpc_handle();
   if (!h) return TMPC_E_NOMEM;
-  h->slab = nullptr; h->d_sched = nullptr; h->ev_in = nullptr;
+  h->slab = nullptr; h->d_sched = nullptr; h->ev_in = nullptr; h->dd_slab = nullptr; h->dd_bytes = 0; h->tight = 0; h->tight_tol = 0x1p-37;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return TMPC_E_HIP; }
   // lanes: one by default -- measured on MI355X (profiles/r2b_lanes.txt), two or four concurrent half-waves gain nothing at the
   // bench shape (6445 / 6526 / 6399 stage-conv/s with 1 / 2 / 4 lanes): every kernel of the loop already fills the chip, so the
@@ -790,6 +903,7 @@ int tmpc_destroy(tmpc_handle* h) {
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
+  if (h->dd_slab) hipFree(h->dd_slab);
   if (h->d_sched) hipFree(h->d_sched);
   delete h;
   return TMPC_OK;
@@ -808,6 +922,31 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
   if (max_iter > 0) h->opt.max_iter = max_iter;
   if (center_iter > 0) h->opt.center_iter = center_iter;
   h->flags = flags;
+  return TMPC_OK;
+}
+
+
+// Tight-accuracy mode (see tunempc_hip.h and tmpc_dd.h).  The double-double workspace (about as large as the block storage of the handle) is
+// allocated at the first enable and kept until tmpc_destroy.
+int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
+  if (!h) return TMPC_E_ARG;
+  if (!enable) { h->tight = 0; return TMPC_OK; }
+  if (h->dm.nr > 0 || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles only (no G / C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
+  if (tight_tol > 0.0 && !(tight_tol >= 0x1p-42 && tight_tol < 1.0)) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: tolerance %g outside [2^-42, 1)", tight_tol); return TMPC_E_ARG; }
+  ON_DEVICE(h);
+  if (!h->dd_slab) {
+    WS tmp;
+    const size_t lane_bytes = carve_dd(tmp, h->dm, nullptr);
+    if (hipMalloc(&h->dd_slab, lane_bytes * h->nlanes) != hipSuccess) {
+      h->dd_slab = nullptr;
+      snprintf(g_err, sizeof(g_err), "tmpc_set_tight: hipMalloc(%zu bytes) failed", lane_bytes * h->nlanes);
+      return TMPC_E_NOMEM;
+    }
+    h->dd_bytes = lane_bytes * h->nlanes;
+    for (int l = 0; l < h->nlanes; ++l) carve_dd(h->lane[l].ws, h->dm, (char*)h->dd_slab + (size_t)l * lane_bytes);
+  }
+  if (tight_tol > 0.0) h->tight_tol = tight_tol;
+  h->tight = 1;
   return TMPC_OK;
 }
 

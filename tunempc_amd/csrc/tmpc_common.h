@@ -36,16 +36,17 @@ enum {
   P_TAU = 0, P_ALPHA, P_S0, P_X0, P_MU, P_MUT, P_SIGMU, P_AP, P_AD, P_S, P_SBETA, P_PINF, P_DINF, P_RELGAP,
   P_STEPN, P_PREVSTEPN, P_DTAU, P_DALPHA, P_DS0, P_DX0, P_RD0, P_CORR0, P_MINEIG_H, P_BTT, P_BTA, P_BAA,
   P_SB00, P_SB01, P_SB11, P_RHS_TAU, P_RHS_ALPHA, P_SXS, P_MINEIG_HC, P_MAXCOND, P_KAPPA, P_BETA, P_ALPHA_OUT,
-  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, PS = 48
+  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, P_TAU_PREV, P_ALPHA_PREV, P_MUT1, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
-enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF, IS = 16 };   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
+enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF,
+       I_DD, I_NDD, I_NPOLISH, IS = 24 };   // I_DD: 1 = tight phase (block linear algebra in double-double, tmpc_dd.h); I_NDD: such iterations; I_NPOLISH: polish steps   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
 //   // I_BOSTEP: 1 = k_ctrl_b (ctrl_backoff_before_rhs) backed mu_t off in this centering iteration (frozen pivots): the step of that factorisation is TAKEN (k_ctrl_c)
 //   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
 //   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
 // phases
-enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2 };
+enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2, PH_POLISH = 3 };     // PH_POLISH: waits for / runs the dd dual-Newton polish of the tight mode (out of the active list)
 // ipm status
 enum { IPM_OPTIMAL = 0, IPM_INACCURATE = 1, IPM_MAXITER = 2 };
 // reference status strings (convexifier.py:442-451)
@@ -96,6 +97,8 @@ struct Opts {
   int center_iter;
   double chord_step;   // centering: once a full Newton step could have been this many times longer before leaving the cone (i.e. the
                        // iterate moved by < 1/chord_step in the local norm), the next steps re-use the factorisation; 0 = never
+  int tight;           // 1: this loop is the tight phase (tmpc_dd.h): no chord steps, no lifts / back-offs, centering hands over to the polish
+  double tight_tol;    // its complementarity tolerance (mu_target = tight_tol * kappa)
   int fast_exit;       // TMPC_FLAG_FAST_EXIT: stop after the FIRST full centering step (feasible, kappa within the gap N mu_t of optimal, but
                        // not the converged central-path point: not reproducible to 1e-8 between implementations)
 };
@@ -163,6 +166,10 @@ struct WS {
   double* t3t; double* t3dt; double* t3beta;                                      // [B,p]
   double* t3psi; double* t3phi;   // [B,p,n,n] full Psi = sym(X2 S2^-1) and Phi(Hb) of the stage (border entries of the theta rows)
   double* Tout;    // [B,p,n,n] output T_k
+  // tight mode (tmpc_dd.h): low words of the double-double planes (high words = D, O, F, Linv, KF, adjV, adjE, W3, Z); null without it
+  double* Dl; double* Ol; double* Fl; double* Linvl; double* KFl; double* adjVl; double* adjEl; double* W3l; double* Zl;
+  double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
+  int* plist;      // [B] problems handed to the polish (count in active[2])
 };
 
 // (problem, stage) of this workgroup for kernels with one workgroup per stage: blockIdx.x = (index in the active list) * p + k

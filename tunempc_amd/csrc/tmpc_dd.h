@@ -1,0 +1,881 @@
+// Tight-accuracy mode: the block linear algebra of the interior-point iteration in DOUBLE-DOUBLE, and a dd dual-Newton polish.
+//
+// Why.  The HKM Schur matrix B = L'(X (x) S^-1)L of the convexifier SDP (convexifier.py:213-308) has eigenvalues ~1/mu on the
+// active x active part of the cone blocks and ~mu on directions inside the optimal face (the SDP minimises beta alone: its minimiser
+// is a face), i.e. cond(B) ~ 1/mu^2.  Assembled and factored in fp64 it loses the small end at mu ~ sqrt(eps) = 1e-8, which is why
+// the default solve stops at mu_t = 2^-25 kappa (a certified gap of N * 3e-8 on kappa).  Measured on the CPU restatement
+// (tests/tools/tight_probe.py, 40-digit arithmetic in exactly these pieces): with the Kronecker-factor images, the assembly, the
+// factorisation and the substitutions carried in extended precision -- and everything else left in fp64 -- the same iteration
+// follows the path to mu ~ 1e-12.  Double-double (hi + lo, eps ~ 1e-32) is enough for that and needs no hardware beyond the fp64 FMA.
+//
+// What.  After the default solve (unchanged), problems that ended Optimal are restarted from their centred point with the target
+// tight_tol * kappa: the same predictor-corrector loop, the same fp64 stage kernels, but k_schur / cr_factor / cr_solve replaced by
+//   k_dd_images     V X V', V S^-1 V', X_E V', S^-1_E V' of both cone blocks in dd (their fp64 rounding alone, eps / mu, is the wall)
+//   k_dd_schur      D_k, C_k in dd from those factors (same storage and orientation as k_schur)
+//   k_dd_potrf / k_dd_trsm / k_dd_update     the cyclic-reduction block Cholesky of tmpc_cr.h (same schedule) on dd planes
+//   k_dd_fwd_diag / k_dd_fwd_off / k_dd_bwd  the substitutions, right-hand sides carried in dd between the levels
+// and the centering phase hands over (first full step below POLISH_ENTER) to Newton's method on the DUAL barrier problem in
+// y = (tau, alpha, P) with every stage quantity in dd (k_dd_polish_pre): the primal-dual iteration keeps X and S^-1 as fp64
+// matrices whose large part buries the small one under an absolute rounding error, so its centred point is reproducible to
+// ~eps/mu only (1e-7 at mu = 2e-12); two or three polish steps reproduce it to 1e-12 (oracle/convexify_oracle.py: _polish_dd).
+//
+// The dd kernels run on the vector ALU (the matrix cores have no extended format; emulating dd products on fp64 MFMA by
+// Ozaki slicing costs as many issue slots as the VALU form because fp64 MFMA and VALU share them on this part): ~12 VALU
+// operations per dd multiply-add, 64 x 64 output tiles, 4 x 4 register micro-tiles, K slabs of 16 through LDS.  Plain model only.
+#pragma once
+#include "tmpc_common.h"
+#include "tmpc_small.h"
+#include "tmpc_cr.h"
+
+// The error-free transformations below (two_sum, two_prod) are exact only if every operation is rounded on its own: the AMDGPU back end fuses a
+// multiply into a following add even when the product has other uses, which turns s = sh + p into fma(ah, bh, sh) and the "error" of the
+// sum into garbage of size eps |p| (measured: non-positive pivots at mu ~ 1e-10 where the CPU restatement factors at 1e-12).
+#pragma clang fp contract(off)
+
+namespace tmpc {
+
+constexpr double POLISH_ENTER = 1e-4;    // as oracle/convexify_oracle.py
+constexpr int POLISH_MAX = 6;
+
+// ------------------------------------------------------------------ dd scalar arithmetic (Dekker / Knuth / QD)
+struct ddv { double h, l; };
+__device__ __forceinline__ ddv dd_qts(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+__device__ __forceinline__ ddv dd_ts(double a, double b) { const double s = a + b, v = s - a; return {s, (a - (s - v)) + (b - v)}; }
+__device__ __forceinline__ ddv dd_tp(double a, double b) { const double p = a * b; return {p, fma(a, b, -p)}; }
+__device__ __forceinline__ ddv dd_add(ddv a, ddv b) { ddv s = dd_ts(a.h, b.h); const ddv t = dd_ts(a.l, b.l); s.l += t.h; s = dd_qts(s.h, s.l); s.l += t.l; return dd_qts(s.h, s.l); }
+__device__ __forceinline__ ddv dd_neg(ddv a) { return {-a.h, -a.l}; }
+__device__ __forceinline__ ddv dd_sub(ddv a, ddv b) { return dd_add(a, dd_neg(b)); }
+__device__ __forceinline__ ddv dd_mul(ddv a, ddv b) { ddv p = dd_tp(a.h, b.h); p.l += fma(a.h, b.l, a.l * b.h); return dd_qts(p.h, p.l); }
+__device__ __forceinline__ ddv dd_muld(ddv a, double b) { ddv p = dd_tp(a.h, b); p.l = fma(a.l, b, p.l); return dd_qts(p.h, p.l); }
+__device__ __forceinline__ ddv dd_from(double a) { return {a, 0.0}; }
+__device__ __forceinline__ double dd_val(ddv a) { return a.h + a.l; }
+__device__ __forceinline__ ddv dd_div(ddv a, ddv b) {
+  const double q1 = a.h / b.h; ddv r = dd_sub(a, dd_muld(b, q1));
+  const double q2 = r.h / b.h; r = dd_sub(r, dd_muld(b, q2));
+  const double q3 = r.h / b.h;
+  return dd_add(dd_qts(q1, q2), dd_from(q3));
+}
+__device__ __forceinline__ ddv dd_sqrt(ddv a) { const double x = 1.0 / sqrt(a.h), ax = a.h * x; const double err = dd_sub(a, dd_tp(ax, ax)).h; return dd_qts(ax, err * x * 0.5); }
+// (sh, sl) += a * b with a deferred renormalisation: the two_sum of the high words is exact, the low word just collects (12 operations)
+__device__ __forceinline__ void dd_fma_acc(double& sh, double& sl, double ah, double al, double bh, double bl) {
+  const double p = ah * bh;
+  double e = fma(ah, bh, -p); e = fma(ah, bl, e); e = fma(al, bh, e);
+  const double s = sh + p, v = s - sh;
+  const double t = (sh - (s - v)) + (p - v);
+  sl += t + e; sh = s;
+}
+__device__ __forceinline__ double* dd_edge_lo(const WS& w, const Dims& dm, int b, int slot) {
+  const size_t bs = (size_t)dm.dp * dm.dp;
+  return (slot < dm.p) ? w.Ol + ((size_t)b * dm.p + slot) * bs : w.Fl + ((size_t)b * dm.p + (slot - dm.p)) * bs;
+}
+
+// ------------------------------------------------------------------ tile GEMM  C (M x N, N <= 64) <op> A (M x K) B (N x K)'
+// 256 threads; thread (ty, tx) = (tid >> 4, tid & 15) owns rows 4 ty .. + 3, columns 4 tx .. + 3 of the 64-row tile.  K slabs of 16 sit in
+// LDS transposed ([k][row], so a thread's four rows are two 16-byte reads).  TA: A is given transposed (element (m, k) at A[k * lda + m]).
+// M, N, K need not be multiples of anything: loads outside read as zero, stores are masked.  In place (C aliasing A) is safe when the
+// call has one N tile and K == its width: all slabs of a row tile are read before its C is written, and other row tiles touch other rows.
+constexpr int DG_K = 16, DG_LD = 68, DG_SLAB = DG_K * DG_LD;
+constexpr int DD_GEMM_LDS = 4 * DG_SLAB;          // doubles: A hi / lo, B hi / lo
+template <bool TA>
+__device__ __forceinline__ void wg_gemm_dd(double* Ch, double* Cl, int ldc, const double* Ah, const double* Al, int lda, const double* Bh, const double* Bl, int ldb,
+                                           int M, int N, int K, int mode, double* lds) {
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double* sAh = lds; double* sAl = lds + DG_SLAB; double* sBh = lds + 2 * DG_SLAB; double* sBl = lds + 3 * DG_SLAB;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    double ah_[4][4], al_[4][4];                     // accumulators [row][col]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ah_[i][j] = 0.0; al_[i][j] = 0.0; }
+    for (int k0 = 0; k0 < K; k0 += DG_K) {
+      __syncthreads();                               // previous slab consumed
+      if (TA) {
+        const int k = tid >> 4, mq = (tid & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (k0 + k < K) && (m0 + mq + q < M);
+          sAh[k * DG_LD + mq + q] = ok ? Ah[(size_t)(k0 + k) * lda + m0 + mq + q] : 0.0;
+          sAl[k * DG_LD + mq + q] = ok ? Al[(size_t)(k0 + k) * lda + m0 + mq + q] : 0.0;
+        }
+      } else {
+        const int r = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (m0 + r < M) && (k0 + kq + q < K);
+          sAh[(kq + q) * DG_LD + r] = ok ? Ah[(size_t)(m0 + r) * lda + k0 + kq + q] : 0.0;
+          sAl[(kq + q) * DG_LD + r] = ok ? Al[(size_t)(m0 + r) * lda + k0 + kq + q] : 0.0;
+        }
+      }
+      {
+        const int r = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (r < N) && (k0 + kq + q < K);
+          sBh[(kq + q) * DG_LD + r] = ok ? Bh[(size_t)r * ldb + k0 + kq + q] : 0.0;
+          sBl[(kq + q) * DG_LD + r] = ok ? Bl[(size_t)r * ldb + k0 + kq + q] : 0.0;
+        }
+      }
+      __syncthreads();
+      if (m0 + 4 * ty < M && 4 * tx < N) {
+#pragma unroll 4
+        for (int k = 0; k < DG_K; ++k) {
+          double xh[4], xl[4], yh[4], yl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { xh[i] = sAh[k * DG_LD + 4 * ty + i]; xl[i] = sAl[k * DG_LD + 4 * ty + i]; yh[i] = sBh[k * DG_LD + 4 * tx + i]; yl[i] = sBl[k * DG_LD + 4 * tx + i]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dd_fma_acc(ah_[i][j], al_[i][j], xh[i], xl[i], yh[j], yl[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 4 * ty + i;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 4 * tx + j;
+        if (col >= N) continue;
+        const ddv acc = dd_qts(ah_[i][j], al_[i][j]);
+        const size_t e = (size_t)row * ldc + col;
+        ddv v;
+        if (mode == GM_SUB) v = dd_sub(ddv{Ch[e], Cl[e]}, acc);
+        else if (mode == GM_NEG) v = dd_neg(acc);
+        else v = acc;
+        Ch[e] = v.h; Cl[e] = v.l;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ 64 x 64 tile Cholesky + inverse in dd
+// The tile lives in LDS (hi / lo, leading dimension 65).  Right-looking column steps; then the inverse of the factor, column c by thread c
+// (forward substitution), parked in the strict upper triangle of the same image (L^-1[i][c] at [c][i]; its diagonal in dinv).  Returns the
+// number of non-positive pivots (0 = fine; the caller stops the problem otherwise: no shift in this mode).
+constexpr int DD_POTRF_LDS = 2 * 64 * 65 + 128 + 8;
+__device__ __forceinline__ int wg_potrf_inv_dd(double* Th, double* Tl, int ldt, double* Tih, double* Til, int nb, double* lds) {
+  const int tid = threadIdx.x;
+  double* Sh = lds; double* Sl = lds + 64 * 65; double* dih = Sl + 64 * 65; double* dil = dih + 64; double* flag = dil + 64;
+  __syncthreads();
+  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; Sh[i * 65 + j] = Th[(size_t)i * ldt + j]; Sl[i * 65 + j] = Tl[(size_t)i * ldt + j]; }
+  if (tid == 0) flag[0] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    ddv piv{Sh[j * 65 + j], Sl[j * 65 + j]};
+    if (!(piv.h > 0.0)) { piv = ddv{1.0, 0.0}; if (tid == 0) flag[0] += 1.0; }      // (uniform: every thread reads the same pivot)
+    const ddv r = dd_sqrt(piv);
+    const ddv rinv = dd_div(dd_from(1.0), r);
+    __syncthreads();
+    if (tid == 0) { Sh[j * 65 + j] = r.h; Sl[j * 65 + j] = r.l; dih[j] = rinv.h; dil[j] = rinv.l; }
+    if (tid > j && tid < nb) { const ddv v = dd_mul(ddv{Sh[tid * 65 + j], Sl[tid * 65 + j]}, rinv); Sh[tid * 65 + j] = v.h; Sl[tid * 65 + j] = v.l; }
+    __syncthreads();
+    for (int i = j + 1 + (tid >> 2); i < nb; i += 64) {
+      const ddv li{Sh[i * 65 + j], Sl[i * 65 + j]};
+      for (int k = j + 1 + (tid & 3); k <= i; k += 4) {
+        const ddv v = dd_sub(ddv{Sh[i * 65 + k], Sl[i * 65 + k]}, dd_mul(li, ddv{Sh[k * 65 + j], Sl[k * 65 + j]}));
+        Sh[i * 65 + k] = v.h; Sl[i * 65 + k] = v.l;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nb) {                     // column c of L^-1:  x_i = -(sum_{k=c}^{i-1} L[i][k] x_k) / L[i][i],  x_c = 1 / L[c][c]
+    const int c = tid;
+    for (int i = c + 1; i < nb; ++i) {
+      ddv s = dd_mul(ddv{Sh[i * 65 + c], Sl[i * 65 + c]}, ddv{dih[c], dil[c]});
+      for (int k = c + 1; k < i; ++k) s = dd_add(s, dd_mul(ddv{Sh[i * 65 + k], Sl[i * 65 + k]}, ddv{Sh[c * 65 + k], Sl[c * 65 + k]}));
+      const ddv x = dd_neg(dd_mul(s, ddv{dih[i], dil[i]}));
+      Sh[c * 65 + i] = x.h; Sl[c * 65 + i] = x.l;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) { Th[(size_t)i * ldt + j] = Sh[i * 65 + j]; Tl[(size_t)i * ldt + j] = Sl[i * 65 + j]; }
+    double vh = 0.0, vl = 0.0;
+    if (j == i) { vh = dih[i]; vl = dil[i]; } else if (j < i) { vh = Sh[j * 65 + i]; vl = Sl[j * 65 + i]; }
+    Tih[i * TB + j] = vh; Til[i * TB + j] = vl;
+  }
+  __syncthreads();
+  return (int)flag[0];
+}
+
+// left-looking blocked Cholesky of one dp x dp diagonal block (wg_block_column of tmpc_factor.h in dd); inverted diagonal tiles into Li
+__device__ __forceinline__ int wg_block_potrf_dd(double* Dh, double* Dl, double* Lih, double* Lil, int dp, double* lds) {
+  int nbad = 0, jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    if (j0 > 0)
+      wg_gemm_dd<false>(Dh + (size_t)j0 * dp + j0, Dl + (size_t)j0 * dp + j0, dp, Dh + (size_t)j0 * dp, Dl + (size_t)j0 * dp, dp, Dh + (size_t)j0 * dp, Dl + (size_t)j0 * dp, dp,
+                        dp - j0, nb, j0, GM_SUB, lds);
+    double* Tih = Lih + (size_t)jt * TB * TB; double* Til = Lil + (size_t)jt * TB * TB;
+    nbad += wg_potrf_inv_dd(Dh + (size_t)j0 * dp + j0, Dl + (size_t)j0 * dp + j0, dp, Tih, Til, nb, lds);
+    if (dp - j0 - nb > 0) {
+      double* Xh = Dh + (size_t)(j0 + nb) * dp + j0; double* Xl = Dl + (size_t)(j0 + nb) * dp + j0;
+      wg_gemm_dd<false>(Xh, Xl, dp, Xh, Xl, dp, Tih, Til, TB, dp - j0 - nb, nb, nb, GM_SET, lds);
+    }
+  }
+  return nbad;
+}
+
+// ------------------------------------------------------------------ factorisation kernels (schedule and storage of tmpc_cr.h)
+constexpr int DD_FACT_LDS = (DD_POTRF_LDS > DD_GEMM_LDS) ? DD_POTRF_LDS : DD_GEMM_LDS;
+
+__global__ void __launch_bounds__(256) k_dd_prep(WS w, Dims dm, CrDev cr, int prep) {
+  const int b = cr.alist[blockIdx.x];
+  const int dp = dm.dp, tid = threadIdx.x;
+  const size_t o = (size_t)b * dm.p * dp * dp;
+  if (prep == 1) {
+    for (int e = tid; e < dp * dp; e += 256) {
+      const int i = e / dp, j = e - i * dp;
+      const size_t et = (size_t)j * dp + i;
+      ddv v = dd_add(ddv{w.D[o + e], w.Dl[o + e]}, dd_add(ddv{w.O[o + e], w.Ol[o + e]}, ddv{w.O[o + et], w.Ol[o + et]}));
+      if (j > i) v = ddv{0.0, 0.0};                      // (the assembly wrote the lower triangle of D only)
+      w.D[o + e] = v.h; w.Dl[o + e] = v.l;
+    }
+  } else {
+    const size_t o1 = o + (size_t)dp * dp;
+    for (int e = tid; e < dp * dp; e += 256) { const ddv v = dd_add(ddv{w.O[o + e], w.Ol[o + e]}, ddv{w.O[o1 + e], w.Ol[o1 + e]}); w.O[o + e] = v.h; w.Ol[o + e] = v.l; }
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_dd_potrf(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp;
+  const size_t bs = (size_t)dp * dp, no = ((size_t)b * dm.p + node);
+  const int nbad = wg_block_potrf_dd(w.D + no * bs, w.Dl + no * bs, w.Linv + no * dm.nt * TB * TB, w.Linvl + no * dm.nt * TB * TB, dp, lds);
+  if (threadIdx.x == 0 && nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
+}
+
+// O_x <- T[x, i] L_i^-T for the two neighbours of an eliminated node, one workgroup per 64-row strip
+__global__ void __launch_bounds__(256, 2) k_dd_trsm(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int nstrip = (dm.dp + 63) / 64, per = 2 * nstrip;
+  const int it = cr_item(count * nelim * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int g = it / per, r = it - g * per;
+  const int b = cr.alist[g / nelim];
+  const int* er = cr.elim + (size_t)(eoff + g % nelim) * CR_EW;
+  const int which = r / nstrip, strip = r - which * nstrip;
+  const int slot = which ? er[CE_EB] : er[CE_EA];
+  if (slot < 0) return;
+  const int node = er[CE_NODE], dp = dm.dp;
+  const size_t bs = (size_t)dp * dp, no = ((size_t)b * dm.p + node);
+  const double* Dh = w.D + no * bs; const double* Dl = w.Dl + no * bs;
+  const double* Lih = w.Linv + no * dm.nt * TB * TB; const double* Lil = w.Linvl + no * dm.nt * TB * TB;
+  const int r0 = strip * 64, rows = (dp - r0 < 64) ? dp - r0 : 64;
+  double* Xh = cr_edge(w, dm, b, slot) + (size_t)r0 * dp; double* Xl = dd_edge_lo(w, dm, b, slot) + (size_t)r0 * dp;
+  int jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    if (j0 > 0) wg_gemm_dd<false>(Xh + j0, Xl + j0, dp, Xh, Xl, dp, Dh + (size_t)j0 * dp, Dl + (size_t)j0 * dp, dp, rows, nb, j0, GM_SUB, lds);
+    wg_gemm_dd<false>(Xh + j0, Xl + j0, dp, Xh + j0, Xl + j0, dp, Lih + (size_t)jt * TB * TB, Lil + (size_t)jt * TB * TB, TB, rows, nb, nb, GM_SET, lds);
+  }
+}
+
+// per surviving node: lower tiles of D_s -= O_s O_s' (one or two eliminated neighbours); per eliminated node: the fill edge (-)= O_x O_y'
+__global__ void __launch_bounds__(256, 2) k_dd_update(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
+  const int dp = dm.dp, nm = (dp + 63) / 64;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
+  const int per = nupd * ntl + nelim * ntf;
+  const int it = cr_item(count * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / per];
+  int r = it % per;
+  const size_t bs = (size_t)dp * dp;
+  if (r < nupd * ntl) {
+    const int* ur = cr.upd + (size_t)(uoff + r / ntl) * CR_UW;
+    int t = r % ntl, tm = 0;
+    while (t > tm) { t -= tm + 1; ++tm; }
+    const int tn = t, m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const size_t co = ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
+    for (int q = 0; q < 2; ++q) {
+      const int slot = ur[q ? CU_E1 : CU_E0];
+      if (slot < 0) break;
+      const double* Oh = cr_edge(w, dm, b, slot); const double* Ol = dd_edge_lo(w, dm, b, slot);
+      wg_gemm_dd<false>(w.D + co, w.Dl + co, dp, Oh + (size_t)m0 * dp, Ol + (size_t)m0 * dp, dp, Oh + (size_t)n0 * dp, Ol + (size_t)n0 * dp, dp, M, N, dp, GM_SUB, lds);
+    }
+  } else {
+    r -= nupd * ntl;
+    const int* er = cr.elim + (size_t)(eoff + r / ntf) * CR_EW;
+    if (er[CE_FILL] < 0) return;
+    const int t = r % ntf, tm = t / nm, tn = t - tm * nm;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const int sx = er[CE_FX] ? er[CE_EB] : er[CE_EA], sy = er[CE_FX] ? er[CE_EA] : er[CE_EB];
+    const double* Oxh = cr_edge(w, dm, b, sx); const double* Oxl = dd_edge_lo(w, dm, b, sx);
+    const double* Oyh = cr_edge(w, dm, b, sy); const double* Oyl = dd_edge_lo(w, dm, b, sy);
+    const size_t co = (size_t)m0 * dp + n0;
+    wg_gemm_dd<false>(cr_edge(w, dm, b, er[CE_FILL]) + co, dd_edge_lo(w, dm, b, er[CE_FILL]) + co, dp, Oxh + (size_t)m0 * dp, Oxl + (size_t)m0 * dp, dp,
+                      Oyh + (size_t)n0 * dp, Oyl + (size_t)n0 * dp, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, lds);
+  }
+}
+
+// ------------------------------------------------------------------ substitutions: dd right-hand sides [NCD][xld] in LDS
+constexpr int NCD = 3;                          // right-hand sides per sweep
+// Y[q][i] (+)= sgn * sum_c Mop[i][c] X[q][c],  Mop = M (rows x cols, ldm) or M'.  Slabs of 64 rows x 16 columns of Mop through LDS; thread
+// (r, kq) = (tid & 63, tid >> 6) multiplies row r with the four columns 4 kq .. + 3 of every slab, the four partial sums meet in LDS.
+constexpr int DD_GEMV_LDS = 2 * DG_SLAB + 2 * 4 * NCD * 64;
+template <bool TRANS>
+__device__ __forceinline__ void wg_gemv_dd(double* Yh, double* Yl, int yld, const double* Xh, const double* Xl, int xld, const double* Mh, const double* Ml, int ldm,
+                                           int rows, int cols, bool accumulate, double sgn, double* As, int nc) {
+  const int tid = threadIdx.x, r = tid & 63, kq = tid >> 6;
+  double* sh = As; double* sl = As + DG_SLAB; double* redh = As + 2 * DG_SLAB; double* redl = redh + 4 * NCD * 64;
+  for (int m0 = 0; m0 < rows; m0 += 64) {
+    double ah_[NCD], al_[NCD];
+#pragma unroll
+    for (int q = 0; q < NCD; ++q) { ah_[q] = 0.0; al_[q] = 0.0; }
+    for (int k0 = 0; k0 < cols; k0 += DG_K) {
+      __syncthreads();
+      if (TRANS) {                    // Mop[i][c] = M[c][i]: a slab row (fixed c) is contiguous in i
+        const int k = tid >> 4, mq = (tid & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (k0 + k < cols) && (m0 + mq + q < rows);
+          sh[k * DG_LD + mq + q] = ok ? Mh[(size_t)(k0 + k) * ldm + m0 + mq + q] : 0.0;
+          sl[k * DG_LD + mq + q] = ok ? Ml[(size_t)(k0 + k) * ldm + m0 + mq + q] : 0.0;
+        }
+      } else {
+        const int rr = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = (m0 + rr < rows) && (k0 + kk + q < cols);
+          sh[(kk + q) * DG_LD + rr] = ok ? Mh[(size_t)(m0 + rr) * ldm + k0 + kk + q] : 0.0;
+          sl[(kk + q) * DG_LD + rr] = ok ? Ml[(size_t)(m0 + rr) * ldm + k0 + kk + q] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kq + kk;
+        if (k0 + k < cols) {
+          const double mh = sh[k * DG_LD + r], ml = sl[k * DG_LD + r];
+#pragma unroll
+          for (int q = 0; q < NCD; ++q) if (q < nc) dd_fma_acc(ah_[q], al_[q], mh, ml, Xh[q * xld + k0 + k], Xl[q * xld + k0 + k]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NCD; ++q) { const ddv v = dd_qts(ah_[q], al_[q]); redh[(kq * NCD + q) * 64 + r] = v.h; redl[(kq * NCD + q) * 64 + r] = v.l; }
+    __syncthreads();
+    if (kq < nc && m0 + r < rows) {            // wave kq joins the partial sums of right-hand side kq
+      const int q = kq;
+      ddv s = ddv{redh[q * 64 + r], redl[q * 64 + r]};
+#pragma unroll
+      for (int g = 1; g < 4; ++g) s = dd_add(s, ddv{redh[(g * NCD + q) * 64 + r], redl[(g * NCD + q) * 64 + r]});
+      s = dd_muld(s, sgn);                      // (+-1: exact)
+      const int i = m0 + r;
+      const ddv y = accumulate ? dd_add(ddv{Yh[q * yld + i], Yl[q * yld + i]}, s) : s;
+      Yh[q * yld + i] = y.h; Yl[q * yld + i] = y.l;
+    }
+  }
+  __syncthreads();
+}
+
+constexpr int dd_solve_lds_doubles(int dp) { return 2 * 2 * NCD * (dp + 4) + 2 * NCD * (TB + 4) + DD_GEMV_LDS; }
+// right-hand sides of a node: fp64 high words in W3 / Z (cr_rhs), low words in W3l / Zl
+__device__ __forceinline__ double* dd_rhs_lo(const WS& w, const Dims& dm, int b, int node, int nc) {
+  return ((nc == 3) ? w.W3l : w.Zl) + ((size_t)b * dm.p + node) * dm.dp * nc;
+}
+__device__ __forceinline__ void ddvec_g2s(double* zh, double* zl, int xld, const double* Rh, const double* Rl, int dp, int nc) {
+  for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; zh[q * xld + i] = Rh[e]; zl[q * xld + i] = Rl[e]; }
+}
+__device__ __forceinline__ void ddvec_s2g(double* Rh, double* Rl, const double* zh, const double* zl, int xld, int dp, int nc) {
+  for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; const ddv v = dd_qts(zh[q * xld + i], zl[q * xld + i]); Rh[e] = v.h; Rl[e] = v.l; }
+}
+// z <- L^-1 z and z <- L^-T z with the inverted diagonal tiles (blk_fwd / blk_bwd of tmpc_factor.h)
+__device__ __forceinline__ void blk_fwd_dd(double* zh, double* zl, int xld, double* th, double* tl, int tld, const double* Dh, const double* Dl, const double* Lih, const double* Lil,
+                                           int dp, double* As, int nc) {
+  int jt = 0;
+  for (int j0 = 0; j0 < dp; j0 += TB, ++jt) {
+    const int nb = (dp - j0 < TB) ? dp - j0 : TB;
+    wg_gemv_dd<false>(th, tl, tld, zh + j0, zl + j0, xld, Lih + (size_t)jt * TB * TB, Lil + (size_t)jt * TB * TB, TB, nb, nb, false, 1.0, As, nc);
+    for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; zh[q * xld + j0 + i] = th[q * tld + i]; zl[q * xld + j0 + i] = tl[q * tld + i]; }
+    __syncthreads();
+    const int rem = dp - j0 - nb;
+    if (rem > 0) wg_gemv_dd<false>(zh + j0 + nb, zl + j0 + nb, xld, zh + j0, zl + j0, xld, Dh + (size_t)(j0 + nb) * dp + j0, Dl + (size_t)(j0 + nb) * dp + j0, dp, rem, nb, true, -1.0, As, nc);
+  }
+}
+__device__ __forceinline__ void blk_bwd_dd(double* zh, double* zl, int xld, double* th, double* tl, int tld, const double* Dh, const double* Dl, const double* Lih, const double* Lil,
+                                           int dp, double* As, int nc) {
+  const int nt = (dp + TB - 1) / TB;
+  for (int jt = nt - 1; jt >= 0; --jt) {
+    const int j0 = jt * TB, nb = (dp - j0 < TB) ? dp - j0 : TB;
+    wg_gemv_dd<true>(th, tl, tld, zh + j0, zl + j0, xld, Lih + (size_t)jt * TB * TB, Lil + (size_t)jt * TB * TB, TB, nb, nb, false, 1.0, As, nc);
+    for (int e = threadIdx.x; e < nb * nc; e += 256) { const int q = e / nb, i = e - q * nb; zh[q * xld + j0 + i] = th[q * tld + i]; zl[q * xld + j0 + i] = tl[q * tld + i]; }
+    __syncthreads();
+    if (j0 > 0) wg_gemv_dd<true>(zh, zl, xld, zh + j0, zl + j0, xld, Dh + (size_t)j0 * dp, Dl + (size_t)j0 * dp, dp, j0, nb, true, -1.0, As, nc);
+  }
+}
+// number of right-hand sides of a problem in the tight loop / polish: pass 1 (main phase) and every centering / polish solve carry three
+__device__ __forceinline__ int dd_nc(const WS& w, int b, int pass) {
+  const int phase = w.iprob[(size_t)b * IS + I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
+  return (pass == 1 || phase != PH_MAIN) ? 3 : 1;
+}
+#define TMPC_DD_SOLVE_LDS                                                                                     \
+  extern __shared__ __attribute__((aligned(16))) double lds[];                                                \
+  const int dp = dm.dp, xld = dp + 4, tld = TB + 4;                                                            \
+  double* zch = lds; double* zcl = zch + NCD * xld; double* znh = zcl + NCD * xld; double* znl = znh + NCD * xld; \
+  double* th = znl + NCD * xld; double* tl = th + NCD * tld; double* As = tl + NCD * tld;
+
+__global__ void __launch_bounds__(256) k_dd_fwd_diag(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  TMPC_DD_SOLVE_LDS
+  const int b = cr.alist[it / nelim];
+  const int nc = dd_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE];
+  const size_t no = (size_t)b * dm.p + node;
+  double* Rh = cr_rhs(w, dm, b, node, nc); double* Rl = dd_rhs_lo(w, dm, b, node, nc);
+  ddvec_g2s(zch, zcl, xld, Rh, Rl, dp, nc);
+  __syncthreads();
+  blk_fwd_dd(zch, zcl, xld, th, tl, tld, w.D + no * dp * dp, w.Dl + no * dp * dp, w.Linv + no * dm.nt * TB * TB, w.Linvl + no * dm.nt * TB * TB, dp, As, nc);
+  ddvec_s2g(Rh, Rl, zch, zcl, xld, dp, nc);
+  (void)znh; (void)znl;
+}
+__global__ void __launch_bounds__(256) k_dd_fwd_off(WS w, Dims dm, CrDev cr, int uoff, int nupd, int count, int pass) {
+  const int it = cr_item(count * nupd);
+  if (it < 0) return;
+  TMPC_DD_SOLVE_LDS
+  const int b = cr.alist[it / nupd];
+  const int nc = dd_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* ur = cr.upd + (size_t)(uoff + it % nupd) * CR_UW;
+  double* Rh = cr_rhs(w, dm, b, ur[CU_NODE], nc); double* Rl = dd_rhs_lo(w, dm, b, ur[CU_NODE], nc);
+  ddvec_g2s(zch, zcl, xld, Rh, Rl, dp, nc);
+  for (int q = 0; q < 2; ++q) {
+    const int slot = ur[q ? CU_E1 : CU_E0];
+    if (slot < 0) break;
+    const int src = ur[q ? CU_S1 : CU_S0];
+    __syncthreads();
+    ddvec_g2s(znh, znl, xld, cr_rhs(w, dm, b, src, nc), dd_rhs_lo(w, dm, b, src, nc), dp, nc);
+    __syncthreads();
+    wg_gemv_dd<false>(zch, zcl, xld, znh, znl, xld, cr_edge(w, dm, b, slot), dd_edge_lo(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);      // z_s -= O_s z_i
+  }
+  __syncthreads();
+  ddvec_s2g(Rh, Rl, zch, zcl, xld, dp, nc);
+  (void)th; (void)tl;
+}
+__global__ void __launch_bounds__(256) k_dd_bwd(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  TMPC_DD_SOLVE_LDS
+  const int b = cr.alist[it / nelim];
+  const int nc = dd_nc(w, b, pass);
+  if (nc == 0) return;
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE];
+  const size_t no = (size_t)b * dm.p + node;
+  double* Rh = cr_rhs(w, dm, b, node, nc); double* Rl = dd_rhs_lo(w, dm, b, node, nc);
+  ddvec_g2s(zch, zcl, xld, Rh, Rl, dp, nc);
+  for (int q = 0; q < 2; ++q) {
+    const int slot = er[q ? CE_EB : CE_EA];
+    if (slot < 0) continue;
+    const int nbr = er[q ? CE_NB : CE_NA];
+    __syncthreads();
+    ddvec_g2s(znh, znl, xld, cr_rhs(w, dm, b, nbr, nc), dd_rhs_lo(w, dm, b, nbr, nc), dp, nc);
+    __syncthreads();
+    wg_gemv_dd<true>(zch, zcl, xld, znh, znl, xld, cr_edge(w, dm, b, slot), dd_edge_lo(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);       // z_i -= O_x' z_x
+  }
+  __syncthreads();
+  blk_bwd_dd(zch, zcl, xld, th, tl, tld, w.D + no * dp * dp, w.Dl + no * dp * dp, w.Linv + no * dm.nt * TB * TB, w.Linvl + no * dm.nt * TB * TB, dp, As, nc);
+  ddvec_s2g(Rh, Rl, zch, zcl, xld, dp, nc);
+}
+
+// ------------------------------------------------------------------ small dd matrices in LDS (stage level: n <= 32), 256 threads
+// a matrix is a pair of images (hi at p, lo at p + MS), leading dimension LD
+struct sdd { double* p; __device__ __forceinline__ double& h(int i, int j) const { return p[i * LD + j]; } __device__ __forceinline__ double& l(int i, int j) const { return p[MS + i * LD + j]; }
+             __device__ __forceinline__ ddv get(int i, int j) const { return ddv{p[i * LD + j], p[MS + i * LD + j]}; } __device__ __forceinline__ void set(int i, int j, ddv v) const { p[i * LD + j] = v.h; p[MS + i * LD + j] = v.l; } };
+// C (m x n) = A (m x k) op(B): tb ? B (n x k)' : B (k x n); ta: A given as (k x m)'
+__device__ __forceinline__ void sdd_mm(sdd C, sdd A, bool ta, sdd B, bool tb, int m, int k, int n) {
+  for (int e = threadIdx.x; e < m * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    double sh = 0.0, sl = 0.0;
+    for (int q = 0; q < k; ++q) {
+      const ddv a = ta ? A.get(q, i) : A.get(i, q), bb = tb ? B.get(j, q) : B.get(q, j);
+      dd_fma_acc(sh, sl, a.h, a.l, bb.h, bb.l);
+    }
+    C.set(i, j, dd_qts(sh, sl));
+  }
+  __syncthreads();
+}
+// in-place lower Cholesky of the n x n dd matrix S, then Z = S^-1 = L^-T L^-1 (W: scratch for L^-1).  Returns non-positive pivots (uniform).
+__device__ __forceinline__ int sdd_inv_spd(sdd Z, sdd S, sdd W, int n, double* flag) {
+  const int tid = threadIdx.x;
+  if (tid == 0) flag[0] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    ddv piv = S.get(j, j);
+    if (!(piv.h > 0.0)) { piv = ddv{1.0, 0.0}; if (tid == 0) flag[0] += 1.0; }
+    const ddv r = dd_sqrt(piv), rinv = dd_div(dd_from(1.0), r);
+    __syncthreads();
+    if (tid == 0) S.set(j, j, r);
+    if (tid > j && tid < n) S.set(tid, j, dd_mul(S.get(tid, j), rinv));
+    __syncthreads();
+    for (int e = tid; e < (n - j - 1) * (n - j - 1); e += 256) {
+      const int i = j + 1 + e / (n - j - 1), k = j + 1 + e % (n - j - 1);
+      if (k <= i) S.set(i, k, dd_sub(S.get(i, k), dd_mul(S.get(i, j), S.get(k, j))));
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < n * n; e += 256) W.set(e / n, e % n, ddv{0.0, 0.0});
+  __syncthreads();
+  if (tid < n) {                     // column c of L^-1 (forward substitution)
+    const int c = tid;
+    for (int i = c; i < n; ++i) {
+      ddv s = dd_from(i == c ? 1.0 : 0.0);
+      for (int k = c; k < i; ++k) s = dd_sub(s, dd_mul(S.get(i, k), W.get(k, c)));
+      W.set(i, c, dd_div(s, S.get(i, i)));
+    }
+  }
+  __syncthreads();
+  sdd_mm(Z, W, true, W, false, n, n, n);          // L^-T L^-1
+  for (int e = tid; e < n * n; e += 256) {        // exact symmetry
+    const int i = e / n, j = e % n;
+    if (j < i) { const ddv v = dd_muld(dd_add(Z.get(i, j), Z.get(j, i)), 0.5); S.set(i, j, v); }
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; if (j < i) { const ddv v = S.get(i, j); Z.set(i, j, v); Z.set(j, i, v); } }
+  __syncthreads();
+  return (int)flag[0];
+}
+__device__ __forceinline__ void sdd_store(double* gh, double* gl, sdd A, int r, int c, int ldg) {       // A[:r, :c] -> global planes
+  for (int e = threadIdx.x; e < r * c; e += 256) { const int i = e / c, j = e - i * c; gh[(size_t)i * ldg + j] = A.h(i, j); gl[(size_t)i * ldg + j] = A.l(i, j); }
+}
+__device__ __forceinline__ void sdd_load64(sdd A, const double* g, int r, int c, int ldg) {              // fp64 global -> dd (lo = 0)
+  for (int e = threadIdx.x; e < r * c; e += 256) { const int i = e / c, j = e - i * c; A.h(i, j) = g[(size_t)i * ldg + j]; A.l(i, j) = 0.0; }
+}
+
+// Kronecker-factor images of one cone block from the dd pair (X, Z): KX = V X V', KS = V Z V', FX = X_E V', FS = Z_E V', XXX, SIXX (t0, t1: scratch)
+__device__ __forceinline__ void dd_images(const WS& w, size_t sid, int r, sdd V, sdd X, sdd Z, sdd t0, sdd t1, int n, int nx) {
+  const int nxx = nx * nx;
+  double* kh = w.KF + (sid * 12 + (size_t)r * KF_PER_LMI) * nxx; double* kl = w.KFl + (sid * 12 + (size_t)r * KF_PER_LMI) * nxx;
+  sdd_mm(t0, V, false, X, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);
+  sdd_store(kh + KF_KX * nxx, kl + KF_KX * nxx, t1, nx, nx, nx);
+  sdd_mm(t1, X, false, V, true, nx, n, nx);                                        // X[:nx, :] V'
+  sdd_store(kh + KF_FX * nxx, kl + KF_FX * nxx, t1, nx, nx, nx);
+  sdd_store(kh + KF_XXX * nxx, kl + KF_XXX * nxx, X, nx, nx, nx);
+  __syncthreads();
+  sdd_mm(t0, V, false, Z, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);
+  sdd_store(kh + KF_KS * nxx, kl + KF_KS * nxx, t1, nx, nx, nx);
+  sdd_mm(t1, Z, false, V, true, nx, n, nx);
+  sdd_store(kh + KF_FS * nxx, kl + KF_FS * nxx, t1, nx, nx, nx);
+  sdd_store(kh + KF_SIXX * nxx, kl + KF_SIXX * nxx, Z, nx, nx, nx);
+  __syncthreads();
+}
+
+// tight loop: the images from the fp64 iterates X_r, S_r^-1 (k_stage_pre wrote them), one workgroup per stage of the active problems
+constexpr int DD_IMG_SLOTS = 10;                 // five dd matrices
+__global__ void __launch_bounds__(256) k_dd_images(WS w, Dims dm) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = stage_id(w, dm);
+  const int b = sid / dm.p;
+  if (w.iprob[(size_t)b * IS + I_PHASE] == PH_DONE) return;
+  const int n = dm.n, nx = dm.nx, nn = n * n;
+  sdd V{sm}, X{sm + 2 * MS}, Z{sm + 4 * MS}, t0{sm + 6 * MS}, t1{sm + 8 * MS};
+  sdd_load64(V, w.V + (size_t)sid * nx * n, nx, n, n);
+  for (int r = 0; r < 2; ++r) {
+    __syncthreads();
+    sdd_load64(X, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n);
+    sdd_load64(Z, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n);
+    __syncthreads();
+    dd_images(w, (size_t)sid, r, V, X, Z, t0, t1, n, nx);
+  }
+}
+
+// ------------------------------------------------------------------ assembly of D_k and the coupling block in dd (k_schur of tmpc_schur.h)
+// One workgroup per stage and part; a thread owns a stored column and walks the rows.  PART 0: D_k (lower triangle), PART 1: coupling block.
+template <int PART> constexpr int ddsch_mats() { return PART == 0 ? 8 : 4; }
+template <int PART>
+__global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
+  constexpr int NM = ddsch_mats<PART>();
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = stage_id(w, dm);
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  if (w.iprob[(size_t)b * IS + I_PHASE] == PH_DONE) return;
+  const int tid = threadIdx.x, nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
+  double* mh = sm; double* ml = sm + (size_t)NM * nxx;                 // [NM][nx][nx] hi, lo
+  unsigned* pair = (unsigned*)(ml + (size_t)NM * nxx);
+  const bool corner = (w.cr_orient[k] != 0);
+  const int km = (k == 0) ? dm.p - 1 : k - 1;
+  const size_t ok = (size_t)sid * 12 * nxx, om = (size_t)(b * dm.p + km) * 12 * nxx;
+  for (int e = tid; e < 12 * nxx; e += 256) {
+    const int m = e / nxx, r = e - m * nxx;
+    const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
+    const bool fmat = (slot == KF_FX || slot == KF_FS);
+    if (fmat != (PART == 1)) continue;
+    const size_t src = ((slot == KF_KX || slot == KF_KS) ? om : ok) + e;
+    int i = r / nx, j = r - i * nx;
+    if (fmat && !corner) { const int t_ = i; i = j; j = t_; }
+    const int q = fmat ? 2 * lmi + (slot - KF_FX) : 4 * lmi + slot;       // D: XXX, SIXX, KX, KS per LMI; C: FX, FS per LMI
+    mh[(size_t)q * nxx + i * nx + j] = w.KF[src]; ml[(size_t)q * nxx + i * nx + j] = w.KFl[src];
+  }
+  if (tid < nx) { int e = tid * nx - (tid * (tid - 1)) / 2; for (int c = tid; c < nx; ++c) pair[e++] = (unsigned)tid | ((unsigned)c << 16); }
+  __syncthreads();
+  double* Gh = (PART == 0 ? w.D : w.O) + (size_t)sid * dp * dp; double* Gl = (PART == 0 ? w.Dl : w.Ol) + (size_t)sid * dp * dp;
+  auto at = [&](int q, int i, int j) { return ddv{mh[(size_t)q * nxx + i * nx + j], ml[(size_t)q * nxx + i * nx + j]}; };
+  auto hkm = [&](int qx, int qs, int a, int bb, int c, int e_) {          // T(Lx, Ls)[(ab),(ce)] without the weights
+    return dd_add(dd_add(dd_mul(at(qx, a, c), at(qs, bb, e_)), dd_mul(at(qx, a, e_), at(qs, bb, c))),
+                  dd_add(dd_mul(at(qx, bb, c), at(qs, a, e_)), dd_mul(at(qx, bb, e_), at(qs, a, c))));
+  };
+  for (int col = tid; col < dp; col += 256) {
+    const bool cin = col < d;
+    const unsigned pc_ = cin ? pair[col] : 0u;
+    const int c = (int)(pc_ & 0xffffu), e_ = (int)(pc_ >> 16);
+    const double wc = (c == e_) ? 0.5 : 1.0;
+    for (int row = (PART == 0 ? col : 0); row < dp; ++row) {
+      const size_t g = (size_t)row * dp + col;
+      if (row >= d || !cin) { Gh[g] = (PART == 0 && row == col) ? 1.0 : 0.0; Gl[g] = 0.0; continue; }
+      const unsigned pr_ = pair[row];
+      const int a = (int)(pr_ & 0xffffu), bb = (int)(pr_ >> 16);
+      const double wgt = ((a == bb) ? 0.5 : 1.0) * wc;
+      ddv v;
+      if (PART == 0) v = dd_add(dd_add(hkm(0, 1, a, bb, c, e_), hkm(2, 3, a, bb, c, e_)), dd_add(hkm(4, 5, a, bb, c, e_), hkm(6, 7, a, bb, c, e_)));
+      else v = dd_neg(dd_add(hkm(0, 1, a, bb, c, e_), hkm(2, 3, a, bb, c, e_)));
+      v = dd_muld(v, wgt);                                               // (a power of two: exact)
+      Gh[g] = v.h; Gl[g] = v.l;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ polish: every stage quantity in dd from the fp64 y = (tau, alpha, P)
+// Writes, per stage: the dd Kronecker factors (X_r := mu S_r^-1); the adjoint pieces V G V' and G_EE in dd of G = X1 - X2 (gradient),
+// Psi = X2 S2^-1 and Phi(Hb) (border columns); the partial sums of the border / gradient scalars; fp64 roundings of S_r, X_r (outputs,
+// dual export) and of M (T1: the step norm).  Q_CHOLBAD counts non-positive pivots (the iterate left the cone).
+constexpr int DD_POL_SLOTS = 18;                 // nine dd matrices
+__global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_sweep) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double flag[2];
+  const int sid = stage_id(w, dm);
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  // final_sweep: the problems whose polish ended Optimal, once more at their final iterate (cone check, X_r and S_r for the outputs)
+  if (final_sweep ? (w.iprob[(size_t)b * IS + I_PHASE] != PH_DONE || w.iprob[(size_t)b * IS + I_NPOLISH] == 0 || w.iprob[(size_t)b * IS + I_IPMSTATUS] != IPM_OPTIMAL)
+                  : (w.iprob[(size_t)b * IS + I_PHASE] != PH_POLISH)) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double tau = pr[P_TAU], alpha = pr[P_ALPHA], mu = pr[P_MUT];
+  const int tid = threadIdx.x, n = dm.n, nx = dm.nx, nn = n * n, nxx = nx * nx;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  sdd V{sm}, Hd{sm + 2 * MS}, M{sm + 4 * MS}, Z1{sm + 6 * MS}, Z2{sm + 8 * MS}, X{sm + 10 * MS}, t0{sm + 12 * MS}, t1{sm + 14 * MS}, t2{sm + 16 * MS};
+  sdd_load64(V, w.V + (size_t)sid * nx * n, nx, n, n);
+  sdd_load64(Hd, w.Hb + (size_t)sid * nn, n, n, n);
+  sdd_load64(t0, w.P + (size_t)(b * dm.p + kn) * nxx, nx, nx, nx);
+  __syncthreads();
+  sdd_mm(t1, V, true, t0, false, n, nx, nx);                 // V' P_{k+1}
+  sdd_mm(M, t1, false, V, false, n, nx, n);                  // (V' P+) V
+  const double* Pk = w.P + (size_t)sid * nxx;
+  for (int e = tid; e < nn; e += 256) {
+    const int i = e / n, j = e - i * n;
+    ddv v = dd_add(M.get(i, j), dd_muld(Hd.get(i, j), alpha));
+    if (i < nx && j < nx) v = dd_sub(v, dd_from(Pk[i * nx + j]));
+    M.set(i, j, v);
+  }
+  __syncthreads();
+  for (int e = tid; e < nn; e += 256) {                     // exact symmetry, fp64 rounding for the step norm
+    const int i = e / n, j = e - i * n;
+    if (j < i) { const ddv v = dd_muld(dd_add(M.get(i, j), M.get(j, i)), 0.5); t0.set(i, j, v); }
+  }
+  __syncthreads();
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; if (j < i) { const ddv v = t0.get(i, j); M.set(i, j, v); M.set(j, i, v); } }
+  __syncthreads();
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; w.T1[(size_t)sid * nn + e] = dd_val(M.get(i, j)); }
+  int nbad = (alpha - ALPHA_MIN > 0.0) ? 0 : 1;
+  // S1 = M - I, S2 = tau I - M, their inverses
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const ddv m = M.get(i, j); t0.set(i, j, (i == j) ? dd_sub(m, dd_from(1.0)) : m); w.S1[(size_t)sid * nn + e] = dd_val(t0.get(i, j)); }
+  __syncthreads();
+  nbad += sdd_inv_spd(Z1, t0, t1, n, flag);
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const ddv m = M.get(i, j); t0.set(i, j, (i == j) ? dd_sub(dd_from(tau), m) : dd_neg(m)); w.S2[(size_t)sid * nn + e] = dd_val(t0.get(i, j)); }
+  __syncthreads();
+  nbad += sdd_inv_spd(Z2, t0, t1, n, flag);
+  // per cone block: X = mu Z, images; the adjoint pieces accumulate G = X1 - X2 (t2) and Phi (M is free now: M <- Phi)
+  double trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0, hbphi = 0.0;
+  for (int r = 0; r < 2; ++r) {
+    sdd Z = r ? Z2 : Z1;
+    for (int e = tid; e < nn; e += 256) {
+      const int i = e / n, j = e - i * n;
+      const ddv x = dd_muld(Z.get(i, j), mu);
+      X.set(i, j, x);
+      (r ? w.X2 : w.X1)[(size_t)sid * nn + e] = dd_val(x);
+      (r ? w.S2i : w.S1i)[(size_t)sid * nn + e] = dd_val(Z.get(i, j));
+      t2.set(i, j, r ? dd_sub(t2.get(i, j), x) : x);
+    }
+    __syncthreads();
+    dd_images(w, (size_t)sid, r, V, X, Z, t0, t1, n, nx);
+    sdd_mm(t0, X, false, Hd, false, n, n, n); sdd_mm(t1, t0, false, Z, false, n, n, n);      // X Hb Z (symmetric up to rounding: Z, Hb symmetric, X = mu Z)
+    for (int e = tid; e < nn; e += 256) {
+      const int i = e / n, j = e - i * n;
+      const ddv ph = dd_muld(dd_add(t1.get(i, j), t1.get(j, i)), 0.5);
+      if (r == 1 && i == j) trphi2 += dd_val(ph);
+      M.set(i, j, r ? dd_add(M.get(i, j), ph) : ph);
+    }
+    __syncthreads();
+    if (r == 1) {
+      sdd_mm(t0, X, false, Z, false, n, n, n);                                              // Psi = X2 Z2
+      for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; if (i == j) { trpsi += dd_val(t0.get(i, j)); trx2 += dd_val(X.get(i, j)); } }
+      sdd_mm(t1, V, false, t0, false, nx, n, n); sdd_mm(X, t1, false, V, true, nx, n, nx);   // V Psi V'   (X is free)
+      sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_PSI) * nxx, X, nx, nx, nx);
+      sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx);
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; hby += dd_val(dd_mul(Hd.get(i, j), t2.get(i, j))); hbphi += dd_val(dd_mul(Hd.get(i, j), M.get(i, j))); }
+  sdd_mm(t0, V, false, t2, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);       // V G V'
+  sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx);
+  sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_G) * nxx, t2, nx, nx, nx);
+  __syncthreads();
+  sdd_mm(t0, V, false, M, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);        // V Phi V'
+  sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx);
+  sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_PHI) * nxx, M, nx, nx, nx);
+  trx2 = block_sum<256>(trx2); hby = block_sum<256>(hby); trpsi = block_sum<256>(trpsi); trphi2 = block_sum<256>(trphi2); hbphi = block_sum<256>(hbphi);
+  if (tid == 0) {
+    double* q = w.part + (size_t)sid * NPART;
+    q[Q_TRT2] = trx2; q[Q_HBG] = hby; q[Q_TRPSI] = trpsi; q[Q_TRPHI2] = trphi2; q[Q_HBPHI] = hbphi; q[Q_CHOLBAD] = (double)nbad; q[Q_TRX2] = trx2; q[Q_HBY] = hby;
+  }
+}
+
+// right-hand sides [rhs | u_tau | u_alpha] of the polish step from the dd adjoint pieces: the subtraction adjV[j-1] - adjE[j] in dd, THEN rounded
+__global__ void __launch_bounds__(64) k_dd_gather(WS w, Dims dm) {
+  const int sid = stage_id(w, dm);
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  if (w.iprob[(size_t)b * IS + I_PHASE] != PH_POLISH) return;
+  const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
+  const int km = (k == 0) ? dm.p - 1 : k - 1;
+  const size_t ov = (size_t)(b * dm.p + km) * NADJ * nxx, oe = (size_t)sid * NADJ * nxx;
+  int e = 0;
+  for (int a = 0; a < nx; ++a) {
+    for (int c = a + lane; c < nx; c += 64) {
+      const int idx = e + (c - a), o = a * nx + c;
+      const double wgt = (a == c) ? 1.0 : 2.0;
+      auto piece = [&](int s) { return dd_val(dd_sub(ddv{w.adjV[ov + s * nxx + o], w.adjVl[ov + s * nxx + o]}, ddv{w.adjE[oe + s * nxx + o], w.adjEl[oe + s * nxx + o]})); };
+      const double g = wgt * piece(ADJ_G), ut = -wgt * piece(ADJ_PSI), ua = wgt * piece(ADJ_PHI);
+      double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3; w3[0] = g; w3[1] = ut; w3[2] = ua;
+      double* u = w.U + ((size_t)sid * dp + idx) * 2; u[0] = ut; u[1] = ua;
+    }
+    e += nx - a;
+  }
+  for (int i = dm.d + lane; i < dp; i += 64) {
+    double* w3 = w.W3 + ((size_t)sid * dp + i) * 3; w3[0] = 0.0; w3[1] = 0.0; w3[2] = 0.0;
+    double* u = w.U + ((size_t)sid * dp + i) * 2; u[0] = 0.0; u[1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------ control of the tight phase
+// restart of the problems that ended Optimal: the same loop towards mu_t = tight_tol * kappa, block linear algebra in dd
+__global__ void __launch_bounds__(64) k_tight_restart(WS w, Dims dm, Opts o) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= dm.B) return;
+  int* ip = w.iprob + (size_t)b * IS;
+  double* pr = w.prob + (size_t)b * PS;
+  if (ip[I_PHASE] != PH_DONE || ip[I_EARLY] || ip[I_IPMSTATUS] != IPM_OPTIMAL) return;
+  const double mut = exp2(rint(log2(o.tight_tol * fmax(1.0, fabs(pr[P_TAU])))));
+  if (!(mut < pr[P_MUT])) return;                 // nothing tighter asked for
+  pr[P_MUT1] = pr[P_MUT]; pr[P_MUT] = mut; pr[P_PREVSTEPN] = -1.0;
+  ip[I_PHASE] = PH_MAIN; ip[I_IPMSTATUS] = IPM_MAXITER; ip[I_NCENT] = 0; ip[I_CHORD] = 0; ip[I_REG] = 0; ip[I_JAM] = 0; ip[I_SHIFTRUN] = 0; ip[I_BOSTEP] = 0;
+  ip[I_DD] = 1;
+  const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; w.flist[slot] = b;
+}
+
+// polish, after k_dd_polish_pre: scalars of the border system and of the gradient (the slots k_solve_border reads), cone check
+__global__ void __launch_bounds__(64) k_polish_ctrl_a(WS w, Dims dm) {
+  const int b = prob_id(w), lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_POLISH) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p;
+  const double trpsi = psum(w.part, b, p, Q_TRPSI, lane), trphi2 = psum(w.part, b, p, Q_TRPHI2, lane), hbphi = psum(w.part, b, p, Q_HBPHI, lane);
+  const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
+  if (nbad > 0.0) {
+    // the last step left the cone (not seen after the centering phase; the CPU restatement would halve the step): back to the iterate before it
+    const int nxx = dm.nx * dm.nx;
+    if (ip[I_NPOLISH] > 0) for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
+    if (lane == 0) {
+      if (ip[I_NPOLISH] > 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; }
+      ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
+    }
+    return;
+  }
+  if (lane != 0) return;
+  const double s0 = pr[P_ALPHA] - ALPHA_MIN, x0 = pr[P_MUT] / s0;
+  pr[P_S0] = s0; pr[P_X0] = x0; pr[P_RD0] = 0.0; pr[P_CORR0] = 0.0; pr[P_SIGMU] = pr[P_MUT]; pr[P_MU] = pr[P_MUT];
+  pr[P_BTT] = trpsi; pr[P_BTA] = -trphi2; pr[P_BAA] = hbphi + x0 / s0;
+  ip[I_CHORD] = 0;
+}
+
+// polish, after k_solve_border: dM of the step and the norms of the step test (M itself: T1, written by k_dd_polish_pre)
+__global__ void __launch_bounds__(256) k_polish_step(WS w, Dims dm) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = stage_id(w, dm);
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  if (w.iprob[(size_t)b * IS + I_PHASE] != PH_POLISH) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const int lane = threadIdx.x, n = dm.n, nx = dm.nx, nn = n * n, nxx = nx * nx;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  double* sV = sm; double* sM = sm + MS; double* t0 = sm + 2 * MS; double* t1 = sm + 3 * MS; double* sHb = sm + 4 * MS;
+  g2s<256>(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  g2s<256>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+  wsync();
+  build_M<256>(sM, sV, t0, t1, sHb, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, pr[P_DALPHA], n, nx, lane);
+  const double ra = pr[P_DALPHA] / pr[P_ALPHA];
+  double dh2 = 0.0, m2 = 0.0;
+  for (int e = lane; e < nn; e += 256) {
+    int i, j; ediv(e, n, i, j);
+    const double m = w.T1[(size_t)sid * nn + e], dh = sM[i * LD + j] - ra * m;
+    dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2);
+  }
+  dh2 = block_sum<256>(dh2); m2 = block_sum<256>(m2);
+  if (lane == 0) { double* q = w.part + (size_t)sid * NPART; q[Q_DH2] = dh2; q[Q_M2] = m2; }
+}
+
+// polish, end of a step: the (full) step is taken; done when it was smaller than center_tol.  Rebuilds the list of problems still polishing.
+__global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, const int* list, int count, int* next, int* nnext) {
+  if ((int)blockIdx.x >= count) return;
+  const int b = list[blockIdx.x], lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_POLISH) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p, nxx = dm.nx * dm.nx;
+  const double dh2 = psum(w.part, b, p, Q_DH2, lane), m2 = psum(w.part, b, p, Q_M2, lane);
+  const double stepn = sqrt(dh2 / m2);
+  const bool fin = (fabs(pr[P_DTAU]) < 1e300) && (fabs(pr[P_DALPHA]) < 1e300) && (stepn == stepn) && (stepn < 1e300);
+  if (fin) for (int e = lane; e < p * nxx; e += 64) { const size_t g = (size_t)b * p * nxx + e; w.Pprev[g] = w.P[g]; w.P[g] += w.dP[g]; }
+  if (lane != 0) return;
+  if (!fin) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; return; }
+  pr[P_TAU_PREV] = pr[P_TAU]; pr[P_ALPHA_PREV] = pr[P_ALPHA];
+  pr[P_TAU] += pr[P_DTAU]; pr[P_ALPHA] += pr[P_DALPHA];
+  pr[P_STEPN] = stepn; pr[P_AP] = 1.0; pr[P_AD] = 1.0;
+  ip[I_NPOLISH] += 1; ip[I_ITERS] += 1;
+  if (w.trace && ip[I_ITERS] >= 1 && ip[I_ITERS] <= TRACE_LEN) {
+    double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
+    t[0] = (double)ip[I_ITERS]; t[1] = (double)PH_POLISH; t[2] = pr[P_MUT]; t[3] = pr[P_TAU]; t[4] = 0.0; t[5] = 0.0; t[6] = 1.0; t[7] = 1.0; t[8] = stepn; t[9] = 0.0;
+  }
+  if (stepn < o.center_tol) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }       // (k_dd_polish_pre of the final sweep checks the cone at the new point)
+  else if (ip[I_NPOLISH] >= POLISH_MAX) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+  else { const int slot = atomicAdd(nnext, 1); next[slot] = b; }
+}
+
+// after the final sweep of k_dd_polish_pre: a last step that left the cone is undone (status Feasible)
+__global__ void __launch_bounds__(64) k_polish_final(WS w, Dims dm) {
+  const int b = prob_id(w), lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_DONE || ip[I_NPOLISH] == 0 || ip[I_IPMSTATUS] != IPM_OPTIMAL) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p, nxx = dm.nx * dm.nx;
+  const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
+  if (!(nbad > 0.0)) { if (lane == 0) { const double s0 = pr[P_ALPHA] - ALPHA_MIN; pr[P_S0] = s0; pr[P_X0] = pr[P_MUT] / s0; pr[P_MU] = pr[P_MUT]; } return; }
+  for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
+  if (lane == 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; ip[I_IPMSTATUS] = IPM_INACCURATE; }
+}
+
+}  // namespace tmpc
+
+#pragma clang fp contract(fast)

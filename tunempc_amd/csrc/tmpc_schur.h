@@ -380,7 +380,11 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
     ip[I_BOSTEP] = 0;
     // two main-phase iterations in a row with frozen pivots and back-offs left: let the step pass, k_ctrl_a starts centering where the iterate stands
     const bool wall_next = (phase == PH_MAIN && !nonfin && ip[I_JAM] < 2 && pr[P_MUT] > 0.0 && ip[I_BACKOFF] < MUT_BACKOFF_MAX);
-    if ((froze || nonfin) && ip[I_REG] < REG_MAX) {
+    if (ip[I_DD] && (froze || nonfin)) {
+      // tight phase (tmpc_dd.h): no lift, no back-off -- a non-positive pivot of the dd factorisation ends the problem with its last iterate
+      ap = 0.0; ad = 0.0;
+      ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
+    } else if ((froze || nonfin) && ip[I_REG] < REG_MAX) {
       // first answer to frozen pivots: discard this direction, lift the Schur diagonal by 1e-12 relative
       // from now on and repeat the iteration from the same iterate -- the matrix sits within ~1e-13 (diagonally scaled) of
       // singular near mu_t, and e.g. the stage-local elimination of an active multiplier (tmpc_phi.h) can use that margin up.
@@ -427,8 +431,15 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= dm.B) return;
   int* ip = w.iprob + (size_t)b * IS;
-  if (ip[I_PHASE] == PH_DONE) return;
+  if (ip[I_PHASE] == PH_DONE || ip[I_PHASE] == PH_POLISH) return;
   double* pr = w.prob + (size_t)b * PS;
+  if (ip[I_DD]) ip[I_NDD] += 1;
+  if (o.tight && ip[I_PHASE] == PH_CENTER && pr[P_AP] == 1.0 && pr[P_AD] == 1.0 && pr[P_STEPN] < 1e-4) {
+    // tight phase: the first full centering step this small hands the problem to the dd dual-Newton polish (tmpc_dd.h: POLISH_ENTER)
+    ip[I_PHASE] = PH_POLISH; ip[I_CHORD] = 0;
+    const int ps = atomicAdd(w.active + 2, 1); w.plist[ps] = b;
+    return;
+  }
   if (ip[I_PHASE] == PH_CENTER) {
     const bool full = (pr[P_AP] == 1.0 && pr[P_AD] == 1.0);
     const bool was_chord = ip[I_CHORD] != 0;
