@@ -1,0 +1,164 @@
+"""GPU tests of the tight-accuracy mode (tmpc_set_tight; run with -m gpu on an MI355X, every call through the C ABI).
+
+VERDICT r3, "Next round" item 1: the reference's solvers stop at a relative gap of ~1e-8 (convexifier.py:363), the default solve at
+N * 2^-25.  The tight mode continues every Optimal problem towards tight_tol * kappa with the block linear algebra in double-double
+(tunempc_amd/csrc/tmpc_dd.h) and finishes with a dd dual-Newton polish.  Checked here:
+  * value parity with the C++ CPU restatement of the same mode (oracle/cpu_ipm, tight=True; tied to the numpy oracle and to a 40-digit
+    mpmath probe in tests/test_tight_cpu.py) to the 1e-8 bar of BASELINE.json, on small shapes, batches with waves and the bench shape;
+  * the solver-independent answers with the values they reach: the certified gap of kappa from the exported dual iterate (numpy only),
+    the identity family (Hc = I, kappa* = 1);
+  * that the default path is untouched (bit-identical outputs with the mode switched off again)."""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before the HIP library is loaded, see tests/test_gpu_parity.py)
+
+pytestmark = pytest.mark.gpu
+
+import convexify_oracle as co  # noqa: E402
+import cpu_ipm  # noqa: E402
+from test_gpu_parity import _certificate  # noqa: E402
+
+PARITY = 1e-8
+TIGHT_TOL = 2.0 ** -37
+HOST_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _solve_tight(p, nx, mb, A, B, H, tol=TIGHT_TOL, **kw):
+    from tunempc_amd._lib import HipConvexifier
+    h = HipConvexifier(p, nx, mb, **kw)
+    try:
+        h.set_tight(True, tol)
+        out = h.convexify_batch(A, B, H)
+        dual = h.dual(min(A.shape[0], h.chunk)) if A.shape[0] <= h.chunk else None
+    finally:
+        h.close()
+    return out, dual
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(3, 2, 6, 4, 2), (11, 3, 8, 4, 1), (60, 2, 2, 3, 2), (61, 3, 1, 3, 1), (70, 4, 16, 12, 4), (80, 2, 30, 4, 1),
+                                             (90, 2, 12, 20, 6), (95, 2, 5, 24, 8)])
+def test_tight_parity_vs_cpu_port(seed, nb, p, nx, mb):
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    out, _ = _solve_tight(p, nx, mb, A, B, H)
+    ref = cpu_ipm.convexify_batch(A, B, H, tol=TIGHT_TOL, threads=HOST_THREADS, tight=True)
+    worst = 0.0
+    for b in range(nb):
+        assert int(out['status'][b]) == int(ref['status'][b]) == 0, (b, out['status'][b], ref['status'][b])
+        if out['info'][b, 13] != 0.0:
+            continue                                   # already convex (convexifier.py:83-85)
+        assert out['info'][b, 6] == ref['mu_t'][b], (b, out['info'][b, 6], ref['mu_t'][b])       # same barrier target (a power of two)
+        e = rel(out['Hc'][b], ref['Hc'][b]); worst = max(worst, e)
+        assert e < PARITY, (b, e)
+        assert abs(out['kappa'][b] - ref['kappa'][b]) < 1e-11 * ref['kappa'][b]
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-9)
+    print(f'tight parity seed {seed} p={p} n={nx + mb}: worst {worst:.2e}, iterations {out["iters"]} (cpu {ref["iters"]} + {ref["polish_steps"]} polish)')
+
+
+def test_tight_other_tolerances():
+    """looser and tighter targets than the default 2^-37 (2^-41 is the edge of what the fp64 stage kernels support: members that both sides
+    finish Optimal must agree)"""
+    p, nx, mb, nb = 8, 5, 2, 4
+    A, B, H = co.gen_batch(4100, nb, p, nx, mb)
+    prev = None
+    for lt in (29, 33, 41):
+        out, _ = _solve_tight(p, nx, mb, A, B, H, tol=2.0 ** -lt)
+        ref = cpu_ipm.convexify_batch(A, B, H, tol=2.0 ** -lt, threads=HOST_THREADS, tight=True)
+        both = [b for b in range(nb) if out['status'][b] == 0 and ref['status'][b] == 0]
+        assert len(both) >= nb - 1
+        for b in both:
+            assert rel(out['Hc'][b], ref['Hc'][b]) < PARITY, (lt, b)
+        if prev is not None:
+            assert (out['kappa'][both] <= prev[both] + 1e-12).all()           # kappa decreases along the path
+        prev = out['kappa'].copy()
+
+
+def test_tight_waves_and_mixed_batch():
+    """batch larger than the chunk (three waves, ragged last one), one already-convex member that never enters the solver"""
+    p, nx, mb, nb = 6, 6, 2, 7
+    A, B, H = co.gen_batch(5200, nb, p, nx, mb)
+    H[3] = np.eye(nx + mb) * 2.0 + 0.1 * co.symmetrize(H[3]) / np.abs(H[3]).max()      # positive definite: early exit
+    out, _ = _solve_tight(p, nx, mb, A, B, H, chunk=3)
+    ref = cpu_ipm.convexify_batch(A, B, H, tol=TIGHT_TOL, threads=HOST_THREADS, tight=True)
+    assert out['info'][3, 13] == 1.0 and out['iters'][3] == 0
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 == int(ref['status'][b])
+        assert rel(out['Hc'][b], ref['Hc'][b]) < PARITY, b
+
+
+def test_tight_bench_shape_member_vs_cpu_port():
+    """BASELINE configs[3] shape (p = 64, n = 32): two members of the bench batch; the CPU side takes ~35 s per member on 8 threads"""
+    from tunempc_amd import synthetic
+    A, B, H = synthetic.gen_batch(100000, 2, 64, 24, 8)
+    out, dual = _solve_tight(64, 24, 8, A, B, H)
+    ref = cpu_ipm.convexify_batch(A, B, H, tol=TIGHT_TOL, threads=HOST_THREADS, tight=True)
+    for b in range(2):
+        assert int(out['status'][b]) == 0 == int(ref['status'][b])
+        e = rel(out['Hc'][b], ref['Hc'][b])
+        print(f'bench shape member {b}: GPU vs cpu_ipm (tight) {e:.2e}, kappa {out["kappa"][b]:.12f} / {ref["kappa"][b]:.12f}, iterations {out["iters"][b]}')
+        assert e < PARITY
+        assert abs(out['kappa'][b] - ref['kappa'][b]) < 1e-11 * ref['kappa'][b]
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(0, 3, 3, 3, 2), (13, 2, 30, 4, 1), (11, 2, 6, 12, 4), (777, 2, 64, 24, 8)])
+def test_tight_dual_certificate(seed, nb, p, nx, mb):
+    """The certified gap of kappa in the tight mode, numpy only (no oracle, no trust in the solver): kappa* in [dual bound - residual slack, kappa],
+    relative width ~ N * 2^-37 = 3e-8 at the bench shape (default mode: 1.2e-4).  VERDICT r3 asks <= 1e-6."""
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    out, dual = _solve_tight(p, nx, mb, A, B, H)
+    N = 2 * p * (nx + mb) + 1
+    for b in range(nb):
+        if out['info'][b, 13] != 0.0:
+            continue
+        assert int(out['status'][b]) == 0
+        kappa, dobj, slack, gap = _certificate(A[b], B[b], H[b], out, dual, b)
+        assert dobj - slack <= kappa
+        width = (kappa - (dobj - slack)) / kappa
+        print(f'tight mode: certified relative gap on kappa, p={p} n={nx + mb} member {b}: {width:.3e}  (N tol = {N * TIGHT_TOL:.3e}; residual slack {slack / kappa:.1e})')
+        assert width <= 1e-6
+        assert width <= 2.0 * N * TIGHT_TOL + 1e-9
+
+
+@pytest.mark.parametrize('seed,p,nx,mb', [(77, 5, 4, 2), (78, 16, 12, 4), (79, 64, 24, 8)])
+def test_tight_identity_family(seed, p, nx, mb):
+    """Hhat = I: Hc = I and kappa* = 1 whatever the solver.  kappa - 1 = N mu_t: 1.2e-4 in the default mode at the bench shape,
+    <= 1e-6 asked for the tight mode."""
+    n = nx + mb
+    A, B, H, _, _ = co.gen_problem(seed, p, nx, mb, identity=True)
+    out, _ = _solve_tight(p, nx, mb, A[None], B[None], H[None])
+    assert int(out['status'][0]) == 0
+    dev = np.abs(out['Hc'][0] - np.eye(n)).max()
+    print(f'tight identity family p={p} n={n}: max|Hc - I| = {dev:.2e}, kappa - 1 = {out["kappa"][0] - 1:.3e}')
+    assert dev <= 1e-9
+    assert 0.0 <= out['kappa'][0] - 1.0 <= 1e-6
+
+
+def test_default_path_untouched_by_the_mode():
+    """enabling and disabling the mode on a handle leaves the default solve bit-identical; handles with G / C rows refuse the mode"""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb = 8, 6, 2, 5
+    A, B, H = co.gen_batch(6300, nb, p, nx, mb)
+    h = HipConvexifier(p, nx, mb)
+    try:
+        a = h.convexify_batch(A, B, H)
+        h.set_tight(True)
+        t = h.convexify_batch(A, B, H)
+        h.set_tight(False)
+        c = h.convexify_batch(A, B, H)
+    finally:
+        h.close()
+    assert np.array_equal(a['Hc'], c['Hc']) and np.array_equal(a['kappa'], c['kappa']) and np.array_equal(a['iters'], c['iters'])
+    assert (t['kappa'] <= a['kappa']).all() and (t['iters'] > a['iters']).all()
+    assert ((a['kappa'] - t['kappa']) / a['kappa'] <= (2 * p * (nx + mb) + 1) * 2.0 ** -25 * 1.5).all()     # the default's gap bound holds
+    hg = HipConvexifier(p, nx, mb, ng=2)
+    try:
+        with pytest.raises(RuntimeError):
+            hg.set_tight(True)
+    finally:
+        hg.close()

@@ -1,0 +1,120 @@
+"""CPU tests of the tight-accuracy mode of the checkers (oracle/ddnum.py, convexify_oracle.sdp_step1(tight=True), oracle/cpu_ipm tight).
+
+What ties them down:
+  * ddnum (double-double on numpy arrays) against mpmath at 50 digits;
+  * the dd block solve of the oracle against the same IPM with the blocks assembled and factored in 40-digit mpmath arithmetic
+    (tests/tools/tight_probe.py: the experiment that located the fp64 wall);
+  * the C++ port against the numpy oracle (same iteration counts, Hc to 1e-8, kappa to 1e-12);
+  * properties no solver can fake: kappa decreases with the tolerance and stays inside the default's certified gap; the identity family
+    (Hc = I, kappa* = 1); reproducibility of the returned point on inputs 1e-14 apart (the polish is what makes the point DEFINED:
+    1e-7 without it at mu = 2e-12, 1e-12 with it)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import convexify_oracle as co
+import cpu_ipm
+import ddnum as dn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+hc_of = lambda A, B, H, r: H + co.symmetrize(co.calH(A, B, r['P']))
+
+
+def test_ddnum_against_mpmath():
+    mp = pytest.importorskip('mpmath')
+    mp.mp.dps = 50
+    rng = np.random.default_rng(0)
+    d = 10
+    G = rng.standard_normal((d, d)); A = G @ G.T + 1e-6 * np.eye(d)
+    Am = mp.matrix(A.tolist())
+    val = lambda x, i, j: mp.mpf(float(x.hi[i, j])) + mp.mpf(float(x.lo[i, j]))
+    L = dn.cholesky(dn.DD(A)); Lm = mp.cholesky(Am)
+    assert max(abs(val(L, i, j) - Lm[i, j]) for i in range(d) for j in range(d)) < 1e-28
+    Bm = rng.standard_normal((d, 2))
+    X = dn.solve_lower(L, dn.solve_lower(L, Bm), trans=True)
+    Xm = mp.inverse(Am) * mp.matrix(Bm.tolist())
+    assert max(abs(val(X, i, j) - Xm[i, j]) / abs(Xm[i, j]) for i in range(d) for j in range(2)) < 1e-26
+    C = dn.matmul_nt(dn.DD(A), dn.DD(A)); Cm = Am * Am.T
+    assert max(abs(val(C, i, j) - Cm[i, j]) / abs(Cm[i, j]) for i in range(d) for j in range(d)) < 1e-30
+    q = dn.DD(np.array([1.0])) / dn.DD(np.array([3.0]))
+    assert abs(mp.mpf(float(q.hi[0])) + mp.mpf(float(q.lo[0])) - mp.mpf(1) / 3) < 1e-31
+    s = dn.DD(np.array([2.0])).sqrt()
+    assert abs(mp.mpf(float(s.hi[0])) + mp.mpf(float(s.lo[0])) - mp.sqrt(2)) < 1e-30
+
+
+def test_fp64_wall_and_dd_block_solve_against_mpmath():
+    """below the wall the fp64 path needs shifts and backs its target off; with the blocks in dd the same iteration arrives, and agrees with
+    the blocks in 40-digit arithmetic to the reproducibility floor of the fp64 stage arithmetic (no polish in either run)"""
+    pytest.importorskip('mpmath')
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+    import tight_probe as tp
+    A, B, H, _, _ = co.gen_problem(3, 6, 4, 2)
+    tol = 2.0 ** -33
+    r64 = co.sdp_step1(A, B, H, dict(tol=2.0 ** -37, max_iter=80, center_iter=20))
+    assert r64['shift'] > 0.0 and r64['mu_target'] > 2.0 ** -37 * r64['kappa'] * 1.5           # the wall: shifted factorisations, backed-off target
+    old = co.POLISH_ENTER
+    co.POLISH_ENTER = 0.0                                                                      # (no hand-over: compare the primal-dual iterations themselves)
+    try:
+        rdd = co.sdp_step1(A, B, H, dict(tol=tol, max_iter=80, center_iter=20, tight=True))
+    finally:
+        co.POLISH_ENTER = old
+    rmp = co.sdp_step1(A, B, H, dict(tol=tol, max_iter=80, center_iter=20, _assemble=tp.assemble_mp, _chol_cls=tp.MpSystem))
+    assert rdd['ipm_status'] == rmp['ipm_status'] == 'optimal' and rdd['shift'] == 0.0 and rdd['dd_iters'] >= 3
+    assert rdd['mu_target'] == rmp['mu_target'] <= 2.0 ** -33 * rdd['kappa'] * 1.5
+    assert rel(hc_of(A, B, H, rdd), hc_of(A, B, H, rmp)) < 1e-8
+    assert abs(rdd['kappa'] - rmp['kappa']) < 1e-12
+
+
+@pytest.mark.parametrize('seed,p,nx,mb,lt', [(3, 6, 4, 2, 37), (11, 8, 4, 1, 37), (21, 5, 5, 2, 41), (8, 2, 3, 2, 35), (5, 16, 4, 1, 37)])
+def test_cpu_port_tight_matches_oracle(seed, p, nx, mb, lt):
+    A, B, H, _, _ = co.gen_problem(seed, p, nx, mb)
+    r = co.sdp_step1(A, B, H, dict(tol=2.0 ** -lt, tight=True))
+    c = cpu_ipm.convexify_batch(A[None], B[None], H[None], tol=2.0 ** -lt, threads=2, tight=True)
+    assert r['ipm_status'] == 'optimal' and c['status'][0] == 0
+    assert r['iters'] == c['iters'][0] and r['dd_iters'] == c['dd_iters'][0]
+    assert r['mu_target'] == c['mu_t'][0]
+    assert rel(hc_of(A, B, H, r), c['Hc'][0]) < 1e-8
+    assert abs(r['kappa'] - c['kappa'][0]) < 1e-12 * r['kappa']
+
+
+def test_tight_point_is_reproducible_and_inside_the_default_gap():
+    A, B, H, _, _ = co.gen_problem(11, 8, 4, 1)
+    rng = np.random.default_rng(1)
+    H2 = co.symmetrize(H * (1 + 1e-14 * rng.standard_normal(H.shape)))
+    r0 = co.sdp_step1(A, B, H)
+    N = 2 * 8 * 5 + 1
+    prev = r0['kappa']
+    for lt in (33, 37, 41):
+        r = co.sdp_step1(A, B, H, dict(tol=2.0 ** -lt, tight=True)); r2 = co.sdp_step1(A, B, H2, dict(tol=2.0 ** -lt, tight=True))
+        assert r['ipm_status'] == 'optimal' and r['polish_steps'] >= 1
+        assert rel(hc_of(A, B, H, r), hc_of(A, B, H2, r2)) < 1e-10                 # (1e-7 ... 4e-6 at 2^-41 without the polish)
+        assert r['kappa'] <= prev + 1e-13                                          # kappa decreases along the path ...
+        assert r0['kappa'] - r['kappa'] <= 1.5 * N * r0['mu_target']              # ... and stays inside the gap the default certifies
+        prev = r['kappa']
+        # the returned dual iterate is on the central path: X_r S_r = mu I to the accuracy fp64 can show
+        V = np.concatenate([A, B], axis=2)
+        Pb = r['P'] * (r['s'] * r['alpha'])
+        M = r['alpha'] * r['s'] * H + np.swapaxes(V, 1, 2) @ np.roll(Pb, -1, axis=0) @ V
+        M[:, :4, :4] -= Pb
+        S1 = M - np.eye(5)
+        assert np.abs(r['X1'] @ S1 - r['mu_target'] * np.eye(5)).max() < 1e-3 * r['mu_target']
+
+
+def test_tight_identity_family():
+    A, B, H, _, _ = co.gen_problem(77, 5, 4, 2, identity=True)
+    c = cpu_ipm.convexify_batch(A[None], B[None], H[None], tol=2.0 ** -37, threads=2, tight=True)
+    assert c['status'][0] == 0
+    assert np.abs(c['Hc'][0] - np.eye(6)).max() < 1e-10
+    assert 0.0 <= c['kappa'][0] - 1.0 <= 61 * 2.0 ** -37 * 1.5
+
+
+def test_tight_batch_of_the_cpu_port():
+    """outer parallelism (batch >= threads) and inner parallelism (batch < threads) give the same numbers"""
+    A, B, H = co.gen_batch(900, 3, 6, 5, 2)
+    a = cpu_ipm.convexify_batch(A, B, H, tol=2.0 ** -37, threads=2, tight=True)
+    b = cpu_ipm.convexify_batch(A, B, H, tol=2.0 ** -37, threads=4, tight=True)
+    assert (a['status'] == 0).all() and (b['status'] == 0).all()
+    assert np.array_equal(a['Hc'], b['Hc']) and np.array_equal(a['kappa'], b['kappa'])

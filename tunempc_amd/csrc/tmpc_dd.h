@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       const int i = e / n, j = e - i * n;
       const ddv x = dd_muld(Z.get(i, j), mu);
       X.set(i, j, x);
-      (r ? w.X2 : w.X1)[(size_t)sid * nn + e] = dd_val(x);
+      (r ? w.X2 : w.X1)[(size_t)sid * nn + e] = final_sweep ? (r ? w.dX2 : w.dX1)[(size_t)sid * nn + e] : dd_val(x);      // (final sweep: the dual iterate of the last step, see k_polish_step)
       (r ? w.S2i : w.S1i)[(size_t)sid * nn + e] = dd_val(Z.get(i, j));
       t2.set(i, j, r ? dd_sub(t2.get(i, j), x) : x);
     }
@@ -834,6 +834,23 @@ __global__ void __launch_bounds__(256) k_polish_step(WS w, Dims dm) {
   }
   dh2 = block_sum<256>(dh2); m2 = block_sum<256>(m2);
   if (lane == 0) { double* q = w.part + (size_t)sid * NPART; q[Q_DH2] = dh2; q[Q_M2] = m2; }
+  // The dual iterate that goes with this step: X_r + dX_r = X_r - sym(X_r dS_r S_r^-1) (X_r = mu S_r^-1: the full primal-dual step).  It satisfies
+  // the linear dual equations EXACTLY whatever y is, while X = mu S(y)^-1 at an fp64 y misses them by eps / mu in the active directions
+  // (1e-5 at mu = 3e-11): this is the X that tmpc_get_dual_host exports with the last step (dX1 / dX2 hold it until the final sweep).
+  const double dtau = pr[P_DTAU];
+  double* sX = sV; double* sZ = sHb;                 // V and Hb are not needed any more
+  for (int r = 0; r < 2; ++r) {
+    wsync();
+    g2s<256>(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
+    g2s<256>(sZ, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    if (r == 1) for (int e = lane; e < nn; e += 256) { int i, j; ediv(e, n, i, j); sM[i * LD + j] = ((i == j) ? dtau : 0.0) - sM[i * LD + j]; }      // dS2 = dtau I - dM
+    wsync();
+    mm<256>(t0, sX, LD, 1, sM, LD, 1, n, n, n, 0, lane);
+    mm<256>(t1, t0, LD, 1, sZ, LD, 1, n, n, n, 0, lane);
+    double* out = (r ? w.dX2 : w.dX1) + (size_t)sid * nn;
+    for (int e = lane; e < nn; e += 256) { int i, j; ediv(e, n, i, j); out[e] = sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]); }
+    if (r == 0) { wsync(); }
+  }
 }
 
 // polish, end of a step: the (full) step is taken; done when it was smaller than center_tol.  Rebuilds the list of problems still polishing.
@@ -851,6 +868,7 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, con
   if (lane != 0) return;
   if (!fin) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; return; }
   pr[P_TAU_PREV] = pr[P_TAU]; pr[P_ALPHA_PREV] = pr[P_ALPHA];
+  pr[P_DX0] = -pr[P_X0] * pr[P_DALPHA] / pr[P_S0];          // x0 + dx0: the scalar of the dual iterate that goes with this step (k_polish_step)
   pr[P_TAU] += pr[P_DTAU]; pr[P_ALPHA] += pr[P_DALPHA];
   pr[P_STEPN] = stepn; pr[P_AP] = 1.0; pr[P_AD] = 1.0;
   ip[I_NPOLISH] += 1; ip[I_ITERS] += 1;
@@ -871,7 +889,7 @@ __global__ void __launch_bounds__(64) k_polish_final(WS w, Dims dm) {
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p, nxx = dm.nx * dm.nx;
   const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
-  if (!(nbad > 0.0)) { if (lane == 0) { const double s0 = pr[P_ALPHA] - ALPHA_MIN; pr[P_S0] = s0; pr[P_X0] = pr[P_MUT] / s0; pr[P_MU] = pr[P_MUT]; } return; }
+  if (!(nbad > 0.0)) { if (lane == 0) { pr[P_X0] += pr[P_DX0]; pr[P_S0] = pr[P_ALPHA] - ALPHA_MIN; pr[P_MU] = pr[P_MUT]; } return; }
   for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
   if (lane == 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; ip[I_IPMSTATUS] = IPM_INACCURATE; }
 }
