@@ -18,6 +18,10 @@ extern "C" {
  * unfactored in the workspace for tmpc_debug_get_array (tests/tools/step3_asm_check.py).  The outputs of such a call are NOT a
  * solution -- never set it in product code. */
 #define TMPC_DEBUG_FLAG_STOP_ASSEMBLED 8
+/* Debug bit: no relative lift of the Schur diagonal after frozen pivots (REG_MAX = 0): frozen pivots in the centering phase then go straight to the
+ * route 'back mu_t off and take the step of this factorisation' (ctrl_backoff_before_rhs / k_ctrl_c), which the lifts make rare in practice
+ * (tests/test_gpu_hard_targets.py::test_backoff_step_is_taken).  Never set it in product code. */
+#define TMPC_DEBUG_FLAG_NO_LIFT 16
 
 /* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMMs of the factorisation; mode 0: C -= AB', 1: C = AB', 2: C = -AB'.
  * mode + 0: the register-staged core (tmpc_factor.h, one workgroup walks all tiles); + 16: the LDS-DMA tile core (tmpc_gemm_dma.h, one

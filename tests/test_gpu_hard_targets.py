@@ -93,3 +93,31 @@ def test_hard_targets_through_the_models_with_multipliers():
         assert back.min() >= 0 and back.max() <= 6, (model, back)
         total += int(back.sum())
     assert total > 0                                 # the case does exercise the back-off
+
+
+def test_backoff_step_is_taken():
+    """after ctrl_backoff_before_rhs backs mu_t off (frozen pivots at the highest lift while centering), the direction of that factorisation is
+    TAKEN, not discarded.  In the trace a centering row whose factorisation froze pivots (shift counter rises) shows the step lengths it took: such a row
+    with ap > 0 exists only through that branch -- every other answer to frozen pivots in the centering phase (lift, plain back-off) repeats the
+    iteration with ap = ad = 0.  (Round 3: the branch was unreachable.)"""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb = 30, 4, 1, 8
+    probs = [synthetic.gen_problem(7000 + 17 * b, p, nx, mb, sigP=100.0, cond_exp=5, rad=0.9) for b in range(nb)]
+    A, B, H = (np.stack([q[i] for q in probs]) for i in range(3))
+    h = HipConvexifier(p, nx, mb, chunk=nb, flags=16)          # TMPC_DEBUG_FLAG_NO_LIFT (tunempc_hip_debug.h): with the lifts the route is rare (scripts/bostep_scan.py: 0 of 580 frozen centering iterations)
+    out = h.convexify_batch(A, B, H)
+    tr = h.trace(nb)
+    h.close()
+    assert (out['status'] == 0).all() and np.linalg.eigvalsh(out['Hc']).min() > 0.0
+    taken = retried = 0
+    for b in range(nb):
+        rows = tr[b][tr[b][:, 0] > 0]
+        shifts = np.concatenate([[0.0], rows[:, 9]])
+        for i, r in enumerate(rows):
+            if int(r[1]) == 1 and shifts[i + 1] > shifts[i]:          # centering iteration whose factorisation froze pivots
+                if r[6] > 0.0:
+                    taken += 1
+                else:
+                    retried += 1
+    print(f'centering iterations with frozen pivots: {taken} with the step taken, {retried} repeated (lift / plain back-off)')
+    assert taken >= 1

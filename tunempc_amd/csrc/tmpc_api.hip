@@ -619,6 +619,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
+  const int reg_max = (h->flags & TMPC_DEBUG_FLAG_NO_LIFT) ? 0 : REG_MAX;      // (debug: no diagonal lifts, frozen pivots while centering go straight to the back-off-and-step route)
   HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
@@ -705,10 +706,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (pass == 1) {
-        hipLaunchKernelGGL(k_ctrl_b, dim3(active), dim3(64), 0, st, w, dm);
+        hipLaunchKernelGGL(k_ctrl_b, dim3(active), dim3(64), 0, st, w, dm, reg_max);
         if (prof) HIPCHK(hipEventRecord(ln->ev[4], st));
       } else {
-        hipLaunchKernelGGL(k_ctrl_c, dim3(active), dim3(64), 0, st, w, dm);
+        hipLaunchKernelGGL(k_ctrl_c, dim3(active), dim3(64), 0, st, w, dm, reg_max);
       }
     }
     TMPC_STAGE_LAUNCH(k_update, 0, st, w, dm);
@@ -913,7 +914,7 @@ int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
-  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) {
+  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED | TMPC_DEBUG_FLAG_NO_LIFT)) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2, TMPC_FLAG_FAST_EXIT = 4)", flags);
     return TMPC_E_ARG;
   }

@@ -286,10 +286,10 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
 // matrix, and the cond(H) = 1e5 members of scripts/robustness_sweep.py ended Feasible at 1024 mu_t instead of Optimal at 2-32 mu_t.)
 // (Runs at the top of k_ctrl_b -- after the factorisation and the predictor pass that centering problems skip, before the right-hand side of
 // pass 2 -- so it costs no launch of its own.)
-__device__ __forceinline__ void ctrl_backoff_before_rhs(WS& w, int b) {
+__device__ __forceinline__ void ctrl_backoff_before_rhs(WS& w, int b, int reg_max) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_CENTER || ip[I_CHORD]) return;
-  if (ip[I_NSHIFT] == ip[I_SHIFT0] || ip[I_REG] < REG_MAX || ip[I_BACKOFF] >= MUT_BACKOFF_MAX) return;   // (frozen pivots first lift the diagonal, 1e-12 ... 1e-10, and repeat: k_ctrl_c)
+  if (ip[I_NSHIFT] == ip[I_SHIFT0] || ip[I_REG] < reg_max || ip[I_BACKOFF] >= MUT_BACKOFF_MAX) return;   // (frozen pivots first lift the diagonal, 1e-12 ... 1e-10, and repeat: k_ctrl_c)
   double* pr = w.prob + (size_t)b * PS;
   pr[P_MUT] *= 2.0; pr[P_SIGMU] = pr[P_MUT];
   ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; pr[P_PREVSTEPN] = -1.0; ip[I_BOSTEP] = 1;
@@ -307,11 +307,11 @@ __device__ __forceinline__ void raw_steps(const double* pr, double minx, double 
 }
 
 // after the predictor direction (pass 1): Mehrotra centring parameter
-__global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
+__global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm, int reg_max) {
   const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_MAIN) {
-    if (lane == 0) ctrl_backoff_before_rhs(w, b);        // centering: hard-target back-off, see above
+    if (lane == 0) ctrl_backoff_before_rhs(w, b, reg_max);        // centering: hard-target back-off, see above
     return;
   }
   double* pr = w.prob + (size_t)b * PS;
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm) {
 }
 
 // after the final direction (pass 2): step lengths, scalar updates
-__global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
+__global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm, int reg_max) {      // reg_max: REG_MAX, or 0 under TMPC_DEBUG_FLAG_NO_LIFT (unit test of the back-off-and-step route)
   const int b = prob_id(w), lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -384,7 +384,13 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
       // tight phase (tmpc_dd.h): no lift, no back-off -- a non-positive pivot of the dd factorisation ends the problem with its last iterate
       ap = 0.0; ad = 0.0;
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
-    } else if ((froze || nonfin) && ip[I_REG] < REG_MAX) {
+    } else if (bostep && !nonfin) {
+      // ctrl_backoff_before_rhs backed mu_t off before this direction was computed: the step is TAKEN (it moves the iterate back up the path, where the
+      // matrix is definite again).  Tested BEFORE the lift rule: the back-off has reset I_REG to 0, so the lift rule below would fire on the very pivots
+      // that triggered the back-off, discard the direction and repeat the iteration from the same iterate (round 3 did exactly that: this branch was
+      // unreachable and every back-off of this kind cost up to three idle lift retries -- ADVICE r3).
+      ip[I_SHIFTRUN] = 0;
+    } else if ((froze || nonfin) && ip[I_REG] < reg_max) {
       // first answer to frozen pivots: discard this direction, lift the Schur diagonal by 1e-12 relative
       // from now on and repeat the iteration from the same iterate -- the matrix sits within ~1e-13 (diagonally scaled) of
       // singular near mu_t, and e.g. the stage-local elimination of an active multiplier (tmpc_phi.h) can use that margin up.
@@ -396,8 +402,6 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm) {
       // linear -- k_ctrl_d then backs mu_t off and drops the lift.
       ip[I_REG] += 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
       ap = 0.0; ad = 0.0; retry = true;
-    } else if (bostep && !nonfin) {
-      ip[I_SHIFTRUN] = 0;                        // the step is taken (ctrl_backoff_before_rhs)
     } else if (phase == PH_CENTER && (froze || nonfin) && ip[I_BACKOFF] < MUT_BACKOFF_MAX) {
       // hard target (cond(H) >~ 1e3: cond of the Schur matrix ~ (tau/mu)^2 passes 1/eps before the default mu_t): aim for the
       // central-path point one power of two earlier instead of giving up -- the problem then ends Optimal at the gap
