@@ -172,6 +172,9 @@ def main():
     ap.add_argument('--mb', type=int, default=8)
     ap.add_argument('--tol', type=float, default=0.0, help='0 = library default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="collective backend; 'gloo' (results staged through the host) lets the multi-rank branch run where RCCL cannot")
+    ap.add_argument('--same-device', action='store_true', help='every rank on cuda:0 (with --backend gloo: the N > 1 code path on a one-GPU box; not a scaling measurement)')
+    ap.add_argument('--digest', action='store_true', help='add the sha256 of the gathered Hc / kappa / status of the last step to the line (tests)')
     ap.add_argument('--no-tight', action='store_true', help='skip the tight-accuracy leg (one extra step, ~10x a default step)')
     ap.add_argument('--no-extra', action='store_true', help='skip the unprofiled and host-buffer legs after the timed region')
     ap.add_argument('--distinct', type=int, default=512, help='distinct synthetic problems generated per rank (tiled to --batch when smaller)')
@@ -190,10 +193,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 ranks with python -m torch.distributed.run '
                          f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...')
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    host_coll = args.backend == 'gloo'            # gloo gathers host tensors
+    cdev = torch.device('cpu') if host_coll else dev
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        if host_coll:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     p, nx, mb, n = args.p, args.nx, args.mb, args.nx + args.mb
     nbl = args.batch
@@ -203,7 +213,7 @@ def main():
     reps = (nbl + nd - 1) // nd
     tile = lambda x: torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:nbl].copy()).to(dev)
     dA, dB, dH = tile(A), tile(B), tile(H)
-    h = HipConvexifier(p, nx, mb, chunk=0, flags=FLAG_PROFILE)
+    h = HipConvexifier(p, nx, mb, chunk=(nbl if (args.same_device and nbl < 512) else 0), flags=FLAG_PROFILE)
     if args.tol > 0:
         h.set_options(tol=args.tol, flags=FLAG_PROFILE)
     out = None
@@ -213,7 +223,7 @@ def main():
         nonlocal out
         out = h.convexify_batch_device(dA, dB, dH, out)
         if use_dist:
-            g = all_gather_results({k: out[k] for k in ('Hc', 'kappa', 'status')}, nbl * world, cache=gather_cache)
+            g = all_gather_results({k: (out[k].cpu() if host_coll else out[k]) for k in ('Hc', 'kappa', 'status')}, nbl * world, cache=gather_cache)
             return g
         return out
 
@@ -231,7 +241,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
@@ -239,7 +249,7 @@ def main():
     status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy()
     ok = int((status == 0).sum())
     # load balance across ranks: the slowest member of every rank's shard sets that rank's step time
-    it_rank = torch.tensor([float(iters.max()), float(iters.mean())], dtype=torch.float64, device=dev)
+    it_rank = torch.tensor([float(iters.max()), float(iters.mean())], dtype=torch.float64, device=cdev)
     if use_dist:
         it_all = [torch.empty_like(it_rank) for _ in range(world)]
         dist.all_gather(it_all, it_rank)
@@ -340,7 +350,7 @@ def main():
                        "ipm_iterations_per_rank": [{"max": int(a), "mean": b} for a, b in it_all],
                        "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
-                       "parallelism": f"batch-sharded x{world}, one all-gather of Hc" if world > 1 else "single GPU"},
+                       "parallelism": (f"batch-sharded x{world}, one all-gather of Hc" + (f" [backend {args.backend}" + (", every rank on cuda:0: the code path, not a scaling measurement]" if args.same_device else "]") if (host_coll or args.same_device) else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                          "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
@@ -358,6 +368,13 @@ def main():
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         line.update(extra_rates)
+        if args.digest:
+            import hashlib
+            hsh = hashlib.sha256()
+            for k in ('Hc', 'kappa', 'status'):
+                hsh.update(np.ascontiguousarray(res[k].cpu().numpy()).tobytes())
+            line["gathered_digest"] = hsh.hexdigest()
+            line["gathered_problems"] = int(res['Hc'].shape[0])
         if not args.no_cpu_baseline and world == 1:
             try:                                                        # the checker's build or run must never cost the GPU measurement its line
                 line["cpu_baseline"] = cpu_baseline(p, nx, mb, args.tol if args.tol > 0 else 2.0 ** -25)

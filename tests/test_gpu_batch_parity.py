@@ -277,3 +277,35 @@ def test_fast_exit_option(hc, seed, nb, p, nx, mb):
     assert max(dev) < 0.2
     print(f'fast exit p={p} n={nx + mb}: iterations {out["iters"].mean():.2f} instead of {ref["iters"].mean():.2f}; Hc differs from the converged point by '
           f'{min(dev):.1e} .. {max(dev):.1e} (relative Frobenius); kappa by {np.abs(out["kappa"] / ref["kappa"] - 1).max():.1e}')
+
+
+# ----------------------------------------------------------------------------- bench.py's own multi-rank branch
+def test_bench_multi_rank_branch_on_one_gpu(hc):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it, except for the two switches that let
+    it run on a one-GPU box (--backend gloo: the gather is staged through the host; --same-device: both ranks on cuda:0).  Exercises `use_dist`: the
+    barriers, the MAX-reduction of the time, the all-gather of Hc / kappa / status through the cached buffers, ipm_iterations_per_rank.  ONE JSON line,
+    and the gathered result equals the two shards solved serially (sha256 over Hc | kappa | status)."""
+    import hashlib
+    from tunempc_amd import synthetic
+    port = 29900 + os.getpid() % 90
+    nbl, p, nx, mb = 24, 16, 6, 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', str(nbl), '--p', str(p), '--nx', str(nx), '--mb', str(mb),
+           '--backend', 'gloo', '--same-device', '--digest', '--no-cpu-baseline']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                     # rank 0 prints ONE line, rank 1 nothing
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['scaling'] == 'weak' and line['unit'] == 'stage-convexifications/s'
+    assert len(line['config']['ipm_iterations_per_rank']) == 2 and line['config']['global_batch'] == 2 * nbl
+    assert line['gathered_problems'] == 2 * nbl and line['value'] > 0 and line['cpu_baseline'] is None
+    hsh = hashlib.sha256()
+    outs = []
+    for r in range(2):
+        A, B, H = synthetic.gen_batch(100000 + r * 10000, nbl, p, nx, mb)
+        outs.append(hc(p, nx, mb, chunk=nbl).convexify_batch(A, B, H))
+    for k in ('Hc', 'kappa', 'status'):
+        hsh.update(np.ascontiguousarray(np.concatenate([o[k] for o in outs])).tobytes())
+    assert line['gathered_digest'] == hsh.hexdigest()
