@@ -58,11 +58,11 @@ extern "C" {
                                     at mu_target: Hc is feasible (positive definite, cond <= kappa), kappa within the same gap N mu_target of
                                     optimal, the linear residuals are gone -- but the point is within ~1e-2 (relative) of the centred one, not
                                     at it, so two implementations agree on it to ~1e-3 only, not to 1e-8.  ~2 factorisations fewer per problem.
-                                    Off by default: the default answer is the reproducible one. */
+                                    Members stopped this way carry info[10] = 3.  Off by default: the default answer is the reproducible one. */
 
 #define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
- *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter),
+ *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter,3 = stopped by TMPC_FLAG_FAST_EXIT: status Optimal, not the converged point),
  *                 11 #shifted pivots, 12 centering iterations, 13 early-exit flag (convexifier.py:83-85),
  *                 14 last centering step norm, 15 smallest Cholesky pivot of the Schur factorisations relative to the assembled diagonal (1 if never below 1e-8; <= 1e-15 = frozen)                                          */
 
@@ -93,11 +93,29 @@ int tmpc_get_chunk(tmpc_handle* h);
  * (the relative duality gap on kappa, the max condition number, is then (2*p*n+1)*tol);
  * center_tol = relative Newton step ending the final centering phase, default 1e-9;
  * max_iter / center_iter = iteration caps (defaults 50 / 12): max_iter bounds the main phase, center_iter the centering iterations
- * per barrier target -- a hard target may visit up to 11 targets (ten back-offs by powers of two, reported in info[6]), so a problem ends
+ * per barrier target (a chord step, which re-uses the factorisation at a fifth of the cost, counts a quarter: up to 4 x center_iter cheap iterations) -- a hard target may visit up to 11 targets (ten back-offs by powers of two, reported in info[6]), so a problem ends
  * after at most max_iter + 11 * center_iter + 2 iterations; flags = TMPC_FLAG_*.  Values <= 0 keep
  * the current setting (flags is always applied; bits other than the TMPC_FLAG_* above -- and the debug bit of
  * tunempc_hip_debug.h -- are rejected with TMPC_E_ARG). */
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags);
+
+/* Performance knobs of a handle (none of them changes WHAT is computed beyond rounding; defaults are the measured optimum on MI355X):
+ *   TMPC_TUNE_CHORD_STEP   value > 0: the centering phase re-uses a factorisation once a full Newton step could have been `value` times longer
+ *                          before leaving the cone (default 10); 0: every centering step re-factors
+ *   TMPC_TUNE_SMALL_BLOCKS 1 (default): blocks of one 16 x 16 tile (the reference's own examples, nx <= 5) are factored / solved by ONE kernel per
+ *                          problem; 0: the batched launch sequence per elimination level
+ *   TMPC_TUNE_EIG_PRETEST  1 (default): the step-length kernel first asks whether the step at the clipping threshold stays in the cone; 0: every
+ *                          eigenvalue is computed
+ *   TMPC_TUNE_FUSE_FWD     1 (default): the forward substitution of the predictor pass rides inside the factorisation; 0: separate sweep
+ * (Rounds 1-3 read these from environment variables once per process.) */
+#define TMPC_TUNE_CHORD_STEP 1
+#define TMPC_TUNE_SMALL_BLOCKS 2
+#define TMPC_TUNE_EIG_PRETEST 3
+#define TMPC_TUNE_FUSE_FWD 4
+int tmpc_set_tuning(tmpc_handle* h, int key, double value);
+/* The general constructor: ng / nc rows of G_k / C_k (0: none), step3 != 0: room for T_k, lanes = concurrent half-waves on their own streams
+ * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */
+int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes);
 
 /* Tight-accuracy mode (opt-in; plain Step 1 handles).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
  * ~1e-8 (convexifier.py:363); the default solve above stops at tol = 2^-25, a certified gap of (2*p*n+1)*3e-8 on kappa, because the HKM

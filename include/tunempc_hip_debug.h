@@ -22,6 +22,9 @@ extern "C" {
  * route 'back mu_t off and take the step of this factorisation' (ctrl_backoff_before_rhs / k_ctrl_c), which the lifts make rare in practice
  * (tests/test_gpu_hard_targets.py::test_backoff_step_is_taken).  Never set it in product code. */
 #define TMPC_DEBUG_FLAG_NO_LIFT 16
+/* Debug bit: the register-staged factorisation kernels (k_cr_potrf / k_cr_trsm / k_cr_update: the path of blocks wider than 320) for every block
+ * size, instead of the LDS-DMA kernels -- keeps that path under test at small shapes. */
+#define TMPC_DEBUG_FLAG_NO_DMA 32
 
 /* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMMs of the factorisation; mode 0: C -= AB', 1: C = AB', 2: C = -AB'.
  * mode + 0: the register-staged core (tmpc_factor.h, one workgroup walks all tiles); + 16: the LDS-DMA tile core (tmpc_gemm_dma.h, one

@@ -266,6 +266,7 @@ def test_fast_exit_option(hc, seed, nb, p, nx, mb):
     N = 2 * p * (nx + mb) + 1
     assert (out['status'] == 0).all() and (ref['status'] == 0).all()
     assert (out['iters'] < ref['iters']).all()
+    assert (ref['info'][:, 10] == 0).all() and set(out['info'][:, 10]) <= {0.0, 3.0} and (out['info'][:, 10] == 3).any()      # a fast exit is told apart from a converged Optimal
     dev = []
     for b in range(nb):
         ev = np.linalg.eigvalsh(out['Hc'][b])

@@ -991,38 +991,23 @@ def test_supplement_with_constraint_and_regularisation_terms(hc):
         assert all(np.array_equal(d, d.T) for d in dHc)
 
 
-_FALLBACK_CODE = r'''
-import os, sys
-import numpy as np
-import torch  # noqa: F401  (first: see the note at the top of tests/test_gpu_parity.py)
-sys.path.insert(0, sys.argv[1])
-from tunempc_amd._lib import HipConvexifier
-worst = 0.0
-for name in sys.argv[3:]:
-    g = np.load(os.path.join(sys.argv[2], name + '.npz'))
-    A, B, H = g['A'], g['B'], g['H']
-    h = HipConvexifier(A.shape[1], A.shape[2], B.shape[3])
-    out = h.convexify_batch(A, B, H)
-    h.close()
-    for b in range(A.shape[0]):
-        assert int(out['status'][b]) == int(g['status'][b]), (name, b, out['status'][b], g['status'][b])
-        err = np.linalg.norm(out['Hc'][b] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b])
-        worst = max(worst, err)
-print('WORST %.3e' % worst)
-'''
-
-
-@pytest.mark.parametrize('env', [{'TMPC_FACTOR_DMA': '0'}, {'TMPC_POTRF_DMA': '0'}, {'TMPC_FUSE_FWD': '0', 'TMPC_CHORD': '0'},
-                                 {'TMPC_STAGE_NT': '64'}, {'TMPC_SMALL': '0'}, {'TMPC_EIG_PRETEST': '0'}], ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
-def test_kernel_variants_behind_environment_switches(golden_dir, env):
-    """The kernel variants behind the environment switches of libtunempc_hip (read once per process: register-staged factorisation
-    kernels, left-looking block Cholesky, separate forward sweep without chord steps, one wave per stage, every step-length eigenvalue computed) against three golden
-    vectors, each variant in a process of its own."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', _FALLBACK_CODE, root, golden_dir, 'c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'awe_shape_n15'],
-                       env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    worst = float(r.stdout.strip().split('WORST')[-1])
-    assert worst < PARITY, (env, worst)
+@pytest.mark.parametrize('variant', [dict(flags=32), dict(tuning=dict(fuse_fwd=0, chord_step=0)), dict(tuning=dict(small_blocks=0)), dict(tuning=dict(eig_pretest=0)),
+                                     dict(lanes=1), dict(lanes=3), dict(flags=1)], ids=str)
+def test_kernel_variants_behind_handle_options(golden_dir, variant):
+    """The kernel variants that rounds 1-3 hid behind environment variables, now options of the handle (tmpc_set_tuning, tmpc_create_ex) or debug flags
+    (tunempc_hip_debug.h): register-staged factorisation kernels (flag 32: the path of blocks wider than 320), separate forward sweep without chord steps, the batched
+    launch sequence for 16-wide blocks, every step-length eigenvalue computed, one / three lanes, scalar-FMA GEMM fragments -- each against four golden vectors."""
+    from tunempc_amd._lib import HipConvexifier
+    worst = 0.0
+    for name in ('c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'awe_shape_n15'):
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        A, B, H = g['A'], g['B'], g['H']
+        h = HipConvexifier(A.shape[1], A.shape[2], B.shape[3], flags=variant.get('flags', 0), lanes=variant.get('lanes', 0))
+        if 'tuning' in variant:
+            h.set_tuning(**variant['tuning'])
+        out = h.convexify_batch(A, B, H)
+        h.close()
+        for b in range(A.shape[0]):
+            assert int(out['status'][b]) == int(g['status'][b]), (name, b, out['status'][b], g['status'][b])
+            worst = max(worst, np.linalg.norm(out['Hc'][b] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b]))
+    assert worst < PARITY, (variant, worst)

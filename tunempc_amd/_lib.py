@@ -18,7 +18,7 @@ STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 # every symbol declared in include/tunempc_hip.h (the drop-in boundary) ...
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
-    'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight',
+    'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight', 'tmpc_set_tuning', 'tmpc_create_ex',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
@@ -89,6 +89,10 @@ def load_library():
     lib.tmpc_destroy.argtypes = [vp]
     lib.tmpc_get_chunk.restype = C.c_int
     lib.tmpc_get_chunk.argtypes = [vp]
+    lib.tmpc_set_tuning.restype = C.c_int
+    lib.tmpc_set_tuning.argtypes = [vp, C.c_int, C.c_double]
+    lib.tmpc_create_ex.restype = C.c_int
+    lib.tmpc_create_ex.argtypes = [C.POINTER(C.c_void_p)] + [C.c_int] * 8
     lib.tmpc_set_tight.restype = C.c_int
     lib.tmpc_set_tight.argtypes = [vp, C.c_int, C.c_double]
     lib.tmpc_set_options.restype = C.c_int
@@ -154,7 +158,7 @@ def _check(lib, rc, what):
 class HipConvexifier:
     """Handle for batched convexification of problems of one shape (p, nx, mb) on the current HIP device."""
 
-    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0, nc=0, step3=False):
+    def __init__(self, p, nx, mb, chunk=0, tol=None, center_tol=None, max_iter=None, center_iter=None, flags=0, ng=0, nc=0, step3=False, lanes=0):
         self.lib = load_library()
         if self.lib.tmpc_device_count() < 1:
             raise RuntimeError("tunempc_amd: no HIP device visible; the convexify hot path has no CPU fallback")
@@ -163,7 +167,9 @@ class HipConvexifier:
         self.ng = int(ng)     # rows of the equality-constraint Jacobian per stage (convexifier.py:249-255), 0: none
         self.nc = int(nc)     # room for active-constraint rows per stage (Step 2, convexifier.py:258-266), 0: none
         self.step3 = bool(step3)      # room for the regularisation T_k of Step 3 (convexifier.py:137-147); such a handle also serves the plain model
-        if self.step3 and (self.ng or self.nc):
+        if lanes:
+            _check(self.lib, self.lib.tmpc_create_ex(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc, int(self.step3), int(lanes)), 'tmpc_create_ex')
+        elif self.step3 and (self.ng or self.nc):
             _check(self.lib, self.lib.tmpc_create_step3_con(C.byref(self._h), int(chunk), self.p, self.nx, self.mb, self.ng, self.nc), 'tmpc_create_step3_con')
         elif self.step3:
             _check(self.lib, self.lib.tmpc_create_step3(C.byref(self._h), int(chunk), self.p, self.nx, self.mb), 'tmpc_create_step3')
@@ -178,6 +184,12 @@ class HipConvexifier:
             self.flags = int(flags)
         _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
                                                    int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
+
+    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None):
+        """Performance knobs of the handle (include/tunempc_hip.h: tmpc_set_tuning); None keeps the current value."""
+        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd)):
+            if v is not None:
+                _check(self.lib, self.lib.tmpc_set_tuning(self._h, key, float(v)), 'tmpc_set_tuning')
 
     def set_tight(self, enable=True, tight_tol=None):
         """Tight-accuracy mode (include/tunempc_hip.h: tmpc_set_tight): continue every Optimal problem towards tight_tol * kappa (default 2^-37)

@@ -79,6 +79,7 @@ struct tmpc_handle {
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
   int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
+  int tune_small, tune_pretest, tune_fuse;     // tmpc_set_tuning
   void* dd_slab;                 // tight mode (tmpc_set_tight): low words of the double-double planes, allocated on first use
   size_t dd_bytes;
   int tight;                     // 1: the tight phase follows the default solve
@@ -389,9 +390,6 @@ static int set_lds_attrs(int device) {
   static bool done[64] = {false};
   if (device >= 0 && device < 64 && done[device]) return TMPC_OK;
   const int big = 160 * 1024;
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_pre<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_rhs<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
   HIPCHK(hipFuncSetAttribute((const void*)k_stage_dir<256>, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));     // (these carry a few bytes of static LDS: the block reductions)
@@ -435,11 +433,13 @@ static int set_lds_attrs(int device) {
 
 // ---------------------------------------------------------------------------------- block factorisation / solves (tmpc_cr.h)
 static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
+// host-side bits of Dims::flags (bit 0 = TMPC_FLAG_NO_MFMA is the only one device code reads)
+constexpr int DF_NO_SMALL = 2;   // tmpc_set_tuning(TMPC_TUNE_SMALL_BLOCKS, 0): the batched launch sequence also for dp = 16
+constexpr int DF_NO_DMA = 4;     // TMPC_DEBUG_FLAG_NO_DMA: the register-staged factorisation kernels (the path of blocks wider than 320) for every block size
 
 // Small blocks (dp = 16): one kernel per factorisation / per solve instead of a launch sequence per level (tmpc_cr_small.h); TMPC_SMALL=0: off
 static bool cr_small_levels(const Dims& dm, const CrSched& sc, CrLevs* out) {
-  static const int small_env = [] { const char* e = getenv("TMPC_SMALL"); return e ? atoi(e) : 1; }();
-  if (!small_env || dm.dp != 16 || (dm.flags & 1) || dm.p > CRS_PMAX || (int)sc.lev.size() > CRS_MAXLEV) return false;
+  if ((dm.flags & DF_NO_SMALL) || dm.dp != 16 || (dm.flags & 1) || dm.p > CRS_PMAX || (int)sc.lev.size() > CRS_MAXLEV) return false;
   if (out) {
     out->n = (int)sc.lev.size();
     for (int l = 0; l < out->n; ++l) { out->v[4 * l] = sc.lev[l].eoff; out->v[4 * l + 1] = sc.lev[l].nelim; out->v[4 * l + 2] = sc.lev[l].uoff; out->v[4 * l + 3] = sc.lev[l].nupd; }
@@ -479,8 +479,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   const int nt64 = (dm.dp + 63) / 64;
   for (const CrLevel& lv : sc.lev) {
     // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
-    static const int use_dma = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();
-    static const int potrf_dma = [] { const char* e = getenv("TMPC_POTRF_DMA"); return e ? atoi(e) : 1; }();
+    const bool use_dma = !(dm.flags & DF_NO_DMA), potrf_dma = use_dma;
     mark(0);
     if (mf && use_dma && potrf_dma && dm.nt <= TRR_NT)
       hipLaunchKernelGGL(k_cr_potrf_dma, dim3(cr_grid((long)count * lv.nelim)), dim3(256), (size_t)potrf_dma_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
@@ -499,7 +498,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
     mark(1);
     if (mf && use_dma && dm.nt <= TRR_NT) {
-      static const size_t trsm_lds = [] { const char* e = getenv("TMPC_TRSM_LDS_KB"); const size_t b = (size_t)trd_lds_doubles() * sizeof(double); return (e && (size_t)atoi(e) * 1024 > b) ? (size_t)atoi(e) * 1024 : b; }();   // (experiment: occupancy of the sweep)
+      const size_t trsm_lds = (size_t)trd_lds_doubles() * sizeof(double);
       hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), trsm_lds, st, w, dm, cd, lv.eoff, lv.nelim, count);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_trsm<true, 2>), dim3(cr_grid(it_trsm)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count, rs);
@@ -571,14 +570,10 @@ static int dd_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* d
   return TMPC_OK;
 }
 
-// TMPC_EIG_PRETEST=0: k_eigmin computes every eigenvalue (round 2)
-static const int g_eig_pretest = [] { const char* e = getenv("TMPC_EIG_PRETEST"); return e ? atoi(e) : 1; }();
-// the per-stage kernels of the plain model run with four waves per stage (TMPC_STAGE_NT=64: one wave, the original form)
-static const int g_stage_nt = [] { const char* e = getenv("TMPC_STAGE_NT"); return (e && atoi(e) == 64) ? 64 : 256; }();
+// the per-stage kernels run with four waves per stage (the one-wave form of round 1 -- profiles/r2*: 7.6 % slower -- went with its environment switch in round 4)
 #define TMPC_STAGE_LAUNCH(K, LDSB, ST, ...)                                                          \
   do {                                                                                               \
-    if (g_stage_nt == 256) hipLaunchKernelGGL((K<256>), dim3(BP), dim3(256), LDSB, ST, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((K<64>), dim3(BP), dim3(64), LDSB, ST, __VA_ARGS__);                      \
+    hipLaunchKernelGGL((K<256>), dim3(BP), dim3(256), LDSB, ST, __VA_ARGS__);                        \
   } while (0)
 
 // one chunk (nb = actual number of problems in this chunk, <= capacity); inputs already on device
@@ -599,7 +594,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   const bool t3 = dm.nT > 0;
   dm.dp = (dm.d + (eq ? dm.nz : 0) + (t3 ? dm.nT + 1 : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
-  dm.flags = h->flags & TMPC_FLAG_NO_MFMA;
+  dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
   const size_t t3_schur_lds = (size_t)(10 * 32 * T3_LD + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
   WS wall = ln->ws;                      // view over ALL problems of the chunk (init / final kernels)
@@ -611,10 +606,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   wall.alist = nullptr;
   Opts o = h->opt;
   o.tight = 0; o.tight_tol = 0.0;
-  // chord steps also with stage-local multipliers since round 3 (their rows are part of the frozen blocks like everything else; all parity
-  // cases, goldens and the five-model fuzz agree to the same bar; Step 1 with G +4.7 %, Step 2 +3.9 %).  TMPC_EQ_CHORD=0: plain model only, as in round 2
-  { static const int eqc = [] { const char* e = getenv("TMPC_EQ_CHORD"); return e ? atoi(e) : 1; }();
-    if ((eq || t3) && !eqc) o.chord_step = 0.0; }
+  // (chord steps also with stage-local multipliers since round 3: their rows are part of the frozen blocks like everything else)
   o.fast_exit = (h->flags & TMPC_FLAG_FAST_EXIT) ? 1 : 0;
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
@@ -672,11 +664,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     // plain model: the right-hand sides of the predictor pass are ready before the factorisation, and its forward substitution
     // rides inside it (k_cr_update_dma reads the O blocks anyway): one read of every O block less per main-phase iteration
-    static const int fuse_env = [] { const char* e = getenv("TMPC_FUSE_FWD"); return e ? atoi(e) : 1; }();
-    static const int dma_env = [] { const char* e = getenv("TMPC_FACTOR_DMA"); return e ? atoi(e) : 1; }();       // (the fused sweep lives in k_cr_update_dma)
     // (round 3: also with the multipliers of G / C -- their right-hand side rows depend on the iterate only, like the others; not with Step 3)
-    static const int fuse_eq_env = [] { const char* e = getenv("TMPC_FUSE_FWD_EQ"); return e ? atoi(e) : 1; }();
-    const bool fuse1 = !ddm && fuse_env && dma_env && (!eq || fuse_eq_env) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
+    const bool fuse1 = !ddm && h->tune_fuse && !(dm.flags & DF_NO_DMA) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
     if (fuse1) {
       TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
@@ -702,7 +691,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
-      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, g_eig_pretest ? o.chord_step : -1.0);
+      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, h->tune_pretest ? o.chord_step : -1.0);
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (pass == 1) {
@@ -819,12 +808,16 @@ int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb) { return tm
 
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng) { return tmpc_create_con(out, chunk, p, nx, mb, ng, 0); }
 
-static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3);
+static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes = 0);
 int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) { return create_handle(out, chunk, p, nx, mb, ng, nc, 0); }
 int tmpc_create_step3(tmpc_handle** out, int chunk, int p, int nx, int mb) { return create_handle(out, chunk, p, nx, mb, 0, 0, 1); }
 int tmpc_create_step3_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc) { return create_handle(out, chunk, p, nx, mb, ng, nc, 1); }
+int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes) {
+  if (lanes < 0 || lanes > MAXL) { snprintf(g_err, sizeof(g_err), "tmpc_create_ex: lanes = %d outside 0..%d", lanes, MAXL); return TMPC_E_ARG; }
+  return create_handle(out, chunk, p, nx, mb, ng, nc, step3 ? 1 : 0, lanes);
+}
 
-static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
+static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes) {
   if (!out) return TMPC_E_ARG;
   *out = nullptr;
   if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
@@ -852,19 +845,18 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   // lanes overlap the launch ramps of one half-wave with the kernels of the other: +8 ... +10 % at the AWE and evaporation shapes with
   // batches of 64 / 256 (repeat-timed scripts/config_sweep.py), nothing to gain at batch 1.
   int nl = (make_dims(1, p, nx, mb, ng, nc, step3).dp <= 64 && chunk >= 2) ? 2 : 1;
-  { const char* e = getenv("TMPC_LANES"); if (e && atoi(e) >= 1) nl = std::min(atoi(e), MAXL); }
+  if (lanes >= 1) nl = std::min(lanes, MAXL);          // tmpc_create_ex
   nl = std::max(1, std::min(nl, chunk));
   h->nlanes = nl;
   const int cap = (chunk + nl - 1) / nl;
   h->chunk = cap * nl;
   h->dm = make_dims(cap, p, nx, mb, ng, nc, step3);
   h->sched = cr_build(p);
-  { const char* e = getenv("TMPC_CR_RS"); h->rs = e ? atoi(e) : 0; if (h->rs % 64) h->rs = 0; }
-  { const char* e = getenv("TMPC_CR_MT"); h->mt = e ? atoi(e) : 0; if (h->mt % 64) h->mt = 0; }
+  h->rs = 0; h->mt = 0;
+  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1;
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->opt.fast_exit = 0;
-  h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); TMPC_CHORD=0 disables
-  { const char* e = getenv("TMPC_CHORD"); if (e) h->opt.chord_step = atof(e); }
+  h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); tmpc_set_tuning(TMPC_TUNE_CHORD_STEP, 0) disables
   h->flags = 0;
   WS tmp;
   const size_t lane_bytes = carve(tmp, h->dm, nullptr, nullptr);
@@ -914,7 +906,7 @@ int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
-  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED | TMPC_DEBUG_FLAG_NO_LIFT)) {
+  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED | TMPC_DEBUG_FLAG_NO_LIFT | TMPC_DEBUG_FLAG_NO_DMA)) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2, TMPC_FLAG_FAST_EXIT = 4)", flags);
     return TMPC_E_ARG;
   }
@@ -926,6 +918,18 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
   return TMPC_OK;
 }
 
+
+// Performance knobs that used to be environment variables (round 4: part of the ABI, per handle)
+int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
+  if (!h) return TMPC_E_ARG;
+  switch (key) {
+    case TMPC_TUNE_CHORD_STEP: if (!(value >= 0.0)) return TMPC_E_ARG; h->opt.chord_step = value; return TMPC_OK;
+    case TMPC_TUNE_SMALL_BLOCKS: h->tune_small = value != 0.0; return TMPC_OK;
+    case TMPC_TUNE_EIG_PRETEST: h->tune_pretest = value != 0.0; return TMPC_OK;
+    case TMPC_TUNE_FUSE_FWD: h->tune_fuse = value != 0.0; return TMPC_OK;
+    default: snprintf(g_err, sizeof(g_err), "tmpc_set_tuning: unknown key %d", key); return TMPC_E_ARG;
+  }
+}
 
 // Tight-accuracy mode (see tunempc_hip.h and tmpc_dd.h).  The double-double workspace (about as large as the block storage of the handle) is
 // allocated at the first enable and kept until tmpc_destroy.
@@ -1108,10 +1112,12 @@ static int dispatch(tmpc_handle* h, const Call& c, hipStream_t user, bool has_us
   std::chrono::steady_clock::time_point t0;
   if (prof) t0 = std::chrono::steady_clock::now();
   for (int l = 0; l < h->nlanes; ++l) h->lane[l].last_nb = 0;
-  for (int off = 0; off < c.nbt; off += h->chunk) {
-    const int nw = std::min(h->chunk, c.nbt - off);
+  // (profile mode: ONE lane -- the hipEvent phase times of concurrent lanes overlap, and their sum is not wall time: ADVICE r3)
+  const int wave = prof ? h->dm.B : h->chunk;
+  for (int off = 0; off < c.nbt; off += wave) {
+    const int nw = std::min(wave, c.nbt - off);
     // balanced contiguous slices (a lane never gets more than its capacity dm.B)
-    const int nl = std::min(h->nlanes, nw);
+    const int nl = prof ? 1 : std::min(h->nlanes, nw);
     int lo[MAXL + 1];
     for (int l = 0; l <= nl; ++l) lo[l] = (int)((long)nw * l / nl);
     int rcs[MAXL]; for (int l = 0; l < MAXL; ++l) { rcs[l] = TMPC_OK; h->lane[l].last_nb = 0; }

@@ -457,7 +457,10 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     // fuzz member whose last chord step contracted the step norm 200-fold and the output only 2-fold: reverted.)
     const double est = was_chord ? stepn : stepn * rr * sqrt(rr);
     bool chord_next = false, full_reset = false;
-    if (full && (o.fast_exit || stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }
+    if (full && (o.fast_exit || stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol))) {
+      ip[I_PHASE] = PH_DONE;
+      ip[I_IPMSTATUS] = (stepn < o.center_tol || (!was_chord && est < 0.1 * o.center_tol)) ? IPM_OPTIMAL : IPM_FAST_EXIT;      // (a fast exit is told apart in info[10]: ADVICE r3)
+    }
     // (rounding floor: the steps stopped contracting below 1e-6.  Not with a lifted diagonal: Newton is damped in the weakest directions then
     // and small steps say nothing about the distance to the centred point -- a fuzz member stopped 1e-4 away with steps of 1e-7; the next
     // branch backs mu_t off and drops the lift instead.)
