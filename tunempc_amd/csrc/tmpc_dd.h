@@ -17,7 +17,7 @@
 // and the centering phase hands over (first full step below POLISH_ENTER) to Newton's method on the DUAL barrier problem in
 // y = (tau, alpha, P) with every stage quantity in dd (k_dd_polish_pre): the primal-dual iteration keeps X and S^-1 as fp64
 // matrices whose large part buries the small one under an absolute rounding error, so its centred point is reproducible to
-// ~eps/mu only (1e-7 at mu = 2e-12); two or three polish steps reproduce it to 1e-12 (oracle/convexify_oracle.py: _polish_dd).
+// ~eps/mu only (1e-7 at mu = 2e-12); two or three polish steps reproduce it to 1e-12 (the CPU restatement used by the tests does the same).
 //
 // The dd kernels run on the vector ALU (the matrix cores have no extended format; emulating dd products on fp64 MFMA by
 // Ozaki slicing costs as many issue slots as the VALU form because fp64 MFMA and VALU share them on this part): ~12 VALU
@@ -34,7 +34,7 @@
 
 namespace tmpc {
 
-constexpr double POLISH_ENTER = 1e-4;    // as oracle/convexify_oracle.py
+constexpr double POLISH_ENTER = 1e-4;    // as the CPU restatement used by the tests
 constexpr int POLISH_MAX = 6;
 
 // ------------------------------------------------------------------ dd scalar arithmetic (Dekker / Knuth / QD)
