@@ -310,3 +310,55 @@ def test_bench_multi_rank_branch_on_one_gpu(hc):
     for k in ('Hc', 'kappa', 'status'):
         hsh.update(np.ascontiguousarray(np.concatenate([o[k] for o in outs])).tobytes())
     assert line['gathered_digest'] == hsh.hexdigest()
+
+
+# ----------------------------------------------------------------------------- the remaining holes on BASELINE's configurations
+def test_c5_share_sampled_members(hc):
+    """BASELINE configs[4] at its per-GPU share: 64 problems, p = 200, n = 30 (nx = 20, m = 10), device-resident entry -- 8 members drawn at random plus
+    the slowest and the fastest against cpu_ipm (as test_bench_batch_sampled_members does for configs[3])."""
+    import torch
+    from tunempc_amd import synthetic
+    p, nx, mb, nb = 200, 20, 10, 64
+    A, B, H = synthetic.gen_batch(41000, nb, p, nx, mb)
+    h = hc(p, nx, mb)
+    dev = torch.device('cuda', 0)
+    o = h.convexify_batch_device(*(torch.from_numpy(x).to(dev) for x in (A, B, H)))
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in o.items()}
+    assert (out['status'] == 0).all()
+    pick = np.sort(np.random.default_rng(20261003).choice(nb, size=8, replace=False))
+    pick = np.unique(np.concatenate([pick, [int(np.argmax(out['iters'])), int(np.argmin(out['iters']))]]))
+    ref = cpu_ipm.convexify_batch(A[pick], B[pick], H[pick], threads=HOST_THREADS)
+    worst = _check_members({k: out[k][pick] for k in ('Hc', 'kappa', 'status')}, ref, range(len(pick)), 'c5 share')
+    print(f'c5 share (64 x p=200 x n=30): members {pick.tolist()}: worst rel. Frobenius error {worst:.2e}; iterations {out["iters"].min()}..{out["iters"].max()}')
+
+
+def test_multiplier_models_at_batch_64(hc):
+    """Step 1 with G and the Step 2 model (ragged C_k, norm terms) at batch 64 (tests/test_gpu_parity.py checks them at nb <= 4): the launches over the
+    compacted lists, chord steps and fused forward sweeps of these models with many members in flight.  Six members each against the numpy oracle."""
+    p, nx, mb, nb, ng, nc = 12, 9, 3, 64, 2, 3
+    n = nx + mb
+    A, B, H = co.gen_batch(42000, nb, p, nx, mb)
+    rng = np.random.default_rng(42)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    og = h.convexify_eq_batch(A, B, H, G)
+    o2 = h.convexify_step2_batch(A, B, H, np.concatenate([G, Cc], axis=2), ncnt, 1e-2)
+    assert (og['status'] == 0).all() and (o2['status'] == 0).all()
+    pick = np.sort(rng.choice(nb, size=6, replace=False))
+    wg = w2 = 0.0
+    for b in pick:
+        r = co.sdp_step1(A[b], B[b], H[b], G=G[b])
+        Hc = H[b] + co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], G=G[b], Fg=r['Fg'])[1]
+        e = rel(og['Hc'][b], Hc); wg = max(wg, e)
+        assert r['ipm_status'] == 'optimal' and e < PARITY, ('G', b, e)
+        Cl = [Cc[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        r = co.sdp_step1(A[b], B[b], H[b], G=G[b], C=Cl, rho=1e-2)
+        Hc = H[b] + co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], G=G[b], Fg=r['Fg'], C=Cl, F=r['F'])[1]
+        e = rel(o2['Hc'][b], Hc); w2 = max(w2, e)
+        assert r['ipm_status'] == 'optimal' and e < PARITY, ('step2', b, e)
+    print(f'batch 64, members {pick.tolist()}: Step 1 with G worst {wg:.2e}, Step 2 worst {w2:.2e}; iterations G {og["iters"].min()}..{og["iters"].max()}, step2 {o2["iters"].min()}..{o2["iters"].max()}')
