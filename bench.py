@@ -33,8 +33,8 @@ def factor_flops_per_problem(p, d):
     return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
 
 
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
-KERNEL_SOURCES = [os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h')]
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r4_traffic.json')
+KERNEL_SOURCES = sorted(os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'tunempc_amd', 'csrc')) if f.endswith(('.h', '.hip')))      # every kernel source (round 3 hashed two of them)
 
 
 def _normalised(path):
@@ -54,7 +54,7 @@ def kernel_sources_sha():
 
 
 def hbm_traffic_per_launch():
-    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r3_traffic.json, written by
+    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r4_traffic.json, written by
     scripts/pmc_traffic.py from separate rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from
     inside this process).  None when the file is missing or was measured on OTHER kernel sources (content hash): a stale number is
     not reported."""
@@ -155,6 +155,42 @@ def cpu_baseline(p, nx, mb, tol):
                       + (f"; {mid} problems on {mid} threads: {points[mid]:.1f} stage-conv/s" if mid else "") + note}
 
 
+def small_configs(HipConvexifier, synthetic):
+    """BASELINE configs[1] and configs[2] on the GPU (host-buffer entry, median of 7 solves after a warm-up) with oracle/cpu_ipm on the host cores beside
+    them (at batch 1 the margin over a CPU is thin and nobody had measured it on the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    out = {}
+    try:
+        import cpu_ipm
+    except Exception:      # noqa: BLE001
+        cpu_ipm = None
+    hw = host_cpu_info()
+    cores = max(1, min(hw["effective_cores"], 64))
+    for key, (seed, nb, p, nx, mb) in {"configs[1] unicycle-shaped p=30 n=5 batch=1": (200000, 1, 30, 4, 1),
+                                        "configs[2] evaporation-shaped p=50 n=4 batch=256": (200100, 256, 50, 2, 2)}.items():
+        A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
+        h = HipConvexifier(p, nx, mb, chunk=nb)
+        h.convexify_batch(A, B, H)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter(); o = h.convexify_batch(A, B, H); ts.append(time.perf_counter() - t0)
+        h.close()
+        tg = float(np.median(ts))
+        rec = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
+               "ipm_iterations_mean": float(o['iters'].mean())}
+        if cpu_ipm is not None:
+            th = 1 if nb == 1 else cores
+            cpu_ipm.convexify_batch(A[:1], B[:1], H[:1], threads=1)
+            tc = []
+            for _ in range(3):
+                t0 = time.perf_counter(); cpu_ipm.convexify_batch(A, B, H, threads=th); tc.append(time.perf_counter() - t0)
+            tcm = float(np.median(tc))
+            rec.update(cpu_ms_per_solve=1e3 * tcm, cpu_stage_conv_per_s=nb * p / tcm, cpu_threads=th, gpu_over_cpu=tcm / tg)
+        out[key] = rec
+    out["note"] = "host-buffer entry (H2D + D2H inside), median of 7; CPU: oracle/cpu_ipm (C++/OpenMP port, one problem per thread), median of 3, same seeds"
+    return out
+
+
 # Everything that libraries print on stdout while the bench runs (RCCL prints its version banner there at communicator creation) goes
 # to stderr: stdout carries exactly one line, the JSON record.
 REAL_STDOUT = os.dup(1)
@@ -175,6 +211,7 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="collective backend; 'gloo' (results staged through the host) lets the multi-rank branch run where RCCL cannot")
     ap.add_argument('--same-device', action='store_true', help='every rank on cuda:0 (with --backend gloo: the N > 1 code path on a one-GPU box; not a scaling measurement)')
     ap.add_argument('--digest', action='store_true', help='add the sha256 of the gathered Hc / kappa / status of the last step to the line (tests)')
+    ap.add_argument('--no-small', action='store_true', help='skip the small-configuration legs (configs[1] latency, configs[2] rate)')
     ap.add_argument('--no-tight', action='store_true', help='skip the tight-accuracy leg (one extra step, ~10x a default step)')
     ap.add_argument('--no-extra', action='store_true', help='skip the unprofiled and host-buffer legs after the timed region')
     ap.add_argument('--distinct', type=int, default=512, help='distinct synthetic problems generated per rank (tiled to --batch when smaller)')
@@ -295,6 +332,13 @@ def main():
                                            "ipm_iterations_mean": float(it2.mean()), "status_optimal": int((st2 == 0).sum()),
                                            "note": "NOT the headline setting: TMPC_FLAG_FAST_EXIT stops every member after its first full centering step -- feasible, "
                                                    "kappa within the same gap, but not the converged central-path point (Hc ~1e-3..1e-2 off it, not reproducible to 1e-8)"}
+        # BASELINE configs[1] (unicycle-shaped, batch 1: latency) and configs[2] (evaporation-shaped, batch 256: rate), each with the CPU port beside it
+        if not args.no_small:
+            try:
+                extra_rates["small_configs"] = small_configs(HipConvexifier, synthetic)
+            except Exception as e:      # noqa: BLE001
+                extra_rates["small_configs"] = None
+                extra_rates["small_configs_error"] = f"{type(e).__name__}: {e}"
         # the opt-in tight-accuracy mode (include/tunempc_hip.h: tmpc_set_tight): every member continued from its centred point to
         # mu_t = 2^-37 kappa with double-double block linear algebra + dd dual-Newton polish (VALU kernels, no matrix cores)
         if not args.no_tight:
@@ -354,7 +398,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                          "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r3_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r4_traffic.json)",
                          "kernel": "k_cr_update_dma (symmetric updates and fill edges of the cyclic-reduction block Cholesky: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles)",
                          "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
                          "algorithmic_flops_per_launch": upd_flops / upd_launches,

@@ -1,5 +1,5 @@
 """HBM traffic per launch of the dominant kernel from two rocprofv3 --pmc passes of the bench command (FETCH_SIZE in one, WRITE_SIZE in the
-other; rocpd sqlite databases) -> profiles/r3_traffic.json, which bench.py reports as roofline.traffic while it is newer than the kernel sources.
+other; rocpd sqlite databases) -> profiles/r4_traffic.json, which bench.py reports as roofline.traffic while it is newer than the kernel sources.
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB-like units of 1024 B... (rocprofv3
 reports kilobytes), and FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 B on gfx950: doubled.
 usage: python scripts/pmc_traffic.py <fetch db dir> <write db dir> [kernel substring]"""
@@ -26,8 +26,9 @@ def _normalised(path):
 def sources_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ('tmpc_cr.h', 'tmpc_gemm_dma.h'):
-        h.update(_normalised(os.path.join(ROOT, 'tunempc_amd', 'csrc', f)))
+    d = os.path.join(ROOT, 'tunempc_amd', 'csrc')
+    for f in sorted(x for x in os.listdir(d) if x.endswith(('.h', '.hip'))):      # every kernel source, as bench.py's kernel_sources_sha
+        h.update(_normalised(os.path.join(d, f)))
     return h.hexdigest()[:16]
 
 
@@ -38,7 +39,7 @@ def main():
     out = {
         "kernel": kernel,
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes) on "
-                  "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`; per-kernel summary in profiles/r3_final_pmc.txt",
+                  "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`; per-kernel summary in profiles/r4_final_pmc.txt",
         "launches": nf,
         "fetch_size_kb_per_launch_raw": f,
         "fetch_correction": "x2: gfx950 FETCH_SIZE counts 128-byte requests as 64 B (MI355X_MICROARCH.md, HBM section)",
@@ -47,7 +48,7 @@ def main():
         "sources_sha": sources_sha(),
         "note": "average over all launches of the kernel (7 levels per factorisation phase, shrinking active sets)",
     }
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r3_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r4_traffic.json'), 'w'), indent=1)
     print(json.dumps(out))
 
 
