@@ -181,6 +181,13 @@ int tmpc_create_step3_con(tmpc_handle** out, int chunk, int p, int nx, int mb, i
 int tmpc_convexify_step3_con_batch_host(tmpc_handle* h, int nb, const double* A, const double* B, const double* H, const double* J,
                                         const int32_t* ncnt, double rho, double* Hc, double* dHc, double* P, double* FgF, double* T,
                                         double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters, double* info);
+/* Device-resident forms of the two Step 3 entries (device pointers in and out; `stream`: the caller's HIP stream, NULL = default -- the call returns
+ * with every result written, as tmpc_convexify_batch_device). */
+int tmpc_convexify_step3_batch_device(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, double rho, double* Hc, double* dHc,
+                                      double* P, double* T, double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters, double* info, void* stream);
+int tmpc_convexify_step3_con_batch_device(tmpc_handle* h, int nb, const double* dA, const double* dB, const double* dH, const double* dJ, const int32_t* d_ncnt,
+                                          double rho, double* Hc, double* dHc, double* P, double* FgF, double* T, double* alpha, double* beta, double* kappa,
+                                          int32_t* status, int32_t* iters, double* info, void* stream);
 
 /* Device-resident form of the two entries above (inputs and outputs in HBM, work queued on `stream`): d_ncnt == NULL is Step 1
  * with G (dJ = G [nb][p][ng][n], FgF [nb][p][ng]); otherwise the Step 2 model (dJ [nb][p][ng+nc][n], d_ncnt [nb][p] with

@@ -664,6 +664,37 @@ def test_step3_with_constraint_rows_parity(hc, seed, p, nx, mb, ng, ncs, rho):
                 assert np.abs(out['FgF'][0, k, ng:ng + ncs[k]] - r['F'][k]).max() < PARITY * max(1.0, np.abs(r['F'][k]).max())
 
 
+def test_step3_device_resident_entries(hc):
+    """tmpc_convexify_step3_batch_device / tmpc_convexify_step3_con_batch_device (round 4): torch tensors in HBM in and out, bit-identical to the host-buffer
+    entries on the same inputs (same kernels, same launch sequence; only the copies differ)."""
+    import torch
+    dev = torch.device('cuda', 0)
+    p, nx, mb, nb, ng, nc, rho = 4, 4, 2, 3, 1, 2, 1e-2
+    n = nx + mb
+    A, B, H = co.gen_batch(7300, nb, p, nx, mb)
+    rng = np.random.default_rng(73)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    J = np.concatenate([G, Cc], axis=2)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    h3 = hc(p, nx, mb, step3=True)
+    a = h3.convexify_step3_batch(A, B, H, rho)
+    d = h3.convexify_step3_batch_device(t(A), t(B), t(H), rho)
+    torch.cuda.synchronize()
+    for k in ('Hc', 'T', 'P', 'kappa', 'status', 'iters'):
+        assert np.array_equal(a[k], d[k].cpu().numpy()), k
+    h3c = hc(p, nx, mb, ng=ng, nc=nc, step3=True)
+    a = h3c.convexify_step3_con_batch(A, B, H, J, ncnt, rho)
+    d = h3c.convexify_step3_batch_device(t(A), t(B), t(H), rho, J=t(J), ncnt=t(ncnt))
+    torch.cuda.synchronize()
+    for k in ('Hc', 'T', 'P', 'FgF', 'kappa', 'status', 'iters'):
+        assert np.array_equal(a[k], d[k].cpu().numpy()), k
+    assert (a['status'] == 0).all()
+
+
 def test_step3_rescues_the_infeasible_vector(golden_dir):
     """The dense model's vector (B = 0, R < 0, no constraints): Steps 1 and 2 cannot help, force -> Step 3 (convexifier.py:137-147).
     The drop-in logs the reference's warnings, takes Step 3 on the GPU and returns a positive definite result; its optimal value

@@ -241,3 +241,22 @@ def test_hard_target_wall_rule_ignores_pinf_after_a_shift():
     r = co.sdp_step1(A, B, H)
     assert r['ipm_status'] == 'optimal' and r['shift'] > 0.0 and r['pinf'] < 1e-6
     assert co.check_convergence(A, B, H, r['P'], r['ipm_status'])[0] == co.STATUS_OPTIMAL
+
+
+def test_step3_with_cost_free_T_is_degenerate():
+    """convexifier.py:283-285 under the reading of `picos.sum(obj, abs(rho*T[i]))` in which the norm term never reaches the solver: T_k is
+    then cost-free, and Step 3 degenerates -- any M_k can be produced by T_k alone, so the optimum is kappa* = 1 with M_k = I and the "convexified"
+    Hessian is Hc_k = I / (s alpha) for every stage, whatever H was; only the scalar alpha is left, and it is not determined (it drifts with the
+    weight as rho -> 0).  Shown on the paper's objective with rho -> 0; this is why the drop-in raises NotImplementedError for force + objective='beta'
+    instead of returning c * I."""
+    A, B, H, _, _ = co.gen_problem(5, 3, 3, 2)
+    cs = []
+    for rho in (1e-4, 1e-6):
+        r = co.sdp_step1(A, B, H, rho=rho, force=True)
+        assert r['ipm_status'] == 'optimal' and r['kappa'] - 1.0 < 1e-5
+        Hc = H + co.convex_hessian_suppl(A, B, r['P'], T=r['T'])[0]
+        c = np.trace(Hc, axis1=1, axis2=2) / Hc.shape[1]
+        assert np.linalg.norm(Hc - c[:, None, None] * np.eye(Hc.shape[1])) / np.linalg.norm(Hc) < 1e-6        # Hc_k = c I: H is gone
+        assert np.ptp(c) < 1e-6 * c.mean() and abs(c.mean() * r['s'] * r['alpha'] - 1.0) < 1e-5                # c = 1 / (s alpha), the same for every stage
+        cs.append(c.mean())
+    assert abs(cs[1] / cs[0] - 1.0) > 0.05                                                                     # ... and alpha is not determined by the SDP

@@ -20,7 +20,7 @@ EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight', 'tmpc_set_tuning', 'tmpc_create_ex',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
-    'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
+    'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_convexify_step3_batch_device', 'tmpc_convexify_step3_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
     'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
     'tmpc_last_error', 'tmpc_version',
 ]
@@ -83,6 +83,10 @@ def load_library():
     lib.tmpc_debug_get_array.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, dp]
     lib.tmpc_convexify_con_batch_device.restype = C.c_int
     lib.tmpc_convexify_con_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_double] + [vp] * 10 + [vp]
+    lib.tmpc_convexify_step3_batch_device.restype = C.c_int
+    lib.tmpc_convexify_step3_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double] + [vp] * 10 + [vp]
+    lib.tmpc_convexify_step3_con_batch_device.restype = C.c_int
+    lib.tmpc_convexify_step3_con_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_double] + [vp] * 11 + [vp]
     lib.tmpc_create.restype = C.c_int
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
@@ -365,6 +369,37 @@ class HipConvexifier:
                                                       ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']),
                                                       ptr(out['iters']), ptr(out['info']), C.c_void_p(st))
         _check(self.lib, rc, 'tmpc_convexify_con_batch_device')
+        return out
+
+    def convexify_step3_batch_device(self, A, B, H, rho, J=None, ncnt=None, stream=None):
+        """Device-resident Step 3 (convexifier.py:137-147): torch CUDA tensors in, torch tensors out (the dict of convexify_batch_device plus 'T'); with J
+        (and ncnt) the multipliers of G / C ride in the same solve (convexifier.py:144), output 'FgF' as well."""
+        import torch
+        nb = A.shape[0]
+        for t in (A, B, H) + ((J,) if J is not None else ()):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        assert self.step3 and (J is None or self.ng + self.nc > 0)
+        assert ncnt is None or (ncnt.is_cuda and ncnt.dtype == torch.int32 and ncnt.is_contiguous())
+        dev = A.device
+        f64 = lambda *sh: torch.empty(sh, dtype=torch.float64, device=dev)
+        out = dict(Hc=torch.empty_like(H), dHc=torch.empty_like(H), P=torch.empty_like(A), T=torch.empty_like(H), alpha=f64(nb), beta=f64(nb), kappa=f64(nb),
+                   status=torch.empty(nb, dtype=torch.int32, device=dev), iters=torch.empty(nb, dtype=torch.int32, device=dev), info=f64(nb, INFO_STRIDE))
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        if J is None:
+            rc = self.lib.tmpc_convexify_step3_batch_device(self._h, nb, ptr(A), ptr(B), ptr(H), float(rho), ptr(out['Hc']), ptr(out['dHc']), ptr(out['P']),
+                                                            ptr(out['T']), ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']),
+                                                            ptr(out['iters']), ptr(out['info']), C.c_void_p(st))
+            _check(self.lib, rc, 'tmpc_convexify_step3_batch_device')
+            return out
+        nr = self.ng if ncnt is None else self.ng + self.nc
+        assert tuple(J.shape) == (nb, self.p, nr, self.n), (tuple(J.shape), nr)
+        out['FgF'] = f64(nb, self.p, nr)
+        rc = self.lib.tmpc_convexify_step3_con_batch_device(self._h, nb, ptr(A), ptr(B), ptr(H), ptr(J), ptr(ncnt) if ncnt is not None else None,
+                                                            float(rho), ptr(out['Hc']), ptr(out['dHc']), ptr(out['P']), ptr(out['FgF']), ptr(out['T']),
+                                                            ptr(out['alpha']), ptr(out['beta']), ptr(out['kappa']), ptr(out['status']), ptr(out['iters']),
+                                                            ptr(out['info']), C.c_void_p(st))
+        _check(self.lib, rc, 'tmpc_convexify_step3_con_batch_device')
         return out
 
     def supplement_batch(self, A, B, P):

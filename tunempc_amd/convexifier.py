@@ -340,8 +340,12 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
         Logger.logger.warning(50 * '*')
         if (opts or {}).get('force', False):                                  # convexifier.py:137-147
             if objective == 'beta':
+                # With a cost-free T_k the SDP of Step 3 is degenerate: T_k alone can produce any M_k, the optimum is kappa* = 1 with M_k = I, and the
+                # result is Hc_k = I / (s alpha) for every stage whatever H was, with alpha undetermined (tests/test_oracle.py::
+                # test_step3_with_cost_free_T_is_degenerate).  Not a model worth a kernel: refuse rather than return c * I.
                 raise NotImplementedError("opts['objective'] = 'beta' covers Step 2; Step 3 with a cost-free T_k (the beta-only reading of "
-                                          "convexifier.py:284-285) has no counterpart in the HIP path -- use the default objective")
+                                          "convexifier.py:284-285) is degenerate -- its optimum is Hc_k = c * I for every stage, see INTEGRATION.md -- "
+                                          "use the default objective")
             Logger.logger.info('Step 3: (η_F = 1), (η_T = 1)')
             Logger.logger.info('Enforcing convexification...')
             Logger.logger.info('solving SDP...')

@@ -1231,6 +1231,32 @@ int tmpc_convexify_step3_con_batch_host(tmpc_handle* h, int nbt, const double* A
   return dispatch(h, c, nullptr, false);
 }
 
+// Device-resident forms of the two Step 3 entries (round 4): device pointers in and out, the lanes start after the work queued on `stream`.
+// d_ncnt is checked on the device side only through the padding (rows beyond the count must be zero, as in tmpc_convexify_con_batch_device).
+int tmpc_convexify_step3_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH, double rho, double* Hc, double* dHc,
+                                      double* P, double* T, double* alpha, double* beta, double* kappa, int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (h && nbt == 0) return TMPC_OK;
+  if (!h || nbt < 1 || !dA || !dH || !(rho > 0.0) || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  if (h->dm.nT < 1) { snprintf(g_err, sizeof(g_err), "handle was created without room for Step 3 (use tmpc_create_step3)"); return TMPC_E_ARG; }
+  ON_DEVICE(h);
+  Call c{nbt, dA, dB, dH, nullptr, nullptr, rho, Hc, dHc, P, nullptr, alpha, beta, kappa, status, iters, info, false, 0};
+  c.step3 = true; c.T = T;
+  return dispatch(h, c, (hipStream_t)stream, true);
+}
+int tmpc_convexify_step3_con_batch_device(tmpc_handle* h, int nbt, const double* dA, const double* dB, const double* dH, const double* dJ, const int32_t* d_ncnt,
+                                          double rho, double* Hc, double* dHc, double* P, double* FgF, double* T, double* alpha, double* beta, double* kappa,
+                                          int32_t* status, int32_t* iters, double* info, void* stream) {
+  if (h && nbt == 0) return TMPC_OK;
+  if (!h || nbt < 1 || !dA || !dH || !dJ || !FgF || !(rho > 0.0) || (h->dm.mb > 0 && !dB)) return TMPC_E_ARG;
+  const Dims& dm = h->dm;
+  if (dm.nT < 1 || dm.nr < 1) { snprintf(g_err, sizeof(g_err), "handle was created without room for Step 3 and constraint rows (use tmpc_create_step3_con)"); return TMPC_E_ARG; }
+  if (d_ncnt && dm.nz <= dm.nr) { snprintf(g_err, sizeof(g_err), "handle was created without active-constraint rows (nc > 0)"); return TMPC_E_ARG; }
+  ON_DEVICE(h);
+  Call c{nbt, dA, dB, dH, dJ, d_ncnt, rho, Hc, dHc, P, FgF, alpha, beta, kappa, status, iters, info, false, d_ncnt ? dm.nr : dm.ng};
+  c.step3 = true; c.T = T;
+  return dispatch(h, c, (hipStream_t)stream, true);
+}
+
 int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, const double* B, const double* P, int nr,
                                      const double* J, const double* wts, const double* T, double* dHc) {
   if (!hh || nbt < 1 || !A || !P || !dHc || (hh->dm.mb > 0 && !B) || nr < 0 || ((J != nullptr) != (wts != nullptr)) || (J && nr < 1)) return TMPC_E_ARG;
