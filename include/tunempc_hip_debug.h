@@ -25,6 +25,9 @@ extern "C" {
 /* Debug bit: the register-staged factorisation kernels (k_cr_potrf / k_cr_trsm / k_cr_update: the path of blocks wider than 320) for every block
  * size, instead of the LDS-DMA kernels -- keeps that path under test at small shapes. */
 #define TMPC_DEBUG_FLAG_NO_DMA 32
+/* Debug bit: the generic per-stage kernels of stage blocks wider than 32 (tmpc_big.h) also at n <= 32 (plain model), so that they can be
+ * compared with the tuned kernels on the same inputs. */
+#define TMPC_DEBUG_FLAG_GENERIC_STAGE 64
 
 /* C (M x N) <op> A (M x K) * B (N x K)' with the fp64 MFMA tile GEMMs of the factorisation; mode 0: C -= AB', 1: C = AB', 2: C = -AB'.
  * mode + 0: the register-staged core (tmpc_factor.h, one workgroup walks all tiles); + 16: the LDS-DMA tile core (tmpc_gemm_dma.h, one

@@ -1042,3 +1042,54 @@ def test_kernel_variants_behind_handle_options(golden_dir, variant):
             assert int(out['status'][b]) == int(g['status'][b]), (name, b, out['status'][b], g['status'][b])
             worst = max(worst, np.linalg.norm(out['Hc'][b] - g['Hc'][b]) / np.linalg.norm(g['Hc'][b]))
     assert worst < PARITY, (variant, worst)
+
+
+# ----------------------------------------------------------------------------- stage blocks wider than 32
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(201, 2, 4, 30, 10), (202, 2, 6, 36, 12), (203, 1, 3, 40, 24), (204, 2, 8, 33, 1), (205, 2, 1, 34, 4), (206, 2, 2, 35, 3)])
+def test_large_stage_blocks_parity(seed, nb, p, nx, mb):
+    """32 < n = nx + m <= 64 (the reference accepts any size: preprocessing.py:157-185): the generic per-stage kernels of csrc/tmpc_big.h with the
+    register-staged block factorisation (blocks up to 820 wide here) against the C++ CPU port, plain Step 1 model, to the 1e-8 bar; the structural
+    invariants; p = 1 and p = 2 included."""
+    from tunempc_amd._lib import HipConvexifier
+    import cpu_ipm
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    h = HipConvexifier(p, nx, mb, chunk=nb)
+    out = h.convexify_batch(A, B, H)
+    h.close()
+    ref = cpu_ipm.convexify_batch(A, B, H, threads=8)
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 == int(ref['status'][b])
+        assert rel(out['Hc'][b], ref['Hc'][b]) < PARITY, (b, rel(out['Hc'][b], ref['Hc'][b]))
+        assert abs(out['kappa'][b] - ref['kappa'][b]) < 1e-9 * ref['kappa'][b]
+        ev = np.linalg.eigvalsh(out['Hc'][b])
+        assert ev.min() > 0 and (ev[:, -1] / ev[:, 0]).max() <= out['kappa'][b] * (1 + 1e-9)
+        dH = co.convex_hessian_suppl(A[b], B[b], out['P'][b])[0]
+        assert rel(out['Hc'][b] - H[b], dH) < 1e-10
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(3, 2, 6, 4, 2), (70, 3, 16, 12, 4), (95, 2, 5, 24, 8), (61, 2, 1, 5, 2)])
+def test_generic_stage_kernels_match_the_tuned_ones(hc, seed, nb, p, nx, mb):
+    """TMPC_DEBUG_FLAG_GENERIC_STAGE (64): the generic per-stage kernels at n <= 32, against the tuned kernels on the same inputs -- same iteration
+    counts, Hc to 1e-9 (they differ in rounding only: one thread per output entry and a Jacobi eigenvalue iteration instead of MFMA tiles, Householder + Sturm)."""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    ref = hc(p, nx, mb).convexify_batch(A, B, H)
+    h = HipConvexifier(p, nx, mb, chunk=nb, flags=64)
+    out = h.convexify_batch(A, B, H)
+    h.close()
+    assert np.array_equal(out['status'], ref['status']) and np.array_equal(out['iters'], ref['iters'])
+    for b in range(nb):
+        assert rel(out['Hc'][b], ref['Hc'][b]) < 1e-9, (b, rel(out['Hc'][b], ref['Hc'][b]))
+
+
+def test_dropin_convexify_large_block():
+    """convexifier.convexify at nx + nu = 38 (rounds 1-3 raised NotImplementedError): same call as the reference's, lists in, lists out."""
+    from tunempc_amd import convexifier
+    p, nx, mb = 3, 30, 8
+    A, B, H = co.gen_batch(207, 1, p, nx, mb)
+    Q = [H[0, k][:nx, :nx] for k in range(p)]; R = [H[0, k][nx:, nx:] for k in range(p)]; N = [H[0, k][:nx, nx:] for k in range(p)]
+    dHc, dQc, dRc, dNc = convexifier.convexify([A[0, k] for k in range(p)], [B[0, k] for k in range(p)], Q, R, N, opts={'rho': 1e-3, 'solver': 'hip', 'force': False})
+    r = co.convexify_arrays(A[0], B[0], H[0])
+    assert rel(np.stack(dHc), r['dHc']) < 1e-7 and all(np.linalg.eigvalsh(H[0, k] + dHc[k]).min() > 0 for k in range(p))
+    assert np.array_equal(dQc[1], dHc[1][:nx, :nx]) and np.array_equal(dNc[2], dHc[2][:nx, nx:])
+    convexifier.release_handles()

@@ -22,6 +22,7 @@
 #include "tmpc_t3.h"
 #include "tmpc_eig.h"
 #include "tmpc_dd.h"
+#include "tmpc_big.h"
 
 using namespace tmpc;
 
@@ -56,6 +57,7 @@ struct Lane {
   int32_t* dncnt;                // [cap][p] rows of C_k per stage (Step 2)
   double* d_info;                // [cap][16]
   double* d_abk;                 // [cap][3]
+  void* big_scr;                 // scratch of the generic per-stage kernels when they are forced at n <= 32 (debug flag), allocated on first use
   int32_t* d_si;                 // [cap][2]
   hipStream_t st;                // the lane's own stream
   hipEvent_t ev[8];
@@ -102,7 +104,7 @@ static CrDev cr_dev(const CrSched& sc, const int* d_sched, const int* alist) {
 }
 
 // ---------------------------------------------------------------------------------- sizes
-static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NMAX && nx + mb >= 1; }
+static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NB && nx + mb >= 1; }      // n <= 32: the tuned per-stage kernels; 32 < n <= 64: tmpc_big.h
 
 static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0, int step3 = 0) {
   Dims d;
@@ -153,6 +155,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.cr_orient = nullptr;
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
+  w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
   w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
@@ -597,6 +600,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
   const size_t t3_schur_lds = (size_t)(10 * 32 * T3_LD + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
+  const bool big = dm.n > NMAX || ((h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE) && !eq && !t3);      // generic per-stage kernels (tmpc_big.h)
+  if (big && !ln->ws.bscr) {                 // (debug flag at n <= 32: the scratch is not part of the workspace)
+    if (hipMalloc(&ln->big_scr, (size_t)h->dm.B * dm.p * BIG_SCR * dm.n * dm.n * sizeof(double)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc of the generic-stage scratch failed"); return TMPC_E_NOMEM; }
+    ln->ws.bscr = (double*)ln->big_scr;
+  }
   WS wall = ln->ws;                      // view over ALL problems of the chunk (init / final kernels)
   wall.A = dA; wall.Bm = dB; wall.H = dH; wall.G = dG; wall.ncnt = dncnt; wall.rho = rho;
   wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
@@ -614,7 +622,9 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   const int reg_max = (h->flags & TMPC_DEBUG_FLAG_NO_LIFT) ? 0 : REG_MAX;      // (debug: no diagonal lifts, frozen pivots while centering go straight to the back-off-and-step route)
   HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
-  hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
+  const size_t big_lds = (size_t)BIG_EIG_LDS * sizeof(double);
+  if (big) hipLaunchKernelGGL(kb_init_stage, dim3(BPall), dim3(256), big_lds, st, wall, dm);
+  else hipLaunchKernelGGL(k_init_stage, dim3(BPall), dim3(64), slots_bytes(2), st, wall, dm);
   {
     WS wi = wall; wi.alist = alist;      // k_init_prob fills the list (its own index is blockIdx: alist is only written)
     hipLaunchKernelGGL(k_init_prob, dim3(nb), dim3(64), 0, st, wi, dm);
@@ -636,7 +646,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
-    TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
+    if (big) hipLaunchKernelGGL(kb_stage_pre, dim3(BP), dim3(256), 0, st, w, dm);
+    else TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
     if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
     if (t3) hipLaunchKernelGGL(k_t3_pre, dim3(BP), dim3(64), t3_lds, st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
@@ -654,7 +665,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (h->flags & TMPC_DEBUG_FLAG_STOP_ASSEMBLED) {   // debug (tunempc_hip_debug.h; tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
-      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      if (big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, 1);
+      else TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
       if (t3) hipLaunchKernelGGL(k_t3_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
@@ -667,7 +679,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     // (round 3: also with the multipliers of G / C -- their right-hand side rows depend on the iterate only, like the others; not with Step 3)
     const bool fuse1 = !ddm && h->tune_fuse && !(dm.flags & DF_NO_DMA) && !t3 && !(dm.flags & 1) && nfac > 0 && dm.p > 1 && dm.nt <= TRR_NT && !cr_small_levels(dm, h->sched, nullptr);
     if (fuse1) {
-      TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
+      if (big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, 1);
+      else TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
       if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
@@ -679,7 +692,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);
-      if (!fused) TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
+      if (!fused && big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, pass);
+      else if (!fused) TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
       if (eq && !fused) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (!fused) hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
@@ -690,8 +704,13 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
       if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
-      TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
-      hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, h->tune_pretest ? o.chord_step : -1.0);
+      if (big) {
+        hipLaunchKernelGGL(kb_stage_dir, dim3(BP), dim3(256), 0, st, w, dm, pass);
+        hipLaunchKernelGGL(kb_eigmin, dim3(BP * 4), dim3(256), big_lds, st, w, dm, pass);
+      } else {
+        TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
+        hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, h->tune_pretest ? o.chord_step : -1.0);
+      }
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (pass == 1) {
@@ -725,7 +744,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   { const int rc_ = ipm_loop(o, false, cap); if (rc_ != TMPC_OK) return rc_; }
   // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
-  if (h->tight && !eq && !t3 && wall.Dl) {
+  if (h->tight && !eq && !t3 && !big && wall.Dl) {
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.chord_step = 0.0; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
     { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3((nb + 63) / 64), dim3(64), 0, st, wi, dm, ot); }
@@ -763,7 +782,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
   }
   ln->prof[7] += it;
-  hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
+  if (big) hipLaunchKernelGGL(kb_final_stage, dim3(BPall), dim3(256), big_lds, st, wall, dm);
+  else hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
   hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, wall, dm);
   HIPCHK(hipGetLastError());
   return TMPC_OK;
@@ -825,6 +845,11 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
     snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
   }
+  if (nx + mb > NMAX) {      // the generic per-stage kernels (tmpc_big.h): plain Step 1 model, blocks that the LDS images of k_schur and of the substitutions can hold
+    const Dims db = make_dims(1, p, nx, mb, 0, 0, 0);
+    if (ng || nc || step3) { snprintf(g_err, sizeof(g_err), "nx+mb=%d > %d: plain Step 1 model only (no G / C rows, no Step 3)", nx + mb, NMAX); return TMPC_E_UNSUPPORTED; }
+    if (schur_lds<0>(db) > 160 * 1024 || solve_lds(db) > 160 * 1024) { snprintf(g_err, sizeof(g_err), "nx=%d: Schur blocks of %d do not fit the LDS images of the assembly / substitution kernels (nx <= 43 at nx+mb > 32)", nx, db.dp); return TMPC_E_UNSUPPORTED; }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }
   if (chunk <= 0) {
@@ -868,7 +893,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   }
   int rc = cr_upload(h->sched, &h->d_sched);
   bool ok = (rc == TMPC_OK) && hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
-  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
+  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.big_scr = nullptr; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
   for (int l = 0; l < nl && ok; ++l) {
     Lane& ln = h->lane[l];
     carve(ln.ws, h->dm, (char*)h->slab + (size_t)l * lane_bytes, &ln);
@@ -893,6 +918,7 @@ int tmpc_destroy(tmpc_handle* h) {
     for (int i = 0; i < 8; ++i) if (ln.ev[i]) hipEventDestroy(ln.ev[i]);
     for (hipEvent_t e : ln.kev) hipEventDestroy(e);
     if (ln.st) hipStreamDestroy(ln.st);
+    if (ln.big_scr) hipFree(ln.big_scr);
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
@@ -906,7 +932,7 @@ int tmpc_get_chunk(tmpc_handle* h) { return h ? h->chunk : TMPC_E_ARG; }
 
 int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter, int center_iter, int flags) {
   if (!h) return TMPC_E_ARG;
-  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED | TMPC_DEBUG_FLAG_NO_LIFT | TMPC_DEBUG_FLAG_NO_DMA)) {
+  if (flags & ~(TMPC_FLAG_NO_MFMA | TMPC_FLAG_PROFILE | TMPC_FLAG_FAST_EXIT | TMPC_DEBUG_FLAG_STOP_ASSEMBLED | TMPC_DEBUG_FLAG_NO_LIFT | TMPC_DEBUG_FLAG_NO_DMA | TMPC_DEBUG_FLAG_GENERIC_STAGE)) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_options: unknown flag bits 0x%x (TMPC_FLAG_NO_MFMA = 1, TMPC_FLAG_PROFILE = 2, TMPC_FLAG_FAST_EXIT = 4)", flags);
     return TMPC_E_ARG;
   }
@@ -936,7 +962,7 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
   if (!h) return TMPC_E_ARG;
   if (!enable) { h->tight = 0; return TMPC_OK; }
-  if (h->dm.nr > 0 || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles only (no G / C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > 0 || h->dm.nT > 0 || h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles with nx + mb <= %d only (no G / C rows, no Step 3)", NMAX); return TMPC_E_UNSUPPORTED; }
   if (tight_tol > 0.0 && !(tight_tol >= 0x1p-42 && tight_tol < 1.0)) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: tolerance %g outside [2^-42, 1)", tight_tol); return TMPC_E_ARG; }
   ON_DEVICE(h);
   if (!h->dd_slab) {

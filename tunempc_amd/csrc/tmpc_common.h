@@ -169,6 +169,7 @@ struct WS {
   // tight mode (tmpc_dd.h): low words of the double-double planes (high words = D, O, F, Linv, KF, adjV, adjE, W3, Z); null without it
   double* Dl; double* Ol; double* Fl; double* Linvl; double* KFl; double* adjVl; double* adjEl; double* W3l; double* Zl;
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
+  double* bscr;    // [B,p,5,n,n] scratch of the generic per-stage kernels (tmpc_big.h: 32 < n <= 64); null otherwise
   int* plist;      // [B] problems handed to the polish (count in active[2])
 };
 
