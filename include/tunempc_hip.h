@@ -252,6 +252,14 @@ int tmpc_get_profile(tmpc_handle* h, double* out16);
  * optimality gap of kappa without trusting this solver (tests/test_gpu_parity.py::test_dual_certificate does it in numpy).
  * Any pointer may be NULL.  Early-exit members (already convex) hold no meaningful dual. */
 int tmpc_get_dual_host(tmpc_handle* h, int nb, double* X1, double* X2, double* scal);
+/* The dual side of the stage-local multipliers of the LAST wave solved by a handle with G / C rows (Step 1 with G, Step 2 model), scaled problem, for the
+ * same solver-independent certificate (tests/test_gpu_parity.py::test_dual_certificate_with_multipliers):
+ *   phi [nb][p][nr]  the multipliers s*[Fg_k; F_k] (nr = ng + nc of the handle; entries beyond a stage's row count are padding),
+ *   z   [nb][p][nr]  their duals (phi_i >= 0  <->  z_i >= 0),
+ *   aX  [nb][p][2][17][17], at [nb][p][2]   Step 2 with rho > 0 only (else pass NULL): the primal blocks X_e of the arrow LMIs of the (up to) two norm terms
+ *                    per stage (leading (m_e + 1) x (m_e + 1) part valid; term 0 = the rows of G if ng > 0, then the rows of C_k) and the epigraph variables t_e.
+ * X1, X2, x0, tau, alpha, mu_target come from tmpc_get_dual_host.  Any pointer may be NULL. */
+int tmpc_get_dual_con_host(tmpc_handle* h, int nb, double* phi, double* z, double* aX, double* at);
 
 /* Per-iteration diagnostics of the LAST chunk solved: out[nb][80][10] = (iteration, phase, mu, tau, pinf, dinf,
  * primal step, dual step, relative output change of the step, cumulative shifted pivots); nb <= chunk. */

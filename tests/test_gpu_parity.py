@@ -1093,3 +1093,79 @@ def test_dropin_convexify_large_block():
     assert rel(np.stack(dHc), r['dHc']) < 1e-7 and all(np.linalg.eigvalsh(H[0, k] + dHc[k]).min() > 0 for k in range(p))
     assert np.array_equal(dQc[1], dHc[1][:nx, :nx]) and np.array_equal(dNc[2], dHc[2][:nx, nx:])
     convexifier.release_handles()
+
+
+# ----------------------------------------------------------------------------- the dual certificate for the models with stage-local multipliers
+@pytest.mark.parametrize('model', ['G', 'step2'])
+def test_dual_certificate_with_multipliers(model):
+    """As test_dual_certificate, for Step 1 with G (cost-free multipliers phi >= 0, duals z) and for the Step 2 model (the norm terms rho ||F_k||, rho ||Fg_k|| as
+    epigraph variables t_e with arrow LMIs, primal blocks X_e): numpy only, no oracle.  The exported dual iterate (tmpc_get_dual_host + tmpc_get_dual_con_host) is
+    feasible up to tiny residuals and its objective is a lower bound of the optimal value (weak duality); the attained primal value kappa (+ sum t_e) is an upper
+    bound; they differ by the complementarity gap N mu_target."""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb, ng, nc, rho = 5, 5, 2, 2, 2, 3, 1e-2
+    n = nx + mb
+    A, B, H = co.gen_batch(8100, nb, p, nx, mb)
+    rng = np.random.default_rng(81)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    if model == 'G':
+        h = HipConvexifier(p, nx, mb, ng=ng, chunk=nb)
+        out = h.convexify_eq_batch(A, B, H, G)
+        J = G; rows = np.full((nb, p), ng)
+    else:
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb)
+        J = np.concatenate([G, Cc], axis=2); rows = ng + ncnt
+        out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    dual = h.dual(nb); dc = h.dual_con(nb, arrows=(model == 'step2'))
+    h.close()
+    for b in range(nb):
+        assert int(out['status'][b]) == 0
+        s = out['info'][b, 0]; sbeta = out['info'][b, 1]
+        alpha, kappa = out['alpha'][b], out['kappa'][b]
+        Hb = s * 0.5 * (H[b] + H[b].transpose(0, 2, 1))
+        V = np.concatenate([A[b], B[b]], axis=2)
+        Pbar = out['P'][b] * (s * alpha)
+        phi, z = dc['phi'][b], dc['z'][b]
+        M = alpha * Hb + V.transpose(0, 2, 1) @ np.roll(Pbar, -1, axis=0) @ V
+        M[:, :nx, :nx] -= Pbar
+        ncone = 2 * p * n + 1
+        for k in range(p):
+            for i in range(rows[b, k]):
+                M[k] += phi[k, i] * np.outer(J[b, k, i], J[b, k, i])
+                assert phi[k, i] > 0 and z[k, i] > 0
+                ncone += 1
+        ev = np.linalg.eigvalsh(M)
+        assert ev.min() >= 1.0 - 1e-9 and ev.max() <= kappa * (1 + 1e-9) and alpha > 1e-8                     # primal feasible
+        X1, X2, x0 = dual['X1'][b], dual['X2'][b], dual['x0'][b]
+        assert np.linalg.eigvalsh(X1).min() > 0 and np.linalg.eigvalsh(X2).min() > 0 and x0 > 0
+        Y = X1 - X2
+        r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
+        r_alpha = -np.sum(Hb * Y) - x0
+        W = V @ Y @ V.transpose(0, 2, 1)
+        r_P = -(np.roll(W, 1, axis=0) - Y[:, :nx, :nx])
+        primal = kappa
+        slack = 2.0 * (abs(r_tau) * kappa + abs(r_alpha) * alpha + np.sqrt(np.sum(r_P ** 2)) * np.sqrt(np.sum(Pbar ** 2)))
+        wr = rho * sbeta / s
+        for k in range(p):
+            r_phi = np.array([-J[b, k, i] @ Y[k] @ J[b, k, i] - z[k, i] for i in range(rows[b, k])])
+            if model == 'step2':
+                e = 0
+                for (a0, m) in ([(0, ng)] if ng else []) + ([(ng, int(ncnt[b, k]))] if ncnt[b, k] else []):
+                    Xe = dc['aX'][b, k, e][:m + 1, :m + 1]; te = dc['at'][b, k, e]
+                    assert np.linalg.eigvalsh(Xe).min() > 0
+                    assert te >= wr * np.linalg.norm(phi[k, a0:a0 + m]) * (1 - 1e-12)                        # the arrow LMI of the epigraph holds
+                    r_phi[a0:a0 + m] -= 2.0 * wr * Xe[0, 1:]
+                    slack += 2.0 * abs(1.0 - np.trace(Xe)) * te
+                    primal += te
+                    ncone += m + 1
+                    e += 1
+            slack += 2.0 * np.sum(np.abs(r_phi) * phi[k, :rows[b, k]])
+        dobj = np.trace(X1, axis1=1, axis2=2).sum() + 1e-8 * x0
+        gap = ncone * dual['mu_target'][b]
+        assert dobj - slack <= primal
+        assert primal - dobj <= 1.05 * gap + slack, (model, b, primal - dobj, gap, slack)
+        print(f'{model}: certified relative gap {(primal - (dobj - slack)) / primal:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e})')

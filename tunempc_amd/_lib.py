@@ -21,7 +21,7 @@ EXPORTS = [
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight', 'tmpc_set_tuning', 'tmpc_create_ex',
     'tmpc_convexify_batch_host', 'tmpc_convexify_batch_device', 'tmpc_convexify_eq_batch_host', 'tmpc_convexify_step2_batch_host',
     'tmpc_convexify_con_batch_device', 'tmpc_workspace_bytes_step3', 'tmpc_create_step3', 'tmpc_convexify_step3_batch_host', 'tmpc_workspace_bytes_step3_con', 'tmpc_create_step3_con', 'tmpc_convexify_step3_con_batch_host', 'tmpc_convexify_step3_batch_device', 'tmpc_convexify_step3_con_batch_device', 'tmpc_supplement_batch_host', 'tmpc_supplement_terms_batch_host',
-    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
+    'tmpc_tracking_reference_host', 'tmpc_eig_scan_host', 'tmpc_get_profile', 'tmpc_get_trace', 'tmpc_get_dual_host', 'tmpc_get_dual_con_host', 'tmpc_pack_sensitivities_host', 'tmpc_eig_clip_host',
     'tmpc_last_error', 'tmpc_version',
 ]
 # ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
@@ -87,6 +87,8 @@ def load_library():
     lib.tmpc_convexify_step3_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_double] + [vp] * 10 + [vp]
     lib.tmpc_convexify_step3_con_batch_device.restype = C.c_int
     lib.tmpc_convexify_step3_con_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_double] + [vp] * 11 + [vp]
+    lib.tmpc_get_dual_con_host.restype = C.c_int
+    lib.tmpc_get_dual_con_host.argtypes = [vp, C.c_int, dp, dp, dp, dp]
     lib.tmpc_create.restype = C.c_int
     lib.tmpc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tmpc_destroy.restype = C.c_int
@@ -474,6 +476,17 @@ class HipConvexifier:
         X1 = np.empty((nb, self.p, self.n, self.n)); X2 = np.empty_like(X1); sc = np.empty((nb, 4))
         _check(self.lib, self.lib.tmpc_get_dual_host(self._h, int(nb), _dptr(X1), _dptr(X2), _dptr(sc)), 'tmpc_get_dual_host')
         return dict(X1=X1, X2=X2, x0=sc[:, 0].copy(), tau=sc[:, 1].copy(), alpha=sc[:, 2].copy(), mu_target=sc[:, 3].copy())
+
+    def dual_con(self, nb, arrows=False):
+        """Dual side of the stage-local multipliers of the last wave (tmpc_get_dual_con_host): dict(phi, z [nb,p,ng+nc][, aX [nb,p,2,17,17], at [nb,p,2]])."""
+        nr = self.ng + self.nc
+        phi = np.zeros((nb, self.p, nr)); z = np.zeros_like(phi)
+        aX = np.zeros((nb, self.p, 2, 17, 17)) if arrows else None; at = np.zeros((nb, self.p, 2)) if arrows else None
+        _check(self.lib, self.lib.tmpc_get_dual_con_host(self._h, int(nb), _dptr(phi), _dptr(z), _dptr(aX) if arrows else None, _dptr(at) if arrows else None), 'tmpc_get_dual_con_host')
+        out = dict(phi=phi, z=z)
+        if arrows:
+            out.update(aX=aX, at=at)
+        return out
 
     def trace(self, nb):
         """[nb, 80, 10] per-iteration diagnostics of the last chunk (it, phase, mu, tau, pinf, dinf, ap, ad, step, shifts)."""

@@ -1030,6 +1030,20 @@ int tmpc_get_dual_host(tmpc_handle* h, int nb, double* X1, double* X2, double* s
   });
 }
 
+// dual side of the stage-local multipliers of the LAST wave solved (Step 1 with G, Step 2): see tunempc_hip.h
+int tmpc_get_dual_con_host(tmpc_handle* h, int nb, double* phi, double* z, double* aX, double* at) {
+  if (!h || nb < 1 || nb > h->chunk || h->dm.nr < 1 || !h->lane[0].ws.phi) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  const size_t row = (size_t)h->dm.p * h->dm.nr, arow = (size_t)h->dm.p * 2 * AE, trow = (size_t)h->dm.p * 2;
+  return for_last_wave(h, nb, [&](Lane& ln, int o, int m) {
+    if (phi) HIPCHK(hipMemcpy(phi + o * row, ln.ws.phi, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    if (z) HIPCHK(hipMemcpy(z + o * row, ln.ws.zph, (size_t)m * row * sizeof(double), hipMemcpyDeviceToHost));
+    if (aX) { if (!ln.ws.aX) return (int)TMPC_E_ARG; HIPCHK(hipMemcpy(aX + o * arow, ln.ws.aX, (size_t)m * arow * sizeof(double), hipMemcpyDeviceToHost)); }
+    if (at) { if (!ln.ws.at) return (int)TMPC_E_ARG; HIPCHK(hipMemcpy(at + o * trow, ln.ws.at, (size_t)m * trow * sizeof(double), hipMemcpyDeviceToHost)); }
+    return (int)TMPC_OK;
+  });
+}
+
 int tmpc_debug_get_multipliers(tmpc_handle* h, int nb, int nr, double* phi, double* z, double* dphi, double* dz) {
   if (!h || nb < 1 || nb > h->chunk || nr < 1 || nr > h->dm.nr || !h->lane[0].ws.phi) return TMPC_E_ARG;
   ON_DEVICE(h);
