@@ -55,15 +55,52 @@ def all_gather_results(local, nb_total, group=None, cache=None):
     return out
 
 
-def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status'), extra=None):
+def balanced_assignment(cost, world):
+    """Straggler-aware split ("dynamic chunking of the local batch to even out iteration counts"): problems sorted by a cost proxy,
+    most expensive first, and dealt to the ranks in snake order (0, 1, .., w-1, w-1, .., 1, 0, ...) -- the expensive members are spread over the ranks
+    instead of sitting in one contiguous shard, and every rank gets nb // world or nb // world + 1 problems.  Returns a list of index arrays (ascending
+    within a rank).  The iteration count of a member grows with the conditioning of its Hessians: `sbeta = max|eig H| / min|eig H|` (convexifier.py:383-399,
+    one batched eigen-scan, tmpc_eig_scan_host) is the proxy bench-style callers have for free."""
+    cost = np.asarray(cost, dtype=np.float64)
+    order = np.argsort(-cost, kind='stable')
+    ranks = [[] for _ in range(world)]
+    for pos, idx in enumerate(order):
+        rnd, off = divmod(pos, world)
+        ranks[off if rnd % 2 == 0 else world - 1 - off].append(int(idx))
+    return [np.sort(np.asarray(r, dtype=np.int64)) for r in ranks]
+
+
+def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status'), extra=None, cost=None):
     """A, B, H: full-batch torch tensors (every rank holds or can generate the full batch; only its slice is
     read).  solve_fn(A_loc, B_loc, H_loc, **extra_loc) -> dict of torch tensors (local batch leading).  `extra`: dict of
     further per-problem inputs sliced the same way -- the equality-/active-constraint Jacobians and row counts of
     Step 1 with G and of Step 2 (G [nb,p,ng,n], C [nb,p,nc,n], ncnt [nb,p]).  Returns the gathered dict (full batch on
-    every rank); add 'Fg' / 'F' to `keys` to gather the multipliers as well."""
+    every rank); add 'Fg' / 'F' to `keys` to gather the multipliers as well.
+    cost [nb] (optional): a per-problem cost proxy -- the shards are then dealt by `balanced_assignment` instead of cut contiguously, and the gathered
+    tensors are put back into the caller's order."""
+    import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nb = A.shape[0]
+    if cost is not None:
+        parts = balanced_assignment(cost, world)
+        mine = torch.as_tensor(parts[rank], device=A.device)
+        sel = lambda t: t.index_select(0, mine.to(t.device))
+        loc = solve_fn(sel(A), sel(B), sel(H), **{k: sel(v) for k, v in (extra or {}).items()})
+        sizes = [len(q) for q in parts]
+        mx = max(sizes)
+        out = {}
+        for key in keys:
+            t = loc[key]
+            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:t.shape[0]] = t
+            full = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(full, pad.contiguous(), group=group)
+            res = torch.empty((nb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            for r in range(world):
+                res[torch.as_tensor(parts[r], device=t.device)] = full[r * mx: r * mx + sizes[r]]
+            out[key] = res
+        return out
     lo, hi = shard_range(nb, rank, world)
     loc = solve_fn(A[lo:hi], B[lo:hi], H[lo:hi], **{k: v[lo:hi] for k, v in (extra or {}).items()})
     return all_gather_results({k: loc[k] for k in keys}, nb, group)
