@@ -124,7 +124,9 @@ int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, 
  * [2^-42, 1), every member of the test families converges down to 2^-37, most down to 2^-41) with the Kronecker-factor images, the
  * assembly, the block Cholesky and the substitutions in double-double arithmetic, and finished by Newton steps on the dual barrier
  * problem in which every stage quantity is double-double (the returned point is then reproducible to ~1e-12 instead of ~eps/mu).
- * Outputs as before; info[6] = the mu_target reached, iters includes the extra iterations.  Costs one more workspace of about the size of
+ * Outputs as before; info[6] = the mu_target reached, iters includes the extra iterations.  A member whose continuation fails (a non-positive
+ * double-double pivot, a polish step that leaves the cone, the iteration cap: most visibly hard targets below 2^-33) gets the result of its default
+ * solve back, status Optimal, info[6] = the default's mu_target: the mode never returns less than the default does.  Costs one more workspace of about the size of
  * the block storage (allocated at the first enable) and ~10 double-double factorisations per problem (vector ALU, no matrix cores).
  * enable == 0 switches back to the default (the workspace stays).  TMPC_E_UNSUPPORTED for handles with G / C rows or Step 3. */
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol);

@@ -187,3 +187,35 @@ def test_hard_targets_value_compared_through_the_tight_mode(p, nx, mb, sigP, rad
         errs.append(rel(out['Hc'][b], ref['Hc'][b]))
         assert errs[-1] < 1e-9, (b, errs[-1])
     print(f'hard targets (cond 1e5) through the tight mode, p={p} n={nx + mb}: all {len(errs)} members value-compared, worst {max(errs):.2e}')
+
+
+def test_tight_mode_never_returns_less_than_the_default():
+    """cond(Hhat) = 1e5 at the default tight target 2^-37: a third of such members exhaust what the fp64 stage arithmetic can resolve (the CPU restatement reports
+    them Feasible).  The library hands those the result of their default solve back (status Optimal, info[6] = the default's mu_target, bit-identical Hc), the
+    others arrive at 2^-37 and agree with the CPU restatement."""
+    from tunempc_amd import synthetic
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb = 30, 4, 1, 8
+    probs = [synthetic.gen_problem(7000 + 17 * b, p, nx, mb, sigP=10.0, cond_exp=5, rad=0.5) for b in range(nb)]
+    A, B, H = (np.stack([q[i] for q in probs]) for i in range(3))
+    h = HipConvexifier(p, nx, mb, chunk=nb)
+    try:
+        dflt = h.convexify_batch(A, B, H)
+        h.set_tight(True)
+        out = h.convexify_batch(A, B, H)
+    finally:
+        h.close()
+    ref = cpu_ipm.convexify_batch(A, B, H, tol=TIGHT_TOL, threads=HOST_THREADS, tight=True)
+    assert (dflt['status'] == 0).all() and (out['status'] == 0).all()
+    arrived = fell = 0
+    for b in range(nb):
+        want = 2.0 ** np.round(np.log2(TIGHT_TOL * max(1.0, out['kappa'][b])))
+        if out['info'][b, 6] == want:
+            arrived += 1
+            if ref['status'][b] == 0:
+                assert rel(out['Hc'][b], ref['Hc'][b]) < 1e-7, b
+        else:
+            fell += 1
+            assert out['info'][b, 6] == dflt['info'][b, 6] and np.array_equal(out['Hc'][b], dflt['Hc'][b]) and out['kappa'][b] == dflt['kappa'][b], b
+    print(f'hard targets at 2^-37: {arrived} arrived, {fell} fell back to the default result (CPU restatement: {int((ref["status"] != 0).sum())} Feasible)')
+    assert arrived >= 1

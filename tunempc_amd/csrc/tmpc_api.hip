@@ -156,7 +156,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
-  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = nullptr; w.plist = nullptr;
+  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
@@ -204,7 +204,7 @@ static size_t carve_dd(WS& w, const Dims& dm, char* base) {
   w.Linvl = c.take<double>(BP * dm.nt * TB * TB);
   w.KFl = c.take<double>(BP * 12 * nxx); w.adjVl = c.take<double>(BP * NADJ * nxx); w.adjEl = c.take<double>(BP * NADJ * nxx);
   w.W3l = c.take<double>(BP * dm.dp * 3); w.Zl = c.take<double>(BP * dm.dp);
-  w.Pprev = c.take<double>(BP * nxx);
+  w.Pprev = c.take<double>(BP * nxx); w.Pdef = c.take<double>(BP * nxx);
   w.plist = c.take<int>((size_t)dm.B);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -747,7 +747,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   if (h->tight && !eq && !t3 && !big && wall.Dl) {
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.chord_step = 0.0; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
-    { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3((nb + 63) / 64), dim3(64), 0, st, wi, dm, ot); }
+    { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3(nb), dim3(64), 0, st, wi, dm, ot); }
     HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     active = cnt[0]; nfac = cnt[0];
@@ -780,6 +780,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       hipLaunchKernelGGL(k_dd_polish_pre, dim3(npol * dm.p), dim3(256), slots_bytes(DD_POL_SLOTS), st, wp, dm, 1);
       hipLaunchKernelGGL(k_polish_final, dim3(npol), dim3(64), 0, st, wp, dm);
     }
+    hipLaunchKernelGGL(k_tight_fallback, dim3(nb), dim3(64), 0, st, wall, dm);      // members whose tight phase failed: back to the result of the default solve
   }
   ln->prof[7] += it;
   if (big) hipLaunchKernelGGL(kb_final_stage, dim3(BPall), dim3(256), big_lds, st, wall, dm);

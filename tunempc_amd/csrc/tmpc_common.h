@@ -36,7 +36,7 @@ enum {
   P_TAU = 0, P_ALPHA, P_S0, P_X0, P_MU, P_MUT, P_SIGMU, P_AP, P_AD, P_S, P_SBETA, P_PINF, P_DINF, P_RELGAP,
   P_STEPN, P_PREVSTEPN, P_DTAU, P_DALPHA, P_DS0, P_DX0, P_RD0, P_CORR0, P_MINEIG_H, P_BTT, P_BTA, P_BAA,
   P_SB00, P_SB01, P_SB11, P_RHS_TAU, P_RHS_ALPHA, P_SXS, P_MINEIG_HC, P_MAXCOND, P_KAPPA, P_BETA, P_ALPHA_OUT,
-  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, P_TAU_PREV, P_ALPHA_PREV, P_MUT1, PS = 48
+  P_MAXEIG_HC, P_MU0, P_MINPIV, P_RAWSTEP, P_TAU_PREV, P_ALPHA_PREV, P_MUT1, P_TAU_DEF, P_ALPHA_DEF, PS = 48
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
 enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF,
@@ -169,6 +169,7 @@ struct WS {
   // tight mode (tmpc_dd.h): low words of the double-double planes (high words = D, O, F, Linv, KF, adjV, adjE, W3, Z); null without it
   double* Dl; double* Ol; double* Fl; double* Linvl; double* KFl; double* adjVl; double* adjEl; double* W3l; double* Zl;
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
+  double* Pdef;    // [B,p,nx,nx] result of the default solve (restored when the tight phase of a member fails)
   double* bscr;    // [B,p,5,n,n] scratch of the generic per-stage kernels (tmpc_big.h: 32 < n <= 64); null otherwise
   int* plist;      // [B] problems handed to the polish (count in active[2])
 };

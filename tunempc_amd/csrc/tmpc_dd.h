@@ -770,19 +770,37 @@ __global__ void __launch_bounds__(64) k_dd_gather(WS w, Dims dm) {
 }
 
 // ------------------------------------------------------------------ control of the tight phase
-// restart of the problems that ended Optimal: the same loop towards mu_t = tight_tol * kappa, block linear algebra in dd
+// restart of the problems that ended Optimal: the same loop towards mu_t = tight_tol * kappa, block linear algebra in dd.  One workgroup per problem;
+// the result of the default solve is kept (Pdef, P_TAU_DEF, P_ALPHA_DEF, P_MUT1) for k_tight_fallback.
 __global__ void __launch_bounds__(64) k_tight_restart(WS w, Dims dm, Opts o) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= dm.B) return;
+  const int b = blockIdx.x, lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
   double* pr = w.prob + (size_t)b * PS;
   if (ip[I_PHASE] != PH_DONE || ip[I_EARLY] || ip[I_IPMSTATUS] != IPM_OPTIMAL) return;
   const double mut = exp2(rint(log2(o.tight_tol * fmax(1.0, fabs(pr[P_TAU])))));
   if (!(mut < pr[P_MUT])) return;                 // nothing tighter asked for
+  const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
+  for (size_t e = lane; e < np_; e += 64) w.Pdef[(size_t)b * np_ + e] = w.P[(size_t)b * np_ + e];
+  if (lane != 0) return;
+  pr[P_TAU_DEF] = pr[P_TAU]; pr[P_ALPHA_DEF] = pr[P_ALPHA];
   pr[P_MUT1] = pr[P_MUT]; pr[P_MUT] = mut; pr[P_PREVSTEPN] = -1.0;
   ip[I_PHASE] = PH_MAIN; ip[I_IPMSTATUS] = IPM_MAXITER; ip[I_NCENT] = 0; ip[I_CHORD] = 0; ip[I_REG] = 0; ip[I_JAM] = 0; ip[I_SHIFTRUN] = 0; ip[I_BOSTEP] = 0;
   ip[I_DD] = 1;
   const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; w.flist[slot] = b;
+}
+// A member whose tight phase did not end Optimal (a non-positive dd pivot, a polish that left the cone, the iteration cap: fp64 stage arithmetic has its own
+// limits, most visibly on hard targets below 2^-33) gets the result of its default solve back: the mode never returns less than the default does.
+// info[6] (mu_target) then shows the default's target; I_DD = 2 marks the member.
+__global__ void __launch_bounds__(64) k_tight_fallback(WS w, Dims dm) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* ip = w.iprob + (size_t)b * IS;
+  double* pr = w.prob + (size_t)b * PS;
+  if (ip[I_DD] != 1 || (ip[I_PHASE] == PH_DONE && ip[I_IPMSTATUS] == IPM_OPTIMAL)) return;
+  const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
+  for (size_t e = lane; e < np_; e += 64) w.P[(size_t)b * np_ + e] = w.Pdef[(size_t)b * np_ + e];
+  if (lane != 0) return;
+  pr[P_TAU] = pr[P_TAU_DEF]; pr[P_ALPHA] = pr[P_ALPHA_DEF]; pr[P_MUT] = pr[P_MUT1]; pr[P_MU] = pr[P_MUT1];
+  ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; ip[I_DD] = 2;
 }
 
 // polish, after k_dd_polish_pre: scalars of the border system and of the gradient (the slots k_solve_border reads), cone check
