@@ -219,3 +219,21 @@ def test_tight_mode_never_returns_less_than_the_default():
             assert out['info'][b, 6] == dflt['info'][b, 6] and np.array_equal(out['Hc'][b], dflt['Hc'][b]) and out['kappa'][b] == dflt['kappa'][b], b
     print(f'hard targets at 2^-37: {arrived} arrived, {fell} fell back to the default result (CPU restatement: {int((ref["status"] != 0).sum())} Feasible)')
     assert arrived >= 1
+
+
+def test_dropin_convexify_tight_option():
+    """convexifier.convexify(..., opts={'tight': True}): the reference's call with one more key; the cached handle does not keep the mode"""
+    from tunempc_amd import convexifier
+    p, nx, mb = 6, 4, 2
+    A, B, H, _, _ = co.gen_problem(3, p, nx, mb)
+    Q = [H[k][:nx, :nx] for k in range(p)]; R = [H[k][nx:, nx:] for k in range(p)]; N = [H[k][:nx, nx:] for k in range(p)]
+    args = ([A[k] for k in range(p)], [B[k] for k in range(p)], Q, R, N)
+    d0 = convexifier.convexify(*args)[0]
+    dt = convexifier.convexify(*args, opts={'rho': 1e-3, 'solver': 'hip', 'force': False, 'tight': True})[0]
+    d1 = convexifier.convexify(*args)[0]
+    r = co.sdp_step1(A, B, H, dict(tol=TIGHT_TOL, tight=True))
+    ref = co.symmetrize(co.calH(A, B, r['P']))
+    assert rel(np.stack(dt), ref) < 1e-7 and all(np.array_equal(a, b) for a, b in zip(d0, d1)) and rel(np.stack(d0), ref) > 1e-5
+    with pytest.raises(NotImplementedError):
+        convexifier.convexify(*args, G=[np.ones((1, nx + mb))] * p, opts={'tight': True})
+    convexifier.release_handles()

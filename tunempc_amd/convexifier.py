@@ -77,12 +77,14 @@ def _to_array(m):
     return np.atleast_2d(np.asarray(m, dtype=np.float64))
 
 
-def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0):
+def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=None):
     """Batched Step 1.  A [nb,p,nx,nx], B [nb,p,nx,mb], H [nb,p,n,n] -> dict with
     Hc, dHc [nb,p,n,n], P [nb,p,nx,nx], alpha, beta, kappa [nb], status [nb] (0 Optimal, 1 Feasible,
     2 Infeasible; convexifier.py:442-451), iters [nb], info [nb,16].
     G [nb,p,ng,n] (optional): equality-constraint Jacobians; their multipliers Fg [nb,p,ng] (convexifier.py:249-255)
-    join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197)."""
+    join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197).
+    tight: None / False: the default accuracy (mu_target = 2^-25 kappa); True or a tolerance: the tight-accuracy mode of the library (tmpc_set_tight:
+    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model, nx + nu <= 32)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
     mb = B.shape[3]
@@ -98,8 +100,20 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0):
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)      # per call: a cached handle never keeps an earlier caller's tolerance
     if ng > 0:
+        if tight:
+            raise NotImplementedError('the tight-accuracy mode covers the plain Step 1 model (no G / C rows)')
         return h.convexify_eq_batch(A, B, H, G)
-    return h.convexify_batch(A, B, H)
+    if tight and (h.ng or h.nc or h.step3):       # (a cached handle with room for constraint rows cannot run the mode: a plain one of its own)
+        h = _handle(p, nx, mb, 0, 0, nb)
+        h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
+        _LAST_HANDLE = h
+    if tight:
+        h.set_tight(True, None if tight is True else float(tight))
+    try:
+        return h.convexify_batch(A, B, H)
+    finally:
+        if tight:
+            h.set_tight(False)                    # a cached handle never keeps an earlier caller's mode
 
 
 def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
@@ -252,7 +266,9 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     :param Q: weighting matrix Q (nx,nx)   :param R: (nu,nu)   :param N: (nx,nu)
     :param C: jacobian of active constraints at steady state (nc, nx+nu)
     :param G: jacobian of equality constraints at steady state (ng, nx+nu)
-    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); one more key,
+    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); 'tight': True or a tolerance -- Step 1 in the
+                 tight-accuracy mode of the library (relative gap on kappa N * 7e-12 instead of N * 3e-8, the accuracy MOSEK / CVXOPT stop at; plain
+                 model only: with G or C it raises NotImplementedError); one more key,
                  'objective': 'paper' (default) | 'beta'.  The reference assembles the Step 2/3 objective with
                  `picos.sum(obj, abs(rho*F[i]))` (convexifier.py:276-285).  In PICOS 1.2.0 the second positional parameter of
                  picos.sum may be an iterator label rather than a summand (unverifiable here, PICOS is not
@@ -315,7 +331,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     Logger.logger.info(50 * '*')
     Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
     Logger.logger.info('solving SDP...')
-    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None], nc_hint=nc if nc <= NC_MAX else 0)
+    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None], nc_hint=nc if nc <= NC_MAX else 0, tight=(opts or {}).get('tight'))
 
     if res['info'][0, 13] != 0.0:      # (the library's own pre-check; same answer as the scan above)
         Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')
