@@ -1169,3 +1169,28 @@ def test_dual_certificate_with_multipliers(model):
         assert dobj - slack <= primal
         assert primal - dobj <= 1.05 * gap + slack, (model, b, primal - dobj, gap, slack)
         print(f'{model}: certified relative gap {(primal - (dobj - slack)) / primal:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e})')
+
+
+def test_large_block_side_entries():
+    """the other entry points of the boundary at 32 < n <= 64 (generic kernels): eigen-scan, supplement of P, tracking reference -- against numpy"""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb = 3, 28, 10, 2
+    n = nx + mb
+    A, B, H = co.gen_batch(208, nb, p, nx, mb)
+    h = HipConvexifier(p, nx, mb, chunk=nb)
+    sc = h.eig_scan(H)
+    ev = np.linalg.eigvalsh(H)
+    assert np.abs(sc[..., 0] - ev[..., 0]).max() < 1e-11 * np.abs(ev).max() and np.abs(sc[..., 1] - ev[..., -1]).max() < 1e-11 * np.abs(ev).max()
+    assert np.abs(sc[..., 2] - np.abs(ev).min(-1)).max() < 1e-11 * np.abs(ev).max() and np.abs(sc[..., 3] - np.abs(ev).max(-1)).max() < 1e-11 * np.abs(ev).max()
+    rng = np.random.default_rng(2)
+    P = rng.standard_normal((nb, p, nx, nx)); P = P + P.transpose(0, 1, 3, 2)
+    dH = h.supplement_batch(A, B, P)
+    for b in range(nb):
+        assert rel(dH[b], co.convex_hessian_suppl(A[b], B[b], P[b])[0]) < 1e-13
+    out = h.convexify_batch(A, B, H)
+    q = rng.standard_normal((nb * p, n)); wref = rng.standard_normal((nb * p, n))
+    W, yref = h.tracking_reference(out['Hc'].reshape(nb * p, n, n), q, wref, 0.1)[:2]
+    Hs = out['Hc'].reshape(nb * p, n, n)
+    assert rel(W, Hs / 0.1) < 1e-14
+    assert rel(yref, wref - np.linalg.solve(Hs, q[..., None])[..., 0]) < 1e-10
+    h.close()

@@ -1322,6 +1322,10 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, 
       HIPCHK(hipMemcpyAsync(dw, wts + so * nr, BP * nr * 8, hipMemcpyHostToDevice, st));
     }
     if (T) HIPCHK(hipMemcpyAsync(h->dH, T + so * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
+    if (dm.n > NMAX) {      // generic form (tmpc_big.h): the supplement of P alone
+      if (J || T) { snprintf(g_err, sizeof(g_err), "tmpc_supplement_terms_batch_host: the J / T terms are handled up to nx + mb = %d", NMAX); return TMPC_E_UNSUPPORTED; }
+      hipLaunchKernelGGL(kb_supplement, dim3((unsigned)BP), dim3(256), 0, st, (const double*)h->dA, (const double*)h->dB, (const double*)h->ws.P, h->ws.dHc, d2, h->ws.bscr);
+    } else
     hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2, nr, dJ, dw,
                        T ? h->dH : nullptr);
     HIPCHK(hipMemcpyAsync(dHc + so * nn, h->ws.dHc, BP * nn * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1371,7 +1375,8 @@ int tmpc_eig_scan_host(tmpc_handle* hh, int nbt, const double* H, double* out) {
     const int nb = std::min(dm.B, nbt - off);
     const size_t BP = (size_t)nb * dm.p;
     HIPCHK(hipMemcpyAsync(h->dH, H + (size_t)off * dm.p * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_eig_scan, dim3((unsigned)BP), dim3(64), slots_bytes(2), st, h->dH, h->ws.part, dm.n);
+    if (dm.n > NMAX) hipLaunchKernelGGL(kb_eig_scan, dim3((unsigned)BP), dim3(256), (size_t)BIG_EIG_LDS * sizeof(double), st, (const double*)h->dH, h->ws.part, dm.n);
+    else hipLaunchKernelGGL(k_eig_scan, dim3((unsigned)BP), dim3(64), slots_bytes(2), st, h->dH, h->ws.part, dm.n);
     HIPCHK(hipMemcpyAsync(out + (size_t)off * dm.p * 4, h->ws.part, BP * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -1455,6 +1460,12 @@ int tmpc_tracking_reference_host(tmpc_handle* h, int nstage, const double* Hc, c
   HIPCHK(hipMemcpy(dH, Hc, (size_t)nstage * nn * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dv, q, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dv + (size_t)nstage * n, wref, (size_t)nstage * n * 8, hipMemcpyHostToDevice));
+  DevBuf bscr;
+  if (n > NMAX) {
+    HIPCHK(bscr.alloc((size_t)nstage * nn * 8));
+    hipLaunchKernelGGL(kb_tracking_ref, dim3((unsigned)nstage), dim3(256), 0, 0, (const double*)dH, (const double*)dv, (const double*)(dv + (size_t)nstage * n), 1.0 / ts, dW,
+                       dv + (size_t)2 * nstage * n, di, n, bscr.as<double>());
+  } else
   hipLaunchKernelGGL(k_tracking_ref, dim3((unsigned)nstage), dim3(64), (size_t)(MS + 64) * sizeof(double), 0, dH, dv, dv + (size_t)nstage * n,
                      1.0 / ts, dW, dv + (size_t)2 * nstage * n, di, n);
   HIPCHK(hipDeviceSynchronize());

@@ -84,7 +84,7 @@ __device__ __forceinline__ void gbuild_M(double* M, double* tq, const double* V,
   gmm(M, n, tq, nx, 1, V, n, 1, n, n, nx, 0);                   // (V' Pn) V
   for (int e = threadIdx.x; e < n * n; e += 256) {
     const int i = e / n, j = e - i * n;
-    double v = M[e] + coef * Hb[e];
+    double v = M[e] + (coef != 0.0 ? coef * Hb[e] : 0.0);
     if (i < nx && j < nx) v -= Pk[i * nx + j];
     M[e] = v;
   }
@@ -413,6 +413,54 @@ __global__ void __launch_bounds__(256) kb_final_stage(WS w, Dims dm) {
   double lo, hi, amin, amax;
   big_eig_extremes(w.Hc + so, n, lds, &lo, &hi, &amin, &amax);
   if (tid == 0) { double* q = w.part + (size_t)sid * NPART; q[Q_MINEIG] = lo; q[Q_MAXEIG] = hi; }
+}
+
+// ------------------------------------------------------------------ the other entry points of the boundary at 32 < n <= 64
+// eigen-scan of arbitrary stage blocks (tmpc_eig_scan_host; k_eig_scan)
+__global__ void __launch_bounds__(256) kb_eig_scan(const double* H, double* out, int n) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double lo, hi, amin, amax;
+  big_eig_extremes(H + (size_t)blockIdx.x * n * n, n, lds, &lo, &hi, &amin, &amax);
+  if (threadIdx.x == 0) { double* o = out + (size_t)blockIdx.x * 4; o[0] = lo; o[1] = hi; o[2] = amin; o[3] = amax; }
+}
+// dHc = sym(V' P+ V - E' P E) for arbitrary P (tmpc_supplement_batch_host; k_supplement without the J / T terms); scr: 3 n x n doubles per stage
+__global__ void __launch_bounds__(256) kb_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm, double* scr_all) {
+  const int sid = blockIdx.x, tid = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int n = dm.n, nx = dm.nx, mb = dm.mb, nn = n * n, nxx = nx * nx;
+  double* sV = scr_all + (size_t)sid * 3 * nn; double* sM = sV + nn; double* t0 = sM + nn;
+  for (int e = tid; e < nx * n; e += 256) { const int i = e / n, j = e - i * n; sV[e] = (j < nx) ? A[(size_t)sid * nxx + i * nx + j] : Bm[(size_t)sid * nx * mb + i * mb + (j - nx)]; }
+  gsync();
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  gbuild_M(sM, t0, sV, sM, P + (size_t)sid * nxx, P + (size_t)(b * dm.p + kn) * nxx, 0.0, n, nx);
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; dHc[(size_t)sid * nn + e] = 0.5 * (sM[i * n + j] + sM[j * n + i]); }
+}
+// W = sym(Hc) / ts, yref = wref - Hc^-1 q by Cholesky and two substitutions (tmpc_tracking_reference_host; k_tracking_ref); scr: n x n doubles per stage
+__global__ void __launch_bounds__(256) kb_tracking_ref(const double* Hc, const double* q, const double* wref, double inv_ts, double* W, double* yref, int* info, int n, double* scr_all) {
+  __shared__ double sflag[2];
+  __shared__ double v[NB];
+  const size_t sid = blockIdx.x;
+  const int tid = threadIdx.x, nn = n * n;
+  double* Aw = scr_all + sid * nn;
+  const double* Hg = Hc + sid * nn;
+  for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const double a = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); Aw[e] = a; if (W) W[sid * nn + e] = a * inv_ts; }
+  if (tid < n) v[tid] = q[sid * n + tid];
+  gsync();
+  const int nbad = gchol(Aw, n, sflag);
+  for (int j = 0; j < n; ++j) {             // L z = q
+    if (tid == j) v[j] /= Aw[j * n + j];
+    __syncthreads();
+    if (tid > j && tid < n) v[tid] -= Aw[tid * n + j] * v[j];
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {        // L' x = z
+    if (tid == j) v[j] /= Aw[j * n + j];
+    __syncthreads();
+    if (tid < j) v[tid] -= Aw[j * n + tid] * v[j];
+    __syncthreads();
+  }
+  if (tid < n) yref[sid * n + tid] = wref[sid * n + tid] - v[tid];
+  if (info && tid == 0) info[sid] = nbad;
 }
 
 }  // namespace tmpc
