@@ -1045,7 +1045,7 @@ def test_kernel_variants_behind_handle_options(golden_dir, variant):
 
 
 # ----------------------------------------------------------------------------- stage blocks wider than 32
-@pytest.mark.parametrize('seed,nb,p,nx,mb', [(201, 2, 4, 30, 10), (202, 2, 6, 36, 12), (203, 1, 3, 40, 24), (204, 2, 8, 33, 1), (205, 2, 1, 34, 4), (206, 2, 2, 35, 3)])
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(201, 2, 4, 30, 10), (202, 2, 6, 36, 12), (203, 1, 3, 40, 24), (204, 2, 8, 33, 1), (205, 2, 1, 34, 4), (206, 2, 2, 35, 3), (209, 1, 3, 48, 8)])
 def test_large_stage_blocks_parity(seed, nb, p, nx, mb):
     """32 < n = nx + m <= 64 (the reference accepts any size: preprocessing.py:157-185): the generic per-stage kernels of csrc/tmpc_big.h with the
     register-staged block factorisation (blocks up to 820 wide here) against the C++ CPU port, plain Step 1 model, to the 1e-8 bar; the structural

@@ -27,7 +27,7 @@ DEFAULT_TOL = 2.0 ** -25
 
 
 NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
-N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (plain model; nx <= 43 there)
+N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (plain model; nx <= 55 there)
 NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 

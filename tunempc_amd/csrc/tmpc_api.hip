@@ -119,6 +119,8 @@ static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0, 
   return d;
 }
 
+// do the interleaved factor records of k_schur (10 nx^2 doubles) fit the LDS?  (nx <= 43; otherwise they live in a per-stage global scratch)
+static bool schur_in_lds(const Dims& dm) { return (size_t)sch_rec<0>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64 <= 158 * 1024; }
 struct Carver {
   char* base; size_t off;
   template <typename T> T* take(size_t count) {
@@ -156,6 +158,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.trace = c.take<double>((size_t)dm.B * TRACE_LEN * TRACE_W);
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
+  w.sscr = schur_in_lds(dm) ? nullptr : c.take<double>(BP * 10 * nxx);
   w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
@@ -384,7 +387,9 @@ __global__ void __launch_bounds__(256, 4) k_debug_gemm_dma(double* C, const doub
 }
 // ---------------------------------------------------------------------------------- launch configuration
 static size_t slots_bytes(int s) { return (size_t)s * MS * sizeof(double); }
-template <int PART> static size_t schur_lds(const Dims& dm) { return (size_t)sch_rec<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
+template <int PART> static size_t schur_lds(const Dims& dm) {
+  if (!schur_in_lds(dm)) return (size_t)dm.d * sizeof(unsigned) + 64;      // factor records in global scratch (k_schur<PART, true>)
+ return (size_t)sch_rec<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
 static size_t factor_lds() { return (size_t)FACT_LDS_DOUBLES * sizeof(double); }
 static size_t solve_lds(const Dims& dm) { return (size_t)cr_solve_lds_doubles(dm.dp) * sizeof(double); }
 
@@ -658,8 +663,13 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       hipLaunchKernelGGL(k_dd_schur<0>, dim3(BP), dim3(256), ddschur_lds<0>(dm), st, w, dm);
       hipLaunchKernelGGL(k_dd_schur<1>, dim3(BP), dim3(256), ddschur_lds<1>(dm), st, w, dm);
     } else if (nfac > 0) {
-      hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
-      hipLaunchKernelGGL(k_schur<1>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
+      if (schur_in_lds(dm)) {
+        hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
+        hipLaunchKernelGGL(k_schur<1>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
+      } else {
+        hipLaunchKernelGGL((k_schur<0, true>), dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
+        hipLaunchKernelGGL((k_schur<1, true>), dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
+      }
     }
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
@@ -849,7 +859,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   if (nx + mb > NMAX) {      // the generic per-stage kernels (tmpc_big.h): plain Step 1 model, blocks that the LDS images of k_schur and of the substitutions can hold
     const Dims db = make_dims(1, p, nx, mb, 0, 0, 0);
     if (ng || nc || step3) { snprintf(g_err, sizeof(g_err), "nx+mb=%d > %d: plain Step 1 model only (no G / C rows, no Step 3)", nx + mb, NMAX); return TMPC_E_UNSUPPORTED; }
-    if (schur_lds<0>(db) > 160 * 1024 || solve_lds(db) > 160 * 1024) { snprintf(g_err, sizeof(g_err), "nx=%d: Schur blocks of %d do not fit the LDS images of the assembly / substitution kernels (nx <= 43 at nx+mb > 32)", nx, db.dp); return TMPC_E_UNSUPPORTED; }
+    if (solve_lds(db) > 160 * 1024) { snprintf(g_err, sizeof(g_err), "nx=%d: Schur blocks of %d do not fit the LDS image of the substitution kernels (nx <= 55)", nx, db.dp); return TMPC_E_UNSUPPORTED; }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }

@@ -170,6 +170,7 @@ struct WS {
   double* Dl; double* Ol; double* Fl; double* Linvl; double* KFl; double* adjVl; double* adjEl; double* W3l; double* Zl;
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
   double* Pdef;    // [B,p,nx,nx] result of the default solve (restored when the tight phase of a member fails)
+  double* sscr;    // [B,p,10,nx,nx] factor records of k_schur when they do not fit the LDS (nx > 43); null otherwise
   double* bscr;    // [B,p,5,n,n] scratch of the generic per-stage kernels (tmpc_big.h: 32 < n <= 64); null otherwise
   int* plist;      // [B] problems handed to the polish (count in active[2])
 };

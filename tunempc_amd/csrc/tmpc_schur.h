@@ -35,7 +35,9 @@ template <int PART> constexpr int sch_rec() { return PART == 0 ? 10 : 6; }      
 __device__ __forceinline__ double hkm_t(double xac, double xad, double xbc, double xbd, double sac, double sad, double sbc, double sbd) {
   return (xac * sbd + xad * sbc) + (xbc * sad + xbd * sac);
 }
-template <int PART>
+// GF: the interleaved factor records live in a per-stage global scratch (w.sscr) instead of LDS -- nx > 43 at n > 32, where 10 nx^2 doubles exceed the LDS; same code,
+// separate instantiation (the LDS form is untouched)
+template <int PART, bool GF = false>
 __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   constexpr int REC = sch_rec<PART>();
   const int sid = stage_id(w, dm);
@@ -48,8 +50,8 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   const int reg = ip[I_REG];
   const double regf = (reg <= 0) ? 1.0 : 1.0 + 1e-13 * ((reg == 1) ? 10.0 : (reg == 2) ? 100.0 : 1000.0);
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* mats = sm;                                        // [nx][nx][REC]
-  unsigned* pair = (unsigned*)(sm + (size_t)nxx * REC);     // [d]: a | b << 16 of the packed index (ab), a <= b
+  double* mats = GF ? w.sscr + (size_t)sid * 10 * nxx : sm;                  // [nx][nx][REC]
+  unsigned* pair = (unsigned*)(GF ? sm : sm + (size_t)nxx * REC);            // [d]: a | b << 16 of the packed index (ab), a <= b
   // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
   // reduction eliminates first.  `corner` = stored as C_k = T[P_k,P_{k+1}], otherwise transposed, O_k = T[P_{k+1},P_k]:
   // stored entry (row, col) = C_k[col][row], i.e. the same expression on the TRANSPOSED factors F', so those go into LDS
