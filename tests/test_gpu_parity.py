@@ -1194,3 +1194,73 @@ def test_large_block_side_entries():
     assert rel(W, Hs / 0.1) < 1e-14
     assert rel(yref, wref - np.linalg.solve(Hs, q[..., None])[..., 0]) < 1e-10
     h.close()
+
+
+# ----------------------------------------------------------------------------- multipliers of G / C at 32 < n <= 64 (second half)
+def _mult_model(seed, nb, p, nx, mb, ng, nc):
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed + 1)
+    n = nx + mb
+    G = rng.standard_normal((nb, p, ng, n)); C = np.zeros((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, :ncnt[b, k]] = rng.standard_normal((ncnt[b, k], n))
+    return A, B, H, G, C, ncnt
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng,nc', [(11, 2, 5, 5, 2, 2, 3), (12, 2, 8, 12, 4, 3, 4), (13, 1, 4, 24, 8, 4, 5), (14, 2, 1, 6, 2, 1, 2), (15, 2, 6, 10, 3, 0, 4)])
+def test_generic_multiplier_kernels_match_the_tuned_ones(seed, nb, p, nx, mb, ng, nc):
+    """debug flag 64 with G / C rows: the <true> forms of k_phi_pre / k_phi_rhs / k_phi_dir (matrices read from global memory, 64-long vectors) on the generic
+    per-stage kernels, against the tuned kernels on the same inputs -- Step 1 with G and the Step 2 model; same iteration counts, Hc and multipliers to 1e-9"""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H, G, C, ncnt = _mult_model(seed, nb, p, nx, mb, ng, nc)
+    J = np.concatenate([G, C], axis=2)
+    res = []
+    for flags in (0, 64):
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb, flags=flags)
+        o2 = h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+        o1 = h.convexify_eq_batch(A, B, H, G) if ng else None
+        h.close()
+        res.append((o1, o2))
+    for a, g in zip(res[0], res[1]):
+        if a is None:
+            continue
+        assert np.array_equal(a['status'], g['status']) and np.array_equal(a['iters'], g['iters'])
+        for b in range(nb):
+            assert rel(g['Hc'][b], a['Hc'][b]) < 1e-9
+        fa = a['FgF'] if 'FgF' in a else a['Fg']; fg = g['FgF'] if 'FgF' in g else g['Fg']
+        assert np.abs(fa - fg).max() < 1e-9 * max(np.abs(fa).max(), 1e-3)
+
+
+@pytest.mark.parametrize('seed,p,nx,mb,ng,nc', [(21, 3, 24, 10, 2, 3), (22, 4, 20, 16, 3, 2), (23, 2, 30, 12, 0, 4), (24, 3, 26, 8, 2, 0), (25, 2, 40, 8, 3, 3)])
+def test_large_stage_blocks_with_multipliers(seed, p, nx, mb, ng, nc):
+    """Steps 1 and 2 at 32 < n <= 64 against the numpy oracle: Hc (= H + the supplement with the multiplier terms), the multipliers, kappa"""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H, G, C, ncnt = _mult_model(seed, 1, p, nx, mb, ng, nc)
+    Cl = [C[0, k, :ncnt[0, k]] if ncnt[0, k] else None for k in range(p)]
+    r = co.sdp_step1(A[0], B[0], H[0], G=G[0] if ng else None, C=Cl if nc else None, rho=1e-2 if nc else None)
+    dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=G[0] if ng else None, Fg=r.get('Fg'), C=Cl if nc else None, F=r.get('F'))[0]
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=1)
+    o = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, 1e-2) if nc else h.convexify_eq_batch(A, B, H, G)
+    h.close()
+    assert int(o['status'][0]) == 0 and r['ipm_status'] == 'optimal'
+    assert rel(o['Hc'][0], H[0] + dH) < PARITY
+    assert abs(o['kappa'][0] - r['kappa']) < 1e-9 * r['kappa']
+    assert np.linalg.eigvalsh(o['Hc'][0]).min() > 0
+
+
+def test_large_block_supplement_with_multiplier_terms():
+    """tmpc_supplement_terms_batch_host at n = 40 with the J' diag(w) J terms (generic kernel) against the oracle's convexHessianSuppl"""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb, nr = 3, 30, 10, 2, 4
+    A, B, H = co.gen_batch(210, nb, p, nx, mb)
+    rng = np.random.default_rng(3)
+    P = rng.standard_normal((nb, p, nx, nx)); P = P + P.transpose(0, 1, 3, 2)
+    J = rng.standard_normal((nb, p, nr, nx + mb)); wts = rng.uniform(0.0, 1.0, (nb, p, nr))
+    h = HipConvexifier(p, nx, mb, chunk=nb)
+    dH = h.supplement_terms_batch(A, B, P, J=J, wts=wts)
+    h.close()
+    for b in range(nb):
+        want = co.convex_hessian_suppl(A[b], B[b], P[b], G=J[b], Fg=wts[b])[0]
+        assert rel(dH[b], want) < 1e-13

@@ -27,7 +27,7 @@ DEFAULT_TOL = 2.0 ** -25
 
 
 NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
-N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (plain model; nx <= 55 there)
+N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (Steps 1 and 2; nx <= 55 there)
 NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
@@ -36,10 +36,10 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
     pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
     of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk."""
-    if nx + mb > N_TUNED and (ng or nc or step3):
-        # 32 < n <= 64 runs on the generic per-stage kernels (csrc/tmpc_big.h): the plain Step 1 model; the multiplier kernels (G / C rows, Step 3) are written
-        # around one 32 x 33 LDS tile per stage block
-        raise NotImplementedError('the HIP path handles G / C rows and Step 3 up to nx + nu = {} (got {}); the plain Step 1 model up to {}'.format(N_TUNED, nx + mb, N_MAX))
+    if nx + mb > N_TUNED and step3:
+        # 32 < n <= 64 runs on the generic per-stage kernels (csrc/tmpc_big.h): Steps 1 and 2, with the multipliers of G / C; the Step 3 kernels (tmpc_t3.h) are
+        # written around 32 x 33 LDS tiles
+        raise NotImplementedError('the HIP path handles Step 3 (force=True) up to nx + nu = {} (got {}); Steps 1 and 2 up to {}'.format(N_TUNED, nx + mb, N_MAX))
     if nx + mb > N_MAX:
         raise NotImplementedError('the HIP path handles stage blocks up to nx + nu = {} (got {})'.format(N_MAX, nx + mb))
     key = (p, nx, mb, ng, bool(step3))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt

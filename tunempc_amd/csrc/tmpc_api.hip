@@ -420,9 +420,12 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -605,7 +608,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
   const size_t t3_schur_lds = (size_t)(10 * 32 * T3_LD + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
-  const bool big = dm.n > NMAX || ((h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE) && !eq && !t3);      // generic per-stage kernels (tmpc_big.h)
+  const bool big = dm.n > NMAX || ((h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE) && !t3);      // generic per-stage kernels (tmpc_big.h)
   if (big && !ln->ws.bscr) {                 // (debug flag at n <= 32: the scratch is not part of the workspace)
     if (hipMalloc(&ln->big_scr, (size_t)h->dm.B * dm.p * BIG_SCR * dm.n * dm.n * sizeof(double)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc of the generic-stage scratch failed"); return TMPC_E_NOMEM; }
     ln->ws.bscr = (double*)ln->big_scr;
@@ -653,7 +656,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
     if (big) hipLaunchKernelGGL(kb_stage_pre, dim3(BP), dim3(256), 0, st, w, dm);
     else TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
-    if (eq) hipLaunchKernelGGL(k_phi_pre, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
+    if (eq && big) hipLaunchKernelGGL(k_phi_pre<true>, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS_BIG * sizeof(double), st, w, dm, 1);
+    else if (eq) hipLaunchKernelGGL(k_phi_pre<false>, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
     if (t3) hipLaunchKernelGGL(k_t3_pre, dim3(BP), dim3(64), t3_lds, st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
@@ -691,7 +695,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (fuse1) {
       if (big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, 1);
       else TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, 1);
-      if (eq) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
+      if (eq && big) hipLaunchKernelGGL(k_phi_rhs<true>, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
+      else if (eq) hipLaunchKernelGGL(k_phi_rhs<false>, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, 1, 1);
       hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
     }
@@ -704,7 +709,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       const bool fused = (pass == 1 && fuse1);
       if (!fused && big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, pass);
       else if (!fused) TMPC_STAGE_LAUNCH(k_stage_rhs, slots_bytes(RHS_SLOTS), st, w, dm, pass);
-      if (eq && !fused) hipLaunchKernelGGL(k_phi_rhs, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
+      if (eq && !fused && big) hipLaunchKernelGGL(k_phi_rhs<true>, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
+      else if (eq && !fused) hipLaunchKernelGGL(k_phi_rhs<false>, dim3(BP), dim3(64), slots_bytes(2), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_rhs, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (!fused) hipLaunchKernelGGL(k_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
       if (eq && !fused) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, pass);
@@ -712,7 +718,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (ddm) { const int rc_ = dd_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, nb); if (rc_ != TMPC_OK) return rc_; }
       else cr_solve(w, dm, h->sched, h->d_sched, alist, active, st, pass, fused);
       hipLaunchKernelGGL(k_solve_border, dim3(active), dim3(256), 0, st, w, dm, (const int*)alist, pass);
-      if (eq) hipLaunchKernelGGL(k_phi_dir, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
+      if (eq && big) {
+        hipLaunchKernelGGL(kb_phi_dm, dim3(BP), dim3(256), 0, st, w, dm, pass);
+        hipLaunchKernelGGL(k_phi_dir<true>, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
+      } else if (eq) hipLaunchKernelGGL(k_phi_dir<false>, dim3(BP), dim3(64), (size_t)PHI_DIR_LDS * sizeof(double), st, w, dm, pass, 1);
       if (t3) hipLaunchKernelGGL(k_t3_dir, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
       if (big) {
         hipLaunchKernelGGL(kb_stage_dir, dim3(BP), dim3(256), 0, st, w, dm, pass);
@@ -856,9 +865,9 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
     snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
   }
-  if (nx + mb > NMAX) {      // the generic per-stage kernels (tmpc_big.h): plain Step 1 model, blocks that the LDS images of k_schur and of the substitutions can hold
-    const Dims db = make_dims(1, p, nx, mb, 0, 0, 0);
-    if (ng || nc || step3) { snprintf(g_err, sizeof(g_err), "nx+mb=%d > %d: plain Step 1 model only (no G / C rows, no Step 3)", nx + mb, NMAX); return TMPC_E_UNSUPPORTED; }
+  if (nx + mb > NMAX) {      // the generic per-stage kernels (tmpc_big.h): Steps 1 and 2 (no Step 3), blocks that the LDS images of k_schur and of the substitutions can hold
+    const Dims db = make_dims(1, p, nx, mb, ng, nc, 0);
+    if (step3) { snprintf(g_err, sizeof(g_err), "nx+mb=%d > %d: Steps 1 and 2 only (no Step 3 regularisation T_k)", nx + mb, NMAX); return TMPC_E_UNSUPPORTED; }
     if (solve_lds(db) > 160 * 1024) { snprintf(g_err, sizeof(g_err), "nx=%d: Schur blocks of %d do not fit the LDS image of the substitution kernels (nx <= 55)", nx, db.dp); return TMPC_E_UNSUPPORTED; }
   }
   int ndev = 0;
@@ -1333,8 +1342,9 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, 
     }
     if (T) HIPCHK(hipMemcpyAsync(h->dH, T + so * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
     if (dm.n > NMAX) {      // generic form (tmpc_big.h): the supplement of P alone
-      if (J || T) { snprintf(g_err, sizeof(g_err), "tmpc_supplement_terms_batch_host: the J / T terms are handled up to nx + mb = %d", NMAX); return TMPC_E_UNSUPPORTED; }
-      hipLaunchKernelGGL(kb_supplement, dim3((unsigned)BP), dim3(256), 0, st, (const double*)h->dA, (const double*)h->dB, (const double*)h->ws.P, h->ws.dHc, d2, h->ws.bscr);
+      if (T) { snprintf(g_err, sizeof(g_err), "tmpc_supplement_terms_batch_host: the T term is handled up to nx + mb = %d", NMAX); return TMPC_E_UNSUPPORTED; }
+      hipLaunchKernelGGL(kb_supplement, dim3((unsigned)BP), dim3(256), 0, st, (const double*)h->dA, (const double*)h->dB, (const double*)h->ws.P, h->ws.dHc, d2, h->ws.bscr,
+                         nr, (const double*)(J ? dJ : nullptr), (const double*)(J ? dw : nullptr));
     } else
     hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2, nr, dJ, dw,
                        T ? h->dH : nullptr);

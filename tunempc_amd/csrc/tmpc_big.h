@@ -18,9 +18,7 @@
 
 namespace tmpc {
 
-constexpr int NB = 64;                      // largest stage block of the generic path
 constexpr int BLD = NB + 1;                 // leading dimension of its one LDS tile (Jacobi)
-constexpr int BIG_SCR = 5;                  // n x n scratch matrices per stage
 
 __device__ __forceinline__ void gsync() { __threadfence_block(); __syncthreads(); }
 // C (M x N, ldc) {=, +=, -=} A B; element (i, k) of A at A[i * ars + k * acs], (k, j) of B at B[k * brs + j * bcs].  C must not alias A or B.
@@ -87,6 +85,16 @@ __device__ __forceinline__ void gbuild_M(double* M, double* tq, const double* V,
     double v = M[e] + (coef != 0.0 ? coef * Hb[e] : 0.0);
     if (i < nx && j < nx) v -= Pk[i * nx + j];
     M[e] = v;
+  }
+  gsync();
+}
+// M (n x n, global) += scale * sum_i coef[i] g_i g_i'   (the multiplier term of [G_k; C_k]; add_gtg of tmpc_stage.h)
+__device__ __forceinline__ void gadd_gtg(double* M, const double* Gg, const double* coef, double scale, int nrow, int n) {
+  for (int e = threadIdx.x; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    double acc = 0.0;
+    for (int r = 0; r < nrow; ++r) acc = fma(scale * coef[r] * Gg[r * n + i], Gg[r * n + j], acc);
+    M[e] += acc;
   }
   gsync();
 }
@@ -208,6 +216,7 @@ __global__ void __launch_bounds__(256) kb_stage_pre(WS w, Dims dm) {
   const double* V = w.V + (size_t)sid * nx * n; const double* Hb = w.Hb + so;
   double* sM = scr; double* t0 = scr + nn; double* t1 = scr + 2 * nn; double* sPhi = scr + 3 * nn; double* t3 = scr + 4 * nn;
   gbuild_M(sM, t0, V, Hb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx);
+  if (dm.nr > 0) gadd_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n);      // + J' diag(phi) J
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0, hbphi = 0.0;
   int nbad = 0;
   for (int r = 0; r < 2; ++r) {
@@ -324,6 +333,7 @@ __global__ void __launch_bounds__(256) kb_stage_dir(WS w, Dims dm, int pass) {
   double* dM = scr; double* t0 = scr + nn; double* t1 = scr + 2 * nn; double* ldy = scr + 3 * nn;
   const double* dPk = w.dP + (size_t)sid * nxx;
   gbuild_M(dM, t0, V, Hb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx);
+  if (dm.nr > 0) gadd_gtg(dM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n);     // + J' diag(dphi) J
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* X = (r ? w.X2 : w.X1) + so; const double* S = (r ? w.S2 : w.S1) + so; const double* Si = (r ? w.S2i : w.S1i) + so;
@@ -378,6 +388,17 @@ __global__ void __launch_bounds__(256) kb_stage_dir(WS w, Dims dm, int pass) {
   }
 }
 
+// dalpha*Hb + calH(dP) of the stage into scratch slot 4, for k_phi_dir<true> (which runs before kb_stage_dir and needs it without the multiplier term)
+__global__ void __launch_bounds__(256) kb_phi_dm(WS w, Dims dm, int pass) {
+  TMPC_BIG_PROLOGUE
+  const int* ip = w.iprob + (size_t)b * IS;
+  const int phase = ip[I_PHASE];
+  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  gbuild_M(scr + 4 * nn, scr, w.V + (size_t)sid * nx * n, w.Hb + so, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, pr[P_DALPHA], n, nx);
+}
+
 // ------------------------------------------------------------------ smallest eigenvalue of one step-length matrix   (k_eigmin; one workgroup per matrix)
 __global__ void __launch_bounds__(256) kb_eigmin(WS w, Dims dm, int pass) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -407,6 +428,11 @@ __global__ void __launch_bounds__(256) kb_final_stage(WS w, Dims dm) {
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; sH[e] = 0.5 * (Hg[i * n + j] + Hg[j * n + i]); }
   gsync();
   gbuild_M(sM, t0, w.V + (size_t)sid * nx * n, sH, Po, Pon, 0.0, n, nx);       // dH = V' Pst+ V - E' Pst E
+  if (dm.nr > 0) {                          // [Fg; F] = sF*phi/(s_alpha*alpha) and their terms of the supplement (k_final_stage)
+    const int nrow = stage_rows(w, dm, sid);
+    if (tid < dm.nr) w.Fg[(size_t)sid * dm.nr + tid] = (tid < nrow) ? sc * w.phi[(size_t)sid * dm.nr + tid] : 0.0;
+    gadd_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, sc, nrow, n);
+  }
   gsym(sM, n);
   for (int e = tid; e < nn; e += 256) { const double dh = sM[e]; w.dHc[so + e] = dh; w.Hc[so + e] = sH[e] + dh; }
   gsync();
@@ -424,7 +450,7 @@ __global__ void __launch_bounds__(256) kb_eig_scan(const double* H, double* out,
   if (threadIdx.x == 0) { double* o = out + (size_t)blockIdx.x * 4; o[0] = lo; o[1] = hi; o[2] = amin; o[3] = amax; }
 }
 // dHc = sym(V' P+ V - E' P E) for arbitrary P (tmpc_supplement_batch_host; k_supplement without the J / T terms); scr: 3 n x n doubles per stage
-__global__ void __launch_bounds__(256) kb_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm, double* scr_all) {
+__global__ void __launch_bounds__(256) kb_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm, double* scr_all, int nr, const double* J, const double* wts) {
   const int sid = blockIdx.x, tid = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int n = dm.n, nx = dm.nx, mb = dm.mb, nn = n * n, nxx = nx * nx;
@@ -433,6 +459,7 @@ __global__ void __launch_bounds__(256) kb_supplement(const double* A, const doub
   gsync();
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   gbuild_M(sM, t0, sV, sM, P + (size_t)sid * nxx, P + (size_t)(b * dm.p + kn) * nxx, 0.0, n, nx);
+  if (J) gadd_gtg(sM, J + (size_t)sid * nr * n, wts + (size_t)sid * nr, 1.0, nr, n);      // + J' diag(w) J (padded rows carry weight 0)
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; dHc[(size_t)sid * nn + e] = 0.5 * (sM[i * n + j] + sM[j * n + i]); }
 }
 // W = sym(Hc) / ts, yref = wref - Hc^-1 q by Cholesky and two substitutions (tmpc_tracking_reference_host; k_tracking_ref); scr: n x n doubles per stage

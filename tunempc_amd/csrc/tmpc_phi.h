@@ -153,9 +153,14 @@ __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
 
 // LDS of k_phi_pre (doubles)
 constexpr int PHI_PRE_LDS = 4 * MS + NRM * NMAX + 4 * NRM * NMAX + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;
+constexpr int PHI_PRE_LDS_BIG = 4 * MS + 4 * NRM * NB + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;      // (152 KB: one workgroup per CU)
 // after k_stage_pre (needs S_r^-1), before k_ctrl_a: vectors w, u, V w, V u; K; c_tau, c_alpha; border / mu / pinf partials
 // aug: the multipliers stay in the block system (k_aug_fill): T_loc,loc itself is stored instead of its inverse and the border
 // scalars are left alone.
+// BIGN (32 < n <= 64, with the generic per-stage kernels of tmpc_big.h): the n x n matrices and the Jacobian rows are read where they
+// lie in global memory instead of LDS slots (every entry is used once per row of [G; C]); the vectors are 64 long; the arrow blocks
+// (at most 17 x 17) keep the four LDS slots.  Same arithmetic in the same order: at n <= 32 both forms return the same bits.
+template <bool BIGN>
 __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), lane = threadIdx.x;
@@ -166,49 +171,59 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   const PhiStage ps = phi_stage(w, dm, sid);
   const int n = dm.n, nx = dm.nx, nn = n * n, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sX = sm; double* sSi = sm + MS; double* sHb = sm + 2 * MS; double* sV = sm + 3 * MS;
-  double* gl = sm + 4 * MS;                 // [nrow][NMAX]
-  double* wl = gl + NRM * NMAX;             // [2][nrow][NMAX]
-  double* ul = wl + 2 * NRM * NMAX;         // [2][nrow][NMAX]
-  double* GXG = ul + 2 * NRM * NMAX;        // [2][NRM][NRM]
+  constexpr int NV = BIGN ? NB : NMAX;      // stride of the per-row vectors
+  double* gl = sm + 4 * MS;                 // [nrow][NMAX]   (BIGN: the rows are read from global memory)
+  double* wl = gl + (BIGN ? 0 : NRM * NMAX); // [2][nrow][NV]
+  double* ul = wl + 2 * NRM * NV;           // [2][nrow][NV]
+  double* GXG = ul + 2 * NRM * NV;          // [2][NRM][NRM]
   double* GSG = GXG + 2 * NRM * NRM;        // [2][NRM][NRM]
   double* Tm = GSG + 2 * NRM * NRM;         // [NZM][2*NZM+1]  T_loc,loc | I  ->  I | K
   double* ctl = Tm + NZM * (2 * NZM + 1); double* cal = ctl + NZM; double* rres = cal + NZM; double* kv = rres + NZM;
   constexpr int TL = 2 * NZM + 1;
   const double* Gg = w.G + (size_t)sid * dm.nr * n;
-  for (int e = lane; e < ng * n; e += 64) gl[(e / n) * NMAX + (e % n)] = Gg[e];
-  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
-  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  // matrices: LDS slots (stride LD) or, BIGN, global memory (stride n)
+  const int ldm = BIGN ? n : LD, ldg = BIGN ? n : NMAX;
+  const double* mHb = BIGN ? w.Hb + (size_t)sid * nn : sHb; const double* mV = BIGN ? w.V + (size_t)sid * nx * n : sV;
+  const double* mG = BIGN ? Gg : gl;
+  if (!BIGN) {
+    for (int e = lane; e < ng * n; e += 64) gl[(e / n) * NMAX + (e % n)] = Gg[e];
+    g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+    g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+  }
   if (lane < NZM) { ctl[lane] = 0.0; cal[lane] = 0.0; rres[lane] = 0.0; }
   for (int r = 0; r < 2; ++r) {
-    g2s(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
-    g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    const double* mX = BIGN ? (r ? w.X2 : w.X1) + (size_t)sid * nn : sX; const double* mSi = BIGN ? (r ? w.S2i : w.S1i) + (size_t)sid * nn : sSi;
+    if (!BIGN) {
+      g2s(sX, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n, lane);
+      g2s(sSi, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n, lane);
+    }
     for (int i = 0; i < ng; ++i) {
       if (lane < n) {
         double a0 = 0.0, a1 = 0.0;
-        for (int c = 0; c < n; ++c) { const double g = gl[i * NMAX + c]; a0 = fma(sX[lane * LD + c], g, a0); a1 = fma(sSi[lane * LD + c], g, a1); }
-        wl[(r * NRM + i) * NMAX + lane] = a0; ul[(r * NRM + i) * NMAX + lane] = a1;
+        for (int c = 0; c < n; ++c) { const double g = mG[i * ldg + c]; a0 = fma(mX[lane * ldm + c], g, a0); a1 = fma(mSi[lane * ldm + c], g, a1); }
+        wl[(r * NRM + i) * NV + lane] = a0; ul[(r * NRM + i) * NV + lane] = a1;
       }
     }
     wsync();
     for (int i = 0; i < ng; ++i) {
       double* pv = pv_at(w.pvec, dm, sid, r, i);
-      const double* wi = wl + (r * NRM + i) * NMAX; const double* ui = ul + (r * NRM + i) * NMAX;
+      const double* wi = wl + (r * NRM + i) * NV; const double* ui = ul + (r * NRM + i) * NV;
       if (lane < n) { pv[lane] = wi[lane]; pv[n + lane] = ui[lane]; }
       if (lane < nx) {
         double a0 = 0.0, a1 = 0.0;
-        for (int c = 0; c < n; ++c) { a0 = fma(sV[lane * LD + c], wi[c], a0); a1 = fma(sV[lane * LD + c], ui[c], a1); }
+        for (int c = 0; c < n; ++c) { a0 = fma(mV[lane * ldm + c], wi[c], a0); a1 = fma(mV[lane * ldm + c], ui[c], a1); }
         pv[2 * n + lane] = a0; pv[2 * n + nx + lane] = a1;
       }
       // c_alpha_i += w' Hb u ;  c_tau_i = -(w_2 . u_2)
       double hu = 0.0;
-      if (lane < n) { for (int c = 0; c < n; ++c) hu = fma(sHb[lane * LD + c], ui[c], hu); hu *= wi[lane]; }
+      if (lane < n) { for (int c = 0; c < n; ++c) hu = fma(mHb[lane * ldm + c], ui[c], hu); hu *= wi[lane]; }
       hu = wave_sum(hu);
       double wu = (lane < n) ? wi[lane] * ui[lane] : 0.0;
       wu = wave_sum(wu);
       if (lane == 0) { cal[i] += hu; if (r == 1) ctl[i] = -wu; }
       for (int j = 0; j < ng; ++j) {
-        double x = (lane < n) ? gl[i * NMAX + lane] * wl[(r * NRM + j) * NMAX + lane] : 0.0;
-        double y = (lane < n) ? gl[i * NMAX + lane] * ul[(r * NRM + j) * NMAX + lane] : 0.0;
+        double x = (lane < n) ? mG[i * ldg + lane] * wl[(r * NRM + j) * NV + lane] : 0.0;
+        double y = (lane < n) ? mG[i * ldg + lane] * ul[(r * NRM + j) * NV + lane] : 0.0;
         x = wave_sum(x); y = wave_sum(y);
         if (lane == 0) { GXG[(r * NRM + i) * NRM + j] = x; GSG[(r * NRM + i) * NRM + j] = y; }
       }
@@ -342,6 +357,7 @@ __device__ __forceinline__ double phi_bvec(const double* pvec, const Dims& dm, s
 }
 
 // after k_stage_rhs, before k_gather / the substitutions: r_loc, K r_loc, and the eliminated part of the border right-hand sides
+template <bool BIGN>
 __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), lane = threadIdx.x;
@@ -357,14 +373,20 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug
   double* sG = sm;                         // T1 - T2
   double* rl = sm + MS;                    // [NZM]
   const double* T1 = w.T1 + (size_t)sid * nn; const double* T2 = w.T2 + (size_t)sid * nn;
-  for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; sG[i * LD + j] = T1[e] - T2[e]; }
-  wsync();
+  if (!BIGN) {
+    for (int e = lane; e < nn; e += 64) { const int i = e / n, j = e - i * n; sG[i * LD + j] = T1[e] - T2[e]; }
+    wsync();
+  }
   const double* Gg = w.G + (size_t)sid * dm.nr * n;
   double* q = psm_at(w.psm, dm, sid);
   const double* phi = w.phi + (size_t)sid * dm.nr; const double* cp = w.corrp + (size_t)sid * dm.nr;
   for (int i = 0; i < ng; ++i) {
     double t = 0.0;
-    if (lane < n) { for (int c = 0; c < n; ++c) t = fma(sG[lane * LD + c], Gg[i * n + c], t); t *= Gg[i * n + lane]; }
+    if (lane < n) {
+      if (BIGN) { for (int c = 0; c < n; ++c) t = fma(T1[lane * n + c] - T2[lane * n + c], Gg[i * n + c], t); }
+      else { for (int c = 0; c < n; ++c) t = fma(sG[lane * LD + c], Gg[i * n + c], t); }
+      t *= Gg[i * n + lane];
+    }
     t = wave_sum(t);
     if (lane == 0) rl[i] = t + sig / phi[i] - (use_corr ? cp[i] : 0.0);
   }
@@ -398,6 +420,8 @@ __global__ void __launch_bounds__(64) k_phi_rhs(WS w, Dims dm, int pass, int aug
 
 // after the substitutions, before k_stage_dir: dy_loc = K (r_loc - T_loc,y dy), dz; arrow blocks: dS, dX, step-length eigenvalues;
 // Mehrotra second-order terms in pass 1
+// BIGN: dalpha*Hb + calH(dP) was left in scratch slot 4 of the stage by kb_phi_dm (tmpc_big.h)
+template <bool BIGN>
 __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), lane = threadIdx.x;
@@ -415,16 +439,20 @@ __global__ void __launch_bounds__(64) k_phi_dir(WS w, Dims dm, int pass, int aug
   double* tl = sm + 5 * MS;                // [NZM] r_loc - T_loc,y dy
   double* dl = tl + NZM;                   // [NZM] dy_loc
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
-  g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
-  g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
-  build_M(sM, sV, t0, t1, sHb, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dalpha*Hb + calH(dP)
+  const int ldm = BIGN ? n : LD;
+  const double* mM = BIGN ? w.bscr + ((size_t)sid * BIG_SCR + 4) * nn : sM;
+  if (!BIGN) {
+    g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
+    g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
+    build_M(sM, sV, t0, t1, sHb, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx, lane);   // dalpha*Hb + calH(dP)
+  }
   double* q = psm_at(w.psm, dm, sid);
   for (int i = 0; i < ng; ++i) {
     double t = 0.0;
     for (int r = 0; r < 2; ++r) {
       const double* pv = pv_at(w.pvec, dm, sid, r, i);       // w = pv[0..n), u = pv[n..2n)
       double x = 0.0;
-      if (lane < n) { for (int c = 0; c < n; ++c) x = fma(sM[lane * LD + c], pv[n + c], x); x *= pv[lane]; }
+      if (lane < n) { for (int c = 0; c < n; ++c) x = fma(mM[lane * ldm + c], pv[n + c], x); x *= pv[lane]; }
       t += wave_sum(x);
     }
     if (lane == 0) tl[i] = PSM_RPHI(q, nzs)[i] - (t + dtau * PSM_CT(q, nzs)[i]);

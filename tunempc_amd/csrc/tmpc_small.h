@@ -10,6 +10,8 @@ namespace tmpc {
 constexpr int NMAX = 32;          // max stage-block size n = nx + nu + ns
 constexpr int LD = 33;            // LDS leading dimension (doubles)
 constexpr int MS = NMAX * LD;     // doubles per LDS matrix slot
+constexpr int NB = 64;            // largest stage block of the generic per-stage kernels (tmpc_big.h; the multiplier kernels of tmpc_phi.h in their <true> form)
+constexpr int BIG_SCR = 5;        // n x n scratch matrices per stage of those kernels (WS::bscr)
 
 __device__ __forceinline__ void wsync() { __syncthreads(); }
 
