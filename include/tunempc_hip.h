@@ -77,11 +77,13 @@ uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
 /* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.
  * Larger batches are processed in chunks.  chunk <= 0 selects a default that fits free HBM. */
 int tmpc_create(tmpc_handle** out, int chunk, int p, int nx, int mb);
-/* The same with room for `ng` equality-constraint rows per stage (0 <= ng <= 16), for tmpc_convexify_eq_batch_host.
+#define TMPC_MAX_ROWS 31         /* rows of G_k, and rows of C_k, per stage (each)                     */
+#define TMPC_ARROW_LD 32         /* leading dimension of the arrow blocks tmpc_get_dual_con_host exports */
+/* The same with room for `ng` equality-constraint rows per stage (0 <= ng <= TMPC_MAX_ROWS), for tmpc_convexify_eq_batch_host.
  * Such a handle also serves every call that takes no G. */
 uint64_t tmpc_workspace_bytes_eq(int chunk, int p, int nx, int mb, int ng);
 int tmpc_create_eq(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng);
-/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= 16),
+/* The same with room for up to `nc` active-constraint rows per stage as well (0 <= nc <= TMPC_MAX_ROWS),
  * for tmpc_convexify_step2_batch_host. */
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc);
 int tmpc_create_con(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc);
@@ -258,7 +260,7 @@ int tmpc_get_dual_host(tmpc_handle* h, int nb, double* X1, double* X2, double* s
  * same solver-independent certificate (tests/test_gpu_parity.py::test_dual_certificate_with_multipliers):
  *   phi [nb][p][nr]  the multipliers s*[Fg_k; F_k] (nr = ng + nc of the handle; entries beyond a stage's row count are padding),
  *   z   [nb][p][nr]  their duals (phi_i >= 0  <->  z_i >= 0),
- *   aX  [nb][p][2][17][17], at [nb][p][2]   Step 2 with rho > 0 only (else pass NULL): the primal blocks X_e of the arrow LMIs of the (up to) two norm terms
+ *   aX  [nb][p][2][TMPC_ARROW_LD][TMPC_ARROW_LD], at [nb][p][2]   Step 2 with rho > 0 only (else pass NULL): the primal blocks X_e of the arrow LMIs of the (up to) two norm terms
  *                    per stage (leading (m_e + 1) x (m_e + 1) part valid; term 0 = the rows of G if ng > 0, then the rows of C_k) and the epigraph variables t_e.
  * X1, X2, x0, tau, alpha, mu_target come from tmpc_get_dual_host.  Any pointer may be NULL. */
 int tmpc_get_dual_con_host(tmpc_handle* h, int nb, double* phi, double* z, double* aX, double* at);

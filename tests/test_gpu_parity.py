@@ -628,7 +628,8 @@ def test_step3_parity_vs_oracle(hc, seed, nb, p, nx, mb, rho):
 
 
 @pytest.mark.parametrize('seed,p,nx,mb,ng,ncs,rho', [(4, 2, 2, 1, 1, None, 1e-2), (1, 3, 3, 2, 1, [2, 0, 1], 1e-2), (3, 1, 3, 1, 0, [2], 1e-1),
-                                                    (3, 4, 4, 2, 2, [1, 3, 0, 2], 1e-3), (4, 2, 6, 3, 1, [2, 2], 1e-2)])
+                                                    (3, 4, 4, 2, 2, [1, 3, 0, 2], 1e-3), (4, 2, 6, 3, 1, [2, 2], 1e-2),
+                                                    (5, 2, 8, 4, 18, [20, 17], 1e-2)])      # (more than 32 rows per stage: Gram products in global memory)
 def test_step3_with_constraint_rows_parity(hc, seed, p, nx, mb, ng, ncs, rho):
     """Step 3 with the multipliers of G / C in the same solve (convexifier.py:144: constr = constraint_contribution, force = True) against
     the structured oracle: Hc, the multipliers Fg / F, T and the objective; ncs None: G only (the reference's constr = False)."""
@@ -1233,9 +1234,11 @@ def test_generic_multiplier_kernels_match_the_tuned_ones(seed, nb, p, nx, mb, ng
         assert np.abs(fa - fg).max() < 1e-9 * max(np.abs(fa).max(), 1e-3)
 
 
-@pytest.mark.parametrize('seed,p,nx,mb,ng,nc', [(21, 3, 24, 10, 2, 3), (22, 4, 20, 16, 3, 2), (23, 2, 30, 12, 0, 4), (24, 3, 26, 8, 2, 0), (25, 2, 40, 8, 3, 3)])
+@pytest.mark.parametrize('seed,p,nx,mb,ng,nc', [(21, 3, 24, 10, 2, 3), (22, 4, 20, 16, 3, 2), (23, 2, 30, 12, 0, 4), (24, 3, 26, 8, 2, 0), (25, 2, 40, 8, 3, 3),
+                                                (31, 3, 8, 4, 20, 18), (32, 2, 20, 10, 24, 24), (33, 3, 12, 6, 31, 0), (34, 2, 36, 12, 24, 24), (35, 2, 6, 2, 0, 31)])
 def test_large_stage_blocks_with_multipliers(seed, p, nx, mb, ng, nc):
-    """Steps 1 and 2 at 32 < n <= 64 against the numpy oracle: Hc (= H + the supplement with the multiplier terms), the multipliers, kappa"""
+    """Steps 1 and 2 at 32 < n <= 64 and / or with more than 16 rows of G_k / C_k per stage (up to 31 each; n = 48 with 24 + 24 rows is the case the
+    round-3 review names) against the numpy oracle: Hc (= H + the supplement with the multiplier terms), kappa"""
     from tunempc_amd._lib import HipConvexifier
     A, B, H, G, C, ncnt = _mult_model(seed, 1, p, nx, mb, ng, nc)
     Cl = [C[0, k, :ncnt[0, k]] if ncnt[0, k] else None for k in range(p)]
@@ -1264,3 +1267,50 @@ def test_large_block_supplement_with_multiplier_terms():
     for b in range(nb):
         want = co.convex_hessian_suppl(A[b], B[b], P[b], G=J[b], Fg=wts[b])[0]
         assert rel(dH[b], want) < 1e-13
+
+
+def test_many_row_handle_matches_the_small_one():
+    """a handle with room for 3 + 31 rows per stage keeps the per-row vectors and Gram products of k_phi_pre in global memory (its <.., true> form);
+    on inputs with at most 4 rows of C_k it must return what the handle with room for 3 + 4 rows (LDS form) returns: same iterations, Hc to 1e-10
+    (the blocks of the two handles are padded differently, so the factorisations round differently)"""
+    from tunempc_amd._lib import HipConvexifier
+    nb, p, nx, mb, ng, nc = 2, 5, 6, 3, 3, 4
+    A, B, H, G, C, ncnt = _mult_model(41, nb, p, nx, mb, ng, nc)
+    outs = []
+    for room in (nc, 31):
+        Cp = np.zeros((nb, p, room, nx + mb)); Cp[:, :, :nc] = C
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=room, chunk=nb)
+        outs.append(h.convexify_step2_batch(A, B, H, np.concatenate([G, Cp], axis=2), ncnt, 1e-2))
+        h.close()
+    a, g = outs
+    assert np.array_equal(a['status'], g['status']) and np.array_equal(a['iters'], g['iters']) and (a['status'] == 0).all()
+    assert rel(g['Hc'], a['Hc']) < 1e-10
+    assert np.abs(g['FgF'][:, :, :ng + nc] - a['FgF']).max() < 1e-10 * max(1.0, np.abs(a['FgF']).max())
+
+
+def test_dropin_convexify_large_block_with_constraints():
+    """convexifier.convexify(..., G=, C=) at nx + nu = 36 with 20 active rows at one stage: the same call as the reference's; Step 1 (with G) is feasible here, so the
+    result is that of the oracle's Step 1 with G"""
+    from tunempc_amd import convexifier
+    p, nx, mb, ng = 3, 26, 10, 2
+    n = nx + mb
+    A, B, H = co.gen_batch(211, 1, p, nx, mb)
+    rng = np.random.default_rng(212)
+    G = [rng.standard_normal((ng, n)) for _ in range(p)]
+    C = [rng.standard_normal((20, n)), None, rng.standard_normal((3, n))]
+    Q = [H[0, k][:nx, :nx] for k in range(p)]; R = [H[0, k][nx:, nx:] for k in range(p)]; N = [H[0, k][:nx, nx:] for k in range(p)]
+    dHc = convexifier.convexify([A[0, k] for k in range(p)], [B[0, k] for k in range(p)], Q, R, N, G=G, C=C, opts={'rho': 1e-3, 'solver': 'hip', 'force': False})[0]
+    r = co.sdp_step1(A[0], B[0], H[0], G=np.stack(G))
+    want = co.convex_hessian_suppl(A[0], B[0], r['P'], G=np.stack(G), Fg=r['Fg'])[0]
+    assert r['ipm_status'] == 'optimal' and rel(np.stack(dHc), want) < 1e-7
+    assert all(np.linalg.eigvalsh(H[0, k] + dHc[k]).min() > 0 for k in range(p))
+    # the Step 2 model of the same data through the batched mirror (what convexify runs when Step 1 is infeasible)
+    Cp = np.zeros((1, p, 20, n)); ncnt = np.zeros((1, p), np.int32)
+    for k in range(p):
+        if C[k] is not None:
+            Cp[0, k, :C[k].shape[0]] = C[k]; ncnt[0, k] = C[k].shape[0]
+    o2 = convexifier.convexify_step2_batch(A, B, H, Cp, ncnt, 1e-3, G=np.stack(G)[None])
+    r2 = co.sdp_step1(A[0], B[0], H[0], G=np.stack(G), C=C, rho=1e-3)
+    want2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], G=np.stack(G), Fg=r2['Fg'], C=C, F=r2['F'])[0]
+    assert int(o2['status'][0]) == 0 and rel(o2['dHc'][0], want2) < 1e-7
+    convexifier.release_handles()

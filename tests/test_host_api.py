@@ -39,7 +39,7 @@ def test_workspace_query_and_unsupported_dims():
     assert lib.tmpc_workspace_bytes(2, 64, 24, 8) > 1.9 * per
     assert lib.tmpc_workspace_bytes(1, 64, 30, 8) > lib.tmpc_workspace_bytes(1, 64, 24, 8)      # n = 38: the generic per-stage kernels (round 4; rounds 1-3: unsupported)
     assert lib.tmpc_workspace_bytes(1, 4, 40, 30) == 0      # n = 70 > 64 unsupported
-    assert lib.tmpc_workspace_bytes_con(1, 4, 30, 10, 2, 0) > 0 and lib.tmpc_workspace_bytes_step3(1, 4, 30, 10) > 0      # (sizes only: creating such a handle is refused, plain model at n > 32)
+    assert lib.tmpc_workspace_bytes_con(1, 4, 30, 10, 2, 0) > 0 and lib.tmpc_workspace_bytes_step3(1, 4, 30, 10) > 0      # (sizes only; creating the Step 3 handle is refused at n > 32)
     assert lib.tmpc_workspace_bytes(1, 0, 4, 1) == 0
 
 
@@ -111,13 +111,14 @@ def test_too_many_equality_rows_are_rejected_loudly():
         convexifier.convexify(A, B, Q, R, N, G=np.ones((convexifier.NG_MAX + 1, 3)))
 
 
-def test_large_blocks_with_constraint_rows_are_rejected_loudly():
-    """32 < nx + nu <= 64 runs the plain Step 1 model (generic per-stage kernels); G / C rows, Step 3 and anything above 64 raise before any device call."""
+def test_large_blocks_limits_are_rejected_loudly():
+    """32 < nx + nu <= 64 runs Steps 1 and 2 (generic per-stage kernels, with the multipliers of G / C); Step 3 there and anything above 64 raise
+    NotImplementedError before any device call."""
     from tunempc_amd import convexifier
     nx, nu = 30, 10
-    A = np.eye(nx) * 0.5; B = np.ones((nx, nu)); Q = -np.eye(nx); R = np.eye(nu); N = np.zeros((nx, nu))
-    with pytest.raises(NotImplementedError, match='G / C rows'):
-        convexifier.convexify(A, B, Q, R, N, G=np.ones((1, nx + nu)))
+    Ab = np.tile(np.eye(nx) * 0.5, (1, 2, 1, 1)); Bb = np.ones((1, 2, nx, nu)); Hb = np.tile(np.eye(nx + nu), (1, 2, 1, 1))
+    with pytest.raises(NotImplementedError, match='Step 3'):
+        convexifier.convexify_step3_batch(Ab, Bb, Hb, 1e-2)
     nx, nu = 50, 20
     A = np.eye(nx) * 0.5; B = np.ones((nx, nu)); Q = -np.eye(nx); R = np.eye(nu); N = np.zeros((nx, nu))
     with pytest.raises(NotImplementedError, match='up to nx \\+ nu = 64'):

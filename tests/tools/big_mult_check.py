@@ -51,7 +51,8 @@ def main():
             (a1, a2), (b1, b2) = res
             print(f'n={nx + mb} p={p} ng={ng} nc={nc}: step2 tuned-vs-generic Hc {max(rel(b2["Hc"][b], a2["Hc"][b]) for b in range(nb)):.2e} iters {a2["iters"]} {b2["iters"]} status {a2["status"]} {b2["status"]}'
                   + (f' | eq Hc {max(rel(b1["Hc"][b], a1["Hc"][b]) for b in range(nb)):.2e} iters {a1["iters"]} {b1["iters"]}' if ng else ''), flush=True)
-    for (seed, nb, p, nx, mb, ng, nc) in [(21, 1, 3, 24, 10, 2, 3), (22, 1, 4, 20, 16, 3, 2), (23, 1, 2, 30, 12, 0, 4), (24, 1, 3, 26, 8, 2, 0)]:
+    for (seed, nb, p, nx, mb, ng, nc) in [(31, 1, 3, 8, 4, 20, 18), (32, 1, 2, 20, 10, 24, 24), (33, 1, 3, 12, 6, 31, 0), (21, 1, 3, 24, 10, 2, 3), (22, 1, 4, 20, 16, 3, 2), (23, 1, 2, 30, 12, 0, 4), (24, 1, 3, 26, 8, 2, 0),
+                                          (34, 1, 2, 36, 12, 24, 24)]:
         A, B, H, G, C, ncnt = model(seed, nb, p, nx, mb, ng, nc)
         t0 = time.time()
         r, Hc = oracle_step2(A[0], B[0], H[0], G[0], C[0], ncnt[0], 1e-2)

@@ -16,6 +16,7 @@ FLAG_FAST_EXIT = 4      # stop after the first full centering step (see include/
 STATUS_NAMES = {0: 'Optimal', 1: 'Feasible', 2: 'Infeasible'}
 
 # every symbol declared in include/tunempc_hip.h (the drop-in boundary) ...
+ARROW_LD = 32       # tunempc_hip.h: TMPC_ARROW_LD
 EXPORTS = [
     'tmpc_device_count', 'tmpc_workspace_bytes', 'tmpc_workspace_bytes_eq', 'tmpc_workspace_bytes_con',
     'tmpc_create', 'tmpc_create_eq', 'tmpc_create_con', 'tmpc_destroy', 'tmpc_get_chunk', 'tmpc_set_options', 'tmpc_set_tight', 'tmpc_set_tuning', 'tmpc_create_ex',
@@ -478,10 +479,10 @@ class HipConvexifier:
         return dict(X1=X1, X2=X2, x0=sc[:, 0].copy(), tau=sc[:, 1].copy(), alpha=sc[:, 2].copy(), mu_target=sc[:, 3].copy())
 
     def dual_con(self, nb, arrows=False):
-        """Dual side of the stage-local multipliers of the last wave (tmpc_get_dual_con_host): dict(phi, z [nb,p,ng+nc][, aX [nb,p,2,17,17], at [nb,p,2]])."""
+        """Dual side of the stage-local multipliers of the last wave (tmpc_get_dual_con_host): dict(phi, z [nb,p,ng+nc][, aX [nb,p,2,32,32], at [nb,p,2]])."""
         nr = self.ng + self.nc
         phi = np.zeros((nb, self.p, nr)); z = np.zeros_like(phi)
-        aX = np.zeros((nb, self.p, 2, 17, 17)) if arrows else None; at = np.zeros((nb, self.p, 2)) if arrows else None
+        aX = np.zeros((nb, self.p, 2, ARROW_LD, ARROW_LD)) if arrows else None; at = np.zeros((nb, self.p, 2)) if arrows else None
         _check(self.lib, self.lib.tmpc_get_dual_con_host(self._h, int(nb), _dptr(phi), _dptr(z), _dptr(aX) if arrows else None, _dptr(at) if arrows else None), 'tmpc_get_dual_con_host')
         out = dict(phi=phi, z=z)
         if arrows:

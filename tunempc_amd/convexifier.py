@@ -26,9 +26,9 @@ _MAX_CHUNK = 512     # problems per workspace chunk the drop-in paths ever ask f
 DEFAULT_TOL = 2.0 ** -25
 
 
-NG_MAX = 16      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
+NG_MAX = 31      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
 N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (Steps 1 and 2; nx <= 55 there)
-NC_MAX = 16      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
+NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
 def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):

@@ -161,7 +161,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.sscr = schur_in_lds(dm) ? nullptr : c.take<double>(BP * 10 * nxx);
   w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
-  w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.Fg = nullptr;
+  w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.prs = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
   if (dm.nr > 0) {
     const size_t g = dm.nr, z = dm.nz;
@@ -169,6 +169,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
     w.corrp = c.take<double>(BP * g); w.Fg = c.take<double>(BP * g);
     w.pvec = c.take<double>(BP * 2 * g * (2 * dm.n + 2 * dm.nx)); w.psm = c.take<double>(BP * (z * z + 6 * z));
     w.asum = c.take<double>(BP * 5);
+    if (dm.nr > NRS) w.prs = c.take<double>(BP * 4 * g * g);
     double* dG = c.take<double>(BP * g * dm.n);
     int32_t* dn = c.take<int32_t>(BP);
     if (h) { h->dG = dG; h->dncnt = dn; }
@@ -420,10 +421,12 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_phi_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -656,8 +659,13 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
     if (big) hipLaunchKernelGGL(kb_stage_pre, dim3(BP), dim3(256), 0, st, w, dm);
     else TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
-    if (eq && big) hipLaunchKernelGGL(k_phi_pre<true>, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS_BIG * sizeof(double), st, w, dm, 1);
-    else if (eq) hipLaunchKernelGGL(k_phi_pre<false>, dim3(BP), dim3(64), (size_t)PHI_PRE_LDS * sizeof(double), st, w, dm, 1);
+    if (eq) {        // <n above 32, more than 32 rows per stage>
+      const bool bigr = dm.nr > NRS;
+      if (big && bigr) hipLaunchKernelGGL((k_phi_pre<true, true>), dim3(BP), dim3(64), (size_t)phi_pre_lds(true, true) * sizeof(double), st, w, dm, 1);
+      else if (big) hipLaunchKernelGGL((k_phi_pre<true, false>), dim3(BP), dim3(64), (size_t)phi_pre_lds(true, false) * sizeof(double), st, w, dm, 1);
+      else if (bigr) hipLaunchKernelGGL((k_phi_pre<false, true>), dim3(BP), dim3(64), (size_t)phi_pre_lds(false, true) * sizeof(double), st, w, dm, 1);
+      else hipLaunchKernelGGL((k_phi_pre<false, false>), dim3(BP), dim3(64), (size_t)phi_pre_lds(false, false) * sizeof(double), st, w, dm, 1);
+    }
     if (t3) hipLaunchKernelGGL(k_t3_pre, dim3(BP), dim3(64), t3_lds, st, w, dm);
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
@@ -832,6 +840,8 @@ static bool rows_ok(int nx, int ng, int nc) {
   (void)nx;
   return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM;
 }
+static_assert(AEL == TMPC_ARROW_LD, "tunempc_hip.h: leading dimension of the exported arrow blocks");
+static_assert(NGM == TMPC_MAX_ROWS && NCM == TMPC_MAX_ROWS, "tunempc_hip.h: row limits");
 static uint64_t workspace_bytes(int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
   if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
   WS w;

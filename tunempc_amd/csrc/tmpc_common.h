@@ -84,10 +84,11 @@ struct Dims {
   int constr;   // 1: Step 2 model (convexifier.py:116-131): multipliers of C_k and the rho-norm terms
   int nT;       // Step 3 (convexifier.py:137-147): n(n+1)/2 entries of the regularisation T_k per stage (0: none); + 1 epigraph variable (tmpc_t3.h)
 };
-constexpr int NGM = 16;  // max ng
-constexpr int NCM = 16;  // max rows of C_k
-constexpr int NRM = NGM + NCM, NZM = NRM + 2;
-constexpr int NAM = 16;  // max rows under one norm term; its arrow LMI is (NAM+1) x (NAM+1)
+constexpr int NGM = 31;  // max ng
+constexpr int NCM = 31;  // max rows of C_k
+constexpr int NRM = NGM + NCM, NZM = NRM + 2;      // (nz <= 64: one lane per stage-local variable)
+constexpr int NRS = 32, NZS = NRS + 2;             // up to NRS rows per stage the multiplier kernels keep their per-row vectors and Gram products in LDS (tmpc_phi.h)
+constexpr int NAM = 31;  // max rows under one norm term; its arrow LMI is (NAM+1) x (NAM+1): one 32 x 33 LDS slot
 constexpr int AEL = NAM + 1, AE = AEL * AEL;
 
 struct Opts {
@@ -154,6 +155,7 @@ struct WS {
   double* phi; double* zph; double* dphi; double* dzph; double* corrp;   // [B,p,nr] multipliers (slack = phi itself), their duals, directions, Mehrotra term
   double* pvec;    // [B,p,2,nr,2n+2nx]  per cone block r and row i: w = X_r g, u = S_r^-1 g, V w, V u
   double* psm;     // [B,p,nz*nz+6*nz]   K = T_zz^-1, c_tau, c_alpha, K c_tau, K c_alpha, r_z, K r_z
+  double* prs;     // [B,p,4,nr,nr]      handles with more than NRS rows per stage: the Gram products g_i' X_r g_j, g_i' S_r^-1 g_j of k_phi_pre (else null: LDS)
   double* Fg;      // [B,p,nr] output: phi / (s*alpha)
   // norm terms t >= ||w v|| as arrow LMIs S = [[t, w v'], [w v, t I]] (always feasible: S is rebuilt from t and phi), up to two per stage
   double* at; double* adt;              // [B,p,2]   epigraph variables and their directions

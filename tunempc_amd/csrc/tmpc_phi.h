@@ -152,15 +152,19 @@ __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
 }
 
 // LDS of k_phi_pre (doubles)
-constexpr int PHI_PRE_LDS = 4 * MS + NRM * NMAX + 4 * NRM * NMAX + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;
-constexpr int PHI_PRE_LDS_BIG = 4 * MS + 4 * NRM * NB + 4 * NRM * NRM + NZM * (2 * NZM + 1) + 4 * NZM;      // (152 KB: one workgroup per CU)
+constexpr int phi_pre_lds(bool bign, bool bigr) {
+  return 4 * MS + (bigr ? NZM * (2 * NZM + 1) + 4 * NZM
+                        : (bign ? 0 : NRS * NMAX) + 4 * NRS * (bign ? NB : NMAX) + 4 * NRS * NRS + NZS * (2 * NZS + 1) + 4 * NZS);
+}
 // after k_stage_pre (needs S_r^-1), before k_ctrl_a: vectors w, u, V w, V u; K; c_tau, c_alpha; border / mu / pinf partials
 // aug: the multipliers stay in the block system (k_aug_fill): T_loc,loc itself is stored instead of its inverse and the border
 // scalars are left alone.
 // BIGN (32 < n <= 64, with the generic per-stage kernels of tmpc_big.h): the n x n matrices and the Jacobian rows are read where they
 // lie in global memory instead of LDS slots (every entry is used once per row of [G; C]); the vectors are 64 long; the arrow blocks
-// (at most 17 x 17) keep the four LDS slots.  Same arithmetic in the same order: at n <= 32 both forms return the same bits.
-template <bool BIGN>
+// keep the four LDS slots.  Same arithmetic in the same order: at n <= 32 both forms return the same bits.
+// BIGR (handles with room for more than NRS = 32 rows per stage, up to 31 + 31): the per-row vectors stay in their place of pvec and the
+// Gram products in WS::prs (global memory) -- only T_loc,loc (64 x 129) and the arrow slots are in LDS.
+template <bool BIGN, bool BIGR>
 __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), lane = threadIdx.x;
@@ -172,25 +176,31 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   const int n = dm.n, nx = dm.nx, nn = n * n, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sX = sm; double* sSi = sm + MS; double* sHb = sm + 2 * MS; double* sV = sm + 3 * MS;
   constexpr int NV = BIGN ? NB : NMAX;      // stride of the per-row vectors
-  double* gl = sm + 4 * MS;                 // [nrow][NMAX]   (BIGN: the rows are read from global memory)
-  double* wl = gl + (BIGN ? 0 : NRM * NMAX); // [2][nrow][NV]
-  double* ul = wl + 2 * NRM * NV;           // [2][nrow][NV]
-  double* GXG = ul + 2 * NRM * NV;          // [2][NRM][NRM]
-  double* GSG = GXG + 2 * NRM * NRM;        // [2][NRM][NRM]
-  double* Tm = GSG + 2 * NRM * NRM;         // [NZM][2*NZM+1]  T_loc,loc | I  ->  I | K
-  double* ctl = Tm + NZM * (2 * NZM + 1); double* cal = ctl + NZM; double* rres = cal + NZM; double* kv = rres + NZM;
-  constexpr int TL = 2 * NZM + 1;
+  constexpr int NZ_ = BIGR ? NZM : NZS;
+  double* gl = sm + 4 * MS;                 // [nrow][NMAX]   (BIGN, BIGR: the rows are read from global memory)
+  double* wl = gl + ((BIGN || BIGR) ? 0 : NRS * NMAX);  // [2][nrow][NV]
+  double* ul = wl + (BIGR ? 0 : 2 * NRS * NV);          // [2][nrow][NV]
+  double* GXGl = ul + (BIGR ? 0 : 2 * NRS * NV);        // [2][NRS][NRS]
+  double* GSGl = GXGl + (BIGR ? 0 : 2 * NRS * NRS);     // [2][NRS][NRS]
+  double* Tm = GSGl + (BIGR ? 0 : 2 * NRS * NRS);       // [NZ_][2*NZ_+1]  T_loc,loc | I  ->  I | K
+  double* ctl = Tm + NZ_ * (2 * NZ_ + 1); double* cal = ctl + NZ_; double* rres = cal + NZ_; double* kv = rres + NZ_;
+  constexpr int TL = 2 * NZ_ + 1;
+  const int gs = BIGR ? dm.nr : NRS;        // stride of the Gram products
+  double* GXG = BIGR ? w.prs + (size_t)sid * 4 * dm.nr * dm.nr : GXGl;
+  double* GSG = BIGR ? GXG + 2 * dm.nr * dm.nr : GSGl;
+  auto WV = [&](int r, int i) -> double* { return BIGR ? pv_at(w.pvec, dm, sid, r, i) : wl + (r * NRS + i) * NV; };        // w_ri = X_r g_i
+  auto UV = [&](int r, int i) -> double* { return BIGR ? pv_at(w.pvec, dm, sid, r, i) + n : ul + (r * NRS + i) * NV; };    // u_ri = S_r^-1 g_i
   const double* Gg = w.G + (size_t)sid * dm.nr * n;
   // matrices: LDS slots (stride LD) or, BIGN, global memory (stride n)
-  const int ldm = BIGN ? n : LD, ldg = BIGN ? n : NMAX;
+  const int ldm = BIGN ? n : LD, ldg = (BIGN || BIGR) ? n : NMAX;
   const double* mHb = BIGN ? w.Hb + (size_t)sid * nn : sHb; const double* mV = BIGN ? w.V + (size_t)sid * nx * n : sV;
-  const double* mG = BIGN ? Gg : gl;
+  const double* mG = (BIGN || BIGR) ? Gg : gl;
+  if (!BIGN && !BIGR) { for (int e = lane; e < ng * n; e += 64) gl[(e / n) * NMAX + (e % n)] = Gg[e]; }
   if (!BIGN) {
-    for (int e = lane; e < ng * n; e += 64) gl[(e / n) * NMAX + (e % n)] = Gg[e];
     g2s(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
     g2s(sV, w.V + (size_t)sid * nx * n, nx, n, n, lane);
   }
-  if (lane < NZM) { ctl[lane] = 0.0; cal[lane] = 0.0; rres[lane] = 0.0; }
+  if (lane < NZ_) { ctl[lane] = 0.0; cal[lane] = 0.0; rres[lane] = 0.0; }
   for (int r = 0; r < 2; ++r) {
     const double* mX = BIGN ? (r ? w.X2 : w.X1) + (size_t)sid * nn : sX; const double* mSi = BIGN ? (r ? w.S2i : w.S1i) + (size_t)sid * nn : sSi;
     if (!BIGN) {
@@ -201,14 +211,15 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
       if (lane < n) {
         double a0 = 0.0, a1 = 0.0;
         for (int c = 0; c < n; ++c) { const double g = mG[i * ldg + c]; a0 = fma(mX[lane * ldm + c], g, a0); a1 = fma(mSi[lane * ldm + c], g, a1); }
-        wl[(r * NRM + i) * NV + lane] = a0; ul[(r * NRM + i) * NV + lane] = a1;
+        WV(r, i)[lane] = a0; UV(r, i)[lane] = a1;
       }
     }
+    if (BIGR) __threadfence_block();
     wsync();
     for (int i = 0; i < ng; ++i) {
       double* pv = pv_at(w.pvec, dm, sid, r, i);
-      const double* wi = wl + (r * NRM + i) * NV; const double* ui = ul + (r * NRM + i) * NV;
-      if (lane < n) { pv[lane] = wi[lane]; pv[n + lane] = ui[lane]; }
+      const double* wi = WV(r, i); const double* ui = UV(r, i);
+      if (!BIGR && lane < n) { pv[lane] = wi[lane]; pv[n + lane] = ui[lane]; }
       if (lane < nx) {
         double a0 = 0.0, a1 = 0.0;
         for (int c = 0; c < n; ++c) { a0 = fma(mV[lane * ldm + c], wi[c], a0); a1 = fma(mV[lane * ldm + c], ui[c], a1); }
@@ -222,12 +233,13 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
       wu = wave_sum(wu);
       if (lane == 0) { cal[i] += hu; if (r == 1) ctl[i] = -wu; }
       for (int j = 0; j < ng; ++j) {
-        double x = (lane < n) ? mG[i * ldg + lane] * wl[(r * NRM + j) * NV + lane] : 0.0;
-        double y = (lane < n) ? mG[i * ldg + lane] * ul[(r * NRM + j) * NV + lane] : 0.0;
+        double x = (lane < n) ? mG[i * ldg + lane] * WV(r, j)[lane] : 0.0;
+        double y = (lane < n) ? mG[i * ldg + lane] * UV(r, j)[lane] : 0.0;
         x = wave_sum(x); y = wave_sum(y);
-        if (lane == 0) { GXG[(r * NRM + i) * NRM + j] = x; GSG[(r * NRM + i) * NRM + j] = y; }
+        if (lane == 0) { GXG[(r * gs + i) * gs + j] = x; GSG[(r * gs + i) * gs + j] = y; }
       }
     }
+    if (BIGR) __threadfence_block();
     wsync();
   }
   const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
@@ -238,7 +250,7 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
     if (j >= nz) t = (j - nz == i) ? 1.0 : 0.0;
     else if (i < ng && j < ng) {
       for (int r = 0; r < 2; ++r)
-        t += 0.5 * (GXG[(r * NRM + i) * NRM + j] * GSG[(r * NRM + j) * NRM + i] + GXG[(r * NRM + j) * NRM + i] * GSG[(r * NRM + i) * NRM + j]);
+        t += 0.5 * (GXG[(r * gs + i) * gs + j] * GSG[(r * gs + j) * gs + i] + GXG[(r * gs + j) * gs + i] * GSG[(r * gs + i) * gs + j]);
       if (i == j) t += z[i] / phi[i];
     }
     Tm[i * TL + j] = t;
@@ -246,7 +258,7 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   double xs = 0.0;
   if (lane < ng) {
     xs = phi[lane] * z[lane];
-    rres[lane] = -(GXG[(0 * NRM + lane) * NRM + lane] - GXG[(1 * NRM + lane) * NRM + lane]) - z[lane];     // stationarity residual of phi_i
+    rres[lane] = -(GXG[(0 * gs + lane) * gs + lane] - GXG[(1 * gs + lane) * gs + lane]) - z[lane];     // stationarity residual of phi_i
   }
   xs = wave_sum(xs);
   wsync();
