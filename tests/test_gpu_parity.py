@@ -1314,3 +1314,49 @@ def test_dropin_convexify_large_block_with_constraints():
     want2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], G=np.stack(G), Fg=r2['Fg'], C=C, F=r2['F'])[0]
     assert int(o2['status'][0]) == 0 and rel(o2['dHc'][0], want2) < 1e-7
     convexifier.release_handles()
+
+
+# ----------------------------------------------------------------------------- Step 3 on the generic per-stage kernels
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(1, 2, 3, 3, 2), (2, 2, 4, 6, 2), (3, 1, 2, 12, 4)])
+def test_step3_generic_stage_kernels_match_the_tuned_ones(seed, nb, p, nx, mb):
+    """debug flag 64 with Step 3: k_t3_schur<true> (X_r, S_r^-1 read from global memory, X_r V' / S_r^-1 V' in the stage scratch) and the T_k terms of the generic
+    per-stage kernels against the tuned kernels -- same iteration counts, Hc and T to 1e-9; also with rows of G / C in the same solve"""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H = co.gen_batch(700 + seed, nb, p, nx, mb)
+    res = []
+    for flags in (0, 64):
+        h = HipConvexifier(p, nx, mb, chunk=nb, step3=True, flags=flags)
+        res.append(h.convexify_step3_batch(A, B, H, 1e-2))
+        h.close()
+    a, g = res
+    assert np.array_equal(a['status'], g['status']) and np.array_equal(a['iters'], g['iters']) and (a['iters'] > 0).all()
+    assert rel(g['Hc'], a['Hc']) < 1e-9 and rel(g['T'], a['T']) < 1e-9
+    ng, nc = 2, 3
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((nb, p, ng + nc, nx + mb)); ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            J[b, k, ng + ncnt[b, k]:] = 0.0
+    res = []
+    for flags in (0, 64):
+        h = HipConvexifier(p, nx, mb, chunk=nb, ng=ng, nc=nc, step3=True, flags=flags)
+        res.append(h.convexify_step3_con_batch(A, B, H, J, ncnt, 1e-2))
+        h.close()
+    a, g = res
+    assert np.array_equal(a['status'], g['status']) and np.array_equal(a['iters'], g['iters'])
+    assert rel(g['Hc'], a['Hc']) < 1e-9 and rel(g['T'], a['T']) < 1e-9 and np.abs(g['FgF'] - a['FgF']).max() < 1e-9 * max(1.0, np.abs(a['FgF']).max())
+
+
+def test_step3_large_stage_block():
+    """Step 3 at nx + nu = 34 (blocks of 300 + 595 + 1 = 896) against the numpy oracle: Hc, T (every entry > 0), kappa"""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb = 2, 24, 10
+    A, B, H = co.gen_batch(300, 1, p, nx, mb)
+    h = HipConvexifier(p, nx, mb, chunk=1, step3=True)
+    o = h.convexify_step3_batch(A, B, H, 1e-2)
+    h.close()
+    r = co.sdp_step1(A[0], B[0], H[0], rho=1e-2, force=True)
+    dHc = co.convex_hessian_suppl(A[0], B[0], r['P'], T=r['T'])[0]
+    assert int(o['status'][0]) == 0 and r['ipm_status'] == 'optimal'
+    assert rel(o['Hc'][0], H[0] + dHc) < PARITY and rel(o['T'][0], r['T']) < PARITY and (o['T'][0] > 0).all()
+    assert abs(o['kappa'][0] - r['kappa']) < 1e-9 * r['kappa']

@@ -112,10 +112,14 @@ def test_too_many_equality_rows_are_rejected_loudly():
 
 
 def test_large_blocks_limits_are_rejected_loudly():
-    """32 < nx + nu <= 64 runs Steps 1 and 2 (generic per-stage kernels, with the multipliers of G / C); Step 3 there and anything above 64 raise
-    NotImplementedError before any device call."""
+    """32 < nx + nu <= 64 runs every step on the generic per-stage kernels; Step 3 there only while its blocks (svec(P) + the n(n+1)/2 entries of T_k) fit the LDS
+    image of the substitution kernels; that and anything above 64 raise NotImplementedError before any device call."""
     from tunempc_amd import convexifier
-    nx, nu = 30, 10
+    from tunempc_amd._lib import load_library
+    lib = load_library()
+    assert lib.tmpc_workspace_bytes_step3(1, 2, 30, 10) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 40, 8) == 0      # blocks of 1286 fit, 1997 do not
+    assert lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 24, 24) > 0 and lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 32, 0) == 0      # rows: up to 31 + 31
+    nx, nu = 40, 8
     Ab = np.tile(np.eye(nx) * 0.5, (1, 2, 1, 1)); Bb = np.ones((1, 2, nx, nu)); Hb = np.tile(np.eye(nx + nu), (1, 2, 1, 1))
     with pytest.raises(NotImplementedError, match='Step 3'):
         convexifier.convexify_step3_batch(Ab, Bb, Hb, 1e-2)

@@ -18,7 +18,7 @@ import numpy as np
 from . import mtools
 from . import preprocessing
 from .logger import Logger
-from ._lib import HipConvexifier, STATUS_NAMES
+from ._lib import HipConvexifier, STATUS_NAMES, load_library
 
 _HANDLES = {}        # (p, nx, mb, ng) -> HipConvexifier; at most _MAX_HANDLES shapes stay resident (least recently used goes first)
 _MAX_HANDLES = 4
@@ -27,7 +27,7 @@ DEFAULT_TOL = 2.0 ** -25
 
 
 NG_MAX = 31      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
-N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (Steps 1 and 2; nx <= 55 there)
+N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (every step; nx <= 55 there, Step 3 while its blocks fit)
 NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
@@ -36,12 +36,13 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
     pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
     of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk."""
-    if nx + mb > N_TUNED and step3:
-        # 32 < n <= 64 runs on the generic per-stage kernels (csrc/tmpc_big.h): Steps 1 and 2, with the multipliers of G / C; the Step 3 kernels (tmpc_t3.h) are
-        # written around 32 x 33 LDS tiles
-        raise NotImplementedError('the HIP path handles Step 3 (force=True) up to nx + nu = {} (got {}); Steps 1 and 2 up to {}'.format(N_TUNED, nx + mb, N_MAX))
     if nx + mb > N_MAX:
         raise NotImplementedError('the HIP path handles stage blocks up to nx + nu = {} (got {})'.format(N_MAX, nx + mb))
+    if step3 and load_library().tmpc_workspace_bytes_step3_con(1, p, nx, mb, ng, nc) == 0:
+        # 32 < n <= 64 runs on the generic per-stage kernels (csrc/tmpc_big.h) for every step; the blocks of Step 3 carry the n(n+1)/2 entries of T_k and must fit
+        # the LDS image of the substitution kernels (nx(nx+1)/2 + n(n+1)/2 + 1 + rows <= 1552: n = 40 with nx = 30 fits, n = 48 does not)
+        raise NotImplementedError('Step 3 (force=True) at nx = {}, nx + nu = {}: Schur blocks of nx(nx+1)/2 + n(n+1)/2 + 1 + multipliers exceed what the '
+                                  'substitution kernels hold in LDS (1552)'.format(nx, nx + mb))
     key = (p, nx, mb, ng, bool(step3))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
     want = 1
     while want < min(max(int(nb), 1), _MAX_CHUNK):

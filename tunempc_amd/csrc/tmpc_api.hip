@@ -429,7 +429,8 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_rhs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_phi_dir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_update, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -610,8 +611,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   dm.nt = (dm.dp + TB - 1) / TB;
   dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
-  const size_t t3_schur_lds = (size_t)(10 * 32 * T3_LD + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
-  const bool big = dm.n > NMAX || ((h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE) && !t3);      // generic per-stage kernels (tmpc_big.h)
+  const bool big = dm.n > NMAX || (h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE);      // generic per-stage kernels (tmpc_big.h)
+  const size_t t3_schur_lds = (size_t)((big ? 0 : 9 * 32 * T3_LD) + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
   if (big && !ln->ws.bscr) {                 // (debug flag at n <= 32: the scratch is not part of the workspace)
     if (hipMalloc(&ln->big_scr, (size_t)h->dm.B * dm.p * BIG_SCR * dm.n * dm.n * sizeof(double)) != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc of the generic-stage scratch failed"); return TMPC_E_NOMEM; }
     ln->ws.bscr = (double*)ln->big_scr;
@@ -684,7 +685,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       }
     }
     if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
-    if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
+    if (t3 && nfac > 0 && big) hipLaunchKernelGGL(k_t3_schur<true>, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
+    else if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur<false>, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (h->flags & TMPC_DEBUG_FLAG_STOP_ASSEMBLED) {   // debug (tunempc_hip_debug.h; tests/tools/step3_asm_check.py): stop with the assembled, unfactored system of the first iteration in the workspace
       if (big) hipLaunchKernelGGL(kb_stage_rhs, dim3(BP), dim3(256), 0, st, w, dm, 1);
@@ -846,6 +848,7 @@ static uint64_t workspace_bytes(int chunk, int p, int nx, int mb, int ng, int nc
   if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
   WS w;
   Dims dm = make_dims(chunk, p, nx, mb, ng, nc, step3);
+  if (solve_lds(dm) > 160 * 1024) return 0;      // blocks (d + multipliers + entries of T_k) beyond the LDS image of the substitution kernels
   return (uint64_t)carve(w, dm, nullptr, nullptr);
 }
 uint64_t tmpc_workspace_bytes_con(int chunk, int p, int nx, int mb, int ng, int nc) { return workspace_bytes(chunk, p, nx, mb, ng, nc, 0); }
@@ -875,10 +878,12 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
     snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
   }
-  if (nx + mb > NMAX) {      // the generic per-stage kernels (tmpc_big.h): Steps 1 and 2 (no Step 3), blocks that the LDS images of k_schur and of the substitutions can hold
-    const Dims db = make_dims(1, p, nx, mb, ng, nc, 0);
-    if (step3) { snprintf(g_err, sizeof(g_err), "nx+mb=%d > %d: Steps 1 and 2 only (no Step 3 regularisation T_k)", nx + mb, NMAX); return TMPC_E_UNSUPPORTED; }
-    if (solve_lds(db) > 160 * 1024) { snprintf(g_err, sizeof(g_err), "nx=%d: Schur blocks of %d do not fit the LDS image of the substitution kernels (nx <= 55)", nx, db.dp); return TMPC_E_UNSUPPORTED; }
+  {                          // blocks that the LDS images of k_schur and of the substitutions can hold
+    const Dims db = make_dims(1, p, nx, mb, ng, nc, step3);
+    if (solve_lds(db) > 160 * 1024) {
+      snprintf(g_err, sizeof(g_err), "nx=%d ng=%d nc=%d step3=%d: Schur blocks of %d (svec(P) + multipliers + entries of T_k) do not fit the LDS image of the substitution kernels (limit 1552; nx <= 55 for the plain model)", nx, ng, nc, step3, db.dp);
+      return TMPC_E_UNSUPPORTED;
+    }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return TMPC_E_NODEVICE; }

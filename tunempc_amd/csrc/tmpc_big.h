@@ -98,6 +98,15 @@ __device__ __forceinline__ void gadd_gtg(double* M, const double* Gg, const doub
   }
   gsync();
 }
+// M (n x n, global) += scale * smat(theta): the regularisation T_k of Step 3 (add_smat_t3 of tmpc_stage.h)
+__device__ __forceinline__ void gadd_smat(double* M, const double* th, double scale, int n) {
+  for (int e = threadIdx.x; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    M[e] += scale * th[a * n - a * (a - 1) / 2 + (b - a)];
+  }
+  gsync();
+}
 // out (nx x nx) = V G V'   (tq: nx x n scratch)
 __device__ __forceinline__ void gadj_V(double* out, double* tq, const double* V, const double* G, int n, int nx) {
   gmm(tq, n, V, n, 1, G, n, 1, nx, n, n, 0);
@@ -217,6 +226,7 @@ __global__ void __launch_bounds__(256) kb_stage_pre(WS w, Dims dm) {
   double* sM = scr; double* t0 = scr + nn; double* t1 = scr + 2 * nn; double* sPhi = scr + 3 * nn; double* t3 = scr + 4 * nn;
   gbuild_M(sM, t0, V, Hb, w.P + (size_t)sid * nxx, w.P + (size_t)(b * dm.p + kn) * nxx, alpha, n, nx);
   if (dm.nr > 0) gadd_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n);      // + J' diag(phi) J
+  if (dm.nT > 0) gadd_smat(sM, w.t3th + (size_t)sid * dm.nT, 1.0, n);                                                               // + T_k
   double rd2 = 0.0, s2 = 0.0, xs = 0.0, trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0, hbphi = 0.0;
   int nbad = 0;
   for (int r = 0; r < 2; ++r) {
@@ -270,12 +280,14 @@ __global__ void __launch_bounds__(256) kb_stage_pre(WS w, Dims dm) {
       gmm(t0, n, X, n, 1, Si, n, 1, n, n, n, 0);                 // Psi = sym(X2 S2i)
       gsym(t0, n);
       for (int i = tid; i < n; i += 256) trpsi += t0[i * n + i];
+      if (dm.nT > 0) { for (int e = tid; e < nn; e += 256) w.t3psi[so + e] = t0[e]; }
       gadj_V(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t3, V, t0, n, nx);
       gcopy_block(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, nx, t0, n, nx, nx);
       gsync();
     }
   }
   for (int e = tid; e < nn; e += 256) hbphi = fma(Hb[e], sPhi[e], hbphi);
+  if (dm.nT > 0) { for (int e = tid; e < nn; e += 256) w.t3phi[so + e] = sPhi[e]; }
   gadj_V(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t3, V, sPhi, n, nx);
   gcopy_block(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, nx, sPhi, n, nx, nx);
   rd2 = block_sum<256>(rd2); s2 = block_sum<256>(s2); xs = block_sum<256>(xs); trx2 = block_sum<256>(trx2); hby = block_sum<256>(hby);
@@ -334,6 +346,7 @@ __global__ void __launch_bounds__(256) kb_stage_dir(WS w, Dims dm, int pass) {
   const double* dPk = w.dP + (size_t)sid * nxx;
   gbuild_M(dM, t0, V, Hb, dPk, w.dP + (size_t)(b * dm.p + kn) * nxx, dalpha, n, nx);
   if (dm.nr > 0) gadd_gtg(dM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n);     // + J' diag(dphi) J
+  if (dm.nT > 0) gadd_smat(dM, w.t3dth + (size_t)sid * dm.nT, 1.0, n);                                                             // + dT_k
   double dxs = 0.0, xds = 0.0, dxds = 0.0;
   for (int r = 0; r < 2; ++r) {
     const double* X = (r ? w.X2 : w.X1) + so; const double* S = (r ? w.S2 : w.S1) + so; const double* Si = (r ? w.S2i : w.S1i) + so;
@@ -432,6 +445,15 @@ __global__ void __launch_bounds__(256) kb_final_stage(WS w, Dims dm) {
     const int nrow = stage_rows(w, dm, sid);
     if (tid < dm.nr) w.Fg[(size_t)sid * dm.nr + tid] = (tid < nrow) ? sc * w.phi[(size_t)sid * dm.nr + tid] : 0.0;
     gadd_gtg(sM, w.G + (size_t)sid * dm.nr * n, w.phi + (size_t)sid * dm.nr, sc, nrow, n);
+  }
+  if (dm.nT > 0) {                          // T_k = s_T theta / (s_alpha alpha) and its term of the supplement
+    const double* th = w.t3th + (size_t)sid * dm.nT;
+    gadd_smat(sM, th, sc, n);
+    for (int e = tid; e < nn; e += 256) {
+      const int i = e / n, j = e - i * n;
+      const int a = i < j ? i : j, bq = i < j ? j : i;
+      w.Tout[so + e] = sc * th[a * n - a * (a - 1) / 2 + (bq - a)];
+    }
   }
   gsym(sM, n);
   for (int e = tid; e < nn; e += 256) { const double dh = sM[e]; w.dHc[so + e] = dh; w.Hc[so + e] = sH[e] + dh; }

@@ -149,7 +149,10 @@ __device__ __forceinline__ double hk_rect(const double* __restrict__ L, const do
 }
 
 // ---------------------------------------------------------------- after k_schur (which writes identity in the padding): rows of theta_k, t_k in block k+1
+// BIGN (32 < n <= 64): X_r, S_r^-1 are read where they lie in global memory and X_r V', S_r^-1 V' go to the scratch matrices of the generic per-stage
+// kernels (WS::bscr, slots 0 .. 3); only the vectors and the index tables are in LDS
 constexpr int T3_LD = 33;
+template <bool BIGN>
 __global__ void __launch_bounds__(256) k_t3_schur(WS w, Dims dm) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), tid = threadIdx.x;
@@ -164,21 +167,31 @@ __global__ void __launch_bounds__(256) k_t3_schur(WS w, Dims dm) {
   const double wr = t3_wr(w, pr);
   const T3Ptr q = t3_at(w, dm, sid);
   // LDS: X_r, Si_r (n x n), XV_r = X_r V', SV_r = Si_r V' (n x nx), all with leading dimension 33; v, J v, w c, theta-pairs
-  double* Xr[2]; double* Sr[2]; double* XV[2]; double* SV[2];
+  const double* Xr[2]; const double* Sr[2]; double* XV[2]; double* SV[2];
   const int msz = 32 * T3_LD;
-  Xr[0] = sm; Sr[0] = sm + msz; Xr[1] = sm + 2 * msz; Sr[1] = sm + 3 * msz;
-  XV[0] = sm + 4 * msz; SV[0] = sm + 5 * msz; XV[1] = sm + 6 * msz; SV[1] = sm + 7 * msz;
-  double* sV = sm + 8 * msz;                 // V (nx x n)
-  double* vv = sV + msz;                     // [m1] v
+  const int ldx = BIGN ? n : T3_LD, ldv = BIGN ? nx : T3_LD;
+  double* vv = BIGN ? sm : sm + 9 * msz;     // [m1] v
   double* wc = vv + m1;                      // [m] w c_e
   short* ea = (short*)(wc + m1); short* eb = ea + m1;       // entry e -> (a, b), n-space
   short* ca = eb + m1; short* cb = ca + d + 1;               // column (cd) -> (c, d), nx-space
-  for (int e = tid; e < nn; e += 256) {
-    const int i = e / n, j = e - i * n;
-    Xr[0][i * T3_LD + j] = w.X1[(size_t)sid * nn + e]; Sr[0][i * T3_LD + j] = w.S1i[(size_t)sid * nn + e];
-    Xr[1][i * T3_LD + j] = w.X2[(size_t)sid * nn + e]; Sr[1][i * T3_LD + j] = w.S2i[(size_t)sid * nn + e];
+  const double* mV;
+  if (BIGN) {
+    double* scr = w.bscr + (size_t)sid * BIG_SCR * nn;
+    Xr[0] = w.X1 + (size_t)sid * nn; Sr[0] = w.S1i + (size_t)sid * nn; Xr[1] = w.X2 + (size_t)sid * nn; Sr[1] = w.S2i + (size_t)sid * nn;
+    XV[0] = scr; SV[0] = scr + nn; XV[1] = scr + 2 * nn; SV[1] = scr + 3 * nn;
+    mV = w.V + (size_t)sid * nx * n;
+  } else {
+    double* X0 = sm; double* S0 = sm + msz; double* X1 = sm + 2 * msz; double* S1 = sm + 3 * msz;
+    XV[0] = sm + 4 * msz; SV[0] = sm + 5 * msz; XV[1] = sm + 6 * msz; SV[1] = sm + 7 * msz;
+    double* sV = sm + 8 * msz;                 // V (nx x n)
+    for (int e = tid; e < nn; e += 256) {
+      const int i = e / n, j = e - i * n;
+      X0[i * T3_LD + j] = w.X1[(size_t)sid * nn + e]; S0[i * T3_LD + j] = w.S1i[(size_t)sid * nn + e];
+      X1[i * T3_LD + j] = w.X2[(size_t)sid * nn + e]; S1[i * T3_LD + j] = w.S2i[(size_t)sid * nn + e];
+    }
+    for (int e = tid; e < nx * n; e += 256) { const int i = e / n, j = e - i * n; sV[i * T3_LD + j] = w.V[(size_t)sid * nx * n + e]; }
+    Xr[0] = X0; Sr[0] = S0; Xr[1] = X1; Sr[1] = S1; mV = sV;
   }
-  for (int e = tid; e < nx * n; e += 256) { const int i = e / n, j = e - i * n; sV[i * T3_LD + j] = w.V[(size_t)sid * nx * n + e]; }
   for (int e = tid; e < m1; e += 256) vv[e] = q.v[e];
   for (int e = tid; e < m; e += 256) { int a, bb; t3_ab(e, n, &a, &bb); ea[e] = (short)a; eb[e] = (short)bb; wc[e] = wr * ((a == bb) ? 1.0 : 1.4142135623730951); }
   for (int e = tid; e < d; e += 256) { int a, bb; t3_ab(e, nx, &a, &bb); ca[e] = (short)a; cb[e] = (short)bb; }
@@ -186,9 +199,10 @@ __global__ void __launch_bounds__(256) k_t3_schur(WS w, Dims dm) {
   for (int e = tid; e < 2 * n * nx; e += 256) {          // X_r V', Si_r V'
     const int r = e / (n * nx), rem = e - r * n * nx, a = rem / nx, c = rem - a * nx;
     double sx = 0.0, ss = 0.0;
-    for (int qq = 0; qq < n; ++qq) { sx = fma(Xr[r][a * T3_LD + qq], sV[c * T3_LD + qq], sx); ss = fma(Sr[r][a * T3_LD + qq], sV[c * T3_LD + qq], ss); }
-    XV[r][a * T3_LD + c] = sx; SV[r][a * T3_LD + c] = ss;
+    for (int qq = 0; qq < n; ++qq) { sx = fma(Xr[r][a * ldx + qq], mV[c * ldx + qq], sx); ss = fma(Sr[r][a * ldx + qq], mV[c * ldx + qq], ss); }
+    XV[r][a * ldv + c] = sx; SV[r][a * ldv + c] = ss;
   }
+  if (BIGN) __threadfence_block();
   __syncthreads();
   const double beta = q.beta[0], ib2 = 1.0 / (beta * beta);
   double vsq = 0.0;
@@ -209,13 +223,13 @@ __global__ void __launch_bounds__(256) k_t3_schur(WS w, Dims dm) {
       const int a = ea[i], bb = eb[i];
       if (j < d) {                                         // P columns: b-coupling (P_{k+1}) in D, a-coupling (P_k) in the edge slot
         const int c = ca[j], dd_ = cb[j];
-        val = hk_rect(XV[0], SV[0], T3_LD, a, bb, c, dd_) + hk_rect(XV[1], SV[1], T3_LD, a, bb, c, dd_);
-        aval = -(hk_rect(Xr[0], Sr[0], T3_LD, a, bb, c, dd_) + hk_rect(Xr[1], Sr[1], T3_LD, a, bb, c, dd_));
+        val = hk_rect(XV[0], SV[0], ldv, a, bb, c, dd_) + hk_rect(XV[1], SV[1], ldv, a, bb, c, dd_);
+        aval = -(hk_rect(Xr[0], Sr[0], ldx, a, bb, c, dd_) + hk_rect(Xr[1], Sr[1], ldx, a, bb, c, dd_));
         has_a = true;
       } else if (j >= oT) {                                // theta columns f <= e
         const int f = j - oT;
         const int c = ea[f], dd_ = eb[f];
-        val = hk_rect(Xr[0], Sr[0], T3_LD, a, bb, c, dd_) + hk_rect(Xr[1], Sr[1], T3_LD, a, bb, c, dd_);
+        val = hk_rect(Xr[0], Sr[0], ldx, a, bb, c, dd_) + hk_rect(Xr[1], Sr[1], ldx, a, bb, c, dd_);
         const double jvi = -vv[1 + i], jvf = -vv[1 + f];
         val += wc[i] * wc[f] * ib2 * (((i == f) ? 1.0 : 0.0) + 4.0 * vsq * jvi * jvf - 2.0 * (jvi * vv[1 + f] + vv[1 + i] * jvf));
         if (i == f) val += zz[i] / th[i];
