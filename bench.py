@@ -191,6 +191,32 @@ def small_configs(HipConvexifier, synthetic):
     return out
 
 
+def large_block_configs(HipConvexifier, synthetic):
+    """Stage blocks beyond the tuned kernels' 32 (generic per-stage kernels, register-staged block factorisation): the plain model at n = 48 and the Step 2 model
+    at n = 48 with 24 + 24 rows of G_k / C_k per stage (the shape the round-3 review names).  Host-buffer entry, median of 3 solves after a warm-up."""
+    out = {}
+    rng = np.random.default_rng(7)
+    for key, (seed, nb, p, nx, mb, ng, nc) in {"plain p=16 nx=40 n=48 batch=32": (200200, 32, 16, 40, 8, 0, 0),
+                                                "step2 p=8 nx=36 n=48 rows=24+24 batch=16": (200300, 16, 8, 36, 12, 24, 24)}.items():
+        A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
+        h = HipConvexifier(p, nx, mb, chunk=nb, ng=ng, nc=nc)
+        if ng or nc:
+            J = rng.standard_normal((nb, p, ng + nc, nx + mb)); ncnt = np.full((nb, p), nc, np.int32)
+            run = lambda: h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+        else:
+            run = lambda: h.convexify_batch(A, B, H)
+        run()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); o = run(); ts.append(time.perf_counter() - t0)
+        h.close()
+        tg = float(np.median(ts))
+        out[key] = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
+                    "ipm_iterations_mean": float(o['iters'].mean()), "schur_block": nx * (nx + 1) // 2 + (ng + nc + 2 if (ng or nc) else 0)}
+    out["note"] = "32 < n <= 64: csrc/tmpc_big.h (one thread per matrix entry, matrices in global memory) + the register-staged factorisation kernels; not the tuned path of the headline"
+    return out
+
+
 # Everything that libraries print on stdout while the bench runs (RCCL prints its version banner there at communicator creation) goes
 # to stderr: stdout carries exactly one line, the JSON record.
 REAL_STDOUT = os.dup(1)
@@ -339,6 +365,11 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra_rates["small_configs"] = None
                 extra_rates["small_configs_error"] = f"{type(e).__name__}: {e}"
+            try:
+                extra_rates["large_blocks"] = large_block_configs(HipConvexifier, synthetic)
+            except Exception as e:      # noqa: BLE001
+                extra_rates["large_blocks"] = None
+                extra_rates["large_blocks_error"] = f"{type(e).__name__}: {e}"
         # the opt-in tight-accuracy mode (include/tunempc_hip.h: tmpc_set_tight): every member continued from its centred point to
         # mu_t = 2^-37 kappa with double-double block linear algebra + dd dual-Newton polish (VALU kernels, no matrix cores)
         if not args.no_tight:

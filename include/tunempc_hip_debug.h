@@ -25,7 +25,7 @@ extern "C" {
 /* Debug bit: the register-staged factorisation kernels (k_cr_potrf / k_cr_trsm / k_cr_update: the path of blocks wider than 320) for every block
  * size, instead of the LDS-DMA kernels -- keeps that path under test at small shapes. */
 #define TMPC_DEBUG_FLAG_NO_DMA 32
-/* Debug bit: the generic per-stage kernels of stage blocks wider than 32 (tmpc_big.h) also at n <= 32 (plain model), so that they can be
+/* Debug bit: the generic per-stage kernels of stage blocks wider than 32 (tmpc_big.h; with them the <true> forms of the multiplier and Step 3 kernels) also at n <= 32, so that they can be
  * compared with the tuned kernels on the same inputs. */
 #define TMPC_DEBUG_FLAG_GENERIC_STAGE 64
 
