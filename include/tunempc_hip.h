@@ -73,7 +73,7 @@ int tmpc_device_count(void);
 
 /* Device workspace needed for `chunk` problems of shape (p, nx, mb), in bytes (0 if unsupported).
  * Supported: p >= 1, nx + mb <= 64 (tuned per-stage kernels up to 32, generic ones above, every model), rows of G_k / C_k up to TMPC_MAX_ROWS each, and
- * Schur blocks -- nx(nx+1)/2, plus the rows, plus (Step 3) the (nx+mb)(nx+mb+1)/2 + 1 entries of T_k and its epigraph variable -- of at most 1552. */
+ * Schur blocks -- nx(nx+1)/2, plus the rows, plus (Step 3) the (nx+mb)(nx+mb+1)/2 + 1 entries of T_k and its epigraph variable -- of at most 2384. */
 uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
 
 /* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.

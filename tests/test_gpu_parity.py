@@ -1360,3 +1360,40 @@ def test_step3_large_stage_block():
     assert int(o['status'][0]) == 0 and r['ipm_status'] == 'optimal'
     assert rel(o['Hc'][0], H[0] + dHc) < PARITY and rel(o['T'][0], r['T']) < PARITY and (o['T'][0] > 0).all()
     assert abs(o['kappa'][0] - r['kappa']) < 1e-9 * r['kappa']
+
+
+# ----------------------------------------------------------------------------- Schur blocks beyond 1552 (compact LDS image of the substitution kernels)
+@pytest.mark.parametrize('seed,p,nx,mb', [(401, 2, 60, 4), (402, 3, 63, 1)])
+def test_widest_plain_blocks(seed, p, nx, mb):
+    """the plain model at nx = 60 and nx = 63 (n = 64; Schur blocks of 1830 and 2016) against the C++ port"""
+    from tunempc_amd._lib import HipConvexifier
+    import cpu_ipm
+    A, B, H = co.gen_batch(seed, 1, p, nx, mb)
+    h = HipConvexifier(p, nx, mb, chunk=1)
+    o = h.convexify_batch(A, B, H)
+    h.close()
+    c = cpu_ipm.convexify_batch(A, B, H, threads=8)
+    assert int(o['status'][0]) == 0 == int(c['status'][0])
+    assert rel(o['Hc'][0], c['Hc'][0]) < PARITY and abs(o['kappa'][0] - c['kappa'][0]) < 1e-9 * c['kappa'][0]
+
+
+@pytest.mark.parametrize('p,nx,mb,ng,nc', [(2, 30, 10, 0, 0), (2, 36, 12, 24, 24)])
+def test_step3_at_the_sizes_the_review_names(p, nx, mb, ng, nc):
+    """Step 3 at n = 40 (nx = 30, m = 10) and at n = 48 with 24 + 24 rows of G_k / C_k in the same solve (Schur blocks of 1286 and 1893) against the numpy oracle
+    (the second takes the oracle ~90 s on the GPU box's host cores)"""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H, G, C, ncnt = _mult_model(34, 1, p, nx, mb, ng, nc)
+    h = HipConvexifier(p, nx, mb, chunk=1, ng=ng, nc=nc, step3=True)
+    if ng or nc:
+        o = h.convexify_step3_con_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, 1e-2)
+        Cl = [C[0, k, :ncnt[0, k]] if ncnt[0, k] else None for k in range(p)]
+        r = co.sdp_step1(A[0], B[0], H[0], G=G[0], C=Cl, rho=1e-2, force=True)
+        dHc = co.convex_hessian_suppl(A[0], B[0], r['P'], G=G[0], Fg=r['Fg'], C=Cl, F=r['F'], T=r['T'])[0]
+    else:
+        o = h.convexify_step3_batch(A, B, H, 1e-2)
+        r = co.sdp_step1(A[0], B[0], H[0], rho=1e-2, force=True)
+        dHc = co.convex_hessian_suppl(A[0], B[0], r['P'], T=r['T'])[0]
+    h.close()
+    assert int(o['status'][0]) == 0 and r['ipm_status'] == 'optimal'
+    assert rel(o['Hc'][0], H[0] + dHc) < PARITY and rel(o['T'][0], r['T']) < PARITY and (o['T'][0] > 0).all()
+    assert abs(o['kappa'][0] - r['kappa']) < 1e-9 * r['kappa']

@@ -117,9 +117,10 @@ def test_large_blocks_limits_are_rejected_loudly():
     from tunempc_amd import convexifier
     from tunempc_amd._lib import load_library
     lib = load_library()
-    assert lib.tmpc_workspace_bytes_step3(1, 2, 30, 10) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 40, 8) == 0      # blocks of 1286 fit, 1997 do not
+    assert lib.tmpc_workspace_bytes_step3(1, 2, 30, 10) > 0 and lib.tmpc_workspace_bytes_step3_con(1, 2, 36, 12, 24, 24) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 40, 24) == 0      # blocks of 1286 and 1893 fit, 2901 do not
+    assert lib.tmpc_workspace_bytes(1, 2, 63, 1) > 0      # the plain model up to nx = 63 (blocks of 2016)
     assert lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 24, 24) > 0 and lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 32, 0) == 0      # rows: up to 31 + 31
-    nx, nu = 40, 8
+    nx, nu = 40, 24
     Ab = np.tile(np.eye(nx) * 0.5, (1, 2, 1, 1)); Bb = np.ones((1, 2, nx, nu)); Hb = np.tile(np.eye(nx + nu), (1, 2, 1, 1))
     with pytest.raises(NotImplementedError, match='Step 3'):
         convexifier.convexify_step3_batch(Ab, Bb, Hb, 1e-2)

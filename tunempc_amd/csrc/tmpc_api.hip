@@ -881,7 +881,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   {                          // blocks that the LDS images of k_schur and of the substitutions can hold
     const Dims db = make_dims(1, p, nx, mb, ng, nc, step3);
     if (solve_lds(db) > 160 * 1024) {
-      snprintf(g_err, sizeof(g_err), "nx=%d ng=%d nc=%d step3=%d: Schur blocks of %d (svec(P) + multipliers + entries of T_k) do not fit the LDS image of the substitution kernels (limit 1552; nx <= 55 for the plain model)", nx, ng, nc, step3, db.dp);
+      snprintf(g_err, sizeof(g_err), "nx=%d ng=%d nc=%d step3=%d: Schur blocks of %d (svec(P) + multipliers + entries of T_k) do not fit the LDS image of the substitution kernels (limit 2384)", nx, ng, nc, step3, db.dp);
       return TMPC_E_UNSUPPORTED;
     }
   }
