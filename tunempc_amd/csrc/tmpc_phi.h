@@ -232,6 +232,14 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
       double wu = (lane < n) ? wi[lane] * ui[lane] : 0.0;
       wu = wave_sum(wu);
       if (lane == 0) { cal[i] += hu; if (r == 1) ctl[i] = -wu; }
+      if (BIGR) {        // one lane per column j (up to 62 of them): a serial dot product each instead of 2 ng wave reductions per row
+        if (lane < ng) {
+          const double* wj = WV(r, lane); const double* uj = UV(r, lane);
+          double x = 0.0, y = 0.0;
+          for (int c = 0; c < n; ++c) { const double g = mG[i * ldg + c]; x = fma(g, wj[c], x); y = fma(g, uj[c], y); }
+          GXG[(r * gs + i) * gs + lane] = x; GSG[(r * gs + i) * gs + lane] = y;
+        }
+      } else
       for (int j = 0; j < ng; ++j) {
         double x = (lane < n) ? mG[i * ldg + lane] * WV(r, j)[lane] : 0.0;
         double y = (lane < n) ? mG[i * ldg + lane] * UV(r, j)[lane] : 0.0;
