@@ -1,0 +1,74 @@
+"""Randomised parity run of the paths added late in round 4: stage blocks 33 <= n <= 56 and / or up to 31 + 31 rows of G_k / C_k per stage -- plain model, Step 1 with G,
+Step 2 model, Step 3 (n <= 36: the oracle needs ~20 s per member there) -- HIP path vs the numpy oracle, one problem per case.
+Usage: python tests/tools/big_fuzz.py [ncases] [seed]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import convexify_oracle as co
+from tunempc_amd._lib import HipConvexifier
+
+rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
+rows = []
+worst = {}
+t0 = time.time()
+for case in range(ncases):
+    wide = case % 3 != 2                 # two of three cases: n > 32; the third: n <= 32 with many rows
+    n = int(rng.integers(33, 57)) if wide else int(rng.integers(8, 33))
+    mb = int(rng.integers(1, max(2, n // 3)))
+    nx = n - mb
+    p = int(rng.integers(1, 5))
+    many = bool(rng.integers(0, 2)) or not wide
+    ng = int(rng.integers(0, 32 if many else 5)); nc = int(rng.integers(0 if ng else 1, 32 if many else 6))
+    seed = int(rng.integers(0, 10 ** 6))
+    A, B, H = co.gen_batch(seed, 1, p, nx, mb, sigP=float(10.0 ** rng.uniform(-0.5, 1.0)))
+    gs = float(10.0 ** rng.uniform(-1, 1))
+    G = gs * rng.standard_normal((1, p, ng, n)); C = gs * rng.standard_normal((1, p, max(nc, 1), n))
+    ncnt = rng.integers(0, nc + 1, size=(1, p)).astype(np.int32)
+    for k in range(p):
+        C[0, k, ncnt[0, k]:] = 0.0
+    rho = float(10.0 ** rng.uniform(-3, 0))
+    Cl = [C[0, k, :ncnt[0, k]] if ncnt[0, k] else None for k in range(p)]
+    Go = G[0] if ng else None
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=1)
+    todo = {'plain': lambda: h.convexify_batch(A, B, H)}
+    if ng:
+        todo['G'] = lambda: h.convexify_eq_batch(A, B, H, G)
+    if nc:
+        todo['step2'] = lambda: h.convexify_step2_batch(A, B, H, np.concatenate([G, C[:, :, :nc]], axis=2), ncnt, rho)
+    outs = {m: f() for m, f in todo.items()}
+    h.close()
+    if n <= 36 and wide:
+        h3 = HipConvexifier(p, nx, mb, chunk=1, step3=True)
+        outs['step3'] = h3.convexify_step3_batch(A, B, H, rho)
+        h3.close()
+    for m, o in outs.items():
+        if m == 'plain':
+            r = co.sdp_step1(A[0], B[0], H[0]); dH = co.convex_hessian_suppl(A[0], B[0], r['P'])[0]
+        elif m == 'G':
+            r = co.sdp_step1(A[0], B[0], H[0], G=Go); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=Go, Fg=r['Fg'])[0]
+        elif m == 'step2':
+            r = co.sdp_step1(A[0], B[0], H[0], G=Go, C=Cl, rho=rho); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=Go, Fg=r.get('Fg'), C=Cl, F=r.get('F'))[0]
+        else:
+            r = co.sdp_step1(A[0], B[0], H[0], rho=rho, force=True); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], T=r['T'])[0]
+        early = bool(o['info'][0, 13] != 0.0)
+        ok_o = r['ipm_status'] == 'optimal'; ok_h = int(o['status'][0]) == 0
+        err = rel(o['Hc'][0], H[0] + dH) if (ok_o and ok_h and not early) else float('nan')
+        same_mu = bool(abs(o['info'][0, 6] - r['mu_target']) <= 1e-12 * r['mu_target']) if not early else True
+        rows.append(dict(case=case, model=m, p=p, nx=nx, mb=mb, ng=ng, nc=nc, seed=seed, hip_status=int(o['status'][0]), oracle=r['ipm_status'], early=early, same_mu=same_mu, err=err,
+                         iters=int(o['iters'][0]), oracle_iters=int(r['iters'])))
+        if err == err and same_mu:
+            worst[m] = max(worst.get(m, 0.0), err)
+        flag = '' if (early or (ok_o == ok_h and (err != err or err < 1e-8 or not same_mu))) else '   <-- MISMATCH'
+        print(f'case {case:2d} {m:6s} p={p} nx={nx:2d} n={n:2d} ng={ng:2d} nc={nc:2d}: hip {int(o["status"][0])} ({int(o["iters"][0])} it) oracle {r["ipm_status"]} ({r["iters"]} it) err {err:.2e}{"" if same_mu else " (different mu_t)"}{flag}', flush=True)
+mism = [r for r in rows if not r['early'] and ((r['hip_status'] == 0) != (r['oracle'] == 'optimal') or (r['err'] == r['err'] and r['same_mu'] and r['err'] >= 1e-8))]
+print(f'members {len(rows)} worst rel error per model {worst} mismatches {len(mism)} seconds {time.time() - t0:.0f}')
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+json.dump(dict(rows=rows, worst=worst, mismatches=mism), open(os.path.join(ROOT, 'gpurun_out', 'big_fuzz.json'), 'w'), indent=1)
