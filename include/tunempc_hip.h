@@ -121,7 +121,7 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value);
  * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */
 int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes);
 
-/* Tight-accuracy mode (opt-in; plain Step 1 handles).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
+/* Tight-accuracy mode (opt-in; plain Step 1 handles -- no G / C rows, no Step 3 -- with nx <= 51, any nx + mb <= 64).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
  * ~1e-8 (convexifier.py:363); the default solve above stops at tol = 2^-25, a certified gap of (2*p*n+1)*3e-8 on kappa, because the HKM
  * Schur matrix (condition ~1/mu^2) cannot be factored in fp64 below mu ~ 1e-8.  With enable != 0 every problem that ended Optimal is
  * continued from its centred point towards mu_target = tight_tol * kappa (default 2^-37 ~ 7.3e-12: gap (2*p*n+1)*7.3e-12; accepted range

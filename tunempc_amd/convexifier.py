@@ -85,7 +85,7 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
     G [nb,p,ng,n] (optional): equality-constraint Jacobians; their multipliers Fg [nb,p,ng] (convexifier.py:249-255)
     join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197).
     tight: None / False: the default accuracy (mu_target = 2^-25 kappa); True or a tolerance: the tight-accuracy mode of the library (tmpc_set_tight:
-    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model, nx + nu <= 32)."""
+    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model, nx <= 51)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
     mb = B.shape[3]

@@ -159,7 +159,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
   w.sscr = schur_in_lds(dm) ? nullptr : c.take<double>(BP * 10 * nxx);
-  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = nullptr; w.plist = nullptr;
+  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = w.ddscr = nullptr; w.plist = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.prs = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
@@ -209,6 +209,7 @@ static size_t carve_dd(WS& w, const Dims& dm, char* base) {
   w.KFl = c.take<double>(BP * 12 * nxx); w.adjVl = c.take<double>(BP * NADJ * nxx); w.adjEl = c.take<double>(BP * NADJ * nxx);
   w.W3l = c.take<double>(BP * dm.dp * 3); w.Zl = c.take<double>(BP * dm.dp);
   w.Pprev = c.take<double>(BP * nxx); w.Pdef = c.take<double>(BP * nxx);
+  w.ddscr = (dm.n > NMAX) ? c.take<double>(BP * DD_SCR_MATS * 2 * (size_t)dm.n * dm.n) : nullptr;
   w.plist = c.take<int>((size_t)dm.B);
   return (c.off + 255) & ~(size_t)255;
 }
@@ -440,6 +441,8 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_images, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_schur<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_polish_pre, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));
   HIPCHK(hipFuncSetAttribute((const void*)k_polish_step, hipFuncAttributeMaxDynamicSharedMemorySize, big - 4096));
   if (device >= 0 && device < 64) done[device] = true;
@@ -554,7 +557,23 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
 }
 
 // ---- the same in double-double (tight mode, tmpc_dd.h): one launch per phase and level, no small-block or fused forms
-template <int PART> static size_t ddschur_lds(const Dims& dm) { return (size_t)2 * ddsch_mats<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64; }
+static bool ddschur_in_lds(const Dims& dm) { return (size_t)2 * ddsch_mats<0>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64 <= 158 * 1024; }
+template <int PART> static size_t ddschur_lds(const Dims& dm) {
+  if (!ddschur_in_lds(dm)) return (size_t)dm.d * sizeof(unsigned) + 64;      // factors read from global memory (k_dd_schur<PART, true>)
+  return (size_t)2 * ddsch_mats<PART>() * dm.nx * dm.nx * sizeof(double) + (size_t)dm.d * sizeof(unsigned) + 64;
+}
+// the dd assembly of D_k and of the coupling blocks for the stages of `grid_stages` problems-times-stages
+static void dd_schur_launch(const WS& w, const Dims& dm, int grid_stages, hipStream_t st) {
+  if (ddschur_in_lds(dm)) {
+    hipLaunchKernelGGL(k_dd_schur<0>, dim3(grid_stages), dim3(256), ddschur_lds<0>(dm), st, w, dm);
+    hipLaunchKernelGGL(k_dd_schur<1>, dim3(grid_stages), dim3(256), ddschur_lds<1>(dm), st, w, dm);
+  } else {
+    hipLaunchKernelGGL((k_dd_schur<0, true>), dim3(grid_stages), dim3(256), ddschur_lds<0>(dm), st, w, dm);
+    hipLaunchKernelGGL((k_dd_schur<1, true>), dim3(grid_stages), dim3(256), ddschur_lds<1>(dm), st, w, dm);
+  }
+}
+// LDS of the stage-level dd kernels: their matrices live in LDS slots at n <= 32, in WS::ddscr above
+static size_t dd_stage_lds(const Dims& dm, int slots) { return dm.n > NMAX ? 64 : slots_bytes(slots); }
 static void dd_factor(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st) {
   const CrDev cd = cr_dev(sc, d_sched, alist);
   const size_t lds = (size_t)DD_FACT_LDS * sizeof(double);
@@ -672,9 +691,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
     if (ddm) {
-      hipLaunchKernelGGL(k_dd_images, dim3(BP), dim3(256), slots_bytes(DD_IMG_SLOTS), st, w, dm);
-      hipLaunchKernelGGL(k_dd_schur<0>, dim3(BP), dim3(256), ddschur_lds<0>(dm), st, w, dm);
-      hipLaunchKernelGGL(k_dd_schur<1>, dim3(BP), dim3(256), ddschur_lds<1>(dm), st, w, dm);
+      hipLaunchKernelGGL(k_dd_images, dim3(BP), dim3(256), dd_stage_lds(dm, DD_IMG_SLOTS), st, w, dm);
+      dd_schur_launch(w, dm, BP, st);
     } else if (nfac > 0) {
       if (schur_in_lds(dm)) {
         hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
@@ -773,7 +791,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   { const int rc_ = ipm_loop(o, false, cap); if (rc_ != TMPC_OK) return rc_; }
   // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
-  if (h->tight && !eq && !t3 && !big && wall.Dl) {
+  if (h->tight && !eq && !t3 && wall.Dl) {
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.chord_step = 0.0; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
     { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3(nb), dim3(64), 0, st, wi, dm, ot); }
@@ -787,15 +805,15 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     int* list = wall.plist; int* next = alist; int count = npol;
     for (int step = 0; step < POLISH_MAX && count > 0; ++step) {
       WS wp = wall; wp.alist = list;
-      hipLaunchKernelGGL(k_dd_polish_pre, dim3(count * dm.p), dim3(256), slots_bytes(DD_POL_SLOTS), st, wp, dm, 0);
+      hipLaunchKernelGGL(k_dd_polish_pre, dim3(count * dm.p), dim3(256), dd_stage_lds(dm, DD_POL_SLOTS), st, wp, dm, 0);
       hipLaunchKernelGGL(k_polish_ctrl_a, dim3(count), dim3(64), 0, st, wp, dm);
-      hipLaunchKernelGGL(k_dd_schur<0>, dim3(count * dm.p), dim3(256), ddschur_lds<0>(dm), st, wp, dm);
-      hipLaunchKernelGGL(k_dd_schur<1>, dim3(count * dm.p), dim3(256), ddschur_lds<1>(dm), st, wp, dm);
+      dd_schur_launch(wp, dm, count * dm.p, st);
       dd_factor(wp, dm, h->sched, h->d_sched, list, count, st);
       hipLaunchKernelGGL(k_dd_gather, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
       { const int rc_ = dd_solve(wp, dm, h->sched, h->d_sched, list, count, st, 2, nb); if (rc_ != TMPC_OK) return rc_; }
       hipLaunchKernelGGL(k_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list, 2);
-      hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
+      if (dm.n > NMAX) hipLaunchKernelGGL(kb_polish_step, dim3(count * dm.p), dim3(256), 0, st, wp, dm);
+      else hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
       HIPCHK(hipMemsetAsync(w.active + 3, 0, sizeof(int), st));
       hipLaunchKernelGGL(k_polish_ctrl_b, dim3(count), dim3(64), 0, st, wp, dm, ot, (const int*)list, count, next, w.active + 3);
       HIPCHK(hipMemcpyAsync(cnt + 3, w.active + 3, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -806,7 +824,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     if (npol > 0) {      // final iterate of every polished problem: cone check, X_r / S_r for the outputs and the dual export
       WS wp = wall; wp.alist = wall.plist;
-      hipLaunchKernelGGL(k_dd_polish_pre, dim3(npol * dm.p), dim3(256), slots_bytes(DD_POL_SLOTS), st, wp, dm, 1);
+      hipLaunchKernelGGL(k_dd_polish_pre, dim3(npol * dm.p), dim3(256), dd_stage_lds(dm, DD_POL_SLOTS), st, wp, dm, 1);
       hipLaunchKernelGGL(k_polish_final, dim3(npol), dim3(64), 0, st, wp, dm);
     }
     hipLaunchKernelGGL(k_tight_fallback, dim3(nb), dim3(64), 0, st, wall, dm);      // members whose tight phase failed: back to the result of the default solve
@@ -997,7 +1015,11 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
   if (!h) return TMPC_E_ARG;
   if (!enable) { h->tight = 0; return TMPC_OK; }
-  if (h->dm.nr > 0 || h->dm.nT > 0 || h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles with nx + mb <= %d only (no G / C rows, no Step 3)", NMAX); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > 0 || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles only (no G / C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
+  if ((size_t)dd_solve_lds_doubles(h->dm.dp) * sizeof(double) > 160 * 1024) {
+    snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Schur blocks of %d do not fit the LDS image of the double-double substitution kernels (nx <= 51)", h->dm.dp);
+    return TMPC_E_UNSUPPORTED;
+  }
   if (tight_tol > 0.0 && !(tight_tol >= 0x1p-42 && tight_tol < 1.0)) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: tolerance %g outside [2^-42, 1)", tight_tol); return TMPC_E_ARG; }
   ON_DEVICE(h);
   if (!h->dd_slab) {

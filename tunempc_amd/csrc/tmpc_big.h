@@ -463,6 +463,32 @@ __global__ void __launch_bounds__(256) kb_final_stage(WS w, Dims dm) {
   if (tid == 0) { double* q = w.part + (size_t)sid * NPART; q[Q_MINEIG] = lo; q[Q_MAXEIG] = hi; }
 }
 
+// ------------------------------------------------------------------ tight mode, polish (k_polish_step of tmpc_dd.h): dM of the step, the norms of the step test, the dual iterate of the step
+__global__ void __launch_bounds__(256) kb_polish_step(WS w, Dims dm) {
+  TMPC_BIG_PROLOGUE
+  if (w.iprob[(size_t)b * IS + I_PHASE] != PH_POLISH) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  double* dM = scr; double* t0 = scr + nn; double* t1 = scr + 2 * nn;
+  gbuild_M(dM, t0, w.V + (size_t)sid * nx * n, w.Hb + so, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, pr[P_DALPHA], n, nx);
+  const double ra = pr[P_DALPHA] / pr[P_ALPHA];
+  double dh2 = 0.0, m2 = 0.0;
+  for (int e = tid; e < nn; e += 256) { const double m = w.T1[so + e], dh = dM[e] - ra * m; dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2); }
+  dh2 = block_sum<256>(dh2); m2 = block_sum<256>(m2);
+  if (tid == 0) { double* q = w.part + (size_t)sid * NPART; q[Q_DH2] = dh2; q[Q_M2] = m2; }
+  const double dtau = pr[P_DTAU];
+  for (int r = 0; r < 2; ++r) {
+    const double* X = (r ? w.X2 : w.X1) + so; const double* Z = (r ? w.S2i : w.S1i) + so;
+    if (r == 1) { for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; dM[e] = ((i == j) ? dtau : 0.0) - dM[e]; } }      // dS2 = dtau I - dM
+    gsync();
+    gmm(t0, n, X, n, 1, dM, n, 1, n, n, n, 0);
+    gmm(t1, n, t0, n, 1, Z, n, 1, n, n, n, 0);
+    double* out = (r ? w.dX2 : w.dX1) + so;
+    for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; out[e] = X[e] - 0.5 * (t1[i * n + j] + t1[j * n + i]); }
+    gsync();
+  }
+}
+
 // ------------------------------------------------------------------ the other entry points of the boundary at 32 < n <= 64
 // eigen-scan of arbitrary stage blocks (tmpc_eig_scan_host; k_eig_scan)
 __global__ void __launch_bounds__(256) kb_eig_scan(const double* H, double* out, int n) {

@@ -170,6 +170,7 @@ struct WS {
   double* Tout;    // [B,p,n,n] output T_k
   // tight mode (tmpc_dd.h): low words of the double-double planes (high words = D, O, F, Linv, KF, adjV, adjE, W3, Z); null without it
   double* Dl; double* Ol; double* Fl; double* Linvl; double* KFl; double* adjVl; double* adjEl; double* W3l; double* Zl;
+  double* ddscr;   // [B,p,DD_SCR_MATS,2,n,n] 32 < n <= 64: the dd stage matrices that the tuned form keeps in LDS (tmpc_dd.h: sdd_slot); else null
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
   double* Pdef;    // [B,p,nx,nx] result of the default solve (restored when the tight phase of a member fails)
   double* sscr;    // [B,p,10,nx,nx] factor records of k_schur when they do not fit the LDS (nx > 43); null otherwise

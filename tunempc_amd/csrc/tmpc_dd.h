@@ -34,6 +34,7 @@
 
 namespace tmpc {
 
+constexpr int DD_SCR_MATS = 9;            // dd matrices per stage of the global scratch (32 < n <= 64; k_dd_polish_pre needs nine)
 constexpr double POLISH_ENTER = 1e-4;    // as the CPU restatement used by the tests
 constexpr int POLISH_MAX = 6;
 
@@ -493,10 +494,22 @@ __global__ void __launch_bounds__(256) k_dd_bwd(WS w, Dims dm, CrDev cr, int eof
   ddvec_s2g(Rh, Rl, zch, zcl, xld, dp, nc);
 }
 
-// ------------------------------------------------------------------ small dd matrices in LDS (stage level: n <= 32), 256 threads
-// a matrix is a pair of images (hi at p, lo at p + MS), leading dimension LD
-struct sdd { double* p; __device__ __forceinline__ double& h(int i, int j) const { return p[i * LD + j]; } __device__ __forceinline__ double& l(int i, int j) const { return p[MS + i * LD + j]; }
-             __device__ __forceinline__ ddv get(int i, int j) const { return ddv{p[i * LD + j], p[MS + i * LD + j]}; } __device__ __forceinline__ void set(int i, int j, ddv v) const { p[i * LD + j] = v.h; p[MS + i * LD + j] = v.l; } };
+// ------------------------------------------------------------------ small dd matrices (stage level), 256 threads
+// a matrix is a pair of images (hi at p, lo at p + ms), leading dimension ld: LDS slots (ld = LD, ms = MS) at n <= 32; for 32 < n <= 64 the same
+// routines run on a per-stage scratch in global memory (ld = n, ms = n * n; WS::ddscr) -- every barrier below is therefore a fence + barrier
+struct sdd {
+  double* p; int ld, ms;
+  __device__ __forceinline__ double& h(int i, int j) const { return p[i * ld + j]; }
+  __device__ __forceinline__ double& l(int i, int j) const { return p[ms + i * ld + j]; }
+  __device__ __forceinline__ ddv get(int i, int j) const { return ddv{p[i * ld + j], p[ms + i * ld + j]}; }
+  __device__ __forceinline__ void set(int i, int j, ddv v) const { p[i * ld + j] = v.h; p[ms + i * ld + j] = v.l; }
+};
+__device__ __forceinline__ void dsync() { __threadfence_block(); __syncthreads(); }
+// slot q of the stage's dd matrices: LDS (sm) or, for n > NMAX, the global scratch
+__device__ __forceinline__ sdd sdd_slot(const WS& w, const Dims& dm, size_t sid, double* sm, int q) {
+  if (dm.n > NMAX) { const int nn = dm.n * dm.n; return sdd{w.ddscr + (sid * DD_SCR_MATS + q) * 2 * (size_t)nn, dm.n, nn}; }
+  return sdd{sm + 2 * q * MS, LD, MS};
+}
 // C (m x n) = A (m x k) op(B): tb ? B (n x k)' : B (k x n); ta: A given as (k x m)'
 __device__ __forceinline__ void sdd_mm(sdd C, sdd A, bool ta, sdd B, bool tb, int m, int k, int n) {
   for (int e = threadIdx.x; e < m * n; e += 256) {
@@ -508,29 +521,29 @@ __device__ __forceinline__ void sdd_mm(sdd C, sdd A, bool ta, sdd B, bool tb, in
     }
     C.set(i, j, dd_qts(sh, sl));
   }
-  __syncthreads();
+  dsync();
 }
 // in-place lower Cholesky of the n x n dd matrix S, then Z = S^-1 = L^-T L^-1 (W: scratch for L^-1).  Returns non-positive pivots (uniform).
 __device__ __forceinline__ int sdd_inv_spd(sdd Z, sdd S, sdd W, int n, double* flag) {
   const int tid = threadIdx.x;
   if (tid == 0) flag[0] = 0.0;
-  __syncthreads();
+  dsync();
   for (int j = 0; j < n; ++j) {
     ddv piv = S.get(j, j);
     if (!(piv.h > 0.0)) { piv = ddv{1.0, 0.0}; if (tid == 0) flag[0] += 1.0; }
     const ddv r = dd_sqrt(piv), rinv = dd_div(dd_from(1.0), r);
-    __syncthreads();
+    dsync();
     if (tid == 0) S.set(j, j, r);
     if (tid > j && tid < n) S.set(tid, j, dd_mul(S.get(tid, j), rinv));
-    __syncthreads();
+    dsync();
     for (int e = tid; e < (n - j - 1) * (n - j - 1); e += 256) {
       const int i = j + 1 + e / (n - j - 1), k = j + 1 + e % (n - j - 1);
       if (k <= i) S.set(i, k, dd_sub(S.get(i, k), dd_mul(S.get(i, j), S.get(k, j))));
     }
-    __syncthreads();
+    dsync();
   }
   for (int e = tid; e < n * n; e += 256) W.set(e / n, e % n, ddv{0.0, 0.0});
-  __syncthreads();
+  dsync();
   if (tid < n) {                     // column c of L^-1 (forward substitution)
     const int c = tid;
     for (int i = c; i < n; ++i) {
@@ -539,15 +552,15 @@ __device__ __forceinline__ int sdd_inv_spd(sdd Z, sdd S, sdd W, int n, double* f
       W.set(i, c, dd_div(s, S.get(i, i)));
     }
   }
-  __syncthreads();
+  dsync();
   sdd_mm(Z, W, true, W, false, n, n, n);          // L^-T L^-1
   for (int e = tid; e < n * n; e += 256) {        // exact symmetry
     const int i = e / n, j = e % n;
     if (j < i) { const ddv v = dd_muld(dd_add(Z.get(i, j), Z.get(j, i)), 0.5); S.set(i, j, v); }
   }
-  __syncthreads();
+  dsync();
   for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; if (j < i) { const ddv v = S.get(i, j); Z.set(i, j, v); Z.set(j, i, v); } }
-  __syncthreads();
+  dsync();
   return (int)flag[0];
 }
 __device__ __forceinline__ void sdd_store(double* gh, double* gl, sdd A, int r, int c, int ldg) {       // A[:r, :c] -> global planes
@@ -566,13 +579,13 @@ __device__ __forceinline__ void dd_images(const WS& w, size_t sid, int r, sdd V,
   sdd_mm(t1, X, false, V, true, nx, n, nx);                                        // X[:nx, :] V'
   sdd_store(kh + KF_FX * nxx, kl + KF_FX * nxx, t1, nx, nx, nx);
   sdd_store(kh + KF_XXX * nxx, kl + KF_XXX * nxx, X, nx, nx, nx);
-  __syncthreads();
+  dsync();
   sdd_mm(t0, V, false, Z, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);
   sdd_store(kh + KF_KS * nxx, kl + KF_KS * nxx, t1, nx, nx, nx);
   sdd_mm(t1, Z, false, V, true, nx, n, nx);
   sdd_store(kh + KF_FS * nxx, kl + KF_FS * nxx, t1, nx, nx, nx);
   sdd_store(kh + KF_SIXX * nxx, kl + KF_SIXX * nxx, Z, nx, nx, nx);
-  __syncthreads();
+  dsync();
 }
 
 // tight loop: the images from the fp64 iterates X_r, S_r^-1 (k_stage_pre wrote them), one workgroup per stage of the active problems
@@ -583,21 +596,22 @@ __global__ void __launch_bounds__(256) k_dd_images(WS w, Dims dm) {
   const int b = sid / dm.p;
   if (w.iprob[(size_t)b * IS + I_PHASE] == PH_DONE) return;
   const int n = dm.n, nx = dm.nx, nn = n * n;
-  sdd V{sm}, X{sm + 2 * MS}, Z{sm + 4 * MS}, t0{sm + 6 * MS}, t1{sm + 8 * MS};
+  const sdd V = sdd_slot(w, dm, sid, sm, 0), X = sdd_slot(w, dm, sid, sm, 1), Z = sdd_slot(w, dm, sid, sm, 2), t0 = sdd_slot(w, dm, sid, sm, 3), t1 = sdd_slot(w, dm, sid, sm, 4);
   sdd_load64(V, w.V + (size_t)sid * nx * n, nx, n, n);
   for (int r = 0; r < 2; ++r) {
-    __syncthreads();
+    dsync();
     sdd_load64(X, (r ? w.X2 : w.X1) + (size_t)sid * nn, n, n, n);
     sdd_load64(Z, (r ? w.S2i : w.S1i) + (size_t)sid * nn, n, n, n);
-    __syncthreads();
+    dsync();
     dd_images(w, (size_t)sid, r, V, X, Z, t0, t1, n, nx);
   }
 }
 
 // ------------------------------------------------------------------ assembly of D_k and the coupling block in dd (k_schur of tmpc_schur.h)
 // One workgroup per stage and part; a thread owns a stored column and walks the rows.  PART 0: D_k (lower triangle), PART 1: coupling block.
+// GF (nx > 35: the eight dd factor matrices of PART 0 do not fit the LDS): the factors are read where k_dd_images / k_dd_polish_pre left them in global memory
 template <int PART> constexpr int ddsch_mats() { return PART == 0 ? 8 : 4; }
-template <int PART>
+template <int PART, bool GF = false>
 __global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
   constexpr int NM = ddsch_mats<PART>();
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -605,11 +619,19 @@ __global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
   const int b = sid / dm.p, k = sid - b * dm.p;
   if (w.iprob[(size_t)b * IS + I_PHASE] == PH_DONE) return;
   const int tid = threadIdx.x, nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
-  double* mh = sm; double* ml = sm + (size_t)NM * nxx;                 // [NM][nx][nx] hi, lo
-  unsigned* pair = (unsigned*)(ml + (size_t)NM * nxx);
+  double* mh = sm; double* ml = sm + (GF ? 0 : (size_t)NM * nxx);                 // [NM][nx][nx] hi, lo
+  unsigned* pair = (unsigned*)(ml + (GF ? 0 : (size_t)NM * nxx));
   const bool corner = (w.cr_orient[k] != 0);
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const size_t ok = (size_t)sid * 12 * nxx, om = (size_t)(b * dm.p + km) * 12 * nxx;
+  size_t gsrc[NM];                       // GF: where matrix q lives in KF / KFl
+  const bool gtr = (PART == 1) && !corner;       // GF: the F matrices are used transposed
+#pragma unroll
+  for (int q = 0; q < NM; ++q) {
+    const int lmi = (PART == 1) ? q / 2 : q / 4, slot = (PART == 1) ? KF_FX + (q - 2 * lmi) : q - 4 * lmi;
+    gsrc[q] = ((slot == KF_KX || slot == KF_KS) ? om : ok) + (size_t)(lmi * KF_PER_LMI + slot) * nxx;
+  }
+  if (!GF)
   for (int e = tid; e < 12 * nxx; e += 256) {
     const int m = e / nxx, r = e - m * nxx;
     const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
@@ -624,7 +646,10 @@ __global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
   if (tid < nx) { int e = tid * nx - (tid * (tid - 1)) / 2; for (int c = tid; c < nx; ++c) pair[e++] = (unsigned)tid | ((unsigned)c << 16); }
   __syncthreads();
   double* Gh = (PART == 0 ? w.D : w.O) + (size_t)sid * dp * dp; double* Gl = (PART == 0 ? w.Dl : w.Ol) + (size_t)sid * dp * dp;
-  auto at = [&](int q, int i, int j) { return ddv{mh[(size_t)q * nxx + i * nx + j], ml[(size_t)q * nxx + i * nx + j]}; };
+  auto at = [&](int q, int i, int j) {
+    if (GF) { const size_t g = gsrc[q] + (gtr ? j * nx + i : i * nx + j); return ddv{w.KF[g], w.KFl[g]}; }
+    return ddv{mh[(size_t)q * nxx + i * nx + j], ml[(size_t)q * nxx + i * nx + j]};
+  };
   auto hkm = [&](int qx, int qs, int a, int bb, int c, int e_) {          // T(Lx, Ls)[(ab),(ce)] without the weights
     return dd_add(dd_add(dd_mul(at(qx, a, c), at(qs, bb, e_)), dd_mul(at(qx, a, e_), at(qs, bb, c))),
                   dd_add(dd_mul(at(qx, bb, c), at(qs, a, e_)), dd_mul(at(qx, bb, e_), at(qs, a, c))));
@@ -666,11 +691,12 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
   const double tau = pr[P_TAU], alpha = pr[P_ALPHA], mu = pr[P_MUT];
   const int tid = threadIdx.x, n = dm.n, nx = dm.nx, nn = n * n, nxx = nx * nx;
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
-  sdd V{sm}, Hd{sm + 2 * MS}, M{sm + 4 * MS}, Z1{sm + 6 * MS}, Z2{sm + 8 * MS}, X{sm + 10 * MS}, t0{sm + 12 * MS}, t1{sm + 14 * MS}, t2{sm + 16 * MS};
+  const sdd V = sdd_slot(w, dm, sid, sm, 0), Hd = sdd_slot(w, dm, sid, sm, 1), M = sdd_slot(w, dm, sid, sm, 2), Z1 = sdd_slot(w, dm, sid, sm, 3), Z2 = sdd_slot(w, dm, sid, sm, 4),
+            X = sdd_slot(w, dm, sid, sm, 5), t0 = sdd_slot(w, dm, sid, sm, 6), t1 = sdd_slot(w, dm, sid, sm, 7), t2 = sdd_slot(w, dm, sid, sm, 8);
   sdd_load64(V, w.V + (size_t)sid * nx * n, nx, n, n);
   sdd_load64(Hd, w.Hb + (size_t)sid * nn, n, n, n);
   sdd_load64(t0, w.P + (size_t)(b * dm.p + kn) * nxx, nx, nx, nx);
-  __syncthreads();
+  dsync();
   sdd_mm(t1, V, true, t0, false, n, nx, nx);                 // V' P_{k+1}
   sdd_mm(M, t1, false, V, false, n, nx, n);                  // (V' P+) V
   const double* Pk = w.P + (size_t)sid * nxx;
@@ -680,22 +706,22 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
     if (i < nx && j < nx) v = dd_sub(v, dd_from(Pk[i * nx + j]));
     M.set(i, j, v);
   }
-  __syncthreads();
+  dsync();
   for (int e = tid; e < nn; e += 256) {                     // exact symmetry, fp64 rounding for the step norm
     const int i = e / n, j = e - i * n;
     if (j < i) { const ddv v = dd_muld(dd_add(M.get(i, j), M.get(j, i)), 0.5); t0.set(i, j, v); }
   }
-  __syncthreads();
+  dsync();
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; if (j < i) { const ddv v = t0.get(i, j); M.set(i, j, v); M.set(j, i, v); } }
-  __syncthreads();
+  dsync();
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; w.T1[(size_t)sid * nn + e] = dd_val(M.get(i, j)); }
   int nbad = (alpha - ALPHA_MIN > 0.0) ? 0 : 1;
   // S1 = M - I, S2 = tau I - M, their inverses
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const ddv m = M.get(i, j); t0.set(i, j, (i == j) ? dd_sub(m, dd_from(1.0)) : m); w.S1[(size_t)sid * nn + e] = dd_val(t0.get(i, j)); }
-  __syncthreads();
+  dsync();
   nbad += sdd_inv_spd(Z1, t0, t1, n, flag);
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const ddv m = M.get(i, j); t0.set(i, j, (i == j) ? dd_sub(dd_from(tau), m) : dd_neg(m)); w.S2[(size_t)sid * nn + e] = dd_val(t0.get(i, j)); }
-  __syncthreads();
+  dsync();
   nbad += sdd_inv_spd(Z2, t0, t1, n, flag);
   // per cone block: X = mu Z, images; the adjoint pieces accumulate G = X1 - X2 (t2) and Phi (M is free now: M <- Phi)
   double trx2 = 0.0, hby = 0.0, trpsi = 0.0, trphi2 = 0.0, hbphi = 0.0;
@@ -709,7 +735,7 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       (r ? w.S2i : w.S1i)[(size_t)sid * nn + e] = dd_val(Z.get(i, j));
       t2.set(i, j, r ? dd_sub(t2.get(i, j), x) : x);
     }
-    __syncthreads();
+    dsync();
     dd_images(w, (size_t)sid, r, V, X, Z, t0, t1, n, nx);
     sdd_mm(t0, X, false, Hd, false, n, n, n); sdd_mm(t1, t0, false, Z, false, n, n, n);      // X Hb Z (symmetric up to rounding: Z, Hb symmetric, X = mu Z)
     for (int e = tid; e < nn; e += 256) {
@@ -718,21 +744,21 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       if (r == 1 && i == j) trphi2 += dd_val(ph);
       M.set(i, j, r ? dd_add(M.get(i, j), ph) : ph);
     }
-    __syncthreads();
+    dsync();
     if (r == 1) {
       sdd_mm(t0, X, false, Z, false, n, n, n);                                              // Psi = X2 Z2
       for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; if (i == j) { trpsi += dd_val(t0.get(i, j)); trx2 += dd_val(X.get(i, j)); } }
       sdd_mm(t1, V, false, t0, false, nx, n, n); sdd_mm(X, t1, false, V, true, nx, n, nx);   // V Psi V'   (X is free)
       sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_PSI) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_PSI) * nxx, X, nx, nx, nx);
       sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx);
-      __syncthreads();
+      dsync();
     }
   }
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; hby += dd_val(dd_mul(Hd.get(i, j), t2.get(i, j))); hbphi += dd_val(dd_mul(Hd.get(i, j), M.get(i, j))); }
   sdd_mm(t0, V, false, t2, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);       // V G V'
   sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_G) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_G) * nxx, t1, nx, nx, nx);
   sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_G) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_G) * nxx, t2, nx, nx, nx);
-  __syncthreads();
+  dsync();
   sdd_mm(t0, V, false, M, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);        // V Phi V'
   sdd_store(w.adjV + ((size_t)sid * NADJ + ADJ_PHI) * nxx, w.adjVl + ((size_t)sid * NADJ + ADJ_PHI) * nxx, t1, nx, nx, nx);
   sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_PHI) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_PHI) * nxx, M, nx, nx, nx);
