@@ -13,6 +13,8 @@ from tunempc_amd._lib import HipConvexifier
 which = sys.argv[1] if len(sys.argv) > 1 else 'plain'
 rng = np.random.default_rng(7)
 seed, nb, p, nx, mb, ng, nc = (200200, 32, 16, 40, 8, 0, 0) if which == 'plain' else (200300, 16, 8, 36, 12, 24, 24)
+if len(sys.argv) > 2:
+    nb = int(sys.argv[2])
 A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
 h = HipConvexifier(p, nx, mb, chunk=nb, ng=ng, nc=nc)
 if ng or nc:

@@ -9,8 +9,10 @@
 // per stage.  Same inputs, same outputs, same partial sums as k_init_stage / k_stage_pre / k_stage_rhs / k_stage_dir / k_eigmin /
 // k_final_stage, so the control kernels, the Schur assembly, the block factorisation (blocks wider than 320: the register-staged kernels of
 // tmpc_cr.h) and k_update / k_gather / k_solve_border are unchanged.  Eigenvalues (scaling, step lengths, status) by a parallel-ordered
-// cyclic Jacobi iteration on one LDS tile.  Plain Step 1 model; roughly 5 x the stage time per entry of the tuned n <= 32 kernels, which
-// matters little at these sizes: the d x d blocks (d = nx (nx + 1) / 2 up to ~1000) dominate.  TMPC_DEBUG_FLAG_GENERIC_STAGE runs this
+// cyclic Jacobi iteration on one LDS tile.  Every model: the terms J' diag(phi) J of the multipliers and T_k of Step 3 are added here, and the kernels of
+// tmpc_phi.h / tmpc_t3.h that touch n x n matrices have a <true> form reading them from global memory; the tight mode has its stage matrices in a global
+// scratch (tmpc_dd.h: sdd_slot) and kb_polish_step below.  Roughly 5 x the stage time per entry of the tuned n <= 32 kernels, which
+// matters little at these sizes: the d x d blocks (d = nx (nx + 1) / 2 up to 2016) dominate.  TMPC_DEBUG_FLAG_GENERIC_STAGE runs this
 // path at n <= 32 as well, which is how it is tested against the tuned one.
 #pragma once
 #include "tmpc_common.h"

@@ -7,7 +7,7 @@
 // itself, dual z).  Each norm term is an epigraph variable t with the arrow LMI S = [[t, w v'], [w v, t I]] >> 0, v the
 // multipliers under the norm and w = rho*sbeta/s (the scaled objective is tau + sum t); S is a function of (t, phi) alone, so it
 // is rebuilt instead of iterated and never carries a residual; its primal block X is (m+1) x (m+1).
-// The stage-local vector y_loc = (phi_k, t_k) (at most 34 entries) touches only the cone blocks of stage k, so in the HKM Schur
+// The stage-local vector y_loc = (phi_k, t_k) (at most 64 entries: up to 31 + 31 rows and two epigraph variables) touches only the cone blocks of stage k, so in the HKM Schur
 // system its rows reach P_k, P_{k+1}, tau and alpha only:
 //     a_k,i = -svec(W_i[:nx,:nx]) (P_k),   b_k,i = svec(V_k W_i V_k') (P_{k+1}),   W_i = sum_r sym(X_r g_i g_i' S_r^-1) = sum_r sym(w_ri u_ri'),
 //     c_tau, c_alpha (border), T_loc,loc (own block; zero coupling for the epigraph entries).

@@ -12,7 +12,7 @@
 // type Gram product <E_ab, X E_cd S^-1> of the n x n LMI blocks of stage k (computed on the fly, never stored as matrices).  Like
 // the multipliers of tmpc_phi.h they ride in block k+1 of the block-cyclic-tridiagonal system behind P_{k+1} (rows oT = d .. d+m:
 // theta, row d+m+1: t), so the block kernels of tmpc_cr.h run unchanged on blocks of size d + m + 1.
-// This first version covers the plain model + T (no G / C rows in the same solve).
+// With G / C rows in the same solve (convexifier.py:144) the multipliers of tmpc_phi.h sit at rows d .. d + nz, theta behind them (k_t3_cross: the block between the two).
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_small.h"
