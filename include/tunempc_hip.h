@@ -111,11 +111,14 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
  *   TMPC_TUNE_EIG_PRETEST  1 (default): the step-length kernel first asks whether the step at the clipping threshold stays in the cone; 0: every
  *                          eigenvalue is computed
  *   TMPC_TUNE_FUSE_FWD     1 (default): the forward substitution of the predictor pass rides inside the factorisation; 0: separate sweep
+ *   TMPC_TUNE_GRAPH        1 (default): problems whose Schur blocks are a single tile (nx <= 10: launch-bound) replay the launch sequence of an iteration as a
+ *                          captured hipGraph (one submission instead of ~35; the handle's own streams only); 0: plain launches
  * (Rounds 1-3 read these from environment variables once per process.) */
 #define TMPC_TUNE_CHORD_STEP 1
 #define TMPC_TUNE_SMALL_BLOCKS 2
 #define TMPC_TUNE_EIG_PRETEST 3
 #define TMPC_TUNE_FUSE_FWD 4
+#define TMPC_TUNE_GRAPH 5
 int tmpc_set_tuning(tmpc_handle* h, int key, double value);
 /* The general constructor: ng / nc rows of G_k / C_k (0: none), step3 != 0: room for T_k, lanes = concurrent half-waves on their own streams
  * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */

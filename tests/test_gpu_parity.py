@@ -1024,7 +1024,7 @@ def test_supplement_with_constraint_and_regularisation_terms(hc):
 
 
 @pytest.mark.parametrize('variant', [dict(flags=32), dict(tuning=dict(fuse_fwd=0, chord_step=0)), dict(tuning=dict(small_blocks=0)), dict(tuning=dict(eig_pretest=0)),
-                                     dict(lanes=1), dict(lanes=3), dict(flags=1)], ids=str)
+                                     dict(tuning=dict(graph=0)), dict(lanes=1), dict(lanes=3), dict(flags=1)], ids=str)
 def test_kernel_variants_behind_handle_options(golden_dir, variant):
     """The kernel variants that rounds 1-3 hid behind environment variables, now options of the handle (tmpc_set_tuning, tmpc_create_ex) or debug flags
     (tunempc_hip_debug.h): register-staged factorisation kernels (flag 32: the path of blocks wider than 320), separate forward sweep without chord steps, the batched
@@ -1397,3 +1397,29 @@ def test_step3_at_the_sizes_the_review_names(p, nx, mb, ng, nc):
     assert int(o['status'][0]) == 0 and r['ipm_status'] == 'optimal'
     assert rel(o['Hc'][0], H[0] + dHc) < PARITY and rel(o['T'][0], r['T']) < PARITY and (o['T'][0] > 0).all()
     assert abs(o['kappa'][0] - r['kappa']) < 1e-9 * r['kappa']
+
+
+def test_iteration_graph_replay_is_bit_identical():
+    """TMPC_TUNE_GRAPH (default on for problems whose Schur blocks are one tile): the launch sequence of an IPM iteration replayed as a captured hipGraph returns the
+    bits of the plain launch sequence -- batch 1, a batch over two lanes with ragged iteration counts, the models with multipliers and Step 3, repeated calls (cache hits)"""
+    from tunempc_amd._lib import HipConvexifier
+    for (seed, nb, p, nx, mb) in [(200000, 1, 30, 4, 1), (11, 7, 8, 4, 1), (3, 5, 6, 4, 2)]:
+        A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+        rng = np.random.default_rng(seed)
+        J = rng.standard_normal((nb, p, 3, nx + mb)); ncnt = rng.integers(0, 3, size=(nb, p)).astype(np.int32)
+        for b in range(nb):
+            for k in range(p):
+                J[b, k, 1 + ncnt[b, k]:] = 0.0
+        outs = []
+        for g in (0, 1):
+            h = HipConvexifier(p, nx, mb, ng=1, nc=2, chunk=nb); h.set_tuning(graph=g)
+            o = [h.convexify_batch(A, B, H), h.convexify_eq_batch(A, B, H, J[:, :, :1]), h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2), h.convexify_batch(A, B, H)]
+            h.close()
+            h3 = HipConvexifier(p, nx, mb, step3=True, chunk=nb); h3.set_tuning(graph=g)
+            o.append(h3.convexify_step3_batch(A, B, H, 1e-2))
+            h3.close()
+            outs.append(o)
+        for a, g in zip(*outs):
+            for k in ('Hc', 'P', 'kappa', 'status', 'iters'):
+                assert np.array_equal(a[k], g[k]), (seed, k)
+        assert np.array_equal(outs[1][0]['Hc'], outs[1][3]['Hc'])

@@ -9,6 +9,9 @@
 #include <thread>
 #include <vector>
 
+#include <string>
+#include <unordered_map>
+
 #include "../../include/tunempc_hip.h"
 #include "../../include/tunempc_hip_debug.h"
 #include "tmpc_common.h"
@@ -64,6 +67,7 @@ struct Lane {
   double prof[16];               // see tmpc_get_profile
   std::vector<hipEvent_t> kev;   // profile mode: event pairs around the launches of one factorisation (class = index % 3)
   int last_nb;                   // problems this lane solved in the last wave (trace / multiplier read-back)
+  std::unordered_map<std::string, hipGraphExec_t>* graphs;   // launch-bound shapes: one IPM iteration as a captured graph, keyed by every launch argument (run_chunk)
   char err[512];                 // error text of the lane's worker thread
 };
 
@@ -81,7 +85,7 @@ struct tmpc_handle {
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
   int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
-  int tune_small, tune_pretest, tune_fuse;     // tmpc_set_tuning
+  int tune_small, tune_pretest, tune_fuse, tune_graph;     // tmpc_set_tuning
   void* dd_slab;                 // tight mode (tmpc_set_tight): low words of the double-double planes, allocated on first use
   size_t dd_bytes;
   int tight;                     // 1: the tight phase follows the default solve
@@ -650,6 +654,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
+  bool use_graph = h->tune_graph && dm.dp <= 64 && !(h->flags & (TMPC_FLAG_PROFILE | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) && st == ln->st;
   const int reg_max = (h->flags & TMPC_DEBUG_FLAG_NO_LIFT) ? 0 : REG_MAX;      // (debug: no diagonal lifts, frozen pivots while centering go straight to the back-off-and-step route)
   HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
@@ -676,6 +681,23 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   auto ipm_loop = [&](const Opts& o, bool ddm, int cap) -> int {
   while (active > 0 && it < cap) {
     const int BP = active * dm.p;        // grids cover the problems still iterating only
+    // Launch-bound shapes (blocks of one tile: the reference's own examples; ~35 dependent launches of a few microseconds each per iteration): the launch
+    // sequence of an iteration is captured once per distinct argument set as a hipGraph and replayed -- one submission instead of ~35.  The key holds
+    // every launch argument (workspace views, dimensions, options, list lengths), so a replay enqueues exactly what the code below would.
+    hipGraphExec_t gexec = nullptr;
+    std::string gkey;
+    bool capturing = false;
+    int nkev = 0;
+    if (use_graph && !ddm) {
+      gkey.assign((const char*)&w, sizeof(WS)); gkey.append((const char*)&dm, sizeof(Dims)); gkey.append((const char*)&o, sizeof(Opts));
+      const int ks[6] = {active, nfac, nb, reg_max, (int)h->flags, h->tune_pretest | (h->tune_fuse << 1) | (h->tune_small << 2)};
+      gkey.append((const char*)ks, sizeof(ks));
+      if (!ln->graphs) ln->graphs = new std::unordered_map<std::string, hipGraphExec_t>();
+      auto f = ln->graphs->find(gkey);
+      if (f != ln->graphs->end()) gexec = f->second;
+      else if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+    }
+    if (!gexec) {
     if (prof) HIPCHK(hipEventRecord(ln->ev[0], st));
     if (big) hipLaunchKernelGGL(kb_stage_pre, dim3(BP), dim3(256), 0, st, w, dm);
     else TMPC_STAGE_LAUNCH(k_stage_pre, slots_bytes(PRE_SLOTS), st, w, dm);
@@ -729,7 +751,6 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
-    int nkev = 0;
     if (ddm) dd_factor(w, dm, h->sched, h->d_sched, alist, active, st);
     else if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
@@ -773,6 +794,20 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[5], st));
+    }      // (!gexec)
+    if (capturing) {
+      hipGraph_t graph = nullptr;
+      const bool ok_ = hipStreamEndCapture(st, &graph) == hipSuccess && graph && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) hipGraphDestroy(graph);
+      if (!ok_) {        // nothing of this iteration ran (it was only recorded): plain launches from here on, same iteration again
+        (void)hipGetLastError();
+        use_graph = false; gexec = nullptr;
+        continue;
+      }
+      if (ln->graphs->size() >= 64) { for (auto& kv : *ln->graphs) hipGraphExecDestroy(kv.second); ln->graphs->clear(); }
+      (*ln->graphs)[gkey] = gexec;
+    }
+    if (gexec) HIPCHK(hipGraphLaunch(gexec, st));
     const int nfac_done = nfac;
     HIPCHK(hipMemcpyAsync(cnt, w.active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -931,7 +966,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   h->dm = make_dims(cap, p, nx, mb, ng, nc, step3);
   h->sched = cr_build(p);
   h->rs = 0; h->mt = 0;
-  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1;
+  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1;
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->opt.fast_exit = 0;
   h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); tmpc_set_tuning(TMPC_TUNE_CHORD_STEP, 0) disables
@@ -946,7 +981,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   }
   int rc = cr_upload(h->sched, &h->d_sched);
   bool ok = (rc == TMPC_OK) && hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
-  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.big_scr = nullptr; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
+  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.big_scr = nullptr; ln.graphs = nullptr; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
   for (int l = 0; l < nl && ok; ++l) {
     Lane& ln = h->lane[l];
     carve(ln.ws, h->dm, (char*)h->slab + (size_t)l * lane_bytes, &ln);
@@ -972,6 +1007,7 @@ int tmpc_destroy(tmpc_handle* h) {
     for (hipEvent_t e : ln.kev) hipEventDestroy(e);
     if (ln.st) hipStreamDestroy(ln.st);
     if (ln.big_scr) hipFree(ln.big_scr);
+    if (ln.graphs) { for (auto& kv : *ln.graphs) hipGraphExecDestroy(kv.second); delete ln.graphs; }
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
@@ -1006,6 +1042,7 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
     case TMPC_TUNE_SMALL_BLOCKS: h->tune_small = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_EIG_PRETEST: h->tune_pretest = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_FUSE_FWD: h->tune_fuse = value != 0.0; return TMPC_OK;
+    case TMPC_TUNE_GRAPH: h->tune_graph = value != 0.0; return TMPC_OK;
     default: snprintf(g_err, sizeof(g_err), "tmpc_set_tuning: unknown key %d", key); return TMPC_E_ARG;
   }
 }
