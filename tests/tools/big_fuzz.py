@@ -43,6 +43,7 @@ for case in range(ncases):
         todo['G'] = lambda: h.convexify_eq_batch(A, B, H, G)
     if nc:
         todo['step2'] = lambda: h.convexify_step2_batch(A, B, H, np.concatenate([G, C[:, :, :nc]], axis=2), ncnt, rho)
+        todo['beta'] = lambda: h.convexify_step2_batch(A, B, H, np.concatenate([G, C[:, :, :nc]], axis=2), ncnt, 0.0)      # the beta-only objective: cost-free multipliers, no norm cones
     outs = {m: f() for m, f in todo.items()}
     h.close()
     if n <= 36 and wide:
@@ -56,6 +57,8 @@ for case in range(ncases):
             r = co.sdp_step1(A[0], B[0], H[0], G=Go); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=Go, Fg=r['Fg'])[0]
         elif m == 'step2':
             r = co.sdp_step1(A[0], B[0], H[0], G=Go, C=Cl, rho=rho); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=Go, Fg=r.get('Fg'), C=Cl, F=r.get('F'))[0]
+        elif m == 'beta':
+            r = co.sdp_step1(A[0], B[0], H[0], G=Go, C=Cl, cost_free=True); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], G=Go, Fg=r.get('Fg'), C=Cl, F=r.get('F'))[0]
         else:
             r = co.sdp_step1(A[0], B[0], H[0], rho=rho, force=True); dH = co.convex_hessian_suppl(A[0], B[0], r['P'], T=r['T'])[0]
         early = bool(o['info'][0, 13] != 0.0)
@@ -66,9 +69,32 @@ for case in range(ncases):
                          iters=int(o['iters'][0]), oracle_iters=int(r['iters'])))
         if err == err and same_mu:
             worst[m] = max(worst.get(m, 0.0), err)
-        flag = '' if (early or (ok_o == ok_h and (err != err or err < 1e-8 or not same_mu))) else '   <-- MISMATCH'
+        note = ''
+        if err == err and same_mu and err >= 1e-8:
+            # is the member determined to that accuracy at all?  the oracle against itself on inputs 1e-14 apart (rule of tests/tools/parity_fuzz.py: set aside when
+            # the oracle's own reproducibility is within a factor 3 of the GPU's deviation; cost-free multipliers with nearly n(n+1)/2 rows make M_k free)
+            H2 = co.symmetrize(H[0] * (1 + 1e-14 * np.random.default_rng(1).standard_normal(H[0].shape)))
+            if m == 'beta':
+                r2 = co.sdp_step1(A[0], B[0], H2, G=Go, C=Cl, cost_free=True); dH2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], G=Go, Fg=r2.get('Fg'), C=Cl, F=r2.get('F'))[0]
+            elif m == 'step2':
+                r2 = co.sdp_step1(A[0], B[0], H2, G=Go, C=Cl, rho=rho); dH2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], G=Go, Fg=r2.get('Fg'), C=Cl, F=r2.get('F'))[0]
+            elif m == 'G':
+                r2 = co.sdp_step1(A[0], B[0], H2, G=Go); dH2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], G=Go, Fg=r2['Fg'])[0]
+            elif m == 'plain':
+                r2 = co.sdp_step1(A[0], B[0], H2); dH2 = co.convex_hessian_suppl(A[0], B[0], r2['P'])[0]
+            else:
+                r2 = co.sdp_step1(A[0], B[0], H2, rho=rho, force=True); dH2 = co.convex_hessian_suppl(A[0], B[0], r2['P'], T=r2['T'])[0]
+            selfrep = rel(H2 + dH2, H[0] + dH)
+            rows[-1]['oracle_self_reproducibility'] = selfrep
+            note = f' (oracle vs itself on inputs 1e-14 apart: {selfrep:.2e})'
+            if selfrep > 0.3 * err:
+                rows[-1]['set_aside'] = True
+                worst[m] = max([r_['err'] for r_ in rows if r_['model'] == m and r_['err'] == r_['err'] and r_['same_mu'] and not r_.get('set_aside')] + [0.0])
+        flag = '' if (early or rows[-1].get('set_aside') or (ok_o == ok_h and (err != err or err < 1e-8 or not same_mu))) else '   <-- MISMATCH'
+        flag = note + (' set aside: ill-determined member' if rows[-1].get('set_aside') else '') + flag
         print(f'case {case:2d} {m:6s} p={p} nx={nx:2d} n={n:2d} ng={ng:2d} nc={nc:2d}: hip {int(o["status"][0])} ({int(o["iters"][0])} it) oracle {r["ipm_status"]} ({r["iters"]} it) err {err:.2e}{"" if same_mu else " (different mu_t)"}{flag}', flush=True)
-mism = [r for r in rows if not r['early'] and ((r['hip_status'] == 0) != (r['oracle'] == 'optimal') or (r['err'] == r['err'] and r['same_mu'] and r['err'] >= 1e-8))]
-print(f'members {len(rows)} worst rel error per model {worst} mismatches {len(mism)} seconds {time.time() - t0:.0f}')
+mism = [r for r in rows if not r['early'] and not r.get('set_aside') and ((r['hip_status'] == 0) != (r['oracle'] == 'optimal') or (r['err'] == r['err'] and r['same_mu'] and r['err'] >= 1e-8))]
+print(f'members {len(rows)} worst rel error per model (set-aside members excluded) {worst} mismatches {len(mism)} set aside {sum(1 for r in rows if r.get("set_aside"))} '
+      f'largest error among the set-aside {max([r["err"] for r in rows if r.get("set_aside")] + [0.0]):.2e} seconds {time.time() - t0:.0f}')
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(dict(rows=rows, worst=worst, mismatches=mism), open(os.path.join(ROOT, 'gpurun_out', 'big_fuzz.json'), 'w'), indent=1)
