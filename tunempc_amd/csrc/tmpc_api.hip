@@ -693,8 +693,13 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       const int ks[6] = {active, nfac, nb, reg_max, (int)h->flags, h->tune_pretest | (h->tune_fuse << 1) | (h->tune_small << 2)};
       gkey.append((const char*)ks, sizeof(ks));
       if (!ln->graphs) ln->graphs = new std::unordered_map<std::string, hipGraphExec_t>();
+      // an argument set seen for the first time runs as plain launches and is only remembered; the second time it is captured; from then on replayed --
+      // the tail of a ragged batch (a new pair of list lengths every iteration) never pays for a capture it would use once
       auto f = ln->graphs->find(gkey);
-      if (f != ln->graphs->end()) gexec = f->second;
+      if (f == ln->graphs->end()) {
+        if (ln->graphs->size() >= 256) { for (auto& kv : *ln->graphs) if (kv.second) hipGraphExecDestroy(kv.second); ln->graphs->clear(); }
+        (*ln->graphs)[gkey] = nullptr;
+      } else if (f->second) gexec = f->second;
       else if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
     }
     if (!gexec) {
@@ -804,7 +809,6 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
         use_graph = false; gexec = nullptr;
         continue;
       }
-      if (ln->graphs->size() >= 64) { for (auto& kv : *ln->graphs) hipGraphExecDestroy(kv.second); ln->graphs->clear(); }
       (*ln->graphs)[gkey] = gexec;
     }
     if (gexec) HIPCHK(hipGraphLaunch(gexec, st));
@@ -1007,7 +1011,7 @@ int tmpc_destroy(tmpc_handle* h) {
     for (hipEvent_t e : ln.kev) hipEventDestroy(e);
     if (ln.st) hipStreamDestroy(ln.st);
     if (ln.big_scr) hipFree(ln.big_scr);
-    if (ln.graphs) { for (auto& kv : *ln.graphs) hipGraphExecDestroy(kv.second); delete ln.graphs; }
+    if (ln.graphs) { for (auto& kv : *ln.graphs) if (kv.second) hipGraphExecDestroy(kv.second); delete ln.graphs; }
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
