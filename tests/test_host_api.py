@@ -216,3 +216,18 @@ def test_synthetic_generator_knobs():
     assert np.allclose(rho, 0.5)
     ev = np.linalg.eigvalsh(H)
     assert ev.min() > 0 and 1e2 < (ev[:, -1] / ev[:, 0]).max() <= 1e5 * (1 + 1e-9)
+
+
+def test_header_constants_match_the_python_mirror():
+    """the limits and keys that include/tunempc_hip.h publishes are the ones the Python side uses"""
+    from tunempc_amd import convexifier, _lib
+    src = open(os.path.join(ROOT, 'include', 'tunempc_hip.h')).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define\s+(TMPC_[A-Z0-9_]+)\s+(-?\d+)\b', src, flags=re.M)}
+    assert defs['TMPC_MAX_ROWS'] == convexifier.NG_MAX == convexifier.NC_MAX == 31
+    assert defs['TMPC_ARROW_LD'] == _lib.ARROW_LD == defs['TMPC_MAX_ROWS'] + 1
+    assert [defs[k] for k in ('TMPC_TUNE_CHORD_STEP', 'TMPC_TUNE_SMALL_BLOCKS', 'TMPC_TUNE_EIG_PRETEST', 'TMPC_TUNE_FUSE_FWD', 'TMPC_TUNE_GRAPH')] == [1, 2, 3, 4, 5]
+    assert defs['TMPC_INFO_STRIDE'] == 16
+    assert convexifier.N_TUNED == 32 and convexifier.N_MAX == 64
+    lib = _lib.load_library()
+    # the row limit is enforced by the library itself (workspace query: 0 = unsupported), not only by the mirror
+    assert lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 31, 31) > 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 32, 0) == 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 0, 32) == 0
