@@ -836,7 +836,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
               U = np.concatenate([U, np.zeros((p, d, len(arrows)))], axis=2)       # the epigraph variables do not reach P
               nb_ = 2 + p * ng + len(arrows)
               Bfull = np.zeros((nb_, nb_)); Bfull[:2, :2] = Bb
-              Bpp = np.einsum('kvab,kwab->kvw', GG, W)                                           # <A_v, Phi(A_w)>  (= (g_v'X g_w)(g_w'S^-1 g_v) summed over the two LMIs for rows)
+              Bpp = GG.reshape(p, ng, n * n) @ W.reshape(p, ng, n * n).transpose(0, 2, 1)         # <A_v, Phi(A_w)>  (= (g_v'X g_w)(g_w'S^-1 g_v) summed over the two LMIs for rows); as one BLAS product per stage (Step 3: ng = n(n+1)/2 'rows')
               c_tau = -np.einsum('kiab,kab->ki', GG, Psi)                                        # <g g', -Psi_k>
               c_alpha = np.einsum('kiab,kab->ki', GG, PhiH)
               for k in range(p):
@@ -870,7 +870,9 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                       Bfull[cols, cols[q]] += 2.0 * wr * cw[a['idx']] * Fq[0, 1:]
               Bb = Bfull
           TU = chol.solve(U)
-          Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
+          # (plain model: two border columns, the einsum as in rounds 1-3 -- the tight-mode tests are sensitive to its summation order; with stage-local border
+          # columns, up to 2 + p n(n+1)/2 of them in Step 3, one BLAS product: 16 s of 24 at n = 34)
+          Sb = Bb - (np.einsum('kdi,kdj->ij', U, TU) if U.shape[2] <= 2 else U.reshape(-1, U.shape[2]).T @ TU.reshape(-1, TU.shape[2]))
 
         def direction(sig_mu, corr1=None, corr2=None, corr0=0.0, corrp=None, corre=None):
             T1 = sig_mu * S1i - symmetrize(X1 @ Rd1 @ S1i)
