@@ -55,6 +55,8 @@ int tmpc_debug_get_array(tmpc_handle* h, int which, uint64_t offset, uint64_t co
 
 /* Smallest eigenvalue of nmat symmetric n x n matrices (Householder tridiagonalisation + Sturm multisection). */
 int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double* out);
+/* The same for n <= 8 by the one-thread-per-matrix routine the small shapes use (lane_min_eig8: Householder + Laguerre in registers; round 5). */
+int tmpc_debug_min_eig_lane(tmpc_handle* h, int nmat, int n, const double* W, double* out);
 
 /* Isolated timing of the block factorisation and of one single-right-hand-side solve on nb copies of one random SPD system:
  * ms_out2[0] = factorisation, [1] = solve (averages over `reps`). */

@@ -9,6 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     nb = int(sys.argv[2])
     A, B, H = synthetic.gen_batch(100000, nb, 64, 24, 8)
     h = HipConvexifier(64, 24, 8, chunk=nb, flags=FLAG_PROFILE)
+    h.set_tuning(chord_step=float(sys.argv[4]))      # (rounds 2-3: the environment variable TMPC_CHORD, removed from the library in round 4)
     h.convexify_batch(A[:8], B[:8], H[:8]); h.profile()
     t = time.time(); o = h.convexify_batch(A, B, H); t = time.time() - t
     pr = h.profile(); tr = h.trace(min(nb, 4))
@@ -20,9 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ref = None
 for thr in ('0', '1000', '100', '30', '10', '4'):
-    env = dict(os.environ, TMPC_CHORD=thr)
     f = f'/tmp/chord_{thr}.npy'
-    out = subprocess.run([sys.executable, __file__, 'child', str(nb), f], env=env, capture_output=True, text=True)
+    out = subprocess.run([sys.executable, __file__, 'child', str(nb), f, thr], capture_output=True, text=True)
     try:
         r = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception:

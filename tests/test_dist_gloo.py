@@ -223,3 +223,54 @@ def test_straggler_aware_split_evens_out_the_ranks():
     assert max(bal) == max(contiguous) and min(bal) > min(contiguous)    # the slowest member sets the job time either way; the other rank is no longer idle-cheap
     assert abs(bal[0] - bal[1]) <= abs(ref[0]['iters'] - ref[1]['iters']) + 1      # what is left is the difference between the two stragglers themselves
     print('per-rank max iterations: balanced', bal, 'contiguous', contiguous)
+
+
+def _worker_balanced_contract(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tunempc_amd.dist import convexify_batch_sharded
+    nb = 5                                                   # ragged: 3 + 2 problems, and NOT the sizes of the contiguous split (2 + 3)
+    A = torch.arange(nb, dtype=torch.float64).view(nb, 1, 1, 1) + 1.0
+    seen = []
+
+    def solve_fn(a, b, h):
+        seen.append(a.flatten().tolist())
+        return dict(Hc=2.0 * a, kappa=a.flatten().clone(), status=torch.zeros(a.shape[0], dtype=torch.int32))
+
+    base = np.array([5.0, 1.0, 9.0, 3.0, 7.0])
+    cost = base if rank == 0 else base[::-1].copy()          # the ranks disagree about the proxy: rank 0's assignment is the one everybody uses
+    cache = {}
+    g1 = convexify_batch_sharded(A, A, A, solve_fn, cost=cost, cache=cache)
+    ptr = g1['Hc'].data_ptr()
+    ok1 = bool(torch.equal(g1['Hc'], 2.0 * A) and torch.equal(g1['kappa'], A.flatten()))
+    g2 = convexify_batch_sharded(A, A, A, solve_fn, cost=torch.from_numpy(cost), cache=cache)      # a tensor works as well; buffers are re-used
+    ok2 = bool(torch.equal(g2['Hc'], 2.0 * A)) and g2['Hc'].data_ptr() == ptr
+    errs = []
+    for bad in (base[:4], np.r_[base[:4], np.nan]):
+        try:
+            convexify_batch_sharded(A, A, A, solve_fn, cost=bad)
+            errs.append(None)
+        except ValueError as e:
+            errs.append(str(e)[:20])
+    ret[rank] = (ok1, ok2, seen[0], errs)
+    dist.destroy_process_group()
+
+
+def test_balanced_split_contract():
+    """one assignment for every rank (rank 0's, broadcast) even when the ranks pass different cost vectors; ragged shards whose sizes are not
+    those of the contiguous split; every row of the result written; result / gather buffers re-used through `cache`; a cost vector of the wrong length or with a NaN
+    is refused before any collective."""
+    from tunempc_amd.dist import balanced_assignment
+    world = 2
+    mgr = mp.Manager(); ret = mgr.dict()
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_worker_balanced_contract, args=(world, port, ret), nprocs=world, join=True)
+    parts = balanced_assignment(np.array([5.0, 1.0, 9.0, 3.0, 7.0]), world)
+    assert [len(q) for q in parts] == [3, 2]
+    for rank in range(world):
+        ok1, ok2, mine, errs = ret[rank]
+        assert ok1 and ok2
+        assert mine == [float(i + 1) for i in parts[rank]]                # rank 1 solved rank 0's share for it, not the one its own cost vector implies
+        assert errs[0] is not None and errs[1] is not None

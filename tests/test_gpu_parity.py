@@ -186,6 +186,32 @@ def test_tridiagonal_min_eig(hc, n):
     assert (np.abs(out - ref) <= 1e-12 * np.maximum(scale, 1e-300)).all(), np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 6, 7, 8])
+def test_lane_min_eig(hc, n):
+    """Round 5: the step-length primitive of the small shapes -- one THREAD per matrix, Householder tridiagonalisation + Laguerre's iteration in registers
+    (lane_min_eig8) -- vs LAPACK: random, multiples of the identity (an n-fold root), diagonal, (nearly) double smallest eigenvalues, scales 1e-8 ... 1e8, zero."""
+    h = hc(2, 3, 1)
+    rng = np.random.default_rng(500 + n)
+    W = rng.standard_normal((300, n, n)); W = W + W.transpose(0, 2, 1)
+    W[0] = np.eye(n) * 3.0; W[1] = -np.eye(n) * 0.25; W[2] = 0.0
+    W[3] = np.diag(np.linspace(-2, 5, n)) if n > 1 else W[3]
+    for i in range(4, 60):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.sort(rng.standard_normal(n))
+        if n > 1 and i % 3 == 0:
+            lam[1] = lam[0]                                   # double smallest eigenvalue (Laguerre converges linearly there)
+        if n > 1 and i % 3 == 1:
+            lam[1] = lam[0] + 1e-9
+        if i % 3 == 2:
+            lam = 10.0 ** rng.uniform(-8, 8, n) * rng.choice([-1, 1], n)
+        W[i] = (q * lam) @ q.T
+    W[60] *= 1e-8; W[61] *= 1e6
+    out = h.debug_min_eig(W, lane=True)
+    sym = (W + W.transpose(0, 2, 1)) / 2
+    ev = np.linalg.eigvalsh(sym)
+    assert (np.abs(out - ev[:, 0]) <= 1e-13 * np.maximum(np.abs(ev).max(-1), 1e-300)).all(), np.abs(out - ev[:, 0]).max()
+
+
 @pytest.mark.parametrize('p,nx,mb', [(1, 3, 1), (4, 4, 2), (3, 24, 8)])
 def test_supplement(hc, p, nx, mb):
     """convexHessianSuppl (convexifier.py:165-211) on the GPU vs numpy."""
@@ -1024,11 +1050,12 @@ def test_supplement_with_constraint_and_regularisation_terms(hc):
 
 
 @pytest.mark.parametrize('variant', [dict(flags=32), dict(tuning=dict(fuse_fwd=0, chord_step=0)), dict(tuning=dict(small_blocks=0)), dict(tuning=dict(eig_pretest=0)),
-                                     dict(tuning=dict(graph=0)), dict(lanes=1), dict(lanes=3), dict(flags=1)], ids=str)
+                                     dict(tuning=dict(graph=0)), dict(lanes=1), dict(lanes=3), dict(flags=1), dict(tuning=dict(persistent=2)), dict(tuning=dict(persistent=0))], ids=str)
 def test_kernel_variants_behind_handle_options(golden_dir, variant):
     """The kernel variants that rounds 1-3 hid behind environment variables, now options of the handle (tmpc_set_tuning, tmpc_create_ex) or debug flags
     (tunempc_hip_debug.h): register-staged factorisation kernels (flag 32: the path of blocks wider than 320), separate forward sweep without chord steps, the batched
-    launch sequence for 16-wide blocks, every step-length eigenvalue computed, one / three lanes, scalar-FMA GEMM fragments -- each against four golden vectors."""
+    launch sequence for 16-wide blocks, every step-length eigenvalue computed, one / three lanes, scalar-FMA GEMM fragments, the persistent one-launch loop of
+    tmpc_persist.h forced on / off (round 5; it serves the two small shapes, the others fall through) -- each against four golden vectors."""
     from tunempc_amd._lib import HipConvexifier
     worst = 0.0
     for name in ('c2_unicycle_shape', 'c3_evaporation_shape', 'mid_n16', 'awe_shape_n15'):
@@ -1263,10 +1290,15 @@ def test_large_block_supplement_with_multiplier_terms():
     J = rng.standard_normal((nb, p, nr, nx + mb)); wts = rng.uniform(0.0, 1.0, (nb, p, nr))
     h = HipConvexifier(p, nx, mb, chunk=nb)
     dH = h.supplement_terms_batch(A, B, P, J=J, wts=wts)
+    T = rng.uniform(0.1, 1.0, (nb, p, nx + mb, nx + mb)); T = T + T.transpose(0, 1, 3, 2)      # round 5: the T term of Step 3 at n > 32 as well
+    dHT = h.supplement_terms_batch(A, B, P, J=J, wts=wts, T=T)
+    dHT0 = h.supplement_terms_batch(A, B, P, T=T)
     h.close()
     for b in range(nb):
         want = co.convex_hessian_suppl(A[b], B[b], P[b], G=J[b], Fg=wts[b])[0]
         assert rel(dH[b], want) < 1e-13
+        assert rel(dHT[b], co.convex_hessian_suppl(A[b], B[b], P[b], G=J[b], Fg=wts[b], T=T[b])[0]) < 1e-13
+        assert rel(dHT0[b], co.convex_hessian_suppl(A[b], B[b], P[b], T=T[b])[0]) < 1e-13
 
 
 def test_many_row_handle_matches_the_small_one():
@@ -1423,3 +1455,52 @@ def test_iteration_graph_replay_is_bit_identical():
             for k in ('Hc', 'P', 'kappa', 'status', 'iters'):
                 assert np.array_equal(a[k], g[k]), (seed, k)
         assert np.array_equal(outs[1][0]['Hc'], outs[1][3]['Hc'])
+
+
+# ----------------------------------------------------------------------------- round 5: the whole interior-point loop of a small problem as one launch (tmpc_persist.h)
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(13, 2, 30, 4, 1), (20, 4, 1, 3, 1), (30, 4, 2, 3, 1), (40, 3, 5, 2, 2), (41, 2, 7, 5, 1), (42, 3, 17, 5, 3), (43, 2, 33, 1, 1), (44, 1, 160, 2, 1),
+                                             (45, 2, 16, 4, 4), (46, 1, 48, 3, 5)])
+def test_persistent_small_kernel_parity(seed, nb, p, nx, mb):
+    """One 16-wave workgroup runs every iteration of a problem (n <= 8, nx <= 5, plain model) -- forced on whatever the batch -- against the CPU oracle (1e-8) and against
+    the launch-sequence path (same code, sums taken by one wave instead of four: rounding only, same iteration counts); periods of 1, 2, one round, a round boundary
+    (16, 17, 33), the longest the LDS image of the substitution takes (160), early-exit members."""
+    from tunempc_amd._lib import HipConvexifier
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    outs = []
+    for mode in (2, 0):
+        h = HipConvexifier(p, nx, mb, chunk=nb)
+        h.set_tuning(persistent=mode)
+        outs.append(h.convexify_batch(A, B, H))
+        h.close()
+    o, s = outs
+    for b in range(nb):
+        r = co.convexify_arrays(A[b], B[b], H[b])
+        assert int(o['status'][b]) == int(r['status'])
+        assert bool(o['info'][b, 13]) == bool(r['early_exit'])
+        assert rel(o['Hc'][b], r['Hc']) < PARITY
+        assert abs(o['kappa'][b] - r['kappa']) < 1e-9 * max(1.0, r['kappa'])
+        assert rel(o['P'][b], r['P']) < PARITY
+    assert np.array_equal(o['status'], s['status'])
+    assert np.abs(o['iters'].astype(int) - s['iters'].astype(int)).max() <= 1
+    assert rel(o['Hc'], s['Hc']) < 1e-9
+
+
+def test_persistent_kernel_takes_batches_by_itself():
+    """The default rule (TMPC_TUNE_PERSISTENT = 1): a batch that fills the chip goes through the persistent kernel, a single long problem through the launch sequence --
+    both equal the forced variants bit for bit; a member that is convex already and an infeasible one inside the batch keep their statuses."""
+    from tunempc_amd._lib import HipConvexifier
+    nb, p, nx, mb = 192, 20, 3, 2
+    A, B, H = co.gen_batch(777, nb, p, nx, mb)
+    H[5] = np.eye(nx + mb)[None] * 2.0                      # early exit
+    B[7] = 0.0; H[7, :, nx:, nx:] = -np.eye(mb)             # infeasible (convexifier.py:157)
+    res = {}
+    for mode in (1, 2, 0):
+        h = HipConvexifier(p, nx, mb, chunk=nb); h.set_tuning(persistent=mode)
+        res[mode] = (h.convexify_batch(A, B, H), h.convexify_batch(A[:1], B[:1], H[:1]))
+        h.close()
+    for k in ('Hc', 'P', 'kappa', 'status', 'iters'):
+        assert np.array_equal(res[1][0][k], res[2][0][k]), k          # 192 problems: persistent by the rule
+        assert np.array_equal(res[1][1][k], res[0][1][k]), k          # 1 problem of period 20: launch sequence
+    st = res[1][0]['status']
+    assert st[5] == 0 and bool(res[1][0]['info'][5, 13]) and st[7] == 2 and (np.delete(st, [5, 7]) == 0).all()
+    assert rel(res[2][0]['Hc'], res[0][0]['Hc']) < 1e-9

@@ -237,4 +237,14 @@ def test_dropin_convexify_tight_option():
     assert rel(np.stack(dt), ref) < 1e-7 and all(np.array_equal(a, b) for a, b in zip(d0, d1)) and rel(np.stack(d0), ref) > 1e-5
     with pytest.raises(NotImplementedError):
         convexifier.convexify(*args, G=[np.ones((1, nx + mb))] * p, opts={'tight': True})
+    # the answer must not depend on the cache history.  A call with C rows leaves a shared handle with room for them behind; the tight call
+    # that follows takes a plain handle of its own and returns the same bits as before; tight + C is refused up front (NotImplementedError, not a RuntimeError
+    # from tmpc_set_tight on the shared handle)
+    Cs = [np.ones((2, nx + mb)) if k % 2 else None for k in range(p)]
+    dc = convexifier.convexify(*args, C=Cs)[0]
+    assert all(np.array_equal(a, b) for a, b in zip(dc, d0))              # (Step 1 is feasible: the rows never enter)
+    dt2 = convexifier.convexify(*args, opts={'rho': 1e-3, 'solver': 'hip', 'force': False, 'tight': True})[0]
+    assert all(np.array_equal(a, b) for a, b in zip(dt, dt2))
+    with pytest.raises(NotImplementedError):
+        convexifier.convexify(*args, C=Cs, opts={'tight': True})
     convexifier.release_handles()

@@ -28,7 +28,7 @@ EXPORTS = [
 # ... and in include/tunempc_hip_debug.h (unit-test / diagnostic entries)
 DEBUG_EXPORTS = [
     'tmpc_debug_gemm_nt', 'tmpc_debug_block_solve', 'tmpc_debug_cr_schedule', 'tmpc_debug_get_multipliers', 'tmpc_debug_get_array',
-    'tmpc_debug_min_eig', 'tmpc_debug_factor_bench',
+    'tmpc_debug_min_eig', 'tmpc_debug_min_eig_lane', 'tmpc_debug_factor_bench',
 ]
 
 
@@ -136,6 +136,8 @@ def load_library():
     lib.tmpc_debug_factor_bench.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     lib.tmpc_debug_min_eig.restype = C.c_int
     lib.tmpc_debug_min_eig.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    lib.tmpc_debug_min_eig_lane.restype = C.c_int
+    lib.tmpc_debug_min_eig_lane.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     lib.tmpc_last_error.restype = C.c_char_p
     lib.tmpc_version.restype = C.c_char_p
     _LIB = lib
@@ -192,9 +194,9 @@ class HipConvexifier:
         _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
                                                    int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
 
-    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None):
+    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None, fused_elim=None, persistent=None):
         """Performance knobs of the handle (include/tunempc_hip.h: tmpc_set_tuning); None keeps the current value."""
-        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph)):
+        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph), (6, fused_elim), (7, persistent)):
             if v is not None:
                 _check(self.lib, self.lib.tmpc_set_tuning(self._h, key, float(v)), 'tmpc_set_tuning')
 
@@ -503,11 +505,13 @@ class HipConvexifier:
         _check(self.lib, self.lib.tmpc_debug_gemm_nt(self._h, _dptr(Cm), _dptr(A), _dptr(B), M, N, K, int(mode), int(lower)), 'tmpc_debug_gemm_nt')
         return Cm
 
-    def debug_min_eig(self, W):
+    def debug_min_eig(self, W, lane=False):
+        """smallest eigenvalues of symmetric matrices [nmat, n, n]; lane=True: the one-thread-per-matrix routine of the small shapes (n <= 8)"""
         W = np.ascontiguousarray(W, dtype=np.float64)
         nmat, n, _ = W.shape
         out = np.empty(nmat)
-        _check(self.lib, self.lib.tmpc_debug_min_eig(self._h, nmat, n, _dptr(W), _dptr(out)), 'tmpc_debug_min_eig')
+        fn = self.lib.tmpc_debug_min_eig_lane if lane else self.lib.tmpc_debug_min_eig
+        _check(self.lib, fn(self._h, nmat, n, _dptr(W), _dptr(out)), 'tmpc_debug_min_eig')
         return out
 
     def tracking_reference(self, Hc, q, wref, ts):

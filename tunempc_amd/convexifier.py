@@ -31,11 +31,15 @@ N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic pe
 NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
-def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):
+def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False):
     """One cached handle per problem shape.  Its workspace is sized for the batch actually asked for (next power of two of nb,
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
     pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
-    of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk."""
+    of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk.
+    plain=True: a handle of its own without any room for rows (the tight-accuracy mode runs on such a handle only: a shared one that an
+    earlier call of the same shape grew rows on would make the answer depend on the cache history -- ADVICE r4)."""
+    if plain:
+        ng = nc = 0
     if nx + mb > N_MAX:
         raise NotImplementedError('the HIP path handles stage blocks up to nx + nu = {} (got {})'.format(N_MAX, nx + mb))
     if step3 and load_library().tmpc_workspace_bytes_step3_con(1, p, nx, mb, ng, nc) == 0:
@@ -43,7 +47,7 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False):
         # the LDS image of the substitution kernels (nx(nx+1)/2 + n(n+1)/2 + 1 + rows <= 2384: n = 48 with nx = 36 and 24 + 24 rows fits, n = 64 with nx = 40 does not)
         raise NotImplementedError('Step 3 (force=True) at nx = {}, nx + nu = {}: Schur blocks of nx(nx+1)/2 + n(n+1)/2 + 1 + multipliers exceed what the '
                                   'substitution kernels hold in LDS (2384)'.format(nx, nx + mb))
-    key = (p, nx, mb, ng, bool(step3))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
+    key = (p, nx, mb, ng, bool(step3), bool(plain))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
     want = 1
     while want < min(max(int(nb), 1), _MAX_CHUNK):
         want *= 2
@@ -95,19 +99,20 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
         ng = G.shape[2]
         if ng > NG_MAX:
             raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
-    h = handle or _handle(p, nx, mb, ng, nc_hint, nb)      # nc_hint: room for the C rows of a Step 2 that may follow (same handle)
+    if tight and ng > 0:
+        raise NotImplementedError('the tight-accuracy mode covers the plain Step 1 model (no G / C rows)')
+    if handle is not None:
+        h = handle
+    elif tight:
+        h = _handle(p, nx, mb, 0, 0, nb, plain=True)       # never the shared handle of the shape (it may have room for rows, which the mode refuses)
+    else:
+        h = _handle(p, nx, mb, ng, nc_hint, nb)            # nc_hint: room for the C rows of a Step 2 that may follow (same handle)
     global _LAST_HANDLE
     _LAST_HANDLE = h
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)      # per call: a cached handle never keeps an earlier caller's tolerance
     if ng > 0:
-        if tight:
-            raise NotImplementedError('the tight-accuracy mode covers the plain Step 1 model (no G / C rows)')
         return h.convexify_eq_batch(A, B, H, G)
-    if tight and (h.ng or h.nc or h.step3):       # (a cached handle with room for constraint rows cannot run the mode: a plain one of its own)
-        h = _handle(p, nx, mb, 0, 0, nb)
-        h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
-        _LAST_HANDLE = h
     if tight:
         h.set_tight(True, None if tight is True else float(tight))
     try:
@@ -224,7 +229,7 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
 _LAST_HANDLE = None      # handle of the most recent batch call (its iteration trace is the solver log of convexify())
 
 
-_IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged'}     # info[10]; plays the role of M.status (convexifier.py:365, :443)
+_IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged', 3: 'optimal'}     # info[10]; plays the role of M.status (convexifier.py:365, :443); 3: TMPC_FLAG_FAST_EXIT stopped after the first full centering step
 
 
 def _log_solution(res):
@@ -237,7 +242,7 @@ def _log_solution(res):
         for r in _LAST_HANDLE.trace(1)[0]:
             if r[0] > 0:
                 Logger.logger.debug('{:3d} {:>6s} {:9.2e} {:11.4e} {:10.2e} {:10.2e} {:8.4f} {:8.4f} {:9.2e}'.format(
-                    int(r[0]), 'main' if r[1] < 1 else ('chord' if r[1] % 1 else 'center'), r[2], r[3], r[4], r[5], min(r[6], 1.0), min(r[7], 1.0), r[8]))
+                    int(r[0]), 'main' if r[1] < 1 else ('chord' if r[1] % 1 else ('polish' if r[1] >= 3 else 'center')), r[2], r[3], r[4], r[5], min(r[6], 1.0), min(r[7], 1.0), r[8]))
     if ipm == 'optimal':
         Logger.logger.debug('SDP solution:')
         Logger.logger.debug('alpha: {}'.format(res['alpha'][0]))
@@ -297,6 +302,8 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     Hs = np.stack([mtools.buildHessian(_to_array(q), _to_array(r), _to_array(n_))
                    for q, r, n_ in zip(arg['Q'], arg['R'], arg['N'])])
 
+    if (opts or {}).get('tight') and (C is not None or G is not None):
+        raise NotImplementedError("opts['tight'] covers the plain model: Step 1 without G and without a Step 2 to fall back on (no C)")
     solver = (opts or {}).get('solver', 'hip')
     if solver not in ('hip', 'mosek', 'cvxopt'):
         raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))

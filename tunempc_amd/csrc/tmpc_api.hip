@@ -7,6 +7,10 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 #include <vector>
 
 #include <string>
@@ -21,6 +25,7 @@
 #include "tmpc_factor.h"
 #include "tmpc_cr.h"
 #include "tmpc_cr_small.h"
+#include "tmpc_persist.h"
 #include "tmpc_phi.h"
 #include "tmpc_t3.h"
 #include "tmpc_eig.h"
@@ -52,7 +57,48 @@ struct DevBuf {
 // block factorisation of one lane overlap with the LDS / latency-bound stage kernels and the HBM-bound triangular solves of the
 // other (the loops are independent: problems never interact).  Results do not depend on the number of lanes.
 constexpr int MAXL = 4;
+// One persistent host thread per extra lane (lanes 1 ..): created the first time a wave is split over lanes, parked on a condition variable between waves, joined
+// by tmpc_destroy.  (Until round 4 every wave spawned and joined a std::thread per extra lane -- tens of microseconds per wave, on exactly the small shapes whose
+// whole solve is a few milliseconds: review of round 4.)  A process forked after the worker was created has no such thread: the pid is checked at every use.
+struct LaneWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, stop = false;
+  pid_t pid = 0;
+  void start() {
+    pid = getpid();
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [&] { return has_job || stop; });
+        if (stop) return;
+        std::function<void()> j = std::move(job);
+        has_job = false;
+        lk.unlock();
+        j();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; done = false; }
+    cv.notify_all();
+  }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done; }); }
+  void shutdown() {
+    if (pid != getpid()) { if (th.joinable()) th.detach(); return; }      // (forked child: the thread never existed here)
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct Lane {
+  LaneWorker* worker;            // host thread of lanes 1 .. (nullptr until first used)
   WS ws;
   // lane-local copies of the user inputs when called with host pointers
   double *dA, *dB, *dH;          // device staging for the host entries (lane capacity)
@@ -85,7 +131,7 @@ struct tmpc_handle {
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
   int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
-  int tune_small, tune_pretest, tune_fuse, tune_graph;     // tmpc_set_tuning
+  int tune_small, tune_pretest, tune_fuse, tune_graph, tune_fused_elim, tune_persist;     // tmpc_set_tuning
   void* dd_slab;                 // tight mode (tmpc_set_tight): low words of the double-double planes, allocated on first use
   size_t dd_bytes;
   int tight;                     // 1: the tight phase follows the default solve
@@ -371,6 +417,11 @@ __global__ void __launch_bounds__(64) k_debug_min_eig(const double* W, double* o
   if (lane == 0) out[mid] = lo;
 }
 
+__global__ void __launch_bounds__(64) k_debug_min_eig_lane(const double* W, double* out, int n, int nmat) {      // one thread per matrix (lane_min_eig8, n <= 8)
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < nmat) out[i] = lane_min_eig8(W + (size_t)i * n * n, n);
+}
+
 template <bool USE_MFMA>
 __global__ void __launch_bounds__(256, 2) k_debug_gemm(double* C, const double* A, const double* B, int M, int N, int K, int mode, int lower) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -416,6 +467,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_trsm_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_potrf_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_cr_elim_dma, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_update<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -423,6 +475,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_cr_small_factor, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_ipm_small, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_debug_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_supplement, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -458,6 +511,7 @@ static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
 // host-side bits of Dims::flags (bit 0 = TMPC_FLAG_NO_MFMA is the only one device code reads)
 constexpr int DF_NO_SMALL = 2;   // tmpc_set_tuning(TMPC_TUNE_SMALL_BLOCKS, 0): the batched launch sequence also for dp = 16
 constexpr int DF_NO_DMA = 4;     // TMPC_DEBUG_FLAG_NO_DMA: the register-staged factorisation kernels (the path of blocks wider than 320) for every block size
+constexpr int DF_FUSED_ELIM = 8; // tmpc_set_tuning(TMPC_TUNE_FUSED_ELIM, 1): block Cholesky and triangular solves of a node in one workgroup (k_cr_elim_dma; round-5 experiment)
 
 // Small blocks (dp = 16): one kernel per factorisation / per solve instead of a launch sequence per level (tmpc_cr_small.h); TMPC_SMALL=0: off
 static bool cr_small_levels(const Dims& dm, const CrSched& sc, CrLevs* out) {
@@ -502,8 +556,11 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   for (const CrLevel& lv : sc.lev) {
     // product path: the LDS-DMA kernels (blocks up to 320 wide); TMPC_FACTOR_DMA=0 or the no-MFMA flag: the register-staged core
     const bool use_dma = !(dm.flags & DF_NO_DMA), potrf_dma = use_dma;
+    const bool fused_elim = (dm.flags & DF_FUSED_ELIM) && mf && use_dma && dm.nt <= TRR_NT && lv.nupd > 0;
     mark(0);
-    if (mf && use_dma && potrf_dma && dm.nt <= TRR_NT)
+    if (fused_elim)
+      hipLaunchKernelGGL(k_cr_elim_dma, dim3(cr_grid((long)count * lv.nelim)), dim3(256), (size_t)potrf_dma_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
+    else if (mf && use_dma && potrf_dma && dm.nt <= TRR_NT)
       hipLaunchKernelGGL(k_cr_potrf_dma, dim3(cr_grid((long)count * lv.nelim)), dim3(256), (size_t)potrf_dma_lds_doubles() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else if (mf) hipLaunchKernelGGL(k_cr_potrf<true>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
     else hipLaunchKernelGGL(k_cr_potrf<false>, dim3(cr_grid((long)count * lv.nelim)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, count);
@@ -519,7 +576,8 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     const long it_trsm = (long)count * lv.nelim * 2 * nstrip;
     const long it_upd = (long)count * ((long)lv.nupd * (nm * (nm + 1) / 2) + (long)lv.nelim * nm * nm);
     mark(1);
-    if (mf && use_dma && dm.nt <= TRR_NT) {
+    if (fused_elim) {}
+    else if (mf && use_dma && dm.nt <= TRR_NT) {
       const size_t trsm_lds = (size_t)trd_lds_doubles() * sizeof(double);
       hipLaunchKernelGGL(k_cr_trsm_dma, dim3(cr_grid((long)count * lv.nelim * 2 * nt64)), dim3(256), trsm_lds, st, w, dm, cd, lv.eoff, lv.nelim, count);
     }
@@ -632,7 +690,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   const bool t3 = dm.nT > 0;
   dm.dp = (dm.d + (eq ? dm.nz : 0) + (t3 ? dm.nT + 1 : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
-  dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
+  dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0) | (h->tune_fused_elim ? DF_FUSED_ELIM : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
   const bool big = dm.n > NMAX || (h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE);      // generic per-stage kernels (tmpc_big.h)
   const size_t t3_schur_lds = (size_t)((big ? 0 : 9 * 32 * T3_LD) + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
@@ -644,6 +702,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   wall.A = dA; wall.Bm = dB; wall.H = dH; wall.G = dG; wall.ncnt = dncnt; wall.rho = rho;
   wall.cr_orient = h->d_sched + h->sched.elim.size() + h->sched.upd.size();
   WS w = wall;                           // view over the problems still iterating (per-iteration kernels map blockIdx through alist)
+  w.A = nullptr; w.Bm = nullptr; w.H = nullptr;      // the caller's input buffers are read by the init / final kernels only (through `wall`): left out of the iteration view, whose
+                                         // bytes are the key of the iteration graphs below, a device call whose inputs move does not capture a new graph per call
   int* alist = wall.alist;
   int* flist = wall.flist;
   wall.alist = nullptr;
@@ -677,6 +737,26 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   // until round 3 the wave stopped at max_iter + center_iter + 2 = 64 and such a member came back Feasible.
   const int cap = o.max_iter + o.center_iter * (MUT_BACKOFF_MAX + 1) + 2;
   int it = 0;
+  // Small problems (one 16 x 16 tile per Schur block, n <= 8, plain model): the whole loop below as ONE launch, a 16-wave workgroup per problem
+  // (tmpc_persist.h; tmpc_set_tuning(TMPC_TUNE_PERSISTENT, 0): the launch sequence)
+  {
+    CrLevs plv;
+    // Where it pays (scripts/persist_check.py, profiles/r5_persist_check.txt): the workgroup of a problem takes its stages sixteen at a time, so a
+    // single long problem is slower than on the launch sequence, which spreads them over the CUs (p = 30, batch 1: 6.9 against 4.6 ms); it wins when
+    // one round covers the period (p <= 16: 1.0 - 1.25 x) and from ~96 problems in flight on the chip, whatever the period (p = 20 ... 100: 0.8 - 0.9 x at 64,
+    // 1.0 at 96, 1.2 at 128, 1.7 - 1.9 x at 256 = one workgroup per CU; profiles/r5_persist_sweep.txt).  A wave is split over the lanes of the handle, each
+    // of which makes this decision for its share.  tune_persist: 0 never, 1 by this rule, 2 whenever the shape allows it.
+    const bool pays = h->tune_persist >= 2 || dm.p <= CRS_NW || active * h->nlanes >= 96;
+    const bool persist = h->tune_persist && pays && !eq && !t3 && !big && dm.dp == 16 && dm.n <= PK_NMAX && !h->tight && !prof &&
+                         !(h->flags & TMPC_DEBUG_FLAG_STOP_ASSEMBLED) && cr_small_levels(dm, h->sched, &plv);
+    if (persist && active > 0) {
+      const CrDev cd = cr_dev(h->sched, h->d_sched, alist);
+      hipLaunchKernelGGL(k_ipm_small, dim3(active), dim3(CRS_NT), (size_t)pk_lds_doubles(dm.p) * sizeof(double), st, w, dm, o, cd, plv, h->sched.prep, reg_max,
+                         h->tune_pretest ? o.chord_step : -1.0, cap);
+      HIPCHK(hipGetLastError());
+      active = 0; nfac = 0;
+    }
+  }
   // one interior-point loop; ddm: the tight phase (tmpc_dd.h) -- assembly, factorisation and substitutions in double-double, every problem of the list
   auto ipm_loop = [&](const Opts& o, bool ddm, int cap) -> int {
   while (active > 0 && it < cap) {
@@ -687,6 +767,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipGraphExec_t gexec = nullptr;
     std::string gkey;
     bool capturing = false;
+    // an error return out of the captured region (HIPCHK) must not leave the lane's stream in capture mode -- every later call on it would fail
+    struct CaptureGuard {
+      hipStream_t st; bool* on;
+      ~CaptureGuard() { if (*on) { hipGraph_t g_ = nullptr; (void)hipStreamEndCapture(st, &g_); if (g_) hipGraphDestroy(g_); (void)hipGetLastError(); } }
+    } capture_guard{st, &capturing};
     int nkev = 0;
     if (use_graph && !ddm) {
       gkey.assign((const char*)&w, sizeof(WS)); gkey.append((const char*)&dm, sizeof(Dims)); gkey.append((const char*)&o, sizeof(Opts));
@@ -782,7 +867,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
         hipLaunchKernelGGL(kb_eigmin, dim3(BP * 4), dim3(256), big_lds, st, w, dm, pass);
       } else {
         TMPC_STAGE_LAUNCH(k_stage_dir, slots_bytes(DIR_SLOTS), st, w, dm, pass);
-        hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, h->tune_pretest ? o.chord_step : -1.0);
+        if (dm.n <= 8) hipLaunchKernelGGL(k_eigmin_lane, dim3((BP * 4 + 63) / 64), dim3(64), 0, st, w, dm, pass, BP * 4);      // one thread per matrix (tmpc_stage.h)
+        else hipLaunchKernelGGL(k_eigmin, dim3(BP * 4), dim3(64), (size_t)(MS + 160) * sizeof(double), st, w, dm, pass, h->tune_pretest ? o.chord_step : -1.0);
       }
       if (eq) hipLaunchKernelGGL(k_phi_steps, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm, pass);
       if (t3) hipLaunchKernelGGL(k_t3_steps, dim3(BP), dim3(64), t3_lds, st, w, dm, pass);
@@ -802,6 +888,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }      // (!gexec)
     if (capturing) {
       hipGraph_t graph = nullptr;
+      capturing = false;
       const bool ok_ = hipStreamEndCapture(st, &graph) == hipSuccess && graph && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) hipGraphDestroy(graph);
       if (!ok_) {        // nothing of this iteration ran (it was only recorded): plain launches from here on, same iteration again
@@ -930,7 +1017,7 @@ int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, 
 static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes) {
   if (!out) return TMPC_E_ARG;
   *out = nullptr;
-  if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NMAX); return TMPC_E_UNSUPPORTED; }
+  if (!dims_ok(p, nx, mb)) { snprintf(g_err, sizeof(g_err), "unsupported dims p=%d nx=%d mb=%d (need nx+mb<=%d)", p, nx, mb, NB); return TMPC_E_UNSUPPORTED; }
   if (!rows_ok(nx, ng, nc)) {
     snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
@@ -970,7 +1057,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   h->dm = make_dims(cap, p, nx, mb, ng, nc, step3);
   h->sched = cr_build(p);
   h->rs = 0; h->mt = 0;
-  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1;
+  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1; h->tune_fused_elim = 0; h->tune_persist = 1;
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->opt.fast_exit = 0;
   h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); tmpc_set_tuning(TMPC_TUNE_CHORD_STEP, 0) disables
@@ -1012,6 +1099,7 @@ int tmpc_destroy(tmpc_handle* h) {
     if (ln.st) hipStreamDestroy(ln.st);
     if (ln.big_scr) hipFree(ln.big_scr);
     if (ln.graphs) { for (auto& kv : *ln.graphs) if (kv.second) hipGraphExecDestroy(kv.second); delete ln.graphs; }
+    if (ln.worker) { ln.worker->shutdown(); delete ln.worker; ln.worker = nullptr; }
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
@@ -1047,6 +1135,8 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
     case TMPC_TUNE_EIG_PRETEST: h->tune_pretest = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_FUSE_FWD: h->tune_fuse = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_GRAPH: h->tune_graph = value != 0.0; return TMPC_OK;
+    case TMPC_TUNE_FUSED_ELIM: h->tune_fused_elim = value != 0.0; return TMPC_OK;
+    case TMPC_TUNE_PERSISTENT: if (!(value >= 0.0 && value <= 2.0)) return TMPC_E_ARG; h->tune_persist = (int)value; return TMPC_OK;
     default: snprintf(g_err, sizeof(g_err), "tmpc_set_tuning: unknown key %d", key); return TMPC_E_ARG;
   }
 }
@@ -1259,14 +1349,17 @@ static int dispatch(tmpc_handle* h, const Call& c, hipStream_t user, bool has_us
     int lo[MAXL + 1];
     for (int l = 0; l <= nl; ++l) lo[l] = (int)((long)nw * l / nl);
     int rcs[MAXL]; for (int l = 0; l < MAXL; ++l) { rcs[l] = TMPC_OK; h->lane[l].last_nb = 0; }
-    std::vector<std::thread> th;
-    for (int l = 1; l < nl; ++l)
-      th.emplace_back([&, l]() {
+    for (int l = 1; l < nl; ++l) {
+      Lane& ln = h->lane[l];
+      if (ln.worker && ln.worker->pid != getpid()) { ln.worker->shutdown(); delete ln.worker; ln.worker = nullptr; }
+      if (!ln.worker) { ln.worker = new LaneWorker(); ln.worker->start(); }
+      ln.worker->submit([&, l]() {
         rcs[l] = lane_run(h, &h->lane[l], c, off + lo[l], lo[l + 1] - lo[l]);
         if (rcs[l] != TMPC_OK) snprintf(h->lane[l].err, sizeof(h->lane[l].err), "%s", g_err);
       });
+    }
     rcs[0] = lane_run(h, &h->lane[0], c, off + lo[0], lo[1] - lo[0]);
-    for (auto& t : th) t.join();
+    for (int l = 1; l < nl; ++l) h->lane[l].worker->wait();
     for (int l = 0; l < nl; ++l)
       if (rcs[l] != TMPC_OK) { if (l > 0) snprintf(g_err, sizeof(g_err), "%s", h->lane[l].err); return rcs[l]; }
   }
@@ -1420,9 +1513,8 @@ int tmpc_supplement_terms_batch_host(tmpc_handle* hh, int nbt, const double* A, 
     }
     if (T) HIPCHK(hipMemcpyAsync(h->dH, T + so * nn, BP * nn * sizeof(double), hipMemcpyHostToDevice, st));
     if (dm.n > NMAX) {      // generic form (tmpc_big.h): the supplement of P alone
-      if (T) { snprintf(g_err, sizeof(g_err), "tmpc_supplement_terms_batch_host: the T term is handled up to nx + mb = %d", NMAX); return TMPC_E_UNSUPPORTED; }
       hipLaunchKernelGGL(kb_supplement, dim3((unsigned)BP), dim3(256), 0, st, (const double*)h->dA, (const double*)h->dB, (const double*)h->ws.P, h->ws.dHc, d2, h->ws.bscr,
-                         nr, (const double*)(J ? dJ : nullptr), (const double*)(J ? dw : nullptr));
+                         nr, (const double*)(J ? dJ : nullptr), (const double*)(J ? dw : nullptr), (const double*)(T ? h->dH : nullptr));
     } else
     hipLaunchKernelGGL(k_supplement, dim3((unsigned)BP), dim3(64), slots_bytes(5), st, h->dA, h->dB, h->ws.P, h->ws.dHc, d2, nr, dJ, dw,
                        T ? h->dH : nullptr);
@@ -1607,6 +1699,18 @@ int tmpc_debug_min_eig(tmpc_handle* h, int nmat, int n, const double* W, double*
   return TMPC_OK;
 }
 
+int tmpc_debug_min_eig_lane(tmpc_handle* h, int nmat, int n, const double* W, double* out) {
+  if (!h || nmat < 1 || n < 1 || n > 8 || !W || !out) return TMPC_E_ARG;
+  ON_DEVICE(h);
+  DevBuf bW, bO;
+  HIPCHK(bW.alloc((size_t)nmat * n * n * 8)); HIPCHK(bO.alloc((size_t)nmat * 8));
+  HIPCHK(hipMemcpy(bW.p, W, (size_t)nmat * n * n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_min_eig_lane, dim3((nmat + 63) / 64), dim3(64), 0, 0, bW.as<double>(), bO.as<double>(), n, nmat);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, bO.p, (size_t)nmat * 8, hipMemcpyDeviceToHost));
+  return TMPC_OK;
+}
+
 // The elimination schedule of the block factorisation for period p (host only, no device): out = [nlev, prep, nelim, nupd,
 // levels (eoff, nelim, uoff, nupd) x nlev, elimination records x 8 ints, update records x 8 ints, orientation x p].
 // Returns the number of ints (call with cap = 0 to size the buffer), or TMPC_E_ARG.
@@ -1704,6 +1808,7 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
   CrBench cb;
   int rc = cb.init(nb, p, d, h->flags);
   if (rc != TMPC_OK) return rc;
+  if (h->tune_fused_elim) cb.dm.flags |= DF_FUSED_ELIM;
   const int dp = cb.dm.dp;
   const size_t bs = (size_t)dp * dp, per = (size_t)p * bs;
   // T = sum_k J_k' J_k + I  with J_k = [E_k G_k] on blocks (k, k+1): SPD by construction

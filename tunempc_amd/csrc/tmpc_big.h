@@ -499,8 +499,9 @@ __global__ void __launch_bounds__(256) kb_eig_scan(const double* H, double* out,
   big_eig_extremes(H + (size_t)blockIdx.x * n * n, n, lds, &lo, &hi, &amin, &amax);
   if (threadIdx.x == 0) { double* o = out + (size_t)blockIdx.x * 4; o[0] = lo; o[1] = hi; o[2] = amin; o[3] = amax; }
 }
-// dHc = sym(V' P+ V - E' P E) for arbitrary P (tmpc_supplement_batch_host; k_supplement without the J / T terms); scr: 3 n x n doubles per stage
-__global__ void __launch_bounds__(256) kb_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm, double* scr_all, int nr, const double* J, const double* wts) {
+// dHc = sym(V' P+ V - E' P E [+ J' diag(w) J] [+ T]) for arbitrary P (tmpc_supplement_batch_host; the generic twin of k_supplement); scr: 3 n x n doubles per stage
+__global__ void __launch_bounds__(256) kb_supplement(const double* A, const double* Bm, const double* P, double* dHc, Dims dm, double* scr_all, int nr, const double* J, const double* wts,
+                                                     const double* T) {
   const int sid = blockIdx.x, tid = threadIdx.x;
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int n = dm.n, nx = dm.nx, mb = dm.mb, nn = n * n, nxx = nx * nx;
@@ -510,6 +511,7 @@ __global__ void __launch_bounds__(256) kb_supplement(const double* A, const doub
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   gbuild_M(sM, t0, sV, sM, P + (size_t)sid * nxx, P + (size_t)(b * dm.p + kn) * nxx, 0.0, n, nx);
   if (J) gadd_gtg(sM, J + (size_t)sid * nr * n, wts + (size_t)sid * nr, 1.0, nr, n);      // + J' diag(w) J (padded rows carry weight 0)
+  if (T) { for (int e = tid; e < nn; e += 256) sM[e] += T[(size_t)sid * nn + e]; gsync(); }  // + T_k (convexifier.py:202-203; round 5: Step 3 runs at n > 32, so does its supplement)
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; dHc[(size_t)sid * nn + e] = 0.5 * (sM[i * n + j] + sM[j * n + i]); }
 }
 // W = sym(Hc) / ts, yref = wref - Hc^-1 q by Cholesky and two substitutions (tmpc_tracking_reference_host; k_tracking_ref); scr: n x n doubles per stage

@@ -165,18 +165,19 @@ __device__ __forceinline__ void atomic_min_pos(double* addr, double v) {      //
 }
 
 // p == 1 / p == 2 preparation (one workgroup per active problem)
-__global__ void __launch_bounds__(256) k_cr_prep(WS w, Dims dm, CrDev cr, int prep) {
-  const int b = cr.alist[blockIdx.x];
+template <int NTH>
+__device__ __forceinline__ void cr_prep_body(const WS& w, const Dims& dm, int b, int prep) {
   const int dp = dm.dp, tid = threadIdx.x;
   double* D = w.D + (size_t)b * dm.p * dp * dp;
   if (prep == 1) {            // P_{k+1} = P_k: the coupling block folds onto the diagonal  D += C + C'
     const double* E = cr_edge(w, dm, b, 0);
-    for (int e = tid; e < dp * dp; e += 256) { const int i = e / dp, j = e - i * dp; D[e] += E[e] + E[(size_t)j * dp + i]; }
+    for (int e = tid; e < dp * dp; e += NTH) { const int i = e / dp, j = e - i * dp; D[e] += E[e] + E[(size_t)j * dp + i]; }
   } else {                    // two edges between the same pair of nodes
     double* E0 = cr_edge(w, dm, b, 0); const double* E1 = cr_edge(w, dm, b, 1);
-    for (int e = tid; e < dp * dp; e += 256) E0[e] += E1[e];
+    for (int e = tid; e < dp * dp; e += NTH) E0[e] += E1[e];
   }
 }
+__global__ void __launch_bounds__(256) k_cr_prep(WS w, Dims dm, CrDev cr, int prep) { cr_prep_body<256>(w, dm, cr.alist[blockIdx.x], prep); }
 
 constexpr int UPD_DMA_DEPTH = 2;                       // LDS buffers of the LDS-DMA tile GEMM in the batched kernels
 // ---- phase 1: Cholesky of the diagonal blocks of this level's eliminated nodes (left-looking on the register-staged core: blocks wider
@@ -608,6 +609,50 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf_dma(WS w, Dims dm, CrDev cr
     const double minr = stat[1];
     if (nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
     if (w.prob && minr < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, minr);
+  }
+}
+
+// ---- phases 1 + 2 of a node in ONE workgroup (round 5 experiment, tmpc_set_tuning(TMPC_TUNE_FUSED_ELIM, 1); off by default): the block
+// Cholesky of the node and then the 2 x nt strips of its two triangular solves, one after the other.  The idea (review of round 4): the
+// latency-bound tile factorisations of one workgroup share a CU with the MFMA-bound sweeps of another.  What it costs: the strips of a node
+// no longer run side by side on one XCD, so the factor L_i (0.74 MB at d = 300) is re-read by ONE workgroup for each of its 10 strips over
+// ~0.6 ms while 63 other workgroups of the XCD do the same with their own factors: 47 MB of factors against 4 MB of L2
+// (measured: profiles/r5_fused_elim.txt).
+__global__ void __launch_bounds__(256, 2) k_cr_elim_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
+  const int it = cr_item(count * nelim);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / nelim];
+  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
+  const int node = er[CE_NODE], dp = dm.dp;
+  double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
+  double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
+  const double* dref = w.Ddiag + ((size_t)b * dm.p + node) * dp;
+  double* stat = lds + FACT_LDS_DOUBLES - 8;
+  if (threadIdx.x == 0) { stat[0] = 0.0; stat[1] = 1.0; }
+  for (int r = 0; r < dm.nt; ++r) {
+    const int r0 = 64 * r, nb = (dp - r0 < 64) ? dp - r0 : 64;
+    if (r > 0) {
+      trd_strip<true>(Dk + (size_t)r0 * dp, Dk, Li, nb, r + 1, dp, it, lds);
+      __syncthreads();
+    }
+    wg_potrf_inv(Dk + (size_t)r0 * dp + r0, dp, Li + (size_t)r * TB * TB, dref + r0, nb, lds, nullptr, stat, (it >> 5) & 3, r > 0);
+  }
+  if (threadIdx.x == 0) {
+    const int nbad = (int)stat[0];
+    const double minr = stat[1];
+    if (nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
+    if (w.prob && minr < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, minr);
+  }
+  __syncthreads();                                          // the factor is in memory (same workgroup: visible after the barrier), the LDS free
+  for (int which = 0; which < 2; ++which) {
+    const int slot = which ? er[CE_EB] : er[CE_EA];
+    if (slot < 0) continue;
+    for (int strip = 0; strip < dm.nt; ++strip) {
+      const int r0 = strip * 64;
+      trd_strip<false>(cr_edge(w, dm, b, slot) + (size_t)r0 * dp, Dk, Li, (dp - r0 < 64) ? dp - r0 : 64, dm.nt, dp, it + strip, lds);
+      __syncthreads();
+    }
   }
 }
 

@@ -24,9 +24,8 @@ constexpr int CRS_NW = 16;               // waves per workgroup: a level of p = 
 constexpr int CRS_NT = 64 * CRS_NW;
 constexpr int CRS_LD = 17;               // leading dimension of the 16 x 16 images in LDS
 constexpr int crs_factor_lds_doubles() { return CRS_NW * (2 * 16 * CRS_LD + 8); }      // per wave: S, Si, two statistics
-__global__ void __launch_bounds__(CRS_NT) k_cr_small_factor(WS w, Dims dm, CrDev cr, CrLevs lv) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int b = cr.alist[blockIdx.x];
+// (body: the CRS_NT threads of one workgroup factor problem b -- the kernel below and the persistent kernel of tmpc_persist.h)
+__device__ __forceinline__ void cr_small_factor_body(const WS& w, const Dims& dm, const CrDev& cr, const CrLevs& lv, int b, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int dp = 16;
   const size_t bs = (size_t)dp * dp;
@@ -93,14 +92,16 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_factor(WS w, Dims dm, CrDev
     if (w.prob && stat[1] < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, stat[1]);
   }
 }
+__global__ void __launch_bounds__(CRS_NT) k_cr_small_factor(WS w, Dims dm, CrDev cr, CrLevs lv) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  cr_small_factor_body(w, dm, cr, lv, cr.alist[blockIdx.x], lds);
+}
 
 // Forward and backward substitution with that factor, right-hand sides of `pass` (cr_nc / cr_rhs of tmpc_cr.h), all levels in one kernel.
 // The vectors of the whole problem sit in LDS ([p][16][nc], as in memory); every (node, row, right-hand side) entry of a level is one
 // thread's 16-long dot product against a block read from L2.
 constexpr int crs_solve_lds_doubles(int p) { return 2 * p * 16 * 3 + 16; }
-__global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev cr, CrLevs lv, int pass) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int b = cr.alist[blockIdx.x];
+__device__ __forceinline__ void cr_small_solve_body(const WS& w, const Dims& dm, const CrDev& cr, const CrLevs& lv, int b, double* lds, int pass) {
   const int nc = cr_nc(w, b, pass);
   if (nc == 0) return;
   const int tid = threadIdx.x;
@@ -194,6 +195,10 @@ __global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev 
     __syncthreads();
   }
   for (int e = tid; e < nz; e += CRS_NT) R[e] = z[e];
+}
+__global__ void __launch_bounds__(CRS_NT) k_cr_small_solve(WS w, Dims dm, CrDev cr, CrLevs lv, int pass) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  cr_small_solve_body(w, dm, cr, lv, cr.alist[blockIdx.x], lds, pass);
 }
 
 }  // namespace tmpc

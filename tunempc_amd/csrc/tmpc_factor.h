@@ -630,25 +630,28 @@ __device__ __forceinline__ void vec_s2g(double* R, const double* z, int xld, int
   for (int e = threadIdx.x; e < dp * nc; e += 256) { const int i = e / nc, q = e - i * nc; R[e] = z[q * xld + i]; }
 }
 
-__device__ __forceinline__ double wg_reduce_sum(double v, double* red) {
+template <int NTH = 256>
+__device__ __forceinline__ double wg_reduce_sum(double v, double* red) {      // red: NTH / 64 doubles of LDS
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
   if (lane == 0) red[wv] = v;
   __syncthreads();
-  const double r = red[0] + red[1] + red[2] + red[3];
+  double r = red[0];
+#pragma unroll
+  for (int q = 1; q < NTH / 64; ++q) r += red[q];
   __syncthreads();
   return r;
 }
 
 // After the block solves (tmpc_cr.h) of pass 1 ([rhs | u_tau | u_alpha]) or pass 2 (rhs; all three while centering): the 2 x 2
 // border system of (tau, alpha) and dP.  One workgroup per active problem.
-__global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* alist, int pass) {
-  const int b = alist[blockIdx.x];
+// (body: the NTH threads of one workgroup; red: NTH / 64 doubles of LDS.  The sums are taken in a different order for NTH != 256.)
+template <int NTH>
+__device__ __forceinline__ void solve_border_body(const WS& w, const Dims& dm, int b, int pass, double* red) {
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE) return;
-  __shared__ double red[8];
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p, dp = dm.dp, tid = threadIdx.x, nx = dm.nx;
   const size_t vl = (size_t)p * dp;
@@ -660,23 +663,23 @@ __global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* 
   const bool three = (pass == 1) || (phase != PH_MAIN && !ip[I_CHORD]);    // chord step: TU and the 2 x 2 border Schur complement of the last factorisation stay
   if (three) {
     double s00 = 0.0, s01 = 0.0, s11 = 0.0;
-    for (size_t e = tid; e < vl; e += 256) {
+    for (size_t e = tid; e < vl; e += NTH) {
       const double t0 = W3[e * 3 + 1], t1 = W3[e * 3 + 2];
       TU[e * 2] = t0; TU[e * 2 + 1] = t1;
       Z[e] = W3[e * 3];
       s00 = fma(U[e * 2], t0, s00); s01 = fma(U[e * 2], t1, s01); s11 = fma(U[e * 2 + 1], t1, s11);
     }
-    s00 = wg_reduce_sum(s00, red); s01 = wg_reduce_sum(s01, red); s11 = wg_reduce_sum(s11, red);
+    s00 = wg_reduce_sum<NTH>(s00, red); s01 = wg_reduce_sum<NTH>(s01, red); s11 = wg_reduce_sum<NTH>(s11, red);
     if (tid == 0) { pr[P_SB00] = pr[P_BTT] - s00; pr[P_SB01] = pr[P_BTA] - s01; pr[P_SB11] = pr[P_BAA] - s11; }
   }
   __syncthreads();
   // border:  rb = [rhs_tau, rhs_alpha] - U' z ;  db = Sb^-1 rb ;  dp = z - TU db
   double u0 = 0.0, u1 = 0.0;
-  for (size_t e = tid; e < vl; e += 256) { const double z = Z[e]; u0 = fma(U[e * 2], z, u0); u1 = fma(U[e * 2 + 1], z, u1); }
-  u0 = wg_reduce_sum(u0, red); u1 = wg_reduce_sum(u1, red);
+  for (size_t e = tid; e < vl; e += NTH) { const double z = Z[e]; u0 = fma(U[e * 2], z, u0); u1 = fma(U[e * 2 + 1], z, u1); }
+  u0 = wg_reduce_sum<NTH>(u0, red); u1 = wg_reduce_sum<NTH>(u1, red);
   double trt2 = 0.0, hbg = 0.0;
-  for (int k = tid; k < p; k += 256) { const double* q = w.part + (size_t)(b * p + k) * NPART; trt2 += q[Q_TRT2]; hbg += q[Q_HBG]; }
-  trt2 = wg_reduce_sum(trt2, red); hbg = wg_reduce_sum(hbg, red);
+  for (int k = tid; k < p; k += NTH) { const double* q = w.part + (size_t)(b * p + k) * NPART; trt2 += q[Q_TRT2]; hbg += q[Q_HBG]; }
+  trt2 = wg_reduce_sum<NTH>(trt2, red); hbg = wg_reduce_sum<NTH>(hbg, red);
   const double sig = (pass == 1) ? 0.0 : pr[P_SIGMU];
   const double corr0 = (pass == 1) ? 0.0 : pr[P_CORR0];
   const double s0 = pr[P_S0], x0 = pr[P_X0], rd0 = pr[P_RD0];
@@ -690,7 +693,7 @@ __global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* 
   // dP_k = smat(z - TU db)
   double* dPg = w.dP + (size_t)b * p * nx * nx;
   const int d = dm.d;
-  for (int e = tid; e < p * d; e += 256) {
+  for (int e = tid; e < p * d; e += NTH) {
     const int k = e / d, idx = e - k * d;
     // idx -> (a,c), a <= c  (row-major upper triangle)
     int a2 = 0, rem = idx;
@@ -701,6 +704,11 @@ __global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* 
     dPg[(size_t)k * nx * nx + a2 * nx + c2] = v;
     dPg[(size_t)k * nx * nx + c2 * nx + a2] = v;
   }
+}
+
+__global__ void __launch_bounds__(256) k_solve_border(WS w, Dims dm, const int* alist, int pass) {
+  __shared__ double red[8];
+  solve_border_body<256>(w, dm, alist[blockIdx.x], pass, red);
 }
 
 }  // namespace tmpc

@@ -37,19 +37,17 @@ __device__ __forceinline__ double hkm_t(double xac, double xad, double xbc, doub
 }
 // GF: the interleaved factor records live in a per-stage global scratch (w.sscr) instead of LDS -- nx > 43 at n > 32, where 10 nx^2 doubles exceed the LDS; same code,
 // separate instantiation (the LDS form is untouched)
-template <int PART, bool GF = false>
-__global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
+// (body: NTS threads assemble the block(s) of stage sid; NTS = SCH_NT: the kernel below, NTS = 64: one wave of the persistent kernel of tmpc_persist.h)
+template <int PART, bool GF, int NTS>
+__device__ __forceinline__ void schur_body(const WS& w, const Dims& dm, int sid, int tid, double* sm) {
   constexpr int REC = sch_rec<PART>();
-  const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
-  const int tid = threadIdx.x;
   const int nx = dm.nx, nxx = nx * nx, d = dm.d, dp = dm.dp;
   // relative lift of the diagonal after an iteration whose factorisation froze pivots (k_ctrl_c): 1e-12
   const int reg = ip[I_REG];
   const double regf = (reg <= 0) ? 1.0 : 1.0 + 1e-13 * ((reg == 1) ? 10.0 : (reg == 2) ? 100.0 : 1000.0);
-  extern __shared__ __attribute__((aligned(16))) double sm[];
   double* mats = GF ? w.sscr + (size_t)sid * 10 * nxx : sm;                  // [nx][nx][REC]
   unsigned* pair = (unsigned*)(GF ? sm : sm + (size_t)nxx * REC);            // [d]: a | b << 16 of the packed index (ab), a <= b
   // orientation of the stored coupling block (edge slot k of tmpc_cr.h): its columns belong to the stage that the cyclic
@@ -60,7 +58,7 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* kfk = w.KF + (size_t)sid * 12 * nxx;
   const double* kfm = w.KF + (size_t)(b * dm.p + km) * 12 * nxx;
-  for (int e = tid; e < 12 * nxx; e += SCH_NT) {
+  for (int e = tid; e < 12 * nxx; e += NTS) {
     const int m = e / nxx, r = e - m * nxx;
     const int lmi = m / KF_PER_LMI, slot = m - lmi * KF_PER_LMI;
     const bool fmat = (slot == KF_FX || slot == KF_FS);
@@ -75,13 +73,14 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
     int e = tid * nx - (tid * (tid - 1)) / 2;
     for (int c = tid; c < nx; ++c) pair[e++] = (unsigned)tid | ((unsigned)c << 16);
   }
-  __syncthreads();
+  if (NTS == 64) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // one wave: its own LDS writes, in order
+  else __syncthreads();
   double* Dg = w.D + (size_t)sid * dp * dp;
   double* Cg = w.O + (size_t)sid * dp * dp;
   double* dd = w.Ddiag + (size_t)sid * dp;
   // D_k: only the lower triangle is ever read (the row strips of the block Cholesky stop at the diagonal tile, whose lower half is
   // used), so only col <= row is computed and written.  Rows and columns beyond d: identity / zero padding.
-  for (int col = tid; col < dp; col += SCH_NT) {
+  for (int col = tid; col < dp; col += NTS) {
     const bool cin = col < d;
     const unsigned pc_ = cin ? pair[col] : 0u;
     const int c = (int)(pc_ & 0xffffu), d_ = (int)(pc_ >> 16);
@@ -130,10 +129,15 @@ __global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
   }
 }
 
+template <int PART, bool GF = false>
+__global__ void __launch_bounds__(SCH_NT) k_schur(WS w, Dims dm) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  schur_body<PART, GF, SCH_NT>(w, dm, stage_id(w, dm), threadIdx.x, sm);
+}
+
 // Gather the adjoint pieces into svec right-hand sides:  v_j[(ab)] = w_ab * (adjV[j-1] - adjE[j])[a][b]
 // which: 0 -> Z (pass-2 rhs), 1 -> W3 (pass-1: rhs | u_tau | u_alpha) and U
-__global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
-  const int sid = stage_id(w, dm);
+__device__ __forceinline__ void gather_body(const WS& w, const Dims& dm, int sid, int lane, int pass) {
   const int b = sid / dm.p, k = sid - b * dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
   // centering phase: no predictor, so pass 1 is skipped and pass 2 solves [rhs | u_tau | u_alpha] in one sweep
   if (pass == 1 && phase != PH_MAIN) return;
   const bool three = (pass == 1) || (phase != PH_MAIN && !ip[I_CHORD]);     // chord step: the border columns of the last factorisation stay
-  const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
+  const int nx = dm.nx, nxx = nx * nx, dp = dm.dp;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const double* av = w.adjV + (size_t)(b * dm.p + km) * NADJ * nxx;
   const double* ae = w.adjE + (size_t)sid * NADJ * nxx;
@@ -176,7 +180,10 @@ __global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) {
   }
 }
 
+__global__ void __launch_bounds__(64) k_gather(WS w, Dims dm, int pass) { gather_body(w, dm, stage_id(w, dm), threadIdx.x, pass); }
+
 // ------------------------------------------------------------------ per-problem control (64 lanes per problem)
+// (bodies: one wave works on problem b -- called by the kernels k_ctrl_a .. k_ctrl_d below and by the persistent kernel of tmpc_persist.h)
 __device__ __forceinline__ double psum(const double* part, int b, int p, int idx, int lane) {
   double acc = 0.0;
   for (int k = lane; k < p; k += 64) acc += part[(size_t)(b * p + k) * NPART + idx];
@@ -193,8 +200,7 @@ __device__ __forceinline__ double emin(const double* eigmin, int b, int p, int w
 }
 
 // after k_stage_pre: mu, residual norms, phase logic (the same control flow as the CPU restatement used by the tests)
-__global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
-  const int b = prob_id(w), lane = threadIdx.x;
+__device__ __forceinline__ void ctrl_a_body(const WS& w, const Dims& dm, const Opts& o, int b, int lane) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE) return;
   double* pr = w.prob + (size_t)b * PS;
@@ -279,6 +285,8 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
   else { pr[P_SIGMU] = 0.0; pr[P_CORR0] = 0.0; }
 }
 
+__global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) { ctrl_a_body(w, dm, o, prob_id(w), threadIdx.x); }
+
 // After the factorisation of a centering iteration, before its right-hand side: hard target.  Frozen pivots while centering mean the Schur matrix
 // is numerically singular AT THIS ITERATE (cond ~ (tau/mu)^2 passes 1/eps before the default mu_t when cond(H) >~ 1e3).  Aim for the
 // central-path point one power of two earlier and TAKE the step this factorisation gives towards it (a frozen pivot leaves its component
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(64) k_ctrl_a(WS w, Dims dm, Opts o) {
 // matrix, and the cond(H) = 1e5 members of scripts/robustness_sweep.py ended Feasible at 1024 mu_t instead of Optimal at 2-32 mu_t.)
 // (Runs at the top of k_ctrl_b -- after the factorisation and the predictor pass that centering problems skip, before the right-hand side of
 // pass 2 -- so it costs no launch of its own.)
-__device__ __forceinline__ void ctrl_backoff_before_rhs(WS& w, int b, int reg_max) {
+__device__ __forceinline__ void ctrl_backoff_before_rhs(const WS& w, int b, int reg_max) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_CENTER || ip[I_CHORD]) return;
   if (ip[I_NSHIFT] == ip[I_SHIFT0] || ip[I_REG] < reg_max || ip[I_BACKOFF] >= MUT_BACKOFF_MAX) return;   // (frozen pivots first lift the diagonal, 1e-12 ... 1e-10, and repeat: k_ctrl_c)
@@ -309,8 +317,7 @@ __device__ __forceinline__ void raw_steps(const double* pr, double minx, double 
 }
 
 // after the predictor direction (pass 1): Mehrotra centring parameter
-__global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm, int reg_max) {
-  const int b = prob_id(w), lane = threadIdx.x;
+__device__ __forceinline__ void ctrl_b_body(const WS& w, const Dims& dm, int reg_max, int b, int lane) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] != PH_MAIN) {
     if (lane == 0) ctrl_backoff_before_rhs(w, b, reg_max);        // centering: hard-target back-off, see above
@@ -340,9 +347,10 @@ __global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm, int reg_max) {
   pr[P_CORR0] = dx0 * ds0 / s0;
 }
 
+__global__ void __launch_bounds__(64) k_ctrl_b(WS w, Dims dm, int reg_max) { ctrl_b_body(w, dm, reg_max, prob_id(w), threadIdx.x); }
+
 // after the final direction (pass 2): step lengths, scalar updates
-__global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm, int reg_max) {      // reg_max: REG_MAX, or 0 under TMPC_DEBUG_FLAG_NO_LIFT (unit test of the back-off-and-step route)
-  const int b = prob_id(w), lane = threadIdx.x;
+__device__ __forceinline__ void ctrl_c_body(const WS& w, const Dims& dm, int reg_max, int b, int lane) {      // reg_max: REG_MAX, or 0 under TMPC_DEBUG_FLAG_NO_LIFT (unit test of the back-off-and-step route)
   int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
   if (phase == PH_DONE) return;
@@ -432,10 +440,11 @@ __global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm, int reg_max) {    
   }
 }
 
-// after k_update: termination of the centering phase; recount active problems
-__global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= dm.B) return;
+__global__ void __launch_bounds__(64) k_ctrl_c(WS w, Dims dm, int reg_max) { ctrl_c_body(w, dm, reg_max, prob_id(w), threadIdx.x); }
+
+// after k_update: termination of the centering phase (one THREAD per problem); lists: re-enter the problem into the active / to-factor lists of the next
+// iteration (the launch-sequence path; the persistent kernel keeps no lists)
+__device__ __forceinline__ void ctrl_d_body(const WS& w, const Dims& dm, const Opts& o, int b, bool lists) {
   int* ip = w.iprob + (size_t)b * IS;
   if (ip[I_PHASE] == PH_DONE || ip[I_PHASE] == PH_POLISH) return;
   double* pr = w.prob + (size_t)b * PS;
@@ -487,10 +496,15 @@ __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
     if (ip[I_CHORD]) ip[I_NCHORD] += 1;
     pr[P_PREVSTEPN] = (full && !full_reset) ? stepn : -1.0;
   }
-  if (ip[I_PHASE] != PH_DONE) {
+  if (lists && ip[I_PHASE] != PH_DONE) {
     const int slot = atomicAdd(w.active, 1); w.alist[slot] = b;
     if (!ip[I_CHORD]) { const int fs = atomicAdd(w.active + 1, 1); w.flist[fs] = b; }
   }
+}
+__global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= dm.B) return;
+  ctrl_d_body(w, dm, o, b, true);
 }
 
 }  // namespace tmpc

@@ -12,18 +12,20 @@ def shard_range(nb, rank, world):
     return (nb * rank) // world, (nb * (rank + 1)) // world
 
 
-def all_gather_results(local, nb_total, group=None, cache=None):
+def all_gather_results(local, nb_total, group=None, cache=None, sizes=None):
     """All-gather per-rank result tensors (dict of torch tensors whose dim 0 is the local batch) into
     full-batch tensors on every rank.  Shards may be ragged by one problem: they are padded to the
     maximum shard size for the collective and trimmed afterwards.
     `cache` (a dict the caller keeps between calls): the gather and padding buffers are allocated once per key and re-used -- a
     serving loop gathers into the same world x shard buffer every step instead of allocating 2 GB per step at the bench shape
     (8 ranks x 268 MB of Hc).  With equal shards the returned tensors ARE those buffers: valid until the next call with the
-    same cache."""
+    same cache.  sizes: the shard length of every rank when the split is not the contiguous one of shard_range (balanced assignment)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    sizes = [shard_range(nb_total, r, world)[1] - shard_range(nb_total, r, world)[0] for r in range(world)]
+    if sizes is None:
+        sizes = [shard_range(nb_total, r, world)[1] - shard_range(nb_total, r, world)[0] for r in range(world)]
+    assert len(sizes) == world and sum(sizes) == nb_total
     mx = max(sizes)
     even = min(sizes) == mx
     out = {}
@@ -70,37 +72,56 @@ def balanced_assignment(cost, world):
     return [np.sort(np.asarray(r, dtype=np.int64)) for r in ranks]
 
 
-def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status'), extra=None, cost=None):
+def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 'status'), extra=None, cost=None, cache=None):
     """A, B, H: full-batch torch tensors (every rank holds or can generate the full batch; only its slice is
     read).  solve_fn(A_loc, B_loc, H_loc, **extra_loc) -> dict of torch tensors (local batch leading).  `extra`: dict of
     further per-problem inputs sliced the same way -- the equality-/active-constraint Jacobians and row counts of
     Step 1 with G and of Step 2 (G [nb,p,ng,n], C [nb,p,nc,n], ncnt [nb,p]).  Returns the gathered dict (full batch on
     every rank); add 'Fg' / 'F' to `keys` to gather the multipliers as well.
     cost [nb] (optional): a per-problem cost proxy -- the shards are then dealt by `balanced_assignment` instead of cut contiguously, and the gathered
-    tensors are put back into the caller's order."""
+    tensors are put back into the caller's order.  The assignment every rank uses is the one RANK 0 computes from its `cost` (one small broadcast), so
+    ranks whose proxies differ in the last bit -- or at all -- cannot duplicate or drop a problem; `cost` must have one finite entry per problem.
+    cache: as in all_gather_results (padding / gather / result buffers kept between calls)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nb = A.shape[0]
     if cost is not None:
+        cost = np.asarray(cost.detach().cpu() if hasattr(cost, 'detach') else cost, dtype=np.float64).reshape(-1)
+        if cost.shape != (nb,):
+            raise ValueError('cost must hold one entry per problem: expected shape ({},), got {}'.format(nb, cost.shape))
+        if not np.isfinite(cost).all():
+            raise ValueError('cost must be finite (a NaN would make the split differ between ranks)')
+        # one assignment for everybody: rank 0's permutation, broadcast as int64 (nb * 8 bytes)
         parts = balanced_assignment(cost, world)
-        mine = torch.as_tensor(parts[rank], device=A.device)
-        sel = lambda t: t.index_select(0, mine.to(t.device))
+        flat = torch.as_tensor(np.concatenate(parts), dtype=torch.int64, device=A.device)
+        if world > 1:
+            dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        sizes = [len(q) for q in parts]                     # (nb // world or + 1 per rank, in rank order: the same on every rank whatever the cost)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        idx = [flat[offs[r]:offs[r + 1]] for r in range(world)]
+        seen = torch.zeros(nb, dtype=torch.int32, device=A.device)
+        seen[flat] += 1
+        if not bool((seen == 1).all()):
+            raise RuntimeError('balanced assignment is not a permutation of the batch')
+        sel = lambda t: t.index_select(0, idx[rank].to(t.device))
         loc = solve_fn(sel(A), sel(B), sel(H), **{k: sel(v) for k, v in (extra or {}).items()})
-        sizes = [len(q) for q in parts]
-        mx = max(sizes)
+        gathered = all_gather_results({k: loc[k] for k in keys}, nb, group, cache, sizes=sizes)      # shards are joined in rank order: the order of `flat`
         out = {}
         for key in keys:
-            t = loc[key]
-            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            pad[:t.shape[0]] = t
-            full = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(full, pad.contiguous(), group=group)
-            res = torch.empty((nb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            for r in range(world):
-                res[torch.as_tensor(parts[r], device=t.device)] = full[r * mx: r * mx + sizes[r]]
+            t = gathered[key]
+            if cache is None:
+                res = torch.empty_like(t)
+            else:
+                ck = ('res', key, tuple(t.shape), t.dtype, str(t.device))
+                res = cache.get(ck)
+                if res is None:
+                    for old_ in [c for c in cache if c[0] == 'res' and c[1] == key]:
+                        del cache[old_]
+                    res = cache[ck] = torch.empty_like(t)
+            res[flat.to(t.device)] = t                       # every row is written: flat is a permutation (checked above)
             out[key] = res
         return out
     lo, hi = shard_range(nb, rank, world)
     loc = solve_fn(A[lo:hi], B[lo:hi], H[lo:hi], **{k: v[lo:hi] for k, v in (extra or {}).items()})
-    return all_gather_results({k: loc[k] for k in keys}, nb, group)
+    return all_gather_results({k: loc[k] for k in keys}, nb, group, cache)
