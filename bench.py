@@ -213,6 +213,22 @@ def large_block_configs(HipConvexifier, synthetic):
         tg = float(np.median(ts))
         out[key] = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
                     "ipm_iterations_mean": float(o['iters'].mean()), "schur_block": nx * (nx + 1) // 2 + (ng + nc + 2 if (ng or nc) else 0)}
+        if not (ng or nc):
+            # the CPU port beside it (plain model only: oracle/cpu_ipm has no multiplier rows), on a bounded sample of the same shape: one problem per thread,
+            # period 4 instead of 16 (the cost of a solve is linear in the period: ~12 s per problem at blocks of 820)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+                import cpu_ipm
+                hw = host_cpu_info()
+                cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
+                ps = 4
+                As, Bs, Hs = synthetic.gen_batch(seed + 50, cores, ps, nx, mb)
+                t0 = time.perf_counter(); oc = cpu_ipm.convexify_batch(As, Bs, Hs, threads=cores); tc = time.perf_counter() - t0
+                out[key].update(cpu_stage_conv_per_s=cores * ps / tc, cpu_threads=cores, gpu_over_cpu=(nb * p / tg) / (cores * ps / tc),
+                                cpu_sample=f"oracle/cpu_ipm, {cores} problems of the same stage shape with period {ps} on {cores} threads in {tc:.1f} s, "
+                                           f"{int((oc['status'] == 0).sum())}/{cores} Optimal")
+            except Exception as e:      # noqa: BLE001
+                out[key]["cpu_error"] = f"{type(e).__name__}: {e}"
     out["note"] = "32 < n <= 64: csrc/tmpc_big.h (one thread per matrix entry, matrices in global memory) + the register-staged factorisation kernels; not the tuned path of the headline"
     return out
 
@@ -241,13 +257,16 @@ def main():
     ap.add_argument('--no-tight', action='store_true', help='skip the tight-accuracy leg (one extra step, ~10x a default step)')
     ap.add_argument('--no-extra', action='store_true', help='skip the unprofiled and host-buffer legs after the timed region')
     ap.add_argument('--distinct', type=int, default=512, help='distinct synthetic problems generated per rank (tiled to --batch when smaller)')
+    ap.add_argument('--balance', action='store_true', help='N > 1: deal the global batch to the ranks by a cost proxy (sbeta = max|eig H| / min|eig H| per problem, one '
+                    'batched eigen-scan) instead of giving every rank the problems it generated: tunempc_amd.dist.convexify_batch_sharded(cost=...)')
+    ap.add_argument('--stragglers', type=int, default=0, help='make the first K problems of rank 0 hard targets (cond Hhat = 10^4.5: ~3x the iterations): what --balance is for')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from tunempc_amd._lib import HipConvexifier, FLAG_PROFILE
     from tunempc_amd import synthetic
-    from tunempc_amd.dist import all_gather_results
+    from tunempc_amd.dist import all_gather_results, convexify_batch_sharded
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -272,18 +291,44 @@ def main():
     nbl = args.batch
     # synthetic data: `distinct` different seeded problems per rank, tiled to the per-GPU batch
     nd = min(args.distinct, nbl)
-    A, B, H = synthetic.gen_batch(100000 + rank * 10000, nd, p, nx, mb)
     reps = (nbl + nd - 1) // nd
     tile = lambda x: torch.from_numpy(np.tile(x, (reps, 1, 1, 1))[:nbl].copy()).to(dev)
-    dA, dB, dH = tile(A), tile(B), tile(H)
+
+    def rank_problems(r):
+        A_, B_, H_ = synthetic.gen_batch(100000 + r * 10000, nd, p, nx, mb)
+        if r == 0:
+            for b in range(min(args.stragglers, nd)):       # hard targets at the head of rank 0's share (a contiguous split leaves them all on one rank)
+                A_[b], B_[b], H_[b] = synthetic.gen_problem(990000 + b, p, nx, mb, cond_exp=4.5)[:3]
+        return A_, B_, H_
+
+    balance = bool(args.balance and use_dist and world > 1)
+    if balance:                                   # every rank holds the global batch (it could not deal it otherwise); it solves the share the assignment gives it
+        parts = [rank_problems(r) for r in range(world)]
+        gA, gB, gH = (torch.cat([tile(q[i]) for q in parts]) for i in range(3))
+        dA, dB, dH = gA[rank * nbl:(rank + 1) * nbl], gB[rank * nbl:(rank + 1) * nbl], gH[rank * nbl:(rank + 1) * nbl]
+    else:
+        A, B, H = rank_problems(rank)
+        dA, dB, dH = tile(A), tile(B), tile(H)
     h = HipConvexifier(p, nx, mb, chunk=(nbl if (args.same_device and nbl < 512) else 0), flags=FLAG_PROFILE)
     if args.tol > 0:
         h.set_options(tol=args.tol, flags=FLAG_PROFILE)
     out = None
     gather_cache = {}                      # the all-gather lands in the same buffers every step (tunempc_amd/dist.py)
+    cost = None
+    if balance:                            # cost proxy of every problem of the global batch: sbeta from one eigen-scan of the stage Hessians (tmpc_eig_scan_host)
+        ev = h.eig_scan(gH.cpu().numpy())                   # [nb, p, 4]: min eig, max eig, min |eig|, max |eig| per stage
+        cost = ev[:, :, 3].max(1) / ev[:, :, 2].min(1)
 
     def step():
         nonlocal out
+        if balance:
+            def solve_fn(a, b, hh):
+                nonlocal out
+                out = h.convexify_batch_device(a.contiguous(), b.contiguous(), hh.contiguous(), None)
+                return {k: (out[k].cpu() if host_coll else out[k]) for k in ('Hc', 'kappa', 'status')}
+            src = (gA.cpu(), gB.cpu(), gH.cpu()) if host_coll else (gA, gB, gH)
+            g = convexify_batch_sharded(*src, lambda a, b, hh: solve_fn(a.to(dev), b.to(dev), hh.to(dev)), cost=cost, cache=gather_cache)
+            return g
         out = h.convexify_batch_device(dA, dB, dH, out)
         if use_dist:
             g = all_gather_results({k: (out[k].cpu() if host_coll else out[k]) for k in ('Hc', 'kappa', 'status')}, nbl * world, cache=gather_cache)
@@ -305,14 +350,16 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
+    el_rank = [el]
     if use_dist:
+        # every rank's own clock between the two barriers is the same wall interval; what differs is the time it spent SOLVING: the profile's wall time of the handle
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
     prof = h.profile()
     status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy()
     ok = int((status == 0).sum())
     # load balance across ranks: the slowest member of every rank's shard sets that rank's step time
-    it_rank = torch.tensor([float(iters.max()), float(iters.mean())], dtype=torch.float64, device=cdev)
+    it_rank = torch.tensor([float(iters.max()), float(iters.mean()), float(prof['total_ms']) / max(args.steps, 1), float(status.size)], dtype=torch.float64, device=cdev)
     if use_dist:
         it_all = [torch.empty_like(it_rank) for _ in range(world)]
         dist.all_gather(it_all, it_rank)
@@ -374,15 +421,42 @@ def main():
         # mu_t = 2^-37 kappa with double-double block linear algebra + dd dual-Newton polish (VALU kernels, no matrix cores)
         if not args.no_tight:
             try:
-                h.set_options(tol=args.tol if args.tol > 0 else None, flags=0)
+                h.set_options(tol=args.tol if args.tol > 0 else None, flags=FLAG_PROFILE)
                 h.set_tight(True)
+                h.profile()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 step()
                 torch.cuda.synchronize()
                 e3 = time.perf_counter() - t0
+                pt = h.profile()
                 st3 = out['status'].cpu().numpy(); it3 = out['iters'].cpu().numpy(); k3 = out['kappa'].cpu().numpy(); in3 = out['info'].cpu().numpy()
+                # the double-double factorisations of the step = everything the profile counts beyond the default solve's share (the main run above, per step)
+                dflt_fac_ms = prof['factor_ms'] / max(args.steps, 1); dflt_nfac = prof['problem_factorisations'] / max(args.steps, 1)
+                dd_ms = max(pt['factor_ms'] - dflt_fac_ms, 1e-9); dd_nfac = max(pt['problem_factorisations'] - dflt_nfac, 0.0)
+                dd_tf = dd_nfac * factor_flops_per_problem(p, nx * (nx + 1) // 2) / (dd_ms * 1e-3) / 1e12
+                tight_cpu = None
+                if not args.no_cpu_baseline:
+                    try:                       # the CPU port in ITS tight mode, bounded sample: one problem per thread at period 8 instead of 64 (cost linear in the period)
+                        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+                        import cpu_ipm
+                        hw = host_cpu_info()
+                        cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
+                        ps = 8
+                        As, Bs, Hs = synthetic.gen_batch(100000, cores, ps, nx, mb)
+                        tc0 = time.perf_counter(); oc = cpu_ipm.convexify_batch(As, Bs, Hs, tol=2.0 ** -37, threads=cores, tight=True); tc = time.perf_counter() - tc0
+                        tight_cpu = {"value": cores * ps / tc, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+                                     "sample": f"oracle/cpu_ipm tight mode (double-double block algebra + polish), {cores} problems of the bench stage shape with period {ps} "
+                                               f"on {cores} threads in {tc:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
+                    except Exception as e:      # noqa: BLE001
+                        tight_cpu = {"error": f"{type(e).__name__}: {e}"}
                 extra_rates["tight_mode"] = {"value": nbl * p / e3, "ms_per_step": 1e3 * e3, "steps": 1, "tight_tol": 2.0 ** -37,
+                                             "fell_back_to_default": int((in3[:, 10] == 4.0).sum()),
+                                             "roofline": {"bound": "fp64 vector ALU (no extended format on the matrix cores)", "achieved": dd_tf, "peak": PEAK_F64_MFMA_TFLOPS / 12.0,
+                                                          "unit": "dd-TFLOP/s (a double-double multiply-add = 2 flops = 12 fp64 vector operations with deferred renormalisation)",
+                                                          "frac": dd_tf / (PEAK_F64_MFMA_TFLOPS / 12.0), "kernel": "k_dd_potrf + k_dd_trsm + k_dd_update, all levels",
+                                                          "dd_factorisations_per_problem": dd_nfac / nbl, "dd_factor_ms": dd_ms},
+                                             "cpu_baseline": tight_cpu,
                                              "ipm_iterations_mean": float(it3.mean()), "ipm_iterations_max": int(it3.max()), "status_optimal": int((st3 == 0).sum()),
                                              "mu_target_max": float(in3[:, 6].max()), "certified_gap_on_kappa": float((2 * p * n + 1) * (in3[:, 6] / k3).max()),
                                              "kappa_mean": float(k3.mean()), "kappa_drop_vs_default_mean": float((kappa - k3).mean()),
@@ -422,7 +496,11 @@ def main():
                        "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
                        "distinct_problems_per_gpu": nd, "mu_tol": args.tol if args.tol > 0 else 2.0 ** -25,
                        "ipm_iterations_max": int(iters.max()), "ipm_iterations_mean": float(iters.mean()),
-                       "ipm_iterations_per_rank": [{"max": int(a), "mean": b} for a, b in it_all],
+                       "ipm_iterations_per_rank": [{"max": int(a), "mean": b} for a, b, _, _ in it_all],
+                       "solve_ms_per_step_per_rank": [c for _, _, c, _ in it_all],      # time inside the library per step (the rest of a rank's step is waiting for the slowest at the gather)
+                       "problems_per_rank": [int(d_) for _, _, _, d_ in it_all],
+                       "balance": ("cost-balanced shards (sbeta proxy, tunempc_amd.dist.balanced_assignment)" if balance else "every rank solves the problems it generated"),
+                       "stragglers": int(args.stragglers),
                        "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": (f"batch-sharded x{world}, one all-gather of Hc" + (f" [backend {args.backend}" + (", every rank on cuda:0: the code path, not a scaling measurement]" if args.same_device else "]") if (host_coll or args.same_device) else "")) if world > 1 else "single GPU"},

@@ -42,7 +42,7 @@ extern "C" {
 
 #define TMPC_OK 0
 #define TMPC_E_ARG (-1)        /* bad argument (null pointer, non-positive size)            */
-#define TMPC_E_UNSUPPORTED (-2) /* n = nx+mb > 32 (one LDS tile per stage block) or p < 1   */
+#define TMPC_E_UNSUPPORTED (-2) /* shape outside what the handle / entry supports: nx+mb > 64, more than TMPC_MAX_ROWS rows, Schur blocks wider than 2384, p < 1; tight mode on a handle with rows */
 #define TMPC_E_NOMEM (-3)      /* hipMalloc failed                                          */
 #define TMPC_E_HIP (-4)        /* HIP runtime error (see tmpc_last_error)                   */
 #define TMPC_E_NODEVICE (-5)   /* no gfx950 device visible                                  */
@@ -52,7 +52,7 @@ extern "C" {
 #define TMPC_STATUS_FEASIBLE 1   /* convexifier.py:446 'Feasible'   */
 #define TMPC_STATUS_INFEASIBLE 2 /* convexifier.py:451 'Infeasible' */
 
-#define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments instead of v_mfma_f64_16x16x4 */
+#define TMPC_FLAG_NO_MFMA 1      /* debug: scalar-FMA GEMM fragments on the register-staged kernels instead of the matrix cores (product path: v_mfma_f64_4x4x4 tiles fed by LDS-DMA) */
 #define TMPC_FLAG_PROFILE 2      /* record hipEvent timings per phase (tmpc_get_profile)           */
 #define TMPC_FLAG_FAST_EXIT 4    /* stop every problem after its FIRST full centering step instead of converging to the central-path point
                                     at mu_target: Hc is feasible (positive definite, cond <= kappa), kappa within the same gap N mu_target of
@@ -62,7 +62,8 @@ extern "C" {
 
 #define TMPC_INFO_STRIDE 16      /* doubles per problem in info[] (layout below)                   */
 /* info[b*16 + i]: 0 s (=1/min|eig H|), 1 sbeta, 2 min eig H, 3 min eig Hc, 4 max cond Hc, 5 mu,
- *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter,3 = stopped by TMPC_FLAG_FAST_EXIT: status Optimal, not the converged point),
+ *                 6 mu_target, 7 pinf, 8 dinf, 9 relgap, 10 ipm status (0 opt,1 inaccurate,2 maxiter,3 = stopped by TMPC_FLAG_FAST_EXIT: status Optimal, not the converged point,
+ *                    4 = tight mode only: the continuation of this member failed and the result of its DEFAULT solve was returned -- status Optimal at the default gap, info[6]),
  *                 11 #shifted pivots, 12 centering iterations, 13 early-exit flag (convexifier.py:83-85),
  *                 14 last centering step norm, 15 smallest Cholesky pivot of the Schur factorisations relative to the assembled diagonal (1 if never below 1e-8; <= 1e-15 = frozen)                                          */
 
@@ -140,7 +141,7 @@ int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, 
  * problem in which every stage quantity is double-double (the returned point is then reproducible to ~1e-12 instead of ~eps/mu).
  * Outputs as before; info[6] = the mu_target reached, iters includes the extra iterations.  A member whose continuation fails (a non-positive
  * double-double pivot, a polish step that leaves the cone, the iteration cap: most visibly hard targets below 2^-33) gets the result of its default
- * solve back, status Optimal, info[6] = the default's mu_target: the mode never returns less than the default does.  Costs one more workspace of about the size of
+ * solve back, status Optimal, info[10] = 4 and info[6] = the default's mu_target: the mode never returns less than the default does, and says so.  Costs one more workspace of about the size of
  * the block storage (allocated at the first enable) and ~10 double-double factorisations per problem (vector ALU, no matrix cores).
  * enable == 0 switches back to the default (the workspace stays).  TMPC_E_UNSUPPORTED for handles with G / C rows or Step 3. */
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol);

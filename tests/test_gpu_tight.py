@@ -213,10 +213,12 @@ def test_tight_mode_never_returns_less_than_the_default():
         want = 2.0 ** np.round(np.log2(TIGHT_TOL * max(1.0, out['kappa'][b])))
         if out['info'][b, 6] == want:
             arrived += 1
+            assert out['info'][b, 10] == 0.0
             if ref['status'][b] == 0:
                 assert rel(out['Hc'][b], ref['Hc'][b]) < 1e-7, b
         else:
             fell += 1
+            assert out['info'][b, 10] == 4.0 and dflt['info'][b, 10] == 0.0          # round 5: the member says that it carries the DEFAULT gap (status alone cannot)
             assert out['info'][b, 6] == dflt['info'][b, 6] and np.array_equal(out['Hc'][b], dflt['Hc'][b]) and out['kappa'][b] == dflt['kappa'][b], b
     print(f'hard targets at 2^-37: {arrived} arrived, {fell} fell back to the default result (CPU restatement: {int((ref["status"] != 0).sum())} Feasible)')
     assert arrived >= 1

@@ -229,7 +229,7 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
 _LAST_HANDLE = None      # handle of the most recent batch call (its iteration trace is the solver log of convexify())
 
 
-_IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged', 3: 'optimal'}     # info[10]; plays the role of M.status (convexifier.py:365, :443); 3: TMPC_FLAG_FAST_EXIT stopped after the first full centering step
+_IPM_STATUS = {0: 'optimal', 1: 'optimal_inaccurate', 2: 'not converged', 3: 'optimal', 4: 'optimal'}     # info[10]; plays the role of M.status (convexifier.py:365, :443); 3: TMPC_FLAG_FAST_EXIT stopped after the first full centering step, 4: tight mode fell back to the default point
 
 
 def _log_solution(res):

@@ -48,7 +48,8 @@ enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, 
 // phases
 enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2, PH_POLISH = 3 };     // PH_POLISH: waits for / runs the dd dual-Newton polish of the tight mode (out of the active list)
 // ipm status
-enum { IPM_OPTIMAL = 0, IPM_INACCURATE = 1, IPM_MAXITER = 2, IPM_FAST_EXIT = 3 };     // IPM_FAST_EXIT: stopped by TMPC_FLAG_FAST_EXIT after the first full centering step (status Optimal, info[10] = 3)
+enum { IPM_OPTIMAL = 0, IPM_INACCURATE = 1, IPM_MAXITER = 2, IPM_FAST_EXIT = 3, IPM_TIGHT_FALLBACK = 4 };     // IPM_TIGHT_FALLBACK: the tight phase of this member failed, the result of its default solve was put back (status Optimal at the DEFAULT gap: info[6])
+//     // IPM_FAST_EXIT: stopped by TMPC_FLAG_FAST_EXIT after the first full centering step (status Optimal, info[10] = 3)
 // reference status strings (convexifier.py:442-451)
 enum { ST_OPTIMAL = 0, ST_FEASIBLE = 1, ST_INFEASIBLE = 2 };
 

@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(64) k_tight_restart(WS w, Dims dm, Opts o) {
 }
 // A member whose tight phase did not end Optimal (a non-positive dd pivot, a polish that left the cone, the iteration cap: fp64 stage arithmetic has its own
 // limits, most visibly on hard targets below 2^-33) gets the result of its default solve back: the mode never returns less than the default does.
-// info[6] (mu_target) then shows the default's target; I_DD = 2 marks the member.
+// info[6] (mu_target) then shows the default's target; info[10] = 4 (IPM_TIGHT_FALLBACK) and I_DD = 2 mark the member (until round 4 only info[6] told).
 __global__ void __launch_bounds__(64) k_tight_fallback(WS w, Dims dm) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(64) k_tight_fallback(WS w, Dims dm) {
   for (size_t e = lane; e < np_; e += 64) w.P[(size_t)b * np_ + e] = w.Pdef[(size_t)b * np_ + e];
   if (lane != 0) return;
   pr[P_TAU] = pr[P_TAU_DEF]; pr[P_ALPHA] = pr[P_ALPHA_DEF]; pr[P_MUT] = pr[P_MUT1]; pr[P_MU] = pr[P_MUT1];
-  ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; ip[I_DD] = 2;
+  ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_TIGHT_FALLBACK; ip[I_DD] = 2;      // (info[10] = 4: a caller who asked for the tight gap can tell that this member has the default one)
 }
 
 // polish, after k_dd_polish_pre: scalars of the border system and of the gradient (the slots k_solve_border reads), cone check

@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64) k_final_prob(WS w, Dims dm) {
     pr[P_MINEIG_HC] = lo; pr[P_MAXEIG_HC] = hi; pr[P_MAXCOND] = mc;
     // status rule of convexifier.py:442-451
     int st;
-    if (lo > 0.0) st = (ip[I_IPMSTATUS] == IPM_OPTIMAL || ip[I_IPMSTATUS] == IPM_FAST_EXIT) ? ST_OPTIMAL : ST_FEASIBLE;
+    if (lo > 0.0) st = (ip[I_IPMSTATUS] == IPM_OPTIMAL || ip[I_IPMSTATUS] == IPM_FAST_EXIT || ip[I_IPMSTATUS] == IPM_TIGHT_FALLBACK) ? ST_OPTIMAL : ST_FEASIBLE;
     else st = ST_INFEASIBLE;
     ip[I_STATUS] = st;
     if (ip[I_EARLY]) { pr[P_KAPPA] = 0.0; pr[P_BETA] = 0.0; pr[P_ALPHA_OUT] = 1.0; }
