@@ -42,7 +42,7 @@ extern "C" {
 
 #define TMPC_OK 0
 #define TMPC_E_ARG (-1)        /* bad argument (null pointer, non-positive size)            */
-#define TMPC_E_UNSUPPORTED (-2) /* shape outside what the handle / entry supports: nx+mb > 64, more than TMPC_MAX_ROWS rows, Schur blocks wider than 2384, p < 1; tight mode on a handle with rows */
+#define TMPC_E_UNSUPPORTED (-2) /* shape outside what the handle / entry supports: nx+mb > 96 (> 64 with rows or Step 3), more than TMPC_MAX_ROWS rows, Schur blocks wider than 3168, p < 1; tight mode on a handle with rows */
 #define TMPC_E_NOMEM (-3)      /* hipMalloc failed                                          */
 #define TMPC_E_HIP (-4)        /* HIP runtime error (see tmpc_last_error)                   */
 #define TMPC_E_NODEVICE (-5)   /* no gfx950 device visible                                  */
@@ -73,8 +73,9 @@ typedef struct tmpc_handle tmpc_handle;
 int tmpc_device_count(void);
 
 /* Device workspace needed for `chunk` problems of shape (p, nx, mb), in bytes (0 if unsupported).
- * Supported: p >= 1, nx + mb <= 64 (tuned per-stage kernels up to 32, generic ones above, every model), rows of G_k / C_k up to TMPC_MAX_ROWS each, and
- * Schur blocks -- nx(nx+1)/2, plus the rows, plus (Step 3) the (nx+mb)(nx+mb+1)/2 + 1 entries of T_k and its epigraph variable -- of at most 2384. */
+ * Supported: p >= 1, nx + mb <= 64 for every model (tuned per-stage kernels up to 32, generic ones above) and <= 96 for the plain model (no G / C rows, no Step 3),
+ * rows of G_k / C_k up to TMPC_MAX_ROWS each, and
+ * Schur blocks -- nx(nx+1)/2, plus the rows, plus (Step 3) the (nx+mb)(nx+mb+1)/2 + 1 entries of T_k and its epigraph variable -- of at most 3168 (round 4: 2384). */
 uint64_t tmpc_workspace_bytes(int chunk, int p, int nx, int mb);
 
 /* Create a handle on the current HIP device with workspace for `chunk` problems per launch wave.

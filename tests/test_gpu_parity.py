@@ -1073,9 +1073,10 @@ def test_kernel_variants_behind_handle_options(golden_dir, variant):
 
 
 # ----------------------------------------------------------------------------- stage blocks wider than 32
-@pytest.mark.parametrize('seed,nb,p,nx,mb', [(201, 2, 4, 30, 10), (202, 2, 6, 36, 12), (203, 1, 3, 40, 24), (204, 2, 8, 33, 1), (205, 2, 1, 34, 4), (206, 2, 2, 35, 3), (209, 1, 3, 48, 8)])
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(201, 2, 4, 30, 10), (202, 2, 6, 36, 12), (203, 1, 3, 40, 24), (204, 2, 8, 33, 1), (205, 2, 1, 34, 4), (206, 2, 2, 35, 3), (209, 1, 3, 48, 8),
+                                             (210, 1, 2, 40, 32), (211, 1, 3, 60, 12), (212, 1, 1, 48, 48), (213, 2, 2, 24, 56)])      # round 5: n = 72, 72 (blocks of 1830), 96, 80
 def test_large_stage_blocks_parity(seed, nb, p, nx, mb):
-    """32 < n = nx + m <= 64 (the reference accepts any size: preprocessing.py:157-185): the generic per-stage kernels of csrc/tmpc_big.h with the
+    """32 < n = nx + m <= 96 (the reference accepts any size: preprocessing.py:157-185; above 64 the plain model only): the generic per-stage kernels of csrc/tmpc_big.h with the
     register-staged block factorisation (blocks up to 820 wide here) against the C++ CPU port, plain Step 1 model, to the 1e-8 bar; the structural
     invariants; p = 1 and p = 2 included."""
     from tunempc_amd._lib import HipConvexifier
@@ -1409,10 +1410,11 @@ def test_widest_plain_blocks(seed, p, nx, mb):
     assert rel(o['Hc'][0], c['Hc'][0]) < PARITY and abs(o['kappa'][0] - c['kappa'][0]) < 1e-9 * c['kappa'][0]
 
 
-@pytest.mark.parametrize('p,nx,mb,ng,nc', [(2, 30, 10, 0, 0), (2, 36, 12, 24, 24)])
+@pytest.mark.parametrize('p,nx,mb,ng,nc', [(2, 30, 10, 0, 0), (2, 36, 12, 24, 24), (1, 40, 24, 0, 0)])
 def test_step3_at_the_sizes_the_review_names(p, nx, mb, ng, nc):
     """Step 3 at n = 40 (nx = 30, m = 10) and at n = 48 with 24 + 24 rows of G_k / C_k in the same solve (Schur blocks of 1286 and 1893) against the numpy oracle
-    (the second takes the oracle ~90 s on the GPU box's host cores)"""
+    (the second takes the oracle ~90 s on the GPU box's host cores); round 5: n = 64 with nx = 40 -- blocks of 2901, beyond the 2384 the substitution kernels held
+    in LDS until round 4 (review of round 4, item 4 iii)"""
     from tunempc_amd._lib import HipConvexifier
     A, B, H, G, C, ncnt = _mult_model(34, 1, p, nx, mb, ng, nc)
     h = HipConvexifier(p, nx, mb, chunk=1, ng=ng, nc=nc, step3=True)

@@ -27,7 +27,7 @@ DEFAULT_TOL = 2.0 ** -25
 
 
 NG_MAX = 31      # equality-constraint rows per stage the HIP path eliminates (tmpc_common.h: NGM)
-N_TUNED, N_MAX = 32, 64          # stage-block sizes: tuned kernels / generic per-stage kernels (every step; Step 3 while its blocks fit)
+N_TUNED, N_ROWS_MAX, N_MAX = 32, 64, 96          # stage-block sizes: tuned kernels / generic per-stage kernels for every model (Step 3 while its blocks fit) / for the plain model (round 5)
 NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
@@ -42,11 +42,14 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False):
         ng = nc = 0
     if nx + mb > N_MAX:
         raise NotImplementedError('the HIP path handles stage blocks up to nx + nu = {} (got {})'.format(N_MAX, nx + mb))
+    if nx + mb > N_ROWS_MAX and (ng or nc or step3) and not plain:
+        raise NotImplementedError('stage blocks beyond nx + nu = {} are handled for the plain model only: no G / C rows, no Step 3 (got nx + nu = {}, ng = {}, nc = {}, '
+                                  'force = {})'.format(N_ROWS_MAX, nx + mb, ng, nc, bool(step3)))
     if step3 and load_library().tmpc_workspace_bytes_step3_con(1, p, nx, mb, ng, nc) == 0:
         # 32 < n <= 64 runs on the generic per-stage kernels (csrc/tmpc_big.h) for every step; the blocks of Step 3 carry the n(n+1)/2 entries of T_k and must fit
-        # the LDS image of the substitution kernels (nx(nx+1)/2 + n(n+1)/2 + 1 + rows <= 2384: n = 48 with nx = 36 and 24 + 24 rows fits, n = 64 with nx = 40 does not)
+        # the LDS image of the substitution kernels (nx(nx+1)/2 + n(n+1)/2 + 1 + rows <= 3168: n = 64 with nx = 40 fits -- 2901 --, n = 64 with nx = 48 does not)
         raise NotImplementedError('Step 3 (force=True) at nx = {}, nx + nu = {}: Schur blocks of nx(nx+1)/2 + n(n+1)/2 + 1 + multipliers exceed what the '
-                                  'substitution kernels hold in LDS (2384)'.format(nx, nx + mb))
+                                  'substitution kernels hold in LDS (3168)'.format(nx, nx + mb))
     key = (p, nx, mb, ng, bool(step3), bool(plain))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
     want = 1
     while want < min(max(int(nb), 1), _MAX_CHUNK):

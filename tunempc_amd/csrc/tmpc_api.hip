@@ -154,7 +154,7 @@ static CrDev cr_dev(const CrSched& sc, const int* d_sched, const int* alist) {
 }
 
 // ---------------------------------------------------------------------------------- sizes
-static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NB && nx + mb >= 1; }      // n <= 32: the tuned per-stage kernels; 32 < n <= 64: tmpc_big.h
+static bool dims_ok(int p, int nx, int mb) { return p >= 1 && nx >= 1 && mb >= 0 && nx + mb <= NB && nx + mb >= 1; }      // n <= 32: the tuned per-stage kernels; 32 < n <= 96: tmpc_big.h (above 64: plain model only, model_dims_ok)
 
 static Dims make_dims(int chunk, int p, int nx, int mb, int ng = 0, int nc = 0, int step3 = 0) {
   Dims d;
@@ -802,9 +802,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipLaunchKernelGGL(k_ctrl_a, dim3(active), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[1], st));
     // assembly and factorisation only for the problems that need a new one (flist; the others take a chord step)
-    if (ddm) {
-      hipLaunchKernelGGL(k_dd_images, dim3(BP), dim3(256), dd_stage_lds(dm, DD_IMG_SLOTS), st, w, dm);
-      dd_schur_launch(w, dm, BP, st);
+    if (ddm) {      // (round 5: like the fp64 loop only for the problems of flist -- the others take a chord step on the double-double factor they have)
+      if (nfac > 0) {
+        hipLaunchKernelGGL(k_dd_images, dim3(nfac * dm.p), dim3(256), dd_stage_lds(dm, DD_IMG_SLOTS), st, wf, dm);
+        dd_schur_launch(wf, dm, nfac * dm.p, st);
+      }
     } else if (nfac > 0) {
       if (schur_in_lds(dm)) {
         hipLaunchKernelGGL(k_schur<0>, dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<0>(dm), st, wf, dm);
@@ -841,7 +843,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(BP), dim3(64), 0, st, w, dm, 1);
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
-    if (ddm) dd_factor(w, dm, h->sched, h->d_sched, alist, active, st);
+    if (ddm) { if (nfac > 0) dd_factor(wf, dm, h->sched, h->d_sched, flist, nfac, st); }
     else if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
@@ -918,7 +920,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
   if (h->tight && !eq && !t3 && wall.Dl) {
-    Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.chord_step = 0.0; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
+    // (round 5: chord steps also in this phase and in the polish -- a double-double factorisation costs ten fp64 ones, a step on an old one a tenth of it)
+    Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
     { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3(nb), dim3(64), 0, st, wi, dm, ot); }
     HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -928,24 +931,31 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     HIPCHK(hipMemcpyAsync(cnt, w.active, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int npol = cnt[2];
-    int* list = wall.plist; int* next = alist; int count = npol;
+    // three index buffers: the problems of this step, those of the next one (written by k_polish_ctrl_b), and the ones of this step that get a new
+    // factorisation (the first step: all; later only the problems whose chord step stopped contracting)
+    int* list = wall.plist; int* next = alist; int* fac = flist; int count = npol, nfp = npol;
+    if (npol > 0) HIPCHK(hipMemcpyAsync(fac, list, (size_t)npol * sizeof(int), hipMemcpyDeviceToDevice, st));
     for (int step = 0; step < POLISH_MAX && count > 0; ++step) {
       WS wp = wall; wp.alist = list;
       hipLaunchKernelGGL(k_dd_polish_pre, dim3(count * dm.p), dim3(256), dd_stage_lds(dm, DD_POL_SLOTS), st, wp, dm, 0);
       hipLaunchKernelGGL(k_polish_ctrl_a, dim3(count), dim3(64), 0, st, wp, dm);
-      dd_schur_launch(wp, dm, count * dm.p, st);
-      dd_factor(wp, dm, h->sched, h->d_sched, list, count, st);
+      if (nfp > 0) {
+        WS wq = wall; wq.alist = fac;
+        dd_schur_launch(wq, dm, nfp * dm.p, st);
+        dd_factor(wq, dm, h->sched, h->d_sched, fac, nfp, st);
+      }
       hipLaunchKernelGGL(k_dd_gather, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
       { const int rc_ = dd_solve(wp, dm, h->sched, h->d_sched, list, count, st, 2, nb); if (rc_ != TMPC_OK) return rc_; }
       hipLaunchKernelGGL(k_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list, 2);
       if (dm.n > NMAX) hipLaunchKernelGGL(kb_polish_step, dim3(count * dm.p), dim3(256), 0, st, wp, dm);
       else hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
       HIPCHK(hipMemsetAsync(w.active + 3, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_polish_ctrl_b, dim3(count), dim3(64), 0, st, wp, dm, ot, (const int*)list, count, next, w.active + 3);
-      HIPCHK(hipMemcpyAsync(cnt + 3, w.active + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemsetAsync(w.active + 1, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_polish_ctrl_b, dim3(count), dim3(64), 0, st, wp, dm, ot, (const int*)list, count, next, w.active + 3, fac, w.active + 1);
+      HIPCHK(hipMemcpyAsync(cnt, w.active, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      count = cnt[3];
-      int* t_ = (list == wall.plist) ? flist : list; list = next; next = t_;
+      count = cnt[3]; nfp = cnt[1];
+      { int* t_ = list; list = next; next = t_; }
       ++it;
     }
     if (npol > 0) {      // final iterate of every polished problem: cone check, X_r / S_r for the outputs and the dual export
@@ -986,10 +996,12 @@ static bool rows_ok(int nx, int ng, int nc) {
   (void)nx;
   return ng >= 0 && ng <= NGM && nc >= 0 && nc <= NCM;
 }
+// stage blocks beyond NBM = 64: the plain model only (the multiplier and Step 3 kernels keep one lane per entry of an n-vector)
+static bool model_dims_ok(int nx, int mb, int ng, int nc, int step3) { return nx + mb <= NBM || (ng == 0 && nc == 0 && !step3); }
 static_assert(AEL == TMPC_ARROW_LD, "tunempc_hip.h: leading dimension of the exported arrow blocks");
 static_assert(NGM == TMPC_MAX_ROWS && NCM == TMPC_MAX_ROWS, "tunempc_hip.h: row limits");
 static uint64_t workspace_bytes(int chunk, int p, int nx, int mb, int ng, int nc, int step3) {
-  if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc)) return 0;
+  if (chunk < 1 || !dims_ok(p, nx, mb) || !rows_ok(nx, ng, nc) || !model_dims_ok(nx, mb, ng, nc, step3)) return 0;
   WS w;
   Dims dm = make_dims(chunk, p, nx, mb, ng, nc, step3);
   if (solve_lds(dm) > 160 * 1024) return 0;      // blocks (d + multipliers + entries of T_k) beyond the LDS image of the substitution kernels
@@ -1022,10 +1034,14 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
     snprintf(g_err, sizeof(g_err), "unsupported constraint rows ng=%d nc=%d (need 0<=ng<=%d, 0<=nc<=%d)", ng, nc, NGM, NCM);
     return TMPC_E_UNSUPPORTED;
   }
+  if (!model_dims_ok(nx, mb, ng, nc, step3)) {
+    snprintf(g_err, sizeof(g_err), "nx+mb = %d > %d is supported for the plain model only (no G / C rows, no Step 3)", nx + mb, NBM);
+    return TMPC_E_UNSUPPORTED;
+  }
   {                          // blocks that the LDS images of k_schur and of the substitutions can hold
     const Dims db = make_dims(1, p, nx, mb, ng, nc, step3);
     if (solve_lds(db) > 160 * 1024) {
-      snprintf(g_err, sizeof(g_err), "nx=%d ng=%d nc=%d step3=%d: Schur blocks of %d (svec(P) + multipliers + entries of T_k) do not fit the LDS image of the substitution kernels (limit 2384)", nx, ng, nc, step3, db.dp);
+      snprintf(g_err, sizeof(g_err), "nx=%d ng=%d nc=%d step3=%d: Schur blocks of %d (svec(P) + multipliers + entries of T_k) do not fit the LDS image of the substitution kernels (limit 3168)", nx, ng, nc, step3, db.dp);
       return TMPC_E_UNSUPPORTED;
     }
   }

@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) kb_polish_step(WS w, Dims dm) {
     gmm(t0, n, X, n, 1, dM, n, 1, n, n, n, 0);
     gmm(t1, n, t0, n, 1, Z, n, 1, n, n, n, 0);
     double* out = (r ? w.dX2 : w.dX1) + so;
-    for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; out[e] = X[e] - 0.5 * (t1[i * n + j] + t1[j * n + i]); }
+    if (!w.iprob[(size_t)b * IS + I_CHORD]) for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; out[e] = X[e] - 0.5 * (t1[i * n + j] + t1[j * n + i]); }      // (chord step: k_polish_step)
     gsync();
   }
 }

@@ -782,9 +782,13 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
 // Right-hand sides R [p][dp][NC] (NC interleaved), in place.  Forward, level by level: z_i <- L_i^-1 z_i for the eliminated nodes,
 // then z_s -= O_s z_i for the surviving neighbours; backward in reverse: z_i <- L_i^-T (z_i - O_a' z_a - O_b' z_b).
 // The matrix-vector work is the skinny MFMA GEMM of tmpc_factor.h (wg_gemv16); every factor block is streamed once per sweep.
-// LDS image: the vector of the node and one neighbour's (two regions of NCP rows), a tile-sized scratch, the slab of the skinny GEMM.
-// 160 KB hold blocks up to dp = 2384 (round 4: a third, unused vector region capped it at 1552).
-constexpr int cr_solve_lds_doubles(int dp) { return 2 * NCP * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
+// LDS image: the vector of the node and one neighbour's (two regions of NCV rows), a tile-sized scratch, the slab of the skinny GEMM.
+// 160 KB hold blocks up to dp = 3168 (round 4: 2384 with four-row regions; before, a third, unused vector region capped it at 1552).
+// Round 5: the two vector regions hold NCV = 3 rows (the right-hand sides there are), not the NCP = 4 the operand fragments of wg_gemv16 address -- fragment column 3 reads
+// whatever follows the region (LDS of this workgroup, never stored: a column of the result depends on its own operand column only).  Blocks up to dp = 3168 instead of 2384:
+// Step 3 at n = 64 with nx = 40 (blocks of 2901) fits.
+constexpr int NCV = 3;
+constexpr int cr_solve_lds_doubles(int dp) { return 2 * NCV * (dp + 4) + NCP * (TB + 4) + 64 * GLDV + 16; }
 
 __global__ void __launch_bounds__(256) k_cr_fwd_diag(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count, int pass) {
   const int it = cr_item(count * nelim);
@@ -795,8 +799,8 @@ __global__ void __launch_bounds__(256) k_cr_fwd_diag(WS w, Dims dm, CrDev cr, in
   if (nc == 0) return;
   const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
   const int node = er[CE_NODE], dp = dm.dp, xld = dp + 4, tld = TB + 4;
-  double* zc = lds; double* tmp = lds + 2 * NCP * xld; double* As = tmp + NCP * tld;
-  for (int e = threadIdx.x; e < NCP * xld; e += 256) zc[e] = 0.0;
+  double* zc = lds; double* tmp = lds + 2 * NCV * xld; double* As = tmp + NCP * tld;
+  for (int e = threadIdx.x; e < NCV * xld; e += 256) zc[e] = 0.0;
   for (int e = threadIdx.x; e < NCP * tld; e += 256) tmp[e] = 0.0;
   __syncthreads();
   double* R = cr_rhs(w, dm, b, node, nc);
@@ -815,8 +819,8 @@ __global__ void __launch_bounds__(256) k_cr_fwd_off(WS w, Dims dm, CrDev cr, int
   if (nc == 0) return;
   const int* ur = cr.upd + (size_t)(uoff + it % nupd) * CR_UW;
   const int dp = dm.dp, xld = dp + 4, tld = TB + 4;
-  double* zs = lds; double* zi = zs + NCP * xld; double* As = lds + 2 * NCP * xld + NCP * tld;
-  for (int e = threadIdx.x; e < 2 * NCP * xld; e += 256) lds[e] = 0.0;
+  double* zs = lds; double* zi = zs + NCV * xld; double* As = lds + 2 * NCV * xld + NCP * tld;
+  for (int e = threadIdx.x; e < 2 * NCV * xld + NCP * tld; e += 256) lds[e] = 0.0;
   __syncthreads();
   double* R = cr_rhs(w, dm, b, ur[CU_NODE], nc);
   vec_g2s(zs, xld, R, dp, nc);
@@ -840,8 +844,8 @@ __global__ void __launch_bounds__(256) k_cr_bwd(WS w, Dims dm, CrDev cr, int eof
   if (nc == 0) return;
   const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
   const int node = er[CE_NODE], dp = dm.dp, xld = dp + 4, tld = TB + 4;
-  double* zc = lds; double* zn = zc + NCP * xld; double* tmp = lds + 2 * NCP * xld; double* As = tmp + NCP * tld;
-  for (int e = threadIdx.x; e < 2 * NCP * xld + NCP * tld; e += 256) lds[e] = 0.0;
+  double* zc = lds; double* zn = zc + NCV * xld; double* tmp = lds + 2 * NCV * xld; double* As = tmp + NCP * tld;
+  for (int e = threadIdx.x; e < 2 * NCV * xld + NCP * tld; e += 256) lds[e] = 0.0;
   __syncthreads();
   double* R = cr_rhs(w, dm, b, node, nc);
   vec_g2s(zc, xld, R, dp, nc);

@@ -36,7 +36,7 @@ namespace tmpc {
 
 constexpr int DD_SCR_MATS = 9;            // dd matrices per stage of the global scratch (32 < n <= 64; k_dd_polish_pre needs nine)
 constexpr double POLISH_ENTER = 1e-4;    // as the CPU restatement used by the tests
-constexpr int POLISH_MAX = 6;
+constexpr int POLISH_MAX = 10;     // steps of the polish, chord steps included (round 5; 6 Newton steps before)
 
 // ------------------------------------------------------------------ dd scalar arithmetic (Dekker / Knuth / QD)
 struct ddv { double h, l; };
@@ -416,11 +416,11 @@ __device__ __forceinline__ void blk_bwd_dd(double* zh, double* zl, int xld, doub
     if (j0 > 0) wg_gemv_dd<true>(zh, zl, xld, zh + j0, zl + j0, xld, Dh + (size_t)j0 * dp, Dl + (size_t)j0 * dp, dp, j0, nb, true, -1.0, As, nc);
   }
 }
-// number of right-hand sides of a problem in the tight loop / polish: pass 1 (main phase) and every centering / polish solve carry three
+// number of right-hand sides of a problem in the tight loop / polish: pass 1 (main phase) and every centering / polish solve with a new factorisation carry three
 __device__ __forceinline__ int dd_nc(const WS& w, int b, int pass) {
   const int phase = w.iprob[(size_t)b * IS + I_PHASE];
   if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return 0;
-  return (pass == 1 || phase != PH_MAIN) ? 3 : 1;
+  return (pass == 1 || (phase != PH_MAIN && !w.iprob[(size_t)b * IS + I_CHORD])) ? 3 : 1;      // chord step (round 5): the right-hand side alone, as cr_nc
 }
 #define TMPC_DD_SOLVE_LDS                                                                                     \
   extern __shared__ __attribute__((aligned(16))) double lds[];                                                \
@@ -774,6 +774,7 @@ __global__ void __launch_bounds__(64) k_dd_gather(WS w, Dims dm) {
   const int sid = stage_id(w, dm);
   const int b = sid / dm.p, k = sid - b * dm.p;
   if (w.iprob[(size_t)b * IS + I_PHASE] != PH_POLISH) return;
+  const bool chord = w.iprob[(size_t)b * IS + I_CHORD] != 0;
   const int lane = threadIdx.x, nx = dm.nx, nxx = nx * nx, dp = dm.dp;
   const int km = (k == 0) ? dm.p - 1 : k - 1;
   const size_t ov = (size_t)(b * dm.p + km) * NADJ * nxx, oe = (size_t)sid * NADJ * nxx;
@@ -783,6 +784,7 @@ __global__ void __launch_bounds__(64) k_dd_gather(WS w, Dims dm) {
       const int idx = e + (c - a), o = a * nx + c;
       const double wgt = (a == c) ? 1.0 : 2.0;
       auto piece = [&](int s) { return dd_val(dd_sub(ddv{w.adjV[ov + s * nxx + o], w.adjVl[ov + s * nxx + o]}, ddv{w.adjE[oe + s * nxx + o], w.adjEl[oe + s * nxx + o]})); };
+      if (chord) { w.Z[(size_t)sid * dp + idx] = wgt * piece(ADJ_G); continue; }      // chord step: the gradient alone; border columns, T^-1 U and the 2 x 2 border complement of the last factorisation stay
       const double g = wgt * piece(ADJ_G), ut = -wgt * piece(ADJ_PSI), ua = wgt * piece(ADJ_PHI);
       double* w3 = w.W3 + ((size_t)sid * dp + idx) * 3; w3[0] = g; w3[1] = ut; w3[2] = ua;
       double* u = w.U + ((size_t)sid * dp + idx) * 2; u[0] = ut; u[1] = ua;
@@ -790,6 +792,7 @@ __global__ void __launch_bounds__(64) k_dd_gather(WS w, Dims dm) {
     e += nx - a;
   }
   for (int i = dm.d + lane; i < dp; i += 64) {
+    if (chord) { w.Z[(size_t)sid * dp + i] = 0.0; continue; }
     double* w3 = w.W3 + ((size_t)sid * dp + i) * 3; w3[0] = 0.0; w3[1] = 0.0; w3[2] = 0.0;
     double* u = w.U + ((size_t)sid * dp + i) * 2; u[0] = 0.0; u[1] = 0.0;
   }
@@ -852,7 +855,7 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_a(WS w, Dims dm) {
   const double s0 = pr[P_ALPHA] - ALPHA_MIN, x0 = pr[P_MUT] / s0;
   pr[P_S0] = s0; pr[P_X0] = x0; pr[P_RD0] = 0.0; pr[P_CORR0] = 0.0; pr[P_SIGMU] = pr[P_MUT]; pr[P_MU] = pr[P_MUT];
   pr[P_BTT] = trpsi; pr[P_BTA] = -trphi2; pr[P_BAA] = hbphi + x0 / s0;
-  ip[I_CHORD] = 0;
+  // (I_CHORD: set by k_polish_ctrl_b for the next step -- 0 at the first step of the polish, k_ctrl_d)
 }
 
 // polish, after k_solve_border: dM of the step and the norms of the step test (M itself: T1, written by k_dd_polish_pre)
@@ -882,6 +885,7 @@ __global__ void __launch_bounds__(256) k_polish_step(WS w, Dims dm) {
   // the linear dual equations EXACTLY whatever y is, while X = mu S(y)^-1 at an fp64 y misses them by eps / mu in the active directions
   // (1e-5 at mu = 3e-11): this is the X that tmpc_get_dual_host exports with the last step (dX1 / dX2 hold it until the final sweep).
   const double dtau = pr[P_DTAU];
+  const bool chord = w.iprob[(size_t)b * IS + I_CHORD] != 0;
   double* sX = sV; double* sZ = sHb;                 // V and Hb are not needed any more
   for (int r = 0; r < 2; ++r) {
     wsync();
@@ -892,13 +896,16 @@ __global__ void __launch_bounds__(256) k_polish_step(WS w, Dims dm) {
     mm<256>(t0, sX, LD, 1, sM, LD, 1, n, n, n, 0, lane);
     mm<256>(t1, t0, LD, 1, sZ, LD, 1, n, n, n, 0, lane);
     double* out = (r ? w.dX2 : w.dX1) + (size_t)sid * nn;
-    for (int e = lane; e < nn; e += 256) { int i, j; ediv(e, n, i, j); out[e] = sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]); }
+    if (!chord) for (int e = lane; e < nn; e += 256) { int i, j; ediv(e, n, i, j); out[e] = sX[i * LD + j] - 0.5 * (t1[i * LD + j] + t1[j * LD + i]); }      // (a chord step keeps the dual iterate of the last Newton step: k_polish_ctrl_b)
     if (r == 0) { wsync(); }
   }
 }
 
 // polish, end of a step: the (full) step is taken; done when it was smaller than center_tol.  Rebuilds the list of problems still polishing.
-__global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, const int* list, int count, int* next, int* nnext) {
+// Chord steps (round 5): the Hessian of the dual barrier at the next iterate differs from the factored one by about the size of the step just taken (1e-5 ... 1e-9
+// here), so Newton with the OLD double-double factorisation contracts by that factor -- the second polish step, whose only job is to confirm convergence, and most
+// third ones cost a substitution instead of a factorisation.  A chord step that contracts by less than 1/4 sends the problem back to a new factorisation (fac / nfac).
+__global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, const int* list, int count, int* next, int* nnext, int* fac, int* nfac) {
   if ((int)blockIdx.x >= count) return;
   const int b = list[blockIdx.x], lane = threadIdx.x;
   int* ip = w.iprob + (size_t)b * IS;
@@ -912,7 +919,10 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, con
   if (lane != 0) return;
   if (!fin) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; return; }
   pr[P_TAU_PREV] = pr[P_TAU]; pr[P_ALPHA_PREV] = pr[P_ALPHA];
-  pr[P_DX0] = -pr[P_X0] * pr[P_DALPHA] / pr[P_S0];          // x0 + dx0: the scalar of the dual iterate that goes with this step (k_polish_step)
+  // x0 + dx0: the scalar of the dual iterate that goes with this step (k_polish_step).  Only a NEWTON step yields a dual iterate that satisfies the linear dual
+  // equations exactly; a chord step misses them by (H - H_0) dy, so the exported dual iterate stays the one of the last Newton step -- weak duality pairs ANY dual
+  // feasible point with the final primal one (round 5; with the chord step's iterate the certified gap of tests/test_gpu_tight.py widened from 4.4e-9 to 5.6e-9)
+  if (!ip[I_CHORD]) pr[P_DX0] = pr[P_X0] - pr[P_X0] * pr[P_DALPHA] / pr[P_S0];
   pr[P_TAU] += pr[P_DTAU]; pr[P_ALPHA] += pr[P_DALPHA];
   pr[P_STEPN] = stepn; pr[P_AP] = 1.0; pr[P_AD] = 1.0;
   ip[I_NPOLISH] += 1; ip[I_ITERS] += 1;
@@ -920,9 +930,18 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, con
     double* t = w.trace + ((size_t)b * TRACE_LEN + (ip[I_ITERS] - 1)) * TRACE_W;
     t[0] = (double)ip[I_ITERS]; t[1] = (double)PH_POLISH; t[2] = pr[P_MUT]; t[3] = pr[P_TAU]; t[4] = 0.0; t[5] = 0.0; t[6] = 1.0; t[7] = 1.0; t[8] = stepn; t[9] = 0.0;
   }
-  if (stepn < o.center_tol) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; }       // (k_dd_polish_pre of the final sweep checks the cone at the new point)
-  else if (ip[I_NPOLISH] >= POLISH_MAX) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
-  else { const int slot = atomicAdd(nnext, 1); next[slot] = b; }
+  const bool was_chord = ip[I_CHORD] != 0;
+  const double prev = pr[P_PREVSTEPN];
+  pr[P_PREVSTEPN] = stepn;
+  if (stepn < o.center_tol) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_OPTIMAL; ip[I_CHORD] = 0; }       // (k_dd_polish_pre of the final sweep checks the cone at the new point)
+  else if (ip[I_NPOLISH] >= POLISH_MAX) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; ip[I_CHORD] = 0; }
+  else {
+    const bool chord_next = (o.chord_step > 0.0) && (!was_chord || (prev > 0.0 && stepn <= 0.25 * prev));
+    ip[I_CHORD] = chord_next ? 1 : 0;
+    if (chord_next) ip[I_NCHORD] += 1;
+    const int slot = atomicAdd(nnext, 1); next[slot] = b;
+    if (!chord_next) { const int fs = atomicAdd(nfac, 1); fac[fs] = b; }
+  }
 }
 
 // after the final sweep of k_dd_polish_pre: a last step that left the cone is undone (status Feasible)
@@ -933,7 +952,7 @@ __global__ void __launch_bounds__(64) k_polish_final(WS w, Dims dm) {
   double* pr = w.prob + (size_t)b * PS;
   const int p = dm.p, nxx = dm.nx * dm.nx;
   const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
-  if (!(nbad > 0.0)) { if (lane == 0) { pr[P_X0] += pr[P_DX0]; pr[P_S0] = pr[P_ALPHA] - ALPHA_MIN; pr[P_MU] = pr[P_MUT]; } return; }
+  if (!(nbad > 0.0)) { if (lane == 0) { pr[P_X0] = pr[P_DX0]; pr[P_S0] = pr[P_ALPHA] - ALPHA_MIN; pr[P_MU] = pr[P_MUT]; } return; }
   for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
   if (lane == 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; ip[I_IPMSTATUS] = IPM_INACCURATE; }
 }

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) k_phi_init(WS w, Dims dm) {
 // LDS of k_phi_pre (doubles)
 constexpr int phi_pre_lds(bool bign, bool bigr) {
   return 4 * MS + (bigr ? NZM * (2 * NZM + 1) + 4 * NZM
-                        : (bign ? 0 : NRS * NMAX) + 4 * NRS * (bign ? NB : NMAX) + 4 * NRS * NRS + NZS * (2 * NZS + 1) + 4 * NZS);
+                        : (bign ? 0 : NRS * NMAX) + 4 * NRS * (bign ? NBM : NMAX) + 4 * NRS * NRS + NZS * (2 * NZS + 1) + 4 * NZS);
 }
 // after k_stage_pre (needs S_r^-1), before k_ctrl_a: vectors w, u, V w, V u; K; c_tau, c_alpha; border / mu / pinf partials
 // aug: the multipliers stay in the block system (k_aug_fill): T_loc,loc itself is stored instead of its inverse and the border
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64) k_phi_pre(WS w, Dims dm, int aug) {
   const PhiStage ps = phi_stage(w, dm, sid);
   const int n = dm.n, nx = dm.nx, nn = n * n, ng = ps.nrow, nz = ps.nz, nzs = dm.nz;
   double* sX = sm; double* sSi = sm + MS; double* sHb = sm + 2 * MS; double* sV = sm + 3 * MS;
-  constexpr int NV = BIGN ? NB : NMAX;      // stride of the per-row vectors
+  constexpr int NV = BIGN ? NBM : NMAX;      // stride of the per-row vectors
   constexpr int NZ_ = BIGR ? NZM : NZS;
   double* gl = sm + 4 * MS;                 // [nrow][NMAX]   (BIGN, BIGR: the rows are read from global memory)
   double* wl = gl + ((BIGN || BIGR) ? 0 : NRS * NMAX);  // [2][nrow][NV]

@@ -11,6 +11,10 @@
 
 namespace tmpc {
 
+#ifndef TMPC_POLISH_ENTER
+#define TMPC_POLISH_ENTER 1e-4
+#endif
+constexpr double POLISH_ENTER_GPU = TMPC_POLISH_ENTER;      // tight phase: a full centering step this small hands the problem to the polish (tmpc_dd.h)
 constexpr int MUT_BACKOFF_MAX = 10;      // mu_t back-offs per problem (2^10: relative gap <= ~1e-4 * default at the worst)
 
 // HKM block entry 0.5*(T(Lx,Ls)+T(Ls,Lx))[(ab),(cd)] with T(L,R)[(ab),(cd)] = <E_ab, L E_cd R'>; the two T's
@@ -449,9 +453,9 @@ __device__ __forceinline__ void ctrl_d_body(const WS& w, const Dims& dm, const O
   if (ip[I_PHASE] == PH_DONE || ip[I_PHASE] == PH_POLISH) return;
   double* pr = w.prob + (size_t)b * PS;
   if (ip[I_DD]) ip[I_NDD] += 1;
-  if (o.tight && ip[I_PHASE] == PH_CENTER && pr[P_AP] == 1.0 && pr[P_AD] == 1.0 && pr[P_STEPN] < 1e-4) {
+  if (o.tight && ip[I_PHASE] == PH_CENTER && pr[P_AP] == 1.0 && pr[P_AD] == 1.0 && pr[P_STEPN] < POLISH_ENTER_GPU) {
     // tight phase: the first full centering step this small hands the problem to the dd dual-Newton polish (tmpc_dd.h: POLISH_ENTER)
-    ip[I_PHASE] = PH_POLISH; ip[I_CHORD] = 0;
+    ip[I_PHASE] = PH_POLISH; ip[I_CHORD] = 0; pr[P_PREVSTEPN] = -1.0;
     const int ps = atomicAdd(w.active + 2, 1); w.plist[ps] = b;
     return;
   }

@@ -4,7 +4,8 @@
 
 namespace tmpc {
 
-constexpr int NB = 64;            // largest stage block of the generic per-stage kernels (tmpc_big.h; the multiplier kernels of tmpc_phi.h in their <true> form)
+constexpr int NB = 96;            // largest stage block of the generic per-stage kernels (tmpc_big.h): plain model (round 5; 64 before -- the Jacobi tile of 96 x 97 doubles is 75 KB)
+constexpr int NBM = 64;           // largest stage block with stage-local multipliers or Step 3: the kernels of tmpc_phi.h / tmpc_t3.h keep one LANE per entry of their n-vectors
 constexpr int BIG_SCR = 5;        // n x n scratch matrices per stage of those kernels (WS::bscr)
 
 #define TMPC_SM_NMAX 32
