@@ -33,7 +33,7 @@ def factor_flops_per_problem(p, d):
     return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
 
 
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r4_traffic.json')
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r5_traffic.json')
 KERNEL_SOURCES = sorted(os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'tunempc_amd', 'csrc')) if f.endswith(('.h', '.hip')))      # every kernel source (round 3 hashed two of them)
 
 
@@ -54,7 +54,7 @@ def kernel_sources_sha():
 
 
 def hbm_traffic_per_launch():
-    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r4_traffic.json, written by
+    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r5_traffic.json, written by
     scripts/pmc_traffic.py from separate rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from
     inside this process).  None when the file is missing or was measured on OTHER kernel sources (content hash): a stale number is
     not reported."""
@@ -507,7 +507,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                          "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r4_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r5_traffic.json)",
                          "kernel": "k_cr_update_dma (symmetric updates and fill edges of the cyclic-reduction block Cholesky: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles)",
                          "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
                          "algorithmic_flops_per_launch": upd_flops / upd_launches,

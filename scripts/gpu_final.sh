@@ -1,7 +1,7 @@
 #!/bin/bash
 # the evidence set of a round at HEAD (gpurun): GPU suite log, profile set, default bench line, parity fuzz at two seeds
 export TMPDIR=/tmp; mkdir -p gpurun_out
-TAG=${1:-r4_final}
+TAG=${1:-r5_final}
 timeout 1800 python -m pytest tests/ -m gpu -q -p no:cacheprovider 2>&1 | tail -n 12 > gpurun_out/${TAG}_gpu_tests.log; tail -n 2 gpurun_out/${TAG}_gpu_tests.log
 bash scripts/gpu_prof.sh $TAG > gpurun_out/${TAG}_prof_stdout.txt 2>&1; head -n 8 gpurun_out/${TAG}_kernel_stats.txt | cut -c 1-150
 timeout 1200 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; python scripts/show_bench.py gpurun_out/${TAG}_bench.json | cut -c 1-250

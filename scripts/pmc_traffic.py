@@ -1,5 +1,5 @@
 """HBM traffic per launch of the dominant kernel from two rocprofv3 --pmc passes of the bench command (FETCH_SIZE in one, WRITE_SIZE in the
-other; rocpd sqlite databases) -> profiles/r4_traffic.json, which bench.py reports as roofline.traffic while it is newer than the kernel sources.
+other; rocpd sqlite databases) -> profiles/r5_traffic.json, which bench.py reports as roofline.traffic while it is newer than the kernel sources.
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB-like units of 1024 B... (rocprofv3
 reports kilobytes), and FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 B on gfx950: doubled.
 usage: python scripts/pmc_traffic.py <fetch db dir> <write db dir> [kernel substring]"""
@@ -48,7 +48,7 @@ def main():
         "sources_sha": sources_sha(),
         "note": "average over all launches of the kernel (7 levels per factorisation phase, shrinking active sets)",
     }
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r4_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r5_traffic.json'), 'w'), indent=1)
     print(json.dumps(out))
 
 
