@@ -38,7 +38,10 @@ def test_workspace_query_and_unsupported_dims():
     assert 142e6 < per < 200e6
     assert lib.tmpc_workspace_bytes(2, 64, 24, 8) > 1.9 * per
     assert lib.tmpc_workspace_bytes(1, 64, 30, 8) > lib.tmpc_workspace_bytes(1, 64, 24, 8)      # n = 38: the generic per-stage kernels (round 4; rounds 1-3: unsupported)
-    assert lib.tmpc_workspace_bytes(1, 4, 40, 30) == 0      # n = 70 > 64 unsupported
+    assert lib.tmpc_workspace_bytes(1, 4, 40, 30) > 0       # n = 70: the plain model runs up to n = 96 since round 5 ...
+    assert lib.tmpc_workspace_bytes_con(1, 4, 40, 30, 2, 0) == 0 and lib.tmpc_workspace_bytes_step3(1, 4, 40, 30) == 0      # ... models with rows or Step 3 up to 64
+    assert lib.tmpc_workspace_bytes(1, 4, 60, 40) == 0      # n = 100 > 96 unsupported
+    assert lib.tmpc_workspace_bytes_step3(1, 2, 40, 24) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 48, 16) == 0          # Step 3 at n = 64: blocks of 2901 fit the substitution kernels (3168), 3257 do not
     assert lib.tmpc_workspace_bytes_con(1, 4, 30, 10, 2, 0) > 0 and lib.tmpc_workspace_bytes_step3(1, 4, 30, 10) > 0      # (sizes only; creating the Step 3 handle is refused at n > 32)
     assert lib.tmpc_workspace_bytes(1, 0, 4, 1) == 0
 
@@ -112,21 +115,28 @@ def test_too_many_equality_rows_are_rejected_loudly():
 
 
 def test_large_blocks_limits_are_rejected_loudly():
-    """32 < nx + nu <= 64 runs every step on the generic per-stage kernels; Step 3 there only while its blocks (svec(P) + the n(n+1)/2 entries of T_k) fit the LDS
-    image of the substitution kernels; that and anything above 64 raise NotImplementedError before any device call."""
+    """nx + nu > 32 runs on the generic per-stage kernels: every model up to 64, the plain model up to 96 (round 5); Step 3 only while its blocks (svec(P) + the
+    n(n+1)/2 entries of T_k) fit the LDS image of the substitution kernels (3168 since round 5); everything beyond raises NotImplementedError before any device call."""
     from tunempc_amd import convexifier
     from tunempc_amd._lib import load_library
     lib = load_library()
-    assert lib.tmpc_workspace_bytes_step3(1, 2, 30, 10) > 0 and lib.tmpc_workspace_bytes_step3_con(1, 2, 36, 12, 24, 24) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 40, 24) == 0      # blocks of 1286 and 1893 fit, 2901 do not
+    assert lib.tmpc_workspace_bytes_step3(1, 2, 30, 10) > 0 and lib.tmpc_workspace_bytes_step3_con(1, 2, 36, 12, 24, 24) > 0      # blocks of 1286 and 1893
+    assert lib.tmpc_workspace_bytes_step3(1, 2, 40, 24) > 0 and lib.tmpc_workspace_bytes_step3(1, 2, 48, 16) == 0                 # 2901 fit since round 5, 3257 do not
     assert lib.tmpc_workspace_bytes(1, 2, 63, 1) > 0      # the plain model up to nx = 63 (blocks of 2016)
     assert lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 24, 24) > 0 and lib.tmpc_workspace_bytes_con(1, 2, 36, 12, 32, 0) == 0      # rows: up to 31 + 31
-    nx, nu = 40, 24
+    nx, nu = 48, 16
     Ab = np.tile(np.eye(nx) * 0.5, (1, 2, 1, 1)); Bb = np.ones((1, 2, nx, nu)); Hb = np.tile(np.eye(nx + nu), (1, 2, 1, 1))
     with pytest.raises(NotImplementedError, match='Step 3'):
         convexifier.convexify_step3_batch(Ab, Bb, Hb, 1e-2)
-    nx, nu = 50, 20
+    nx, nu = 50, 20                                       # n = 70: the plain model is accepted (it needs a device from here on), rows and Step 3 are not
+    Ab = np.tile(np.eye(nx) * 0.5, (1, 2, 1, 1)); Bb = np.ones((1, 2, nx, nu)); Hb = np.tile(np.eye(nx + nu), (1, 2, 1, 1))
+    with pytest.raises(NotImplementedError, match='plain model only'):
+        convexifier.convexify_batch(Ab, Bb, Hb, G=np.ones((1, 2, 1, nx + nu)))
+    with pytest.raises(NotImplementedError, match='plain model only'):
+        convexifier.convexify_step3_batch(Ab, Bb, Hb, 1e-2)
+    nx, nu = 60, 40
     A = np.eye(nx) * 0.5; B = np.ones((nx, nu)); Q = -np.eye(nx); R = np.eye(nu); N = np.zeros((nx, nu))
-    with pytest.raises(NotImplementedError, match='up to nx \\+ nu = 64'):
+    with pytest.raises(NotImplementedError, match='up to nx \\+ nu = 96'):
         convexifier.convexify(A, B, Q, R, N)
 
 
@@ -225,9 +235,10 @@ def test_header_constants_match_the_python_mirror():
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define\s+(TMPC_[A-Z0-9_]+)\s+(-?\d+)\b', src, flags=re.M)}
     assert defs['TMPC_MAX_ROWS'] == convexifier.NG_MAX == convexifier.NC_MAX == 31
     assert defs['TMPC_ARROW_LD'] == _lib.ARROW_LD == defs['TMPC_MAX_ROWS'] + 1
-    assert [defs[k] for k in ('TMPC_TUNE_CHORD_STEP', 'TMPC_TUNE_SMALL_BLOCKS', 'TMPC_TUNE_EIG_PRETEST', 'TMPC_TUNE_FUSE_FWD', 'TMPC_TUNE_GRAPH')] == [1, 2, 3, 4, 5]
+    assert [defs[k] for k in ('TMPC_TUNE_CHORD_STEP', 'TMPC_TUNE_SMALL_BLOCKS', 'TMPC_TUNE_EIG_PRETEST', 'TMPC_TUNE_FUSE_FWD', 'TMPC_TUNE_GRAPH', 'TMPC_TUNE_FUSED_ELIM',
+                             'TMPC_TUNE_PERSISTENT')] == [1, 2, 3, 4, 5, 6, 7]      # (the positions HipConvexifier.set_tuning passes)
     assert defs['TMPC_INFO_STRIDE'] == 16
-    assert convexifier.N_TUNED == 32 and convexifier.N_MAX == 64
+    assert convexifier.N_TUNED == 32 and convexifier.N_ROWS_MAX == 64 and convexifier.N_MAX == 96
     lib = _lib.load_library()
     # the row limit is enforced by the library itself (workspace query: 0 = unsupported), not only by the mirror
     assert lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 31, 31) > 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 32, 0) == 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 0, 32) == 0
