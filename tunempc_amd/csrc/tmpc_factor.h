@@ -9,7 +9,10 @@
 namespace tmpc {
 
 
-constexpr int FACT_LDS_DOUBLES = 2 * 64 * 65 + 72 + 4 * 16 * 17 + 8;   // the tile Cholesky (tile + inverse + pivot refs + one 16 x 17 scratch per wave); the <2,2,2> GEMM slabs (4*2*64*17) alias the front
+#ifndef TMPC_LDP
+#define TMPC_LDP 65
+#endif
+constexpr int FACT_LDS_DOUBLES = 2 * 64 * TMPC_LDP + 72 + 4 * 16 * 17 + 8;   // the tile Cholesky (tile + inverse + pivot refs + one 16 x 17 scratch per wave); the <2,2,2> GEMM slabs (4*2*64*17) alias the front
 
 enum { GM_SUB = 0, GM_SET = 1, GM_NEG = 2 };   // C -= A B',  C = A B',  C = -A B'
 constexpr int GM_NOTRI = -(1 << 30);       // tmpc_gemm_dma.h: `tri` of a tile that does not touch the diagonal of a symmetric update
@@ -273,7 +276,7 @@ __device__ __forceinline__ void wg_gemm_nt(double* C, int ldc, const double* A, 
 // v_mfma_f64_16x16x4 on LDS operands (one 16 x 16 block per wave); the inverse of the whole tile is then assembled block row by
 // block row from the diagonal inverses.  ~20 workgroup barriers per tile instead of the ~200 of a column-by-column sweep
 // (the tile factorisations were 20 % of the factorisation phase, all of it barrier latency).
-constexpr int LDP = 65;                                  // leading dimension of the tile images in LDS
+constexpr int LDP = TMPC_LDP;                            // leading dimension of the tile images in LDS (65; -DTMPC_LDP=66 / 68: the conflict experiments of round 5, profiles/r5_potrf_ldp.txt)
 // (wave_lds_sync, mm16, load_d16, store_d16: tmpc_small.h)
 
 // One wave: Cholesky (lower, in place) of the 16 x 16 block at S and its inverse into Si (same position; upper part zero).
