@@ -209,10 +209,28 @@ def large_block_configs(HipConvexifier, synthetic):
         ts = []
         for _ in range(3):
             t0 = time.perf_counter(); o = run(); ts.append(time.perf_counter() - t0)
-        h.close()
         tg = float(np.median(ts))
         out[key] = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
                     "ipm_iterations_mean": float(o['iters'].mean()), "schur_block": nx * (nx + 1) // 2 + (ng + nc + 2 if (ng or nc) else 0)}
+        # roofline of the leg: one more solve with the phase events on -- the factorisation flops of the whole solve against the fp64 matrix peak, and what the peak
+        # would allow for this batch (the time of the factorisation flops alone at 100 % of it)
+        try:
+            from tunempc_amd._lib import FLAG_PROFILE
+            h.set_options(flags=FLAG_PROFILE)
+            h.profile(); run(); pf = h.profile()
+            dblk = out[key]["schur_block"]
+            fl = pf['problem_factorisations'] * factor_flops_per_problem(p, dblk)
+            out[key]["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F64_MFMA_TFLOPS,
+                                    "achieved": fl / (pf['factor_ms'] * 1e-3) / 1e12 if pf['factor_ms'] > 0 else None,
+                                    "frac": fl / (pf['factor_ms'] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS if pf['factor_ms'] > 0 else None,
+                                    "kernel": "block factorisation, all levels (register-staged k_cr_potrf / k_cr_trsm + k_cr_update_dma: blocks wider than 320)",
+                                    "factorisations_per_problem": pf['problem_factorisations'] / nb, "factor_ms_per_solve": pf['factor_ms'],
+                                    "whole_solve_tflops": fl / tg / 1e12,
+                                    "stage_conv_per_s_at_peak": nb * p / (fl / (PEAK_F64_MFMA_TFLOPS * 1e12)),
+                                    "note": "stage_conv_per_s_at_peak: the rate if the factorisation flops of this batch ran at 100 % of the datasheet peak and nothing else took time"}
+        except Exception as e:      # noqa: BLE001
+            out[key]["roofline_error"] = f"{type(e).__name__}: {e}"
+        h.close()
         if not (ng or nc):
             # the CPU port beside it (plain model only: oracle/cpu_ipm has no multiplier rows), on a bounded sample of the same shape: one problem per thread,
             # period 4 instead of 16 (the cost of a solve is linear in the period: ~12 s per problem at blocks of 820)

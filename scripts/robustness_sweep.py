@@ -30,6 +30,8 @@ rows = []
 nbad = 0
 for (p, nx, mb) in [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]:
     h = HipConvexifier(p, nx, mb)
+    if os.environ.get('ROBUST_PERSIST'):      # round 5: 2 = the persistent one-launch kernel for every small shape whatever the batch, 0 = never (tmpc_set_tuning)
+        h.set_tuning(persistent=int(os.environ['ROBUST_PERSIST']))
     for sigP in (0.1, 1.0, 10.0, 100.0):
         for cond_exp in CONDS:
             for rad in (0.5, 0.9, 1.2):
