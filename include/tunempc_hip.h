@@ -119,7 +119,7 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
  *                          that lost: profiles/r5_fused_elim.txt; kept for the measurement)
  *   TMPC_TUNE_PERSISTENT   plain-model problems with single-tile Schur blocks and n = nx + mb <= 8 (the reference's own examples) can run their whole
  *                          interior-point loop as ONE launch, one workgroup per problem (tmpc_persist.h).  1 (default): where that is faster -- period
- *                          p <= 16, or at least 96 problems of the call on the chip at once; 0: never (the launch sequence); 2: whenever the shape allows it
+ *                          p <= 8, or at least 96 problems of the call on the chip at once; 0: never (the launch sequence); 2: whenever the shape allows it
  * (Rounds 1-3 read these from environment variables once per process.) */
 #define TMPC_TUNE_CHORD_STEP 1
 #define TMPC_TUNE_SMALL_BLOCKS 2

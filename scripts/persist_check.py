@@ -9,6 +9,8 @@ from tunempc_amd import synthetic
 shapes = [(1, 30, 4, 1), (4, 1, 3, 1), (3, 2, 2, 2), (5, 3, 5, 3), (8, 7, 4, 2), (16, 12, 5, 1), (256, 50, 2, 2), (64, 30, 4, 1), (2, 160, 3, 2), (4, 33, 1, 1), (512, 30, 4, 1)]
 if len(sys.argv) > 1 and sys.argv[1] == 'quick':
     shapes = shapes[:4]
+if len(sys.argv) > 1 and sys.argv[1] == 'short':              # the p <= 16 half of the rule at larger batches
+    shapes = [(nb, p, nx, mb) for (p, nx, mb) in ((8, 4, 1), (16, 3, 2), (4, 5, 3)) for nb in (1, 8, 32, 64, 94)]
 if len(sys.argv) > 1 and sys.argv[1] == 'sweep':             # where the persistent kernel starts to pay (the handle splits a batch over two lanes: half of nb each)
     shapes = [(nb, p, nx, mb) for (p, nx, mb) in ((30, 4, 1), (50, 2, 2), (20, 3, 2), (100, 3, 1)) for nb in (64, 96, 128, 192, 256, 384)]
 for (nb, p, nx, mb) in shapes:

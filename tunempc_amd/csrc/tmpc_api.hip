@@ -742,11 +742,12 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   {
     CrLevs plv;
     // Where it pays (scripts/persist_check.py, profiles/r5_persist_check.txt): the workgroup of a problem takes its stages sixteen at a time, so a
-    // single long problem is slower than on the launch sequence, which spreads them over the CUs (p = 30, batch 1: 6.9 against 4.6 ms); it wins when
-    // one round covers the period (p <= 16: 1.0 - 1.25 x) and from ~96 problems in flight on the chip, whatever the period (p = 20 ... 100: 0.8 - 0.9 x at 64,
-    // 1.0 at 96, 1.2 at 128, 1.7 - 1.9 x at 256 = one workgroup per CU; profiles/r5_persist_sweep.txt).  A wave is split over the lanes of the handle, each
-    // of which makes this decision for its share.  tune_persist: 0 never, 1 by this rule, 2 whenever the shape allows it.
-    const bool pays = h->tune_persist >= 2 || dm.p <= CRS_NW || active * h->nlanes >= 96;
+    // single long problem is slower than on the launch sequence, which spreads them over the CUs (p = 30, batch 1: 6.9 against 4.6 ms); it wins for short
+    // periods at any batch (p <= 8: 1.05 - 1.2 x from 1 to 94 problems; p = 16: 0.9 - 1.0 x, profiles/r5_persist_short_periods.txt) and from ~96 problems in flight
+    // on the chip whatever the period (p = 20 ... 100: 0.8 - 0.9 x at 64, 1.0 at 96, 1.2 at 128, 1.7 - 1.9 x at 256 = one workgroup per CU;
+    // profiles/r5_persist_sweep.txt).  A wave is split over the lanes of the handle, each of which makes this decision for its share.
+    // tune_persist: 0 never, 1 by this rule, 2 whenever the shape allows it.
+    const bool pays = h->tune_persist >= 2 || dm.p <= 8 || active * h->nlanes >= 96;
     const bool persist = h->tune_persist && pays && !eq && !t3 && !big && dm.dp == 16 && dm.n <= PK_NMAX && !h->tight && !prof &&
                          !(h->flags & TMPC_DEBUG_FLAG_STOP_ASSEMBLED) && cr_small_levels(dm, h->sched, &plv);
     if (persist && active > 0) {
