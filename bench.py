@@ -174,10 +174,22 @@ def small_configs(HipConvexifier, synthetic):
         ts = []
         for _ in range(7):
             t0 = time.perf_counter(); o = h.convexify_batch(A, B, H); ts.append(time.perf_counter() - t0)
-        h.close()
         tg = float(np.median(ts))
         rec = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
-               "ipm_iterations_mean": float(o['iters'].mean())}
+               "ipm_iterations_mean": float(o['iters'].mean()),
+               "path": ("k_ipm_small: the whole interior-point loop in one launch, one workgroup per problem (tmpc_persist.h)" if (p <= 8 or nb >= 96)
+                        else "launch sequence (one long problem: its stages spread over the CUs)")}
+        # the other path, for the record (TMPC_TUNE_PERSISTENT 0 / 2): what the default rule chose against what it did not
+        try:
+            h.set_tuning(persistent=0 if (p <= 8 or nb >= 96) else 2)
+            h.convexify_batch(A, B, H)
+            t2 = []
+            for _ in range(5):
+                t0 = time.perf_counter(); h.convexify_batch(A, B, H); t2.append(time.perf_counter() - t0)
+            rec["other_path_ms_per_solve"] = 1e3 * float(np.median(t2))
+        except Exception as e:      # noqa: BLE001
+            rec["other_path_error"] = f"{type(e).__name__}: {e}"
+        h.close()
         if cpu_ipm is not None:
             th = 1 if nb == 1 else cores
             cpu_ipm.convexify_batch(A[:1], B[:1], H[:1], threads=1)

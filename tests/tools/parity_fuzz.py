@@ -32,6 +32,8 @@ for case in range(ncases):
             C[b, k, ncnt[b, k]:] = 0.0
     rho = float(10.0 ** rng.uniform(-3, 0))
     h = HipConvexifier(p, nx, mb, ng=ng, nc=nc)
+    if os.environ.get('FUZZ_PERSIST'):          # round 5: 2 = the plain model of every small shape through the persistent one-launch kernel, 0 = never
+        h.set_tuning(persistent=int(os.environ['FUZZ_PERSIST']))
     outs = dict(plain=h.convexify_batch(A, B, H), G=h.convexify_eq_batch(A, B, H, G),
                 step2=h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, rho))
     outs['beta'] = h.convexify_step2_batch(A, B, H, np.concatenate([G, C], axis=2), ncnt, 0.0)
