@@ -12,9 +12,11 @@ L.library_path = lambda: PROF
 from tunempc_amd._lib import HipConvexifier
 from tunempc_amd import synthetic
 names = ['stage_pre', 'ctrl_a', 'schur assembly', 'factorisation', 'stage_rhs', 'gather', 'substitution', 'border', 'stage_dir', 'eigmin', 'ctrl_b / ctrl_c', 'update + ctrl_d']
-for (nb, p, nx, mb) in [(1, 30, 4, 1), (256, 50, 2, 2)]:
+shapes = [(1, 30, 4, 1), (256, 50, 2, 2)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]      # python scripts/persist_prof.py nb,p,nx,mb ...
+for (nb, p, nx, mb) in shapes:
     A, B, H = synthetic.gen_batch(2000, nb, p, nx, mb)
     h = HipConvexifier(p, nx, mb, chunk=nb)
+    h.set_tuning(persistent=2)
     lib = h.lib
     lib.tmpc_debug_cycle_prof.argtypes = [C.POINTER(C.c_double)]
     out = np.zeros(64)
