@@ -9,6 +9,11 @@
 // control bodies (tmpc_schur.h) -- separated by workgroup barriers.  State stays where the launch-sequence path keeps it (global memory,
 // L2-resident: a p = 30, n = 5 problem is ~0.4 MB), so both paths run the SAME code on the same data layout and differ by rounding only
 // (sums of the 4-wave kernels are taken by one wave here).  No list, no host round trip, no launch between the first iteration and the last.
+//
+// What it buys and what it cannot (profiles/r5_persist_*.txt): the sixteen waves take the stages sixteen at a time, so a batch that fills the chip
+// gains 1.7 - 1.9 x (BASELINE configs[2]: 446 k -> 875 k stage-conv/s) and short periods gain 1.05 - 1.2 x at any batch, while ONE long problem is slower than on the launch
+// sequence, which spreads its stages over the CUs -- run_chunk chooses (TMPC_TUNE_PERSISTENT).  The cost of an iteration is a chain of dependent LDS / L2 round trips on
+// matrices of a few dozen entries (0.2 ms at p = 4, 0.43 ms at p = 30), not launches: the phases below are where it goes.
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_cr_small.h"
@@ -29,7 +34,7 @@ constexpr int pk_lds_doubles(int p) {
   return v;
 }
 
-// cap: iterations per problem (run_chunk's bound); chord_pre: the threshold handed to the step-length pre-test (k_eigmin), < 0: off
+// cap: iterations per problem (run_chunk's bound); chord_pre: unused since the step-length eigenvalues are computed one per THREAD (eigmin_lane_body: always the exact value)
 __global__ void __launch_bounds__(CRS_NT) k_ipm_small(WS w, Dims dm, Opts o, CrDev cr, CrLevs lv, int prep, int reg_max, double chord_pre, int cap) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = w.alist ? w.alist[blockIdx.x] : (int)blockIdx.x;
