@@ -923,6 +923,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   if (h->tight && !eq && !t3 && wall.Dl) {
     // (round 5: chord steps also in this phase and in the polish -- a double-double factorisation costs ten fp64 ones, a step on an old one a tenth of it)
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
+    // where a factorisation costs ten fp64 ones and a step on the old one a twentieth of it, chord steps pay from a much shorter safe step on: threshold 3 instead of 10
+    // (a chord step that contracts by less than 1/4 still returns to Newton).  Measured at the bench shape (profiles/r5_tight_chord.txt): 10 -> 1476, 5 -> 1507,
+    // 3 -> 1547, 2 -> 1579, 1.5 -> 1585 stage-conv/s; at 2 the certified gap of one test shape leaves its bound (chord steps right before the hand-over to the polish)
+    if (ot.chord_step > TIGHT_CHORD_STEP) ot.chord_step = TIGHT_CHORD_STEP;
     HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
     { WS wi = wall; wi.alist = alist; wi.flist = flist; hipLaunchKernelGGL(k_tight_restart, dim3(nb), dim3(64), 0, st, wi, dm, ot); }
     HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));

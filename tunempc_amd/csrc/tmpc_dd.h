@@ -36,6 +36,7 @@ namespace tmpc {
 
 constexpr int DD_SCR_MATS = 9;            // dd matrices per stage of the global scratch (32 < n <= 64; k_dd_polish_pre needs nine)
 constexpr double POLISH_ENTER = 1e-4;    // as the CPU restatement used by the tests
+constexpr double TIGHT_CHORD_STEP = 3.0;   // chord threshold of the tight phase (run_chunk): the centering phase re-uses a double-double factorisation once a full step could have been 3 x longer
 constexpr int POLISH_MAX = 10;     // steps of the polish, chord steps included (round 5; 6 Newton steps before)
 
 // ------------------------------------------------------------------ dd scalar arithmetic (Dekker / Knuth / QD)
