@@ -11,7 +11,7 @@
 // (sums of the 4-wave kernels are taken by one wave here).  No list, no host round trip, no launch between the first iteration and the last.
 //
 // What it buys and what it cannot (profiles/r5_persist_*.txt): the sixteen waves take the stages sixteen at a time, so a batch that fills the chip
-// gains 1.7 - 1.9 x (BASELINE configs[2]: 446 k -> 875 k stage-conv/s) and short periods gain 1.05 - 1.2 x at any batch, while ONE long problem is slower than on the launch
+// gains 1.7 - 1.9 x (BASELINE configs[2]: 446 k -> 850 - 920 k stage-conv/s) and short periods gain 1.05 - 1.2 x at any batch, while ONE long problem is slower than on the launch
 // sequence, which spreads its stages over the CUs -- run_chunk chooses (TMPC_TUNE_PERSISTENT).  The cost of an iteration is a chain of dependent LDS / L2 round trips on
 // matrices of a few dozen entries (0.2 ms at p = 4, 0.43 ms at p = 30), not launches: the phases below are where it goes.
 #pragma once
