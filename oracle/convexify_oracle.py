@@ -361,6 +361,7 @@ class _CyclicBlockCholDD:
 
 POLISH_ENTER = 1e-4       # tight mode: the primal-dual centering phase hands over to the dd dual-Newton polish after a full step this small
 POLISH_MAX = 6
+_POLISH_W64 = False
 
 
 def _inv_dd(S):
@@ -373,14 +374,16 @@ def _inv_dd(S):
     return out
 
 
-def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False):
+def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, mask=None, phi=None):
     """Tight mode, last phase: Newton's method on the DUAL barrier problem  min tau - mu (sum logdet S1_k + logdet S2_k + log(alpha - 1e-8))
     in y = (tau, alpha, P) alone, with every stage quantity in double-double: S_r(y) is formed in dd from the fp64 y (no cancellation in
     M - I), S_r^-1 in dd, X_r := mu S_r^-1 is not an iterate any more.  The primal-dual iteration stores X and S^-1 as fp64 matrices whose
     large part (active x active, O(1) resp. 1/mu) buries the small one (~mu resp. O(1)) under an ABSOLUTE rounding error eps, and the
     directions inside the optimal face are determined by the small part: its centred point is reproducible to ~eps/mu only (1e-7 at
     mu = 2e-12, measured).  The minimiser of the barrier problem IS the central-path point at mu; two or three steps from the end of the
-    primal-dual centering phase reproduce it to ~1e-12 (two runs on inputs 1e-14 apart).  Returns (tau, alpha, P, X1, X2, ok, steps, stepn)."""
+    primal-dual centering phase reproduce it to ~1e-12 (two runs on inputs 1e-14 apart).  Returns (tau, alpha, P, X1, X2, ok, steps, stepn[, phi]).
+    GG [p, ng, n, n], mask [p, ng], phi [p, ng] (round 5): the cost-free multipliers of the equality-constraint rows (convexifier.py:249-255) join y,
+    M_k gains sum_i phi_ki g_i g_i' (in dd), the barrier -mu sum log phi_ki; their border columns are formed in dd and rounded like those of tau and alpha."""
     p, nx, _ = A.shape
     n = Hb.shape[1]
     d = nx * (nx + 1) // 2
@@ -394,21 +397,31 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False):
     adj = lambda G: roll1(dn.matmul_nt(dn.matmul(Vd, G), Vd)) - G[:, :nx, :nx]          # calH_adj in dd
     tr = lambda G: np.trace(G.to_float(), axis1=1, axis2=2).sum()
 
-    def cones(tau_, alpha_, P_):
+    ng = 0 if GG is None else GG.shape[1]
+    if ng:
+        GGd = dn.DD(GG)
+        phi = np.where(mask, phi, 1.0)
+
+    def cones(tau_, alpha_, P_, phi_=None):
         M = Hd * alpha_ + dn.matmul(dn.matmul(Vd.T, dn.DD(np.roll(P_, -1, axis=0))), Vd)
         M[:, :nx, :nx] = M[:, :nx, :nx] - dn.DD(P_)
         if not alpha_ - ALPHA_MIN > 0.0:
             raise np.linalg.LinAlgError('alpha')
+        for i in range(ng):
+            if not (phi_[:, i] > 0.0).all():
+                raise np.linalg.LinAlgError('phi')
+            M = M + GGd[:, i] * (phi_[:, i] * mask[:, i])[:, None, None]
         return M, _inv_dd(M - I), _inv_dd((-M) + tau_ * I)
 
     stepn = np.inf
     X1 = X2 = None
     ok = False
     steps = 0
+    ret = lambda *a: a + ((phi,) if ng else ())
     try:
-        M, Z1, Z2 = cones(tau, alpha, P)
+        M, Z1, Z2 = cones(tau, alpha, P, phi)
     except np.linalg.LinAlgError:
-        return tau, alpha, P, None, None, False, 0, stepn
+        return ret(tau, alpha, P, None, None, False, 0, stepn)
     for steps in range(1, POLISH_MAX + 1):
         s0 = alpha - ALPHA_MIN
         X1 = Z1 * mu; X2 = Z2 * mu; x0 = mu / s0
@@ -428,32 +441,66 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False):
         Y = X1 - X2
         g_tau = 1.0 - tr(X2); g_alpha = -np.sum((Hd * Y).to_float()) - x0
         rhsP = sv(adj(Y)).to_float()                              # -gradient in P, rounded to fp64 AFTER the subtractions
+        rb = np.array([-g_tau, -g_alpha])
+        if ng:
+            # one border column per multiplier (as in sdp_step1): W = Phi_k(g g') in dd, entries at P_k and P_{k+1} only
+            Ug = np.zeros((p, d, p * ng)); Bfull = np.zeros((2 + p * ng, 2 + p * ng)); Bfull[:2, :2] = Bb
+            Psif = Psi.to_float(); PhiHf = PhiH.to_float(); Yf = Y.to_float()
+            Wf = np.zeros((p, ng, n, n))
+            for i in range(ng):
+                if _POLISH_W64:      # (experiment: the multiplier columns from the fp64 roundings of X_r, S_r^-1, as the HIP path forms them with k_phi_pre)
+                    Wd = dn.DD(symmetrize(X1.to_float() @ GG[:, i] @ Z1.to_float()) + symmetrize(X2.to_float() @ GG[:, i] @ Z2.to_float()))
+                else:
+                    Wd = sym(dn.matmul(dn.matmul(X1, GGd[:, i]), Z1)) + sym(dn.matmul(dn.matmul(X2, GGd[:, i]), Z2))
+                Wf[:, i] = Wd.to_float()
+                cE = (-sv(Wd[:, :nx, :nx])).to_float()                               # at P_k
+                cV = sv(dn.matmul_nt(dn.matmul(Vd, Wd), Vd)).to_float()              # at P_{k+1}
+                for k in range(p):
+                    Ug[k, :, k * ng + i] += cE[k]
+                    Ug[(k + 1) % p, :, k * ng + i] += cV[k]
+            Bpp = GG.reshape(p, ng, n * n) @ Wf.reshape(p, ng, n * n).transpose(0, 2, 1)
+            zf = mu / phi
+            g_phi = -(np.einsum('kiab,kab->ki', GG, Yf) + zf)
+            for k in range(p):
+                sl = slice(2 + k * ng, 2 + (k + 1) * ng)
+                Bfull[sl, sl] = symmetrize(Bpp[k][None])[0] + np.diag(np.where(mask[k], zf[k] / phi[k], 1.0))
+                Bfull[0, sl] = Bfull[sl, 0] = -np.einsum('iab,ab->i', GG[k], Psif[k]) * mask[k]
+                Bfull[1, sl] = Bfull[sl, 1] = np.einsum('iab,ab->i', GG[k], PhiHf[k]) * mask[k]
+            Ug = Ug * mask.reshape(1, 1, p * ng)
+            U = np.concatenate([U, Ug], axis=2); Bb = Bfull
+            rb = np.concatenate([rb, (-g_phi * mask).ravel()])
         TU = chol.solve(U)
-        Sb = Bb - np.einsum('kdi,kdj->ij', U, TU)
+        Sb = Bb - (np.einsum('kdi,kdj->ij', U, TU) if U.shape[2] <= 2 else U.reshape(-1, U.shape[2]).T @ TU.reshape(-1, TU.shape[2]))
         z = chol.solve(rhsP[:, :, None])[:, :, 0]
-        db = np.linalg.solve(Sb, np.array([-g_tau, -g_alpha]) - np.einsum('kdi,kd->i', U, z))
+        db = np.linalg.solve(Sb, rb - np.einsum('kdi,kd->i', U, z))
         dp = z - TU @ db
         dP = _smat(dp, nx, ia, ib)
         Mf = M.to_float()
         dM = db[1] * Hb + calH(A, B, dP)
+        dphi = None
+        if ng:
+            dphi = db[2:].reshape(p, ng) * mask
+            dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
         stepn = np.sqrt(np.sum((dM - (db[1] / alpha) * Mf) ** 2) / np.sum(Mf ** 2))
         th = 1.0
         while True:                                               # damped only if the full step leaves the cone (not seen after the centering phase)
             try:
-                M, Z1, Z2 = cones(tau + th * db[0], alpha + th * db[1], P + th * dP)
+                M, Z1, Z2 = cones(tau + th * db[0], alpha + th * db[1], P + th * dP, phi + th * dphi if ng else None)
                 break
             except np.linalg.LinAlgError:
                 th *= 0.5
                 if th < 1e-3:
-                    return tau, alpha, P, X1.to_float(), X2.to_float(), False, steps, stepn
+                    return ret(tau, alpha, P, X1.to_float(), X2.to_float(), False, steps, stepn)
         tau += th * db[0]; alpha += th * db[1]; P = P + th * dP
+        if ng:
+            phi = phi + th * dphi
         if verbose:
             print(f"      polish {steps}: |dy|rel={stepn:.3e} step={th:.3f}")
         if th == 1.0 and stepn < center_tol:
             ok = True
             break
     X1 = (Z1 * mu).to_float(); X2 = (Z2 * mu).to_float()
-    return tau, alpha, P, X1, X2, ok, steps, stepn
+    return ret(tau, alpha, P, X1, X2, ok, steps, stepn)
 
 
 # ------------------------------------------------------------ small batched helpers
@@ -687,8 +734,8 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     arrows.append(dict(k=k, idx=idx, t=t0, soc=False, X=x0 * np.linalg.inv(_arrow(t0, cw[idx] * phi[k, idx], wr))))
                     N = N + m + 1
     mu_t = None
-    tight = bool(o.get('tight', False))       # tight-accuracy mode (plain model): see DD_SWITCH
-    assert not (tight and ng), 'tight mode: plain Step 1 model only'
+    tight = bool(o.get('tight', False))       # tight-accuracy mode (plain model, and Step 1 with the cost-free multipliers of G): see DD_SWITCH
+    assert not (tight and (arrows or nT or (constr and not cost_free))), 'tight mode: Step 1 models only (no norm terms, no T_k)'
     dd_on = False
     ndd = 0
     extrap_terms = None
@@ -1038,10 +1085,15 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             prev_stepn = stepn if full else None
     npolish = 0
     if status == 'polish':
-        tau, alpha, P, Xp1, Xp2, okp, npolish, stepn = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose)
+        if ng:
+            tau, alpha, P, Xp1, Xp2, okp, npolish, stepn, phi = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose, GG=GG, mask=mask, phi=phi)
+        else:
+            tau, alpha, P, Xp1, Xp2, okp, npolish, stepn = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose)
         status = 'optimal' if okp else 'optimal_inaccurate'
         if Xp1 is not None:
             X1, X2 = Xp1, Xp2; s0 = alpha - ALPHA_MIN; x0 = mu_t / s0
+            if ng:
+                z = np.where(mask, mu_t / phi, 0.0)
     Pst = P / (s * alpha)                               # convexifier.py:406 (sP = s_alpha = s)
     out = dict(P=Pst, alpha=alpha, beta=tau / sbeta, kappa=tau, s=s, sbeta=sbeta, iters=it + 1,
                ipm_status=status, mu=mu, mu_target=mu_t, pinf=pinf, dinf=dinf, shift=shift_used, dd_iters=ndd, polish_steps=npolish, stepn=stepn, X1=X1, X2=X2, x0=x0)
