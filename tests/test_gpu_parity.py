@@ -1153,51 +1153,59 @@ def test_dual_certificate_with_multipliers(model):
     h.close()
     for b in range(nb):
         assert int(out['status'][b]) == 0
-        s = out['info'][b, 0]; sbeta = out['info'][b, 1]
-        alpha, kappa = out['alpha'][b], out['kappa'][b]
-        Hb = s * 0.5 * (H[b] + H[b].transpose(0, 2, 1))
-        V = np.concatenate([A[b], B[b]], axis=2)
-        Pbar = out['P'][b] * (s * alpha)
-        phi, z = dc['phi'][b], dc['z'][b]
-        M = alpha * Hb + V.transpose(0, 2, 1) @ np.roll(Pbar, -1, axis=0) @ V
-        M[:, :nx, :nx] -= Pbar
-        ncone = 2 * p * n + 1
-        for k in range(p):
-            for i in range(rows[b, k]):
-                M[k] += phi[k, i] * np.outer(J[b, k, i], J[b, k, i])
-                assert phi[k, i] > 0 and z[k, i] > 0
-                ncone += 1
-        ev = np.linalg.eigvalsh(M)
-        assert ev.min() >= 1.0 - 1e-9 and ev.max() <= kappa * (1 + 1e-9) and alpha > 1e-8                     # primal feasible
-        X1, X2, x0 = dual['X1'][b], dual['X2'][b], dual['x0'][b]
-        assert np.linalg.eigvalsh(X1).min() > 0 and np.linalg.eigvalsh(X2).min() > 0 and x0 > 0
-        Y = X1 - X2
-        r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
-        r_alpha = -np.sum(Hb * Y) - x0
-        W = V @ Y @ V.transpose(0, 2, 1)
-        r_P = -(np.roll(W, 1, axis=0) - Y[:, :nx, :nx])
-        primal = kappa
-        slack = 2.0 * (abs(r_tau) * kappa + abs(r_alpha) * alpha + np.sqrt(np.sum(r_P ** 2)) * np.sqrt(np.sum(Pbar ** 2)))
-        wr = rho * sbeta / s
-        for k in range(p):
-            r_phi = np.array([-J[b, k, i] @ Y[k] @ J[b, k, i] - z[k, i] for i in range(rows[b, k])])
-            if model == 'step2':
-                e = 0
-                for (a0, m) in ([(0, ng)] if ng else []) + ([(ng, int(ncnt[b, k]))] if ncnt[b, k] else []):
-                    Xe = dc['aX'][b, k, e][:m + 1, :m + 1]; te = dc['at'][b, k, e]
-                    assert np.linalg.eigvalsh(Xe).min() > 0
-                    assert te >= wr * np.linalg.norm(phi[k, a0:a0 + m]) * (1 - 1e-12)                        # the arrow LMI of the epigraph holds
-                    r_phi[a0:a0 + m] -= 2.0 * wr * Xe[0, 1:]
-                    slack += 2.0 * abs(1.0 - np.trace(Xe)) * te
-                    primal += te
-                    ncone += m + 1
-                    e += 1
-            slack += 2.0 * np.sum(np.abs(r_phi) * phi[k, :rows[b, k]])
-        dobj = np.trace(X1, axis1=1, axis2=2).sum() + 1e-8 * x0
-        gap = ncone * dual['mu_target'][b]
+        primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], J[b], rows[b], ncnt[b], ng, rho, out, dual, dc, b, model == 'step2')
         assert dobj - slack <= primal
         assert primal - dobj <= 1.05 * gap + slack, (model, b, primal - dobj, gap, slack)
         print(f'{model}: certified relative gap {(primal - (dobj - slack)) / primal:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e})')
+
+
+def _certificate_con(A, B, H, J, rows, ncnt, ng, rho, out, dual, dc, b, arrows):
+    """Certificate of member b of a model with stage-local multipliers, numpy only: (attained primal value, dual objective, slack from the dual residuals,
+    N * mu_target).  A, B, H, J [p, ...] of the member; rows [p] = rows of [G_k; C_k] present; arrows: Step 2 (norm terms)."""
+    p, nx, _ = A.shape
+    n = H.shape[1]
+    s = out['info'][b, 0]; sbeta = out['info'][b, 1]
+    alpha, kappa = out['alpha'][b], out['kappa'][b]
+    Hb = s * 0.5 * (H + H.transpose(0, 2, 1))
+    V = np.concatenate([A, B], axis=2)
+    Pbar = out['P'][b] * (s * alpha)
+    phi, z = dc['phi'][b], dc['z'][b]
+    M = alpha * Hb + V.transpose(0, 2, 1) @ np.roll(Pbar, -1, axis=0) @ V
+    M[:, :nx, :nx] -= Pbar
+    ncone = 2 * p * n + 1
+    for k in range(p):
+        for i in range(rows[k]):
+            M[k] += phi[k, i] * np.outer(J[k, i], J[k, i])
+            assert phi[k, i] > 0 and z[k, i] > 0
+            ncone += 1
+    ev = np.linalg.eigvalsh(M)
+    assert ev.min() >= 1.0 - 1e-9 and ev.max() <= kappa * (1 + 1e-9) and alpha > 1e-8                     # primal feasible
+    X1, X2, x0 = dual['X1'][b], dual['X2'][b], dual['x0'][b]
+    assert np.linalg.eigvalsh(X1).min() > 0 and np.linalg.eigvalsh(X2).min() > 0 and x0 > 0
+    Y = X1 - X2
+    r_tau = 1.0 - np.trace(X2, axis1=1, axis2=2).sum()
+    r_alpha = -np.sum(Hb * Y) - x0
+    W = V @ Y @ V.transpose(0, 2, 1)
+    r_P = -(np.roll(W, 1, axis=0) - Y[:, :nx, :nx])
+    primal = kappa
+    slack = 2.0 * (abs(r_tau) * kappa + abs(r_alpha) * alpha + np.sqrt(np.sum(r_P ** 2)) * np.sqrt(np.sum(Pbar ** 2)))
+    wr = rho * sbeta / s
+    for k in range(p):
+        r_phi = np.array([-J[k, i] @ Y[k] @ J[k, i] - z[k, i] for i in range(rows[k])])
+        if arrows:
+            e = 0
+            for (a0, m) in ([(0, ng)] if ng else []) + ([(ng, int(ncnt[k]))] if ncnt[k] else []):
+                Xe = dc['aX'][b, k, e][:m + 1, :m + 1]; te = dc['at'][b, k, e]
+                assert np.linalg.eigvalsh(Xe).min() > 0
+                assert te >= wr * np.linalg.norm(phi[k, a0:a0 + m]) * (1 - 1e-12)                        # the arrow LMI of the epigraph holds
+                r_phi[a0:a0 + m] -= 2.0 * wr * Xe[0, 1:]
+                slack += 2.0 * abs(1.0 - np.trace(Xe)) * te
+                primal += te
+                ncone += m + 1
+                e += 1
+        slack += 2.0 * np.sum(np.abs(r_phi) * phi[k, :rows[k]])
+    dobj = np.trace(X1, axis1=1, axis2=2).sum() + 1e-8 * x0
+    return primal, dobj, slack, ncone * dual['mu_target'][b]
 
 
 def test_large_block_side_entries():

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 import convexify_oracle as co  # noqa: E402
 import cpu_ipm  # noqa: E402
-from test_gpu_parity import _certificate  # noqa: E402
+from test_gpu_parity import _certificate, _certificate_con  # noqa: E402
 
 PARITY = 1e-8
 TIGHT_TOL = 2.0 ** -37
@@ -126,6 +126,58 @@ def test_tight_dual_certificate(seed, nb, p, nx, mb):
         assert width <= 2.0 * N * TIGHT_TOL + 1e-9
 
 
+# ----------------------------------------------------------------------------- round 5: the mode for Step 1 with rows of G (cost-free multipliers, convexifier.py:249-255)
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng', [(100, 3, 4, 3, 2, 2), (101, 3, 6, 4, 2, 1), (102, 2, 3, 5, 3, 3), (103, 2, 8, 3, 1, 2), (105, 2, 1, 4, 2, 2), (106, 2, 5, 4, 4, 3),
+                                                (107, 1, 6, 10, 4, 2), (108, 1, 4, 16, 6, 3), (109, 1, 3, 24, 8, 4)])
+def test_tight_with_equality_rows_vs_oracle(seed, nb, p, nx, mb, ng):
+    """Tight mode on a handle with rows of G against the numpy oracle's tight mode (oracle/convexify_oracle.py: sdp_step1(tight=True, G=...), the multipliers as variables
+    of the dd dual-Newton polish): Hc, the multipliers Fg, kappa and the barrier target, to the 1e-8 bar; the certificate of the exported dual iterate, numpy only."""
+    from tunempc_amd._lib import HipConvexifier
+    n = nx + mb
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    G = np.random.default_rng(seed).standard_normal((nb, p, ng, n))
+    h = HipConvexifier(p, nx, mb, ng=ng, chunk=nb)
+    out0 = h.convexify_eq_batch(A, B, H, G)
+    h.set_tight(True, TIGHT_TOL)
+    out = h.convexify_eq_batch(A, B, H, G)
+    dual = h.dual(nb); dc = h.dual_con(nb, arrows=False)
+    h.set_tight(False)
+    again = h.convexify_eq_batch(A, B, H, G)
+    h.close()
+    assert np.array_equal(again['Hc'], out0['Hc']) and np.array_equal(again['Fg'], out0['Fg'])         # the default path is untouched by the mode
+    N = 2 * p * n + 1 + p * ng
+    worst = 0.0
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 and int(out['info'][b, 10]) == 0, (b, out['status'][b], out['info'][b, 10])
+        r = co.sdp_step1(A[b], B[b], H[b], dict(tol=TIGHT_TOL, tight=True), G=G[b])
+        assert r['ipm_status'] == 'optimal' and out['info'][b, 6] == r['mu_target']
+        Hc = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'])[0]
+        e = rel(out['Hc'][b], Hc); worst = max(worst, e)
+        assert e < PARITY, (b, e)
+        assert np.abs(out['Fg'][b] - r['Fg']).max() < PARITY * max(1.0, np.abs(r['Fg']).max())
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-11 * r['kappa']
+        assert out['kappa'][b] <= out0['kappa'][b] * (1 + 1e-12)                      # further down the central path
+        primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], G[b], np.full(p, ng), np.zeros(p, int), ng, 0.0, out, dual, dc, b, False)
+        assert dobj - slack <= primal
+        width = (primal - (dobj - slack)) / primal
+        assert width <= 1e-7 and width <= 2.0 * N * TIGHT_TOL + 1e-9, (b, width)
+    print(f'tight mode with G rows p={p} n={n} ng={ng}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
+
+
+def test_tight_refused_where_the_mode_does_not_reach():
+    """handles with room for C rows (Step 2) or Step 3, and rows of G on the generic kernels (n > 32): TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
+    from tunempc_amd._lib import HipConvexifier
+    for kw in (dict(ng=1, nc=2), dict(step3=True)):
+        h = HipConvexifier(3, 3, 2, **kw)
+        with pytest.raises(RuntimeError, match='tmpc_set_tight'):
+            h.set_tight(True)
+        h.close()
+    h = HipConvexifier(2, 30, 6, ng=2)
+    with pytest.raises(RuntimeError, match='tmpc_set_tight'):
+        h.set_tight(True)
+    h.close()
+
+
 @pytest.mark.parametrize('seed,p,nx,mb', [(77, 5, 4, 2), (78, 16, 12, 4), (79, 64, 24, 8), (81, 3, 28, 12)])
 def test_tight_identity_family(seed, p, nx, mb):
     """Hhat = I: Hc = I and kappa* = 1 whatever the solver.  kappa - 1 = N mu_t: 1.2e-4 in the default mode at the bench shape,
@@ -157,7 +209,7 @@ def test_default_path_untouched_by_the_mode():
     assert np.array_equal(a['Hc'], c['Hc']) and np.array_equal(a['kappa'], c['kappa']) and np.array_equal(a['iters'], c['iters'])
     assert (t['kappa'] <= a['kappa']).all() and (t['iters'] > a['iters']).all()
     assert ((a['kappa'] - t['kappa']) / a['kappa'] <= (2 * p * (nx + mb) + 1) * 2.0 ** -25 * 1.5).all()     # the default's gap bound holds
-    hg = HipConvexifier(p, nx, mb, ng=2)
+    hg = HipConvexifier(p, nx, mb, ng=2, nc=2)        # (room for C rows: Step 2 handles are outside the mode; rows of G alone are inside since round 5)
     try:
         with pytest.raises(RuntimeError):
             hg.set_tight(True)

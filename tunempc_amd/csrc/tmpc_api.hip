@@ -209,7 +209,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
   w.sscr = schur_in_lds(dm) ? nullptr : c.take<double>(BP * 10 * nxx);
-  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = w.ddscr = nullptr; w.plist = nullptr;
+  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = w.phidef = w.Zdd = w.TUl = w.ddscr = nullptr; w.plist = w.pnext = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.prs = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
@@ -257,10 +257,12 @@ static size_t carve_dd(WS& w, const Dims& dm, char* base) {
   w.Dl = c.take<double>(BP * bs); w.Ol = c.take<double>(BP * bs); w.Fl = c.take<double>(BP * bs);
   w.Linvl = c.take<double>(BP * dm.nt * TB * TB);
   w.KFl = c.take<double>(BP * 12 * nxx); w.adjVl = c.take<double>(BP * NADJ * nxx); w.adjEl = c.take<double>(BP * NADJ * nxx);
-  w.W3l = c.take<double>(BP * dm.dp * 3); w.Zl = c.take<double>(BP * dm.dp);
+  w.W3l = c.take<double>(BP * dm.dp * 3); w.Zl = c.take<double>(BP * dm.dp); w.TUl = c.take<double>(BP * dm.dp * 2);
   w.Pprev = c.take<double>(BP * nxx); w.Pdef = c.take<double>(BP * nxx);
+  w.phidef = c.take<double>(BP * (size_t)dm.nr);
+  w.Zdd = dm.nr > 0 ? c.take<double>(BP * 4 * (size_t)dm.n * dm.n) : nullptr;
   w.ddscr = (dm.n > NMAX) ? c.take<double>(BP * DD_SCR_MATS * 2 * (size_t)dm.n * dm.n) : nullptr;
-  w.plist = c.take<int>((size_t)dm.B);
+  w.plist = c.take<int>((size_t)dm.B); w.pnext = c.take<int>((size_t)dm.B);
   return (c.off + 255) & ~(size_t)255;
 }
 
@@ -490,6 +492,7 @@ static int set_lds_attrs(int device) {
   HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_t3_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dd_aug_fill, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_update, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dd_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -817,7 +820,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
         hipLaunchKernelGGL((k_schur<1, true>), dim3(nfac * dm.p), dim3(SCH_NT), schur_lds<1>(dm), st, wf, dm);
       }
     }
-    if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
+    if (eq && nfac > 0 && ddm) hipLaunchKernelGGL(k_dd_aug_fill, dim3(nfac * dm.p), dim3(256), (size_t)dd_aug_lds_doubles(dm.nr, dm.n, dm.nx) * sizeof(double), st, wf, dm, 0);
+    else if (eq && nfac > 0) hipLaunchKernelGGL(k_aug_fill, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
     if (t3 && nfac > 0 && big) hipLaunchKernelGGL(k_t3_schur<true>, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     else if (t3 && nfac > 0) hipLaunchKernelGGL(k_t3_schur<false>, dim3(nfac * dm.p), dim3(256), t3_schur_lds, st, wf, dm);
     if (t3 && eq && nfac > 0) hipLaunchKernelGGL(k_t3_cross, dim3(nfac * dm.p), dim3(64), 0, st, wf, dm);
@@ -920,7 +924,9 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   { const int rc_ = ipm_loop(o, false, cap); if (rc_ != TMPC_OK) return rc_; }
   // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
-  if (h->tight && !eq && !t3 && wall.Dl) {
+  // (round 5: also Step 1 with rows of G -- cost-free multipliers, no norm terms: they ride in the augmented blocks of tmpc_phi.h, whose rows stay fp64 numbers in the
+  // double-double planes, and join the polish as variables: k_dd_polish_pre, k_polish_phi)
+  if (h->tight && !t3 && wall.Dl && (!eq || (!dm.constr && !big))) {
     // (round 5: chord steps also in this phase and in the polish -- a double-double factorisation costs ten fp64 ones, a step on an old one a tenth of it)
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     // where a factorisation costs ten fp64 ones and a step on the old one a twentieth of it, chord steps pay from a much shorter safe step on: threshold 3 instead of 10
@@ -938,8 +944,14 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     const int npol = cnt[2];
     // three index buffers: the problems of this step, those of the next one (written by k_polish_ctrl_b), and the ones of this step that get a new
     // factorisation (the first step: all; later only the problems whose chord step stopped contracting)
-    int* list = wall.plist; int* next = alist; int* fac = flist; int count = npol, nfp = npol;
-    if (npol > 0) HIPCHK(hipMemcpyAsync(fac, list, (size_t)npol * sizeof(int), hipMemcpyDeviceToDevice, st));
+    // (plist itself is read again by the final sweep: until round 5 it served as one of the two ping-pong buffers, and a member that needed a third polish step was
+    // written over its head -- the member there missed the final sweep and exported mu S(y)^-1 instead of the dual iterate of its last Newton step: dual residuals
+    // 1e-3 instead of 1e-15, found with the certificate of the models with multipliers)
+    int* list = alist; int* next = wall.pnext; int* fac = flist; int count = npol, nfp = npol;
+    if (npol > 0) {
+      HIPCHK(hipMemcpyAsync(list, wall.plist, (size_t)npol * sizeof(int), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(fac, wall.plist, (size_t)npol * sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
     for (int step = 0; step < POLISH_MAX && count > 0; ++step) {
       WS wp = wall; wp.alist = list;
       hipLaunchKernelGGL(k_dd_polish_pre, dim3(count * dm.p), dim3(256), dd_stage_lds(dm, DD_POL_SLOTS), st, wp, dm, 0);
@@ -947,11 +959,19 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       if (nfp > 0) {
         WS wq = wall; wq.alist = fac;
         dd_schur_launch(wq, dm, nfp * dm.p, st);
+        if (eq) {        // rows of the multipliers: vectors, T_loc,loc and border entries from the fp64 roundings of X_r = mu S_r^-1, S_r^-1 (the Hessian only sets the rate)
+          const bool bigr = dm.nr > NRS;
+          if (bigr) hipLaunchKernelGGL((k_phi_pre<false, true>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(false, true) * sizeof(double), st, wq, dm, 1);
+          else hipLaunchKernelGGL((k_phi_pre<false, false>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(false, false) * sizeof(double), st, wq, dm, 1);
+          hipLaunchKernelGGL(k_dd_aug_fill, dim3(nfp * dm.p), dim3(256), (size_t)dd_aug_lds_doubles(dm.nr, dm.n, dm.nx) * sizeof(double), st, wq, dm, 1);
+        }
         dd_factor(wq, dm, h->sched, h->d_sched, fac, nfp, st);
       }
       hipLaunchKernelGGL(k_dd_gather, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
+      if (eq) hipLaunchKernelGGL(k_aug_gather, dim3(count * dm.p), dim3(64), 0, st, wp, dm, 2);
       { const int rc_ = dd_solve(wp, dm, h->sched, h->d_sched, list, count, st, 2, nb); if (rc_ != TMPC_OK) return rc_; }
-      hipLaunchKernelGGL(k_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list, 2);
+      hipLaunchKernelGGL(k_dd_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list);
+      if (eq) hipLaunchKernelGGL(k_polish_phi, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
       if (dm.n > NMAX) hipLaunchKernelGGL(kb_polish_step, dim3(count * dm.p), dim3(256), 0, st, wp, dm);
       else hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
       HIPCHK(hipMemsetAsync(w.active + 3, 0, sizeof(int), st));
@@ -1167,7 +1187,8 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
   if (!h) return TMPC_E_ARG;
   if (!enable) { h->tight = 0; return TMPC_OK; }
-  if (h->dm.nr > 0 || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: plain Step 1 handles only (no G / C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > h->dm.ng || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Step 1 handles only (plain, or with rows of G; no room for C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > 0 && h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: with rows of G the mode covers nx + mb <= %d", NMAX); return TMPC_E_UNSUPPORTED; }
   if ((size_t)dd_solve_lds_doubles(h->dm.dp) * sizeof(double) > 160 * 1024) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Schur blocks of %d do not fit the LDS image of the double-double substitution kernels (nx <= 51)", h->dm.dp);
     return TMPC_E_UNSUPPORTED;

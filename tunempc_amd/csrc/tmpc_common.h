@@ -174,9 +174,13 @@ struct WS {
   double* ddscr;   // [B,p,DD_SCR_MATS,2,n,n] 32 < n <= 64: the dd stage matrices that the tuned form keeps in LDS (tmpc_dd.h: sdd_slot); else null
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
   double* Pdef;    // [B,p,nx,nx] result of the default solve (restored when the tight phase of a member fails)
+  double* phidef;  // [B,p,nr] multipliers of the default solve (tight mode with rows of G)
+  double* TUl;     // [B,p,dp,2] low words of T^-1 U (the border system of the polish is solved in double-double: k_dd_solve_border)
+  double* Zdd;     // [B,p,2,2,n,n] S_r^-1 of the polish in double-double (hi plane, lo plane per cone block): the rows of the multipliers are formed from it (k_dd_aug_fill)
   double* sscr;    // [B,p,10,nx,nx] factor records of k_schur when they do not fit the LDS (nx > 43); null otherwise
   double* bscr;    // [B,p,5,n,n] scratch of the generic per-stage kernels (tmpc_big.h: 32 < n <= 64); null otherwise
   int* plist;      // [B] problems handed to the polish (count in active[2])
+  int* pnext;      // [B] second index buffer of the polish steps (plist itself must survive until the final sweep)
 };
 
 // (problem, stage) of this workgroup for kernels with one workgroup per stage: blockIdx.x = (index in the active list) * p + k

@@ -675,6 +675,99 @@ __global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
   }
 }
 
+// ------------------------------------------------------------------ rows of the stage-local multipliers in dd (k_phi_pre + k_aug_fill of tmpc_phi.h)
+// Tight mode with rows of G (round 5).  The augmented blocks are factored by a Cholesky without any safeguard, and the pivot of a multiplier row is what is left of
+// T_ii ~ 1/mu after b_i' D^-1 b_i has been taken off: z_i / phi_i ~ mu for an active row -- a difference 1e-21 of the terms.  With the rows formed in fp64 (relative error
+// 1e-16) its sign is noise: measured, 91 non-positive pivots at the first polish step of a member whose oracle run (a pivoted LU of the border system) is uneventful.  Here
+// every entry of the rows is a dd function of the same (X_r, S_r^-1) the dd blocks are made of: w = X g, u = S^-1 g, V w, V u,
+//   a_i = -svec(sum_r sym(w u')[:nx,:nx]) (P_k),  b_i = svec(sum_r sym(V w (V u)')) (P_{k+1}),  T_ij = sum_r ((g_i'X g_j)(g_j'S^-1 g_i) + (i <-> j)) / 2 + delta_ij z_i / phi_i.
+// polish = 0: the loop (X_r, S_r^-1, z, phi the fp64 iterates); 1: the polish (S_r^-1 in dd from k_dd_polish_pre, X_r = mu S_r^-1, z = mu / phi).
+// The border entries c_tau, c_alpha and the vectors k_phi_dir needs stay with k_phi_pre (fp64, like the border columns of tau and alpha).  One workgroup per stage, n <= 32.
+__host__ __device__ constexpr int dd_aug_lds_doubles(int nr, int n, int nx) { return 4 * nr * (2 * n + 2 * nx) + 16; }       // 125 KB at 31 rows, n = 32
+__global__ void __launch_bounds__(256) k_dd_aug_fill(WS w, Dims dm, int polish) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int sid = stage_id(w, dm), tid = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int phase = w.iprob[(size_t)b * IS + I_PHASE];
+  if (polish ? phase != PH_POLISH : (phase == PH_DONE || phase == PH_POLISH)) return;
+  const int ng = stage_rows(w, dm, sid);
+  if (ng < 1) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const double mu = pr[P_MUT];
+  const int n = dm.n, nx = dm.nx, nn = n * n, d = dm.d, dp = dm.dp, p = dm.p, vl = 2 * n + 2 * nx;
+  double* vh = sm; double* vlo = sm + 2 * ng * vl;                    // [2][ng][w | u | V w | V u], hi and lo
+  const double* Gg = w.G + (size_t)sid * dm.nr * n;
+  const double* Vg = w.V + (size_t)sid * nx * n;
+  auto mat = [&](int r, int which, int a, int c) -> ddv {             // which 0: X_r, 1: S_r^-1
+    if (polish) {
+      const double* zd = w.Zdd + ((size_t)sid * 2 + r) * 2 * nn;
+      const ddv z = ddv{zd[a * n + c], zd[nn + a * n + c]};
+      return which ? z : dd_muld(z, mu);
+    }
+    return ddv{(which ? (r ? w.S2i : w.S1i) : (r ? w.X2 : w.X1))[(size_t)sid * nn + a * n + c], 0.0};
+  };
+  for (int e = tid; e < 4 * ng * n; e += 256) {                       // w = X g, u = S^-1 g
+    const int a = e % n, i = (e / n) % ng, which = (e / (n * ng)) & 1, r = e / (2 * n * ng);
+    double sh = 0.0, sl = 0.0;
+    for (int c = 0; c < n; ++c) { const ddv m = mat(r, which, a, c); dd_fma_acc(sh, sl, m.h, m.l, Gg[i * n + c], 0.0); }
+    const ddv v = dd_qts(sh, sl);
+    vh[(r * ng + i) * vl + which * n + a] = v.h; vlo[(r * ng + i) * vl + which * n + a] = v.l;
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * ng * nx; e += 256) {                      // V w, V u
+    const int a = e % nx, i = (e / nx) % ng, which = (e / (nx * ng)) & 1, r = e / (2 * nx * ng);
+    const int o = (r * ng + i) * vl + which * n;
+    double sh = 0.0, sl = 0.0;
+    for (int c = 0; c < n; ++c) dd_fma_acc(sh, sl, vh[o + c], vlo[o + c], Vg[a * n + c], 0.0);
+    const ddv v = dd_qts(sh, sl);
+    vh[(r * ng + i) * vl + 2 * n + which * nx + a] = v.h; vlo[(r * ng + i) * vl + 2 * n + which * nx + a] = v.l;
+  }
+  __syncthreads();
+  const int kn = (k + 1 == p) ? 0 : k + 1;
+  const size_t bs = (size_t)dp * dp;
+  double* Dh = w.D + ((size_t)b * p + kn) * bs; double* Dl = w.Dl + ((size_t)b * p + kn) * bs;
+  double* ddn = w.Ddiag + ((size_t)b * p + kn) * dp;
+  const bool corner = (w.cr_orient[k] != 0);
+  double* Ch = w.O + (size_t)sid * bs; double* Cl = w.Ol + (size_t)sid * bs;
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
+  auto gram = [&](int r, int which, int i, int j) {                   // g_i' (X_r | S_r^-1) g_j
+    const int o = (r * ng + j) * vl + which * n;
+    double sh = 0.0, sl = 0.0;
+    for (int c = 0; c < n; ++c) dd_fma_acc(sh, sl, vh[o + c], vlo[o + c], Gg[i * n + c], 0.0);
+    return dd_qts(sh, sl);
+  };
+  for (int e = tid; e < ng * ng; e += 256) {                          // T_loc,loc (lower triangle) and its pivot reference
+    const int i = e / ng, j = e - i * ng;
+    if (j > i) continue;
+    ddv t = ddv{0.0, 0.0};
+    for (int r = 0; r < 2; ++r)
+      t = dd_add(t, dd_muld(dd_add(dd_mul(gram(r, 0, i, j), gram(r, 1, j, i)), dd_mul(gram(r, 0, j, i), gram(r, 1, i, j))), 0.5));
+    if (i == j) t = dd_add(t, polish ? dd_div(dd_from(mu), dd_mul(dd_from(phi[i]), dd_from(phi[i]))) : dd_div(dd_from(z[i]), dd_from(phi[i])));
+    Dh[(size_t)(d + i) * dp + d + j] = t.h; Dl[(size_t)(d + i) * dp + d + j] = t.l;
+    if (i == j) ddn[d + i] = t.h;
+  }
+  for (int e = tid; e < ng * d; e += 256) {                           // the rows a_i (coupling block) and b_i (D_{k+1})
+    const int i = e / d, idx = e - i * d;
+    int a = 0, rem = idx;
+    while (rem >= nx - a) { rem -= nx - a; ++a; }
+    const int c = a + rem;
+    ddv av = ddv{0.0, 0.0}, bv = ddv{0.0, 0.0};
+    for (int r = 0; r < 2; ++r) {
+      const int o = (r * ng + i) * vl;
+      auto V_ = [&](int off, int q) { return ddv{vh[o + off + q], vlo[o + off + q]}; };
+      av = dd_add(av, dd_muld(dd_add(dd_mul(V_(0, a), V_(n, c)), dd_mul(V_(0, c), V_(n, a))), 0.5));
+      bv = dd_add(bv, dd_muld(dd_add(dd_mul(V_(2 * n, a), V_(2 * n + nx, c)), dd_mul(V_(2 * n, c), V_(2 * n + nx, a))), 0.5));
+    }
+    if (a != c) { av = dd_muld(av, 2.0); bv = dd_muld(bv, 2.0); }
+    av = dd_neg(av);
+    const size_t ro = (size_t)(d + i) * dp + idx;
+    if (p == 1) { const ddv s_ = dd_add(av, bv); Dh[ro] = s_.h; Dl[ro] = s_.l; continue; }       // both couplings land in the one P block
+    Dh[ro] = bv.h; Dl[ro] = bv.l;
+    const size_t co = corner ? (size_t)idx * dp + d + i : ro;                                 // stored [block k][block k+1] or [block k+1][block k]
+    Ch[co] = av.h; Cl[co] = av.l;
+  }
+}
+
 // ------------------------------------------------------------------ polish: every stage quantity in dd from the fp64 y = (tau, alpha, P)
 // Writes, per stage: the dd Kronecker factors (X_r := mu S_r^-1); the adjoint pieces V G V' and G_EE in dd of G = X1 - X2 (gradient),
 // Psi = X2 S2^-1 and Phi(Hb) (border columns); the partial sums of the border / gradient scalars; fp64 roundings of S_r, X_r (outputs,
@@ -701,10 +794,14 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
   sdd_mm(t1, V, true, t0, false, n, nx, nx);                 // V' P_{k+1}
   sdd_mm(M, t1, false, V, false, n, nx, n);                  // (V' P+) V
   const double* Pk = w.P + (size_t)sid * nxx;
+  // rows of G_k (round 5; Step 1 with the cost-free multipliers phi of convexifier.py:249-255): M += sum_i phi_i g_i g_i', products exact, sums in dd
+  const int ngs = dm.nr > 0 ? stage_rows(w, dm, sid) : 0;
+  const double* Gg = w.G + (size_t)sid * dm.nr * n; const double* ph = w.phi + (size_t)sid * dm.nr;
   for (int e = tid; e < nn; e += 256) {
     const int i = e / n, j = e - i * n;
     ddv v = dd_add(M.get(i, j), dd_muld(Hd.get(i, j), alpha));
     if (i < nx && j < nx) v = dd_sub(v, dd_from(Pk[i * nx + j]));
+    for (int r_ = 0; r_ < ngs; ++r_) v = dd_add(v, dd_muld(dd_tp(Gg[r_ * n + i], Gg[r_ * n + j]), ph[r_]));
     M.set(i, j, v);
   }
   dsync();
@@ -717,6 +814,7 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
   dsync();
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; w.T1[(size_t)sid * nn + e] = dd_val(M.get(i, j)); }
   int nbad = (alpha - ALPHA_MIN > 0.0) ? 0 : 1;
+  for (int r_ = 0; r_ < ngs; ++r_) nbad += (ph[r_] > 0.0) ? 0 : 1;
   // S1 = M - I, S2 = tau I - M, their inverses
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; const ddv m = M.get(i, j); t0.set(i, j, (i == j) ? dd_sub(m, dd_from(1.0)) : m); w.S1[(size_t)sid * nn + e] = dd_val(t0.get(i, j)); }
   dsync();
@@ -734,6 +832,7 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       X.set(i, j, x);
       (r ? w.X2 : w.X1)[(size_t)sid * nn + e] = final_sweep ? (r ? w.dX2 : w.dX1)[(size_t)sid * nn + e] : dd_val(x);      // (final sweep: the dual iterate of the last step, see k_polish_step)
       (r ? w.S2i : w.S1i)[(size_t)sid * nn + e] = dd_val(Z.get(i, j));
+      if (w.Zdd) { double* zd = w.Zdd + ((size_t)sid * 2 + r) * 2 * nn; zd[e] = Z.h(i, j); zd[nn + e] = Z.l(i, j); }
       t2.set(i, j, r ? dd_sub(t2.get(i, j), x) : x);
     }
     dsync();
@@ -754,6 +853,26 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       sdd_store(w.adjE + ((size_t)sid * NADJ + ADJ_PSI) * nxx, w.adjEl + ((size_t)sid * NADJ + ADJ_PSI) * nxx, t0, nx, nx, nx);
       dsync();
     }
+  }
+  if (ngs > 0) {
+    // minus the gradient of the dual barrier in phi_i: g_i' (X1 - X2) g_i + mu / phi_i -- the quadratic form in dd (its terms are O(1), the sum ~ mu / phi_i), THEN rounded:
+    // the tail of the right-hand side of block k+1 (k_aug_gather).  z_i := mu / phi_i is not an iterate any more (the diagonal z / phi of T_loc,loc: k_phi_pre).
+    for (int e = tid; e < ngs * n; e += 256) {
+      const int i = e / n, a = e - i * n;
+      double sh = 0.0, sl = 0.0;
+      for (int c = 0; c < n; ++c) { const ddv y = t2.get(a, c); dd_fma_acc(sh, sl, y.h, y.l, Gg[i * n + c], 0.0); }
+      t0.set(i, a, dd_muld(dd_qts(sh, sl), Gg[i * n + a]));
+    }
+    dsync();
+    if (tid < ngs) {
+      ddv sq = ddv{0.0, 0.0};
+      for (int a = 0; a < n; ++a) sq = dd_add(sq, t0.get(tid, a));
+      const ddv zz = dd_div(dd_from(mu), dd_from(ph[tid]));
+      PSM_RPHI(psm_at(w.psm, dm, sid), dm.nz)[tid] = dd_val(dd_add(sq, zz));
+      // (final sweep: the multiplier of the dual iterate that goes with the last Newton step, k_polish_phi)
+      w.zph[(size_t)sid * dm.nr + tid] = final_sweep ? w.dzph[(size_t)sid * dm.nr + tid] : dd_val(zz);
+    }
+    dsync();
   }
   for (int e = tid; e < nn; e += 256) { const int i = e / n, j = e - i * n; hby += dd_val(dd_mul(Hd.get(i, j), t2.get(i, j))); hbphi += dd_val(dd_mul(Hd.get(i, j), M.get(i, j))); }
   sdd_mm(t0, V, false, t2, false, nx, n, n); sdd_mm(t1, t0, false, V, true, nx, n, nx);       // V G V'
@@ -811,6 +930,7 @@ __global__ void __launch_bounds__(64) k_tight_restart(WS w, Dims dm, Opts o) {
   if (!(mut < pr[P_MUT])) return;                 // nothing tighter asked for
   const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
   for (size_t e = lane; e < np_; e += 64) w.Pdef[(size_t)b * np_ + e] = w.P[(size_t)b * np_ + e];
+  for (size_t e = lane; e < (size_t)dm.p * dm.nr; e += 64) w.phidef[(size_t)b * dm.p * dm.nr + e] = w.phi[(size_t)b * dm.p * dm.nr + e];
   if (lane != 0) return;
   pr[P_TAU_DEF] = pr[P_TAU]; pr[P_ALPHA_DEF] = pr[P_ALPHA];
   pr[P_MUT1] = pr[P_MUT]; pr[P_MUT] = mut; pr[P_PREVSTEPN] = -1.0;
@@ -828,6 +948,7 @@ __global__ void __launch_bounds__(64) k_tight_fallback(WS w, Dims dm) {
   if (ip[I_DD] != 1 || (ip[I_PHASE] == PH_DONE && ip[I_IPMSTATUS] == IPM_OPTIMAL)) return;
   const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
   for (size_t e = lane; e < np_; e += 64) w.P[(size_t)b * np_ + e] = w.Pdef[(size_t)b * np_ + e];
+  for (size_t e = lane; e < (size_t)dm.p * dm.nr; e += 64) w.phi[(size_t)b * dm.p * dm.nr + e] = w.phidef[(size_t)b * dm.p * dm.nr + e];
   if (lane != 0) return;
   pr[P_TAU] = pr[P_TAU_DEF]; pr[P_ALPHA] = pr[P_ALPHA_DEF]; pr[P_MUT] = pr[P_MUT1]; pr[P_MU] = pr[P_MUT1];
   ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_TIGHT_FALLBACK; ip[I_DD] = 2;      // (info[10] = 4: a caller who asked for the tight gap can tell that this member has the default one)
@@ -846,6 +967,7 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_a(WS w, Dims dm) {
     // the last step left the cone (not seen after the centering phase; the CPU restatement would halve the step): back to the iterate before it
     const int nxx = dm.nx * dm.nx;
     if (ip[I_NPOLISH] > 0) for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
+    if (ip[I_NPOLISH] > 0) for (int e = lane; e < p * dm.nr; e += 64) w.phi[(size_t)b * p * dm.nr + e] = w.corrp[(size_t)b * p * dm.nr + e];
     if (lane == 0) {
       if (ip[I_NPOLISH] > 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; }
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
@@ -857,6 +979,96 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_a(WS w, Dims dm) {
   pr[P_S0] = s0; pr[P_X0] = x0; pr[P_RD0] = 0.0; pr[P_CORR0] = 0.0; pr[P_SIGMU] = pr[P_MUT]; pr[P_MU] = pr[P_MUT];
   pr[P_BTT] = trpsi; pr[P_BTA] = -trphi2; pr[P_BAA] = hbphi + x0 / s0;
   // (I_CHORD: set by k_polish_ctrl_b for the next step -- 0 at the first step of the polish, k_ctrl_d)
+}
+
+// polish: the 2 x 2 border system (tau, alpha) and dP = z - T^-1 U db in double-double (k_solve_border of tmpc_factor.h does it in fp64).  The block solutions
+// z, T^-1 U arrive as dd numbers (W3 / W3l, Z / Zl); with rows of multipliers in the blocks the border columns reach 1e12 and U' T^-1 U cancels against B to ten digits
+// and more: in fp64 the step (dtau, dalpha) -- and with it the exported dual iterate X + dX, which takes the step at full weight -- was good to 1e-3 only on some
+// members (measured: dual residuals 1e-3 instead of 1e-12; the iterate itself does not care, Newton's fixed point is the gradient's).  One workgroup per problem.
+// The low words of dtau, dalpha and of the border complement (kept for the chord steps) live in the part[] slots of stage 0 that the polish does not use.
+__device__ __forceinline__ ddv wg_reduce_dd(double sh, double sl, double* red) {       // red: 512 doubles
+  const int tid = threadIdx.x;
+  __syncthreads();
+  red[tid] = sh; red[256 + tid] = sl;
+  __syncthreads();
+  ddv s = ddv{0.0, 0.0};
+  if (tid == 0) { for (int i = 0; i < 256; ++i) s = dd_add(s, dd_ts(red[i], red[256 + i])); red[0] = s.h; red[256] = s.l; }
+  __syncthreads();
+  s = ddv{red[0], red[256]};
+  return s;
+}
+__global__ void __launch_bounds__(256) k_dd_solve_border(WS w, Dims dm, const int* alist) {
+  __shared__ double red[512];
+  const int b = alist[blockIdx.x], tid = threadIdx.x;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_POLISH) return;
+  double* pr = w.prob + (size_t)b * PS;
+  const int p = dm.p, dp = dm.dp, nx = dm.nx, d = dm.d;
+  const size_t vl = (size_t)p * dp;
+  const double* W3 = w.W3 + (size_t)b * vl * 3; const double* W3l = w.W3l + (size_t)b * vl * 3;
+  double* Z = w.Z + (size_t)b * vl; double* Zl = w.Zl + (size_t)b * vl;
+  double* TU = w.TU + (size_t)b * vl * 2; double* TUl = w.TUl + (size_t)b * vl * 2;
+  const double* U = w.U + (size_t)b * vl * 2;
+  double* lo = w.part + (size_t)b * p * NPART;            // stage 0: Q_MINX, Q_MINS, Q_DXS = low words of Sb00, Sb01, Sb11; Q_XDS, Q_DXDS = of dtau, dalpha
+  if (!ip[I_CHORD]) {
+    double h00 = 0.0, l00 = 0.0, h01 = 0.0, l01 = 0.0, h11 = 0.0, l11 = 0.0;
+    for (size_t e = tid; e < vl; e += 256) {
+      const ddv t0 = ddv{W3[e * 3 + 1], W3l[e * 3 + 1]}, t1 = ddv{W3[e * 3 + 2], W3l[e * 3 + 2]};
+      TU[e * 2] = t0.h; TUl[e * 2] = t0.l; TU[e * 2 + 1] = t1.h; TUl[e * 2 + 1] = t1.l;
+      Z[e] = W3[e * 3]; Zl[e] = W3l[e * 3];
+      dd_fma_acc(h00, l00, t0.h, t0.l, U[e * 2], 0.0); dd_fma_acc(h01, l01, t1.h, t1.l, U[e * 2], 0.0); dd_fma_acc(h11, l11, t1.h, t1.l, U[e * 2 + 1], 0.0);
+    }
+    const ddv s00 = wg_reduce_dd(h00, l00, red), s01 = wg_reduce_dd(h01, l01, red), s11 = wg_reduce_dd(h11, l11, red);
+    if (tid == 0) {
+      const ddv a = dd_sub(dd_from(pr[P_BTT]), s00), bb = dd_sub(dd_from(pr[P_BTA]), s01), c = dd_sub(dd_from(pr[P_BAA]), s11);
+      pr[P_SB00] = a.h; pr[P_SB01] = bb.h; pr[P_SB11] = c.h; lo[Q_MINX] = a.l; lo[Q_MINS] = bb.l; lo[Q_DXS] = c.l;
+    }
+  }
+  __syncthreads();
+  double uh0 = 0.0, ul0 = 0.0, uh1 = 0.0, ul1 = 0.0;
+  for (size_t e = tid; e < vl; e += 256) { dd_fma_acc(uh0, ul0, Z[e], Zl[e], U[e * 2], 0.0); dd_fma_acc(uh1, ul1, Z[e], Zl[e], U[e * 2 + 1], 0.0); }
+  const ddv u0 = wg_reduce_dd(uh0, ul0, red), u1 = wg_reduce_dd(uh1, ul1, red);
+  double trt2 = 0.0, hbg = 0.0;
+  for (int k = tid; k < p; k += 256) { const double* q = w.part + (size_t)(b * p + k) * NPART; trt2 += q[Q_TRT2]; hbg += q[Q_HBG]; }
+  const ddv st = wg_reduce_dd(trt2, 0.0, red), sh_ = wg_reduce_dd(hbg, 0.0, red);
+  const double t0 = pr[P_SIGMU] / pr[P_S0] - pr[P_X0] * pr[P_RD0] / pr[P_S0] - pr[P_CORR0];
+  const ddv rb0 = dd_sub(dd_sub(st, dd_from(1.0)), u0), rb1 = dd_sub(dd_add(sh_, dd_from(t0)), u1);
+  const ddv a = ddv{pr[P_SB00], lo[Q_MINX]}, bb = ddv{pr[P_SB01], lo[Q_MINS]}, c = ddv{pr[P_SB11], lo[Q_DXS]};
+  const ddv det = dd_sub(dd_mul(a, c), dd_mul(bb, bb));
+  const ddv dtau = dd_div(dd_sub(dd_mul(c, rb0), dd_mul(bb, rb1)), det), dalpha = dd_div(dd_sub(dd_mul(a, rb1), dd_mul(bb, rb0)), det);
+  __syncthreads();
+  if (tid == 0) { pr[P_DTAU] = dtau.h; pr[P_DALPHA] = dalpha.h; lo[Q_XDS] = dtau.l; lo[Q_DXDS] = dalpha.l; }
+  double* dPg = w.dP + (size_t)b * p * nx * nx;
+  for (int e = tid; e < p * d; e += 256) {
+    const int k = e / d, idx = e - k * d;
+    int a2 = 0, rem = idx;
+    while (rem >= nx - a2) { rem -= nx - a2; ++a2; }
+    const int c2 = a2 + rem;
+    const size_t vi = (size_t)k * dp + idx;
+    const double v = dd_val(dd_sub(dd_sub(ddv{Z[vi], Zl[vi]}, dd_mul(ddv{TU[vi * 2], TUl[vi * 2]}, dtau)), dd_mul(ddv{TU[vi * 2 + 1], TUl[vi * 2 + 1]}, dalpha)));
+    dPg[(size_t)k * nx * nx + a2 * nx + c2] = v;
+    dPg[(size_t)k * nx * nx + c2 * nx + a2] = v;
+  }
+}
+
+// polish with rows of G, after k_solve_border: dphi = the tail of the block solution (as k_phi_dir does in the loop), and the multiplier z + dz = mu / phi - mu dphi / phi^2
+// of the dual iterate that goes with a Newton step (exported by tmpc_get_dual_con_host; a chord step keeps the one of the last Newton step, see k_polish_ctrl_b)
+__global__ void __launch_bounds__(64) k_polish_phi(WS w, Dims dm) {
+  const int sid = stage_id(w, dm), lane = threadIdx.x;
+  const int b = sid / dm.p, k = sid - b * dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_POLISH) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const int kn = (k + 1 == dm.p) ? 0 : k + 1;
+  if (lane < stage_rows(w, dm, sid)) {
+    const size_t vi = ((size_t)b * dm.p + kn) * dm.dp + dm.d + lane, gi = (size_t)sid * dm.nr + lane;
+    const double* lo = w.part + (size_t)b * dm.p * NPART;      // low words of dtau, dalpha (k_dd_solve_border)
+    const ddv dtau = ddv{pr[P_DTAU], lo[Q_XDS]}, dalpha = ddv{pr[P_DALPHA], lo[Q_DXDS]};
+    const double v = dd_val(dd_sub(dd_sub(ddv{w.Z[vi], w.Zl[vi]}, dd_mul(ddv{w.TU[vi * 2], w.TUl[vi * 2]}, dtau)), dd_mul(ddv{w.TU[vi * 2 + 1], w.TUl[vi * 2 + 1]}, dalpha)));
+    w.dphi[gi] = v;
+    const double phi = w.phi[gi], mu = pr[P_MUT];
+    if (!ip[I_CHORD]) w.dzph[gi] = mu / phi - mu * v / (phi * phi);
+  }
 }
 
 // polish, after k_solve_border: dM of the step and the norms of the step test (M itself: T1, written by k_dd_polish_pre)
@@ -873,6 +1085,17 @@ __global__ void __launch_bounds__(256) k_polish_step(WS w, Dims dm) {
   g2s<256>(sHb, w.Hb + (size_t)sid * nn, n, n, n, lane);
   wsync();
   build_M<256>(sM, sV, t0, t1, sHb, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, pr[P_DALPHA], n, nx, lane);
+  if (dm.nr > 0) {                       // + sum_i dphi_i g_i g_i'
+    const int ngs = stage_rows(w, dm, sid);
+    const double* Gg = w.G + (size_t)sid * dm.nr * n; const double* dph = w.dphi + (size_t)sid * dm.nr;
+    for (int e = lane; e < nn; e += 256) {
+      int i, j; ediv(e, n, i, j);
+      double v = sM[i * LD + j];
+      for (int r_ = 0; r_ < ngs; ++r_) v = fma(dph[r_] * Gg[r_ * n + i], Gg[r_ * n + j], v);
+      sM[i * LD + j] = v;
+    }
+    wsync();
+  }
   const double ra = pr[P_DALPHA] / pr[P_ALPHA];
   double dh2 = 0.0, m2 = 0.0;
   for (int e = lane; e < nn; e += 256) {
@@ -917,6 +1140,7 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, con
   const double stepn = sqrt(dh2 / m2);
   const bool fin = (fabs(pr[P_DTAU]) < 1e300) && (fabs(pr[P_DALPHA]) < 1e300) && (stepn == stepn) && (stepn < 1e300);
   if (fin) for (int e = lane; e < p * nxx; e += 64) { const size_t g = (size_t)b * p * nxx + e; w.Pprev[g] = w.P[g]; w.P[g] += w.dP[g]; }
+  if (fin) for (int e = lane; e < p * dm.nr; e += 64) { const size_t g = (size_t)b * p * dm.nr + e; w.corrp[g] = w.phi[g]; w.phi[g] += w.dphi[g]; }      // (corrp: free in the polish -- phi before the step)
   if (lane != 0) return;
   if (!fin) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; return; }
   pr[P_TAU_PREV] = pr[P_TAU]; pr[P_ALPHA_PREV] = pr[P_ALPHA];
@@ -955,6 +1179,7 @@ __global__ void __launch_bounds__(64) k_polish_final(WS w, Dims dm) {
   const double nbad = psum(w.part, b, p, Q_CHOLBAD, lane);
   if (!(nbad > 0.0)) { if (lane == 0) { pr[P_X0] = pr[P_DX0]; pr[P_S0] = pr[P_ALPHA] - ALPHA_MIN; pr[P_MU] = pr[P_MUT]; } return; }
   for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
+  for (int e = lane; e < p * dm.nr; e += 64) w.phi[(size_t)b * p * dm.nr + e] = w.corrp[(size_t)b * p * dm.nr + e];
   if (lane == 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; ip[I_IPMSTATUS] = IPM_INACCURATE; }
 }
 

@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(64) k_phi_steps(WS w, Dims dm, int pass) {
   const int b = sid / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
   const int phase = ip[I_PHASE];
-  if (phase == PH_DONE || (pass == 1 && phase != PH_MAIN)) return;
+  if (phase == PH_DONE || phase == PH_POLISH || (pass == 1 && phase != PH_MAIN)) return;
   const int ng = stage_rows(w, dm, sid);
   const double* phi = w.phi + (size_t)sid * dm.nr; const double* z = w.zph + (size_t)sid * dm.nr;
   const double* dph = w.dphi + (size_t)sid * dm.nr; const double* dzp = w.dzph + (size_t)sid * dm.nr;
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(64) k_phi_update(WS w, Dims dm) {
   if (sid >= dm.B * dm.p) return;
   const int b = sid / dm.p;
   const int* ip = w.iprob + (size_t)b * IS;
-  if (ip[I_PHASE] == PH_DONE) return;
+  if (ip[I_PHASE] == PH_DONE || ip[I_PHASE] == PH_POLISH) return;      // (PH_POLISH: a member of the tight mode that waits for the polish while others still iterate -- this grid covers every problem)
   const double* pr = w.prob + (size_t)b * PS;
   const double ap = pr[P_AP], ad = pr[P_AD];
   if (ap == 0.0 && ad == 0.0) return;      // discarded direction
