@@ -374,7 +374,7 @@ def _inv_dd(S):
     return out
 
 
-def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, mask=None, phi=None):
+def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, mask=None, phi=None, arrows=None, wr=0.0, cw=None):
     """Tight mode, last phase: Newton's method on the DUAL barrier problem  min tau - mu (sum logdet S1_k + logdet S2_k + log(alpha - 1e-8))
     in y = (tau, alpha, P) alone, with every stage quantity in double-double: S_r(y) is formed in dd from the fp64 y (no cancellation in
     M - I), S_r^-1 in dd, X_r := mu S_r^-1 is not an iterate any more.  The primal-dual iteration stores X and S^-1 as fp64 matrices whose
@@ -383,7 +383,9 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
     mu = 2e-12, measured).  The minimiser of the barrier problem IS the central-path point at mu; two or three steps from the end of the
     primal-dual centering phase reproduce it to ~1e-12 (two runs on inputs 1e-14 apart).  Returns (tau, alpha, P, X1, X2, ok, steps, stepn[, phi]).
     GG [p, ng, n, n], mask [p, ng], phi [p, ng] (round 5): the cost-free multipliers of the equality-constraint rows (convexifier.py:249-255) join y,
-    M_k gains sum_i phi_ki g_i g_i' (in dd), the barrier -mu sum log phi_ki; their border columns are formed in dd and rounded like those of tau and alpha."""
+    M_k gains sum_i phi_ki g_i g_i' (in dd), the barrier -mu sum log phi_ki; their border columns are formed in dd and rounded like those of tau and alpha.
+    arrows (list of dict(k, idx, t), wr, cw): the norm terms of Step 2 (convexifier.py:276-283) -- epigraph variables t_e join y with cost 1 and the barrier
+    -mu logdet arrow(t_e, cw o phi[idx], wr); the arrow matrix is formed and inverted in dd (t^2 - |w v|^2 cancels to ~mu on an active norm).  Returns (..., phi, arrows)."""
     p, nx, _ = A.shape
     n = Hb.shape[1]
     d = nx * (nx + 1) // 2
@@ -398,9 +400,24 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
     tr = lambda G: np.trace(G.to_float(), axis1=1, axis2=2).sum()
 
     ng = 0 if GG is None else GG.shape[1]
+    arrows = [dict(a) for a in (arrows or [])]
     if ng:
         GGd = dn.DD(GG)
         phi = np.where(mask, phi, 1.0)
+
+    def arrow_inv(t_, phi_):
+        out = []
+        for a in arrows:
+            m = len(a['idx'])
+            S = dn.zeros((m + 1, m + 1))
+            v = dn.DD(cw[a['idx']] * wr) * phi_[a['k'], a['idx']]              # (products of two fp64 numbers: exact in dd)
+            for i in range(m + 1):
+                S[i, i] = dn.DD(np.float64(t_[len(out)]))
+            S[0, 1:] = v; S[1:, 0] = v
+            if not t_[len(out)] > 0.0:
+                raise np.linalg.LinAlgError('t')
+            out.append(_inv_dd(S[None])[0])
+        return out
 
     def cones(tau_, alpha_, P_, phi_=None):
         M = Hd * alpha_ + dn.matmul(dn.matmul(Vd.T, dn.DD(np.roll(P_, -1, axis=0))), Vd)
@@ -417,9 +434,15 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
     X1 = X2 = None
     ok = False
     steps = 0
-    ret = lambda *a: a + ((phi,) if ng else ())
+    tt = np.array([a['t'] for a in arrows], dtype=np.float64)
+
+    def ret(*a):
+        for e_, ar in enumerate(arrows):
+            ar['t'] = float(tt[e_])
+        return a + ((phi,) if ng else ()) + ((arrows,) if arrows else ())
     try:
         M, Z1, Z2 = cones(tau, alpha, P, phi)
+        Za = arrow_inv(tt, phi)
     except np.linalg.LinAlgError:
         return ret(tau, alpha, P, None, None, False, 0, stepn)
     for steps in range(1, POLISH_MAX + 1):
@@ -468,7 +491,28 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
                 Bfull[1, sl] = Bfull[sl, 1] = np.einsum('iab,ab->i', GG[k], PhiHf[k]) * mask[k]
             Ug = Ug * mask.reshape(1, 1, p * ng)
             U = np.concatenate([U, Ug], axis=2); Bb = Bfull
-            rb = np.concatenate([rb, (-g_phi * mask).ravel()])
+            if arrows:
+                na = len(arrows)
+                U = np.concatenate([U, np.zeros((p, d, na))], axis=2)             # the epigraph variables do not reach P
+                Bf2 = np.zeros((2 + p * ng + na, 2 + p * ng + na)); Bf2[:2 + p * ng, :2 + p * ng] = Bb
+                g_t = np.zeros(na)
+                for e_, a in enumerate(arrows):
+                    te = 2 + p * ng + e_
+                    cols = 2 + a['k'] * ng + a['idx']
+                    m = len(a['idx'])
+                    Xe = (Za[e_] * mu); Xf = Xe.to_float(); Sif = Za[e_].to_float()
+                    Pe = symmetrize((dn.matmul(Xe, Za[e_])).to_float()[None])[0]
+                    Bf2[te, te] = np.trace(Pe)
+                    for q in range(m):
+                        wq = wr * cw[a['idx'][q]]
+                        Eq = np.zeros((m + 1, m + 1)); Eq[0, q + 1] = wq; Eq[q + 1, 0] = wq
+                        Bf2[cols[q], te] = Bf2[te, cols[q]] = 2.0 * wq * Pe[0, q + 1]
+                        Fq = symmetrize((Xf @ Eq @ Sif)[None])[0]
+                        Bf2[cols, cols[q]] += 2.0 * wr * cw[a['idx']] * Fq[0, 1:]
+                    g_phi[a['k'], a['idx']] -= 2.0 * wr * cw[a['idx']] * Xf[0, 1:]
+                    g_t[e_] = 1.0 - (Xe[np.arange(m + 1), np.arange(m + 1)]).to_float().sum()
+                Bb = Bf2
+            rb = np.concatenate([rb, (-g_phi * mask).ravel()] + ([-g_t] if arrows else []))
         TU = chol.solve(U)
         Sb = Bb - (np.einsum('kdi,kdj->ij', U, TU) if U.shape[2] <= 2 else U.reshape(-1, U.shape[2]).T @ TU.reshape(-1, TU.shape[2]))
         z = chol.solve(rhsP[:, :, None])[:, :, 0]
@@ -479,13 +523,16 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
         dM = db[1] * Hb + calH(A, B, dP)
         dphi = None
         if ng:
-            dphi = db[2:].reshape(p, ng) * mask
+            dphi = db[2:2 + p * ng].reshape(p, ng) * mask
             dM = dM + np.einsum('ki,kiab->kab', dphi, GG)
+        dtt = db[2 + p * ng:] if arrows else None
         stepn = np.sqrt(np.sum((dM - (db[1] / alpha) * Mf) ** 2) / np.sum(Mf ** 2))
         th = 1.0
         while True:                                               # damped only if the full step leaves the cone (not seen after the centering phase)
             try:
                 M, Z1, Z2 = cones(tau + th * db[0], alpha + th * db[1], P + th * dP, phi + th * dphi if ng else None)
+                if arrows:
+                    Za = arrow_inv(tt + th * dtt, phi + th * dphi)
                 break
             except np.linalg.LinAlgError:
                 th *= 0.5
@@ -494,6 +541,8 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
         tau += th * db[0]; alpha += th * db[1]; P = P + th * dP
         if ng:
             phi = phi + th * dphi
+        if arrows:
+            tt = tt + th * dtt
         if verbose:
             print(f"      polish {steps}: |dy|rel={stepn:.3e} step={th:.3f}")
         if th == 1.0 and stepn < center_tol:
@@ -735,7 +784,7 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     N = N + m + 1
     mu_t = None
     tight = bool(o.get('tight', False))       # tight-accuracy mode (plain model, and Step 1 with the cost-free multipliers of G): see DD_SWITCH
-    assert not (tight and (arrows or nT or (constr and not cost_free))), 'tight mode: Step 1 models only (no norm terms, no T_k)'
+    assert not (tight and nT), 'tight mode: Steps 1 and 2 (no T_k)'
     dd_on = False
     ndd = 0
     extrap_terms = None
@@ -1085,7 +1134,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             prev_stepn = stepn if full else None
     npolish = 0
     if status == 'polish':
-        if ng:
+        if ng and arrows:
+            tau, alpha, P, Xp1, Xp2, okp, npolish, stepn, phi, arrows = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose, GG=GG, mask=mask, phi=phi,
+                                                                                   arrows=arrows, wr=wr, cw=cw)
+        elif ng:
             tau, alpha, P, Xp1, Xp2, okp, npolish, stepn, phi = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose, GG=GG, mask=mask, phi=phi)
         else:
             tau, alpha, P, Xp1, Xp2, okp, npolish, stepn = _polish_dd(A, B, Hb, tau, alpha, P, mu_t, o['center_tol'], verbose)
