@@ -164,14 +164,67 @@ def test_tight_with_equality_rows_vs_oracle(seed, nb, p, nx, mb, ng):
     print(f'tight mode with G rows p={p} n={n} ng={ng}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
 
 
-def test_tight_refused_where_the_mode_does_not_reach():
-    """handles with room for C rows (Step 2) or Step 3, and rows of G on the generic kernels (n > 32): TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
+@pytest.mark.parametrize('seed,nb,p,nx,mb,ng,nc', [(300, 3, 4, 3, 2, 1, 2), (301, 3, 5, 4, 2, 0, 2), (302, 2, 3, 5, 3, 2, 3), (303, 2, 6, 3, 1, 1, 1), (304, 2, 2, 6, 2, 2, 2),
+                                                   (306, 2, 6, 10, 4, 2, 3), (307, 1, 4, 16, 6, 1, 4), (308, 1, 3, 24, 8, 2, 5)])
+def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
+    """Tight mode on the Step 2 model (convexifier.py:116-131: multipliers of ragged C_k, norm terms rho ||F_k||, rho ||Fg_k|| as epigraph variables with arrow LMIs) against
+    the numpy oracle's tight mode -- Hc, F, Fg, kappa, the barrier target to the 1e-8 bar -- and the certificate of the exported dual iterate (LMI blocks, multipliers,
+    arrow blocks), numpy only."""
     from tunempc_amd._lib import HipConvexifier
-    for kw in (dict(ng=1, nc=2), dict(step3=True)):
+    n = nx + mb; rho = 1e-2
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    J = np.concatenate([G, Cc], axis=2)
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb)
+    out0 = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    h.set_tight(True, TIGHT_TOL)
+    out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    dual = h.dual(nb); dc = h.dual_con(nb, arrows=True)
+    h.set_tight(False)
+    again = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    h.close()
+    assert np.array_equal(again['Hc'], out0['Hc']) and np.array_equal(again['FgF'], out0['FgF'])        # the default path is untouched by the mode
+    worst = 0.0
+    for b in range(nb):
+        if out['info'][b, 13] != 0.0:
+            continue
+        assert int(out['status'][b]) == 0 and int(out['info'][b, 10]) == 0, (b, out['status'][b], out['info'][b, 10])
+        Cl = [Cc[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        r = co.sdp_step1(A[b], B[b], H[b], dict(tol=TIGHT_TOL, tight=True), G=G[b] if ng else None, C=Cl, rho=rho)
+        assert r['ipm_status'] == 'optimal' and out['info'][b, 6] == r['mu_target']
+        Hc = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b] if ng else None, Fg=r.get('Fg'), C=Cl, F=r['F'])[0]
+        e = rel(out['Hc'][b], Hc); worst = max(worst, e)
+        assert e < PARITY, (b, e)
+        for k in range(p):
+            if ng:
+                assert np.abs(out['FgF'][b, k, :ng] - r['Fg'][k]).max() < PARITY * max(1.0, np.abs(r['Fg']).max())
+            if ncnt[b, k]:
+                assert np.abs(out['FgF'][b, k, ng:ng + ncnt[b, k]] - r['F'][k]).max() < PARITY * max(1.0, np.abs(r['F'][k]).max())
+        assert abs(out['kappa'][b] - r['kappa']) < 1e-11 * r['kappa']
+        primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], J[b], ng + ncnt[b], ncnt[b], ng, rho, out, dual, dc, b, True)
+        assert dobj - slack <= primal
+        width = (primal - (dobj - slack)) / primal
+        assert width <= 1e-7 and width <= 2.0 * gap / primal + 1e-9, (b, width, gap / primal)
+    print(f'tight mode on the Step 2 model p={p} n={n} ng={ng} nc={nc}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
+
+
+def test_tight_refused_where_the_mode_does_not_reach():
+    """Step 3 handles, rows on the generic kernels (n > 32), more rows than the LDS holds in double-double: TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
+    from tunempc_amd._lib import HipConvexifier
+    for kw in (dict(step3=True), dict(ng=1, nc=2, step3=True)):
         h = HipConvexifier(3, 3, 2, **kw)
         with pytest.raises(RuntimeError, match='tmpc_set_tight'):
             h.set_tight(True)
         h.close()
+    h = HipConvexifier(2, 24, 8, ng=31, nc=31)             # 62 rows of 2 n + 2 nx = 112 double-double entries each: beyond the LDS
+    with pytest.raises(RuntimeError, match='tmpc_set_tight'):
+        h.set_tight(True)
+    h.close()
     h = HipConvexifier(2, 30, 6, ng=2)
     with pytest.raises(RuntimeError, match='tmpc_set_tight'):
         h.set_tight(True)
@@ -209,7 +262,7 @@ def test_default_path_untouched_by_the_mode():
     assert np.array_equal(a['Hc'], c['Hc']) and np.array_equal(a['kappa'], c['kappa']) and np.array_equal(a['iters'], c['iters'])
     assert (t['kappa'] <= a['kappa']).all() and (t['iters'] > a['iters']).all()
     assert ((a['kappa'] - t['kappa']) / a['kappa'] <= (2 * p * (nx + mb) + 1) * 2.0 ** -25 * 1.5).all()     # the default's gap bound holds
-    hg = HipConvexifier(p, nx, mb, ng=2, nc=2)        # (room for C rows: Step 2 handles are outside the mode; rows of G alone are inside since round 5)
+    hg = HipConvexifier(p, nx, mb, step3=True)        # (Step 3 handles are outside the mode; rows of G and C are inside since round 5)
     try:
         with pytest.raises(RuntimeError):
             hg.set_tight(True)

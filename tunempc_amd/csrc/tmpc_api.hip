@@ -209,7 +209,7 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.Hc = c.take<double>(BP * nn); w.dHc = c.take<double>(BP * nn); w.Pout = c.take<double>(BP * nxx);
   w.bscr = (dm.n > NMAX) ? c.take<double>(BP * BIG_SCR * nn) : nullptr;
   w.sscr = schur_in_lds(dm) ? nullptr : c.take<double>(BP * 10 * nxx);
-  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = w.phidef = w.Zdd = w.TUl = w.ddscr = nullptr; w.plist = w.pnext = nullptr;
+  w.Dl = w.Ol = w.Fl = w.Linvl = w.KFl = w.adjVl = w.adjEl = w.W3l = w.Zl = w.Pprev = w.Pdef = w.phidef = w.Zdd = w.TUl = w.atdef = w.ddscr = nullptr; w.plist = w.pnext = nullptr;
   w.G = nullptr; w.ncnt = nullptr; w.rho = 0.0;
   w.phi = w.zph = w.dphi = w.dzph = w.corrp = w.pvec = w.psm = w.prs = w.Fg = nullptr;
   w.at = w.adt = w.aX = w.adX = w.acor = w.aSi = w.aLi = w.aLXi = w.asum = nullptr;
@@ -261,6 +261,7 @@ static size_t carve_dd(WS& w, const Dims& dm, char* base) {
   w.Pprev = c.take<double>(BP * nxx); w.Pdef = c.take<double>(BP * nxx);
   w.phidef = c.take<double>(BP * (size_t)dm.nr);
   w.Zdd = dm.nr > 0 ? c.take<double>(BP * 4 * (size_t)dm.n * dm.n) : nullptr;
+  w.atdef = dm.nz > dm.nr ? c.take<double>(BP * 2) : nullptr;
   w.ddscr = (dm.n > NMAX) ? c.take<double>(BP * DD_SCR_MATS * 2 * (size_t)dm.n * dm.n) : nullptr;
   w.plist = c.take<int>((size_t)dm.B); w.pnext = c.take<int>((size_t)dm.B);
   return (c.off + 255) & ~(size_t)255;
@@ -924,9 +925,9 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   { const int rc_ = ipm_loop(o, false, cap); if (rc_ != TMPC_OK) return rc_; }
   // ---- tight mode (tmpc_set_tight; plain model): restart the problems that ended Optimal towards tight_tol * kappa with the block linear
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
-  // (round 5: also Step 1 with rows of G -- cost-free multipliers, no norm terms: they ride in the augmented blocks of tmpc_phi.h, whose rows stay fp64 numbers in the
-  // double-double planes, and join the polish as variables: k_dd_polish_pre, k_polish_phi)
-  if (h->tight && !t3 && wall.Dl && (!eq || (!dm.constr && !big))) {
+  // (round 5: also the models with rows -- Step 1 with G, Step 2 with C and the norm terms: the multipliers and epigraph variables ride in the augmented blocks of
+  // tmpc_phi.h, their rows formed in double-double (k_dd_aug_fill), and join the polish as variables: k_dd_polish_pre, k_polish_phi, k_polish_arrows)
+  if (h->tight && !t3 && wall.Dl && (!eq || !big)) {
     // (round 5: chord steps also in this phase and in the polish -- a double-double factorisation costs ten fp64 ones, a step on an old one a tenth of it)
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     // where a factorisation costs ten fp64 ones and a step on the old one a twentieth of it, chord steps pay from a much shorter safe step on: threshold 3 instead of 10
@@ -972,6 +973,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       { const int rc_ = dd_solve(wp, dm, h->sched, h->d_sched, list, count, st, 2, nb); if (rc_ != TMPC_OK) return rc_; }
       hipLaunchKernelGGL(k_dd_solve_border, dim3(count), dim3(256), 0, st, wp, dm, (const int*)list);
       if (eq) hipLaunchKernelGGL(k_polish_phi, dim3(count * dm.p), dim3(64), 0, st, wp, dm);
+      if (eq && dm.constr) hipLaunchKernelGGL(k_polish_arrows, dim3(count * dm.p), dim3(256), 0, st, wp, dm);
       if (dm.n > NMAX) hipLaunchKernelGGL(kb_polish_step, dim3(count * dm.p), dim3(256), 0, st, wp, dm);
       else hipLaunchKernelGGL(k_polish_step, dim3(count * dm.p), dim3(256), slots_bytes(5), st, wp, dm);
       HIPCHK(hipMemsetAsync(w.active + 3, 0, sizeof(int), st));
@@ -1187,8 +1189,12 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
   if (!h) return TMPC_E_ARG;
   if (!enable) { h->tight = 0; return TMPC_OK; }
-  if (h->dm.nr > h->dm.ng || h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Step 1 handles only (plain, or with rows of G; no room for C rows, no Step 3)"); return TMPC_E_UNSUPPORTED; }
-  if (h->dm.nr > 0 && h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: with rows of G the mode covers nx + mb <= %d", NMAX); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Steps 1 and 2 only (no Step 3 handles)"); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > 0 && h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: with rows of G / C the mode covers nx + mb <= %d", NMAX); return TMPC_E_UNSUPPORTED; }
+  if (h->dm.nr > 0 && (size_t)dd_aug_lds_doubles(h->dm.nr, h->dm.n, h->dm.nx) * sizeof(double) > 160 * 1024) {
+    snprintf(g_err, sizeof(g_err), "tmpc_set_tight: %d rows per stage at nx = %d, nx + mb = %d: their double-double vectors do not fit the LDS (rows * (2 n + 2 nx) <= 4040)", h->dm.nr, h->dm.nx, h->dm.n);
+    return TMPC_E_UNSUPPORTED;
+  }
   if ((size_t)dd_solve_lds_doubles(h->dm.dp) * sizeof(double) > 160 * 1024) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Schur blocks of %d do not fit the LDS image of the double-double substitution kernels (nx <= 51)", h->dm.dp);
     return TMPC_E_UNSUPPORTED;

@@ -175,6 +175,7 @@ struct WS {
   double* Pprev;   // [B,p,nx,nx] iterate before the last polish step
   double* Pdef;    // [B,p,nx,nx] result of the default solve (restored when the tight phase of a member fails)
   double* phidef;  // [B,p,nr] multipliers of the default solve (tight mode with rows of G)
+  double* atdef;   // [B,p,2] epigraph variables of the default solve (tight mode on the Step 2 model)
   double* TUl;     // [B,p,dp,2] low words of T^-1 U (the border system of the polish is solved in double-double: k_dd_solve_border)
   double* Zdd;     // [B,p,2,2,n,n] S_r^-1 of the polish in double-double (hi plane, lo plane per cone block): the rows of the multipliers are formed from it (k_dd_aug_fill)
   double* sscr;    // [B,p,10,nx,nx] factor records of k_schur when they do not fit the LDS (nx > 43); null otherwise

@@ -683,7 +683,39 @@ __global__ void __launch_bounds__(256) k_dd_schur(WS w, Dims dm) {
 //   a_i = -svec(sum_r sym(w u')[:nx,:nx]) (P_k),  b_i = svec(sum_r sym(V w (V u)')) (P_{k+1}),  T_ij = sum_r ((g_i'X g_j)(g_j'S^-1 g_i) + (i <-> j)) / 2 + delta_ij z_i / phi_i.
 // polish = 0: the loop (X_r, S_r^-1, z, phi the fp64 iterates); 1: the polish (S_r^-1 in dd from k_dd_polish_pre, X_r = mu S_r^-1, z = mu / phi).
 // The border entries c_tau, c_alpha and the vectors k_phi_dir needs stay with k_phi_pre (fp64, like the border columns of tau and alpha).  One workgroup per stage, n <= 32.
-__host__ __device__ constexpr int dd_aug_lds_doubles(int nr, int n, int nx) { return 4 * nr * (2 * n + 2 * nx) + 16; }       // 125 KB at 31 rows, n = 32
+static_assert(AEL + 1 == LD && AEL == NMAX, "arrow blocks share the 32 x 33 LDS slots of the stage kernels");
+constexpr int ARW_LD = AEL + 1;                                 // leading dimension of an arrow block in LDS
+constexpr int ARW_DOUBLES = 4 * AEL * ARW_LD + 8;              // S^-1 and X of one arrow block, hi and lo
+__host__ __device__ constexpr int dd_aug_lds_doubles(int nr, int n, int nx) { return 4 * nr * (2 * n + 2 * nx) + ARW_DOUBLES + 16; }       // rows of [G; C]: 125 KB at 31 rows, n = 32
+// Closed-form inverse of the arrow matrix S = [[t, u'], [u, t I]], u_i = wr phi_i (m entries), in dd: gam = t^2 - |u|^2 cancels to ~mu t on an active norm term
+// (k_phi_init has the fp64 form).  S^-1 = [[t, -u'], [-u, (gam / t) I + u u' / t]] / gam.  256 threads; Sih / Sil: ne x ne with leading dimension ARW_LD.
+// Returns gam (uniform); the caller checks t > 0 and gam > 0.  sc: 8 doubles of LDS.
+__device__ __forceinline__ ddv arrow_inv_dd(double* Sih, double* Sil, double t, const double* phi, double wr, int m, double* sc) {
+  const int tid = threadIdx.x, ne = m + 1;
+  __syncthreads();
+  if (tid == 0) {
+    ddv usq = ddv{0.0, 0.0};
+    for (int i = 0; i < m; ++i) { const ddv u = dd_tp(wr, phi[i]); usq = dd_add(usq, dd_mul(u, u)); }
+    const ddv gam = dd_sub(dd_tp(t, t), usq);
+    const ddv gi = dd_div(dd_from(1.0), gam), ti = dd_div(dd_from(1.0), dd_from(t));
+    sc[0] = gam.h; sc[1] = gam.l; sc[2] = gi.h; sc[3] = gi.l; sc[4] = ti.h; sc[5] = ti.l;
+  }
+  __syncthreads();
+  const ddv gi = ddv{sc[2], sc[3]}, ti = ddv{sc[4], sc[5]};
+  for (int e = tid; e < ne * ne; e += 256) {
+    const int i = e / ne, j = e - i * ne;
+    ddv v;
+    if (i == 0 && j == 0) v = dd_muld(gi, t);
+    else if (i == 0 || j == 0) v = dd_neg(dd_mul(dd_tp(wr, phi[(i ? i : j) - 1]), gi));
+    else {
+      v = dd_mul(dd_mul(dd_tp(wr, phi[i - 1]), dd_tp(wr, phi[j - 1])), dd_mul(ti, gi));
+      if (i == j) v = dd_add(v, ti);
+    }
+    Sih[i * ARW_LD + j] = v.h; Sil[i * ARW_LD + j] = v.l;
+  }
+  __syncthreads();
+  return ddv{sc[0], sc[1]};
+}
 __global__ void __launch_bounds__(256) k_dd_aug_fill(WS w, Dims dm, int polish) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int sid = stage_id(w, dm), tid = threadIdx.x;
@@ -765,6 +797,51 @@ __global__ void __launch_bounds__(256) k_dd_aug_fill(WS w, Dims dm, int polish) 
     Dh[ro] = bv.h; Dl[ro] = bv.l;
     const size_t co = corner ? (size_t)idx * dp + d + i : ro;                                 // stored [block k][block k+1] or [block k+1][block k]
     Ch[co] = av.h; Cl[co] = av.l;
+  }
+  // Step 2: the norm terms.  Arrow block e covers rows a0 .. a0 + m - 1; its epigraph variable is local variable ng + e (no coupling to P, tau, alpha).  Entries of
+  // T_loc,loc as k_phi_pre forms them in fp64, here from the dd closed-form inverse:  <E_q, sym(X E_t S^-1)> etc.
+  const PhiStage ps = phi_stage(w, dm, sid);
+  if (ps.na > 0) {
+    const double wr = phi_wr(w, pr);
+    double* Sih = sm + 4 * ng * vl; double* Sil = Sih + AEL * ARW_LD; double* Xh = Sil + AEL * ARW_LD; double* Xl = Xh + AEL * ARW_LD; double* sc = Xl + AEL * ARW_LD;
+    for (int e_ = 0; e_ < ps.na; ++e_) {
+      const int m = ps.am[e_], ne = m + 1, c0 = ps.a0[e_], te = ng + e_;
+      arrow_inv_dd(Sih, Sil, w.at[(size_t)sid * 2 + e_], phi + c0, wr, m, sc);
+      const double* aXg = w.aX + ((size_t)sid * 2 + e_) * AE;
+      for (int e = tid; e < ne * ne; e += 256) {
+        const int i = e / ne, j = e - i * ne;
+        const ddv x = polish ? dd_muld(ddv{Sih[i * ARW_LD + j], Sil[i * ARW_LD + j]}, mu) : ddv{aXg[i * AEL + j], 0.0};
+        Xh[i * ARW_LD + j] = x.h; Xl[i * ARW_LD + j] = x.l;
+      }
+      __syncthreads();
+      auto SI = [&](int i, int j) { return ddv{Sih[i * ARW_LD + j], Sil[i * ARW_LD + j]}; };
+      auto XX = [&](int i, int j) { return ddv{Xh[i * ARW_LD + j], Xl[i * ARW_LD + j]}; };
+      for (int e = tid; e < ng * ng; e += 256) {                        // phi-phi part: same thread as the Gram part above (read-modify-write of its own entry)
+        const int i = e / ng, j = e - i * ng;
+        if (j > i || i < c0 || i >= c0 + m || j < c0) continue;
+        const int a = i - c0, q = j - c0;
+        ddv v = dd_add(dd_add(dd_mul(XX(0, 0), SI(q + 1, a + 1)), dd_mul(XX(0, q + 1), SI(0, a + 1))), dd_add(dd_mul(XX(a + 1, 0), SI(q + 1, 0)), dd_mul(XX(a + 1, q + 1), SI(0, 0))));
+        v = dd_mul(v, dd_tp(wr, wr));
+        const size_t g = (size_t)(d + i) * dp + d + j;
+        const ddv t = dd_add(ddv{Dh[g], Dl[g]}, v);
+        Dh[g] = t.h; Dl[g] = t.l;
+        if (i == j) ddn[d + i] = t.h;
+      }
+      for (int q = tid; q <= m; q += 256) {                             // row of the epigraph variable: couplings to its phi_q, and tr(X S^-1) on the diagonal
+        ddv v = ddv{0.0, 0.0};
+        if (q < m) {
+          for (int r = 0; r < ne; ++r) v = dd_add(v, dd_add(dd_mul(XX(0, r), SI(r, q + 1)), dd_mul(XX(q + 1, r), SI(r, 0))));
+          v = dd_muld(v, wr);
+          Dh[(size_t)(d + te) * dp + d + c0 + q] = v.h; Dl[(size_t)(d + te) * dp + d + c0 + q] = v.l;
+        } else {
+          for (int i = 0; i < ne; ++i) for (int r = 0; r < ne; ++r) v = dd_add(v, dd_mul(XX(i, r), SI(r, i)));
+          Dh[(size_t)(d + te) * dp + d + te] = v.h; Dl[(size_t)(d + te) * dp + d + te] = v.l; ddn[d + te] = v.h;
+        }
+      }
+      for (int j = tid; j < te; j += 256)                                // (the rest of the row: no coupling to the other block's rows or to another epigraph variable)
+        if (j < c0 || j >= c0 + m) { Dh[(size_t)(d + te) * dp + d + j] = 0.0; Dl[(size_t)(d + te) * dp + d + j] = 0.0; }
+      __syncthreads();
+    }
   }
 }
 
@@ -854,6 +931,33 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       dsync();
     }
   }
+  // Step 2: the norm terms.  X_e := mu S_e^-1 from the dd closed form (cone check: t > 0, gam > 0); tr(X_e) - 1 is minus the gradient in t_e, 2 wr X_e[0][i+1] joins the
+  // one in phi_i -- both in dd, then rounded.
+  const PhiStage pst = phi_stage(w, dm, sid);
+  __shared__ double arw_gi[4];                        // 1 / gam of the two arrow blocks (dd)
+  if (pst.na > 0) {
+    const double wr = phi_wr(w, pr);
+    __shared__ double sc[8];
+    double* Sih = t0.p; double* Sil = t0.p + t0.ms;                  // (t0 is free here; LDS slot of 32 x 33 = AEL x ARW_LD doubles per plane: handles with room for C rows have n <= 32)
+    for (int e_ = 0; e_ < pst.na; ++e_) {
+      const int m = pst.am[e_], ne = m + 1, c0 = pst.a0[e_];
+      const double te = w.at[(size_t)sid * 2 + e_];
+      const ddv gam = arrow_inv_dd(Sih, Sil, te, ph + c0, wr, m, sc);
+      nbad += (te > 0.0 && gam.h > 0.0) ? 0 : 1;
+      double* aXg = w.aX + ((size_t)sid * 2 + e_) * AE; const double* adXg = w.adX + ((size_t)sid * 2 + e_) * AE;
+      for (int e = tid; e < ne * ne; e += 256) {
+        const int i = e / ne, j = e - i * ne;
+        aXg[i * AEL + j] = final_sweep ? adXg[i * AEL + j] : dd_val(dd_muld(ddv{Sih[i * ARW_LD + j], Sil[i * ARW_LD + j]}, mu));      // (final sweep: the dual iterate of the last Newton step, k_polish_arrows)
+      }
+      if (tid == 0) {
+        ddv tr = ddv{0.0, 0.0};
+        for (int i = 0; i < ne; ++i) tr = dd_add(tr, ddv{Sih[i * ARW_LD + i], Sil[i * ARW_LD + i]});
+        PSM_RPHI(psm_at(w.psm, dm, sid), dm.nz)[pst.nrow + e_] = dd_val(dd_sub(dd_muld(tr, mu), dd_from(1.0)));
+        arw_gi[2 * e_] = sc[2]; arw_gi[2 * e_ + 1] = sc[3];
+      }
+      __syncthreads();
+    }
+  }
   if (ngs > 0) {
     // minus the gradient of the dual barrier in phi_i: g_i' (X1 - X2) g_i + mu / phi_i -- the quadratic form in dd (its terms are O(1), the sum ~ mu / phi_i), THEN rounded:
     // the tail of the right-hand side of block k+1 (k_aug_gather).  z_i := mu / phi_i is not an iterate any more (the diagonal z / phi of T_loc,loc: k_phi_pre).
@@ -868,6 +972,11 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
       ddv sq = ddv{0.0, 0.0};
       for (int a = 0; a < n; ++a) sq = dd_add(sq, t0.get(tid, a));
       const ddv zz = dd_div(dd_from(mu), dd_from(ph[tid]));
+      for (int e_ = 0; e_ < pst.na; ++e_)
+        if (tid >= pst.a0[e_] && tid < pst.a0[e_] + pst.am[e_]) {        // + 2 wr X_e[0][i+1],  X_e[0][i+1] = -mu wr phi_i / gam
+          const double wr = phi_wr(w, pr);
+          sq = dd_sub(sq, dd_muld(dd_mul(dd_tp(wr, ph[tid]), ddv{arw_gi[2 * e_], arw_gi[2 * e_ + 1]}), 2.0 * wr * mu));
+        }
       PSM_RPHI(psm_at(w.psm, dm, sid), dm.nz)[tid] = dd_val(dd_add(sq, zz));
       // (final sweep: the multiplier of the dual iterate that goes with the last Newton step, k_polish_phi)
       w.zph[(size_t)sid * dm.nr + tid] = final_sweep ? w.dzph[(size_t)sid * dm.nr + tid] : dd_val(zz);
@@ -931,6 +1040,7 @@ __global__ void __launch_bounds__(64) k_tight_restart(WS w, Dims dm, Opts o) {
   const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
   for (size_t e = lane; e < np_; e += 64) w.Pdef[(size_t)b * np_ + e] = w.P[(size_t)b * np_ + e];
   for (size_t e = lane; e < (size_t)dm.p * dm.nr; e += 64) w.phidef[(size_t)b * dm.p * dm.nr + e] = w.phi[(size_t)b * dm.p * dm.nr + e];
+  if (dm.constr) for (int e = lane; e < dm.p * 2; e += 64) w.atdef[(size_t)b * dm.p * 2 + e] = w.at[(size_t)b * dm.p * 2 + e];
   if (lane != 0) return;
   pr[P_TAU_DEF] = pr[P_TAU]; pr[P_ALPHA_DEF] = pr[P_ALPHA];
   pr[P_MUT1] = pr[P_MUT]; pr[P_MUT] = mut; pr[P_PREVSTEPN] = -1.0;
@@ -949,6 +1059,7 @@ __global__ void __launch_bounds__(64) k_tight_fallback(WS w, Dims dm) {
   const size_t np_ = (size_t)dm.p * dm.nx * dm.nx;
   for (size_t e = lane; e < np_; e += 64) w.P[(size_t)b * np_ + e] = w.Pdef[(size_t)b * np_ + e];
   for (size_t e = lane; e < (size_t)dm.p * dm.nr; e += 64) w.phi[(size_t)b * dm.p * dm.nr + e] = w.phidef[(size_t)b * dm.p * dm.nr + e];
+  if (dm.constr) for (int e = lane; e < dm.p * 2; e += 64) w.at[(size_t)b * dm.p * 2 + e] = w.atdef[(size_t)b * dm.p * 2 + e];
   if (lane != 0) return;
   pr[P_TAU] = pr[P_TAU_DEF]; pr[P_ALPHA] = pr[P_ALPHA_DEF]; pr[P_MUT] = pr[P_MUT1]; pr[P_MU] = pr[P_MUT1];
   ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_TIGHT_FALLBACK; ip[I_DD] = 2;      // (info[10] = 4: a caller who asked for the tight gap can tell that this member has the default one)
@@ -968,6 +1079,7 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_a(WS w, Dims dm) {
     const int nxx = dm.nx * dm.nx;
     if (ip[I_NPOLISH] > 0) for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
     if (ip[I_NPOLISH] > 0) for (int e = lane; e < p * dm.nr; e += 64) w.phi[(size_t)b * p * dm.nr + e] = w.corrp[(size_t)b * p * dm.nr + e];
+    if (ip[I_NPOLISH] > 0 && dm.constr) for (int e = lane; e < p * 2; e += 64) if ((e & 1) < phi_stage(w, dm, (size_t)b * p + (e >> 1)).na) w.at[(size_t)b * p * 2 + e] = w.acor[((size_t)b * p * 2 + e) * AE];
     if (lane == 0) {
       if (ip[I_NPOLISH] > 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; }
       ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE;
@@ -1069,6 +1181,48 @@ __global__ void __launch_bounds__(64) k_polish_phi(WS w, Dims dm) {
     const double phi = w.phi[gi], mu = pr[P_MUT];
     if (!ip[I_CHORD]) w.dzph[gi] = mu / phi - mu * v / (phi * phi);
   }
+  const PhiStage ps = phi_stage(w, dm, sid);
+  if (lane < ps.na) {                                     // epigraph variables: local variables nrow + e
+    const double* lo = w.part + (size_t)b * dm.p * NPART;
+    const ddv dtau = ddv{pr[P_DTAU], lo[Q_XDS]}, dalpha = ddv{pr[P_DALPHA], lo[Q_DXDS]};
+    const size_t vi = ((size_t)b * dm.p + kn) * dm.dp + dm.d + ps.nrow + lane;
+    w.adt[(size_t)sid * 2 + lane] = dd_val(dd_sub(dd_sub(ddv{w.Z[vi], w.Zl[vi]}, dd_mul(ddv{w.TU[vi * 2], w.TUl[vi * 2]}, dtau)), dd_mul(ddv{w.TU[vi * 2 + 1], w.TUl[vi * 2 + 1]}, dalpha)));
+  }
+}
+
+// polish on the Step 2 model, after k_polish_phi: the primal block of every norm term that goes with a Newton step, X_e + dX_e = mu S_e^-1 - mu sym(S_e^-1 dS_e S_e^-1)
+// with dS_e = arrow(dt_e, wr dphi) -- it satisfies tr(X_e) = 1 and the stationarity rows of its phi_i to rounding, as X_r + dX_r does for the LMI blocks
+// (k_polish_step); S_e^-1 from the dd closed form.  Exported by tmpc_get_dual_con_host after the final sweep.
+__global__ void __launch_bounds__(256) k_polish_arrows(WS w, Dims dm) {
+  __shared__ double Sih[AEL * ARW_LD], Sil[AEL * ARW_LD], sc[8], dsv[AEL];
+  const int sid = stage_id(w, dm), tid = threadIdx.x;
+  const int b = sid / dm.p;
+  const int* ip = w.iprob + (size_t)b * IS;
+  if (ip[I_PHASE] != PH_POLISH || ip[I_CHORD]) return;
+  const double* pr = w.prob + (size_t)b * PS;
+  const PhiStage ps = phi_stage(w, dm, sid);
+  const double wr = phi_wr(w, pr), mu = pr[P_MUT];
+  const double* phi = w.phi + (size_t)sid * dm.nr; const double* dph = w.dphi + (size_t)sid * dm.nr;
+  for (int e_ = 0; e_ < ps.na; ++e_) {
+    const int m = ps.am[e_], ne = m + 1, c0 = ps.a0[e_];
+    arrow_inv_dd(Sih, Sil, w.at[(size_t)sid * 2 + e_], phi + c0, wr, m, sc);
+    if (tid < ne) dsv[tid] = tid ? wr * dph[c0 + tid - 1] : w.adt[(size_t)sid * 2 + e_];      // dS: diagonal dsv[0], first row / column dsv[1..m]
+    __syncthreads();
+    auto SI = [&](int i, int j) { return ddv{Sih[i * ARW_LD + j], Sil[i * ARW_LD + j]}; };
+    double* out = w.adX + ((size_t)sid * 2 + e_) * AE;
+    for (int e = tid; e < ne * ne; e += 256) {
+      const int i = e / ne, j = e - i * ne;
+      if (j > i) continue;
+      // (S^-1 dS S^-1)[i][j] = dt sum_a Si[i][a] Si[a][j] + sum_{q >= 1} ds_q (Si[i][0] Si[q][j] + Si[i][q] Si[0][j])   (symmetric)
+      ddv acc = ddv{0.0, 0.0}, s2 = ddv{0.0, 0.0};
+      for (int a = 0; a < ne; ++a) s2 = dd_add(s2, dd_mul(SI(i, a), SI(a, j)));
+      acc = dd_muld(s2, dsv[0]);
+      for (int q = 1; q < ne; ++q) acc = dd_add(acc, dd_muld(dd_add(dd_mul(SI(i, 0), SI(q, j)), dd_mul(SI(i, q), SI(0, j))), dsv[q]));
+      const double v = dd_val(dd_muld(dd_sub(SI(i, j), acc), mu));
+      out[i * AEL + j] = v; out[j * AEL + i] = v;
+    }
+    __syncthreads();
+  }
 }
 
 // polish, after k_solve_border: dM of the step and the norms of the step test (M itself: T1, written by k_dd_polish_pre)
@@ -1141,6 +1295,10 @@ __global__ void __launch_bounds__(64) k_polish_ctrl_b(WS w, Dims dm, Opts o, con
   const bool fin = (fabs(pr[P_DTAU]) < 1e300) && (fabs(pr[P_DALPHA]) < 1e300) && (stepn == stepn) && (stepn < 1e300);
   if (fin) for (int e = lane; e < p * nxx; e += 64) { const size_t g = (size_t)b * p * nxx + e; w.Pprev[g] = w.P[g]; w.P[g] += w.dP[g]; }
   if (fin) for (int e = lane; e < p * dm.nr; e += 64) { const size_t g = (size_t)b * p * dm.nr + e; w.corrp[g] = w.phi[g]; w.phi[g] += w.dphi[g]; }      // (corrp: free in the polish -- phi before the step)
+  if (fin && dm.constr) for (int e = lane; e < p * 2; e += 64) {      // (acor[0] of the block: free in the polish -- t_e before the step)
+    const size_t g = (size_t)b * p * 2 + e;
+    if ((e & 1) < phi_stage(w, dm, (size_t)b * p + (e >> 1)).na) { w.acor[g * AE] = w.at[g]; w.at[g] += w.adt[g]; }
+  }
   if (lane != 0) return;
   if (!fin) { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; return; }
   pr[P_TAU_PREV] = pr[P_TAU]; pr[P_ALPHA_PREV] = pr[P_ALPHA];
@@ -1180,6 +1338,7 @@ __global__ void __launch_bounds__(64) k_polish_final(WS w, Dims dm) {
   if (!(nbad > 0.0)) { if (lane == 0) { pr[P_X0] = pr[P_DX0]; pr[P_S0] = pr[P_ALPHA] - ALPHA_MIN; pr[P_MU] = pr[P_MUT]; } return; }
   for (int e = lane; e < p * nxx; e += 64) w.P[(size_t)b * p * nxx + e] = w.Pprev[(size_t)b * p * nxx + e];
   for (int e = lane; e < p * dm.nr; e += 64) w.phi[(size_t)b * p * dm.nr + e] = w.corrp[(size_t)b * p * dm.nr + e];
+  if (dm.constr) for (int e = lane; e < p * 2; e += 64) if ((e & 1) < phi_stage(w, dm, (size_t)b * p + (e >> 1)).na) w.at[(size_t)b * p * 2 + e] = w.acor[((size_t)b * p * 2 + e) * AE];
   if (lane == 0) { pr[P_TAU] = pr[P_TAU_PREV]; pr[P_ALPHA] = pr[P_ALPHA_PREV]; ip[I_IPMSTATUS] = IPM_INACCURATE; }
 }
 
