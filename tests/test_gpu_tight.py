@@ -213,6 +213,52 @@ def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
     print(f'tight mode on the Step 2 model p={p} n={n} ng={ng} nc={nc}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
 
 
+def test_tight_beta_only_objective_with_ragged_rows():
+    """rho = 0 (the beta-only reading of convexifier.py:276-283: the rows of C_k are cost-free like those of G_k, but ragged) in the tight mode, against the oracle"""
+    from tunempc_amd._lib import HipConvexifier
+    seed, nb, p, nx, mb, ng, nc = 320, 3, 5, 4, 2, 1, 3
+    n = nx + mb
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    J = np.concatenate([G, Cc], axis=2)
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb)
+    h.set_tight(True, TIGHT_TOL)
+    out = h.convexify_step2_batch(A, B, H, J, ncnt, 0.0)
+    dual = h.dual(nb); dc = h.dual_con(nb, arrows=False)
+    h.close()
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 and int(out['info'][b, 10]) == 0
+        Cl = [Cc[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        r = co.sdp_step1(A[b], B[b], H[b], dict(tol=TIGHT_TOL, tight=True), G=G[b], C=Cl, rho=0.0)
+        Hc = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'], C=Cl, F=r['F'])[0]
+        assert r['ipm_status'] == 'optimal' and out['info'][b, 6] == r['mu_target'] and rel(out['Hc'][b], Hc) < PARITY
+        primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], J[b], ng + ncnt[b], ncnt[b], ng, 0.0, out, dual, dc, b, False)
+        assert dobj - slack <= primal and (primal - (dobj - slack)) / primal <= 1e-7
+
+
+def test_dropin_convexify_tight_with_constraints():
+    """convexify(..., opts={'tight': True}) with G and C (Steps 1 and 2 at the tight gap) against the oracle's step logic in its tight mode"""
+    from tunempc_amd import convexifier as cv
+    p, nx, mb, ng = 4, 3, 2, 1
+    n = nx + mb
+    A, B, H = co.gen_batch(331, 1, p, nx, mb)
+    rng = np.random.default_rng(331)
+    G = rng.standard_normal((p, ng, n)); C = [rng.standard_normal((2, n)) if k % 2 == 0 else None for k in range(p)]
+    Q = [H[0, k][:nx, :nx] for k in range(p)]; R = [H[0, k][nx:, nx:] for k in range(p)]; N = [H[0, k][:nx, nx:] for k in range(p)]
+    dHc, _, _, _ = cv.convexify([a for a in A[0]], [b_ for b_ in B[0]], Q, R, N, G=[g for g in G], C=C, opts={'tight': True})
+    r = co.convexify_arrays(A[0], B[0], H[0], dict(tol=TIGHT_TOL, tight=True), G=G, C=C)
+    assert r['status'] == 0
+    assert rel(np.stack(dHc), r['dHc']) < PARITY
+    with pytest.raises(NotImplementedError):
+        cv.convexify([a for a in A[0]], [b_ for b_ in B[0]], Q, R, N, C=C, opts={'tight': True, 'force': True})
+    cv.release_handles()
+
+
 def test_tight_refused_where_the_mode_does_not_reach():
     """Step 3 handles, rows on the generic kernels (n > 32), more rows than the LDS holds in double-double: TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
     from tunempc_amd._lib import HipConvexifier
@@ -343,15 +389,15 @@ def test_dropin_convexify_tight_option():
     ref = co.symmetrize(co.calH(A, B, r['P']))
     assert rel(np.stack(dt), ref) < 1e-7 and all(np.array_equal(a, b) for a, b in zip(d0, d1)) and rel(np.stack(d0), ref) > 1e-5
     with pytest.raises(NotImplementedError):
-        convexifier.convexify(*args, G=[np.ones((1, nx + mb))] * p, opts={'tight': True})
+        convexifier.convexify(*args, opts={'tight': True, 'force': True})       # Step 3 has no tight mode: refused up front
     # the answer must not depend on the cache history.  A call with C rows leaves a shared handle with room for them behind; the tight call
-    # that follows takes a plain handle of its own and returns the same bits as before; tight + C is refused up front (NotImplementedError, not a RuntimeError
-    # from tmpc_set_tight on the shared handle)
+    # that follows takes a plain handle of its own and returns the same bits as before; so does tight + C while Step 1 is feasible (round 5: the mode covers
+    # Step 2, on a handle of its own with exactly the rows of the call -- test_dropin_convexify_tight_with_constraints)
     Cs = [np.ones((2, nx + mb)) if k % 2 else None for k in range(p)]
     dc = convexifier.convexify(*args, C=Cs)[0]
     assert all(np.array_equal(a, b) for a, b in zip(dc, d0))              # (Step 1 is feasible: the rows never enter)
     dt2 = convexifier.convexify(*args, opts={'rho': 1e-3, 'solver': 'hip', 'force': False, 'tight': True})[0]
     assert all(np.array_equal(a, b) for a, b in zip(dt, dt2))
-    with pytest.raises(NotImplementedError):
-        convexifier.convexify(*args, C=Cs, opts={'tight': True})
+    dt3 = convexifier.convexify(*args, C=Cs, opts={'tight': True})[0]
+    assert all(np.array_equal(a, b) for a, b in zip(dt, dt3))
     convexifier.release_handles()

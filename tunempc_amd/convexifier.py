@@ -31,13 +31,14 @@ N_TUNED, N_ROWS_MAX, N_MAX = 32, 64, 96          # stage-block sizes: tuned kern
 NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
-def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False):
+def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False, exact=False):
     """One cached handle per problem shape.  Its workspace is sized for the batch actually asked for (next power of two of nb,
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
     pins 0.15 GB instead of 75 GB.  A handle with room for G / C rows also serves the calls without them, so Step 1 and Step 2
     of one convexify() share it; it is rebuilt only when a call needs more rows or a larger chunk.
-    plain=True: a handle of its own without any room for rows (the tight-accuracy mode runs on such a handle only: a shared one that an
-    earlier call of the same shape grew rows on would make the answer depend on the cache history -- ADVICE r4)."""
+    plain=True: a handle of its own without any room for rows; exact=True: a handle of its own with room for exactly the rows asked for.  The
+    tight-accuracy mode runs on such handles only: a shared one that an earlier call of the same shape grew rows on could refuse the mode (its
+    double-double vectors of the rows must fit the LDS) or not, depending on the cache history -- ADVICE r4."""
     if plain:
         ng = nc = 0
     if nx + mb > N_MAX:
@@ -50,7 +51,7 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False):
         # the LDS image of the substitution kernels (nx(nx+1)/2 + n(n+1)/2 + 1 + rows <= 3168: n = 64 with nx = 40 fits -- 2901 --, n = 64 with nx = 48 does not)
         raise NotImplementedError('Step 3 (force=True) at nx = {}, nx + nu = {}: Schur blocks of nx(nx+1)/2 + n(n+1)/2 + 1 + multipliers exceed what the '
                                   'substitution kernels hold in LDS (3168)'.format(nx, nx + mb))
-    key = (p, nx, mb, ng, bool(step3), bool(plain))   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
+    key = (p, nx, mb, ng, bool(step3), bool(plain), nc if exact else -1)   # the ng rows of G are live in every call of a handle; the room for C rows is padded per stage by ncnt
     want = 1
     while want < min(max(int(nb), 1), _MAX_CHUNK):
         want *= 2
@@ -92,7 +93,7 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
     G [nb,p,ng,n] (optional): equality-constraint Jacobians; their multipliers Fg [nb,p,ng] (convexifier.py:249-255)
     join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197).
     tight: None / False: the default accuracy (mu_target = 2^-25 kappa); True or a tolerance: the tight-accuracy mode of the library (tmpc_set_tight:
-    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model, nx <= 51)."""
+    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model up to nx = 51, with rows of G up to nx + nu = 32)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
     mb = B.shape[3]
@@ -102,34 +103,35 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
         ng = G.shape[2]
         if ng > NG_MAX:
             raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
-    if tight and ng > 0:
-        raise NotImplementedError('the tight-accuracy mode covers the plain Step 1 model (no G / C rows)')
+    if tight and ng > 0 and nx + mb > N_TUNED:
+        raise NotImplementedError('the tight-accuracy mode covers rows of G / C up to nx + nu = {} (got {})'.format(N_TUNED, nx + mb))
     if handle is not None:
         h = handle
+    elif tight and ng > 0:
+        h = _handle(p, nx, mb, ng, 0, nb, exact=True)      # never the shared handle of the shape (room for C rows it may have grown counts against the LDS of the mode)
     elif tight:
-        h = _handle(p, nx, mb, 0, 0, nb, plain=True)       # never the shared handle of the shape (it may have room for rows, which the mode refuses)
+        h = _handle(p, nx, mb, 0, 0, nb, plain=True)
     else:
         h = _handle(p, nx, mb, ng, nc_hint, nb)            # nc_hint: room for the C rows of a Step 2 that may follow (same handle)
     global _LAST_HANDLE
     _LAST_HANDLE = h
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)      # per call: a cached handle never keeps an earlier caller's tolerance
-    if ng > 0:
-        return h.convexify_eq_batch(A, B, H, G)
     if tight:
         h.set_tight(True, None if tight is True else float(tight))
     try:
-        return h.convexify_batch(A, B, H)
+        return h.convexify_eq_batch(A, B, H, G) if ng > 0 else h.convexify_batch(A, B, H)
     finally:
         if tight:
             h.set_tight(False)                    # a cached handle never keeps an earlier caller's mode
 
 
-def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
+def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None, tight=None):
     """Batched Step 2 model (convexifier.py:116-131, setUpModelPicos with constr=True): A, B, H as in convexify_batch;
     C [nb,p,nc,n] active-constraint Jacobians zero-padded to nc rows, ncnt [nb,p] rows present per stage (0: C_k is None);
     G [nb,p,ng,n] optional.  Returns the dict of convexify_batch plus 'F' [nb,p,nc] (zeros in the padding) and, with G, 'Fg'.
-    rho = 0: the beta-only objective (cost-free multipliers; see `convexify`, opts['objective'])."""
+    rho = 0: the beta-only objective (cost-free multipliers; see `convexify`, opts['objective']).
+    tight: as in convexify_batch (round 5: the mode covers this model, either objective, up to nx + nu = 32)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     C = np.asarray(C, dtype=np.float64); ncnt = np.asarray(ncnt, dtype=np.int32)
     nb, p, nx, _ = A.shape
@@ -141,7 +143,9 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
                                   '(got ng={}, nc={})'.format(NG_MAX, NC_MAX, ng, nc))
     if ncnt.shape != (nb, p) or (ncnt < 0).any() or (ncnt > nc).any():
         raise ValueError('ncnt must be an int array [nb, p] with 0 <= ncnt <= C.shape[2] = {}'.format(nc))
-    h = handle or _handle(p, nx, mb, ng, nc, nb)
+    if tight and nx + mb > N_TUNED:
+        raise NotImplementedError('the tight-accuracy mode covers the Step 2 model up to nx + nu = {} (got {})'.format(N_TUNED, nx + mb))
+    h = handle or (_handle(p, nx, mb, ng, nc, nb, exact=True) if tight else _handle(p, nx, mb, ng, nc, nb))
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
     # the handle may have more room than this call needs (it is shared between the steps): zero rows are padding
@@ -151,7 +155,13 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None):
     J[:, :, h.ng:h.ng + nc] = C
     global _LAST_HANDLE
     _LAST_HANDLE = h
-    out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    if tight:
+        h.set_tight(True, None if tight is True else float(tight))
+    try:
+        out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    finally:
+        if tight:
+            h.set_tight(False)
     FgF = out.pop('FgF')
     out['F'] = FgF[:, :, h.ng:h.ng + nc]
     if ng:
@@ -275,9 +285,9 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     :param Q: weighting matrix Q (nx,nx)   :param R: (nu,nu)   :param N: (nx,nu)
     :param C: jacobian of active constraints at steady state (nc, nx+nu)
     :param G: jacobian of equality constraints at steady state (ng, nx+nu)
-    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); 'tight': True or a tolerance -- Step 1 in the
-                 tight-accuracy mode of the library (relative gap on kappa N * 7e-12 instead of N * 3e-8, the accuracy MOSEK / CVXOPT stop at; plain
-                 model only: with G or C it raises NotImplementedError); one more key,
+    :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); 'tight': True or a tolerance -- Steps 1 and 2 in the
+                 tight-accuracy mode of the library (relative gap on kappa N * 7e-12 instead of N * 3e-8, the accuracy MOSEK / CVXOPT stop at; with G or C
+                 up to nx + nu = 32; not with 'force': Step 3 has no tight mode -- NotImplementedError); one more key,
                  'objective': 'paper' (default) | 'beta'.  The reference assembles the Step 2/3 objective with
                  `picos.sum(obj, abs(rho*F[i]))` (convexifier.py:276-285).  In PICOS 1.2.0 the second positional parameter of
                  picos.sum may be an iterator label rather than a summand (unverifiable here, PICOS is not
@@ -305,8 +315,10 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     Hs = np.stack([mtools.buildHessian(_to_array(q), _to_array(r), _to_array(n_))
                    for q, r, n_ in zip(arg['Q'], arg['R'], arg['N'])])
 
-    if (opts or {}).get('tight') and (C is not None or G is not None):
-        raise NotImplementedError("opts['tight'] covers the plain model: Step 1 without G and without a Step 2 to fall back on (no C)")
+    if (opts or {}).get('tight') and (opts or {}).get('force', False):
+        raise NotImplementedError("opts['tight'] covers Steps 1 and 2; it cannot be combined with opts['force'] (Step 3 has no tight mode)")
+    if (opts or {}).get('tight') and (C is not None or G is not None) and nx + nu > N_TUNED:
+        raise NotImplementedError("opts['tight'] with G or C covers nx + nu <= {} (got {})".format(N_TUNED, nx + nu))
     solver = (opts or {}).get('solver', 'hip')
     if solver not in ('hip', 'mosek', 'cvxopt'):
         raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))
@@ -362,7 +374,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
                 Cp[k, :rows[k]] = c
         Logger.logger.info('solving SDP...')
         res = convexify_step2_batch(As[None], Bs[None], Hs[None], Cp[None], np.asarray(rows, np.int32)[None],
-                                    rho2, G=None if Gs is None else Gs[None])
+                                    rho2, G=None if Gs is None else Gs[None], tight=(opts or {}).get('tight'))
         status = _log_solution(res)
         if status in ['Optimal', 'Feasible']:
             Logger.logger.info('EQUIVALENCE TYPE B')
