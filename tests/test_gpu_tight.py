@@ -213,6 +213,41 @@ def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
     print(f'tight mode on the Step 2 model p={p} n={n} ng={ng} nc={nc}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
 
 
+@pytest.mark.parametrize('model', ['G', 'step2'])
+def test_tight_certificate_with_rows_at_the_bench_shape(model):
+    """p = 64, nx = 24, mb = 8 with rows of G (and of C with the norm terms): no oracle at this size -- the certificate of the exported dual iterate alone, numpy only.
+    kappa (+ sum t_e) is pinned from both sides to <= 1e-7 relative (certified gaps of the models with multipliers)."""
+    from tunempc_amd._lib import HipConvexifier
+    p, nx, mb, nb, ng, nc, rho = 64, 24, 8, 2, 2, 3, 1e-2
+    n = nx + mb
+    A, B, H = co.gen_batch(777, nb, p, nx, mb)
+    rng = np.random.default_rng(778)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    if model == 'G':
+        h = HipConvexifier(p, nx, mb, ng=ng, chunk=nb)
+        h.set_tight(True, TIGHT_TOL)
+        out = h.convexify_eq_batch(A, B, H, G)
+        J = G; rows = np.full((nb, p), ng); cnt = np.zeros((nb, p), int)
+    else:
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb)
+        h.set_tight(True, TIGHT_TOL)
+        J = np.concatenate([G, Cc], axis=2); rows = ng + ncnt; cnt = ncnt
+        out = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+    dual = h.dual(nb); dc = h.dual_con(nb, arrows=(model == 'step2'))
+    h.close()
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 and int(out['info'][b, 10]) == 0, (b, out['status'][b], out['info'][b, 10])
+        primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], J[b], rows[b], cnt[b], ng, rho, out, dual, dc, b, model == 'step2')
+        assert dobj - slack <= primal
+        width = (primal - (dobj - slack)) / primal
+        print(f'{model} at the bench shape, member {b}: certified relative gap {width:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e}), {int(out["iters"][b])} iterations')
+        assert width <= 1e-7
+
+
 def test_tight_beta_only_objective_with_ragged_rows():
     """rho = 0 (the beta-only reading of convexifier.py:276-283: the rows of C_k are cost-free like those of G_k, but ragged) in the tight mode, against the oracle"""
     from tunempc_amd._lib import HipConvexifier
