@@ -493,6 +493,32 @@ def main():
                                              "note": "NOT the headline setting: opt-in tmpc_set_tight, default solve + continuation to mu_t = 2^-37 kappa (relative gap on kappa "
                                                      "N * 7.3e-12 instead of N * 3e-8) in double-double arithmetic on the vector ALU (tmpc_dd.h)"}
                 h.set_tight(False)
+                # round 5: the mode on the Step 2 model (rows of G, ragged rows of C, norm terms) at the bench stage shape -- a small batch through the host-buffer entry
+                try:
+                    nb2, ng2, nc2, rho2 = 64, 2, 3, 1e-2
+                    rng2 = np.random.default_rng(5)
+                    A2, B2, H2 = synthetic.gen_batch(100000, nb2, p, nx, mb)
+                    J2 = rng2.standard_normal((nb2, p, ng2 + nc2, n)); cnt2 = rng2.integers(0, nc2 + 1, size=(nb2, p)).astype(np.int32)
+                    for b_ in range(nb2):
+                        for k_ in range(p):
+                            J2[b_, k_, ng2 + cnt2[b_, k_]:] = 0.0
+                    h2 = HipConvexifier(p, nx, mb, ng=ng2, nc=nc2, chunk=nb2)
+                    h2.convexify_step2_batch(A2[:4], B2[:4], H2[:4], J2[:4], cnt2[:4], rho2)
+                    t0 = time.perf_counter(); od = h2.convexify_step2_batch(A2, B2, H2, J2, cnt2, rho2); ed = time.perf_counter() - t0
+                    h2.set_tight(True)
+                    h2.convexify_step2_batch(A2[:4], B2[:4], H2[:4], J2[:4], cnt2[:4], rho2)
+                    t0 = time.perf_counter(); ot = h2.convexify_step2_batch(A2, B2, H2, J2, cnt2, rho2); et = time.perf_counter() - t0
+                    h2.close()
+                    # cone dimension: the 2 p LMI blocks and alpha, one linear cone per row, an (m + 1)-dimensional arrow block per norm term (rows of G; rows of C where present)
+                    ncone = 2 * p * n + 1 + (ng2 + cnt2).sum(1) + p * (ng2 + 1) + (cnt2 + (cnt2 > 0)).sum(1)
+                    extra_rates["tight_mode"]["step2_model"] = {
+                        "value": nb2 * p / et, "default_value": nb2 * p / ed, "batch": nb2, "rows_G": ng2, "rows_C_max": nc2, "rho": rho2,
+                        "ipm_iterations_mean": float(ot['iters'].mean()), "default_ipm_iterations_mean": float(od['iters'].mean()),
+                        "status_optimal": int((ot['status'] == 0).sum()), "fell_back_to_default": int((ot['info'][:, 10] == 4.0).sum()),
+                        "certified_gap_on_value": float((ncone * ot['info'][:, 6] / ot['kappa']).max()),
+                        "note": "Step 2 model (convexifier.py:116-131) in the tight mode, host-buffer entry (H2D + D2H inside), one handle, one timed call each"}
+                except Exception as e:      # noqa: BLE001
+                    extra_rates["tight_mode"]["step2_model"] = {"error": f"{type(e).__name__}: {e}"}
             except Exception as e:      # noqa: BLE001
                 extra_rates["tight_mode"] = None
                 extra_rates["tight_mode_error"] = f"{type(e).__name__}: {e}"
