@@ -133,7 +133,8 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value);
  * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */
 int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes);
 
-/* Tight-accuracy mode (opt-in; plain Step 1 handles -- no G / C rows, no Step 3 -- with nx <= 51, any nx + mb <= 64).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
+/* Tight-accuracy mode (opt-in; Step 1 and Step 2 handles: plain with nx <= 51 and any nx + mb <= 64; with rows of G / C -- round 5 -- nx + mb <= 32 and
+ * rows * (2 (nx + mb) + 2 nx) <= 4040; no Step 3).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
  * ~1e-8 (convexifier.py:363); the default solve above stops at tol = 2^-25, a certified gap of (2*p*n+1)*3e-8 on kappa, because the HKM
  * Schur matrix (condition ~1/mu^2) cannot be factored in fp64 below mu ~ 1e-8.  With enable != 0 every problem that ended Optimal is
  * continued from its centred point towards mu_target = tight_tol * kappa (default 2^-37 ~ 7.3e-12: gap (2*p*n+1)*7.3e-12; accepted range
@@ -144,7 +145,10 @@ int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, 
  * double-double pivot, a polish step that leaves the cone, the iteration cap: most visibly hard targets below 2^-33) gets the result of its default
  * solve back, status Optimal, info[10] = 4 and info[6] = the default's mu_target: the mode never returns less than the default does, and says so.  Costs one more workspace of about the size of
  * the block storage (allocated at the first enable) and ~10 double-double factorisations per problem (vector ALU, no matrix cores).
- * enable == 0 switches back to the default (the workspace stays).  TMPC_E_UNSUPPORTED for handles with G / C rows or Step 3. */
+ * With rows (Step 1 with G; the Step 2 model with either objective) the multipliers and the epigraph variables of the norm terms ride in the augmented blocks
+ * as in the default solve, their rows formed in double-double, and join the polish as variables; tmpc_get_dual_host / tmpc_get_dual_con_host export the dual
+ * iterate that goes with the last Newton step of the polish (LMI blocks, multipliers z, primal blocks of the norm terms): it certifies the gap to ~N * tight_tol.
+ * enable == 0 switches back to the default (the workspace stays).  TMPC_E_UNSUPPORTED for Step 3 handles and for rows beyond the limits above. */
 int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol);
 
 /* Step 1 of convexifier.convexify for `nb` independent problems.  Any output pointer may be NULL.
