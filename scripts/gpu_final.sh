@@ -7,3 +7,4 @@ bash scripts/gpu_prof.sh $TAG > gpurun_out/${TAG}_prof_stdout.txt 2>&1; head -n 
 timeout 1200 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; python scripts/show_bench.py gpurun_out/${TAG}_bench.json | cut -c 1-250
 timeout 900 python tests/tools/parity_fuzz.py 120 90001 2>&1 | tail -n 5 | cut -c 1-600; cp gpurun_out/parity_fuzz.json gpurun_out/${TAG}_fuzz_seed90001.json
 timeout 900 python tests/tools/parity_fuzz.py 40 90002 12 24 2>&1 | tail -n 3 | cut -c 1-600; cp gpurun_out/parity_fuzz.json gpurun_out/${TAG}_fuzz_seed90002_nx24.json
+timeout 900 python tests/tools/tight_models_fuzz.py 97002 150 2>&1 | tail -n 1 | cut -c 1-800 > gpurun_out/${TAG}_tight_models_fuzz_seed97002.json; cat gpurun_out/${TAG}_tight_models_fuzz_seed97002.json
