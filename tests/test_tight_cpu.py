@@ -118,3 +118,47 @@ def test_tight_batch_of_the_cpu_port():
     b = cpu_ipm.convexify_batch(A, B, H, tol=2.0 ** -37, threads=4, tight=True)
     assert (a['status'] == 0).all() and (b['status'] == 0).all()
     assert np.array_equal(a['Hc'], b['Hc']) and np.array_equal(a['kappa'], b['kappa'])
+
+
+# ----------------------------------------------------------------------------- round 5: the oracle's tight mode on the models with rows
+def _rows_case(seed, p, nx, mb, ng, nc, model):
+    n = nx + mb
+    rng = np.random.default_rng(seed)
+    A, B, H = co.gen_batch(400 + seed, 1, p, nx, mb)
+    A, B, H = A[0], B[0], H[0]
+    G = rng.standard_normal((p, ng, n)) if ng else None
+    ncs = rng.integers(0, nc + 1, size=p) if nc else [0] * p
+    C = [rng.standard_normal((ncs[k], n)) if ncs[k] else None for k in range(p)] if nc else None
+    rho = 0.0 if model == 'beta' else 1e-2
+    kw = dict(G=G)
+    if model != 'G':
+        kw.update(C=C, rho=rho)
+    return A, B, H, G, C, rho, kw
+
+
+@pytest.mark.parametrize('seed,p,nx,mb,ng,nc,model', [(0, 3, 3, 2, 2, 0, 'G'), (1, 4, 3, 2, 1, 2, 'step2'), (2, 2, 4, 2, 0, 2, 'step2'), (3, 3, 3, 1, 1, 2, 'beta')])
+def test_tight_with_rows_against_the_dense_solver(seed, p, nx, mb, ng, nc, model):
+    """sdp_step1(tight=True) with rows of G, with the Step 2 model and with the beta-only objective (multipliers and the epigraph variables of the norm terms as variables
+    of the dd dual-Newton polish) against oracle/reference_sdp.py -- the dense restatement of the COMPLETE reference model with a dense Mehrotra solver that shares nothing
+    with the structured one: the objective value (beta + rho * norm terms, solver-independent) agrees to the dense solver's tolerance, an order and more closer than the
+    default mode's; and the returned point is reproducible on inputs 1e-14 apart."""
+    import reference_sdp as rs
+    A, B, H, G, C, rho, kw = _rows_case(seed, p, nx, mb, ng, nc, model)
+    r = co.sdp_step1(A, B, H, dict(tol=2.0 ** -37, tight=True), **kw)
+    r0 = co.sdp_step1(A, B, H, **kw)
+    assert r['ipm_status'] == r0['ipm_status'] == 'optimal' and r['polish_steps'] >= 1
+    Q = [H[k][:nx, :nx] for k in range(p)]; R = [H[k][nx:, nx:] for k in range(p)]; N = [H[k][:nx, nx:] for k in range(p)]
+    d = rs.solve_step(list(A), list(B), Q, R, N, G=None if G is None else list(G), C=C, rho=rho, constr=(model != 'G'), tol=1e-9)
+    assert d['solver_status'] == 'optimal'
+    obj, obj0 = r.get('objective', r['beta']), r0.get('objective', r0['beta'])
+    assert obj <= obj0                                                           # further down the central path
+    assert abs(obj - d['objective']) <= 5e-8 * obj                               # (measured 3e-10 ... 1.2e-8: the dense solver stops at 1e-9)
+    assert abs(obj - d['objective']) < 0.1 * abs(obj0 - d['objective'])          # the default mode is 4e-7 ... 1e-6 away
+    r2 = co.sdp_step1(A * (1 + 1e-14), B, H, dict(tol=2.0 ** -37, tight=True), **kw)
+    assert np.abs(r2['P'] - r['P']).max() <= 1e-9 * np.abs(r['P']).max()
+    if G is not None:
+        assert np.abs(r2['Fg'] - r['Fg']).max() <= 1e-9 * max(1.0, np.abs(r['Fg']).max())
+    if C is not None:
+        for k in range(p):
+            if C[k] is not None:
+                assert np.abs(r2['F'][k] - r['F'][k]).max() <= 1e-9 * max(1.0, np.abs(r['F'][k]).max())
