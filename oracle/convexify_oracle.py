@@ -409,6 +409,17 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
         out = []
         for a in arrows:
             m = len(a['idx'])
+            if a.get('soc'):
+                # second-order cone of Step 3 (the Frobenius norm of T_k): s = (t, wr c o theta), s^-1 = (t, -s_1) / det, det = t^2 - |s_1|^2 in dd
+                s1 = dn.DD(cw[a['idx']] * wr) * phi_[a['k'], a['idx']]
+                td = dn.DD(np.float64(t_[len(out)]))
+                det = td * td
+                for i in range(m):
+                    det = det - s1[i] * s1[i]
+                if not (t_[len(out)] > 0.0 and det.to_float() > 0.0):
+                    raise np.linalg.LinAlgError('soc')
+                out.append((td / det, (-s1) / det, det))             # (s^-1_0, s^-1_1, det)
+                continue
             S = dn.zeros((m + 1, m + 1))
             v = dn.DD(cw[a['idx']] * wr) * phi_[a['k'], a['idx']]              # (products of two fp64 numbers: exact in dd)
             for i in range(m + 1):
@@ -500,6 +511,20 @@ def _polish_dd(A, B, Hb, tau, alpha, P, mu, center_tol, verbose=False, GG=None, 
                     te = 2 + p * ng + e_
                     cols = 2 + a['k'] * ng + a['idx']
                     m = len(a['idx'])
+                    if a.get('soc'):
+                        # x = mu s^-1; Hessian of -(mu / 2) log det(s) in s: mu (2 s^-1 s^-1' - J / det); chain rule with s = (t, wr c o theta)
+                        i0, i1, det = Za[e_]
+                        x0d = i0 * mu; x1d = i1 * mu
+                        si = np.concatenate([[i0.to_float()], np.atleast_1d(i1.to_float())])
+                        Jd = np.diag(np.concatenate([[1.0], -np.ones(m)]))
+                        Hs = mu * (2.0 * np.outer(si, si) - Jd / det.to_float())
+                        wc_ = wr * cw[a['idx']]
+                        Bf2[te, te] = Hs[0, 0]
+                        Bf2[cols, te] = wc_ * Hs[0, 1:]; Bf2[te, cols] = wc_ * Hs[0, 1:]
+                        Bf2[np.ix_(cols, cols)] += np.outer(wc_, wc_) * Hs[1:, 1:]
+                        g_phi[a['k'], a['idx']] -= wc_ * np.atleast_1d(x1d.to_float())
+                        g_t[e_] = (1.0 - x0d).to_float()
+                        continue
                     Xe = (Za[e_] * mu); Xf = Xe.to_float(); Sif = Za[e_].to_float()
                     Pe = symmetrize((dn.matmul(Xe, Za[e_])).to_float()[None])[0]
                     Bf2[te, te] = np.trace(Pe)
@@ -784,7 +809,6 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
                     N = N + m + 1
     mu_t = None
     tight = bool(o.get('tight', False))       # tight-accuracy mode (plain model, and Step 1 with the cost-free multipliers of G): see DD_SWITCH
-    assert not (tight and nT), 'tight mode: Steps 1 and 2 (no T_k)'
     dd_on = False
     ndd = 0
     extrap_terms = None

@@ -162,3 +162,32 @@ def test_tight_with_rows_against_the_dense_solver(seed, p, nx, mb, ng, nc, model
         for k in range(p):
             if C[k] is not None:
                 assert np.abs(r2['F'][k] - r['F'][k]).max() <= 1e-9 * max(1.0, np.abs(r['F'][k]).max())
+
+
+@pytest.mark.parametrize('seed,p,nx,mb,ng,nc', [(0, 2, 2, 1, 0, 0), (1, 3, 3, 2, 0, 0), (2, 2, 3, 1, 1, 0), (3, 2, 2, 2, 1, 2)])
+def test_tight_step3_against_the_dense_solver(seed, p, nx, mb, ng, nc):
+    """The oracle's tight mode on the Step 3 model (convexifier.py:137-147: the entries of T_k as multipliers, their Frobenius norm through a second-order cone whose
+    Jordan inverse and log-det barrier join the dd polish) against the dense solver of oracle/reference_sdp.py: objective to its tolerance, an order and more closer than the
+    default mode.  (The HIP library has no tight mode for Step 3 yet: tmpc_set_tight refuses such handles; this pins the definition it will have to meet.)"""
+    import reference_sdp as rs
+    n = nx + mb
+    rng = np.random.default_rng(9 + seed)
+    A, B, H = co.gen_batch(500 + seed, 1, p, nx, mb)
+    A, B, H = A[0], B[0], H[0]
+    G = rng.standard_normal((p, ng, n)) if ng else None
+    ncs = rng.integers(0, nc + 1, size=p) if nc else [0] * p
+    C = [rng.standard_normal((ncs[k], n)) if ncs[k] else None for k in range(p)] if nc else None
+    kw = dict(G=G, rho=1e-2, force=True)
+    if C is not None:
+        kw.update(C=C)
+    r0 = co.sdp_step1(A, B, H, **kw)
+    r = co.sdp_step1(A, B, H, dict(tol=2.0 ** -37, tight=True), **kw)
+    assert r['ipm_status'] == r0['ipm_status'] == 'optimal' and r['polish_steps'] >= 1 and (r['T'] > 0).all()
+    Q = [H[k][:nx, :nx] for k in range(p)]; R = [H[k][nx:, nx:] for k in range(p)]; N = [H[k][:nx, nx:] for k in range(p)]
+    d = rs.solve_step(list(A), list(B), Q, R, N, G=None if G is None else list(G), C=C, rho=1e-2, constr=C is not None, force=True, tol=1e-9)
+    assert d['solver_status'] == 'optimal'
+    assert r['objective'] <= r0['objective']
+    assert abs(r['objective'] - d['objective']) <= 5e-8 * r['objective']               # (measured 1e-10 ... 8e-9)
+    assert abs(r['objective'] - d['objective']) < 0.1 * abs(r0['objective'] - d['objective'])
+    r2 = co.sdp_step1(A * (1 + 1e-14), B, H, dict(tol=2.0 ** -37, tight=True), **kw)
+    assert np.abs(r2['T'] - r['T']).max() <= 1e-7 * np.abs(r['T']).max()
