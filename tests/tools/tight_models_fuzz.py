@@ -11,13 +11,16 @@ from tunempc_amd._lib import HipConvexifier
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 97001
 members = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+nxmax = int(sys.argv[3]) if len(sys.argv) > 3 else 8          # largest nx
+rmax = int(sys.argv[4]) if len(sys.argv) > 4 else 3           # most rows of G and of C per stage
+pmax = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 rng = np.random.default_rng(seed)
 TOL = 2.0 ** -37
 done = 0; worst = 0.0; fell_back = 0; skipped = 0; backed_off = 0; bad = []
 t0 = time.time()
 while done < members:
-    p = int(rng.integers(1, 9)); nx = int(rng.integers(2, 9)); mb = int(rng.integers(1, 5)); n = nx + mb
-    ng = int(rng.integers(0, 4)); nc = int(rng.integers(0, 4)); model = ['G', 'step2', 'beta'][int(rng.integers(0, 3))]
+    p = int(rng.integers(1, pmax + 1)); nx = int(rng.integers(2, nxmax + 1)); mb = int(rng.integers(1, 5)); n = nx + mb
+    ng = int(rng.integers(0, rmax + 1)); nc = int(rng.integers(0, rmax + 1)); model = ['G', 'step2', 'beta'][int(rng.integers(0, 3))]
     if model == 'G':
         nc = 0; ng = max(ng, 1)
     else:
@@ -52,5 +55,5 @@ while done < members:
         worst = max(worst, e)
         if not (e < 1e-8 and int(o['status'][b]) == 0):
             bad.append(dict(model=model, p=p, nx=nx, mb=mb, ng=ng, nc=nc, b=b, err=e, status=int(o['status'][b])))
-print(json.dumps(dict(seed=seed, members=done, worst_rel_err=worst, fell_back_to_default=fell_back, oracle_at_other_target=backed_off, already_convex=skipped, mismatches=bad,
+print(json.dumps(dict(seed=seed, nx_max=nxmax, rows_max=rmax, p_max=pmax, members=done, worst_rel_err=worst, fell_back_to_default=fell_back, oracle_at_other_target=backed_off, already_convex=skipped, mismatches=bad,
                       seconds=round(time.time() - t0, 1))))
