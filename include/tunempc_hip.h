@@ -133,7 +133,7 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value);
  * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */
 int tmpc_create_ex(tmpc_handle** out, int chunk, int p, int nx, int mb, int ng, int nc, int step3, int lanes);
 
-/* Tight-accuracy mode (opt-in; Step 1 and Step 2 handles: plain with nx <= 51 and any nx + mb <= 64; with rows of G / C -- round 5 -- nx + mb <= 32 and
+/* Tight-accuracy mode (opt-in; Step 1 and Step 2 handles with nx <= 51 and nx + mb <= 64; with rows of G / C -- round 5 -- while
  * rows * (2 (nx + mb) + 2 nx) <= 4040; no Step 3).  The reference hands its SDP to MOSEK / CVXOPT, which stop at a relative gap of
  * ~1e-8 (convexifier.py:363); the default solve above stops at tol = 2^-25, a certified gap of (2*p*n+1)*3e-8 on kappa, because the HKM
  * Schur matrix (condition ~1/mu^2) cannot be factored in fp64 below mu ~ 1e-8.  With enable != 0 every problem that ended Optimal is

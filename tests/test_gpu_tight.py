@@ -128,7 +128,7 @@ def test_tight_dual_certificate(seed, nb, p, nx, mb):
 
 # ----------------------------------------------------------------------------- round 5: the mode for Step 1 with rows of G (cost-free multipliers, convexifier.py:249-255)
 @pytest.mark.parametrize('seed,nb,p,nx,mb,ng', [(100, 3, 4, 3, 2, 2), (101, 3, 6, 4, 2, 1), (102, 2, 3, 5, 3, 3), (103, 2, 8, 3, 1, 2), (105, 2, 1, 4, 2, 2), (106, 2, 5, 4, 4, 3),
-                                                (107, 1, 6, 10, 4, 2), (108, 1, 4, 16, 6, 3), (109, 1, 3, 24, 8, 4)])
+                                                (107, 1, 6, 10, 4, 2), (108, 1, 4, 16, 6, 3), (109, 1, 3, 24, 8, 4), (110, 1, 2, 28, 6, 2)])        # (the last: n = 34, generic per-stage kernels)
 def test_tight_with_equality_rows_vs_oracle(seed, nb, p, nx, mb, ng):
     """Tight mode on a handle with rows of G against the numpy oracle's tight mode (oracle/convexify_oracle.py: sdp_step1(tight=True, G=...), the multipliers as variables
     of the dd dual-Newton polish): Hc, the multipliers Fg, kappa and the barrier target, to the 1e-8 bar; the certificate of the exported dual iterate, numpy only."""
@@ -166,7 +166,7 @@ def test_tight_with_equality_rows_vs_oracle(seed, nb, p, nx, mb, ng):
 
 @pytest.mark.parametrize('seed,nb,p,nx,mb,ng,nc', [(300, 3, 4, 3, 2, 1, 2), (301, 3, 5, 4, 2, 0, 2), (302, 2, 3, 5, 3, 2, 3), (303, 2, 6, 3, 1, 1, 1), (304, 2, 2, 6, 2, 2, 2),
                                                    (306, 2, 6, 10, 4, 2, 3), (307, 1, 4, 16, 6, 1, 4), (308, 1, 3, 24, 8, 2, 5),
-                                                   (309, 2, 3, 4, 2, 17, 17)])        # (the last: 34 rows per stage -- k_phi_pre keeps its per-row vectors in global memory above 32)
+                                                   (309, 2, 3, 4, 2, 17, 17), (310, 1, 2, 28, 6, 1, 2)])        # (309: 34 rows per stage -- k_phi_pre keeps its per-row vectors in global memory above 32; 310: n = 34, generic per-stage kernels)
 def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
     """Tight mode on the Step 2 model (convexifier.py:116-131: multipliers of ragged C_k, norm terms rho ||F_k||, rho ||Fg_k|| as epigraph variables with arrow LMIs) against
     the numpy oracle's tight mode -- Hc, F, Fg, kappa, the barrier target to the 1e-8 bar -- and the certificate of the exported dual iterate (LMI blocks, multipliers,
@@ -214,12 +214,12 @@ def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
     print(f'tight mode on the Step 2 model p={p} n={n} ng={ng} nc={nc}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
 
 
-@pytest.mark.parametrize('model', ['G', 'step2'])
-def test_tight_certificate_with_rows_at_the_bench_shape(model):
+@pytest.mark.parametrize('model,p,nx,mb', [('G', 64, 24, 8), ('step2', 64, 24, 8), ('step2', 4, 32, 8), ('G', 3, 40, 8)])
+def test_tight_certificate_with_rows_at_the_bench_shape(model, p, nx, mb):
     """p = 64, nx = 24, mb = 8 with rows of G (and of C with the norm terms): no oracle at this size -- the certificate of the exported dual iterate alone, numpy only.
     kappa (+ sum t_e) is pinned from both sides to <= 1e-7 relative (certified gaps of the models with multipliers)."""
     from tunempc_amd._lib import HipConvexifier
-    p, nx, mb, nb, ng, nc, rho = 64, 24, 8, 2, 2, 3, 1e-2
+    nb, ng, nc, rho = 2, 2, 3, 1e-2            # (the last two shapes: 32 < n <= 64, generic per-stage kernels, Schur blocks of 535 / 822)
     n = nx + mb
     A, B, H = co.gen_batch(777, nb, p, nx, mb)
     rng = np.random.default_rng(778)
@@ -245,7 +245,7 @@ def test_tight_certificate_with_rows_at_the_bench_shape(model):
         primal, dobj, slack, gap = _certificate_con(A[b], B[b], H[b], J[b], rows[b], cnt[b], ng, rho, out, dual, dc, b, model == 'step2')
         assert dobj - slack <= primal
         width = (primal - (dobj - slack)) / primal
-        print(f'{model} at the bench shape, member {b}: certified relative gap {width:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e}), {int(out["iters"][b])} iterations')
+        print(f'{model} at p={p} n={n}, member {b}: certified relative gap {width:.3e} (N mu_t / value = {gap / primal:.3e}, residual slack {slack / primal:.1e}), {int(out["iters"][b])} iterations')
         assert width <= 1e-7
 
 
@@ -296,7 +296,7 @@ def test_dropin_convexify_tight_with_constraints():
 
 
 def test_tight_refused_where_the_mode_does_not_reach():
-    """Step 3 handles, rows on the generic kernels (n > 32), more rows than the LDS holds in double-double: TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
+    """Step 3 handles, more rows than the LDS holds in double-double (at any n): TMPC_E_UNSUPPORTED with a message, never a silent default solve"""
     from tunempc_amd._lib import HipConvexifier
     for kw in (dict(step3=True), dict(ng=1, nc=2, step3=True)):
         h = HipConvexifier(3, 3, 2, **kw)
@@ -307,7 +307,7 @@ def test_tight_refused_where_the_mode_does_not_reach():
     with pytest.raises(RuntimeError, match='tmpc_set_tight'):
         h.set_tight(True)
     h.close()
-    h = HipConvexifier(2, 30, 6, ng=2)
+    h = HipConvexifier(2, 40, 8, ng=12, nc=12)             # n = 48: 24 rows of 176 entries
     with pytest.raises(RuntimeError, match='tmpc_set_tight'):
         h.set_tight(True)
     h.close()

@@ -93,7 +93,7 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
     G [nb,p,ng,n] (optional): equality-constraint Jacobians; their multipliers Fg [nb,p,ng] (convexifier.py:249-255)
     join Step 1 and are returned as 'Fg'; dHc then includes G' diag(Fg) G (convexifier.py:196-197).
     tight: None / False: the default accuracy (mu_target = 2^-25 kappa); True or a tolerance: the tight-accuracy mode of the library (tmpc_set_tight:
-    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; plain model up to nx = 51, with rows of G up to nx + nu = 32)."""
+    continuation to tight_tol * kappa, default 2^-37, in double-double arithmetic; up to nx = 51; with rows of G while their double-double vectors fit the LDS: rows * (2 n + 2 nx) <= 4040)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     nb, p, nx, _ = A.shape
     mb = B.shape[3]
@@ -103,8 +103,6 @@ def convexify_batch(A, B, H, tol=None, handle=None, G=None, nc_hint=0, tight=Non
         ng = G.shape[2]
         if ng > NG_MAX:
             raise NotImplementedError('the HIP path handles up to {} equality-constraint rows per stage (got {})'.format(NG_MAX, ng))
-    if tight and ng > 0 and nx + mb > N_TUNED:
-        raise NotImplementedError('the tight-accuracy mode covers rows of G / C up to nx + nu = {} (got {})'.format(N_TUNED, nx + mb))
     if handle is not None:
         h = handle
     elif tight and ng > 0:
@@ -131,7 +129,7 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None, 
     C [nb,p,nc,n] active-constraint Jacobians zero-padded to nc rows, ncnt [nb,p] rows present per stage (0: C_k is None);
     G [nb,p,ng,n] optional.  Returns the dict of convexify_batch plus 'F' [nb,p,nc] (zeros in the padding) and, with G, 'Fg'.
     rho = 0: the beta-only objective (cost-free multipliers; see `convexify`, opts['objective']).
-    tight: as in convexify_batch (round 5: the mode covers this model, either objective, up to nx + nu = 32)."""
+    tight: as in convexify_batch (round 5: the mode covers this model, either objective)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
     C = np.asarray(C, dtype=np.float64); ncnt = np.asarray(ncnt, dtype=np.int32)
     nb, p, nx, _ = A.shape
@@ -143,8 +141,6 @@ def convexify_step2_batch(A, B, H, C, ncnt, rho, G=None, tol=None, handle=None, 
                                   '(got ng={}, nc={})'.format(NG_MAX, NC_MAX, ng, nc))
     if ncnt.shape != (nb, p) or (ncnt < 0).any() or (ncnt > nc).any():
         raise ValueError('ncnt must be an int array [nb, p] with 0 <= ncnt <= C.shape[2] = {}'.format(nc))
-    if tight and nx + mb > N_TUNED:
-        raise NotImplementedError('the tight-accuracy mode covers the Step 2 model up to nx + nu = {} (got {})'.format(N_TUNED, nx + mb))
     h = handle or (_handle(p, nx, mb, ng, nc, nb, exact=True) if tight else _handle(p, nx, mb, ng, nc, nb))
     if handle is None or tol is not None:
         h.set_options(tol=tol if tol is not None else DEFAULT_TOL)
@@ -287,7 +283,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     :param G: jacobian of equality constraints at steady state (ng, nx+nu)
     :param opts: tuning options {'rho', 'solver', 'force'}  (never mutated, unlike convexifier.py:89-91); 'tight': True or a tolerance -- Steps 1 and 2 in the
                  tight-accuracy mode of the library (relative gap on kappa N * 7e-12 instead of N * 3e-8, the accuracy MOSEK / CVXOPT stop at; with G or C
-                 up to nx + nu = 32; not with 'force': Step 3 has no tight mode -- NotImplementedError); one more key,
+                 while rows * (2 n + 2 nx) <= 4040; not with 'force': Step 3 has no tight mode -- NotImplementedError); one more key,
                  'objective': 'paper' (default) | 'beta'.  The reference assembles the Step 2/3 objective with
                  `picos.sum(obj, abs(rho*F[i]))` (convexifier.py:276-285).  In PICOS 1.2.0 the second positional parameter of
                  picos.sum may be an iterator label rather than a summand (unverifiable here, PICOS is not
@@ -317,8 +313,6 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
 
     if (opts or {}).get('tight') and (opts or {}).get('force', False):
         raise NotImplementedError("opts['tight'] covers Steps 1 and 2; it cannot be combined with opts['force'] (Step 3 has no tight mode)")
-    if (opts or {}).get('tight') and (C is not None or G is not None) and nx + nu > N_TUNED:
-        raise NotImplementedError("opts['tight'] with G or C covers nx + nu <= {} (got {})".format(N_TUNED, nx + nu))
     solver = (opts or {}).get('solver', 'hip')
     if solver not in ('hip', 'mosek', 'cvxopt'):
         raise ValueError("unknown solver '{}' (this build provides 'hip')".format(solver))

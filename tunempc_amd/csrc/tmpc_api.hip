@@ -927,7 +927,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   // algebra in double-double, then the dd dual-Newton polish (tmpc_dd.h)
   // (round 5: also the models with rows -- Step 1 with G, Step 2 with C and the norm terms: the multipliers and epigraph variables ride in the augmented blocks of
   // tmpc_phi.h, their rows formed in double-double (k_dd_aug_fill), and join the polish as variables: k_dd_polish_pre, k_polish_phi, k_polish_arrows)
-  if (h->tight && !t3 && wall.Dl && (!eq || !big)) {
+  if (h->tight && !t3 && wall.Dl) {
     // (round 5: chord steps also in this phase and in the polish -- a double-double factorisation costs ten fp64 ones, a step on an old one a tenth of it)
     Opts ot = o; ot.tight = 1; ot.tight_tol = h->tight_tol; ot.fast_exit = 0; ot.max_iter = 2 * o.max_iter;
     // where a factorisation costs ten fp64 ones and a step on the old one a twentieth of it, chord steps pay from a much shorter safe step on: threshold 3 instead of 10
@@ -961,8 +961,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
         WS wq = wall; wq.alist = fac;
         dd_schur_launch(wq, dm, nfp * dm.p, st);
         if (eq) {        // rows of the multipliers: vectors, T_loc,loc and border entries from the fp64 roundings of X_r = mu S_r^-1, S_r^-1 (the Hessian only sets the rate)
-          const bool bigr = dm.nr > NRS;
-          if (bigr) hipLaunchKernelGGL((k_phi_pre<false, true>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(false, true) * sizeof(double), st, wq, dm, 1);
+          const bool bigr = dm.nr > NRS, bign = dm.n > NMAX;
+          if (bign && bigr) hipLaunchKernelGGL((k_phi_pre<true, true>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(true, true) * sizeof(double), st, wq, dm, 1);
+          else if (bign) hipLaunchKernelGGL((k_phi_pre<true, false>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(true, false) * sizeof(double), st, wq, dm, 1);
+          else if (bigr) hipLaunchKernelGGL((k_phi_pre<false, true>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(false, true) * sizeof(double), st, wq, dm, 1);
           else hipLaunchKernelGGL((k_phi_pre<false, false>), dim3(nfp * dm.p), dim3(64), (size_t)phi_pre_lds(false, false) * sizeof(double), st, wq, dm, 1);
           hipLaunchKernelGGL(k_dd_aug_fill, dim3(nfp * dm.p), dim3(256), (size_t)dd_aug_lds_doubles(dm.nr, dm.n, dm.nx) * sizeof(double), st, wq, dm, 1);
         }
@@ -1190,7 +1192,6 @@ int tmpc_set_tight(tmpc_handle* h, int enable, double tight_tol) {
   if (!h) return TMPC_E_ARG;
   if (!enable) { h->tight = 0; return TMPC_OK; }
   if (h->dm.nT > 0) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: Steps 1 and 2 only (no Step 3 handles)"); return TMPC_E_UNSUPPORTED; }
-  if (h->dm.nr > 0 && h->dm.n > NMAX) { snprintf(g_err, sizeof(g_err), "tmpc_set_tight: with rows of G / C the mode covers nx + mb <= %d", NMAX); return TMPC_E_UNSUPPORTED; }
   if (h->dm.nr > 0 && (size_t)dd_aug_lds_doubles(h->dm.nr, h->dm.n, h->dm.nx) * sizeof(double) > 160 * 1024) {
     snprintf(g_err, sizeof(g_err), "tmpc_set_tight: %d rows per stage at nx = %d, nx + mb = %d: their double-double vectors do not fit the LDS (rows * (2 n + 2 nx) <= 4040)", h->dm.nr, h->dm.nx, h->dm.n);
     return TMPC_E_UNSUPPORTED;

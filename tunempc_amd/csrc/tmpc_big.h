@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(256) kb_polish_step(WS w, Dims dm) {
   const int kn = (k + 1 == dm.p) ? 0 : k + 1;
   double* dM = scr; double* t0 = scr + nn; double* t1 = scr + 2 * nn;
   gbuild_M(dM, t0, w.V + (size_t)sid * nx * n, w.Hb + so, w.dP + (size_t)sid * nxx, w.dP + (size_t)(b * dm.p + kn) * nxx, pr[P_DALPHA], n, nx);
+  if (dm.nr > 0) gadd_gtg(dM, w.G + (size_t)sid * dm.nr * n, w.dphi + (size_t)sid * dm.nr, 1.0, stage_rows(w, dm, sid), n);     // + J' diag(dphi) J (round 5: rows in the tight mode)
   const double ra = pr[P_DALPHA] / pr[P_ALPHA];
   double dh2 = 0.0, m2 = 0.0;
   for (int e = tid; e < nn; e += 256) { const double m = w.T1[so + e], dh = dM[e] - ra * m; dh2 = fma(dh, dh, dh2); m2 = fma(m, m, m2); }

@@ -689,10 +689,10 @@ constexpr int ARW_DOUBLES = 4 * AEL * ARW_LD + 8;              // S^-1 and X of 
 __host__ __device__ constexpr int dd_aug_lds_doubles(int nr, int n, int nx) { return 4 * nr * (2 * n + 2 * nx) + ARW_DOUBLES + 16; }       // rows of [G; C]: 125 KB at 31 rows, n = 32
 // Closed-form inverse of the arrow matrix S = [[t, u'], [u, t I]], u_i = wr phi_i (m entries), in dd: gam = t^2 - |u|^2 cancels to ~mu t on an active norm term
 // (k_phi_init has the fp64 form).  S^-1 = [[t, -u'], [-u, (gam / t) I + u u' / t]] / gam.  256 threads; Sih / Sil: ne x ne with leading dimension ARW_LD.
-// Returns gam (uniform); the caller checks t > 0 and gam > 0.  sc: 8 doubles of LDS.
+// Returns gam (uniform); the caller checks t > 0 and gam > 0.  sc: 8 doubles of LDS.  (Sih / Sil may be global memory -- the scratch of k_dd_polish_pre at n > 32: fences with the barriers.)
 __device__ __forceinline__ ddv arrow_inv_dd(double* Sih, double* Sil, double t, const double* phi, double wr, int m, double* sc) {
   const int tid = threadIdx.x, ne = m + 1;
-  __syncthreads();
+  __threadfence_block(); __syncthreads();
   if (tid == 0) {
     ddv usq = ddv{0.0, 0.0};
     for (int i = 0; i < m; ++i) { const ddv u = dd_tp(wr, phi[i]); usq = dd_add(usq, dd_mul(u, u)); }
@@ -700,7 +700,7 @@ __device__ __forceinline__ ddv arrow_inv_dd(double* Sih, double* Sil, double t, 
     const ddv gi = dd_div(dd_from(1.0), gam), ti = dd_div(dd_from(1.0), dd_from(t));
     sc[0] = gam.h; sc[1] = gam.l; sc[2] = gi.h; sc[3] = gi.l; sc[4] = ti.h; sc[5] = ti.l;
   }
-  __syncthreads();
+  __threadfence_block(); __syncthreads();
   const ddv gi = ddv{sc[2], sc[3]}, ti = ddv{sc[4], sc[5]};
   for (int e = tid; e < ne * ne; e += 256) {
     const int i = e / ne, j = e - i * ne;
@@ -713,7 +713,7 @@ __device__ __forceinline__ ddv arrow_inv_dd(double* Sih, double* Sil, double t, 
     }
     Sih[i * ARW_LD + j] = v.h; Sil[i * ARW_LD + j] = v.l;
   }
-  __syncthreads();
+  __threadfence_block(); __syncthreads();
   return ddv{sc[0], sc[1]};
 }
 __global__ void __launch_bounds__(256) k_dd_aug_fill(WS w, Dims dm, int polish) {
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(256) k_dd_polish_pre(WS w, Dims dm, int final_
   if (pst.na > 0) {
     const double wr = phi_wr(w, pr);
     __shared__ double sc[8];
-    double* Sih = t0.p; double* Sil = t0.p + t0.ms;                  // (t0 is free here; LDS slot of 32 x 33 = AEL x ARW_LD doubles per plane: handles with room for C rows have n <= 32)
+    double* Sih = t0.p; double* Sil = t0.p + t0.ms;                  // (t0 is free here: an LDS slot of 32 x 33 = AEL x ARW_LD doubles per plane, or n x n > that of the global scratch at n > 32)
     for (int e_ = 0; e_ < pst.na; ++e_) {
       const int m = pst.am[e_], ne = m + 1, c0 = pst.a0[e_];
       const double te = w.at[(size_t)sid * 2 + e_];
