@@ -145,6 +145,64 @@ def step2():
         print(name, 'kappa', out['kappa'], 'iters', out['iters'], 'objective', out['objective'])
 
 
+TIGHT_TOL = 2.0 ** -37
+
+
+def tight():
+    """Round 5: vectors of the tight-accuracy mode (sdp_step1(tight=True): continuation to 2^-37 kappa with the block algebra in double-double and the dd dual-Newton
+    polish) for the plain model, Step 1 with G and the Step 2 model -- the inputs of 'eq_term_n5' / 'step2_with_g_n6' and a plain pair, with the oracle's outputs in that
+    mode; cross-checked at generation time against the dense solver's objective (oracle/reference_sdp.py) and by a second run on inputs 1e-14 apart."""
+    def check(A, B, H, r, kw, dense_kw):
+        nx = A.shape[1]
+        r2 = co.sdp_step1(A * (1 + 1e-14), B, H, dict(tol=TIGHT_TOL, tight=True), **kw)
+        assert r['ipm_status'] == 'optimal' and np.abs(r2['P'] - r['P']).max() <= 1e-9 * np.abs(r['P']).max()
+        Q = [H[k][:nx, :nx] for k in range(len(A))]; R = [H[k][nx:, nx:] for k in range(len(A))]; N = [H[k][:nx, nx:] for k in range(len(A))]
+        d = rs.solve_step(list(A), list(B), Q, R, N, tol=1e-9, **dense_kw)
+        obj = r.get('objective', r['beta'])
+        assert d['solver_status'] == 'optimal' and abs(obj - d['objective']) <= 5e-8 * obj, (obj, d['objective'])
+    # plain
+    A, B, Hs = co.gen_batch(3, 2, 6, 4, 2)
+    out = dict(Hc=[], P=[], kappa=[], mu_target=[])
+    for b in range(2):
+        r = co.sdp_step1(A[b], B[b], Hs[b], dict(tol=TIGHT_TOL, tight=True))
+        check(A[b], B[b], Hs[b], r, {}, dict(constr=False))
+        r['Hc'] = Hs[b] + co.symmetrize(co.calH(A[b], B[b], r['P']))
+        for k in out:
+            out[k].append(r[k])
+    np.savez(os.path.join(HERE, 'tight_plain_n6.npz'), A=A, B=B, H=Hs, tol=TIGHT_TOL, **{k: np.array(v) for k, v in out.items()})
+    print('tight_plain_n6 kappa', out['kappa'])
+    # Step 1 with G
+    seed, nb, p, nx, mb, ng = EQ_CASES['eq_term_n5']
+    A, B, Hs = co.gen_batch(seed, nb, p, nx, mb)
+    G = np.random.default_rng(seed + 99).standard_normal((nb, p, ng, nx + mb))
+    out = dict(Hc=[], P=[], Fg=[], kappa=[], mu_target=[])
+    for b in range(nb):
+        r = co.sdp_step1(A[b], B[b], Hs[b], dict(tol=TIGHT_TOL, tight=True), G=G[b])
+        check(A[b], B[b], Hs[b], r, dict(G=G[b]), dict(G=list(G[b]), constr=False))
+        r['Hc'] = Hs[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'])[0]
+        for k in out:
+            out[k].append(r[k])
+    np.savez(os.path.join(HERE, 'tight_eq_term_n5.npz'), A=A, B=B, H=Hs, G=G, tol=TIGHT_TOL, **{k: np.array(v) for k, v in out.items()})
+    print('tight_eq_term_n5 kappa', out['kappa'])
+    # Step 2
+    seed, nb, p, nx, mb, ng, ncs, rho = STEP2_CASES['step2_with_g_n6']
+    A, B, Hs, G, C, ncnt = step2_inputs(seed, nb, p, nx, mb, ng, ncs)
+    out = dict(Hc=[], P=[], F=[], Fg=[], kappa=[], objective=[], mu_target=[])
+    for b in range(nb):
+        Cl = [C[b, k, :ncs[k]] if ncs[k] else None for k in range(p)]
+        r = co.sdp_step1(A[b], B[b], Hs[b], dict(tol=TIGHT_TOL, tight=True), G=G[b], C=Cl, rho=rho)
+        check(A[b], B[b], Hs[b], r, dict(G=G[b], C=Cl, rho=rho), dict(G=list(G[b]), C=Cl, rho=rho, constr=True))
+        Fp = np.zeros((p, max(ncs)))
+        for k in range(p):
+            if ncs[k]:
+                Fp[k, :ncs[k]] = r['F'][k]
+        r.update(Hc=Hs[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'], C=Cl, F=r['F'])[0], F=Fp)
+        for k in out:
+            out[k].append(r[k])
+    np.savez(os.path.join(HERE, 'tight_step2_with_g_n6.npz'), A=A, B=B, H=Hs, G=G, C=C, ncnt=ncnt, rho=rho, tol=TIGHT_TOL, **{k: np.array(v) for k, v in out.items()})
+    print('tight_step2_with_g_n6 kappa', out['kappa'], 'objective', out['objective'])
+
+
 def rblock_problem(p=2, nx=2, nu=1, seed=0):
     """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
     Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
@@ -180,8 +238,11 @@ if __name__ == '__main__':
         step2()
     elif sys.argv[1:] == ['c5']:
         c5()
+    elif sys.argv[1:] == ['tight']:
+        tight()
     else:
         main()
         equality_term()
         step2()
         c5()
+        tight()

@@ -249,6 +249,36 @@ def test_tight_certificate_with_rows_at_the_bench_shape(model, p, nx, mb):
         assert width <= 1e-7
 
 
+@pytest.mark.parametrize('name', ['tight_plain_n6', 'tight_eq_term_n5', 'tight_step2_with_g_n6'])
+def test_tight_golden_vectors_on_the_gpu(name):
+    """HIP library in the tight mode against the committed vectors tests/golden/tight_*.npz (inputs + the oracle's outputs in that mode; the file is data, the oracle does not run)"""
+    from tunempc_amd._lib import HipConvexifier
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
+    A, B, H = g['A'], g['B'], g['H']
+    nb, p, nx, _ = A.shape
+    mb = B.shape[3]
+    if 'C' in g.files:
+        ng, nc = g['G'].shape[2], g['C'].shape[2]
+        h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=nb)
+        h.set_tight(True, float(g['tol']))
+        out = h.convexify_step2_batch(A, B, H, np.concatenate([g['G'], g['C']], axis=2), g['ncnt'], float(g['rho']))
+        assert np.abs(out['FgF'][:, :, :ng] - g['Fg']).max() < PARITY * max(1.0, np.abs(g['Fg']).max())
+        assert np.abs(out['FgF'][:, :, ng:] - g['F']).max() < PARITY * max(1.0, np.abs(g['F']).max())
+    elif 'G' in g.files:
+        h = HipConvexifier(p, nx, mb, ng=g['G'].shape[2], chunk=nb)
+        h.set_tight(True, float(g['tol']))
+        out = h.convexify_eq_batch(A, B, H, g['G'])
+        assert np.abs(out['Fg'] - g['Fg']).max() < PARITY * max(1.0, np.abs(g['Fg']).max())
+    else:
+        h = HipConvexifier(p, nx, mb, chunk=nb)
+        h.set_tight(True, float(g['tol']))
+        out = h.convexify_batch(A, B, H)
+    h.close()
+    for b in range(nb):
+        assert int(out['status'][b]) == 0 and int(out['info'][b, 10]) == 0 and out['info'][b, 6] == g['mu_target'][b]
+        assert rel(out['Hc'][b], g['Hc'][b]) < PARITY and abs(out['kappa'][b] - g['kappa'][b]) < 1e-10 * g['kappa'][b]
+
+
 def test_tight_beta_only_objective_with_ragged_rows():
     """rho = 0 (the beta-only reading of convexifier.py:276-283: the rows of C_k are cost-free like those of G_k, but ragged) in the tight mode, against the oracle"""
     from tunempc_amd._lib import HipConvexifier

@@ -191,3 +191,23 @@ def test_tight_step3_against_the_dense_solver(seed, p, nx, mb, ng, nc):
     assert abs(r['objective'] - d['objective']) < 0.1 * abs(r0['objective'] - d['objective'])
     r2 = co.sdp_step1(A * (1 + 1e-14), B, H, dict(tol=2.0 ** -37, tight=True), **kw)
     assert np.abs(r2['T'] - r['T']).max() <= 1e-7 * np.abs(r['T']).max()
+
+
+@pytest.mark.parametrize('name', ['tight_plain_n6', 'tight_eq_term_n5', 'tight_step2_with_g_n6'])
+def test_tight_golden_vectors(name):
+    """tests/golden/tight_*.npz (make_golden.py tight): the oracle's tight mode reproduces the committed outputs (generated with the dense-solver and reproducibility checks
+    on); the GPU suite compares the HIP library with the same files (tests/test_gpu_tight.py::test_tight_golden_vectors_on_the_gpu)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+    A, B, H = g['A'], g['B'], g['H']
+    for b in range(A.shape[0]):
+        kw = {}
+        if 'G' in g.files:
+            kw['G'] = g['G'][b]
+        if 'C' in g.files:
+            ncs = g['ncnt'][b]
+            kw.update(C=[g['C'][b, k, :ncs[k]] if ncs[k] else None for k in range(A.shape[1])], rho=float(g['rho']))
+        r = co.sdp_step1(A[b], B[b], H[b], dict(tol=float(g['tol']), tight=True), **kw)
+        assert r['ipm_status'] == 'optimal' and r['mu_target'] == g['mu_target'][b]
+        assert np.abs(r['P'] - g['P'][b]).max() <= 1e-10 * np.abs(g['P'][b]).max() and abs(r['kappa'] - g['kappa'][b]) <= 1e-12 * g['kappa'][b]
+        if 'Fg' in g.files:
+            assert np.abs(r['Fg'] - g['Fg'][b]).max() <= 1e-10 * max(1.0, np.abs(g['Fg'][b]).max())
