@@ -242,3 +242,57 @@ def test_header_constants_match_the_python_mirror():
     lib = _lib.load_library()
     # the row limit is enforced by the library itself (workspace query: 0 = unsupported), not only by the mirror
     assert lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 31, 31) > 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 32, 0) == 0 and lib.tmpc_workspace_bytes_con(1, 3, 4, 2, 0, 32) == 0
+
+
+def test_tight_calls_take_handles_of_their_own(monkeypatch):
+    """Host logic of the tight-accuracy mode without a device (a recording stand-in for the handle class): a tight call never takes the shared handle of its shape --
+    a plain one without rows, or one with exactly the rows of the call -- the mode is switched off again in a `finally`, and tight together with `force` is refused
+    before anything is built (round 5: the mode covers G and Step 2)."""
+    from tunempc_amd import convexifier as cv
+    made = []
+
+    class Fake:
+        def __init__(self, p, nx, mb, chunk=0, ng=0, nc=0, step3=False, **kw):
+            self.p, self.nx, self.mb, self.chunk, self.ng, self.nc, self.step3 = p, nx, mb, chunk, ng, nc, step3
+            self.calls = []
+            made.append(self)
+
+        def set_options(self, **kw): pass
+        def set_tight(self, on, tol=None): self.calls.append(('tight', bool(on)))
+        def close(self): self.calls.append(('close',))
+
+        def _out(self, nb, extra):
+            n = self.nx + self.mb
+            o = dict(Hc=np.zeros((nb, self.p, n, n)), dHc=np.zeros((nb, self.p, n, n)), P=np.zeros((nb, self.p, self.nx, self.nx)), alpha=np.ones(nb), beta=np.ones(nb),
+                     kappa=np.ones(nb), status=np.zeros(nb, np.int32), iters=np.zeros(nb, np.int32), info=np.zeros((nb, 16)))
+            o.update(extra)
+            return o
+
+        def convexify_batch(self, A, B, H): self.calls.append(('plain',)); return self._out(A.shape[0], {})
+        def convexify_eq_batch(self, A, B, H, G): self.calls.append(('eq',)); return self._out(A.shape[0], dict(Fg=np.zeros((A.shape[0], self.p, self.ng))))
+        def convexify_step2_batch(self, A, B, H, J, ncnt, rho): self.calls.append(('step2',)); return self._out(A.shape[0], dict(FgF=np.zeros((A.shape[0], self.p, self.ng + self.nc))))
+
+    monkeypatch.setattr(cv, 'HipConvexifier', Fake)
+    monkeypatch.setattr(cv, '_HANDLES', type(cv._HANDLES)())
+    p, nx, mb, ng, nc = 3, 3, 2, 2, 2
+    A = np.zeros((1, p, nx, nx)); B = np.zeros((1, p, nx, mb)); H = np.zeros((1, p, nx + mb, nx + mb)); G = np.zeros((1, p, ng, nx + mb)); C = np.zeros((1, p, nc, nx + mb))
+    cnt = np.full((1, p), nc, np.int32)
+    cv.convexify_step2_batch(A, B, H, C, cnt, 1e-3, G=G)                    # the shared handle of the shape grows room for C rows
+    shared = made[-1]
+    cv.convexify_batch(A, B, H, G=G, tight=True)
+    h_eq = made[-1]
+    assert h_eq is not shared and (h_eq.ng, h_eq.nc) == (ng, 0) and h_eq.calls == [('tight', True), ('eq',), ('tight', False)]
+    cv.convexify_batch(A, B, H, tight=True)
+    h_plain = made[-1]
+    assert h_plain is not shared and h_plain is not h_eq and (h_plain.ng, h_plain.nc) == (0, 0) and h_plain.calls == [('tight', True), ('plain',), ('tight', False)]
+    cv.convexify_step2_batch(A, B, H, C, cnt, 1e-3, G=G, tight=True)
+    h_s2 = made[-1]
+    assert h_s2 is not shared and (h_s2.ng, h_s2.nc) == (ng, nc) and h_s2.calls == [('tight', True), ('step2',), ('tight', False)]
+    n_made = len(made)
+    cv.convexify_batch(A, B, H, G=G, tight=True)                              # cached: the same handle again
+    assert len(made) == n_made and h_eq.calls[-3:] == [('tight', True), ('eq',), ('tight', False)]
+    assert ('tight', True) not in shared.calls                                # the shared handle never saw the mode
+    Q = [np.eye(nx)] * p; R = [np.eye(mb)] * p; N = [np.zeros((nx, mb))] * p
+    with pytest.raises(NotImplementedError):
+        cv.convexify([np.eye(nx)] * p, [np.zeros((nx, mb))] * p, Q, R, N, opts={'tight': True, 'force': True})
+    assert len(made) == n_made
