@@ -202,7 +202,8 @@ class HipConvexifier:
 
     def set_tight(self, enable=True, tight_tol=None):
         """Tight-accuracy mode (include/tunempc_hip.h: tmpc_set_tight): continue every Optimal problem towards tight_tol * kappa (default 2^-37)
-        with double-double block linear algebra and a dd dual-Newton polish.  Plain Step 1 handles only (nx <= 51)."""
+        with double-double block linear algebra and a dd dual-Newton polish.  Step 1 and Step 2 handles (nx <= 51; with rows of G / C while
+        rows * (2 n + 2 nx) <= 4040); Step 3 handles are refused (RuntimeError from TMPC_E_UNSUPPORTED)."""
         _check(self.lib, self.lib.tmpc_set_tight(self._h, 1 if enable else 0, float(tight_tol or 0.0)), 'tmpc_set_tight')
 
     def close(self):

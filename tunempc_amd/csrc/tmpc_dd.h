@@ -21,7 +21,7 @@
 //
 // The dd kernels run on the vector ALU (the matrix cores have no extended format; emulating dd products on fp64 MFMA by
 // Ozaki slicing costs as many issue slots as the VALU form because fp64 MFMA and VALU share them on this part): ~12 VALU
-// operations per dd multiply-add, 64 x 64 output tiles, 4 x 4 register micro-tiles, K slabs of 16 through LDS.  Plain model only.
+// operations per dd multiply-add, 64 x 64 output tiles, 4 x 4 register micro-tiles, K slabs of 16 through LDS.  Round 5: also the models with rows (Step 1 with G, Step 2) -- k_dd_aug_fill, k_dd_solve_border, k_polish_phi, k_polish_arrows below; not Step 3.
 #pragma once
 #include "tmpc_common.h"
 #include "tmpc_small.h"
