@@ -214,7 +214,7 @@ def test_tight_step2_vs_oracle(seed, nb, p, nx, mb, ng, nc):
     print(f'tight mode on the Step 2 model p={p} n={n} ng={ng} nc={nc}: worst |Hc - oracle| / |oracle| = {worst:.2e}')
 
 
-@pytest.mark.parametrize('model,p,nx,mb', [('G', 64, 24, 8), ('step2', 64, 24, 8), ('step2', 4, 32, 8), ('G', 3, 40, 8)])
+@pytest.mark.parametrize('model,p,nx,mb', [('G', 64, 24, 8), ('step2', 64, 24, 8), ('step2', 4, 32, 8), ('G', 3, 40, 8), ('step2', 200, 20, 10)])      # (the last: the AWE shape of BASELINE configs[4], a Step 2 problem in the paper)
 def test_tight_certificate_with_rows_at_the_bench_shape(model, p, nx, mb):
     """p = 64, nx = 24, mb = 8 with rows of G (and of C with the norm terms): no oracle at this size -- the certificate of the exported dual iterate alone, numpy only.
     kappa (+ sum t_e) is pinned from both sides to <= 1e-7 relative (certified gaps of the models with multipliers)."""
