@@ -279,6 +279,48 @@ def test_tight_golden_vectors_on_the_gpu(name):
         assert rel(out['Hc'][b], g['Hc'][b]) < PARITY and abs(out['kappa'][b] - g['kappa'][b]) < 1e-10 * g['kappa'][b]
 
 
+@pytest.mark.parametrize('seed,p,nx,mb,ng,nc,model', [(0, 3, 3, 2, 2, 0, 'G'), (1, 4, 3, 2, 1, 2, 'step2'), (2, 2, 4, 2, 0, 2, 'step2'), (3, 3, 3, 1, 1, 2, 'beta'), (4, 5, 4, 2, 0, 0, 'plain')])
+def test_tight_objective_against_the_dense_solver(seed, p, nx, mb, ng, nc, model):
+    """The HIP library in the tight mode against oracle/reference_sdp.py directly -- the dense restatement of the complete reference model with a dense Mehrotra solver
+    that shares no line with the structured algorithm (neither the numpy oracle's nor the kernels'): the objective value beta + rho * (norm terms), which is
+    solver-independent, agrees to the dense solver's tolerance (1e-9), and the default mode is an order and more further away."""
+    import reference_sdp as rs
+    from tunempc_amd._lib import HipConvexifier
+    n = nx + mb
+    rng = np.random.default_rng(seed)
+    A, B, H = co.gen_batch(440 + seed, 1, p, nx, mb)
+    assert np.linalg.eigvalsh(H[0])[:, 0].min() < 0                      # (an indefinite member: the library returns early on a convex one, convexifier.py:83-85)
+    G = rng.standard_normal((1, p, ng, n)) if ng else None
+    ncs = (rng.integers(0, nc + 1, size=p) if nc else np.zeros(p, int)).astype(np.int32)
+    Cc = np.zeros((1, p, max(nc, 1), n))
+    for k in range(p):
+        Cc[0, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+    rho = 0.0 if model == 'beta' else 1e-2
+    h = HipConvexifier(p, nx, mb, ng=ng, nc=nc, chunk=1)
+
+    def run():
+        if model == 'plain':
+            o = h.convexify_batch(A, B, H); return o['beta'][0]
+        if model == 'G':
+            o = h.convexify_eq_batch(A, B, H, G); return o['beta'][0]
+        J = np.concatenate([G, Cc], axis=2) if ng else Cc
+        o = h.convexify_step2_batch(A, B, H, J, ncs[None], rho)
+        t = h.dual_con(1, arrows=True)['at'][0] if rho > 0 else np.zeros((p, 2))
+        na = (1 if ng else 0) + (ncs > 0)                                  # arrow blocks present at each stage
+        return (o['kappa'][0] + sum(t[k, :na[k]].sum() for k in range(p))) / o['info'][0, 1]
+    obj0 = run()
+    h.set_tight(True, TIGHT_TOL)
+    obj = run()
+    h.close()
+    Q = [H[0, k][:nx, :nx] for k in range(p)]; R = [H[0, k][nx:, nx:] for k in range(p)]; N = [H[0, k][:nx, nx:] for k in range(p)]
+    Cl = [Cc[0, k, :ncs[k]] if ncs[k] else None for k in range(p)] if nc else None
+    d = rs.solve_step(list(A[0]), list(B[0]), Q, R, N, G=None if G is None else list(G[0]), C=Cl, rho=rho, constr=model in ('step2', 'beta'), tol=1e-9)
+    assert d['solver_status'] == 'optimal'
+    print(f'{model} p={p} n={n}: objective tight {obj:.12f} default {obj0:.12f} dense {d["objective"]:.12f}')
+    assert abs(obj - d['objective']) <= 5e-8 * obj
+    assert abs(obj - d['objective']) < 0.1 * abs(obj0 - d['objective'])
+
+
 def test_tight_beta_only_objective_with_ragged_rows():
     """rho = 0 (the beta-only reading of convexifier.py:276-283: the rows of C_k are cost-free like those of G_k, but ragged) in the tight mode, against the oracle"""
     from tunempc_amd._lib import HipConvexifier
