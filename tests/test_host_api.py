@@ -292,6 +292,19 @@ def test_tight_calls_take_handles_of_their_own(monkeypatch):
     cv.convexify_batch(A, B, H, G=G, tight=True)                              # cached: the same handle again
     assert len(made) == n_made and h_eq.calls[-3:] == [('tight', True), ('eq',), ('tight', False)]
     assert ('tight', True) not in shared.calls                                # the shared handle never saw the mode
+    # the step logic of a batch passes the mode to both steps: Step 1 on the handle with the rows of G, Step 2 (members that came back Infeasible) on the one with G and C
+    class Infeasible(Fake):
+        def convexify_eq_batch(self, A, B, H, G):
+            o = Fake.convexify_eq_batch(self, A, B, H, G); o['status'][:] = 2; return o
+    monkeypatch.setattr(cv, 'HipConvexifier', Infeasible)
+    monkeypatch.setattr(cv, '_HANDLES', type(cv._HANDLES)())
+    n0 = len(made)
+    o = cv.convexify_steps_batch(A, B, H, G=G, C=C, ncnt=cnt, rho=1e-3, tight=True)
+    assert list(o['step']) == [2] and len(made) == n0 + 2
+    assert made[n0].calls == [('tight', True), ('eq',), ('tight', False)] and (made[n0].ng, made[n0].nc) == (ng, 0)
+    assert made[n0 + 1].calls == [('tight', True), ('step2',), ('tight', False)] and (made[n0 + 1].ng, made[n0 + 1].nc) == (ng, nc)
+    monkeypatch.setattr(cv, 'HipConvexifier', Fake)
+    n_made = len(made)
     Q = [np.eye(nx)] * p; R = [np.eye(mb)] * p; N = [np.zeros((nx, mb))] * p
     with pytest.raises(NotImplementedError):
         cv.convexify([np.eye(nx)] * p, [np.zeros((nx, mb))] * p, Q, R, N, opts={'tight': True, 'force': True})

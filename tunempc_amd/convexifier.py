@@ -210,14 +210,15 @@ def convexify_step3_batch(A, B, H, rho, tol=None, handle=None, G=None, C=None, n
     return out
 
 
-def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None):
+def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None, tight=None):
     """The step logic of convexify() (convexifier.py:98-131) for a whole batch: Step 1 for every problem (with the equality-
     constraint multipliers when G is given), then the Step 2 model for the members that came back Infeasible, when C is given.
     Inputs as in convexify_batch / convexify_step2_batch.  Returns the dict of convexify_batch with the Step 2 results merged
     in, plus 'step' [nb] (0: already convex, 1, 2), 'F' [nb,p,nc] (zeros where Step 1 sufficed) and, with G, 'Fg'.
-    Members that are still Infeasible keep status 2 (convexify() raises for them; a batch does not abort)."""
+    Members that are still Infeasible keep status 2 (convexify() raises for them; a batch does not abort).
+    tight: as in convexify_batch, for both steps (round 5)."""
     A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64); H = np.asarray(H, dtype=np.float64)
-    out = convexify_batch(A, B, H, tol=tol, G=G)
+    out = convexify_batch(A, B, H, tol=tol, G=G, tight=tight)
     nb, p = A.shape[:2]
     out['step'] = np.where(out['info'][:, 13] != 0.0, 0, 1).astype(np.int32)
     if C is None:
@@ -228,7 +229,7 @@ def convexify_steps_batch(A, B, H, G=None, C=None, ncnt=None, rho=1e-3, tol=None
     out['F'] = np.zeros((nb, p, C.shape[2]))
     redo = np.where(out['status'] == 2)[0]
     if redo.size:
-        r2 = convexify_step2_batch(A[redo], B[redo], H[redo], C[redo], ncnt[redo], rho, G=None if G is None else np.asarray(G)[redo], tol=tol)
+        r2 = convexify_step2_batch(A[redo], B[redo], H[redo], C[redo], ncnt[redo], rho, G=None if G is None else np.asarray(G)[redo], tol=tol, tight=tight)
         for key, val in r2.items():
             out[key][redo] = val
         out['step'][redo] = 2
