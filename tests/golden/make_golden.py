@@ -203,6 +203,25 @@ def tight():
     print('tight_step2_with_g_n6 kappa', out['kappa'], 'objective', out['objective'])
 
 
+def tight_step3():
+    """The oracle's tight mode on the Step 3 model (second-order cone in the polish): a vector for the kernels to come -- tmpc_set_tight refuses Step 3 handles so far."""
+    p, nx, mb, rho = 3, 3, 2, 1e-2
+    A, B, Hs = co.gen_batch(501, 2, p, nx, mb)
+    out = dict(Hc=[], P=[], T=[], kappa=[], objective=[], mu_target=[])
+    for b in range(2):
+        r = co.sdp_step1(A[b], B[b], Hs[b], dict(tol=TIGHT_TOL, tight=True), rho=rho, force=True)
+        r2 = co.sdp_step1(A[b] * (1 + 1e-14), B[b], Hs[b], dict(tol=TIGHT_TOL, tight=True), rho=rho, force=True)
+        assert r['ipm_status'] == 'optimal' and np.abs(r2['T'] - r['T']).max() <= 1e-7 * np.abs(r['T']).max()
+        Q = [Hs[b][k][:nx, :nx] for k in range(p)]; R = [Hs[b][k][nx:, nx:] for k in range(p)]; N = [Hs[b][k][:nx, nx:] for k in range(p)]
+        d = rs.solve_step(list(A[b]), list(B[b]), Q, R, N, rho=rho, constr=False, force=True, tol=1e-9)
+        assert d['solver_status'] == 'optimal' and abs(r['objective'] - d['objective']) <= 5e-8 * r['objective']
+        r['Hc'] = Hs[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], T=r['T'])[0]
+        for k in out:
+            out[k].append(r[k])
+    np.savez(os.path.join(HERE, 'tight_step3_n5.npz'), A=A, B=B, H=Hs, rho=rho, tol=TIGHT_TOL, **{k: np.array(v) for k, v in out.items()})
+    print('tight_step3_n5 kappa', out['kappa'], 'objective', out['objective'])
+
+
 def rblock_problem(p=2, nx=2, nu=1, seed=0):
     """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
     Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
@@ -240,9 +259,11 @@ if __name__ == '__main__':
         c5()
     elif sys.argv[1:] == ['tight']:
         tight()
+        tight_step3()
     else:
         main()
         equality_term()
         step2()
         c5()
         tight()
+        tight_step3()

@@ -193,7 +193,7 @@ def test_tight_step3_against_the_dense_solver(seed, p, nx, mb, ng, nc):
     assert np.abs(r2['T'] - r['T']).max() <= 1e-7 * np.abs(r['T']).max()
 
 
-@pytest.mark.parametrize('name', ['tight_plain_n6', 'tight_eq_term_n5', 'tight_step2_with_g_n6'])
+@pytest.mark.parametrize('name', ['tight_plain_n6', 'tight_eq_term_n5', 'tight_step2_with_g_n6', 'tight_step3_n5'])
 def test_tight_golden_vectors(name):
     """tests/golden/tight_*.npz (make_golden.py tight): the oracle's tight mode reproduces the committed outputs (generated with the dense-solver and reproducibility checks
     on); the GPU suite compares the HIP library with the same files (tests/test_gpu_tight.py::test_tight_golden_vectors_on_the_gpu)."""
@@ -206,8 +206,13 @@ def test_tight_golden_vectors(name):
         if 'C' in g.files:
             ncs = g['ncnt'][b]
             kw.update(C=[g['C'][b, k, :ncs[k]] if ncs[k] else None for k in range(A.shape[1])], rho=float(g['rho']))
+        if 'T' in g.files:                       # Step 3 (the library has no tight mode for it yet: the vector pins the oracle's definition)
+            kw.update(rho=float(g['rho']), force=True)
         r = co.sdp_step1(A[b], B[b], H[b], dict(tol=float(g['tol']), tight=True), **kw)
         assert r['ipm_status'] == 'optimal' and r['mu_target'] == g['mu_target'][b]
+        if 'T' in g.files:
+            assert np.abs(r['T'] - g['T'][b]).max() <= 1e-9 * np.abs(g['T'][b]).max() and abs(r['kappa'] - g['kappa'][b]) <= 1e-11 * g['kappa'][b]
+            continue
         assert np.abs(r['P'] - g['P'][b]).max() <= 1e-10 * np.abs(g['P'][b]).max() and abs(r['kappa'] - g['kappa'][b]) <= 1e-12 * g['kappa'][b]
         if 'Fg' in g.files:
             assert np.abs(r['Fg'] - g['Fg'][b]).max() <= 1e-10 * max(1.0, np.abs(g['Fg'][b]).max())
