@@ -20,6 +20,8 @@ for seed, (p, nx, mb, ng, nb) in enumerate([(4, 3, 2, 2, 3), (6, 4, 2, 1, 3), (3
     o = h.convexify_eq_batch(A, B, H, G)
     h.close()
     for b in range(nb):
+        if o['info'][b, 13] != 0.0:
+            print(f'p={p} nx={nx} mb={mb} b={b}: already convex (convexifier.py:83-85), nothing solved'); continue
         r = co.sdp_step1(A[b], B[b], H[b], dict(tol=2.0 ** -37, tight=True), G=G[b])
         Hc = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b], Fg=r['Fg'])[0]
         e = np.linalg.norm(o['Hc'][b] - Hc) / np.linalg.norm(Hc)

@@ -26,6 +26,8 @@ for seed, (p, nx, mb, ng, nc, nb) in enumerate([(4, 3, 2, 1, 2, 3), (5, 4, 2, 0,
     o = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
     h.close()
     for b in range(nb):
+        if o['info'][b, 13] != 0.0:
+            print(f'p={p} nx={nx} mb={mb} b={b}: already convex (convexifier.py:83-85), nothing solved'); continue
         Cl = [Cc[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
         r = co.sdp_step1(A[b], B[b], H[b], dict(tol=2.0 ** -37, tight=True), G=G[b] if ng else None, C=Cl, rho=rho)
         Hc = H[b] + co.convex_hessian_suppl(A[b], B[b], r['P'], G=G[b] if ng else None, Fg=r.get('Fg'), C=Cl, F=r['F'])[0]
