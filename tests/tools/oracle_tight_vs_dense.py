@@ -1,5 +1,7 @@
 """CPU only: the numpy oracle's tight mode (Step 1 with G, Step 2, beta-only objective, Step 3) against the dense solver of oracle/reference_sdp.py on random small problems:
-objective values to the dense solver's tolerance.  python tests/tools/oracle_tight_vs_dense.py  (round 5: 33 members compared, all Optimal, worst 5.0e-8)"""
+objective values to the dense solver's tolerance.  python tests/tools/oracle_tight_vs_dense.py  (round 5: 33 members compared, all Optimal, worst 5.0e-8 -- a Step 2 member
+with rho = 1e-3 whose dense objective moves 0.00214349356821 / ...243776 / ...233568 at tol 1e-8 / 1e-9 / 1e-10 towards the oracle's 0.00214349233162 (2^-37) and ...233142 (2^-41):
+the dense solver's tolerance, not the oracle, sets the distance)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'oracle'))
 import numpy as np, convexify_oracle as co, reference_sdp as rs
