@@ -321,6 +321,45 @@ def test_tight_objective_against_the_dense_solver(seed, p, nx, mb, ng, nc, model
     assert abs(obj - d['objective']) < 0.1 * abs(obj0 - d['objective'])
 
 
+@pytest.mark.parametrize('model', ['plain', 'G', 'step2'])
+def test_tight_member_alone_equals_member_in_a_batch(model):
+    """Regression test of the two defects the certificates of round 5 uncovered: a member solved alone and the same member inside a batch whose other members take more
+    iterations (it WAITS for the polish while they iterate; another one needs a third polish step) must return the same point AND export the same dual iterate.  (The multiplier
+    updates of the loop used to run on waiting members; the polish used the list of its members as a scratch buffer, and the member at its head missed the final sweep.)"""
+    from tunempc_amd._lib import HipConvexifier
+    seed, nb, p, nx, mb, ng, nc = 101, 3, 6, 4, 2, 1, 2
+    n = nx + mb
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((nb, p, ng, n)); Cc = rng.standard_normal((nb, p, nc, n))
+    ncnt = np.random.default_rng(7).integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            Cc[b, k, ncnt[b, k]:] = 0.0
+    J = np.concatenate([G, Cc], axis=2)
+
+    def solve(sel):
+        kw = {} if model == 'plain' else (dict(ng=ng) if model == 'G' else dict(ng=ng, nc=nc))
+        h = HipConvexifier(p, nx, mb, chunk=len(sel), **kw)
+        h.set_tight(True, TIGHT_TOL)
+        if model == 'plain':
+            o = h.convexify_batch(A[sel], B[sel], H[sel])
+        elif model == 'G':
+            o = h.convexify_eq_batch(A[sel], B[sel], H[sel], G[sel])
+        else:
+            o = h.convexify_step2_batch(A[sel], B[sel], H[sel], J[sel], ncnt[sel], 1e-2)
+        d = h.dual(len(sel))
+        h.close()
+        return o, d
+    ob, db = solve([0, 1, 2])
+    assert (ob['info'][:, 10] == 0).all() and len(set(ob['iters'].tolist())) > 1              # members finish at different iterations: some wait
+    for b in range(nb):
+        oa, da = solve([b])
+        assert int(oa['iters'][0]) == int(ob['iters'][b]) and oa['info'][0, 6] == ob['info'][b, 6]
+        assert rel(ob['Hc'][b], oa['Hc'][0]) < 1e-13 and abs(ob['kappa'][b] - oa['kappa'][0]) <= 1e-14 * oa['kappa'][0]
+        assert rel(db['X1'][b], da['X1'][0]) < 1e-9 and rel(db['X2'][b], da['X2'][0]) < 1e-9 and abs(db['x0'][b] - da['x0'][0]) <= 1e-9 * da['x0'][0]
+
+
 def test_tight_beta_only_objective_with_ragged_rows():
     """rho = 0 (the beta-only reading of convexifier.py:276-283: the rows of C_k are cost-free like those of G_k, but ragged) in the tight mode, against the oracle"""
     from tunempc_amd._lib import HipConvexifier
