@@ -210,12 +210,13 @@ struct Problem {
   vec V, Hb;                      // [p][nx][n], [p][n][n]
   std::vector<int> ia, ib;        // svec index -> (a, c), a <= c, row-major upper triangle
 
-  // block system (column-major d x d blocks)
+  // block system (column-major db x db blocks; db = d for the plain model, d + stage-local variables for the models with rows: cpu_ipm_con.h)
+  int db = 0;
   vec D, Csub, Lkk, O, F, Ldense;
   double shift = 0.0;
 
   void setup(int p_, int nx_, int mb_, const double* A_, const double* B_, const double* H_) {
-    p = p_; nx = nx_; mb = mb_; n = nx + mb; d = nx * (nx + 1) / 2; A = A_; B = B_; H = H_;
+    p = p_; nx = nx_; mb = mb_; n = nx + mb; d = nx * (nx + 1) / 2; db = d; A = A_; B = B_; H = H_;
     V.assign((size_t)p * nx * n, 0.0);
     for (int k = 0; k < p; ++k)
       for (int i = 0; i < nx; ++i)
@@ -270,14 +271,14 @@ struct Problem {
         const double wr = (a == b) ? 0.5 : 1.0;
         const double t = (L[a * nx + cc] * R[b * nx + dd] + L[a * nx + dd] * R[b * nx + cc]) + (L[b * nx + cc] * R[a * nx + dd] + L[b * nx + dd] * R[a * nx + cc]);
         const double v = sg * wr * wc * t;
-        if (tr) M[(size_t)r * d + c] += v; else M[(size_t)c * d + r] += v;      // column-major: entry (row r, col c) at c*d + r
+        if (tr) M[(size_t)r * db + c] += v; else M[(size_t)c * db + r] += v;      // column-major: entry (row r, col c) at c*db + r
       }
     }
   }
 
   // Cholesky of the block-cyclic-tridiagonal matrix: diagonal blocks D[k], Csub[k] = block [k+1][k] (k < p-1), Csub[p-1] = block [p-1][0]
   bool factor_once(double sh) {
-    const int dd_ = d; const double one = 1.0, mone = -1.0, zero = 0.0; int info;
+    const int dd_ = db, d = db; const double one = 1.0, mone = -1.0, zero = 0.0; int info;
     const size_t bs = (size_t)d * d;
     if (p <= 2) {
       const int N = p * d;
@@ -338,7 +339,7 @@ struct Problem {
   }
   // R [p][d] x nrhs, stored as nrhs column-major panels: R[(q*p + k)*d + i]
   void solve(double* R, int nrhs) const {
-    const double one = 1.0, mone = -1.0; const int dd_ = d; const size_t bs = (size_t)d * d;
+    const double one = 1.0, mone = -1.0; const int dd_ = db, d = db; const size_t bs = (size_t)d * d;
     for (int q = 0; q < nrhs; ++q) {
       double* z = R + (size_t)q * p * d;
       const int i1 = 1;
@@ -889,6 +890,8 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
   return res;
 }
 
+#include "cpu_ipm_con.h"
+
 }  // namespace
 
 extern "C" {
@@ -940,6 +943,35 @@ int cpu_ipm_convexify_batch2(int nb, int p, int nx, int mb, const double* A, con
     if (info) { info[4 * b] = r.mu_t; info[4 * b + 1] = r.dd_iters; info[4 * b + 2] = r.polish; info[4 * b + 3] = r.stepn; }
   }
   omp_set_num_threads(saved);
+  scipy_openblas_set_num_threads(blas_threads_before);
+  return 0;
+}
+
+// The models with rows (cpu_ipm_con.h): Step 1 with G, Step 2 (either objective), Step 3, Step 3 with rows.
+// J [nb][p][ng0 + ncmax][n]: rows of G_k, then the rows of C_k padded to ncmax; ncnt [nb][p] active rows of C_k (NULL: all ncmax).
+// flags: 1 constr (Step 2: the rows of C_k take part, norm terms with weight rho), 2 cost_free (beta-only objective), 4 force (Step 3).
+// Outputs: Hc [nb][p][n][n], P [nb][p][nx][nx], FgF [nb][p][ng0 + ncmax] (padding zero), T [nb][p][n][n] (may be NULL), kappa, objective, status, iters.
+int cpu_ipm_convexify_con_batch(int nb, int p, int nx, int mb, int ng0, int ncmax, const double* A, const double* B, const double* H, const double* J,
+                                const int32_t* ncnt, double rho, int flags, double tol, int threads, double* Hc, double* P, double* FgF, double* T,
+                                double* kappa, double* objective, int32_t* status, int32_t* iters) {
+  if (nb < 0 || p < 1 || nx < 1 || mb < 0 || ng0 < 0 || ncmax < 0 || !A || !H || !Hc || ((ng0 + ncmax) > 0 && !J)) return -1;
+  const int n = nx + mb, nJ = ng0 + ncmax;
+  if (tol <= 0.0) tol = 0x1p-25;
+  const int blas_threads_before = scipy_openblas_get_num_threads();
+  scipy_openblas_set_num_threads(1);
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int b = 0; b < nb; ++b) {
+    ConIn ci; ci.ng0 = ng0; ci.ncmax = ncmax; ci.J = J ? J + (size_t)b * p * nJ * n : nullptr; ci.ncnt = ncnt ? ncnt + (size_t)b * p : nullptr;
+    ci.rho = rho; ci.constr = (flags & 1) != 0; ci.cost_free = (flags & 2) != 0; ci.force = (flags & 4) != 0;
+    ConOut co; co.P = P ? P + (size_t)b * p * nx * nx : nullptr; co.FgF = FgF ? FgF + (size_t)b * p * nJ : nullptr; co.T = T ? T + (size_t)b * p * n * n : nullptr;
+    const Result r = solve_problem_con(p, nx, mb, A + (size_t)b * p * nx * nx, B + (size_t)b * p * nx * mb, H + (size_t)b * p * n * n, ci, tol, 50, 12, 1e-9,
+                                       Hc + (size_t)b * p * n * n, co);
+    if (kappa) kappa[b] = r.kappa;
+    if (objective) objective[b] = co.objective;
+    if (status) status[b] = r.status;
+    if (iters) iters[b] = r.iters;
+  }
   scipy_openblas_set_num_threads(blas_threads_before);
   return 0;
 }
