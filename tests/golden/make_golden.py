@@ -222,6 +222,45 @@ def tight_step3():
     print('tight_step3_n5 kappa', out['kappa'], 'objective', out['objective'])
 
 
+def awe_step2():
+    """Round 6: the Step 2 model at the REAL AWE shape -- the one constrained example the reference convexifies on a real system (paper p.5:
+    p = 40, nx = 9, m = 6, Step 2 with eta_F = 1; examples/awe_system/prepare_inputs.py:86, main.py:56 with Tuner.convexify's default rho = 1.0,
+    tuner.py:134): the inputs of 'awe_shape_n15' with ng = 3 rows of G_k and ragged active sets C_k of 0..4 rows (pocp.py:325-339 leaves None where
+    no constraint is active), solved by the structured numpy oracle in the default mode and in the tight mode; both cross-checked against
+    oracle/cpu_ipm (an independent elimination order) and, for the tight point, by a second run on inputs 1e-14 apart."""
+    import cpu_ipm
+    seed, nb, p, nx, mb, _ = CASES['awe_shape_n15']
+    ng, rho = 3, 1.0
+    n = nx + mb
+    A, B, Hs = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed + 5)
+    ncs = rng.integers(0, 5, size=p)
+    G = rng.standard_normal((nb, p, ng, n)); C = np.zeros((nb, p, 4, n)); ncnt = np.tile(ncs.astype(np.int32), (nb, 1))
+    for k in range(p):
+        C[0, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+    Cl = [C[0, k, :ncs[k]] if ncs[k] else None for k in range(p)]
+    out = {}
+    for tag, o in (('', None), ('_tight', dict(tol=TIGHT_TOL, tight=True))):
+        r = co.sdp_step1(A[0], B[0], Hs[0], o, G=G[0], C=Cl, rho=rho)
+        st, dHc = co.check_convergence(A[0], B[0], Hs[0], r['P'], r['ipm_status'], G=G[0], Fg=r['Fg'], C=Cl, F=r['F'])[:2]
+        assert st == co.STATUS_OPTIMAL and r['ipm_status'] == 'optimal'
+        Fp = np.zeros((p, 4))
+        for k in range(p):
+            if ncs[k]:
+                Fp[k, :ncs[k]] = r['F'][k]
+        if tag:
+            r2 = co.sdp_step1(A[0] * (1 + 1e-14), B[0], Hs[0], o, G=G[0], C=Cl, rho=rho)
+            assert np.abs(r2['P'] - r['P']).max() <= 1e-9 * np.abs(r['P']).max()
+        else:
+            c = cpu_ipm.convexify_con_batch(A, B, Hs, np.concatenate([G, C], axis=2), ng=ng, ncnt=ncnt, rho=rho)
+            assert np.linalg.norm(c['Hc'][0] - Hs[0] - dHc) <= 2e-9 * np.linalg.norm(Hs[0] + dHc) and abs(c['kappa'][0] - r['kappa']) <= 1e-10 * r['kappa']
+        for key, v in (('Hc', Hs[0] + dHc), ('P', r['P']), ('Fg', r['Fg']), ('F', Fp), ('kappa', r['kappa']), ('objective', r['objective']),
+                       ('mu_target', r['mu_target']), ('iters', r['iters'])):
+            out[key + tag] = np.asarray(v)[None]
+        print('awe_step2_n15' + tag, 'kappa', r['kappa'], 'objective', r['objective'], 'iters', r['iters'])
+    np.savez(os.path.join(HERE, 'awe_step2_n15.npz'), A=A, B=B, H=Hs, G=G, C=C, ncnt=ncnt, rho=rho, tol=co.DEFAULT_OPTS['tol'], tight_tol=TIGHT_TOL, **out)
+
+
 def rblock_problem(p=2, nx=2, nu=1, seed=0):
     """B_k = 0, R_k < 0 (Step 1 infeasible: the R block of Hc_k can only come from the constraint / regularisation terms),
     Q_k = I, N_k = 0; Cu = rows reaching exactly the input directions."""
@@ -260,6 +299,8 @@ if __name__ == '__main__':
     elif sys.argv[1:] == ['tight']:
         tight()
         tight_step3()
+    elif sys.argv[1:] == ['awe']:
+        awe_step2()
     else:
         main()
         equality_term()
@@ -267,3 +308,4 @@ if __name__ == '__main__':
         c5()
         tight()
         tight_step3()
+        awe_step2()

@@ -1516,3 +1516,23 @@ def test_persistent_kernel_takes_batches_by_itself():
     keep = np.delete(np.arange(nb), [7])                    # (the infeasible member returns wherever its diverging iteration stopped: nothing to compare)
     assert rel(res[2][0]['Hc'][keep], res[0][0]['Hc'][keep]) < 1e-9
     assert res[2][0]['status'][7] == res[0][0]['status'][7] == 2
+
+
+@pytest.mark.parametrize('seed,nb,p,nx,mb', [(47, 3, 40, 4, 1), (48, 2, 100, 3, 2), (49, 4, 23, 5, 3)])
+def test_persistent_kernel_last_update_of_every_stage(seed, nb, p, nx, mb):
+    """in k_ipm_small thread 0 ran the control body that may end the problem (PH_DONE) while other waves were still taking their stages through
+    update_body, which returns at once on PH_DONE -- a wave handling several stages (p > 16) could skip the LAST update of its later stages.  With TMPC_FLAG_FAST_EXIT
+    the skipped update is a whole centering step of the stage (1e-3 ... 1e-2 of Hc); with the barrier both paths stop after the same step of every stage and differ by
+    the rounding the not-yet-converged point amplifies (measured 2e-7 ... 5e-6 on these shapes; converged points agree to 1e-10), run to run identically."""
+    from tunempc_amd._lib import HipConvexifier, FLAG_FAST_EXIT
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    outs = []
+    for mode in (2, 2, 0):
+        h = HipConvexifier(p, nx, mb, chunk=nb, flags=FLAG_FAST_EXIT)
+        h.set_tuning(persistent=mode)
+        outs.append(h.convexify_batch(A, B, H))
+        h.close()
+    a, a2, s = outs
+    assert (a['status'] == 0).all() and np.array_equal(a['status'], s['status']) and np.array_equal(a['iters'], s['iters'])
+    assert np.array_equal(a['Hc'], a2['Hc'])                # deterministic
+    assert rel(a['Hc'], s['Hc']) < 1e-4 and rel(a['P'], s['P']) < 1e-4

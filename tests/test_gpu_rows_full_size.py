@@ -1,0 +1,180 @@
+"""The models WITH ROWS (Step 1 with G, Step 2, Step 3) value-checked at the sizes BASELINE.json names (run with -m gpu on an MI355X).
+
+Until round 5 these models were compared with the numpy oracle at periods p <= 12 only (its dense border columns need minutes beyond that) and held to properties
+and certificates at p = 64 / p = 200.  oracle/cpu_ipm now carries the same models by stage-local elimination (cpu_ipm_con.h; tied to the numpy oracle at <= 2e-9 in
+tests/test_cpu_ipm.py), which makes Hc, P, Fg, F, T comparable at the full shapes: the bench stage size and period (p = 64, n = 32, 2 + 3 rows), BASELINE configs[4]
+(p = 200, n = 30) at its 64-problem share, configs[2] (p = 50, n = 4) at batch 256, and the REAL AWE shape (p = 40, nx = 9, m = 6) against a committed golden vector.
+convexifier.py:116-131, :249-285, :346-355.  VERDICT r5, "Next round" item 1."""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+import convexify_oracle as co  # noqa: E402
+import cpu_ipm  # noqa: E402
+
+PARITY = 1e-8
+HOST_THREADS = max(1, min(8, len(os.sched_getaffinity(0))))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def hc():
+    from tunempc_amd._lib import HipConvexifier
+    cache = {}
+
+    def get(p, nx, mb, **kw):
+        key = (p, nx, mb, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = HipConvexifier(p, nx, mb, **kw)
+        return cache[key]
+    yield get
+    for h in cache.values():
+        h.close()
+
+
+def _rows(seed, nb, p, n, ng, nc):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((nb, p, ng, n)); C = rng.standard_normal((nb, p, nc, n))
+    ncnt = rng.integers(0, nc + 1, size=(nb, p)).astype(np.int32)
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, ncnt[b, k]:] = 0.0
+    return G, C, ncnt
+
+
+def _compare(out, ref, members, ng, ncnt, what, refidx=None):
+    """Hc, P, kappa, status and the multipliers of every listed member against cpu_ipm: the 1e-8 bar of every parity test."""
+    worst = dict(Hc=0.0, P=0.0, F=0.0)
+    for j, b in enumerate(members):
+        r = j if refidx is None else refidx[j]
+        assert int(out['status'][b]) == int(ref['status'][r]) == 0, (what, b, out['status'][b], ref['status'][r])
+        e = rel(out['Hc'][b], ref['Hc'][r]); eP = rel(out['P'][b], ref['P'][r])
+        assert e < PARITY and eP < PARITY, (what, b, e, eP)
+        assert abs(out['kappa'][b] - ref['kappa'][r]) < 1e-9 * max(1.0, ref['kappa'][r]), (what, b)
+        Fo = out['FgF'][b] if 'FgF' in out else out['Fg'][b]
+        Fr = ref['FgF'][r][:, :Fo.shape[1]]
+        assert (Fo >= 0).all()
+        eF = np.linalg.norm(Fo - Fr) / max(1.0, np.linalg.norm(Fr))
+        assert eF < PARITY, (what, b, eF)
+        if ncnt is not None:
+            for k in range(Fo.shape[0]):
+                assert not Fo[k, ng + ncnt[b, k]:].any()
+        worst = dict(Hc=max(worst['Hc'], e), P=max(worst['P'], eP), F=max(worst['F'], eF))
+    return worst
+
+
+def test_rows_models_at_the_bench_shape(hc):
+    """p = 64, nx = 24, m = 8 (BASELINE configs[3]'s stage size and period) with 2 rows of G_k and 0..3 rows of C_k: Step 1 with G, the Step 2 model at two weights
+    and its beta-only reading -- Hc, P, Fg, F of every member against cpu_ipm (the numpy oracle needs ~10 minutes per member here)."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb, ng, nc = 64, 24, 8, 6, 2, 3
+    A, B, H = synthetic.gen_batch(61000, nb, p, nx, mb)
+    G, C, ncnt = _rows(61, nb, p, nx + mb, ng, nc)
+    J = np.concatenate([G, C], axis=2)
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    eq = h.convexify_eq_batch(A, B, H, G)
+    w = _compare(eq, cpu_ipm.convexify_con_batch(A, B, H, G, ng=ng, threads=HOST_THREADS), range(nb), ng, None, 'G')
+    print(f'bench shape, Step 1 with G: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg {w["F"]:.2e}; iterations {eq["iters"].min()}..{eq["iters"].max()}')
+    for rho in (1e-3, 1.0, 0.0):
+        o = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+        kw = dict(cost_free=True) if rho == 0.0 else dict(rho=rho)
+        w = _compare(o, cpu_ipm.convexify_con_batch(A, B, H, J, ng=ng, ncnt=ncnt, threads=HOST_THREADS, **kw), range(nb), ng, ncnt, f'step2 rho={rho}')
+        print(f'bench shape, Step 2 rho = {rho}: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg/F {w["F"]:.2e}; iterations {o["iters"].min()}..{o["iters"].max()}')
+
+
+def test_rows_models_at_the_c5_share(hc):
+    """BASELINE configs[4] (AWE-shaped synthetic: p = 200, nx = 20, m = 10) with the rows SURVEY 8(d) asks for (ng = 3, nc in {0..3}) at its per-GPU share of 64
+    problems, through the device-resident entry: eight members drawn at random plus the slowest and the fastest, Step 1 with G and the Step 2 model."""
+    from tunempc_amd import synthetic
+    p, nx, mb, nb, ng, nc = 200, 20, 10, 64, 3, 3
+    A, B, H = synthetic.gen_batch(62000, nb, p, nx, mb)
+    G, C, ncnt = _rows(62, nb, p, nx + mb, ng, nc)
+    J = np.concatenate([G, C], axis=2)
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    dev = torch.device('cuda', 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for what, Jd, nd, kw in (('G', G, None, {}), ('step2', J, ncnt, dict(rho=1e-2))):
+        o = h.convexify_con_batch_device(t(A), t(B), t(H), t(Jd), t(nd) if nd is not None else None, 1e-2 if nd is not None else 0.0)
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in o.items()}
+        assert (out['status'] == 0).all()
+        pick = np.sort(np.random.default_rng(20261004).choice(nb, size=8, replace=False))
+        pick = np.unique(np.concatenate([pick, [int(np.argmax(out['iters'])), int(np.argmin(out['iters']))]]))
+        ref = cpu_ipm.convexify_con_batch(A[pick], B[pick], H[pick], Jd[pick], ng=ng, ncnt=nd[pick] if nd is not None else None, threads=HOST_THREADS, **kw)
+        w = _compare(out, ref, pick, ng, nd, f'c5 share {what}', refidx=range(len(pick)))
+        print(f'c5 share (64 x p=200 x n=30), {what}: members {pick.tolist()}: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg/F {w["F"]:.2e}; iterations {out["iters"].min()}..{out["iters"].max()}')
+
+
+def test_rows_models_at_the_c3_shape_batch_256(hc):
+    """BASELINE configs[2] (evaporation-shaped: p = 50, nx = 2, m = 2) at batch 256 with one row of G_k and 0..2 rows of C_k: EVERY member, both models."""
+    p, nx, mb, nb, ng, nc = 50, 2, 2, 256, 1, 2
+    A, B, H = co.gen_batch(63000, nb, p, nx, mb)
+    G, C, ncnt = _rows(63, nb, p, nx + mb, ng, nc)
+    J = np.concatenate([G, C], axis=2)
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    eq = h.convexify_eq_batch(A, B, H, G)
+    w = _compare(eq, cpu_ipm.convexify_con_batch(A, B, H, G, ng=ng, threads=HOST_THREADS), range(nb), ng, None, 'c3 G')
+    print(f'c3 shape batch 256, Step 1 with G: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg {w["F"]:.2e}')
+    o = h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    w = _compare(o, cpu_ipm.convexify_con_batch(A, B, H, J, ng=ng, ncnt=ncnt, rho=1e-2, threads=HOST_THREADS), range(nb), ng, ncnt, 'c3 step2')
+    print(f'c3 shape batch 256, Step 2: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg/F {w["F"]:.2e}')
+
+
+@pytest.mark.parametrize('p,nx,mb,ng,nc,nb', [(12, 12, 4, 0, 0, 3), (8, 12, 4, 2, 3, 2), (40, 9, 6, 0, 0, 2), (6, 20, 4, 0, 0, 1)])
+def test_step3_against_cpu_ipm_beyond_the_oracle_sizes(hc, p, nx, mb, ng, nc, nb):
+    """Step 3 (convexifier.py:137-147; T_k and its second-order cone, alone and with rows) at n = 15 ... 24 and periods up to the AWE example's 40 -- blocks of
+    d + n(n+1)/2 + 1 (+ rows) = 166 ... 511 -- against cpu_ipm: Hc, P, T (and Fg, F).  The numpy oracle was the checker up to n = 15, p <= 4."""
+    from tunempc_amd import synthetic
+    n = nx + mb
+    A, B, H = synthetic.gen_batch(64000 + p, nb, p, nx, mb)
+    rho = 1e-2
+    if ng + nc:
+        G, C, ncnt = _rows(64, nb, p, n, ng, nc)
+        J = np.concatenate([G, C], axis=2)
+        o = hc(p, nx, mb, ng=ng, nc=nc, step3=True).convexify_step3_con_batch(A, B, H, J, ncnt, rho)
+        ref = cpu_ipm.convexify_con_batch(A, B, H, J, ng=ng, ncnt=ncnt, rho=rho, force=True, threads=HOST_THREADS)
+        w = _compare(o, ref, range(nb), ng, ncnt, 'step3 with rows')
+    else:
+        o = hc(p, nx, mb, step3=True).convexify_step3_batch(A, B, H, rho)
+        ref = cpu_ipm.convexify_con_batch(A, B, H, rho=rho, force=True, threads=HOST_THREADS)
+        w = dict(Hc=0.0, P=0.0)
+        for b in range(nb):
+            assert int(o['status'][b]) == int(ref['status'][b]) == 0
+            w['Hc'] = max(w['Hc'], rel(o['Hc'][b], ref['Hc'][b])); w['P'] = max(w['P'], rel(o['P'][b], ref['P'][b]))
+            assert abs(o['kappa'][b] - ref['kappa'][b]) < 1e-9 * max(1.0, ref['kappa'][b])
+        assert w['Hc'] < PARITY and w['P'] < PARITY, w
+    eT = max(rel(o['T'][b], ref['T'][b]) for b in range(nb))
+    assert eT < 1e-6 and (o['T'] > 0).all()                 # (T: the bar of test_step3_parity_vs_oracle)
+    print(f'Step 3 p={p} n={n} rows {ng}+{nc}: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  T {eT:.2e}; iterations {o["iters"].min()}..{o["iters"].max()}')
+
+
+def test_awe_shape_step2_golden(hc, golden_dir):
+    """The one constrained example the reference convexifies on a real system: AWE, p = 40, nx = 9, m = 6, Step 2 (paper p.5; examples/awe_system/prepare_inputs.py:86,
+    main.py:56, rho = 1.0 of tuner.py:134) -- the committed vector tests/golden/awe_step2_n15.npz (numpy oracle, default and tight mode; generator make_golden.py awe)."""
+    g = np.load(os.path.join(golden_dir, 'awe_step2_n15.npz'))
+    A, B, H, G, C, ncnt, rho = g['A'], g['B'], g['H'], g['G'], g['C'], g['ncnt'], float(g['rho'])
+    nb, p, nx, _ = A.shape
+    mb = B.shape[3]; ng = G.shape[2]; nc = C.shape[2]
+    assert (p, nx, mb, ng) == (40, 9, 6, 3)
+    J = np.concatenate([G, C], axis=2)
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    for tag in ('', '_tight'):
+        h.set_tight(bool(tag), float(g['tight_tol']))
+        o = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
+        assert int(o['status'][0]) == 0
+        if tag:
+            assert int(o['info'][0, 10]) == 0 and o['info'][0, 6] == g['mu_target_tight'][0]          # at the tight target, no fall-back
+        e = rel(o['Hc'][0], g['Hc' + tag][0]); eP = rel(o['P'][0], g['P' + tag][0])
+        eF = np.linalg.norm(o['FgF'][0, :, :ng] - g['Fg' + tag][0]) / max(1.0, np.linalg.norm(g['Fg' + tag][0]))
+        eC = np.linalg.norm(o['FgF'][0, :, ng:] - g['F' + tag][0]) / max(1.0, np.linalg.norm(g['F' + tag][0]))
+        assert e < PARITY and eP < PARITY and eF < PARITY and eC < PARITY, (tag, e, eP, eF, eC)
+        assert abs(o['kappa'][0] - g['kappa' + tag][0]) < 1e-9 * g['kappa' + tag][0]
+        print(f'AWE shape Step 2{tag}: Hc {e:.2e}  P {eP:.2e}  Fg {eF:.2e}  F {eC:.2e}  kappa {o["kappa"][0]:.10f}')
+    h.set_tight(False)

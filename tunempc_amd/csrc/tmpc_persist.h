@@ -86,6 +86,10 @@ __global__ void __launch_bounds__(CRS_NT) k_ipm_small(WS w, Dims dm, Opts o, CrD
       PK_T(10)
     }
     for (int k = wv; k < p; k += CRS_NW) sm8::update_body<64>(w, dm, s0 + k, lane);
+    // (update_body leaves at once when the phase is PH_DONE and ctrl_d_body may set it: every wave must be through its stages first -- on the launch
+    // sequence k_update and k_ctrl_d are separate launches.  Without the barrier a wave that reaches its later stages after thread 0 is done skips their
+    // last update: ADVICE r5, tests/test_gpu_parity.py::test_persistent_kernel_last_update_of_every_stage)
+    __syncthreads();
     if (tid == 0) ctrl_d_body(w, dm, o, b, false);
     PK_T(11)
   }
