@@ -243,22 +243,26 @@ def large_block_configs(HipConvexifier, synthetic):
         except Exception as e:      # noqa: BLE001
             out[key]["roofline_error"] = f"{type(e).__name__}: {e}"
         h.close()
-        if not (ng or nc):
-            # the CPU port beside it (plain model only: oracle/cpu_ipm has no multiplier rows), on a bounded sample of the same shape: one problem per thread,
-            # period 4 instead of 16 (the cost of a solve is linear in the period: ~12 s per problem at blocks of 820)
-            try:
-                sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-                import cpu_ipm
-                hw = host_cpu_info()
-                cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
-                ps = 4
-                As, Bs, Hs = synthetic.gen_batch(seed + 50, cores, ps, nx, mb)
+        # the CPU port beside it, on a bounded sample of the same stage shape (same rows): one problem per thread at a shorter period (the cost of a solve is linear
+        # in the period: ~12 s per problem at blocks of 820).  Round 6: oracle/cpu_ipm carries the models with rows (cpu_ipm_con.h).
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+            import cpu_ipm
+            hw = host_cpu_info()
+            cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
+            ps = 4
+            As, Bs, Hs = synthetic.gen_batch(seed + 50, cores, ps, nx, mb)
+            if ng or nc:
+                Js = np.random.default_rng(8).standard_normal((cores, ps, ng + nc, nx + mb))
+                t0 = time.perf_counter(); oc = cpu_ipm.convexify_con_batch(As, Bs, Hs, Js, ng=ng, ncnt=np.full((cores, ps), nc, np.int32), rho=1e-2, threads=cores); tc = time.perf_counter() - t0
+            else:
                 t0 = time.perf_counter(); oc = cpu_ipm.convexify_batch(As, Bs, Hs, threads=cores); tc = time.perf_counter() - t0
-                out[key].update(cpu_stage_conv_per_s=cores * ps / tc, cpu_threads=cores, gpu_over_cpu=(nb * p / tg) / (cores * ps / tc),
-                                cpu_sample=f"oracle/cpu_ipm, {cores} problems of the same stage shape with period {ps} on {cores} threads in {tc:.1f} s, "
-                                           f"{int((oc['status'] == 0).sum())}/{cores} Optimal")
-            except Exception as e:      # noqa: BLE001
-                out[key]["cpu_error"] = f"{type(e).__name__}: {e}"
+            out[key].update(cpu_stage_conv_per_s=cores * ps / tc, cpu_threads=cores, gpu_over_cpu=(nb * p / tg) / (cores * ps / tc),
+                            cpu_baseline={"value": cores * ps / tc, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+                                          "sample": f"oracle/cpu_ipm ({'Step 2 model, stage-local elimination' if (ng or nc) else 'plain model'}), {cores} problems of the same stage shape "
+                                                    f"{'and rows ' if (ng or nc) else ''}with period {ps} on {cores} threads in {tc:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"})
+        except Exception as e:      # noqa: BLE001
+            out[key]["cpu_error"] = f"{type(e).__name__}: {e}"
     out["note"] = "32 < n <= 64: csrc/tmpc_big.h (one thread per matrix entry, matrices in global memory) + the register-staged factorisation kernels; not the tuned path of the headline"
     return out
 
@@ -386,7 +390,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())
     prof = h.profile()
-    status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy()
+    status = out['status'].cpu().numpy(); iters = out['iters'].cpu().numpy(); kappa = out['kappa'].cpu().numpy(); info0 = out['info'].cpu().numpy()
     ok = int((status == 0).sum())
     # load balance across ranks: the slowest member of every rank's shard sets that rank's step time
     it_rank = torch.tensor([float(iters.max()), float(iters.mean()), float(prof['total_ms']) / max(args.steps, 1), float(status.size)], dtype=torch.float64, device=cdev)
@@ -509,6 +513,26 @@ def main():
                     h2.convexify_step2_batch(A2[:4], B2[:4], H2[:4], J2[:4], cnt2[:4], rho2)
                     t0 = time.perf_counter(); ot = h2.convexify_step2_batch(A2, B2, H2, J2, cnt2, rho2); et = time.perf_counter() - t0
                     h2.close()
+                    step2_cpu = None
+                    if not args.no_cpu_baseline:
+                        try:                   # the CPU port on the same model (default mode and, when built, its tight mode), bounded sample: one problem per thread at period 8
+                            sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+                            import cpu_ipm
+                            hw = host_cpu_info()
+                            cores = max(1, min(hw["effective_cores"], cpu_ipm.max_threads(), 64))
+                            ps = 8
+                            As, Bs, Hs = synthetic.gen_batch(100000, cores, ps, nx, mb)
+                            Js = J2[:cores, :ps] if cores <= nb2 else np.tile(J2[:, :ps], ((cores + nb2 - 1) // nb2, 1, 1, 1))[:cores]
+                            cs = cnt2[:cores, :ps] if cores <= nb2 else np.tile(cnt2[:, :ps], ((cores + nb2 - 1) // nb2, 1))[:cores]
+                            tc0 = time.perf_counter(); oc = cpu_ipm.convexify_con_batch(As, Bs, Hs, Js, ng=ng2, ncnt=cs, rho=rho2, threads=cores); tcd = time.perf_counter() - tc0
+                            step2_cpu = {"value": cores * ps / tcd, "unit": "stage-convexifications/s", "cores": cores, "kind": "port", "mode": "default",
+                                         "sample": f"oracle/cpu_ipm, Step 2 model (stage-local elimination, cpu_ipm_con.h), {cores} problems of the bench stage shape and rows with period {ps} "
+                                                   f"on {cores} threads in {tcd:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
+                            if hasattr(cpu_ipm, 'convexify_con_batch_tight'):
+                                tc0 = time.perf_counter(); oc = cpu_ipm.convexify_con_batch_tight(As, Bs, Hs, Js, ng=ng2, ncnt=cs, rho=rho2, tol=2.0 ** -37, threads=cores); tct = time.perf_counter() - tc0
+                                step2_cpu["tight"] = {"value": cores * ps / tct, "sample": f"the same sample in the port's tight mode in {tct:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
+                        except Exception as e:      # noqa: BLE001
+                            step2_cpu = {"error": f"{type(e).__name__}: {e}"}
                     # cone dimension: the 2 p LMI blocks and alpha, one linear cone per row, an (m + 1)-dimensional arrow block per norm term (rows of G; rows of C where present)
                     ncone = 2 * p * n + 1 + (ng2 + cnt2).sum(1) + p * (ng2 + 1) + (cnt2 + (cnt2 > 0)).sum(1)
                     extra_rates["tight_mode"]["step2_model"] = {
@@ -516,6 +540,7 @@ def main():
                         "ipm_iterations_mean": float(ot['iters'].mean()), "default_ipm_iterations_mean": float(od['iters'].mean()),
                         "status_optimal": int((ot['status'] == 0).sum()), "fell_back_to_default": int((ot['info'][:, 10] == 4.0).sum()),
                         "certified_gap_on_value": float((ncone * ot['info'][:, 6] / ot['kappa']).max()),
+                        "cpu_baseline": step2_cpu,
                         "note": "Step 2 model (convexifier.py:116-131) in the tight mode, host-buffer entry (H2D + D2H inside), one handle, one timed call each"}
                 except Exception as e:      # noqa: BLE001
                     extra_rates["tight_mode"]["step2_model"] = {"error": f"{type(e).__name__}: {e}"}
@@ -551,6 +576,7 @@ def main():
                                    f"{nbl} problems per GPU ({nbl * world} total; published batch 4096 = 512 x 8 GPUs)",
                        "p": p, "nx": nx, "m": mb, "batch_per_gpu": nbl, "global_batch": nbl * world,
                        "distinct_problems_per_gpu": nd, "mu_tol": args.tol if args.tol > 0 else 2.0 ** -25,
+                       "certified_gap_on_kappa": float((2 * p * n + 1) * (info0[:, 6] / np.maximum(kappa, 1e-300)).max()),      # N mu_t / kappa: what mu_tol means for kappa (the reference solvers stop at ~1e-8: `tight_mode`)
                        "ipm_iterations_max": int(iters.max()), "ipm_iterations_mean": float(iters.mean()),
                        "ipm_iterations_per_rank": [{"max": int(a), "mean": b} for a, b, _, _ in it_all],
                        "solve_ms_per_step_per_rank": [c for _, _, c, _ in it_all],      # time inside the library per step (the rest of a rank's step is waiting for the slowest at the gather)
@@ -572,8 +598,9 @@ def main():
                                                  "problems_per_phase": nfac / phases,
                                                  "potrf_ms": prof['potrf_ms'] / phases, "trsm_ms": prof['trsm_ms'] / phases,
                                                  "update_ms": upd_ms / phases},
-                         "peak_note": "datasheet FP64 matrix peak at 2.4 GHz; under this kernel the chip holds 1.8-1.9 GHz (GRBM_GUI_ACTIVE / wall time, "
-                                      "profiles/r2v_pmc_gemm_core_micro.txt), i.e. 59-62 TFLOP/s at the sustained clock"},
+                         "peak_note": "datasheet FP64 matrix peak at 2.4 GHz.  Under this kernel the chip runs at 2.28 GHz (GRBM_GUI_ACTIVE / wall time) with the matrix pipes busy "
+                                      "72 % of the SIMD cycles and 1.08 MFMA flops executed per algorithmic flop (edge tiles): 0.72 x 2.28 / 2.4 / 1.08 = 0.63 "
+                                      "(profiles/r5_final_pmc.txt).  The kernel is MFMA-idle 28 % of the time -- it is not power-capped"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         line.update(extra_rates)
