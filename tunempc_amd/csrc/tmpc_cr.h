@@ -612,50 +612,6 @@ __global__ void __launch_bounds__(256, 2) k_cr_potrf_dma(WS w, Dims dm, CrDev cr
   }
 }
 
-// ---- phases 1 + 2 of a node in ONE workgroup (round 5 experiment, tmpc_set_tuning(TMPC_TUNE_FUSED_ELIM, 1); off by default): the block
-// Cholesky of the node and then the 2 x nt strips of its two triangular solves, one after the other.  The idea (review of round 4): the
-// latency-bound tile factorisations of one workgroup share a CU with the MFMA-bound sweeps of another.  What it costs: the strips of a node
-// no longer run side by side on one XCD, so the factor L_i (0.74 MB at d = 300) is re-read by ONE workgroup for each of its 10 strips over
-// ~0.6 ms while 63 other workgroups of the XCD do the same with their own factors: 47 MB of factors against 4 MB of L2
-// (measured: profiles/r5_fused_elim.txt).
-__global__ void __launch_bounds__(256, 2) k_cr_elim_dma(WS w, Dims dm, CrDev cr, int eoff, int nelim, int count) {
-  const int it = cr_item(count * nelim);
-  if (it < 0) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int b = cr.alist[it / nelim];
-  const int* er = cr.elim + (size_t)(eoff + it % nelim) * CR_EW;
-  const int node = er[CE_NODE], dp = dm.dp;
-  double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
-  double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
-  const double* dref = w.Ddiag + ((size_t)b * dm.p + node) * dp;
-  double* stat = lds + FACT_LDS_DOUBLES - 8;
-  if (threadIdx.x == 0) { stat[0] = 0.0; stat[1] = 1.0; }
-  for (int r = 0; r < dm.nt; ++r) {
-    const int r0 = 64 * r, nb = (dp - r0 < 64) ? dp - r0 : 64;
-    if (r > 0) {
-      trd_strip<true>(Dk + (size_t)r0 * dp, Dk, Li, nb, r + 1, dp, it, lds);
-      __syncthreads();
-    }
-    wg_potrf_inv(Dk + (size_t)r0 * dp + r0, dp, Li + (size_t)r * TB * TB, dref + r0, nb, lds, nullptr, stat, (it >> 5) & 3, r > 0);
-  }
-  if (threadIdx.x == 0) {
-    const int nbad = (int)stat[0];
-    const double minr = stat[1];
-    if (nbad) atomicAdd(w.iprob + (size_t)b * IS + I_NSHIFT, nbad);
-    if (w.prob && minr < 1.0) atomic_min_pos(w.prob + (size_t)b * PS + P_MINPIV, minr);
-  }
-  __syncthreads();                                          // the factor is in memory (same workgroup: visible after the barrier), the LDS free
-  for (int which = 0; which < 2; ++which) {
-    const int slot = which ? er[CE_EB] : er[CE_EA];
-    if (slot < 0) continue;
-    for (int strip = 0; strip < dm.nt; ++strip) {
-      const int r0 = strip * 64;
-      trd_strip<false>(cr_edge(w, dm, b, slot) + (size_t)r0 * dp, Dk, Li, (dp - r0 < 64) ? dp - r0 : 64, dm.nt, dp, it + strip, lds);
-      __syncthreads();
-    }
-  }
-}
-
 // ---- phase 3: symmetric updates of the surviving neighbours and the fill edges, one 64 x 64 output tile per workgroup
 // (register-staged core of tmpc_factor.h: the fallback / debug path; the product path is k_cr_update_dma below)
 template <bool USE_MFMA, int NS>
@@ -776,6 +732,85 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
     double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
     wg_tile_dma<UPD_DMA_DEPTH>(C, dp, Ox + (size_t)m0 * dp, Oy + (size_t)n0 * dp, nullptr, nullptr, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, GM_NOTRI, it, lds);
   }
+}
+
+// The same items as ONE slab stream per workgroup (wg_tiles_dma_stream, round 6): workgroup i takes the `tpw` consecutive items i tpw .. i tpw + tpw - 1.
+__device__ __forceinline__ DmaTile cr_upd_tile(const WS& w, const Dims& dm, const CrDev& cr, int eoff, int nelim, int uoff, int nupd, long nitems, int fuse, long it) {
+  DmaTile T;
+  T.nst = 0; T.A1 = nullptr; T.B1 = nullptr; T.z0 = nullptr; T.z1 = nullptr; T.yz = nullptr;
+  if (it >= nitems) return T;
+  const int dp = dm.dp;
+  const int nm = (dp + 63) / 64;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
+  const int per = nupd * ntl + nelim * ntf;
+  const int b = cr.alist[it / per];
+  const int r = (int)(it % per);
+  const size_t bs = (size_t)dp * dp;
+  const int slot_items = ntf + ntl;
+  int j = r / slot_items, rr = r - j * slot_items;
+  bool is_upd;
+  {
+    const int nmin = nelim < nupd ? nelim : nupd;
+    const int full = nmin * slot_items;
+    if (r < full) { is_upd = rr >= ntf; if (is_upd) rr -= ntf; }
+    else if (nelim > nupd) { const int q = r - full; j = nmin + q / ntf; rr = q % ntf; is_upd = false; }
+    else { const int q = r - full; j = nmin + q / ntl; rr = q % ntl; is_upd = true; }
+  }
+  T.rot = (int)it;
+  if (is_upd) {
+    const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
+    int t = rr, tm = 0;
+    while (t > tm) { t -= tm + 1; ++tm; }
+    const int tn = t;
+    const int m0 = tm * 64, n0 = tn * 64;
+    T.M = (dp - m0 < 64) ? dp - m0 : 64; T.N = (dp - n0 < 64) ? dp - n0 : 64;
+    T.C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
+    const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
+    const double* O1 = ur[CU_E1] >= 0 ? cr_edge(w, dm, b, ur[CU_E1]) : nullptr;
+    T.A0 = O0 + (size_t)m0 * dp; T.B0 = O0 + (size_t)n0 * dp;
+    if (O1) { T.A1 = O1 + (size_t)m0 * dp; T.B1 = O1 + (size_t)n0 * dp; }
+    const bool fz = fuse && tn == 0 && cr_nc(w, b, 1) == 3;
+    if (fz) {
+      T.z0 = cr_rhs(w, dm, b, ur[CU_S0], 3);
+      if (O1) T.z1 = cr_rhs(w, dm, b, ur[CU_S1], 3);
+      T.yz = cr_rhs(w, dm, b, ur[CU_NODE], 3) + (size_t)m0 * 3;
+    }
+    T.mode = GM_SUB; T.tri = (tm == tn) ? 0 : GM_NOTRI;
+    T.nst = (dp >> 4) * (O1 ? 2 : 1);
+  } else {
+    const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
+    if (er[CE_FILL] < 0) return T;
+    const int tm = rr / nm, tn = rr - tm * nm;
+    const int m0 = tm * 64, n0 = tn * 64;
+    T.M = (dp - m0 < 64) ? dp - m0 : 64; T.N = (dp - n0 < 64) ? dp - n0 : 64;
+    const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
+    const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
+    T.C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
+    T.A0 = Ox + (size_t)m0 * dp; T.B0 = Oy + (size_t)n0 * dp;
+    T.mode = er[CE_FACC] ? GM_SUB : GM_NEG; T.tri = GM_NOTRI;
+    T.nst = dp >> 4;
+  }
+  return T;
+}
+// Which items a workgroup takes matters as much as the stream: the tiles in flight on an XCD at any moment must stay a CONTIGUOUS window of items (the
+// tiles of one or two nodes, whose O blocks that L2 holds; round 5 measured what leaving that window costs).  Workgroups are dispatched in order,
+// UPD_WIN = 128 of them are resident on an XCD (32 CUs x 4), so window w of an XCD covers the items [w 128 T, (w + 1) 128 T) and its workgroup l takes
+// the items l, l + 128, l + 256, ...: the 128 resident workgroups sweep the window front to back together.  (T CONSECUTIVE items per workgroup --
+// the first form tried -- puts 128 T items in flight at once: 119 / 127 / 133 ms per factorisation at T = 4 / 8 / 16 against 108, profiles/r6_update_stream.txt.)
+constexpr int UPD_WIN = 128;
+template <int DEPTH>
+__global__ void __launch_bounds__(256, 4) k_cr_update_dma_stream(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int fuse, int tpw) {
+  const int dp = dm.dp;
+  const int nm = (dp + 63) / 64;
+  const long nitems = (long)count * ((long)nupd * (nm * (nm + 1) / 2) + (long)nelim * nm * nm);
+  const int per = gridDim.x >> 3;                          // workgroups per XCD (block i runs on XCD i % 8)
+  const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+  const int nfull = per / UPD_WIN, blk = l / UPD_WIN;
+  const int stride = blk < nfull ? UPD_WIN : per - nfull * UPD_WIN;
+  const long it0 = ((long)x * per + (long)(blk < nfull ? blk : nfull) * UPD_WIN) * tpw + (l - blk * UPD_WIN);
+  if (it0 >= nitems) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  wg_tiles_dma_stream<DEPTH>([&](int t) { return cr_upd_tile(w, dm, cr, eoff, nelim, uoff, nupd, nitems, fuse, it0 + (long)t * stride); }, tpw, dp, dp, lds);
 }
 
 // ------------------------------------------------------------------ triangular solves in the same order
