@@ -115,9 +115,6 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
  *   TMPC_TUNE_FUSE_FWD     1 (default): the forward substitution of the predictor pass rides inside the factorisation; 0: separate sweep
  *   TMPC_TUNE_GRAPH        1 (default): problems whose Schur blocks are a single tile (nx <= 10: launch-bound) replay the launch sequence of an iteration as a
  *                          captured hipGraph (one submission instead of ~35; the handle's own streams only); 0: plain launches
- *   TMPC_TUNE_UPDATE_STREAM  tiles per workgroup of the symmetric-update kernel of the block factorisation (k_cr_update_dma): 0 / 1: one 64 x 64 tile per workgroup;
- *                          T in 2..64: a workgroup walks T consecutive tiles as ONE slab stream (the first slabs of a tile are in flight while the previous tile's
- *                          last slabs are multiplied and its result is stored; bit-identical results).  + 300: a ring of three LDS slab buffers instead of two.
  *   TMPC_TUNE_PERSISTENT   plain-model problems with single-tile Schur blocks and n = nx + mb <= 8 (the reference's own examples) can run their whole
  *                          interior-point loop as ONE launch, one workgroup per problem (tmpc_persist.h).  1 (default): where that is faster -- period
  *                          p <= 8, or at least 96 problems of the call on the chip at once; 0: never (the launch sequence); 2: whenever the shape allows it
@@ -127,7 +124,7 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
 #define TMPC_TUNE_EIG_PRETEST 3
 #define TMPC_TUNE_FUSE_FWD 4
 #define TMPC_TUNE_GRAPH 5
-#define TMPC_TUNE_UPDATE_STREAM 6
+/* (key 6 belonged to two measured-and-dropped experiments -- rounds 5 and 6, profiles/r5_fused_elim.txt, profiles/r6_update_stream_*.txt -- and is not reused) */
 #define TMPC_TUNE_PERSISTENT 7
 int tmpc_set_tuning(tmpc_handle* h, int key, double value);
 /* The general constructor: ng / nc rows of G_k / C_k (0: none), step3 != 0: room for T_k, lanes = concurrent half-waves on their own streams

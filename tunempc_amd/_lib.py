@@ -194,9 +194,9 @@ class HipConvexifier:
         _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
                                                    int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
 
-    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None, update_stream=None, persistent=None):
+    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None, persistent=None):
         """Performance knobs of the handle (include/tunempc_hip.h: tmpc_set_tuning); None keeps the current value."""
-        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph), (6, update_stream), (7, persistent)):
+        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph), (7, persistent)):
             if v is not None:
                 _check(self.lib, self.lib.tmpc_set_tuning(self._h, key, float(v)), 'tmpc_set_tuning')
 

@@ -131,7 +131,7 @@ struct tmpc_handle {
   CrSched sched;                 // elimination order of the block factorisation (tmpc_cr.h)
   int* d_sched;                  // device copy: elimination records | update records | orientation
   int rs, mt;                    // rows per workgroup of k_cr_trsm / output tile edge of k_cr_update (0: chosen per launch)
-  int tune_small, tune_pretest, tune_fuse, tune_graph, tune_upd_stream, tune_persist;     // tmpc_set_tuning
+  int tune_small, tune_pretest, tune_fuse, tune_graph, tune_persist;     // tmpc_set_tuning
   void* dd_slab;                 // tight mode (tmpc_set_tight): low words of the double-double planes, allocated on first use
   size_t dd_bytes;
   int tight;                     // 1: the tight phase follows the default solve
@@ -514,7 +514,6 @@ static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
 // host-side bits of Dims::flags (bit 0 = TMPC_FLAG_NO_MFMA is the only one device code reads)
 constexpr int DF_NO_SMALL = 2;   // tmpc_set_tuning(TMPC_TUNE_SMALL_BLOCKS, 0): the batched launch sequence also for dp = 16
 constexpr int DF_NO_DMA = 4;     // TMPC_DEBUG_FLAG_NO_DMA: the register-staged factorisation kernels (the path of blocks wider than 320) for every block size
-constexpr int DF_STREAM_SHIFT = 8; // bits 8..15: tiles per workgroup of the update kernel's continuous slab stream (tmpc_set_tuning(TMPC_TUNE_UPDATE_STREAM)), bits 16..17: its ring depth (0 / 2: two buffers, 3: three)
 
 // Small blocks (dp = 16): one kernel per factorisation / per solve instead of a launch sequence per level (tmpc_cr_small.h); TMPC_SMALL=0: off
 static bool cr_small_levels(const Dims& dm, const CrSched& sc, CrLevs* out) {
@@ -586,12 +585,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     if (mf && use_dma) {
       const int nm64 = (dm.dp + 63) / 64;
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
-      const int tpw = (dm.flags >> DF_STREAM_SHIFT) & 0xff, sdepth = (dm.flags >> (DF_STREAM_SHIFT + 8)) & 3;
-      (void)sdepth;
-      if (tpw > 1)
-        hipLaunchKernelGGL(k_cr_update_dma_stream<2>, dim3(cr_grid((it_dma + tpw - 1) / tpw)), dim3(256), (size_t)dmas_lds_doubles<2>(tpw) * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1, tpw);
-      else
-        hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
+      hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
@@ -694,7 +688,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   const bool t3 = dm.nT > 0;
   dm.dp = (dm.d + (eq ? dm.nz : 0) + (t3 ? dm.nT + 1 : 0) + 15) / 16 * 16;
   dm.nt = (dm.dp + TB - 1) / TB;
-  dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0) | ((h->tune_upd_stream & 0x3ff) << DF_STREAM_SHIFT);
+  dm.flags = (h->flags & TMPC_FLAG_NO_MFMA) | (h->tune_small ? 0 : DF_NO_SMALL) | ((h->flags & TMPC_DEBUG_FLAG_NO_DMA) ? DF_NO_DMA : 0);
   const size_t t3_lds = (size_t)(3 * (dm.nT + 1) + 8) * sizeof(double);
   const bool big = dm.n > NMAX || (h->flags & TMPC_DEBUG_FLAG_GENERIC_STAGE);      // generic per-stage kernels (tmpc_big.h)
   const size_t t3_schur_lds = (size_t)((big ? 0 : 9 * 32 * T3_LD) + 2 * (dm.nT + 1)) * sizeof(double) + (size_t)(2 * (dm.nT + 1) + 2 * (dm.d + 1)) * sizeof(short) + 64;
@@ -1102,7 +1096,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   h->dm = make_dims(cap, p, nx, mb, ng, nc, step3);
   h->sched = cr_build(p);
   h->rs = 0; h->mt = 0;
-  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1; h->tune_upd_stream = 0; h->tune_persist = 1;
+  h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1; h->tune_persist = 1;
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->opt.fast_exit = 0;
   h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); tmpc_set_tuning(TMPC_TUNE_CHORD_STEP, 0) disables
@@ -1180,11 +1174,6 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
     case TMPC_TUNE_EIG_PRETEST: h->tune_pretest = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_FUSE_FWD: h->tune_fuse = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_GRAPH: h->tune_graph = value != 0.0; return TMPC_OK;
-    case TMPC_TUNE_UPDATE_STREAM: {
-      const int v = (int)value, tpw = v % 100, depth = v / 100;      // value = tiles per workgroup (+ 300: ring of three buffers)
-      if (v < 0 || tpw > 64 || (depth != 0 && depth != 2 && depth != 3)) return TMPC_E_ARG;
-      h->tune_upd_stream = tpw | ((depth == 3 ? 3 : 0) << 8); return TMPC_OK;
-    }
     case TMPC_TUNE_PERSISTENT: if (!(value >= 0.0 && value <= 2.0)) return TMPC_E_ARG; h->tune_persist = (int)value; return TMPC_OK;
     default: snprintf(g_err, sizeof(g_err), "tmpc_set_tuning: unknown key %d", key); return TMPC_E_ARG;
   }
@@ -1861,7 +1850,6 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
   CrBench cb;
   int rc = cb.init(nb, p, d, h->flags);
   if (rc != TMPC_OK) return rc;
-  cb.dm.flags |= (h->tune_upd_stream & 0x3ff) << DF_STREAM_SHIFT;
   const int dp = cb.dm.dp;
   const size_t bs = (size_t)dp * dp, per = (size_t)p * bs;
   // T = sum_k J_k' J_k + I  with J_k = [E_k G_k] on blocks (k, k+1): SPD by construction

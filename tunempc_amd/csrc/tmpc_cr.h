@@ -734,85 +734,6 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
   }
 }
 
-// The same items as ONE slab stream per workgroup (wg_tiles_dma_stream, round 6): workgroup i takes the `tpw` consecutive items i tpw .. i tpw + tpw - 1.
-__device__ __forceinline__ DmaTile cr_upd_tile(const WS& w, const Dims& dm, const CrDev& cr, int eoff, int nelim, int uoff, int nupd, long nitems, int fuse, long it) {
-  DmaTile T;
-  T.nst = 0; T.A1 = nullptr; T.B1 = nullptr; T.z0 = nullptr; T.z1 = nullptr; T.yz = nullptr;
-  if (it >= nitems) return T;
-  const int dp = dm.dp;
-  const int nm = (dp + 63) / 64;
-  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
-  const int per = nupd * ntl + nelim * ntf;
-  const int b = cr.alist[it / per];
-  const int r = (int)(it % per);
-  const size_t bs = (size_t)dp * dp;
-  const int slot_items = ntf + ntl;
-  int j = r / slot_items, rr = r - j * slot_items;
-  bool is_upd;
-  {
-    const int nmin = nelim < nupd ? nelim : nupd;
-    const int full = nmin * slot_items;
-    if (r < full) { is_upd = rr >= ntf; if (is_upd) rr -= ntf; }
-    else if (nelim > nupd) { const int q = r - full; j = nmin + q / ntf; rr = q % ntf; is_upd = false; }
-    else { const int q = r - full; j = nmin + q / ntl; rr = q % ntl; is_upd = true; }
-  }
-  T.rot = (int)it;
-  if (is_upd) {
-    const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
-    int t = rr, tm = 0;
-    while (t > tm) { t -= tm + 1; ++tm; }
-    const int tn = t;
-    const int m0 = tm * 64, n0 = tn * 64;
-    T.M = (dp - m0 < 64) ? dp - m0 : 64; T.N = (dp - n0 < 64) ? dp - n0 : 64;
-    T.C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
-    const double* O0 = cr_edge(w, dm, b, ur[CU_E0]);
-    const double* O1 = ur[CU_E1] >= 0 ? cr_edge(w, dm, b, ur[CU_E1]) : nullptr;
-    T.A0 = O0 + (size_t)m0 * dp; T.B0 = O0 + (size_t)n0 * dp;
-    if (O1) { T.A1 = O1 + (size_t)m0 * dp; T.B1 = O1 + (size_t)n0 * dp; }
-    const bool fz = fuse && tn == 0 && cr_nc(w, b, 1) == 3;
-    if (fz) {
-      T.z0 = cr_rhs(w, dm, b, ur[CU_S0], 3);
-      if (O1) T.z1 = cr_rhs(w, dm, b, ur[CU_S1], 3);
-      T.yz = cr_rhs(w, dm, b, ur[CU_NODE], 3) + (size_t)m0 * 3;
-    }
-    T.mode = GM_SUB; T.tri = (tm == tn) ? 0 : GM_NOTRI;
-    T.nst = (dp >> 4) * (O1 ? 2 : 1);
-  } else {
-    const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
-    if (er[CE_FILL] < 0) return T;
-    const int tm = rr / nm, tn = rr - tm * nm;
-    const int m0 = tm * 64, n0 = tn * 64;
-    T.M = (dp - m0 < 64) ? dp - m0 : 64; T.N = (dp - n0 < 64) ? dp - n0 : 64;
-    const double* Ox = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
-    const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
-    T.C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
-    T.A0 = Ox + (size_t)m0 * dp; T.B0 = Oy + (size_t)n0 * dp;
-    T.mode = er[CE_FACC] ? GM_SUB : GM_NEG; T.tri = GM_NOTRI;
-    T.nst = dp >> 4;
-  }
-  return T;
-}
-// Which items a workgroup takes matters as much as the stream: the tiles in flight on an XCD at any moment must stay a CONTIGUOUS window of items (the
-// tiles of one or two nodes, whose O blocks that L2 holds; round 5 measured what leaving that window costs).  Workgroups are dispatched in order,
-// UPD_WIN = 128 of them are resident on an XCD (32 CUs x 4), so window w of an XCD covers the items [w 128 T, (w + 1) 128 T) and its workgroup l takes
-// the items l, l + 128, l + 256, ...: the 128 resident workgroups sweep the window front to back together.  (T CONSECUTIVE items per workgroup --
-// the first form tried -- puts 128 T items in flight at once: 119 / 127 / 133 ms per factorisation at T = 4 / 8 / 16 against 108, profiles/r6_update_stream.txt.)
-constexpr int UPD_WIN = 128;
-template <int DEPTH>
-__global__ void __launch_bounds__(256, 4) k_cr_update_dma_stream(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count, int fuse, int tpw) {
-  const int dp = dm.dp;
-  const int nm = (dp + 63) / 64;
-  const long nitems = (long)count * ((long)nupd * (nm * (nm + 1) / 2) + (long)nelim * nm * nm);
-  const int per = gridDim.x >> 3;                          // workgroups per XCD (block i runs on XCD i % 8)
-  const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
-  const int nfull = per / UPD_WIN, blk = l / UPD_WIN;
-  const int stride = blk < nfull ? UPD_WIN : per - nfull * UPD_WIN;
-  const long it0 = ((long)x * per + (long)(blk < nfull ? blk : nfull) * UPD_WIN) * tpw + (l - blk * UPD_WIN);
-  if (it0 >= nitems) return;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  wg_tiles_dma_stream<DEPTH>([&](int t) { return cr_upd_tile(w, dm, cr, eoff, nelim, uoff, nupd, nitems, fuse, it0 + (long)t * stride); }, tpw, dp, dp, lds);
-}
-
 // ------------------------------------------------------------------ triangular solves in the same order
 // Right-hand sides R [p][dp][NC] (NC interleaved), in place.  Forward, level by level: z_i <- L_i^-1 z_i for the eliminated nodes,
 // then z_s -= O_s z_i for the surviving neighbours; backward in reverse: z_i <- L_i^-T (z_i - O_a' z_a - O_b' z_b).
