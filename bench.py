@@ -284,6 +284,7 @@ def main():
     ap.add_argument('--mb', type=int, default=8)
     ap.add_argument('--tol', type=float, default=0.0, help='0 = library default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lowp-switch', type=float, default=-1.0, help='TMPC_TUNE_LOWP_SWITCH of the handle (single-precision Schur-complement updates while mu / kappa > value; 0: off); < 0: library default')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="collective backend; 'gloo' (results staged through the host) lets the multi-rank branch run where RCCL cannot")
     ap.add_argument('--same-device', action='store_true', help='every rank on cuda:0 (with --backend gloo: the N > 1 code path on a one-GPU box; not a scaling measurement)')
     ap.add_argument('--digest', action='store_true', help='add the sha256 of the gathered Hc / kappa / status of the last step to the line (tests)')
@@ -346,6 +347,8 @@ def main():
     h = HipConvexifier(p, nx, mb, chunk=(nbl if (args.same_device and nbl < 512) else 0), flags=FLAG_PROFILE)
     if args.tol > 0:
         h.set_options(tol=args.tol, flags=FLAG_PROFILE)
+    if args.lowp_switch >= 0:
+        h.set_tuning(lowp_switch=args.lowp_switch)
     out = None
     gather_cache = {}                      # the all-gather lands in the same buffers every step (tunempc_amd/dist.py)
     cost = None

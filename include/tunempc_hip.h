@@ -115,6 +115,10 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
  *   TMPC_TUNE_FUSE_FWD     1 (default): the forward substitution of the predictor pass rides inside the factorisation; 0: separate sweep
  *   TMPC_TUNE_GRAPH        1 (default): problems whose Schur blocks are a single tile (nx <= 10: launch-bound) replay the launch sequence of an iteration as a
  *                          captured hipGraph (one submission instead of ~35; the handle's own streams only); 0: plain launches
+ *   TMPC_TUNE_LOWP_SWITCH  value >= 0 (default TMPC_LOWP_SWITCH_DEFAULT): in the main-phase iterations of a problem with mu > value * max(1, kappa) the Schur-complement updates of
+ *                          the block factorisation (k_cr_update_dma, a third of a solve) run on float32 copies of their operands with float32 accumulation (fp32 MFMA:
+ *                          twice the fp64 matrix rate); Cholesky, triangular solves, substitutions and every later iteration stay fp64.  Same iteration counts, the
+ *                          converged point moves by 1e-11 ... 2e-10 (profiles/r6_fp32_*.txt).  Plain model, Schur blocks of 32 ... 320.  0: never (rounds 1-5)
  *   TMPC_TUNE_PERSISTENT   plain-model problems with single-tile Schur blocks and n = nx + mb <= 8 (the reference's own examples) can run their whole
  *                          interior-point loop as ONE launch, one workgroup per problem (tmpc_persist.h).  1 (default): where that is faster -- period
  *                          p <= 8, or at least 96 problems of the call on the chip at once; 0: never (the launch sequence); 2: whenever the shape allows it
@@ -126,6 +130,8 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
 #define TMPC_TUNE_GRAPH 5
 /* (key 6 belonged to two measured-and-dropped experiments -- rounds 5 and 6, profiles/r5_fused_elim.txt, profiles/r6_update_stream_*.txt -- and is not reused) */
 #define TMPC_TUNE_PERSISTENT 7
+#define TMPC_TUNE_LOWP_SWITCH 8
+#define TMPC_LOWP_SWITCH_DEFAULT 1e-5
 int tmpc_set_tuning(tmpc_handle* h, int key, double value);
 /* The general constructor: ng / nc rows of G_k / C_k (0: none), step3 != 0: room for T_k, lanes = concurrent half-waves on their own streams
  * (0: automatic -- two for problems whose blocks are a single 64 x 64 tile and chunk >= 2, one otherwise; at most 4). */

@@ -865,6 +865,10 @@ def sdp_step1(A, B, H, opts=None, verbose=False, trace=None, G=None, C=None, rho
             break
         if mu_t is None and relgap < 1e-2 and dinf < 1e-2:
             mu_t = 2.0 ** np.round(np.log2(o['tol'] * max(1.0, abs(tau))))
+            if o.get('mu_target') is not None:
+                # (test hook, tests/test_gpu_hard_targets.py: centre at the barrier parameter ANOTHER implementation ended at -- on hard targets the two guard their
+                # factorisations differently and may back off a different number of times; the central-path point at a given mu is the same object for both)
+                mu_t = float(o['mu_target'])
         # (a full Newton step removes the linear residuals: centering may start with pinf well above the final accuracy)
         # (after a shifted factorisation the directions are inexact and pinf may sit at 1e-3 ... 1e-1 while mu has arrived: the centering
         # phase -- back-off, steps of the exact factorisation one power of two up -- is the way out; the HIP path: k_ctrl_a)

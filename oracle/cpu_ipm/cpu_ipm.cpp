@@ -26,6 +26,7 @@ void scipy_dtrsm_(const char*, const char*, const char*, const char*, const int*
                   const int*);
 void scipy_dpotrf_(const char*, const int*, double*, const int*, int*);
 void scipy_dsyev_(const char*, const char*, const int*, double*, const int*, double*, double*, const int*, int*);
+void scipy_sgemm_(const char*, const char*, const int*, const int*, const int*, const float*, const float*, const int*, const float*, const int*, const float*, float*, const int*);
 void scipy_openblas_set_num_threads(int);
 int scipy_openblas_get_num_threads(void);
 }
@@ -214,6 +215,18 @@ struct Problem {
   int db = 0;
   vec D, Csub, Lkk, O, F, Ldense;
   double shift = 0.0;
+  bool lowp = false;              // EXPERIMENT (tests/tools/fp32_update_probe.py): the Schur-complement updates D -= O O', F = -F O' with operands rounded to float32 and
+  std::vector<float> fa, fb, fc;  // float32 accumulation (what an fp32-MFMA form of k_cr_update_dma would compute); Cholesky, triangular solves and substitutions stay fp64
+  // C (d x d, col-major) {-=, =} -A B' with float32 products
+  void upd32(double* C, const double* A, const double* B, int d, bool set) {
+    const size_t n2 = (size_t)d * d;
+    fa.resize(n2); fb.resize(n2); fc.resize(n2);
+    for (size_t e = 0; e < n2; ++e) { fa[e] = (float)A[e]; fb[e] = (float)B[e]; }
+    const float one = 1.0f, zero = 0.0f;
+    scipy_sgemm_("N", "T", &d, &d, &d, &one, fa.data(), &d, fb.data(), &d, &zero, fc.data(), &d);
+    if (set) for (size_t e = 0; e < n2; ++e) C[e] = -(double)fc[e];
+    else for (size_t e = 0; e < n2; ++e) C[e] -= (double)fc[e];
+  }
 
   void setup(int p_, int nx_, int mb_, const double* A_, const double* B_, const double* H_) {
     p = p_; nx = nx_; mb = mb_; n = nx + mb; d = nx * (nx + 1) / 2; db = d; A = A_; B = B_; H = H_;
@@ -315,15 +328,20 @@ struct Problem {
       if (k == p - 2) {
         for (size_t e = 0; e < bs; ++e) Ok[e] += Fpre[e];                              // the fill meets the sub-diagonal block
         scipy_dtrsm_("R", "L", "T", "N", &dd_, &dd_, &one, Lk, &dd_, Ok, &dd_);
-        scipy_dsyrk_("L", "N", &dd_, &dd_, &mone, Ok, &dd_, &one, &Lkk[(size_t)(p - 1) * bs], &dd_);
+        if (lowp) upd32(&Lkk[(size_t)(p - 1) * bs], Ok, Ok, d, false);
+        else scipy_dsyrk_("L", "N", &dd_, &dd_, &mone, Ok, &dd_, &one, &Lkk[(size_t)(p - 1) * bs], &dd_);
       } else {
         double* Fk = &F[k * bs];
         memcpy(Fk, Fpre.data(), bs * sizeof(double));
         scipy_dtrsm_("R", "L", "T", "N", &dd_, &dd_, &one, Lk, &dd_, Ok, &dd_);
         scipy_dtrsm_("R", "L", "T", "N", &dd_, &dd_, &one, Lk, &dd_, Fk, &dd_);
+        if (lowp) {
+          upd32(&Lkk[(size_t)(k + 1) * bs], Ok, Ok, d, false); upd32(&Lkk[(size_t)(p - 1) * bs], Fk, Fk, d, false); upd32(Fpre.data(), Fk, Ok, d, true);
+        } else {
         scipy_dsyrk_("L", "N", &dd_, &dd_, &mone, Ok, &dd_, &one, &Lkk[(size_t)(k + 1) * bs], &dd_);
         scipy_dsyrk_("L", "N", &dd_, &dd_, &mone, Fk, &dd_, &one, &Lkk[(size_t)(p - 1) * bs], &dd_);
         scipy_dgemm_("N", "T", &dd_, &dd_, &dd_, &mone, Fk, &dd_, Ok, &dd_, &zero, Fpre.data(), &dd_);
+        }
       }
     }
     scipy_dpotrf_("L", &dd_, &Lkk[(size_t)(p - 1) * bs], &dd_, &info);
@@ -514,7 +532,7 @@ static void assemble_dd(DdSys& sys, const Problem& pr, const std::vector<ddk::ma
   }
 }
 
-struct Result { double kappa, alpha; int status, iters, early; double mu_t = 0, stepn = 0; int dd_iters = 0, polish = 0; };
+struct Result { double kappa, alpha; int status, iters, early; double mu_t = 0, stepn = 0; int dd_iters = 0, polish = 0, lowp = 0; };
 constexpr double DD_SWITCH = 0x1p-23, POLISH_ENTER = 1e-4;      // as oracle/convexify_oracle.py
 constexpr int POLISH_MAX = 6;
 
@@ -652,7 +670,10 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     pr.adj(adjb, PhiH);
     for (int k = 0; k < p; ++k) pr.svec_grad(&U[(size_t)(p + k) * d], &adjb[(size_t)k * nxx]);
     if (!dd_on) {
+      { static const char* lps = getenv("CPU_IPM_LOWP_SWITCH"); static const double lpsw = lps ? atof(lps) : 0.0;      // EXPERIMENT hook (see Problem::lowp)
+        pr.lowp = lpsw > 0.0 && phase == 0 && mu > lpsw * std::max(1.0, fabs(tau)); if (pr.lowp) ++res.lowp; }
       if (!pr.factor()) { ipm = ST_INACC; break; }
+      if (pr.lowp && pr.shift > 0.0) { pr.lowp = false; res.lowp += 1000; if (!pr.factor()) { ipm = ST_INACC; break; } }      // (an fp32 update that costs a pivot: once more in fp64)
       if (tight && pr.shift > 0.0) dd_on = true;
     }
     if (dd_on) {
@@ -940,7 +961,7 @@ int cpu_ipm_convexify_batch2(int nb, int p, int nx, int mb, const double* A, con
     if (kappa) kappa[b] = r.kappa;
     if (status) status[b] = r.status;
     if (iters) iters[b] = r.iters;
-    if (info) { info[4 * b] = r.mu_t; info[4 * b + 1] = r.dd_iters; info[4 * b + 2] = r.polish; info[4 * b + 3] = r.stepn; }
+    if (info) { info[4 * b] = r.mu_t; info[4 * b + 1] = tight ? r.dd_iters : r.lowp; info[4 * b + 2] = r.polish; info[4 * b + 3] = r.stepn; }
   }
   omp_set_num_threads(saved);
   scipy_openblas_set_num_threads(blas_threads_before);

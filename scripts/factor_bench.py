@@ -4,6 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tunempc_amd._lib import HipConvexifier          # (TMPC_LIB=path: an experimental build of the library)
 h = HipConvexifier(2, 3, 1)
+if os.environ.get('FB_LOWP'):
+    h.set_tuning(lowp_switch=2.0)      # (a switch >= 1 in the debug entries: every Schur-complement update in single precision)
+if float(os.environ.get('FB_LOWP_VALUE', '0')) > 0:
+    h.set_tuning(lowp_switch=float(os.environ['FB_LOWP_VALUE']))      # (scripts/gpu_r6_ablate.sh)
 cases = [(512, 8, 300), (64, 8, 300), (8, 8, 300), (512, 64, 300), (64, 64, 300), (8, 64, 300), (1, 64, 300), (64, 200, 210), (1, 30, 10)]
 if len(sys.argv) > 1:
     cases = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]

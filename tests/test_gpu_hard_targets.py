@@ -6,9 +6,10 @@ gives towards it (k_ctrl_b / k_ctrl_a in tmpc_schur.h; convexify_oracle.py), and
 Until round 3 the iteration was repeated from the same iterate instead: these members ended `Feasible` at 1024 mu_t.
 
 The two implementations guard the factorisation differently (frozen pivots + a diagonal lift vs a uniform relative shift), so they may need
-a different number of back-offs; a member is value-compared where the final mu_t agree (tests/tools/hard_target_probe.py: 17 of 32, Hc to
-<= 5.4e-7; one back-off apart the points differ by 1-4 %, as DESIGN.md section 2 measures for the central path in general).  The bound of
-the value comparison is 1e-5, not 1e-8: cond(H) = 1e5 amplifies the rounding of either side by that factor."""
+a different number of back-offs (one back-off apart the points differ by 1-4 %, as DESIGN.md section 2 measures for the central path in general).
+Round 6: the comparison no longer depends on that coincidence -- the oracle is asked to centre at the mu_t the HIP path reports (`mu_target`
+hook of sdp_step1), so EVERY member is value-compared at the same barrier parameter (rounds 3-5: 17 of 32, only where the two happened to agree).
+cond(Hhat) = 1e5 amplifies the rounding of either side; the bound is HARD_BOUND, the measured values are printed."""
 import numpy as np
 import pytest
 import torch  # noqa: F401  (before the HIP library is loaded, see tests/test_gpu_parity.py)
@@ -17,6 +18,9 @@ pytestmark = pytest.mark.gpu
 
 import convexify_oracle as co  # noqa: E402
 from tunempc_amd import synthetic  # noqa: E402
+
+
+HARD_BOUND = 1e-5      # relative Frobenius bound of the value comparison at cond(Hhat) = 1e5 (measured values are printed)
 
 
 def _calH(A, B, P):
@@ -35,7 +39,7 @@ def test_hard_targets_end_optimal_after_backoff(p, nx, mb, sigP, rad):
     h = HipConvexifier(p, nx, mb)
     out = h.convexify_batch(A, B, H)
     h.close()
-    backoffs, compared, worst = [], 0, 0.0
+    backoffs, compared, worst, errs = [], 0, 0.0, []
     for b in range(nb):
         assert int(out['status'][b]) == 0, (b, out['status'][b], out['iters'][b])                  # 'Optimal' (rounds 1-2: up to 5 of 8 'Feasible')
         # solver-independent: Hc > 0, cond(Hc_k) <= kappa, Hc - H = calH(P)
@@ -53,14 +57,20 @@ def test_hard_targets_end_optimal_after_backoff(p, nx, mb, sigP, rad):
         assert r['ipm_status'] == 'optimal', (b, r['ipm_status'])
         # kappa: both are within N mu_t of the optimum whatever the back-off count
         assert abs(out['kappa'][b] - r['kappa']) <= 2.0 * (2 * p * (nx + mb) + 1) * max(out['info'][b, 6], r['mu_target'])
-        if r['mu_target'] == out['info'][b, 6]:
+        # value comparison at the SAME barrier parameter (round 6): the oracle centres at the mu_t the HIP path ended at (its own back-off rule may stop a power
+        # of two away: different safeguards of the factorisation).  Every member is compared unless the oracle cannot hold that target itself.
+        if r['mu_target'] != out['info'][b, 6]:
+            r = co.sdp_step1(A[b], B[b], H[b], dict(mu_target=out['info'][b, 6]))
+        if r['ipm_status'] == 'optimal' and r['mu_target'] == out['info'][b, 6]:
             Hc = H[b] + co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'])[1]
             e = np.linalg.norm(out['Hc'][b] - Hc) / np.linalg.norm(Hc)
             worst = max(worst, e); compared += 1
-            assert e < 1e-5, (b, k, e)
+            errs.append(e)
+            assert e < HARD_BOUND, (b, k, e)
+            assert abs(out['kappa'][b] - r['kappa']) <= 1e-8 * r['kappa']
     assert max(backoffs) >= 1                        # the case does exercise the back-off
-    assert compared >= 2, (compared, backoffs)
-    print(f'back-offs {backoffs}, value-compared {compared} members, worst {worst:.2e}')
+    assert compared >= nb - 1 - int(out['info'][:, 13].sum()), (compared, backoffs)      # (at most one member whose target the oracle cannot hold)
+    print(f'back-offs {backoffs}, value-compared {compared} of {nb} members at the same mu_t, worst {worst:.2e}, median {np.median(errs):.2e}')
 
 
 def test_hard_targets_through_the_models_with_multipliers():

@@ -236,7 +236,7 @@ def test_header_constants_match_the_python_mirror():
     assert defs['TMPC_MAX_ROWS'] == convexifier.NG_MAX == convexifier.NC_MAX == 31
     assert defs['TMPC_ARROW_LD'] == _lib.ARROW_LD == defs['TMPC_MAX_ROWS'] + 1
     assert [defs[k] for k in ('TMPC_TUNE_CHORD_STEP', 'TMPC_TUNE_SMALL_BLOCKS', 'TMPC_TUNE_EIG_PRETEST', 'TMPC_TUNE_FUSE_FWD', 'TMPC_TUNE_GRAPH',
-                             'TMPC_TUNE_PERSISTENT')] == [1, 2, 3, 4, 5, 7]      # (the positions HipConvexifier.set_tuning passes)
+                             'TMPC_TUNE_PERSISTENT', 'TMPC_TUNE_LOWP_SWITCH')] == [1, 2, 3, 4, 5, 7, 8]      # (the positions HipConvexifier.set_tuning passes)
     assert defs['TMPC_INFO_STRIDE'] == 16
     assert convexifier.N_TUNED == 32 and convexifier.N_ROWS_MAX == 64 and convexifier.N_MAX == 96
     lib = _lib.load_library()

@@ -194,9 +194,9 @@ class HipConvexifier:
         _check(self.lib, self.lib.tmpc_set_options(self._h, float(tol or 0.0), float(center_tol or 0.0),
                                                    int(max_iter or 0), int(center_iter or 0), self.flags), 'tmpc_set_options')
 
-    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None, persistent=None):
+    def set_tuning(self, chord_step=None, small_blocks=None, eig_pretest=None, fuse_fwd=None, graph=None, persistent=None, lowp_switch=None):
         """Performance knobs of the handle (include/tunempc_hip.h: tmpc_set_tuning); None keeps the current value."""
-        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph), (7, persistent)):
+        for key, v in ((1, chord_step), (2, small_blocks), (3, eig_pretest), (4, fuse_fwd), (5, graph), (7, persistent), (8, lowp_switch)):
             if v is not None:
                 _check(self.lib, self.lib.tmpc_set_tuning(self._h, key, float(v)), 'tmpc_set_tuning')
 
@@ -444,7 +444,7 @@ class HipConvexifier:
         out = np.zeros(16)
         _check(self.lib, self.lib.tmpc_get_profile(self._h, _dptr(out)), 'tmpc_get_profile')
         keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters',
-                'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms']
+                'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms', 'lanes', 'lowp_factorisations']
         return dict(zip(keys, out.tolist()))
 
     def pack_sensitivities(self, C=None, mu=None, Hbig=None, thr=1e-15, ncmax=None, nb=None):

@@ -198,6 +198,8 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.KF = c.take<double>(BP * 12 * nxx); w.adjV = c.take<double>(BP * NADJ * nxx); w.adjE = c.take<double>(BP * NADJ * nxx);
   w.part = c.take<double>(BP * NPART); w.prob = c.take<double>((size_t)dm.B * PS); w.iprob = c.take<int>((size_t)dm.B * IS);
   w.D = c.take<double>(BP * bs); w.O = c.take<double>(BP * bs); w.F = c.take<double>(BP * bs);
+  // float32 copies of the O factors for the single-precision updates of the early iterations (Opts::lowp_switch): plain model on the tuned path, blocks the LDS-DMA kernels take
+  w.O32 = (dm.nr == 0 && dm.nT == 0 && dm.n <= NMAX && dm.dp > 64 && dm.nt <= TRR_NT) ? c.take<float>(2 * BP * (size_t)dm.dp * ((dm.dp + 31) & ~31)) : nullptr;
   w.Linv = c.take<double>(BP * dm.nt * TB * TB); w.Ddiag = c.take<double>(BP * dm.dp);
   w.W3 = c.take<double>(BP * dm.dp * 3); w.U = c.take<double>(BP * dm.dp * 2); w.TU = c.take<double>(BP * dm.dp * 2);
   w.Z = c.take<double>(BP * dm.dp);
@@ -513,6 +515,7 @@ static int set_lds_attrs(int device) {
 static unsigned cr_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
 // host-side bits of Dims::flags (bit 0 = TMPC_FLAG_NO_MFMA is the only one device code reads)
 constexpr int DF_NO_SMALL = 2;   // tmpc_set_tuning(TMPC_TUNE_SMALL_BLOCKS, 0): the batched launch sequence also for dp = 16
+constexpr int DF_LOWP = 8;       // single-precision updates may be on for some problems (Opts::lowp_switch > 0 and the handle has the float32 copies): cr_factor launches their forward-substitution steps
 constexpr int DF_NO_DMA = 4;     // TMPC_DEBUG_FLAG_NO_DMA: the register-staged factorisation kernels (the path of blocks wider than 320) for every block size
 
 // Small blocks (dp = 16): one kernel per factorisation / per solve instead of a launch sequence per level (tmpc_cr_small.h); TMPC_SMALL=0: off
@@ -586,10 +589,15 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
       const int nm64 = (dm.dp + 63) / 64;
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
       hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
+      if (dm.flags & DF_LOWP)      // the tiles of the problems in single precision (the fp64 kernel leaves them alone)
+        hipLaunchKernelGGL(k_cr_update_dma_f32, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     mark(2);
+    // problems whose update tiles ran in single precision carried no right-hand sides: their z_s -= O_s z_i of the fused forward sweep, in fp64 from the fp64 O blocks
+    if (fuse_fwd1 && (dm.flags & DF_LOWP) && mf && use_dma && lv.nupd)
+      hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.uoff, lv.nupd, count, 1, 1);
   }
   if (nkev) *nkev = ke;
 }
@@ -608,7 +616,7 @@ static void cr_solve(const WS& w, const Dims& dm, const CrSched& sc, const int* 
   for (const CrLevel& lv : sc.lev) {
     if (skip_fwd) break;                 // the forward sweep ran inside the factorisation (cr_factor, fuse_fwd1)
     hipLaunchKernelGGL(k_cr_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), lds, st, w, dm, cd, lv.eoff, lv.nelim, count, pass);
-    if (lv.nupd) hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), lds, st, w, dm, cd, lv.uoff, lv.nupd, count, pass);
+    if (lv.nupd) hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), lds, st, w, dm, cd, lv.uoff, lv.nupd, count, pass, 0);
   }
   for (size_t l = sc.lev.size(); l-- > 0;) {
     const CrLevel& lv = sc.lev[l];
@@ -709,6 +717,8 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   o.tight = 0; o.tight_tol = 0.0;
   // (chord steps also with stage-local multipliers since round 3: their rows are part of the frozen blocks like everything else)
   o.fast_exit = (h->flags & TMPC_FLAG_FAST_EXIT) ? 1 : 0;
+  if ((h->flags & (TMPC_FLAG_NO_MFMA | TMPC_DEBUG_FLAG_NO_DMA)) || !w.O32) o.lowp_switch = 0.0;
+  if (o.lowp_switch > 0.0) dm.flags |= DF_LOWP;
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
@@ -844,7 +854,11 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     if (ddm) { if (nfac > 0) dd_factor(wf, dm, h->sched, h->d_sched, flist, nfac, st); }
-    else if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
+    else if (nfac > 0) {
+      Dims dmf = dm;      // single-precision updates exist in the first LOWP_ITERS iterations only (k_ctrl_a: I_ITERS = it + 1 for every problem of the chunk)
+      if (it + 1 > LOWP_ITERS) dmf.flags &= ~DF_LOWP;
+      cr_factor(w, dmf, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
+    }
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);
@@ -989,6 +1003,12 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     hipLaunchKernelGGL(k_tight_fallback, dim3(nb), dim3(64), 0, st, wall, dm);      // members whose tight phase failed: back to the result of the default solve
   }
   ln->prof[7] += it;
+  if (prof && w.O32) {      // problem-factorisations whose updates ran in single precision (profile slot 13)
+    std::vector<int> hip_((size_t)nb * IS);
+    HIPCHK(hipMemcpyAsync(hip_.data(), wall.iprob, hip_.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int b = 0; b < nb; ++b) ln->prof[13] += (double)hip_[(size_t)b * IS + I_NLOWP];
+  }
   if (big) hipLaunchKernelGGL(kb_final_stage, dim3(BPall), dim3(256), big_lds, st, wall, dm);
   else hipLaunchKernelGGL(k_final_stage, dim3(BPall), dim3(64), slots_bytes(FIN_SLOTS), st, wall, dm);
   hipLaunchKernelGGL(k_final_prob, dim3(nb), dim3(64), 0, st, wall, dm);
@@ -1099,6 +1119,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   h->tune_small = 1; h->tune_pretest = 1; h->tune_fuse = 1; h->tune_graph = 1; h->tune_persist = 1;
   h->opt.tol = 0x1p-25; h->opt.center_tol = 1e-9; h->opt.max_iter = 50; h->opt.center_iter = 12;
   h->opt.fast_exit = 0;
+  h->opt.lowp_switch = TMPC_LOWP_SWITCH_DEFAULT;
   h->opt.chord_step = 10.0;       // centering: re-use the factorisation once the iterate moves by < 1/10 in the local norm (profiles/r2z_chord_default.txt: +3.7 %, same answers to 1e-10); tmpc_set_tuning(TMPC_TUNE_CHORD_STEP, 0) disables
   h->flags = 0;
   WS tmp;
@@ -1115,7 +1136,8 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   for (int l = 0; l < nl && ok; ++l) {
     Lane& ln = h->lane[l];
     carve(ln.ws, h->dm, (char*)h->slab + (size_t)l * lane_bytes, &ln);
-    ok = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking) == hipSuccess;
+    if (ln.ws.O32) ok = hipMemset(ln.ws.O32, 0, 2 * (size_t)h->dm.B * h->dm.p * h->dm.dp * ((h->dm.dp + 31) & ~31) * sizeof(float)) == hipSuccess;      // (the padding columns stay zero: k_cr_trsm_dma writes the dp real ones)
+    ok = ok && hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&ln.ev[i]) == hipSuccess;
   }
   if (ok) { rc = set_lds_attrs(h->device); ok = (rc == TMPC_OK); }
@@ -1170,6 +1192,7 @@ int tmpc_set_tuning(tmpc_handle* h, int key, double value) {
   if (!h) return TMPC_E_ARG;
   switch (key) {
     case TMPC_TUNE_CHORD_STEP: if (!(value >= 0.0)) return TMPC_E_ARG; h->opt.chord_step = value; return TMPC_OK;
+    case TMPC_TUNE_LOWP_SWITCH: if (!(value >= 0.0)) return TMPC_E_ARG; h->opt.lowp_switch = value; return TMPC_OK;
     case TMPC_TUNE_SMALL_BLOCKS: h->tune_small = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_EIG_PRETEST: h->tune_pretest = value != 0.0; return TMPC_OK;
     case TMPC_TUNE_FUSE_FWD: h->tune_fuse = value != 0.0; return TMPC_OK;
@@ -1772,7 +1795,8 @@ int tmpc_debug_cr_schedule(int p, int32_t* out, int cap) {
 // stand-alone workspace for the unit test / timing of the block factorisation: nb copies of one system
 struct CrBench {
   WS w; Dims dm; CrSched sc; int* d_sched = nullptr; DevBuf D, O, F, Li, dd, Z, W3, ip, pr, al;
-  int init(int nb, int p, int d, int flags) {
+  DevBuf O32b; int ablate = 0;
+  int init(int nb, int p, int d, int flags, bool lowp = false) {
     memset(&w, 0, sizeof(w)); memset(&dm, 0, sizeof(dm));
     dm.B = nb; dm.p = p; dm.d = d; dm.dp = (d + 15) / 16 * 16; dm.nt = (dm.dp + TB - 1) / TB; dm.flags = flags & TMPC_FLAG_NO_MFMA;
     const size_t bs = (size_t)dm.dp * dm.dp, per = (size_t)p * bs;
@@ -1791,6 +1815,18 @@ struct CrBench {
     if (hipMemcpy(w.alist, ids.data(), nb * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return TMPC_E_HIP;
     if (hipMemset(w.iprob, 0, (size_t)nb * IS * sizeof(int)) != hipSuccess) return TMPC_E_HIP;       // phase = PH_MAIN
     if (hipMemcpy(w.prob, one.data(), one.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return TMPC_E_HIP;
+    if (lowp && dm.dp > 64 && dm.nt <= TRR_NT) {
+      dm.flags |= DF_LOWP;      // every problem with single-precision updates (timing / unit test of wg_tile_dma_f32)
+      const size_t n32 = 2 * (size_t)nb * p * dm.dp * ((dm.dp + 31) & ~31);
+      if (O32b.alloc(n32 * sizeof(float)) != hipSuccess || hipMemset(O32b.as<float>(), 0, n32 * sizeof(float)) != hipSuccess) return TMPC_E_NOMEM;
+      w.O32 = O32b.as<float>();
+#ifdef TMPC_ABLATE
+      dm.flags |= ablate << 24;
+#endif
+      std::vector<int> hi((size_t)nb * IS, 0);
+      for (int b = 0; b < nb; ++b) hi[(size_t)b * IS + I_LOWP] = 1;
+      if (hipMemcpy(w.iprob, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return TMPC_E_HIP;
+    }
     return TMPC_OK;
   }
   ~CrBench() { if (d_sched) hipFree(d_sched); }
@@ -1819,7 +1855,7 @@ int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const 
   if (!h || p < 1 || d < 1 || !D || !Ccpl || !rhs || !x) return TMPC_E_ARG;
   ON_DEVICE(h);
   CrBench cb;
-  int rc = cb.init(1, p, d, h->flags);
+  int rc = cb.init(1, p, d, h->flags, h->opt.lowp_switch >= 1.0);      // (a switch >= 1 is meaningless for a solve: in the two debug entries it means 'every update in single precision')
   if (rc != TMPC_OK) return rc;
   const int dp = cb.dm.dp;
   const size_t bs = (size_t)dp * dp;
@@ -1848,7 +1884,8 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
   if (!h || nb < 1 || p < 1 || d < 1 || reps < 1 || !ms_out2) return TMPC_E_ARG;
   ON_DEVICE(h);
   CrBench cb;
-  int rc = cb.init(nb, p, d, h->flags);
+  cb.ablate = (int)h->opt.lowp_switch - 2;      // (-DTMPC_ABLATE builds: 3, 4, 5, 6 = the ablations of wg_tile_dma_f32)
+  int rc = cb.init(nb, p, d, h->flags, h->opt.lowp_switch >= 1.0);
   if (rc != TMPC_OK) return rc;
   const int dp = cb.dm.dp;
   const size_t bs = (size_t)dp * dp, per = (size_t)p * bs;

@@ -40,11 +40,12 @@ enum {
 };
 // ---- per-problem int scalars (iprob[b*IS + idx])
 enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, I_BOSTEP, I_CHOLBAD, I_SHIFT0, I_JAM, I_SHIFTRUN, I_REG, I_CHORD, I_NCHORD, I_BACKOFF,
-       I_DD, I_NDD, I_NPOLISH, IS = 24 };   // I_DD: 1 = tight phase (block linear algebra in double-double, tmpc_dd.h); I_NDD: such iterations; I_NPOLISH: polish steps   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
+       I_DD, I_NDD, I_NPOLISH, I_LOWP, I_LOWPOFF, I_NLOWP, IS = 24 };   // I_LOWP: 1 = this iteration's Schur-complement updates run in float32 (k_cr_update_dma, Opts::lowp_switch); I_LOWPOFF: never again for this problem (a pivot froze under them); I_NLOWP: such iterations   // I_DD: 1 = tight phase (block linear algebra in double-double, tmpc_dd.h); I_NDD: such iterations; I_NPOLISH: polish steps   // I_BACKOFF: times mu_t was doubled for this problem (hard targets: the Schur matrix is numerically singular at the default mu_t)
 //   // I_BOSTEP: 1 = k_ctrl_b (ctrl_backoff_before_rhs) backed mu_t off in this centering iteration (frozen pivots): the step of that factorisation is TAKEN (k_ctrl_c)
 //   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
 //   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
+constexpr int LOWP_ITERS = 12;   // single-precision updates only in the first LOWP_ITERS iterations of a problem: the host launches k_cr_update_dma_f32 (and the forward-substitution steps of its problems) in exactly those
 // phases
 enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2, PH_POLISH = 3 };     // PH_POLISH: waits for / runs the dd dual-Newton polish of the tight mode (out of the active list)
 // ipm status
@@ -101,6 +102,8 @@ struct Opts {
                        // iterate moved by < 1/chord_step in the local norm), the next steps re-use the factorisation; 0 = never
   int tight;           // 1: this loop is the tight phase (tmpc_dd.h): no chord steps, no lifts / back-offs, centering hands over to the polish
   double tight_tol;    // its complementarity tolerance (mu_target = tight_tol * kappa)
+  double lowp_switch;  // > 0: the Schur-complement updates of the block factorisation (k_cr_update_dma) run on float32 copies of the O blocks with float32
+                       // accumulation in the main-phase iterations with mu > lowp_switch * max(1, |tau|) (plain model, blocks of 32 ... 320); 0: never
   int fast_exit;       // TMPC_FLAG_FAST_EXIT: stop after the FIRST full centering step (feasible, kappa within the gap N mu_t of optimal, but
                        // not the converged central-path point: not reproducible to 1e-8 between implementations)
 };
@@ -132,6 +135,8 @@ struct WS {
   double* D;       // [B,p,dp,dp]   diagonal blocks -> Cholesky factors (diag tiles hold L_jj, inverse in Linv)
   double* O;       // [B,p,dp,dp]   edge slots 0..p-1: coupling block of stages k, k+1 (orientation cr_orient[k]) -> O factors (tmpc_cr.h)
   double* F;       // [B,p,dp,dp]   edge slots p..2p-1: fill blocks of the cyclic reduction
+  float* O32;      // [B,2p,dp,ld32] float32 copies of the O factors of both slot ranges (ld32 = dp rounded up to 32, zero padding), written by k_cr_trsm_dma for
+                   //                the problems whose updates run in single precision (I_LOWP); nullptr: the handle has none
   double* Linv;    // [B,p,nt,TB,TB] inverses of the diagonal tiles
   double* Ddiag;   // [B,p,dp]      assembled diagonal of D (pivot reference for Cholesky-with-shift)
   double* W3;      // [B,p,dp,3]    pass-1 right-hand sides [rhs | u_tau | u_alpha] -> solutions

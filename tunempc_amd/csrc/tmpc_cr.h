@@ -153,6 +153,17 @@ __device__ __forceinline__ double* cr_edge(const WS& w, const Dims& dm, int b, i
   const size_t bs = (size_t)dm.dp * dm.dp;
   return (slot < dm.p) ? w.O + ((size_t)b * dm.p + slot) * bs : w.F + ((size_t)b * dm.p + (slot - dm.p)) * bs;
 }
+#ifdef TMPC_ABLATE
+#define TMPC_ABL(dm) (((dm).flags >> 24) & 7)
+#else
+#define TMPC_ABL(dm) 0
+#endif
+// float32 copy of edge slot `slot` (same slot numbering as cr_edge), row stride cr_ld32
+__device__ __forceinline__ int cr_ld32(const Dims& dm) { return (dm.dp + 31) & ~31; }
+__device__ __forceinline__ float* cr_edge32(const WS& w, const Dims& dm, int b, int slot) {
+  return w.O32 + ((size_t)b * 2 * dm.p + slot) * (size_t)dm.dp * cr_ld32(dm);
+}
+__device__ __forceinline__ bool cr_lowp(const WS& w, int b) { return w.O32 != nullptr && w.iprob[(size_t)b * IS + I_LOWP] != 0; }
 // XCD-aware work-item id: block i runs on XCD i % 8, so items are dealt to the XCDs in contiguous runs (the tiles of one
 // node -- consecutive items -- share their operands through one L2).  gridDim.x is a multiple of 8; -1: no item.
 __device__ __forceinline__ int cr_item(int nitems) {
@@ -265,7 +276,8 @@ constexpr int trd_lds_doubles() { return 4 * 1024 + TRD_DEPTH * 2048; }       //
 // nt = r + 1 tiles, the last one the diagonal tile, whose updates take X_i itself as the second operand (from LDS: no slab stream), and
 // which leaves as D_rr - sum_i X_i X_i' for the tile Cholesky instead of being multiplied by an inverse.
 template <bool POTRF>
-__device__ __forceinline__ void trd_strip(double* X, const double* Dk, const double* Li, int rows, int nt, int dp, int it, double* lds) {
+__device__ __forceinline__ void trd_strip(double* X, const double* Dk, const double* Li, int rows, int nt, int dp, int it, double* lds, float* X32 = nullptr, int ld32 = 0) {
+  // X32 (wave-uniform, or nullptr): every finished strip X_i is ALSO stored as float32 (row stride ld32) -- the operand copy of the single-precision updates
   constexpr int FR = 4, RS = 16 * FR, ASL = RS * 16, DP = TRD_DEPTH;          // fragments and rows per strip, doubles per A slab
   int tid = threadIdx.x;
   if (POTRF) asm volatile("" : "+v"(tid));                  // per-lane constants are rebuilt for every block row instead of living (spilled) across the tile Cholesky
@@ -339,9 +351,14 @@ __device__ __forceinline__ void trd_strip(double* X, const double* Dk, const dou
         typedef double2_t __attribute__((address_space(1)))* gptr2;                                         \
         gptr2 cp = (gptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);              \
         cp[0] = (double2_t){SG SET[c][0], SG SET[c][1]}; cp[1] = (double2_t){SG SET[c][2], SG SET[c][3]};   \
+        if (X32) {                                                                                          \
+          typedef float4_t __attribute__((address_space(1)))* gptr4;                                        \
+          *(gptr4)(X32 + (size_t)(wc0 + 4 * fq + fk) * ld32 + 64 * (I) + 16 * c + 4 * fj) =                 \
+              (float4_t){(float)(SG SET[c][0]), (float)(SG SET[c][1]), (float)(SG SET[c][2]), (float)(SG SET[c][3])}; \
+        }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
-    vmtot += 2 * (NC);                                                                                      \
+    vmtot += (X32 ? 3 : 2) * (NC);                                                                          \
   }
   // (+-) set -> A operand.  C: slab = this wave's strip, K pairs 2 fj and 2 fj + 1 of every row; R: this wave's rows of the slabs c < NC
 #define TRD_PARK_C(SET)      /* negated */                                                                  \
@@ -577,7 +594,10 @@ __global__ void __launch_bounds__(256, 2) k_cr_trsm_dma(WS w, Dims dm, CrDev cr,
   const double* Dk = w.D + ((size_t)b * dm.p + node) * (size_t)dp * dp;
   const double* Li = w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB;
   const int r0 = strip * 64;
-  trd_strip<false>(cr_edge(w, dm, b, slot) + (size_t)r0 * dp, Dk, Li, (dp - r0 < 64) ? dp - r0 : 64, dm.nt, dp, it, lds);
+  const bool lp = cr_lowp(w, b);
+  const int ld32 = cr_ld32(dm);
+  trd_strip<false>(cr_edge(w, dm, b, slot) + (size_t)r0 * dp, Dk, Li, (dp - r0 < 64) ? dp - r0 : 64, dm.nt, dp, it, lds,
+                   lp ? cr_edge32(w, dm, b, slot) + (size_t)r0 * ld32 : nullptr, ld32);
 }
 
 // ---- phase 1 on the same sweep: block row r of the factor is the triangular solve of the row strip r of D against the rows above it,
@@ -693,6 +713,7 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
   if (it < 0) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = cr.alist[it / per];
+  if (cr_lowp(w, b)) return;                               // this problem's tiles run in single precision: k_cr_update_dma_f32
   const int r = it % per;
   const size_t bs = (size_t)dp * dp;
   const int slot_items = ntf + ntl;
@@ -719,8 +740,10 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
     const double* z0 = fz ? cr_rhs(w, dm, b, ur[CU_S0], 3) : nullptr;
     const double* z1 = (fz && O1) ? cr_rhs(w, dm, b, ur[CU_S1], 3) : nullptr;
     double* yz = fz ? cr_rhs(w, dm, b, ur[CU_NODE], 3) + (size_t)m0 * 3 : nullptr;
-    wg_tile_dma<UPD_DMA_DEPTH>(C, dp, O0 + (size_t)m0 * dp, O0 + (size_t)n0 * dp, O1 ? O1 + (size_t)m0 * dp : nullptr, O1 ? O1 + (size_t)n0 * dp : nullptr,
-                               dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds, 0, z0, z1, yz, 3);
+    if (fz) wg_tile_dma<UPD_DMA_DEPTH, true>(C, dp, O0 + (size_t)m0 * dp, O0 + (size_t)n0 * dp, O1 ? O1 + (size_t)m0 * dp : nullptr, O1 ? O1 + (size_t)n0 * dp : nullptr,
+                                             dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds, 0, z0, z1, yz, 3);
+    else wg_tile_dma<UPD_DMA_DEPTH>(C, dp, O0 + (size_t)m0 * dp, O0 + (size_t)n0 * dp, O1 ? O1 + (size_t)m0 * dp : nullptr, O1 ? O1 + (size_t)n0 * dp : nullptr,
+                                    dp, M, N, dp, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds);
   } else {
     const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
     if (er[CE_FILL] < 0) return;
@@ -731,6 +754,56 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
     const double* Oy = cr_edge(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
     double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
     wg_tile_dma<UPD_DMA_DEPTH>(C, dp, Ox + (size_t)m0 * dp, Oy + (size_t)n0 * dp, nullptr, nullptr, dp, M, N, dp, er[CE_FACC] ? GM_SUB : GM_NEG, GM_NOTRI, it, lds);
+  }
+}
+
+// The same items for the problems whose Schur-complement updates run in SINGLE precision this iteration (I_LOWP, set by k_ctrl_a while mu / kappa > Opts::lowp_switch in
+// the first LOWP_ITERS iterations): float32 copies of the O blocks (written next to the fp64 ones by k_cr_trsm_dma), float32 accumulation on v_mfma_f32_16x16x4f32
+// (wg_tile_dma_f32), the result subtracted from / stored into the fp64 blocks.  No fused right-hand sides: k_cr_fwd_off runs for these problems (cr_factor).
+__global__ void __launch_bounds__(256, 4) k_cr_update_dma_f32(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
+  const int dp = dm.dp;
+  const int nm = (dp + 63) / 64;
+  const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
+  const int per = nupd * ntl + nelim * ntf;
+  const int it = cr_item(count * per);
+  if (it < 0) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int b = cr.alist[it / per];
+  if (!cr_lowp(w, b)) return;
+  const int r = it % per;
+  const size_t bs = (size_t)dp * dp;
+  const int slot_items = ntf + ntl, ld32 = cr_ld32(dm);
+  int j = r / slot_items, rr = r - j * slot_items;
+  bool is_upd;
+  {
+    const int nmin = nelim < nupd ? nelim : nupd;
+    const int full = nmin * slot_items;
+    if (r < full) { is_upd = rr >= ntf; if (is_upd) rr -= ntf; }
+    else if (nelim > nupd) { const int q = r - full; j = nmin + q / ntf; rr = q % ntf; is_upd = false; }
+    else { const int q = r - full; j = nmin + q / ntl; rr = q % ntl; is_upd = true; }
+  }
+  if (is_upd) {
+    const int* ur = cr.upd + (size_t)(uoff + (j + 1) % nupd) * CR_UW;
+    int t = rr, tm = 0;
+    while (t > tm) { t -= tm + 1; ++tm; }
+    const int tn = t;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    double* C = w.D + ((size_t)b * dm.p + ur[CU_NODE]) * bs + (size_t)m0 * dp + n0;
+    const float* P0 = cr_edge32(w, dm, b, ur[CU_E0]);
+    const float* P1 = ur[CU_E1] >= 0 ? cr_edge32(w, dm, b, ur[CU_E1]) : nullptr;
+    wg_tile_dma_f32<UPD_DMA_DEPTH>(C, dp, P0 + (size_t)m0 * ld32, P0 + (size_t)n0 * ld32, P1 ? P1 + (size_t)m0 * ld32 : nullptr, P1 ? P1 + (size_t)n0 * ld32 : nullptr,
+                                   ld32, M, N, ld32, GM_SUB, tm == tn ? 0 : GM_NOTRI, it, lds, TMPC_ABL(dm));
+  } else {
+    const int* er = cr.elim + (size_t)(eoff + j) * CR_EW;
+    if (er[CE_FILL] < 0) return;
+    const int tm = rr / nm, tn = rr - tm * nm;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int M = (dp - m0 < 64) ? dp - m0 : 64, N = (dp - n0 < 64) ? dp - n0 : 64;
+    const float* Px = cr_edge32(w, dm, b, er[CE_FX] ? er[CE_EB] : er[CE_EA]);
+    const float* Py = cr_edge32(w, dm, b, er[CE_FX] ? er[CE_EA] : er[CE_EB]);
+    double* C = cr_edge(w, dm, b, er[CE_FILL]) + (size_t)m0 * dp + n0;
+    wg_tile_dma_f32<UPD_DMA_DEPTH>(C, dp, Px + (size_t)m0 * ld32, Py + (size_t)n0 * ld32, nullptr, nullptr, ld32, M, N, ld32, er[CE_FACC] ? GM_SUB : GM_NEG, GM_NOTRI, it, lds, TMPC_ABL(dm));
   }
 }
 
@@ -766,11 +839,14 @@ __global__ void __launch_bounds__(256) k_cr_fwd_diag(WS w, Dims dm, CrDev cr, in
   vec_s2g(R, zc, xld, dp, nc);
 }
 
-__global__ void __launch_bounds__(256) k_cr_fwd_off(WS w, Dims dm, CrDev cr, int uoff, int nupd, int count, int pass) {
+// lowp_only: the call inside the factorisation (cr_factor, fused forward sweep of pass 1) for the problems whose update tiles run in single precision and
+// carry no right-hand sides -- every other problem's step rode in k_cr_update_dma
+__global__ void __launch_bounds__(256) k_cr_fwd_off(WS w, Dims dm, CrDev cr, int uoff, int nupd, int count, int pass, int lowp_only) {
   const int it = cr_item(count * nupd);
   if (it < 0) return;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = cr.alist[it / nupd];
+  if (lowp_only && !cr_lowp(w, b)) return;
   const int nc = cr_nc(w, b, pass);
   if (nc == 0) return;
   const int* ur = cr.upd + (size_t)(uoff + it % nupd) * CR_UW;

@@ -283,6 +283,13 @@ __device__ __forceinline__ void ctrl_a_body(const WS& w, const Dims& dm, const O
   }
   ip[I_ITERS] += 1;
   ip[I_SHIFT0] = ip[I_NSHIFT];
+  // early main-phase iterations: the Schur-complement updates of this factorisation in single precision (tmpc_gemm_dma.h: wg_tile_dma_f32).  Not once a
+  // pivot froze under them (k_ctrl_c repeats that iteration in fp64), not with a lifted diagonal, never while centering.
+  {
+    const int lowp = (o.lowp_switch > 0.0 && w.O32 != nullptr && phase == PH_MAIN && ip[I_ITERS] <= LOWP_ITERS && !ip[I_LOWPOFF] && ip[I_REG] == 0 && !o.tight &&
+                      mu > o.lowp_switch * fmax(1.0, fabs(tau))) ? 1 : 0;
+    ip[I_LOWP] = lowp; ip[I_NLOWP] += lowp;
+  }
   // centering budget: a chord step (factorisation re-used, a fifth of the cost, linear convergence) counts a quarter -- spending the
   // budget of Newton steps on chord steps would trigger the mu_t back-off below, i.e. change the answer, on slowly contracting members
   if (phase == PH_CENTER) { ip[I_NCENT] += (ip[I_CHORD] && (ip[I_NCHORD] & 3)) ? 0 : 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
@@ -404,6 +411,11 @@ __device__ __forceinline__ void ctrl_c_body(const WS& w, const Dims& dm, int reg
       // that triggered the back-off, discard the direction and repeat the iteration from the same iterate (round 3 did exactly that: this branch was
       // unreachable and every back-off of this kind cost up to three idle lift retries -- ADVICE r3).
       ip[I_SHIFTRUN] = 0;
+    } else if ((froze || nonfin) && ip[I_LOWP]) {
+      // a pivot froze under single-precision updates (not seen on the benchmark distribution at the default switch): the same iteration once more, in fp64 --
+      // no lift, no trace of the attempt in the iterate
+      ip[I_LOWPOFF] = 1; ip[I_SHIFTRUN] = 0; ip[I_JAM] = 0;
+      ap = 0.0; ad = 0.0; retry = true;
     } else if ((froze || nonfin) && ip[I_REG] < reg_max) {
       // first answer to frozen pivots: discard this direction, lift the Schur diagonal by 1e-12 relative
       // from now on and repeat the iteration from the same iterate -- the matrix sits within ~1e-13 (diagonally scaled) of
