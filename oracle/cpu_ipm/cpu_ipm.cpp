@@ -345,8 +345,10 @@ struct Problem {
       }
     }
     scipy_dpotrf_("L", &dd_, &Lkk[(size_t)(p - 1) * bs], &dd_, &info);
+    if (lowp && lowp_solve) { for (double& v : O) v = (double)(float)v; for (double& v : F) v = (double)(float)v; }      // EXPERIMENT: the substitutions read the float32 copies of the O blocks
     return info == 0;
   }
+  bool lowp_solve = false;
   bool factor() {
     double sh = 0.0;
     for (;;) {
@@ -671,6 +673,7 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
     for (int k = 0; k < p; ++k) pr.svec_grad(&U[(size_t)(p + k) * d], &adjb[(size_t)k * nxx]);
     if (!dd_on) {
       { static const char* lps = getenv("CPU_IPM_LOWP_SWITCH"); static const double lpsw = lps ? atof(lps) : 0.0;      // EXPERIMENT hook (see Problem::lowp)
+        static const bool lpsolve = getenv("CPU_IPM_LOWP_SOLVE") != nullptr; pr.lowp_solve = lpsolve;
         pr.lowp = lpsw > 0.0 && phase == 0 && mu > lpsw * std::max(1.0, fabs(tau)); if (pr.lowp) ++res.lowp; }
       if (!pr.factor()) { ipm = ST_INACC; break; }
       if (pr.lowp && pr.shift > 0.0) { pr.lowp = false; res.lowp += 1000; if (!pr.factor()) { ipm = ST_INACC; break; } }      // (an fp32 update that costs a pivot: once more in fp64)

@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
 nb, p, nx, mb = (int(v) for v in sys.argv[1:5])
 th = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 res = {}
-for sw in ('0', '1e-4', '3e-5', '1e-5', '3e-6'):
+for sw in ('0', '3e-5', '1e-5'):
     env = dict(os.environ)
     if sw != '0':
         env['CPU_IPM_LOWP_SWITCH'] = sw

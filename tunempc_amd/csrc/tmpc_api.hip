@@ -532,7 +532,8 @@ static bool cr_small_levels(const Dims& dm, const CrSched& sc, CrLevs* out) {
 // rs / mt: rows per workgroup of the triangular solves / edge of the output tile of the updates; 0 = by the amount of work
 // (whole 128-wide pieces while every CU still gets several workgroups, 64 otherwise).  The result does not depend on them.
 static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int* d_sched, const int* alist, int count, hipStream_t st,
-                      int rs_opt, int mt_opt, std::vector<hipEvent_t>* kev = nullptr, int* nkev = nullptr, int fuse_fwd1 = 0) {
+                      int rs_opt, int mt_opt, std::vector<hipEvent_t>* kev = nullptr, int* nkev = nullptr, int fuse_fwd1 = 0, int nlowp = 0) {
+  // nlowp: how many of the `count` problems run their Schur-complement updates in single precision (exact: k_ctrl_d / k_init_prob counted them)
   const CrDev cd = cr_dev(sc, d_sched, alist);
   int ke = 0;
   // profile mode: an event before and after every launch; pair i belongs to class i % 3 (potrf, trsm, update)
@@ -588,15 +589,16 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     if (mf && use_dma) {
       const int nm64 = (dm.dp + 63) / 64;
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
-      hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
-      if (dm.flags & DF_LOWP)      // the tiles of the problems in single precision (the fp64 kernel leaves them alone)
-        hipLaunchKernelGGL(k_cr_update_dma_f32, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
+      if (nlowp < count)           // (each kernel leaves the other's problems alone)
+        hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
+      if (nlowp > 0)               // no right-hand-side mini slabs in the float32 tile: 32 KB of LDS, five workgroups per CU
+        hipLaunchKernelGGL(k_cr_update_dma_f32, dim3(cr_grid(it_dma)), dim3(256), (size_t)UPD_DMA_DEPTH * DMA_SLAB * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
     }
     else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
     mark(2);
     // problems whose update tiles ran in single precision carried no right-hand sides: their z_s -= O_s z_i of the fused forward sweep, in fp64 from the fp64 O blocks
-    if (fuse_fwd1 && (dm.flags & DF_LOWP) && mf && use_dma && lv.nupd)
+    if (fuse_fwd1 && nlowp > 0 && mf && use_dma && lv.nupd)
       hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.uoff, lv.nupd, count, 1, 1);
   }
   if (nkev) *nkev = ke;
@@ -724,7 +726,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
   bool use_graph = h->tune_graph && dm.dp <= 64 && !(h->flags & (TMPC_FLAG_PROFILE | TMPC_DEBUG_FLAG_STOP_ASSEMBLED)) && st == ln->st;
   const int reg_max = (h->flags & TMPC_DEBUG_FLAG_NO_LIFT) ? 0 : REG_MAX;      // (debug: no diagonal lifts, frozen pivots while centering go straight to the back-off-and-step route)
-  HIPCHK(hipMemsetAsync(w.active, 0, 4 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.active, 0, 5 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.trace, 0, (size_t)nb * TRACE_LEN * TRACE_W * sizeof(double), st));
   const size_t big_lds = (size_t)BIG_EIG_LDS * sizeof(double);
   if (big) hipLaunchKernelGGL(kb_init_stage, dim3(BPall), dim3(256), big_lds, st, wall, dm);
@@ -736,10 +738,10 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   hipLaunchKernelGGL(k_init_state, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (eq) hipLaunchKernelGGL(k_phi_init, dim3(BPall), dim3(64), 0, st, wall, dm);
   if (t3) hipLaunchKernelGGL(k_t3_init, dim3(BPall), dim3(64), 0, st, wall, dm);
-  int cnt[4] = {0, 0, 0, 0};              // problems still iterating / of which need a factorisation / handed to the polish / still polishing
-  HIPCHK(hipMemcpyAsync(cnt, w.active, sizeof(int), hipMemcpyDeviceToHost, st));
+  int cnt[5] = {0, 0, 0, 0, 0};           // problems still iterating / of which need a factorisation / handed to the polish / still polishing / to factor with single-precision updates
+  HIPCHK(hipMemcpyAsync(cnt, w.active, 5 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  int active = cnt[0], nfac = cnt[0];
+  int active = cnt[0], nfac = cnt[0], nlowp = cnt[4];
   // main-phase cap + a centering budget per target the back-off may visit (the CPU restatement's bound).  Only members that keep backing
   // off get there -- a degenerate Step 3 member of the fuzz (kappa* = 1, damped centering steps at every target) needs ~110 iterations;
   // until round 3 the wave stopped at max_iter + center_iter + 2 = 64 and such a member came back Feasible.
@@ -854,11 +856,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     if (prof) HIPCHK(hipEventRecord(ln->ev[2], st));
     if (ddm) { if (nfac > 0) dd_factor(wf, dm, h->sched, h->d_sched, flist, nfac, st); }
-    else if (nfac > 0) {
-      Dims dmf = dm;      // single-precision updates exist in the first LOWP_ITERS iterations only (k_ctrl_a: I_ITERS = it + 1 for every problem of the chunk)
-      if (it + 1 > LOWP_ITERS) dmf.flags &= ~DF_LOWP;
-      cr_factor(w, dmf, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0);
-    }
+    else if (nfac > 0) cr_factor(w, dm, h->sched, h->d_sched, flist, nfac, st, h->rs, h->mt, prof ? &ln->kev : nullptr, &nkev, fuse1 ? 1 : 0, ddm ? 0 : nlowp);
     if (prof) HIPCHK(hipEventRecord(ln->ev[3], st));
     for (int pass = 1; pass <= 2; ++pass) {
       const bool fused = (pass == 1 && fuse1);
@@ -899,6 +897,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     if (eq) hipLaunchKernelGGL(k_phi_update, dim3((BPall + 63) / 64), dim3(64), 0, st, w, dm);
     if (t3) hipLaunchKernelGGL(k_t3_update, dim3(BP), dim3(64), 0, st, w, dm);
     HIPCHK(hipMemsetAsync(w.active, 0, 2 * sizeof(int), st));
+    if (dm.flags & DF_LOWP) HIPCHK(hipMemsetAsync(w.active + 4, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_ctrl_d, dim3((nb + 63) / 64), dim3(64), 0, st, w, dm, o);
     if (prof) HIPCHK(hipEventRecord(ln->ev[5], st));
     }      // (!gexec)
@@ -916,9 +915,9 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
     }
     if (gexec) HIPCHK(hipGraphLaunch(gexec, st));
     const int nfac_done = nfac;
-    HIPCHK(hipMemcpyAsync(cnt, w.active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(cnt, w.active, ((dm.flags & DF_LOWP) ? 5 : 2) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    active = cnt[0]; nfac = cnt[1];
+    active = cnt[0]; nfac = cnt[1]; nlowp = (dm.flags & DF_LOWP) ? cnt[4] : 0;
     if (prof) {
       float ms;
       for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[i], ln->ev[i + 1])); ln->prof[i] += ms; }
@@ -1866,7 +1865,7 @@ int tmpc_debug_block_solve(tmpc_handle* h, int p, int d, const double* D, const 
   HIPCHK(hipMemcpy(cb.w.O, hO.data(), p * bs * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cb.w.Ddiag, hdd.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(cb.w.Z, hz.data(), (size_t)p * dp * 8, hipMemcpyHostToDevice));
-  cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, 1, 0, h->rs, h->mt);
+  cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, 1, 0, h->rs, h->mt, nullptr, nullptr, 0, cb.w.O32 ? 1 : 0);
   cr_solve(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, 1, 0, 2);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipGetLastError());
@@ -1922,7 +1921,7 @@ int tmpc_debug_factor_bench(tmpc_handle* h, int nb, int p, int d, int reps, doub
       HIPCHK(hipMemcpyAsync(cb.w.O + b * per, pO.p, per * 8, hipMemcpyDeviceToDevice, 0));
     }
     HIPCHK(hipEventRecord(e0, 0));
-    cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, nb, 0, h->rs, h->mt);
+    cr_factor(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, nb, 0, h->rs, h->mt, nullptr, nullptr, 0, cb.w.O32 ? nb : 0);
     HIPCHK(hipEventRecord(e1, 0));
     cr_solve(cb.w, cb.dm, cb.sc, cb.d_sched, cb.w.alist, nb, 0, 2);
     HIPCHK(hipEventRecord(e2, 0));

@@ -45,7 +45,6 @@ enum { I_PHASE = 0, I_ITERS, I_NCENT, I_IPMSTATUS, I_EARLY, I_NSHIFT, I_STATUS, 
 //   // I_REG: regularisation level of the Schur diagonal (0: none), raised after an iteration with frozen pivots
 //   // I_CHORD: 1 = this centering iteration re-uses the factorisation (and border columns) of the previous one; I_NCHORD: such iterations so far
 //   // I_SHIFT0: I_NSHIFT at the start of the iteration; I_JAM: consecutive iterations with collapsed step lengths; I_SHIFTRUN: consecutive iterations with frozen pivots
-constexpr int LOWP_ITERS = 12;   // single-precision updates only in the first LOWP_ITERS iterations of a problem: the host launches k_cr_update_dma_f32 (and the forward-substitution steps of its problems) in exactly those
 // phases
 enum { PH_MAIN = 0, PH_CENTER = 1, PH_DONE = 2, PH_POLISH = 3 };     // PH_POLISH: waits for / runs the dd dual-Newton polish of the tight mode (out of the active list)
 // ipm status
@@ -67,6 +66,7 @@ enum {
 // Kronecker-factor slots per stage (KF[((b*p+k)*12 + slot) * nx*nx])
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 enum { KF_XXX = 0, KF_SIXX, KF_KX, KF_KS, KF_FX, KF_FS, KF_PER_LMI = 6 };
 // adjoint slots per stage: 0: G = T1-T2 (rhs), 1: Psi (tau column), 2: PhiH (alpha column)
 enum { ADJ_G = 0, ADJ_PSI, ADJ_PHI, NADJ = 3 };
@@ -79,7 +79,7 @@ struct Dims {
   int d;        // nx(nx+1)/2
   int dp;       // d padded to a multiple of 16
   int nt;       // ceil(dp / TB)
-  int flags;    // bit0: debug - replace MFMA by scalar FMAs
+  int flags;    // bit0: debug - replace MFMA by scalar FMAs; bit3 (DF_LOWP, tmpc_api.hip): single-precision updates are on for this call (k_init_prob: the first iteration)
   int ng;       // rows of the equality-constraint Jacobian G_k per stage (0: none), <= NGM
   int nr;       // row stride of the stage-local multipliers: ng + (max rows of the active-constraint Jacobians C_k, Step 2), <= NRM
   int nz;       // stride of the stage-local variable vector: nr (+ 2 epigraph variables of the norm terms in Step 2)

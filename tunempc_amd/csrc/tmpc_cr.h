@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256, 4) k_cr_update_dma(WS w, Dims dm, CrDev c
 // The same items for the problems whose Schur-complement updates run in SINGLE precision this iteration (I_LOWP, set by k_ctrl_a while mu / kappa > Opts::lowp_switch in
 // the first LOWP_ITERS iterations): float32 copies of the O blocks (written next to the fp64 ones by k_cr_trsm_dma), float32 accumulation on v_mfma_f32_16x16x4f32
 // (wg_tile_dma_f32), the result subtracted from / stored into the fp64 blocks.  No fused right-hand sides: k_cr_fwd_off runs for these problems (cr_factor).
-__global__ void __launch_bounds__(256, 4) k_cr_update_dma_f32(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
+__global__ void __launch_bounds__(256, 5) k_cr_update_dma_f32(WS w, Dims dm, CrDev cr, int eoff, int nelim, int uoff, int nupd, int count) {
   const int dp = dm.dp;
   const int nm = (dp + 63) / 64;
   const int ntl = nm * (nm + 1) / 2, ntf = nm * nm;
@@ -861,7 +861,9 @@ __global__ void __launch_bounds__(256) k_cr_fwd_off(WS w, Dims dm, CrDev cr, int
     if (slot < 0) break;
     vec_g2s(zi, xld, cr_rhs(w, dm, b, ur[q ? CU_S1 : CU_S0], nc), dp, nc);
     __syncthreads();
-    wg_gemv16<false>(zs, xld, zi, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);      // z_s -= O_s z_i
+    // z_s -= O_s z_i; in an iteration whose updates run in single precision the sweep reads the float32 copies of the O blocks (half the bytes)
+    if (cr_lowp(w, b)) wg_gemv16<false, false, float>(zs, xld, zi, xld, cr_edge32(w, dm, b, slot), cr_ld32(dm), dp, dp, true, -1.0, As, nc);
+    else wg_gemv16<false>(zs, xld, zi, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);
   }
   __syncthreads();
   vec_s2g(R, zs, xld, dp, nc);
@@ -887,7 +889,9 @@ __global__ void __launch_bounds__(256) k_cr_bwd(WS w, Dims dm, CrDev cr, int eof
     __syncthreads();
     vec_g2s(zn, xld, cr_rhs(w, dm, b, er[q ? CE_NB : CE_NA], nc), dp, nc);
     __syncthreads();
-    wg_gemv16<true>(zc, xld, zn, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);       // z_i -= O_x' z_x
+    // z_i -= O_x' z_x
+    if (cr_lowp(w, b)) wg_gemv16<true, false, float>(zc, xld, zn, xld, cr_edge32(w, dm, b, slot), cr_ld32(dm), dp, dp, true, -1.0, As, nc);
+    else wg_gemv16<true>(zc, xld, zn, xld, cr_edge(w, dm, b, slot), dp, dp, dp, true, -1.0, As, nc);
   }
   __syncthreads();
   blk_bwd(zc, xld, tmp, tld, w.D + ((size_t)b * dm.p + node) * dp * dp, w.Linv + ((size_t)b * dm.p + node) * dm.nt * TB * TB, dp, As, nc);

@@ -41,6 +41,12 @@ typedef const double2_t __attribute__((address_space(1)))* gcptr2;
     const double2_t u1_ = (ok) ? ((gcptr2)(p))[1] : (double2_t){0.0, 0.0};              \
     dst[(off) + 0] = u0_[0]; dst[(off) + 1] = u0_[1]; dst[(off) + 2] = u1_[0]; dst[(off) + 3] = u1_[1]; \
   }
+// the same piece of a float32 matrix (one 16-byte load), widened to double
+#define TMPC_LD4F(dst, off, p, ok)                                                      \
+  {                                                                                     \
+    const float4_t u_ = (ok) ? *(const float4_t __attribute__((address_space(1)))*)(p) : (float4_t){0.f, 0.f, 0.f, 0.f}; \
+    dst[(off) + 0] = (double)u_[0]; dst[(off) + 1] = (double)u_[1]; dst[(off) + 2] = (double)u_[2]; dst[(off) + 3] = (double)u_[3]; \
+  }
 typedef double __attribute__((address_space(1)))* gptr;
 // WM x WN waves per workgroup (blockDim.x = 64 WM WN), FA fragments of 16 rows per wave: a wave owns (16 FA) x 32 of C, the
 // workgroup tile is TM x TN = (16 FA WM) x (32 WN).  Two shapes are used: <2,2,2> = 64 x 64 with 256 threads (two workgroups per
@@ -530,9 +536,12 @@ constexpr int GKV = 16, GLDV = GKV + 1;   // K slab of the skinny GEMM
 
 // LOWER: M is a lower-triangular tile (an inverted diagonal tile): the 4-element pieces above the diagonal are zeros in memory and are
 // not fetched (3/8 of the tile: the substitutions are bound by the bytes they stream)
-template <bool TRANS, bool LOWER = false>
-__device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, int xld, const double* M, int ldm,
+// MT = float: M is a float32 copy of the matrix (the O blocks of an iteration whose updates run in single precision, tmpc_cr.h: half the bytes of a sweep that is
+// bound by them); its entries are widened on the way into LDS, products and sums stay fp64.
+template <bool TRANS, bool LOWER = false, typename MT = double>
+__device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, int xld, const MT* M, int ldm,
                                           int rows, int cols, bool accumulate, double sgn, double* As, int nc) {
+  constexpr bool F32 = sizeof(MT) == 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   const int nks = cols / GKV;
@@ -543,16 +552,17 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
     const int lrow = TRANS ? (tid >> 4) : (tid >> 2);            // TRANS: k index (0..15) ; else row (0..63)
     const int lcol = TRANS ? ((tid & 15) * 4) : ((tid & 3) * 4); // TRANS: first i ; else first k
     const bool ok = TRANS ? (m0 + lcol < rows) : (m0 + lrow < rows);
-    const double* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
+    const MT* src = TRANS ? (M + (size_t)lrow * ldm + m0 + lcol) : (M + (size_t)(m0 + lrow) * ldm + lcol);
     const size_t kstep = TRANS ? (size_t)GKV * ldm : (size_t)GKV;
     // four slabs of loads in flight per thread (ra..rd, slab ks mod 4): the solve streams the factors once and is bound by
     // bytes in flight (512 workgroups x 8 KB with a single prefetch: 4.4 TB/s; two in flight: 5.2)
     double rb[4], rc[4], rd[4];
 #define TMPC_GEMV_OK(KS) (ok && (!LOWER || (TRANS ? (m0 + lcol <= GKV * (KS) + lrow) : (GKV * (KS) + lcol <= m0 + lrow))))
-    TMPC_LD4(ra, 0, src, TMPC_GEMV_OK(0))
-    if (nks > 1) { const double* s1 = src + kstep; TMPC_LD4(rb, 0, s1, TMPC_GEMV_OK(1)) }
-    if (nks > 2) { const double* s1 = src + 2 * kstep; TMPC_LD4(rc, 0, s1, TMPC_GEMV_OK(2)) }
-    if (nks > 3) { const double* s1 = src + 3 * kstep; TMPC_LD4(rd, 0, s1, TMPC_GEMV_OK(3)) }
+#define TMPC_GEMV_LD(RG, P, OK) { if (F32) TMPC_LD4F(RG, 0, P, OK) else TMPC_LD4(RG, 0, P, OK) }
+    TMPC_GEMV_LD(ra, src, TMPC_GEMV_OK(0))
+    if (nks > 1) { const MT* s1 = src + kstep; TMPC_GEMV_LD(rb, s1, TMPC_GEMV_OK(1)) }
+    if (nks > 2) { const MT* s1 = src + 2 * kstep; TMPC_GEMV_LD(rc, s1, TMPC_GEMV_OK(2)) }
+    if (nks > 3) { const MT* s1 = src + 3 * kstep; TMPC_GEMV_LD(rd, s1, TMPC_GEMV_OK(3)) }
 #define TMPC_GEMV_SLAB(RG, KS)                                                                                  \
     {                                                                                                             \
       __syncthreads();                                                                                            \
@@ -563,8 +573,8 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
       }                                                                                                           \
       __syncthreads();                                                                                            \
       if ((KS) + 4 < nks) {                                                                                       \
-        const double* s2 = src + (size_t)((KS) + 4) * kstep;                                                      \
-        TMPC_LD4(RG, 0, s2, TMPC_GEMV_OK((KS) + 4))                                                              \
+        const MT* s2 = src + (size_t)((KS) + 4) * kstep;                                                          \
+        TMPC_GEMV_LD(RG, s2, TMPC_GEMV_OK((KS) + 4))                                                             \
       }                                                                                                           \
       if (m0 + 16 * wv < rows) {                                                                                  \
         const int k0 = (KS) * GKV;                                                                                \
@@ -582,6 +592,7 @@ __device__ __forceinline__ void wg_gemv16(double* Y, int yld, const double* X, i
       if (ks + 3 < nks) TMPC_GEMV_SLAB(rd, ks + 3)
     }
 #undef TMPC_GEMV_SLAB
+#undef TMPC_GEMV_LD
 #undef TMPC_GEMV_OK
     if (m0 + 16 * wv < rows && fr < nc) {
 #pragma unroll

@@ -202,7 +202,6 @@ __device__ __forceinline__ void wg_tile_dma(double* C, int ldc, const double* A0
 // granule swizzle are those of wg_tile_dma; a lane reads one 16-byte granule (four consecutive k) of row lane & 15 per fragment and feeds
 // element e of it to MFMA e -- A and B agree on which k a slot means, the sum over k is the same.  Accumulator of fragment i: C rows
 // 16 i + 4 (lane >> 4) + r, column wc0 + (lane & 15).
-typedef float float4_t __attribute__((ext_vector_type(4)));
 template <int DEPTH>
 __device__ __forceinline__ void wg_tile_dma_f32(double* C, int ldc, const float* A0, const float* B0, const float* A1, const float* B1, int ld32,
                                                 int M, int N, int K32, int mode, int tri, int rot, double* lds, int ablate = 0) {

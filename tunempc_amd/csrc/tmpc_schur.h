@@ -283,13 +283,7 @@ __device__ __forceinline__ void ctrl_a_body(const WS& w, const Dims& dm, const O
   }
   ip[I_ITERS] += 1;
   ip[I_SHIFT0] = ip[I_NSHIFT];
-  // early main-phase iterations: the Schur-complement updates of this factorisation in single precision (tmpc_gemm_dma.h: wg_tile_dma_f32).  Not once a
-  // pivot froze under them (k_ctrl_c repeats that iteration in fp64), not with a lifted diagonal, never while centering.
-  {
-    const int lowp = (o.lowp_switch > 0.0 && w.O32 != nullptr && phase == PH_MAIN && ip[I_ITERS] <= LOWP_ITERS && !ip[I_LOWPOFF] && ip[I_REG] == 0 && !o.tight &&
-                      mu > o.lowp_switch * fmax(1.0, fabs(tau))) ? 1 : 0;
-    ip[I_LOWP] = lowp; ip[I_NLOWP] += lowp;
-  }
+  ip[I_NLOWP] += ip[I_LOWP];      // (this iteration's Schur-complement updates run in single precision: decided by k_ctrl_d of the previous iteration / k_init_prob)
   // centering budget: a chord step (factorisation re-used, a fifth of the cost, linear convergence) counts a quarter -- spending the
   // budget of Newton steps on chord steps would trigger the mu_t back-off below, i.e. change the answer, on slowly contracting members
   if (phase == PH_CENTER) { ip[I_NCENT] += (ip[I_CHORD] && (ip[I_NCHORD] & 3)) ? 0 : 1; pr[P_SIGMU] = mut; pr[P_CORR0] = 0.0; }
@@ -512,9 +506,23 @@ __device__ __forceinline__ void ctrl_d_body(const WS& w, const Dims& dm, const O
     if (ip[I_CHORD]) ip[I_NCHORD] += 1;
     pr[P_PREVSTEPN] = (full && !full_reset) ? stepn : -1.0;
   }
+  // Early main-phase iterations: the Schur-complement updates of the NEXT factorisation in single precision (tmpc_gemm_dma.h: wg_tile_dma_f32) while the barrier
+  // parameter it will meet -- predicted from this iteration's step, (1 - a) mu + a sigma mu with a = min(ap, ad) -- is above lowp_switch * kappa.  Decided here,
+  // a whole iteration ahead, because the host sizes its launches from the counters this kernel leaves (w.active[4]: such problems among those to factor): it
+  // starts the float32 kernel, the fp64 one, or both.  Not once a pivot froze under them (k_ctrl_c repeats that iteration in fp64), not with a lifted diagonal,
+  // never while centering (the switch sits two to three orders of magnitude above mu_t).
+  {
+    int lowp = 0;
+    if (o.lowp_switch > 0.0 && w.O32 != nullptr && !o.tight && ip[I_PHASE] == PH_MAIN && !ip[I_LOWPOFF] && ip[I_REG] == 0) {
+      const double a = fmin(pr[P_AP], pr[P_AD]);
+      const double mu_next = (1.0 - a) * pr[P_MU] + a * pr[P_SIGMU];
+      lowp = mu_next > o.lowp_switch * fmax(1.0, fabs(pr[P_TAU]));
+    }
+    ip[I_LOWP] = lowp;
+  }
   if (lists && ip[I_PHASE] != PH_DONE) {
     const int slot = atomicAdd(w.active, 1); w.alist[slot] = b;
-    if (!ip[I_CHORD]) { const int fs = atomicAdd(w.active + 1, 1); w.flist[fs] = b; }
+    if (!ip[I_CHORD]) { const int fs = atomicAdd(w.active + 1, 1); w.flist[fs] = b; if (ip[I_LOWP]) atomicAdd(w.active + 4, 1); }
   }
 }
 __global__ void __launch_bounds__(64) k_ctrl_d(WS w, Dims dm, Opts o) {

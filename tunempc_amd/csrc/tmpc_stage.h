@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(64) k_init_prob(WS w, Dims dm) {
     ip[I_PHASE] = early ? PH_DONE : PH_MAIN;
     ip[I_IPMSTATUS] = early ? IPM_OPTIMAL : IPM_MAXITER;
     if (!early) { const int slot = atomicAdd(w.active, 1); w.alist[slot] = b; w.flist[slot] = b; }
+    // the first factorisation with single-precision updates when the call has them on (later iterations: k_ctrl_d)
+    if (!early && (dm.flags & 8) && w.O32) { ip[I_LOWP] = 1; atomicAdd(w.active + 4, 1); }
   }
 }
 
