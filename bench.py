@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD CDNA4 datasheet figure; not in MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TFLOPS = 157.3  # fp32-in / fp32-accumulate MFMA (v_mfma_f32_16x16x4_f32; /opt/skills/guides/cdna_hip_programming.md: 155 TF measured)
 
 
 def factor_flops_per_problem(p, d):
@@ -33,7 +34,7 @@ def factor_flops_per_problem(p, d):
     return full + (1.0 / 3 + 1 + 1) * d3 + d3 / 3.0                 # stage p-2 (no fill row), stage p-1 (chol only)
 
 
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r5_traffic.json')
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r6_traffic.json')
 KERNEL_SOURCES = sorted(os.path.join(ROOT, 'tunempc_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'tunempc_amd', 'csrc')) if f.endswith(('.h', '.hip')))      # every kernel source (round 3 hashed two of them)
 
 
@@ -53,16 +54,15 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def hbm_traffic_per_launch():
-    """HBM bytes per k_cr_update_dma launch from the committed PMC passes (profiles/r5_traffic.json, written by
-    scripts/pmc_traffic.py from separate rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from
-    inside this process).  None when the file is missing or was measured on OTHER kernel sources (content hash): a stale number is
-    not reported."""
+def hbm_traffic_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r6_traffic.json, written by scripts/pmc_traffic.py from separate
+    rocprofv3 --pmc runs of this same command; PMC counters cannot be collected from inside this process).  None when the file is missing, has no
+    entry for the kernel, or was measured on OTHER kernel sources (content hash): a stale number is not reported."""
     try:
         j = json.load(open(TRAFFIC_JSON))
         if j.get('sources_sha') != kernel_sources_sha():
             return None
-        return float(j['hbm_bytes_per_launch'])
+        return float(j['kernels'][kernel]['hbm_bytes_per_launch'])
     except Exception:
         return None
 
@@ -561,11 +561,30 @@ def main():
         upd_levels = int((sched['levels'][:, 3] > 0).sum())              # levels with a k_cr_update launch
         phases = max(prof['factor_launches'], 1.0)                       # factorisation phases (one per IPM iteration and chunk)
         nfac = max(prof['problem_factorisations'], 1.0)                  # problem-factorisations: only problems still iterating are factored
-        # dominant kernel: k_cr_update (symmetric updates + fill edges): 4 d^3 per elimination with two neighbours, d^3 for the last pair
-        upd_flops = nfac * (max(p - 2, 0) * 4.0 + (1.0 if p >= 2 else 0.0)) * d3
-        upd_launches = phases * max(upd_levels, 1)
-        upd_ms = prof['update_ms']
-        achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        # the four kernels of the factorisation phase, each against the matrix peak of the arithmetic it runs in; the dominant one (largest share of the timed region)
+        # is the `roofline` of the line.  Algorithmic flops per problem-factorisation (unpadded d): block Cholesky p d^3 / 3; triangular solves d^3 per edge,
+        # 2 (p - 2) + 1 edges; updates 4 d^3 per elimination with two neighbours, d^3 for the last pair -- in float32 for the problem-factorisations of the early
+        # main-phase iterations (TMPC_TUNE_LOWP_SWITCH), in fp64 for the others.
+        nlow = float(prof.get('lowp_factorisations', 0.0))
+        f_upd = (max(p - 2, 0) * 4.0 + (1.0 if p >= 2 else 0.0)) * d3
+        f_trsm = (max(p - 2, 0) * 2.0 + (1.0 if p >= 2 else 0.0)) * d3
+        kern = {
+            "k_cr_trsm_dma": dict(flops=nfac * f_trsm, ms=prof['trsm_ms'], peak=PEAK_F64_MFMA_TFLOPS, dtype="f64",
+                                  what="triangular solves O <- E L^-T of the cyclic-reduction block Cholesky, register-resident right-looking strips on v_mfma_f64_4x4x4_4b"),
+            "k_cr_update_dma": dict(flops=(nfac - nlow) * f_upd, ms=prof['update_ms'], peak=PEAK_F64_MFMA_TFLOPS, dtype="f64",
+                                    what="symmetric updates and fill edges in fp64: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles"),
+            "k_cr_update_dma_f32": dict(flops=nlow * f_upd, ms=prof.get('update_f32_ms', 0.0), peak=PEAK_F32_MFMA_TFLOPS, dtype="f32",
+                                        what="the same updates on float32 copies of the O blocks with float32 accumulation (v_mfma_f32_16x16x4_f32), early main-phase iterations only"),
+            "k_cr_potrf_dma": dict(flops=nfac * p * d3 / 3.0, ms=prof['potrf_ms'], peak=PEAK_F64_MFMA_TFLOPS, dtype="f64",
+                                   what="block Cholesky of the diagonal blocks (latency-bound 64 x 64 tile factorisations between MFMA sweeps)"),
+        }
+        for k_, v_ in kern.items():
+            v_["tflops"] = v_["flops"] / (v_["ms"] * 1e-3) / 1e12 if v_["ms"] > 0 else 0.0
+            v_["frac"] = v_["tflops"] / v_["peak"]
+        dom = max(kern, key=lambda k_: kern[k_]["ms"])
+        dom_launches = phases * max(upd_levels, 1) if dom != "k_cr_potrf_dma" else phases * len(sched['levels'])
+        achieved = kern[dom]["tflops"]
+        upd_ms = prof['update_ms'] + prof.get('update_f32_ms', 0.0)
         phase_tf = nfac * factor_flops_per_problem(p, d) / (prof['factor_ms'] * 1e-3) / 1e12 if prof['factor_ms'] > 0 else 0.0
         line = {
             "metric": "stage-Hessian convexifications/sec at (nx+nu)=32, p=64",
@@ -589,21 +608,29 @@ def main():
                        "status_optimal": ok, "status_total": int(status.size),
                        "kappa_mean": float(kappa.mean()),
                        "parallelism": (f"batch-sharded x{world}, one all-gather of Hc" + (f" [backend {args.backend}" + (", every rank on cuda:0: the code path, not a scaling measurement]" if args.same_device else "]") if (host_coll or args.same_device) else "")) if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                         "traffic": hbm_traffic_per_launch() if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r5_traffic.json)",
-                         "kernel": "k_cr_update_dma (symmetric updates and fill edges of the cyclic-reduction block Cholesky: v_mfma_f64_4x4x4_4b on LDS-DMA fed 64 x 64 tiles)",
-                         "avg_launch_ms": upd_ms / upd_launches, "launches": int(upd_launches),
-                         "algorithmic_flops_per_launch": upd_flops / upd_launches,
-                         "factorisation_phase": {"kernels": "k_cr_potrf_dma + k_cr_trsm_dma + k_cr_update_dma (+ the fused forward sweep of the predictor pass), all levels", "tflops": phase_tf,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": kern[dom]["peak"], "unit": "TFLOP/s",
+                         "frac": achieved / kern[dom]["peak"],
+                         "traffic": hbm_traffic_per_launch(dom) if (nbl == 512 and p == 64 and nx == 24 and mb == 8) else None,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r6_traffic.json)",
+                         "kernel": f"{dom} ({kern[dom]['what']})", "dtype": kern[dom]["dtype"],
+                         "dominant_by": "largest total time among the kernels of the factorisation phase in the timed region (HIP events around every launch)",
+                         "avg_launch_ms": kern[dom]["ms"] / max(dom_launches, 1), "launches": int(dom_launches),
+                         "algorithmic_flops_per_launch": kern[dom]["flops"] / max(dom_launches, 1),
+                         "kernels": {k_: {"ms_per_step": v_["ms"] / max(args.steps, 1), "tflops": v_["tflops"], "peak": v_["peak"], "frac": v_["frac"], "dtype": v_["dtype"]} for k_, v_ in kern.items()},
+                         "single_precision_updates": {"switch_mu_over_kappa": (args.lowp_switch if args.lowp_switch >= 0 else 1e-5), "problem_factorisations": nlow / max(args.steps, 1),
+                                                      "of": nfac / max(args.steps, 1),
+                                                      "note": "TMPC_TUNE_LOWP_SWITCH: Schur-complement updates (and the O-block reads of the substitutions) of the main-phase iterations with mu > switch * kappa "
+                                                              "in float32; Cholesky, triangular solves, every later iteration and the returned point stay fp64 (same iteration counts, Hc within 2e-10 of the "
+                                                              "all-fp64 answer: profiles/r6_fp32_*.txt, tests)"},
+                         "factorisation_phase": {"kernels": "k_cr_potrf_dma + k_cr_trsm_dma + k_cr_update_dma + k_cr_update_dma_f32 (+ the fused forward sweep of the predictor pass), all levels", "tflops": phase_tf,
                                                  "frac": phase_tf / PEAK_F64_MFMA_TFLOPS, "avg_ms": prof['factor_ms'] / phases,
                                                  "problems_per_phase": nfac / phases,
                                                  "potrf_ms": prof['potrf_ms'] / phases, "trsm_ms": prof['trsm_ms'] / phases,
-                                                 "update_ms": upd_ms / phases},
-                         "peak_note": "datasheet FP64 matrix peak at 2.4 GHz.  Under this kernel the chip runs at 2.28 GHz (GRBM_GUI_ACTIVE / wall time) with the matrix pipes busy "
-                                      "72 % of the SIMD cycles and 1.08 MFMA flops executed per algorithmic flop (edge tiles): 0.72 x 2.28 / 2.4 / 1.08 = 0.63 "
-                                      "(profiles/r5_final_pmc.txt).  The kernel is MFMA-idle 28 % of the time -- it is not power-capped"},
+                                                 "update_ms": upd_ms / phases, "update_f64_ms": prof['update_ms'] / phases, "update_f32_ms": prof.get('update_f32_ms', 0.0) / phases,
+                                                 "note": "tflops / frac: algorithmic flops of the whole phase against the FP64 matrix peak (part of them run in float32: a mixed-precision phase has no single roof)"},
+                         "peak_note": "datasheet matrix peaks at 2.4 GHz (FP64 78.6, FP32 157.3 TFLOP/s).  Under the fp64 kernels the chip runs at 2.28 GHz (GRBM_GUI_ACTIVE / wall time) with the "
+                                      "matrix pipes busy 60 % (k_cr_trsm_dma) / 72 % (k_cr_update_dma) of the SIMD cycles (profiles/r5_final_pmc.txt, r6_final_pmc.txt): they are MFMA-idle a third "
+                                      "of the time, not power-capped"},
             "phase_ms": {k: prof[k] for k in ('pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'total_ms')},
         }
         line.update(extra_rates)

@@ -536,7 +536,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
   // nlowp: how many of the `count` problems run their Schur-complement updates in single precision (exact: k_ctrl_d / k_init_prob counted them)
   const CrDev cd = cr_dev(sc, d_sched, alist);
   int ke = 0;
-  // profile mode: an event before and after every launch; pair i belongs to class i % 3 (potrf, trsm, update)
+  // profile mode: an event before and after every launch; pair i belongs to class i % 4 (potrf, trsm, update in fp64, update in float32)
   auto mark = [&](int cls) {
 #ifdef TMPC_CYCLE_PROF
     { static int cls_ids[4] = {0, 1, 2, 3}; hipMemcpyToSymbolAsync(HIP_SYMBOL(tmpc::g_prof_cls), &cls_ids[cls + 1], sizeof(int), 0, hipMemcpyHostToDevice, st); }
@@ -570,7 +570,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     mark(0);
     // fused forward substitution of pass 1 (see k_cr_update_dma): z_i <- L_i^-1 z_i for this level's nodes as soon as L_i exists
     if (fuse_fwd1) hipLaunchKernelGGL(k_cr_fwd_diag, dim3(cr_grid((long)count * lv.nelim)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.eoff, lv.nelim, count, 1);
-    if (lv.nupd == 0) { mark(1); mark(1); mark(2); mark(2); continue; }                  // last node: nothing left to update
+    if (lv.nupd == 0) { mark(1); mark(1); mark(2); mark(2); mark(3); mark(3); continue; }                  // last node: nothing left to update
     const long work64 = (long)count * lv.nelim * 2 * nt64;                 // 64-row strips of this level
     const int rs = rs_opt > 0 ? rs_opt : (work64 >= 16384 ? 128 : 64);
     const int mt = mt_opt > 0 ? mt_opt : 64;      // one 64 x 64 tile per workgroup: ~64 consecutive items per XCD span the tiles of 1-2 nodes, whose O blocks fit that L2
@@ -591,12 +591,13 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
       const long it_dma = (long)count * ((long)lv.nupd * (nm64 * (nm64 + 1) / 2) + (long)lv.nelim * nm64 * nm64);
       if (nlowp < count)           // (each kernel leaves the other's problems alone)
         hipLaunchKernelGGL(k_cr_update_dma, dim3(cr_grid(it_dma)), dim3(256), (size_t)dma_lds_doubles<UPD_DMA_DEPTH>() * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, fuse_fwd1);
+      mark(2); mark(3);
       if (nlowp > 0)               // no right-hand-side mini slabs in the float32 tile: 32 KB of LDS, five workgroups per CU
         hipLaunchKernelGGL(k_cr_update_dma_f32, dim3(cr_grid(it_dma)), dim3(256), (size_t)UPD_DMA_DEPTH * DMA_SLAB * sizeof(double), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count);
+      mark(3);
     }
-    else if (mf) hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
-    else hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt);
-    mark(2);
+    else if (mf) { hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt); mark(2); mark(3); mark(3); }
+    else { hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt); mark(2); mark(3); mark(3); }
     // problems whose update tiles ran in single precision carried no right-hand sides: their z_s -= O_s z_i of the fused forward sweep, in fp64 from the fp64 O blocks
     if (fuse_fwd1 && nlowp > 0 && mf && use_dma && lv.nupd)
       hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.uoff, lv.nupd, count, 1, 1);
@@ -923,7 +924,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       for (int i = 0; i < 5; ++i) { HIPCHK(hipEventElapsedTime(&ms, ln->ev[i], ln->ev[i + 1])); ln->prof[i] += ms; }
       if (nfac_done > 0) ln->prof[5] += 1.0;
       ln->prof[8] += (double)nfac_done;
-      for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, ln->kev[i], ln->kev[i + 1])); ln->prof[9 + (i / 2) % 3] += ms; }
+      for (int i = 0; i + 1 < nkev; i += 2) { HIPCHK(hipEventElapsedTime(&ms, ln->kev[i], ln->kev[i + 1])); const int c_ = (nkev > 2) ? (i / 2) % 4 : 0; ln->prof[c_ < 3 ? 9 + c_ : 14] += ms; }
     }
     ++it;
   }
