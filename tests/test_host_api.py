@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_query_and_unsupported_dims():
     from tunempc_amd._lib import load_library
     lib = load_library()
-    # c4: 64 stages of d=300 (dp=304): D,O,F alone are 3*64*304^2*8 B = 142 MB per problem
+    # c4: 64 stages of d=300 (dp=304): D,O,F alone are 3*64*304^2*8 B = 142 MB per problem, the float32 copies of the O / fill blocks (round 6) 2*64*304*320*4 B = 50 MB
     per = lib.tmpc_workspace_bytes(1, 64, 24, 8)
-    assert 142e6 < per < 200e6
+    assert 192e6 < per < 240e6
     assert lib.tmpc_workspace_bytes(2, 64, 24, 8) > 1.9 * per
     assert lib.tmpc_workspace_bytes(1, 64, 30, 8) > lib.tmpc_workspace_bytes(1, 64, 24, 8)      # n = 38: the generic per-stage kernels (round 4; rounds 1-3: unsupported)
     assert lib.tmpc_workspace_bytes(1, 4, 40, 30) > 0       # n = 70: the plain model runs up to n = 96 since round 5 ...
