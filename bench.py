@@ -166,8 +166,13 @@ def small_configs(HipConvexifier, synthetic):
         cpu_ipm = None
     hw = host_cpu_info()
     cores = max(1, min(hw["effective_cores"], 64))
+    # (round 6: the reference's steady-state examples, p = 1 -- examples/convex_lqr.py:40-46 nx = 3, m = 1; examples/cstr/main.py nx = 4, m = 2;
+    # examples/evaporation_process/main.py:110-111 nx = 2, m = 2 -- as synthetic problems of their shapes, batch 1)
     for key, (seed, nb, p, nx, mb) in {"configs[1] unicycle-shaped p=30 n=5 batch=1": (200000, 1, 30, 4, 1),
-                                        "configs[2] evaporation-shaped p=50 n=4 batch=256": (200100, 256, 50, 2, 2)}.items():
+                                        "configs[2] evaporation-shaped p=50 n=4 batch=256": (200100, 256, 50, 2, 2),
+                                        "LQR-shaped p=1 n=4 batch=1": (200200, 1, 1, 3, 1),
+                                        "CSTR-shaped p=1 n=6 batch=1": (200300, 1, 1, 4, 2),
+                                        "evaporation-shaped p=1 n=4 batch=1": (200400, 1, 1, 2, 2)}.items():
         A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
         h = HipConvexifier(p, nx, mb, chunk=nb)
         h.convexify_batch(A, B, H)

@@ -339,7 +339,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
 
     # check if hessian is already convex (convexifier.py:82-85: before anything is constructed or logged about the SDP):
     # batched eigenvalue scan on the device
-    h = _handle(period, nx, nu, 0 if Gs is None else Gs.shape[1], nc if nc <= NC_MAX else 0, 1)
+    h = _handle(period, nx, nu, 0 if Gs is None else Gs.shape[1], nc if (nc <= NC_MAX and nx + nu <= N_ROWS_MAX) else 0, 1)
     if h.eig_scan(Hs[None])[0, :, 0].min() > 0:
         Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')
         return np.zeros((nx + nu, nx + nu)), np.zeros((nx, nx)), np.zeros((nu, nu)), np.zeros((nx, nu))
@@ -349,7 +349,7 @@ def convexify(A, B, Q, R, N, G=None, C=None, opts={'rho': 1e-3, 'solver': 'hip',
     Logger.logger.info(50 * '*')
     Logger.logger.info('Step 1: (η_F = 0), (η_T = 0)')
     Logger.logger.info('solving SDP...')
-    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None], nc_hint=nc if nc <= NC_MAX else 0, tight=(opts or {}).get('tight'))
+    res = convexify_batch(As[None], Bs[None], Hs[None], G=None if Gs is None else Gs[None], nc_hint=nc if (nc <= NC_MAX and nx + nu <= N_ROWS_MAX) else 0, tight=(opts or {}).get('tight'))      # (no room for C rows beyond n = 64: Step 1 then runs on the plain handle and may well succeed -- ADVICE r5)
 
     if res['info'][0, 13] != 0.0:      # (the library's own pre-check; same answer as the scan above)
         Logger.logger.info('Provided hessian(s) are already positive definite. No convexification needed!')

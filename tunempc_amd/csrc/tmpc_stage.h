@@ -179,9 +179,11 @@ __device__ __forceinline__ double lane_min_eig8(const double* __restrict__ Wg, i
 #undef TMPC_A8
   if (n == 1) return dd[0];
   double scale = 0.0;
+  bool bad = false;                                          // fmax / fmin drop NaN operands: test for it explicitly, so that a NaN step-length matrix is handed on
 #pragma unroll
-  for (int i = 0; i < 8; ++i) if (i < n) scale = fmax(scale, fmax(fabs(dd[i]), (i + 1 < n) ? fabs(ee[i]) : 0.0));
-  if (!(scale > 0.0) || !(scale < 1e300)) return (scale == 0.0) ? 0.0 : scale;       // zero matrix; NaN / Inf is handed on (the control body treats a non-finite step as a breakdown)
+  for (int i = 0; i < 8; ++i) if (i < n) { bad |= !(dd[i] == dd[i]) || ((i + 1 < n) && !(ee[i] == ee[i])); scale = fmax(scale, fmax(fabs(dd[i]), (i + 1 < n) ? fabs(ee[i]) : 0.0)); }
+  if (bad) return __builtin_nan("");                         // (the control body treats a non-finite step as a breakdown)
+  if (!(scale > 0.0) || !(scale < 1e300)) return (scale == 0.0) ? 0.0 : scale;       // zero matrix; Inf is handed on
   const double rs = 1.0 / scale;
   double e2[8];
   double lo = 1e300;

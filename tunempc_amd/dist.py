@@ -87,17 +87,29 @@ def convexify_batch_sharded(A, B, H, solve_fn, group=None, keys=('Hc', 'kappa', 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nb = A.shape[0]
     if cost is not None:
-        cost = np.asarray(cost.detach().cpu() if hasattr(cost, 'detach') else cost, dtype=np.float64).reshape(-1)
-        if cost.shape != (nb,):
-            raise ValueError('cost must hold one entry per problem: expected shape ({},), got {}'.format(nb, cost.shape))
-        if not np.isfinite(cost).all():
-            raise ValueError('cost must be finite (a NaN would make the split differ between ranks)')
-        # one assignment for everybody: rank 0's permutation, broadcast as int64 (nb * 8 bytes)
-        parts = balanced_assignment(cost, world)
-        flat = torch.as_tensor(np.concatenate(parts), dtype=torch.int64, device=A.device)
+        # one assignment for everybody: rank 0 validates ITS cost and computes the permutation; an ok-flag travels with it (nb + 1 int64), so a bad proxy raises
+        # on every rank together instead of leaving the others in the collective.  Only rank 0's cost is ever used: the other ranks neither check
+        # theirs nor run the O(nb) deal.
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        msg = torch.zeros(nb + 1, dtype=torch.int64, device=A.device)
+        err = None
+        if rank == 0:
+            c0 = np.asarray(cost.detach().cpu() if hasattr(cost, 'detach') else cost, dtype=np.float64).reshape(-1)
+            if c0.shape != (nb,):
+                err = 'cost must hold one entry per problem: expected shape ({},), got {}'.format(nb, c0.shape)
+            elif not np.isfinite(c0).all():
+                err = 'cost must be finite (a NaN would make the split meaningless)'
+            else:
+                msg[0] = 1
+                msg[1:] = torch.as_tensor(np.concatenate(balanced_assignment(c0, world)), dtype=torch.int64)
         if world > 1:
-            dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        sizes = [len(q) for q in parts]                     # (nb // world or + 1 per rank, in rank order: the same on every rank whatever the cost)
+            dist.broadcast(msg, src=src, group=group)
+        if int(msg[0].item()) != 1:
+            raise ValueError(err or "rank 0's cost proxy was rejected (wrong shape or not finite): no rank solved anything")
+        flat = msg[1:]
+        # snake dealing gives every rank nb // world problems and the first (even last round) or last (odd) nb % world ranks one more: known without the cost
+        base, rem = divmod(nb, world)
+        sizes = [base + (1 if ((r < rem) if base % 2 == 0 else (r >= world - rem)) else 0) for r in range(world)]
         offs = np.concatenate([[0], np.cumsum(sizes)])
         idx = [flat[offs[r]:offs[r + 1]] for r in range(world)]
         seen = torch.zeros(nb, dtype=torch.int32, device=A.device)
