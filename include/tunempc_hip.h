@@ -118,7 +118,8 @@ int tmpc_set_options(tmpc_handle* h, double tol, double center_tol, int max_iter
  *   TMPC_TUNE_LOWP_SWITCH  value >= 0 (default TMPC_LOWP_SWITCH_DEFAULT): in the main-phase iterations of a problem with mu > value * max(1, kappa) the Schur-complement updates of
  *                          the block factorisation (k_cr_update_dma, a third of a solve) run on float32 copies of their operands with float32 accumulation (fp32 MFMA:
  *                          twice the fp64 matrix rate); Cholesky, triangular solves, substitutions and every later iteration stay fp64.  Same iteration counts, the
- *                          converged point moves by 1e-11 ... 2e-10 (profiles/r6_fp32_*.txt).  Plain model, Schur blocks of 32 ... 320.  0: never (rounds 1-5)
+ *                          converged point moves by 1e-11 ... 2e-10 (profiles/r6_fp32_*.txt).  Steps 1 and 2 (not Step 3), stage blocks up to 32 x 32, Schur blocks of 80 ... 320; a pivot that freezes under
+ *                          them repeats the iteration in fp64 and turns them off for that problem.  0: never (rounds 1-5, bit for bit)
  *   TMPC_TUNE_PERSISTENT   plain-model problems with single-tile Schur blocks and n = nx + mb <= 8 (the reference's own examples) can run their whole
  *                          interior-point loop as ONE launch, one workgroup per problem (tmpc_persist.h).  1 (default): where that is faster -- period
  *                          p <= 8, or at least 96 problems of the call on the chip at once; 0: never (the launch sequence); 2: whenever the shape allows it

@@ -113,6 +113,7 @@ struct Lane {
   double prof[16];               // see tmpc_get_profile
   std::vector<hipEvent_t> kev;   // profile mode: event pairs around the launches of one factorisation (class = index % 3)
   int last_nb;                   // problems this lane solved in the last wave (trace / multiplier read-back)
+  int o32_dp;                    // block width of the last call that wrote float32 O copies (0: none yet, the array is all zero): a call with another width finds stale data where its zero padding should be
   std::unordered_map<std::string, hipGraphExec_t>* graphs;   // launch-bound shapes: one IPM iteration as a captured graph, keyed by every launch argument (run_chunk)
   char err[512];                 // error text of the lane's worker thread
 };
@@ -198,8 +199,8 @@ static size_t carve(WS& w, const Dims& dm, char* base, Lane* h) {
   w.KF = c.take<double>(BP * 12 * nxx); w.adjV = c.take<double>(BP * NADJ * nxx); w.adjE = c.take<double>(BP * NADJ * nxx);
   w.part = c.take<double>(BP * NPART); w.prob = c.take<double>((size_t)dm.B * PS); w.iprob = c.take<int>((size_t)dm.B * IS);
   w.D = c.take<double>(BP * bs); w.O = c.take<double>(BP * bs); w.F = c.take<double>(BP * bs);
-  // float32 copies of the O factors for the single-precision updates of the early iterations (Opts::lowp_switch): plain model on the tuned path, blocks the LDS-DMA kernels take
-  w.O32 = (dm.nr == 0 && dm.nT == 0 && dm.n <= NMAX && dm.dp > 64 && dm.nt <= TRR_NT) ? c.take<float>(2 * BP * (size_t)dm.dp * ((dm.dp + 31) & ~31)) : nullptr;
+  // float32 copies of the O factors for the single-precision updates of the early iterations (Opts::lowp_switch): Steps 1 / 2 on the tuned path (not Step 3), blocks the LDS-DMA kernels take
+  w.O32 = (dm.nT == 0 && dm.n <= NMAX && dm.dp > 64 && dm.nt <= TRR_NT) ? c.take<float>(2 * BP * (size_t)dm.dp * ((dm.dp + 31) & ~31)) : nullptr;
   w.Linv = c.take<double>(BP * dm.nt * TB * TB); w.Ddiag = c.take<double>(BP * dm.dp);
   w.W3 = c.take<double>(BP * dm.dp * 3); w.U = c.take<double>(BP * dm.dp * 2); w.TU = c.take<double>(BP * dm.dp * 2);
   w.Z = c.take<double>(BP * dm.dp);
@@ -720,8 +721,14 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
   o.tight = 0; o.tight_tol = 0.0;
   // (chord steps also with stage-local multipliers since round 3: their rows are part of the frozen blocks like everything else)
   o.fast_exit = (h->flags & TMPC_FLAG_FAST_EXIT) ? 1 : 0;
-  if ((h->flags & (TMPC_FLAG_NO_MFMA | TMPC_DEBUG_FLAG_NO_DMA)) || !w.O32) o.lowp_switch = 0.0;
-  if (o.lowp_switch > 0.0) dm.flags |= DF_LOWP;
+  if ((h->flags & (TMPC_FLAG_NO_MFMA | TMPC_DEBUG_FLAG_NO_DMA)) || !w.O32 || t3 || dm.dp <= 64 || dm.nt > TRR_NT) o.lowp_switch = 0.0;
+  if (o.lowp_switch > 0.0) {
+    dm.flags |= DF_LOWP;
+    // the float32 copies are laid out by this call's block width; where the last call used another one (a handle with room for rows serving the plain model, or
+    // the other way round) its data sit where the zero padding of this call's rows must be
+    if (ln->o32_dp != 0 && ln->o32_dp != dm.dp) HIPCHK(hipMemsetAsync(w.O32, 0, 2 * (size_t)h->dm.B * h->dm.p * h->dm.dp * ((h->dm.dp + 31) & ~31) * sizeof(float), st));
+    ln->o32_dp = dm.dp;
+  }
   WS wf = w; wf.alist = flist;            // view over the problems that get a new factorisation this iteration
   const int BPall = nb * dm.p;
   const bool prof = (h->flags & TMPC_FLAG_PROFILE) != 0;
@@ -1132,7 +1139,7 @@ static int create_handle(tmpc_handle** out, int chunk, int p, int nx, int mb, in
   }
   int rc = cr_upload(h->sched, &h->d_sched);
   bool ok = (rc == TMPC_OK) && hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
-  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.big_scr = nullptr; ln.graphs = nullptr; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
+  for (int l = 0; l < MAXL; ++l) { Lane& ln = h->lane[l]; ln.big_scr = nullptr; ln.o32_dp = 0; ln.graphs = nullptr; ln.st = nullptr; for (int i = 0; i < 8; ++i) ln.ev[i] = nullptr; memset(ln.prof, 0, sizeof(ln.prof)); ln.last_nb = 0; ln.err[0] = 0; }
   for (int l = 0; l < nl && ok; ++l) {
     Lane& ln = h->lane[l];
     carve(ln.ws, h->dm, (char*)h->slab + (size_t)l * lane_bytes, &ln);
