@@ -399,7 +399,8 @@ struct DdSys {
     Dh.assign(n, 0.0); Dl.assign(n, 0.0); Ch.assign(n, 0.0); Cl.assign(n, 0.0);
   }
   // M[(ab)][(cd)] += sg * T(L, R)[(ab),(cd)]   (Problem::add_T in dd; L, R nx x nx dd, row-major block M)
-  static void add_T(double* Mh, double* Ml, const ddk::mat& L, const ddk::mat& R, double sg, int nx, int d, const std::vector<int>& ia, const std::vector<int>& ib) {
+  static void add_T(double* Mh, double* Ml, const ddk::mat& L, const ddk::mat& R, double sg, int nx, int d, const std::vector<int>& ia, const std::vector<int>& ib, int ld = 0) {
+    if (ld == 0) ld = d;      // (row stride of the block: d, or d + stage-local variables for the models with rows)
     using namespace ddk;
     for (int r = 0; r < d; ++r) {
       const int a = ia[r], b = ib[r];
@@ -409,8 +410,8 @@ struct DdSys {
         const double wgt = sg * wr * ((cc == e) ? 0.5 : 1.0);
         dd t = add(add(mul(L[a * nx + cc], R[b * nx + e]), mul(L[a * nx + e], R[b * nx + cc])), add(mul(L[b * nx + cc], R[a * nx + e]), mul(L[b * nx + e], R[a * nx + cc])));
         t = muld(t, wgt);                                                          // (a power of two: exact)
-        const dd v = add(dd{Mh[(size_t)r * d + c], Ml[(size_t)r * d + c]}, t);
-        Mh[(size_t)r * d + c] = v.h; Ml[(size_t)r * d + c] = v.l;
+        const dd v = add(dd{Mh[(size_t)r * ld + c], Ml[(size_t)r * ld + c]}, t);
+        Mh[(size_t)r * ld + c] = v.h; Ml[(size_t)r * ld + c] = v.l;
       }
     }
   }
@@ -499,9 +500,9 @@ struct DdSys {
 static void assemble_dd(DdSys& sys, const Problem& pr, const std::vector<ddk::mat>& X1, const std::vector<ddk::mat>& Z1, const std::vector<ddk::mat>& X2,
                         const std::vector<ddk::mat>& Z2) {
   using namespace ddk;
-  const int p = pr.p, nx = pr.nx, n = pr.n, d = pr.d;
-  sys.init(p, d, sys.par);
-  const size_t bs = (size_t)d * d;
+  const int p = pr.p, nx = pr.nx, n = pr.n, d = pr.d, db = pr.db;      // db >= d: the P part sits in the leading d x d corner of every block
+  sys.init(p, db, sys.par);
+  const size_t bs = (size_t)db * db;
 #pragma omp parallel for schedule(dynamic, 1) if (sys.par)
   for (int k = 0; k < p; ++k) {
     mat Vd((size_t)nx * n), Fx, Fs, Xe((size_t)nx * nx), Ze((size_t)nx * nx), Xr((size_t)nx * n), Zr((size_t)nx * n);
@@ -511,8 +512,8 @@ static void assemble_dd(DdSys& sys, const Problem& pr, const std::vector<ddk::ma
       for (int a = 0; a < nx; ++a) for (int c = 0; c < n; ++c) { Xr[(size_t)a * n + c] = X[(size_t)a * n + c]; Zr[(size_t)a * n + c] = Z[(size_t)a * n + c]; }
       mm(Fx, Xr, Vd, nx, n, nx, true); mm(Fs, Zr, Vd, nx, n, nx, true);
       for (int a = 0; a < nx; ++a) for (int c = 0; c < nx; ++c) { Xe[a * nx + c] = X[(size_t)a * n + c]; Ze[a * nx + c] = Z[(size_t)a * n + c]; }
-      DdSys::add_T(&sys.Dh[k * bs], &sys.Dl[k * bs], Xe, Ze, 1.0, nx, d, pr.ia, pr.ib);
-      DdSys::add_T(&sys.Ch[k * bs], &sys.Cl[k * bs], Fx, Fs, -1.0, nx, d, pr.ia, pr.ib);
+      DdSys::add_T(&sys.Dh[k * bs], &sys.Dl[k * bs], Xe, Ze, 1.0, nx, d, pr.ia, pr.ib, db);
+      DdSys::add_T(&sys.Ch[k * bs], &sys.Cl[k * bs], Fx, Fs, -1.0, nx, d, pr.ia, pr.ib, db);
     }
   }
   // second sweep for the V-side terms (a different block than the loop index: no races)
@@ -525,7 +526,7 @@ static void assemble_dd(DdSys& sys, const Problem& pr, const std::vector<ddk::ma
       const mat& X = r ? X2[k] : X1[k]; const mat& Z = r ? Z2[k] : Z1[k];
       mm(t, Vd, X, nx, n, n, false); mm(Kx, t, Vd, nx, n, nx, true);
       mm(t, Vd, Z, nx, n, n, false); mm(Ks, t, Vd, nx, n, nx, true);
-      DdSys::add_T(&sys.Oh[k * bs], &sys.Ol[k * bs], Kx, Ks, 1.0, nx, d, pr.ia, pr.ib);
+      DdSys::add_T(&sys.Oh[k * bs], &sys.Ol[k * bs], Kx, Ks, 1.0, nx, d, pr.ia, pr.ib, db);
     }
   }
   for (int k = 0; k < p; ++k) {

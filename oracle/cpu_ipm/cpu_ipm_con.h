@@ -115,8 +115,35 @@ static bool spd_inv(const Small& sm, vec& out, const vec& S, vec& L, vec& Li) { 
   return true;
 }
 
+
+// ---------------------------------------------------------------- tight mode with rows (round 6): the stage-local rows of the augmented blocks in double-double
+// As the HIP library (tmpc_dd.h: k_dd_aug_fill): the rows of a multiplier are double-double FUNCTIONS of the same (X_r, Z_r = S_r^-1) the P part of the blocks is
+// made of -- w = X g, u = Z g, V w, V u, the Gram products -- so the augmented block is, to double-double accuracy, the Gram matrix it is in exact arithmetic and its
+// pivots stay positive where a pivot of an active multiplier is what is left of ~1/mu after ~1/mu has been taken off.  (The numpy oracle carries these variables as
+// dense border columns, forms its Schur complement in fp64 and solves it by LU: nothing there needs a positive pivot.)
+static inline ddk::dd dd_dot(const std::vector<ddk::dd>& a, const double* b, int n) { ddk::dd s{0.0, 0.0}; for (int i = 0; i < n; ++i) s = ddk::add(s, ddk::muld(a[i], b[i])); return s; }
+// closed-form inverse of the arrow matrix [[t, u'], [u, t I]] in dd, gamma = t^2 - |u|^2 (cancels to ~ mu t on an active norm); false outside the cone
+static bool arrow_inv_dd(ddk::mat& Si, double t, const std::vector<ddk::dd>& u, int m) {
+  using namespace ddk;
+  const int m1 = m + 1;
+  if (!(t > 0.0)) return false;
+  dd gam = tp(t, t);
+  for (int i = 0; i < m; ++i) gam = sub(gam, mul(u[i], u[i]));
+  if (!(gam.h > 0.0)) return false;
+  Si.assign((size_t)m1 * m1, dd{0.0, 0.0});
+  const dd td = from(t);
+  Si[0] = div(td, gam);
+  for (int i = 0; i < m; ++i) { const dd v = neg(div(u[i], gam)); Si[i + 1] = v; Si[(size_t)(i + 1) * m1] = v; }
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) {
+    dd v = div(mul(u[i], u[j]), gam);
+    if (i == j) v = add(v, from(1.0));
+    Si[(size_t)(i + 1) * m1 + j + 1] = div(v, td);
+  }
+  return true;
+}
+
 Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B, const double* Hin, const ConIn& ci, double tol, int max_iter, int center_iter,
-                         double center_tol, double* Hc_out, ConOut& co) {
+                         double center_tol, double* Hc_out, ConOut& co, bool tight = false, bool par = false) {
   const int n = nx + mb, nn = n * n, d = nx * (nx + 1) / 2, nxx = nx * nx;
   Small sm(n);
   Result res; res.kappa = 0; res.alpha = 1; res.status = 0; res.iters = 0; res.early = 0;
@@ -258,6 +285,95 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
       if (i < nJ) { const double* g = gg(k, i); for (int e = 0; e < nn; ++e) Mk[e] += c * g[e]; }
       else { const int q = i - nJ; Mk[ta[q] * n + tb[q]] += c; if (ta[q] != tb[q]) Mk[tb[q] * n + ta[q]] += c; }
     }
+  };
+  // ---- tight mode (convexify_oracle.sdp_step1(tight=True) with rows; Steps 1 / 2): block linear algebra in double-double below DD_SWITCH, dd dual-Newton polish
+  bool dd_on = false, polish = false; int ndd = 0;
+  DdSys dsys; dsys.par = par;
+  std::vector<ddk::mat> qX1, qZ1, qX2, qZ2;
+  auto to_dd = [&](std::vector<ddk::mat>& out, const vec& src) { out.resize(p); for (int k = 0; k < p; ++k) { out[k].resize(nn); for (int e = 0; e < nn; ++e) out[k][e] = ddk::from(src[(size_t)k * nn + e]); } };
+  // the rows of the stage-local variables in the augmented dd blocks (after assemble_dd filled the P part): Xa / Za, Xb / Zb the dd matrices (X_r, S_r^-1) of the two
+  // LMI blocks per stage, aX / aSi those of the arrow blocks (per arrow), zphi [p][ng] = z / phi (loop) or mu / phi^2 (polish)
+  auto fill_locals_dd = [&](const std::vector<ddk::mat>& Xa, const std::vector<ddk::mat>& Za, const std::vector<ddk::mat>& Xb, const std::vector<ddk::mat>& Zb,
+                            const std::vector<ddk::mat>& aX, const std::vector<ddk::mat>& aSi, const std::vector<ddk::dd>& zphi) {
+    using namespace ddk;
+    const size_t bsd = (size_t)db * db;
+    auto accD = [&](int blk, int r, int c, dd v) { const size_t e = blk * bsd + (size_t)r * db + c; const dd t = add(dd{dsys.Dh[e], dsys.Dl[e]}, v); dsys.Dh[e] = t.h; dsys.Dl[e] = t.l; };
+    auto setD = [&](int blk, int r, int c, dd v) { const size_t e = blk * bsd + (size_t)r * db + c; dsys.Dh[e] = v.h; dsys.Dl[e] = v.l; };
+    auto accC = [&](int blk, int r, int c, dd v) { const size_t e = blk * bsd + (size_t)r * db + c; const dd t = add(dd{dsys.Ch[e], dsys.Cl[e]}, v); dsys.Ch[e] = t.h; dsys.Cl[e] = t.l; };
+    std::vector<std::vector<dd>> wv((size_t)ng * 4, std::vector<dd>(n)), vw((size_t)ng * 4, std::vector<dd>(nx));      // per row: X_a g, Z_a g, X_b g, Z_b g and their images under V
+    std::vector<dd> Bl((size_t)ng * ng);
+    for (int k = 0; k < p; ++k) {
+      const int kn = (k + 1) % p; const double* v = pr.Vk(k);
+      for (int i = 0; i < nz; ++i) setD(kn, d + i, d + i, from(1.0));                       // padding rows / unused arrow slots
+      for (int i = 0; i < nJ; ++i) {
+        if (!mask[(size_t)k * ng + i]) continue;
+        const double* g = ci.J + ((size_t)k * nJin + i) * n;
+        const mat* Ms[4] = {&Xa[k], &Za[k], &Xb[k], &Zb[k]};
+        for (int r = 0; r < 4; ++r) {
+          for (int a = 0; a < n; ++a) { dd sacc{0.0, 0.0}; for (int q = 0; q < n; ++q) sacc = add(sacc, muld((*Ms[r])[(size_t)a * n + q], g[q])); wv[(size_t)i * 4 + r][a] = sacc; }
+          for (int a = 0; a < nx; ++a) { dd sacc{0.0, 0.0}; for (int q = 0; q < n; ++q) sacc = add(sacc, muld(wv[(size_t)i * 4 + r][q], v[a * n + q])); vw[(size_t)i * 4 + r][a] = sacc; }
+        }
+        const int col = d + i;
+        for (int e = 0; e < d; ++e) {
+          const int a = pr.ia[e], c = pr.ib[e];
+          dd cV{0.0, 0.0}, cE{0.0, 0.0};
+          for (int r = 0; r < 4; r += 2) {
+            const std::vector<dd>& Vw = vw[(size_t)i * 4 + r]; const std::vector<dd>& Vu = vw[(size_t)i * 4 + r + 1];
+            const std::vector<dd>& w_ = wv[(size_t)i * 4 + r]; const std::vector<dd>& u_ = wv[(size_t)i * 4 + r + 1];
+            if (a == c) { cV = add(cV, mul(Vw[a], Vu[a])); cE = add(cE, mul(w_[a], u_[a])); }
+            else { cV = add(cV, add(mul(Vw[a], Vu[c]), mul(Vu[a], Vw[c]))); cE = add(cE, add(mul(w_[a], u_[c]), mul(u_[a], w_[c]))); }
+          }
+          accD(kn, e, col, cV); accD(kn, col, e, cV);
+          accC(k, e, col, neg(cE));                                                          // C_k = T[block k, block k+1]: rows of block k
+        }
+      }
+      // T_loc,loc: <g_a g_a', Phi(g_b g_b')> = sum_r (g_a' X_r g_b)(g_a' Z_r g_b), symmetrised, + z / phi on the diagonal
+      for (int a = 0; a < nJ; ++a) for (int b = 0; b < nJ; ++b) {
+        dd val{0.0, 0.0};
+        if (mask[(size_t)k * ng + a] && mask[(size_t)k * ng + b]) {
+          const double* ga = ci.J + ((size_t)k * nJin + a) * n;
+          for (int r = 0; r < 4; r += 2) val = add(val, mul(dd_dot(wv[(size_t)b * 4 + r], ga, n), dd_dot(wv[(size_t)b * 4 + r + 1], ga, n)));
+        }
+        Bl[(size_t)a * ng + b] = val;
+      }
+      for (int a = 0; a < nJ; ++a) for (int b = 0; b < nJ; ++b) {
+        if (!(mask[(size_t)k * ng + a] && mask[(size_t)k * ng + b])) continue;
+        dd val = muld(add(Bl[(size_t)a * ng + b], Bl[(size_t)b * ng + a]), 0.5);
+        if (a == b) val = add(val, zphi[(size_t)k * ng + a]);
+        setD(kn, d + a, d + b, val);
+      }
+    }
+    for (size_t e_ = 0; e_ < arrows.size(); ++e_) {
+      const Arrow& a = arrows[e_];
+      const int kn = (a.k + 1) % p, te = d + ng + a.slot, m1 = a.m + 1;
+      const mat& X = aX[e_]; const mat& Si = aSi[e_];
+      mat T; mm(T, X, Si, m1, m1, m1, false);
+      auto Pe = [&](int i, int j) { return muld(add(T[(size_t)i * m1 + j], T[(size_t)j * m1 + i]), 0.5); };
+      dd trP{0.0, 0.0}; for (int i = 0; i < m1; ++i) trP = add(trP, T[(size_t)i * m1 + i]);
+      setD(kn, te, te, trP);
+      for (int q = 0; q < a.m; ++q) {
+        const double wq = wr * cw[a.idx[q]];
+        const dd v = muld(Pe(0, q + 1), 2.0 * wq);
+        setD(kn, d + a.idx[q], te, v); setD(kn, te, d + a.idx[q], v);
+        for (int r = 0; r < a.m; ++r) {
+          // Fq[0][r+1] of sym(X Eq Si), Eq = wq (e_0 e_{q+1}' + e_{q+1} e_0')
+          dd f = add(add(mul(X[0], Si[(size_t)(q + 1) * m1 + r + 1]), mul(X[q + 1], Si[r + 1])), add(mul(X[(size_t)(r + 1) * m1], Si[(size_t)(q + 1) * m1]), mul(X[(size_t)(r + 1) * m1 + q + 1], Si[0])));
+          f = muld(f, 0.5 * wq * 2.0 * wr * cw[a.idx[r]]);
+          accD(kn, d + a.idx[r], d + a.idx[q], f);
+        }
+      }
+    }
+  };
+  // arrow matrices (dd) of the current (t, phi): the slack S^-1 in closed form, and X as given (fp64 iterate) or mu S^-1
+  auto arrow_mats = [&](const vec& phi_, const std::vector<double>& tt_, std::vector<ddk::mat>& aSi) -> bool {
+    aSi.resize(arrows.size());
+    for (size_t e_ = 0; e_ < arrows.size(); ++e_) {
+      const Arrow& a = arrows[e_];
+      std::vector<ddk::dd> u(a.m);
+      for (int i = 0; i < a.m; ++i) u[i] = ddk::tp(wr * cw[a.idx[i]], phi_[(size_t)a.k * ng + a.idx[i]]);
+      if (!arrow_inv_dd(aSi[e_], tt_[e_], u, a.m)) return false;
+    }
+    return true;
   };
   double dtau = 0, dalpha = 0, ds0 = 0, dx0 = 0;
   for (it = 0; it < max_iter + center_iter * (MUT_BACKOFF_MAX + 1) + 1; ++it) {
@@ -421,11 +537,30 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
       }
     }
     if (!ok) { ipm = ST_DIV; break; }
-    if (!pr.factor()) { ipm = ST_INACC; break; }
+    if (tight && !dd_on && mu <= DD_SWITCH * std::max(1.0, fabs(tau))) dd_on = true;
+    if (!dd_on) {
+      if (!pr.factor()) { ipm = ST_INACC; break; }
+      if (tight && pr.shift > 0.0) dd_on = true;
+    }
+    if (dd_on) {
+      ++ndd;
+      to_dd(qX1, X1); to_dd(qZ1, S1i); to_dd(qX2, X2); to_dd(qZ2, S2i);
+      assemble_dd(dsys, pr, qX1, qZ1, qX2, qZ2);
+      std::vector<ddk::mat> aXd(arrows.size()), aSid;
+      std::vector<double> tts(arrows.size());
+      for (size_t e_ = 0; e_ < arrows.size(); ++e_) { tts[e_] = arrows[e_].t; aXd[e_].resize(arrows[e_].X.size()); for (size_t q = 0; q < arrows[e_].X.size(); ++q) aXd[e_][q] = ddk::from(arrows[e_].X[q]); }
+      std::vector<ddk::dd> zphi(PG, ddk::dd{0.0, 0.0});
+      for (size_t e = 0; e < PG && ng; ++e) if (mask[e]) zphi[e] = ddk::div(ddk::from(z[e]), ddk::from(phi[e]));
+      if (!arrow_mats(phi, tts, aSid)) { ipm = ST_INACC; break; }
+      fill_locals_dd(qX1, qZ1, qX2, qZ2, aXd, aSid, zphi);
+      if (!dsys.factor()) { ipm = ST_INACC; break; }
+      pr.shift = 0.0;
+    }
+    auto bsolve = [&](double* R, int nrhs) { if (dd_on) dsys.solve(R, nrhs); else pr.solve(R, nrhs); };
     nshiftrun = pr.shift > 0.0 ? nshiftrun + 1 : 0;
     if (phase == 1 && pr.shift > 0.0 && nbackoff < MUT_BACKOFF_MAX) { mu_t *= 2.0; ++nbackoff; ncent = 0; prev_stepn = -1.0; nshiftrun = 0; }
     else if ((phase == 1 && pr.shift > 0.0) || (nshiftrun >= 2 && (mu_t < 0.0 || nbackoff >= MUT_BACKOFF_MAX))) { ipm = ST_INACC; break; }
-    TU = U; pr.solve(TU.data(), 2);
+    TU = U; bsolve(TU.data(), 2);
     double sb00 = b_tt, sb01 = b_ta, sb11 = b_aa;
     for (size_t e = 0; e < (size_t)p * db; ++e) { sb00 -= U[e] * TU[e]; sb01 -= U[e] * TU[(size_t)p * db + e]; sb11 -= U[(size_t)p * db + e] * TU[(size_t)p * db + e]; }
     auto direction = [&](double sig, bool corr, double corr0) {
@@ -462,7 +597,7 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
         zs[(size_t)kn * db + d + ng + a.slot] = rt;
       }
       for (int k = 0; k < p; ++k) for (int i = 0; i < ng; ++i) zs[(size_t)((k + 1) % p) * db + d + i] = mask[(size_t)k * ng + i] ? rph[(size_t)k * ng + i] : 0.0;
-      pr.solve(zs.data(), 1);
+      bsolve(zs.data(), 1);
       double u0 = 0, u1 = 0;
       for (size_t e = 0; e < (size_t)p * db; ++e) { u0 += U[e] * zs[e]; u1 += U[(size_t)p * db + e] * zs[e]; }
       const double rb0 = rhs_tau - u0, rb1 = rhs_alpha - u1, det = sb00 * sb11 - sb01 * sb01;
@@ -581,6 +716,7 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
     if (phase == 1) {
       const bool full = (ap == 1.0 && ad == 1.0);
       const double est = (prev_stepn >= 0.0) ? stepn * pow(std::min(1.0, stepn / prev_stepn), 1.5) : stepn;
+      if (tight && full && stepn < POLISH_ENTER) { polish = true; ++it; break; }
       if (full && (stepn < center_tol || est < 0.1 * center_tol)) { ipm = ST_OPT; ++it; break; }
       if (full && prev_stepn >= 0.0 && stepn > 0.5 * prev_stepn && stepn < 1e-6) { ipm = ST_OPT; ++it; break; }
       if (ncent >= center_iter) {
@@ -589,6 +725,154 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
       }
       prev_stepn = full ? stepn : -1.0;
     }
+  }
+  int npolish = 0;
+  if (polish) {
+    // dual-Newton polish in double-double (convexify_oracle._polish_dd with GG / arrows): y = (tau, alpha, P, phi, t); every stage quantity from the fp64 y
+    using namespace ddk;
+    ipm = ST_INACC;
+    std::vector<mat> Mq(p), Z1q(p), Z2q(p), X1q(p), X2q(p);
+    std::vector<double> tt(arrows.size());
+    for (size_t e_ = 0; e_ < arrows.size(); ++e_) tt[e_] = arrows[e_].t;
+    auto cones = [&](double tau_, double alpha_, const vec& P_, const vec& phi_) -> bool {
+      if (!(alpha_ - ALPHA_MIN > 0.0)) return false;
+      for (size_t e = 0; e < PG && ng; ++e) if (mask[e] && !(phi_[e] > 0.0)) return false;
+      bool okc = true;
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+      for (int k = 0; k < p; ++k) {
+        const int kn = (k + 1) % p;
+        mat Vd((size_t)nx * n), Pn((size_t)nx * nx), t, Mk, S((size_t)nn);
+        for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+        for (int e = 0; e < nxx; ++e) Pn[e] = from(P_[(size_t)kn * nxx + e]);
+        mat Vt((size_t)n * nx); for (int a = 0; a < nx; ++a) for (int c = 0; c < n; ++c) Vt[(size_t)c * nx + a] = Vd[(size_t)a * n + c];
+        mm(t, Vt, Pn, n, nx, nx, false); mm(Mk, t, Vd, n, nx, n, false);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+          dd v = add(Mk[(size_t)i * n + j], muld(from(Hb[(size_t)k * nn + i * n + j]), alpha_));
+          if (i < nx && j < nx) v = sub(v, from(P_[(size_t)k * nxx + i * nx + j]));
+          Mk[(size_t)i * n + j] = v;
+        }
+        for (int i2 = 0; i2 < nJ; ++i2) {
+          if (!mask[(size_t)k * ng + i2]) continue;
+          const double* g = ci.J + ((size_t)k * nJin + i2) * n; const double ph = phi_[(size_t)k * ng + i2];
+          for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Mk[(size_t)i * n + j] = add(Mk[(size_t)i * n + j], muld(tp(g[i], g[j]), ph));
+        }
+        Mq[k] = Mk;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (i == j) ? sub(Mk[(size_t)i * n + j], from(1.0)) : Mk[(size_t)i * n + j];
+        if (!inv_spd(Z1q[k], S, n)) { okc = false; continue; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (i == j) ? sub(from(tau_), Mk[(size_t)i * n + j]) : neg(Mk[(size_t)i * n + j]);
+        if (!inv_spd(Z2q[k], S, n)) okc = false;
+      }
+      return okc;
+    };
+    auto adj_sv = [&](double* out, const std::vector<mat>& Gm, double sg) {      // svec of the adjoint, into the P rows of an augmented vector [p][db]
+      std::vector<mat> Wm(p);
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+      for (int k = 0; k < p; ++k) {
+        mat Vd((size_t)nx * n), t;
+        for (int e = 0; e < nx * n; ++e) Vd[e] = from(pr.Vk(k)[e]);
+        mm(t, Vd, Gm[k], nx, n, n, false); mm(Wm[k], t, Vd, nx, n, nx, true);
+      }
+      for (int j = 0; j < p; ++j) {
+        const int jm = (j + p - 1) % p;
+        for (int e = 0; e < d; ++e) {
+          const int a = pr.ia[e], c = pr.ib[e];
+          out[(size_t)j * db + e] = sg * val(sub(Wm[jm][a * nx + c], Gm[j][(size_t)a * n + c])) * (a == c ? 1.0 : 2.0);
+        }
+      }
+    };
+    std::vector<mat> aSi;
+    bool okp = cones(tau, alpha, P, phi) && arrow_mats(phi, tt, aSi);
+    vec Pn_(P.size()), phin(PG, 1.0);
+    std::vector<double> ttn(arrows.size());
+    for (npolish = 1; okp && npolish <= POLISH_MAX; ++npolish) {
+      const double mu_p = mu_t;
+      s0 = alpha - ALPHA_MIN; x0 = mu_p / s0;
+      std::vector<mat> Psi(p), Ph(p), Ph2(p), Yq(p);
+      double b_tt = 0, b_ta = 0, b_aa = 0, g_tau = 1.0, g_alpha = -x0;
+      for (int k = 0; k < p; ++k) {
+        const size_t o = (size_t)k * nn;
+        X1q[k].resize(nn); X2q[k].resize(nn); Yq[k].resize(nn);
+        for (int e = 0; e < nn; ++e) { X1q[k][e] = muld(Z1q[k][e], mu_p); X2q[k][e] = muld(Z2q[k][e], mu_p); Yq[k][e] = sub(X1q[k][e], X2q[k][e]); }
+        mat Hd(nn), t; for (int e = 0; e < nn; ++e) Hd[e] = from(Hb[o + e]);
+        mm(Psi[k], X2q[k], Z2q[k], n, n, n, false);
+        mm(t, X2q[k], Hd, n, n, n, false); mm(Ph2[k], t, Z2q[k], n, n, n, false);
+        mm(t, X1q[k], Hd, n, n, n, false); mm(Ph[k], t, Z1q[k], n, n, n, false);
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) {
+          auto sy = [&](mat& Gm) { const dd v = muld(add(Gm[(size_t)i * n + j], Gm[(size_t)j * n + i]), 0.5); Gm[(size_t)i * n + j] = v; Gm[(size_t)j * n + i] = v; };
+          sy(Psi[k]); sy(Ph2[k]); sy(Ph[k]);
+        }
+        for (int e = 0; e < nn; ++e) Ph[k][e] = add(Ph[k][e], Ph2[k][e]);
+        dd trp = from(0.0), trh = from(0.0), hp = from(0.0), trx = from(0.0), hy = from(0.0);
+        for (int i = 0; i < n; ++i) { trp = add(trp, Psi[k][(size_t)i * n + i]); trh = add(trh, Ph2[k][(size_t)i * n + i]); trx = add(trx, X2q[k][(size_t)i * n + i]); }
+        for (int e = 0; e < nn; ++e) { hp = add(hp, mul(Hd[e], Ph[k][e])); hy = add(hy, mul(Hd[e], Yq[k][e])); }
+        b_tt += val(trp); b_ta -= val(trh); b_aa += val(hp); g_tau -= val(trx); g_alpha -= val(hy);
+      }
+      b_aa += x0 / s0;
+      assemble_dd(dsys, pr, X1q, Z1q, X2q, Z2q);
+      std::vector<mat> aXd(arrows.size());
+      for (size_t e_ = 0; e_ < arrows.size(); ++e_) { aXd[e_].resize(aSi[e_].size()); for (size_t q = 0; q < aSi[e_].size(); ++q) aXd[e_][q] = muld(aSi[e_][q], mu_p); }
+      std::vector<dd> zphi(PG, dd{0.0, 0.0});
+      for (size_t e = 0; e < PG && ng; ++e) if (mask[e]) zphi[e] = div(div(from(mu_p), from(phi[e])), from(phi[e]));
+      fill_locals_dd(X1q, Z1q, X2q, Z2q, aXd, aSi, zphi);
+      if (!dsys.factor()) break;
+      // border columns (tau, alpha) and the right-hand side = minus the gradient, both with their stage-local rows
+      std::fill(U.begin(), U.end(), 0.0); std::fill(zs.begin(), zs.end(), 0.0);
+      adj_sv(&U[0], Psi, -1.0); adj_sv(&U[(size_t)p * db], Ph, 1.0); adj_sv(zs.data(), Yq, 1.0);
+      for (int k = 0; k < p; ++k) {
+        const int kn = (k + 1) % p;
+        for (int i = 0; i < nJ; ++i) {
+          if (!mask[(size_t)k * ng + i]) continue;
+          const double* g = ci.J + ((size_t)k * nJin + i) * n;
+          dd cps{0.0, 0.0}, cph{0.0, 0.0}, gy{0.0, 0.0};
+          for (int a = 0; a < n; ++a) for (int c = 0; c < n; ++c) { const dd gg_ = tp(g[a], g[c]); cps = add(cps, mul(gg_, Psi[k][(size_t)a * n + c])); cph = add(cph, mul(gg_, Ph[k][(size_t)a * n + c])); gy = add(gy, mul(gg_, Yq[k][(size_t)a * n + c])); }
+          U[(size_t)kn * db + d + i] = -val(cps); U[(size_t)(p + kn) * db + d + i] = val(cph);
+          // minus the gradient in phi: <g g', Y> + mu / phi (+ the arrow term below), evaluated in dd, then rounded
+          zs[(size_t)kn * db + d + i] = val(add(gy, div(from(mu_p), from(phi[(size_t)k * ng + i]))));
+        }
+      }
+      for (size_t e_ = 0; e_ < arrows.size(); ++e_) {
+        const Arrow& a = arrows[e_];
+        const int kn = (a.k + 1) % p, m1 = a.m + 1;
+        dd trx{0.0, 0.0}; for (int i = 0; i < m1; ++i) trx = add(trx, aXd[e_][(size_t)i * m1 + i]);
+        zs[(size_t)kn * db + d + ng + a.slot] = -(1.0 - val(trx));
+        for (int q = 0; q < a.m; ++q) zs[(size_t)kn * db + d + a.idx[q]] += 2.0 * wr * cw[a.idx[q]] * val(aXd[e_][q + 1]);
+      }
+      TU = U; dsys.solve(TU.data(), 2); dsys.solve(zs.data(), 1);
+      double sb00 = b_tt, sb01 = b_ta, sb11 = b_aa, u0 = 0, u1 = 0;
+      for (size_t e = 0; e < (size_t)p * db; ++e) {
+        sb00 -= U[e] * TU[e]; sb01 -= U[e] * TU[(size_t)p * db + e]; sb11 -= U[(size_t)p * db + e] * TU[(size_t)p * db + e];
+        u0 += U[e] * zs[e]; u1 += U[(size_t)p * db + e] * zs[e];
+      }
+      const double rb0 = -g_tau - u0, rb1 = -g_alpha - u1, det = sb00 * sb11 - sb01 * sb01;
+      dtau = (sb11 * rb0 - sb01 * rb1) / det; dalpha = (sb00 * rb1 - sb01 * rb0) / det;
+      for (size_t e = 0; e < (size_t)p * db; ++e) zs[e] -= TU[e] * dtau + TU[(size_t)p * db + e] * dalpha;
+      for (int k = 0; k < p; ++k) for (int e = 0; e < d; ++e) {
+        const double v = zs[(size_t)k * db + e];
+        dP[(size_t)k * nxx + pr.ia[e] * nx + pr.ib[e]] = v; dP[(size_t)k * nxx + pr.ib[e] * nx + pr.ia[e]] = v;
+      }
+      for (int k = 0; k < p; ++k) for (int i = 0; i < ng; ++i) dphi[(size_t)k * ng + i] = mask[(size_t)k * ng + i] ? zs[(size_t)((k + 1) % p) * db + d + i] : 0.0;
+      pr.calH(dM, dP, dalpha);
+      add_gg(dM, dphi);
+      double num = 0, den = 0; const double ra = dalpha / alpha;
+      for (int k = 0; k < p; ++k) for (int e = 0; e < nn; ++e) { const double mv = val(Mq[k][e]); const double dh = dM[(size_t)k * nn + e] - ra * mv; num += dh * dh; den += mv * mv; }
+      stepn = sqrt(num / den);
+      double th = 1.0;
+      for (;;) {
+        for (size_t e = 0; e < P.size(); ++e) Pn_[e] = P[e] + th * dP[e];
+        for (size_t e = 0; e < PG && ng; ++e) phin[e] = mask[e] ? phi[e] + th * dphi[e] : 1.0;
+        for (size_t e_ = 0; e_ < arrows.size(); ++e_) ttn[e_] = tt[e_] + th * zs[(size_t)((arrows[e_].k + 1) % p) * db + d + ng + arrows[e_].slot];
+        if (cones(tau + th * dtau, alpha + th * dalpha, Pn_, phin) && arrow_mats(phin, ttn, aSi)) break;
+        th *= 0.5;
+        if (th < 1e-3) { okp = false; break; }
+      }
+      if (!okp) break;
+      tau += th * dtau; alpha += th * dalpha; P = Pn_;
+      for (size_t e = 0; e < PG && ng; ++e) if (mask[e]) phi[e] = phin[e];
+      tt = ttn;
+      if (th == 1.0 && stepn < center_tol) { ipm = ST_OPT; break; }
+    }
+    if (npolish > POLISH_MAX) npolish = POLISH_MAX;
+    for (size_t e_ = 0; e_ < arrows.size(); ++e_) arrows[e_].t = tt[e_];
   }
   // un-scaling, supplement, status (convexifier.py:403-456)
   const double sc = 1.0 / (s * alpha);
@@ -612,7 +896,7 @@ Result solve_problem_con(int p, int nx, int mb, const double* A, const double* B
   if (co.T && nT) for (int k = 0; k < p; ++k) for (int q = 0; q < nT; ++q) { co.T[(size_t)k * nn + ta[q] * n + tb[q]] = phs[(size_t)k * ng + nJ + q]; co.T[(size_t)k * nn + tb[q] * n + ta[q]] = phs[(size_t)k * ng + nJ + q]; }
   double tsum = 0; for (const Arrow& a : arrows) tsum += a.t;
   co.objective = tau / sbeta + tsum / sbeta;
-  res.kappa = tau; res.alpha = alpha; res.iters = it; res.mu_t = mu_t; res.stepn = stepn;
+  res.kappa = tau; res.alpha = alpha; res.iters = it; res.mu_t = mu_t; res.stepn = stepn; res.dd_iters = ndd; res.polish = npolish;
   res.status = (lo2 > 0.0) ? (ipm == ST_OPT ? 0 : 1) : 2;
   return res;
 }

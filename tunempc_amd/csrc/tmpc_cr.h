@@ -350,15 +350,16 @@ __device__ __forceinline__ void trd_strip(double* X, const double* Dk, const dou
       if (c < (NC)) {                                                                                       \
         typedef double2_t __attribute__((address_space(1)))* gptr2;                                         \
         gptr2 cp = (gptr2)(X + (size_t)(wc0 + 4 * fq + fk) * dp + 64 * (I) + 16 * c + 4 * fj);              \
-        cp[0] = (double2_t){SG SET[c][0], SG SET[c][1]}; cp[1] = (double2_t){SG SET[c][2], SG SET[c][3]};   \
-        if (X32) {                                                                                          \
+        if (X32) {      /* an iteration in single precision reads ONLY the float32 copy of this block (updates, substitutions): the fp64 store is skipped */ \
           typedef float4_t __attribute__((address_space(1)))* gptr4;                                        \
           *(gptr4)(X32 + (size_t)(wc0 + 4 * fq + fk) * ld32 + 64 * (I) + 16 * c + 4 * fj) =                 \
               (float4_t){(float)(SG SET[c][0]), (float)(SG SET[c][1]), (float)(SG SET[c][2]), (float)(SG SET[c][3])}; \
+        } else {                                                                                            \
+          cp[0] = (double2_t){SG SET[c][0], SG SET[c][1]}; cp[1] = (double2_t){SG SET[c][2], SG SET[c][3]}; \
         }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
-    vmtot += (X32 ? 3 : 2) * (NC);                                                                          \
+    vmtot += (X32 ? 1 : 2) * (NC);                                                                          \
   }
   // (+-) set -> A operand.  C: slab = this wave's strip, K pairs 2 fj and 2 fj + 1 of every row; R: this wave's rows of the slabs c < NC
 #define TRD_PARK_C(SET)      /* negated */                                                                  \
