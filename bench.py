@@ -523,7 +523,7 @@ def main():
                     h2.close()
                     step2_cpu = None
                     if not args.no_cpu_baseline:
-                        try:                   # the CPU port on the same model (default mode and, when built, its tight mode), bounded sample: one problem per thread at period 8
+                        try:                   # the CPU port on the same model (default mode and its tight mode), bounded sample: one problem per thread at period 8
                             sys.path.insert(0, os.path.join(ROOT, 'oracle'))
                             import cpu_ipm
                             hw = host_cpu_info()
@@ -536,9 +536,9 @@ def main():
                             step2_cpu = {"value": cores * ps / tcd, "unit": "stage-convexifications/s", "cores": cores, "kind": "port", "mode": "default",
                                          "sample": f"oracle/cpu_ipm, Step 2 model (stage-local elimination, cpu_ipm_con.h), {cores} problems of the bench stage shape and rows with period {ps} "
                                                    f"on {cores} threads in {tcd:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
-                            if hasattr(cpu_ipm, 'convexify_con_batch_tight'):
-                                tc0 = time.perf_counter(); oc = cpu_ipm.convexify_con_batch_tight(As, Bs, Hs, Js, ng=ng2, ncnt=cs, rho=rho2, tol=2.0 ** -37, threads=cores); tct = time.perf_counter() - tc0
-                                step2_cpu["tight"] = {"value": cores * ps / tct, "sample": f"the same sample in the port's tight mode in {tct:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
+                            tc0 = time.perf_counter(); oc = cpu_ipm.convexify_con_batch(As, Bs, Hs, Js, ng=ng2, ncnt=cs, rho=rho2, tol=2.0 ** -37, threads=cores, tight=True); tct = time.perf_counter() - tc0
+                            step2_cpu["tight"] = {"value": cores * ps / tct, "unit": "stage-convexifications/s", "cores": cores, "kind": "port",
+                                                  "sample": f"the same sample in the port's tight mode (double-double rows and polish, cpu_ipm_con.h) in {tct:.1f} s, {int((oc['status'] == 0).sum())}/{cores} Optimal"}
                         except Exception as e:      # noqa: BLE001
                             step2_cpu = {"error": f"{type(e).__name__}: {e}"}
                     # cone dimension: the 2 p LMI blocks and alpha, one linear cone per row, an (m + 1)-dimensional arrow block per norm term (rows of G; rows of C where present)

@@ -1001,6 +1001,40 @@ int cpu_ipm_convexify_con_batch(int nb, int p, int nx, int mb, int ng0, int ncma
   return 0;
 }
 
+// The same with the tight-accuracy mode for Step 1 with G and Step 2 (tight != 0; Step 3 in this mode: the numpy oracle only): double-double block linear algebra with the
+// stage-local rows in double-double below DD_SWITCH, dd dual-Newton polish in (tau, alpha, P, phi, t).  info [nb][4]: mu_t, dd iterations, polish steps, last relative step.
+int cpu_ipm_convexify_con_batch2(int nb, int p, int nx, int mb, int ng0, int ncmax, const double* A, const double* B, const double* H, const double* J,
+                                 const int32_t* ncnt, double rho, int flags, double tol, int threads, int tight, double* Hc, double* P, double* FgF, double* T,
+                                 double* kappa, double* objective, int32_t* status, int32_t* iters, double* info) {
+  if (nb < 0 || p < 1 || nx < 1 || mb < 0 || ng0 < 0 || ncmax < 0 || !A || !H || !Hc || ((ng0 + ncmax) > 0 && !J)) return -1;
+  if (tight && (flags & 4)) return -2;      // Step 3 in the tight mode: not in this port
+  const int n = nx + mb, nJ = ng0 + ncmax;
+  if (tol <= 0.0) tol = 0x1p-25;
+  const int blas_threads_before = scipy_openblas_get_num_threads();
+  scipy_openblas_set_num_threads(1);
+  if (threads < 1) threads = 1;
+  const bool inner = tight && nb < threads;
+  omp_set_max_active_levels(1);
+  const int saved = omp_get_max_threads();
+  omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (!inner)
+  for (int b = 0; b < nb; ++b) {
+    ConIn ci; ci.ng0 = ng0; ci.ncmax = ncmax; ci.J = J ? J + (size_t)b * p * nJ * n : nullptr; ci.ncnt = ncnt ? ncnt + (size_t)b * p : nullptr;
+    ci.rho = rho; ci.constr = (flags & 1) != 0; ci.cost_free = (flags & 2) != 0; ci.force = (flags & 4) != 0;
+    ConOut co; co.P = P ? P + (size_t)b * p * nx * nx : nullptr; co.FgF = FgF ? FgF + (size_t)b * p * nJ : nullptr; co.T = T ? T + (size_t)b * p * n * n : nullptr;
+    const Result r = solve_problem_con(p, nx, mb, A + (size_t)b * p * nx * nx, B + (size_t)b * p * nx * mb, H + (size_t)b * p * n * n, ci, tol, 50, 12, 1e-9,
+                                       Hc + (size_t)b * p * n * n, co, tight != 0, inner);
+    if (kappa) kappa[b] = r.kappa;
+    if (objective) objective[b] = co.objective;
+    if (status) status[b] = r.status;
+    if (iters) iters[b] = r.iters;
+    if (info) { info[4 * b] = r.mu_t; info[4 * b + 1] = r.dd_iters; info[4 * b + 2] = r.polish; info[4 * b + 3] = r.stepn; }
+  }
+  omp_set_num_threads(saved);
+  scipy_openblas_set_num_threads(blas_threads_before);
+  return 0;
+}
+
 int cpu_ipm_max_threads(void) { return omp_get_max_threads(); }
 
 }  // extern "C"

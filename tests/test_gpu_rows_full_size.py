@@ -178,3 +178,28 @@ def test_awe_shape_step2_golden(hc, golden_dir):
         assert abs(o['kappa'][0] - g['kappa' + tag][0]) < 1e-9 * g['kappa' + tag][0]
         print(f'AWE shape Step 2{tag}: Hc {e:.2e}  P {eP:.2e}  Fg {eF:.2e}  F {eC:.2e}  kappa {o["kappa"][0]:.10f}')
     h.set_tight(False)
+
+
+@pytest.mark.parametrize('p,nx,mb,ng,nc,nb', [(12, 9, 3, 2, 3, 3), (40, 9, 6, 3, 4, 2), (64, 24, 8, 2, 3, 2)])
+def test_tight_mode_with_rows_against_cpu_ipm_tight(hc, p, nx, mb, ng, nc, nb):
+    """The tight mode on the Step 2 model (rows of G, ragged rows of C, norm terms) beyond the sizes the numpy oracle's tight mode reaches in seconds: mid size, the AWE
+    example's shape and the bench stage shape with 2 + 3 rows, against the C++ port's tight mode (cpu_ipm_con.h, tied to the oracle's in tests/test_tight_cpu.py).
+    Until round 6 the mode was value-checked at p <= 6 / n <= 34 and held to certificates at the bench shape."""
+    from tunempc_amd import synthetic
+    n = nx + mb
+    A, B, H = synthetic.gen_batch(65000, nb, p, nx, mb)
+    G, C, ncnt = _rows(65, nb, p, n, ng, nc)
+    J = np.concatenate([G, C], axis=2)
+    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h.set_tight(True, 2.0 ** -37)
+    o = h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
+    h.set_tight(False)
+    ref = cpu_ipm.convexify_con_batch(A, B, H, J, ng=ng, ncnt=ncnt, rho=1e-2, tol=2.0 ** -37, threads=HOST_THREADS * 2, tight=True)
+    worst = 0.0
+    for b in range(nb):
+        assert int(o['status'][b]) == int(ref['status'][b]) == 0 and int(o['info'][b, 10]) == 0 and o['info'][b, 6] == ref['mu_t'][b]          # at the tight target, no fall-back
+        e = rel(o['Hc'][b], ref['Hc'][b]); worst = max(worst, e)
+        assert e < PARITY and rel(o['P'][b], ref['P'][b]) < PARITY
+        assert abs(o['kappa'][b] - ref['kappa'][b]) < 1e-9 * ref['kappa'][b]
+        assert np.linalg.norm(o['FgF'][b] - ref['FgF'][b]) < PARITY * max(1.0, np.linalg.norm(ref['FgF'][b]))
+    print(f'tight Step 2 p={p} n={n} rows {ng}+{nc}: worst Hc {worst:.2e}; GPU iterations {o["iters"].tolist()}, port {ref["iters"].tolist()} (+ {ref["polish_steps"].tolist()} polish)')

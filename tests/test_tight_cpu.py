@@ -216,3 +216,51 @@ def test_tight_golden_vectors(name):
         assert np.abs(r['P'] - g['P'][b]).max() <= 1e-10 * np.abs(g['P'][b]).max() and abs(r['kappa'] - g['kappa'][b]) <= 1e-12 * g['kappa'][b]
         if 'Fg' in g.files:
             assert np.abs(r['Fg'] - g['Fg'][b]).max() <= 1e-10 * max(1.0, np.abs(g['Fg'][b]).max())
+
+
+# ----------------------------------------------------------------------------- round 6: the C++ port's tight mode on the models with rows
+def _rows_inputs(seed, nb, p, nx, mb, ng, ncs):
+    n = nx + mb
+    A, B, H = co.gen_batch(seed, nb, p, nx, mb)
+    rng = np.random.default_rng(seed + 5)
+    nc = max(max(ncs), 1)
+    G = rng.standard_normal((nb, p, ng, n))
+    C = np.zeros((nb, p, nc, n)); ncnt = np.tile(np.asarray(ncs, np.int32), (nb, 1))
+    for b in range(nb):
+        for k in range(p):
+            C[b, k, :ncs[k]] = rng.standard_normal((ncs[k], n))
+    return A, B, H, G, C, ncnt
+
+
+@pytest.mark.parametrize('mode,seed,nb,p,nx,mb,ng,ncs,rho', [
+    ('eq', 20, 2, 3, 3, 2, 2, [0, 0, 0], 0.0), ('eq', 9, 2, 6, 5, 2, 3, [0] * 6, 0.0), ('step2', 20, 2, 3, 3, 2, 0, [2, 0, 1], 1e-3),
+    ('step2', 7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 1e-2), ('step2', 30, 2, 2, 3, 1, 1, [1, 1], 1e-3), ('step2', 20, 1, 1, 3, 1, 0, [2], 1.0),
+    ('beta', 7, 2, 5, 4, 2, 3, [0, 3, 1, 2, 3], 0.0)])
+def test_cpu_ipm_tight_mode_with_rows_matches_the_oracle(mode, seed, nb, p, nx, mb, ng, ncs, rho):
+    """oracle/cpu_ipm/cpu_ipm_con.h in the tight mode (stage-local rows of the augmented blocks in double-double, as tmpc_dd.h's k_dd_aug_fill; dd dual-Newton polish
+    in (tau, alpha, P, phi, t)) against the numpy oracle's tight mode (dense border columns in fp64, `_polish_dd`): the same central-path point at 2^-37 kappa."""
+    import cpu_ipm
+    TT = 2.0 ** -37
+    A, B, H, G, C, ncnt = _rows_inputs(seed, nb, p, nx, mb, ng, ncs)
+    J = np.concatenate([G, C], axis=2)
+    kw = dict(eq={}, step2=dict(rho=rho), beta=dict(cost_free=True))[mode]
+    o = cpu_ipm.convexify_con_batch(A, B, H, G if mode == 'eq' else J, ng=ng, ncnt=None if mode == 'eq' else ncnt, tol=TT, tight=True, **kw)
+    for b in range(nb):
+        if np.linalg.eigvalsh(H[b]).min() > 0:
+            continue
+        Cl = None if mode == 'eq' else [C[b, k, :ncnt[b, k]] if ncnt[b, k] else None for k in range(p)]
+        Gb = G[b] if ng else None
+        r = co.sdp_step1(A[b], B[b], H[b], dict(tol=TT, tight=True), G=Gb, C=Cl, **kw)
+        st, dHc = co.check_convergence(A[b], B[b], H[b], r['P'], r['ipm_status'], G=Gb, Fg=r.get('Fg'), C=Cl, F=r.get('F'))[:2]
+        assert int(o['status'][b]) == int(st) == 0 and r['ipm_status'] == 'optimal' and o['mu_t'][b] == r['mu_target']
+        assert np.linalg.norm(o['Hc'][b] - H[b] - dHc) <= 1e-9 * np.linalg.norm(H[b] + dHc)
+        assert abs(o['kappa'][b] - r['kappa']) <= 1e-10 * r['kappa']
+        if ng:
+            assert np.abs(o['FgF'][b, :, :ng] - r['Fg']).max() <= 1e-8 * max(1.0, np.abs(r['Fg']).max())
+
+
+def test_cpu_ipm_tight_mode_refuses_step3():
+    import cpu_ipm
+    A, B, H = co.gen_batch(0, 1, 2, 2, 1)
+    with pytest.raises(NotImplementedError):
+        cpu_ipm.convexify_con_batch(A, B, H, rho=1e-3, force=True, tight=True)
