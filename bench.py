@@ -168,30 +168,39 @@ def small_configs(HipConvexifier, synthetic):
     cores = max(1, min(hw["effective_cores"], 64))
     # (round 6: the reference's steady-state examples, p = 1 -- examples/convex_lqr.py:40-46 nx = 3, m = 1; examples/cstr/main.py nx = 4, m = 2;
     # examples/evaporation_process/main.py:110-111 nx = 2, m = 2 -- as synthetic problems of their shapes, batch 1)
-    for key, (seed, nb, p, nx, mb) in {"configs[1] unicycle-shaped p=30 n=5 batch=1": (200000, 1, 30, 4, 1),
-                                        "configs[2] evaporation-shaped p=50 n=4 batch=256": (200100, 256, 50, 2, 2),
-                                        "LQR-shaped p=1 n=4 batch=1": (200200, 1, 1, 3, 1),
-                                        "CSTR-shaped p=1 n=6 batch=1": (200300, 1, 1, 4, 2),
-                                        "evaporation-shaped p=1 n=4 batch=1": (200400, 1, 1, 2, 2)}.items():
-        A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb)
+    # (the LQR example is convex: its H passes the pre-check, as in the reference -- convexifier.py:83-85; the two economic steady states have an indefinite H:
+    #  sigP = 3 makes the synthetic member of their shape indefinite too, so that the leg times an interior-point solve)
+    for key, (seed, nb, p, nx, mb, sigP) in {"configs[1] unicycle-shaped p=30 n=5 batch=1": (200000, 1, 30, 4, 1, 1.0),
+                                              "configs[2] evaporation-shaped p=50 n=4 batch=256": (200100, 256, 50, 2, 2, 1.0),
+                                              "LQR-shaped p=1 n=4 batch=1 (convex: pre-check only)": (200200, 1, 1, 3, 1, 1.0),
+                                              "CSTR-shaped p=1 n=6 batch=1": (200300, 1, 1, 4, 2, 3.0),
+                                              "evaporation-shaped p=1 n=4 batch=1": (200400, 1, 1, 2, 2, 3.0)}.items():
+        A, B, H = synthetic.gen_batch(seed, nb, p, nx, mb, sigP=sigP)
         h = HipConvexifier(p, nx, mb, chunk=nb)
         h.convexify_batch(A, B, H)
+        h.profile()                          # (clears the counters)
         ts = []
         for _ in range(7):
             t0 = time.perf_counter(); o = h.convexify_batch(A, B, H); ts.append(time.perf_counter() - t0)
         tg = float(np.median(ts))
+        # which path the library took, as the library reports it (profile slot 15: problems solved by the one-launch kernel; members that were convex already never reach either)
+        names = {True: "k_ipm_small: the whole interior-point loop in one launch, one workgroup per problem (tmpc_persist.h)", False: "launch sequence (per-phase kernels, stages spread over the CUs)"}
+        took = h.profile()['persistent_problems'] > 0
         rec = {"gpu_ms_per_solve": 1e3 * tg, "gpu_stage_conv_per_s": nb * p / tg, "status_optimal": int((o['status'] == 0).sum()), "batch": nb,
-               "ipm_iterations_mean": float(o['iters'].mean()),
-               "path": ("k_ipm_small: the whole interior-point loop in one launch, one workgroup per problem (tmpc_persist.h)" if (p <= 8 or nb >= 96)
-                        else "launch sequence (one long problem: its stages spread over the CUs)")}
+               "ipm_iterations_mean": float(o['iters'].mean()), "path": names[took] if o['iters'].max() > 0 else "pre-check only: every member convex already (convexifier.py:83-85), no interior-point iteration"}
         # the other path, for the record (TMPC_TUNE_PERSISTENT 0 / 2): what the default rule chose against what it did not
         try:
-            h.set_tuning(persistent=0 if (p <= 8 or nb >= 96) else 2)
+            h.set_tuning(persistent=0 if took else 2)
             h.convexify_batch(A, B, H)
+            h.profile()
             t2 = []
             for _ in range(5):
                 t0 = time.perf_counter(); h.convexify_batch(A, B, H); t2.append(time.perf_counter() - t0)
-            rec["other_path_ms_per_solve"] = 1e3 * float(np.median(t2))
+            other = h.profile()['persistent_problems'] > 0
+            if o['iters'].max() > 0 and other != took:
+                rec["other_path_ms_per_solve"] = 1e3 * float(np.median(t2))
+            else:
+                rec["other_path_ms_per_solve"] = None      # the shape is not eligible for the other path (or nothing iterated): nothing to compare
         except Exception as e:      # noqa: BLE001
             rec["other_path_error"] = f"{type(e).__name__}: {e}"
         h.close()

@@ -267,7 +267,9 @@ int tmpc_eig_clip_host(int nb, int n, const double* A, double tol, double* out, 
  * out[0] stage_pre+ctrl, [1] schur assembly, [2] block factorisation (all kernels of tmpc_cr.h's factor phase), [3] predictor
  * pass, [4] corrector pass + update, [5] number of factorisation phases (= IPM iterations of the chunks), [6] total ms of the
  * convexify calls, [7] IPM iterations (max over chunk, summed over chunks), [8] problem-factorisations (sum over the phases of
- * the problems still iterating), [9] / [10] / [11] ms inside k_cr_potrf / k_cr_trsm / k_cr_update, [12..15] reserved. */
+ * the problems still iterating), [9] / [10] / [11] ms inside k_cr_potrf / k_cr_trsm / k_cr_update (fp64), [12] lanes of the handle, [13] problem-factorisations
+ * whose Schur-complement updates ran in single precision (TMPC_TUNE_LOWP_SWITCH), [14] ms inside k_cr_update_dma_f32.
+ * Counted with or without the flag: [15] problems solved through the one-launch kernel of TMPC_TUNE_PERSISTENT (k_ipm_small) since the last call. */
 int tmpc_get_profile(tmpc_handle* h, double* out16);
 
 /* Optimality certificate of the LAST wave solved (nb <= chunk, plain Step 1 model): the DUAL iterate of the interior-point method,

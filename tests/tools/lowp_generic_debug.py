@@ -1,3 +1,5 @@
+"""Checker (test infrastructure, run on the GPU box): the generic and the tuned stage kernels on one shape with the single-precision updates on / off,
+against the numpy oracle -- how the retry of a frozen pivot moves the point (round 6; tests/test_gpu_parity.py runs the comparison with lowp_switch = 0)."""
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'oracle')
 import numpy as np, convexify_oracle as co
 from tunempc_amd._lib import HipConvexifier

@@ -444,7 +444,7 @@ class HipConvexifier:
         out = np.zeros(16)
         _check(self.lib, self.lib.tmpc_get_profile(self._h, _dptr(out)), 'tmpc_get_profile')
         keys = ['pre_ms', 'schur_ms', 'factor_ms', 'pass1_ms', 'pass2_ms', 'factor_launches', 'total_ms', 'ipm_iters',
-                'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms', 'lanes', 'lowp_factorisations', 'update_f32_ms']
+                'problem_factorisations', 'potrf_ms', 'trsm_ms', 'update_ms', 'lanes', 'lowp_factorisations', 'update_f32_ms', 'persistent_problems']
         return dict(zip(keys, out.tolist()))
 
     def pack_sensitivities(self, C=None, mu=None, Hbig=None, thr=1e-15, ncmax=None, nb=None):

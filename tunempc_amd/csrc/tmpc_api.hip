@@ -90,10 +90,18 @@ struct LaneWorker {
   }
   void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done; }); }
   void shutdown() {
-    if (pid != getpid()) { if (th.joinable()) th.detach(); return; }      // (forked child: the thread never existed here)
     { std::lock_guard<std::mutex> lk(m); stop = true; }
     cv.notify_all();
     if (th.joinable()) th.join();
+  }
+  // End of a worker's life.  In the process that created it: stop, join, delete.  In a process forked after start() the thread does not exist and the mutex /
+  // condition variable were copied while the parent's worker sat in cv.wait -- destroying that condition variable may wait for a waiter that never leaves
+  // (glibc) and the std::thread object must not be destroyed joinable: the object is LEAKED there on purpose (a few hundred bytes per lane; handles are not
+  // meant to be used across fork).
+  static void retire(LaneWorker*& wk) {
+    if (!wk) return;
+    if (wk->pid == getpid()) { wk->shutdown(); delete wk; }
+    wk = nullptr;
   }
 };
 
@@ -773,6 +781,7 @@ static int run_chunk(tmpc_handle* h, Lane* ln, int nb, const double* dA, const d
       hipLaunchKernelGGL(k_ipm_small, dim3(active), dim3(CRS_NT), (size_t)pk_lds_doubles(dm.p) * sizeof(double), st, w, dm, o, cd, plv, h->sched.prep, reg_max,
                          h->tune_pretest ? o.chord_step : -1.0, cap);
       HIPCHK(hipGetLastError());
+      ln->prof[15] += (double)active;        // (counted with or without TMPC_FLAG_PROFILE: which path a wave took -- bench.py's label)
       active = 0; nfac = 0;
     }
   }
@@ -1167,7 +1176,7 @@ int tmpc_destroy(tmpc_handle* h) {
     if (ln.st) hipStreamDestroy(ln.st);
     if (ln.big_scr) hipFree(ln.big_scr);
     if (ln.graphs) { for (auto& kv : *ln.graphs) if (kv.second) hipGraphExecDestroy(kv.second); delete ln.graphs; }
-    if (ln.worker) { ln.worker->shutdown(); delete ln.worker; ln.worker = nullptr; }
+    LaneWorker::retire(ln.worker);
   }
   if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->slab) hipFree(h->slab);
@@ -1423,7 +1432,7 @@ static int dispatch(tmpc_handle* h, const Call& c, hipStream_t user, bool has_us
     int rcs[MAXL]; for (int l = 0; l < MAXL; ++l) { rcs[l] = TMPC_OK; h->lane[l].last_nb = 0; }
     for (int l = 1; l < nl; ++l) {
       Lane& ln = h->lane[l];
-      if (ln.worker && ln.worker->pid != getpid()) { ln.worker->shutdown(); delete ln.worker; ln.worker = nullptr; }
+      if (ln.worker && ln.worker->pid != getpid()) LaneWorker::retire(ln.worker);      // forked child: leaked, a fresh worker is started below
       if (!ln.worker) { ln.worker = new LaneWorker(); ln.worker->start(); }
       ln.worker->submit([&, l]() {
         rcs[l] = lane_run(h, &h->lane[l], c, off + lo[l], lo[l + 1] - lo[l]);
