@@ -28,8 +28,13 @@ def calH(A, B, P):
 CONDS = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 3, 5)      # exponents of cond(Hhat)
 rows = []
 nbad = 0
-for (p, nx, mb) in [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]:
+SHAPES = [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]
+if os.environ.get('ROBUST_WIDE'):      # round 6: only shapes whose Schur blocks are wide enough for the single-precision updates (TMPC_TUNE_LOWP_SWITCH: blocks wider than 64)
+    SHAPES = [(6, 24, 8), (12, 12, 4)]
+for (p, nx, mb) in SHAPES:
     h = HipConvexifier(p, nx, mb)
+    if os.environ.get('ROBUST_LOWP'):         # switch-over of the single-precision updates (0 = fp64 throughout)
+        h.set_tuning(lowp_switch=float(os.environ['ROBUST_LOWP']))
     if os.environ.get('ROBUST_PERSIST'):      # round 5: 2 = the persistent one-launch kernel for every small shape whatever the batch, 0 = never (tmpc_set_tuning)
         h.set_tuning(persistent=int(os.environ['ROBUST_PERSIST']))
     for sigP in (0.1, 1.0, 10.0, 100.0):
@@ -54,4 +59,4 @@ for (p, nx, mb) in [(1, 3, 1), (2, 4, 2), (5, 9, 6), (30, 4, 1), (8, 16, 4)]:
                     print('NOT ALL OK', rows[-1])
     h.close()
 print('cases', len(rows), 'with a failing member', nbad, 'max iterations', max(r['iters_max'] for r in rows))
-json.dump(rows, open(os.path.join(ROOT, 'gpurun_out', 'robustness_sweep.json'), 'w'))
+json.dump(rows, open(os.path.join(ROOT, 'gpurun_out', os.environ.get('ROBUST_OUT', 'robustness_sweep.json')), 'w'))
