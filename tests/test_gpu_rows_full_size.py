@@ -24,18 +24,18 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.fixture(scope='module')
+@pytest.fixture
 def hc():
+    """Handles of ONE test, each sized for the batch it solves (`chunk`) and closed when the test ends, pass or fail: the default chunk takes 60 % of the free HBM, a
+    tight-mode handle as much again -- handles that outlive their test starve the ones after them (seen once: hipMalloc of 90 GB failed in the full suite)."""
     from tunempc_amd._lib import HipConvexifier
-    cache = {}
+    made = []
 
-    def get(p, nx, mb, **kw):
-        key = (p, nx, mb, tuple(sorted(kw.items())))
-        if key not in cache:
-            cache[key] = HipConvexifier(p, nx, mb, **kw)
-        return cache[key]
+    def get(p, nx, mb, chunk, **kw):
+        made.append(HipConvexifier(p, nx, mb, chunk=chunk, **kw))
+        return made[-1]
     yield get
-    for h in cache.values():
+    for h in made:
         h.close()
 
 
@@ -78,7 +78,7 @@ def test_rows_models_at_the_bench_shape(hc):
     A, B, H = synthetic.gen_batch(61000, nb, p, nx, mb)
     G, C, ncnt = _rows(61, nb, p, nx + mb, ng, nc)
     J = np.concatenate([G, C], axis=2)
-    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h = hc(p, nx, mb, nb, ng=ng, nc=nc)
     eq = h.convexify_eq_batch(A, B, H, G)
     w = _compare(eq, cpu_ipm.convexify_con_batch(A, B, H, G, ng=ng, threads=HOST_THREADS), range(nb), ng, None, 'G')
     print(f'bench shape, Step 1 with G: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg {w["F"]:.2e}; iterations {eq["iters"].min()}..{eq["iters"].max()}')
@@ -97,7 +97,7 @@ def test_rows_models_at_the_c5_share(hc):
     A, B, H = synthetic.gen_batch(62000, nb, p, nx, mb)
     G, C, ncnt = _rows(62, nb, p, nx + mb, ng, nc)
     J = np.concatenate([G, C], axis=2)
-    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h = hc(p, nx, mb, nb, ng=ng, nc=nc)
     dev = torch.device('cuda', 0)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     for what, Jd, nd, kw in (('G', G, None, {}), ('step2', J, ncnt, dict(rho=1e-2))):
@@ -118,7 +118,7 @@ def test_rows_models_at_the_c3_shape_batch_256(hc):
     A, B, H = co.gen_batch(63000, nb, p, nx, mb)
     G, C, ncnt = _rows(63, nb, p, nx + mb, ng, nc)
     J = np.concatenate([G, C], axis=2)
-    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h = hc(p, nx, mb, nb, ng=ng, nc=nc)
     eq = h.convexify_eq_batch(A, B, H, G)
     w = _compare(eq, cpu_ipm.convexify_con_batch(A, B, H, G, ng=ng, threads=HOST_THREADS), range(nb), ng, None, 'c3 G')
     print(f'c3 shape batch 256, Step 1 with G: worst Hc {w["Hc"]:.2e}  P {w["P"]:.2e}  Fg {w["F"]:.2e}')
@@ -138,11 +138,11 @@ def test_step3_against_cpu_ipm_beyond_the_oracle_sizes(hc, p, nx, mb, ng, nc, nb
     if ng + nc:
         G, C, ncnt = _rows(64, nb, p, n, ng, nc)
         J = np.concatenate([G, C], axis=2)
-        o = hc(p, nx, mb, ng=ng, nc=nc, step3=True).convexify_step3_con_batch(A, B, H, J, ncnt, rho)
+        o = hc(p, nx, mb, nb, ng=ng, nc=nc, step3=True).convexify_step3_con_batch(A, B, H, J, ncnt, rho)
         ref = cpu_ipm.convexify_con_batch(A, B, H, J, ng=ng, ncnt=ncnt, rho=rho, force=True, threads=HOST_THREADS)
         w = _compare(o, ref, range(nb), ng, ncnt, 'step3 with rows')
     else:
-        o = hc(p, nx, mb, step3=True).convexify_step3_batch(A, B, H, rho)
+        o = hc(p, nx, mb, nb, step3=True).convexify_step3_batch(A, B, H, rho)
         ref = cpu_ipm.convexify_con_batch(A, B, H, rho=rho, force=True, threads=HOST_THREADS)
         w = dict(Hc=0.0, P=0.0)
         for b in range(nb):
@@ -164,7 +164,7 @@ def test_awe_shape_step2_golden(hc, golden_dir):
     mb = B.shape[3]; ng = G.shape[2]; nc = C.shape[2]
     assert (p, nx, mb, ng) == (40, 9, 6, 3)
     J = np.concatenate([G, C], axis=2)
-    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h = hc(p, nx, mb, nb, ng=ng, nc=nc)
     for tag in ('', '_tight'):
         h.set_tight(bool(tag), float(g['tight_tol']))
         o = h.convexify_step2_batch(A, B, H, J, ncnt, rho)
@@ -190,7 +190,7 @@ def test_tight_mode_with_rows_against_cpu_ipm_tight(hc, p, nx, mb, ng, nc, nb):
     A, B, H = synthetic.gen_batch(65000, nb, p, nx, mb)
     G, C, ncnt = _rows(65, nb, p, n, ng, nc)
     J = np.concatenate([G, C], axis=2)
-    h = hc(p, nx, mb, ng=ng, nc=nc)
+    h = hc(p, nx, mb, nb, ng=ng, nc=nc)
     h.set_tight(True, 2.0 ** -37)
     o = h.convexify_step2_batch(A, B, H, J, ncnt, 1e-2)
     h.set_tight(False)

@@ -607,7 +607,7 @@ static void cr_factor(const WS& w, const Dims& dm, const CrSched& sc, const int*
     }
     else if (mf) { hipLaunchKernelGGL((k_cr_update<true, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt); mark(2); mark(3); mark(3); }
     else { hipLaunchKernelGGL((k_cr_update<false, 2>), dim3(cr_grid(it_upd)), dim3(256), factor_lds(), st, w, dm, cd, lv.eoff, lv.nelim, lv.uoff, lv.nupd, count, mt); mark(2); mark(3); mark(3); }
-    // problems whose update tiles ran in single precision carried no right-hand sides: their z_s -= O_s z_i of the fused forward sweep, in fp64 from the fp64 O blocks
+    // problems whose update tiles ran in single precision carried no right-hand sides: their z_s -= O_s z_i of the fused forward sweep here, fp64 products on the float32 O copies (k_cr_fwd_off with lowp_only: the other problems are skipped)
     if (fuse_fwd1 && nlowp > 0 && mf && use_dma && lv.nupd)
       hipLaunchKernelGGL(k_cr_fwd_off, dim3(cr_grid((long)count * lv.nupd)), dim3(256), solve_lds(dm), st, w, dm, cd, lv.uoff, lv.nupd, count, 1, 1);
   }

@@ -495,7 +495,7 @@ __device__ __forceinline__ void ctrl_d_body(const WS& w, const Dims& dm, const O
       if (ip[I_BACKOFF] < MUT_BACKOFF_MAX) { pr[P_MUT] *= 2.0; ip[I_BACKOFF] += 1; ip[I_NCENT] = 0; ip[I_REG] = 0; full_reset = true; }
       else { ip[I_PHASE] = PH_DONE; ip[I_IPMSTATUS] = IPM_INACCURATE; }
     }
-    else if (o.chord_step > 0.0 && full && ip[I_REG] == 0) {
+    else if (o.chord_step > 0.0 && full && ip[I_REG] == 0 && !ip[I_LOWP]) {      // (never on a factorisation with single-precision updates: its fp64 O blocks were not written, and the decision below has not replaced I_LOWP yet -- unreachable by the numbers, the switch sits far above 2 mu_t, but cheap to rule out)
       // Chord steps: the last step moved the iterate by less than 1/chord_step in the local norm, so the Schur matrix at the new
       // iterate differs from the factored one by about that much and Newton with the OLD factorisation still contracts by that
       // factor per step -- at a fifth of the cost.  A chord step that contracts by less than 1/4 goes back to a fresh factorisation.
