@@ -747,6 +747,11 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       for (size_t e = 0; e < PN; ++e) xs_aff += (X1[e] + ap * dX1[e]) * (S1[e] + ad * dS1[e]) + (X2[e] + ap * dX2[e]) * (S2[e] + ad * dS2[e]);
       const double rat = (xs_aff / N) / mu;
       double sigma = std::min(std::max(rat * rat, 1e-6), 1.0);
+      if (const char* ev_ = getenv("CPU_IPM_SIGMA_EXP")) {      // experiment hook (tests/tools/sigma_rule_probe.py): other centering rules, iteration counts only
+        const double e_ = atof(ev_);
+        if (e_ > 0.0) sigma = std::min(std::max(pow(rat, e_), 1e-6), 1.0);
+        else { const double am_ = std::min(ap, ad); const double ee_ = std::max(1.0, 3.0 * am_ * am_); sigma = std::min(std::max(pow(rat, ee_), 1e-6), 1.0); }      // SDPT3's adaptive exponent
+      }
       double sig_mu = sigma * mu;
       if (mu_t > 0.0) sig_mu = std::max(sig_mu, mu_t);
       for (int k = 0; k < p; ++k) {
@@ -757,7 +762,8 @@ Result solve_problem(int p, int nx, int mb, const double* A, const double* B, co
       const double corr0 = dx0 * ds0 / s0;
       direction(sig_mu, true, corr0);
       steps(ap, ad);
-      const double gam = 0.9 + 0.09 * std::min(std::min(ap, ad), 1.0);
+      double gam = 0.9 + 0.09 * std::min(std::min(ap, ad), 1.0);
+      if (const char* ev_ = getenv("CPU_IPM_GAMMA_MAX")) gam = 0.9 + (atof(ev_) - 0.9) * std::min(std::min(ap, ad), 1.0);
       ap = std::min(1.0, gam * ap); ad = std::min(1.0, gam * ad);
     } else {
       ++ncent;
