@@ -107,3 +107,28 @@ def test_frozen_pivot_under_single_precision_falls_back_per_problem():
     # (iteration counts on such inputs differ in both directions -- the back-off path of a hard target is sensitive to every rounding, DESIGN.md section 3 / NOTEBOOK 3:
     # no bound is asserted on them; the cap of the loop is what protects a caller)
     assert on['iters'].max() <= 50 + 12 * 11 + 2
+
+
+def test_drop_in_entry_points_take_the_module_switch(monkeypatch):
+    """tunempc_amd.convexifier.LOWP_SWITCH (None: library default, 0: fp64 throughout) reaches the cached handles of convexify_batch: with 0 no factorisation
+    runs in single precision and the answer is the all-fp64 one; with the default some do and the answer agrees to the parity bar."""
+    from tunempc_amd import convexifier as cv, synthetic
+    from tunempc_amd._lib import FLAG_PROFILE
+    p, nx, mb, nb = 8, 16, 4, 3
+    A, B, H = synthetic.gen_batch(66000, nb, p, nx, mb)
+    outs = {}
+    for sw in (None, 0.0):
+        monkeypatch.setattr(cv, 'LOWP_SWITCH', sw)
+        h = cv._handle(p, nx, mb, 0, 0, nb)
+        h.set_options(flags=FLAG_PROFILE)
+        h.profile()
+        outs[sw] = cv.convexify_batch(A, B, H, handle=h)
+        nlow = h.profile()['lowp_factorisations']
+        h.set_options(flags=0)
+        assert (nlow > 0) == (sw is None), (sw, nlow)
+    cv.release_handles()
+    assert (outs[None]['status'] == 0).all() and (outs[0.0]['status'] == 0).all()
+    e = np.linalg.norm(outs[None]['Hc'] - outs[0.0]['Hc']) / np.linalg.norm(outs[0.0]['Hc'])
+    print(f'drop-in entry: float32 updates on / off differ by {e:.2e}')
+    assert e < 1e-8
+

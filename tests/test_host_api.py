@@ -258,6 +258,7 @@ def test_tight_calls_take_handles_of_their_own(monkeypatch):
             made.append(self)
 
         def set_options(self, **kw): pass
+        def set_tuning(self, **kw): self.tuning = kw
         def set_tight(self, on, tol=None): self.calls.append(('tight', bool(on)))
         def close(self): self.calls.append(('close',))
 
@@ -288,6 +289,11 @@ def test_tight_calls_take_handles_of_their_own(monkeypatch):
     cv.convexify_step2_batch(A, B, H, C, cnt, 1e-3, G=G, tight=True)
     h_s2 = made[-1]
     assert h_s2 is not shared and (h_s2.ng, h_s2.nc) == (ng, nc) and h_s2.calls == [('tight', True), ('step2',), ('tight', False)]
+    assert h_s2.tuning == dict(lowp_switch=cv.LOWP_SWITCH_DEFAULT)             # every fetch sets the switch of the single-precision updates: the library default ...
+    monkeypatch.setattr(cv, 'LOWP_SWITCH', 0.0)
+    cv.convexify_step2_batch(A, B, H, C, cnt, 1e-3, G=G, tight=True)
+    assert made[-1] is h_s2 and h_s2.tuning == dict(lowp_switch=0.0)            # ... or the module's (0: fp64 throughout), also on a cached handle
+    monkeypatch.setattr(cv, 'LOWP_SWITCH', None)
     n_made = len(made)
     cv.convexify_batch(A, B, H, G=G, tight=True)                              # cached: the same handle again
     assert len(made) == n_made and h_eq.calls[-3:] == [('tight', True), ('eq',), ('tight', False)]

@@ -31,6 +31,13 @@ N_TUNED, N_ROWS_MAX, N_MAX = 32, 64, 96          # stage-block sizes: tuned kern
 NC_MAX = 31      # active-constraint rows per stage in Step 2 (tmpc_common.h: NCM)
 
 
+# Mixed precision of the drop-in entry points (round 6; include/tunempc_hip.h: TMPC_TUNE_LOWP_SWITCH).  None: the library default -- the Schur-complement updates of
+# a problem's early main-phase iterations (barrier parameter above 1e-5 kappa) run on the fp32 matrix cores, everything that defines the returned point stays fp64.
+# 0.0: fp64 throughout (the arithmetic of rounds 1-5, bit for bit).  A module attribute, not an `opts` key: the reference's opts (convexifier.py:36) know nothing of it.
+LOWP_SWITCH = None
+LOWP_SWITCH_DEFAULT = 1e-5      # TMPC_LOWP_SWITCH_DEFAULT
+
+
 def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False, exact=False):
     """One cached handle per problem shape.  Its workspace is sized for the batch actually asked for (next power of two of nb,
     at most _MAX_CHUNK), not for the 60 %-of-free-HBM default of tmpc_create: a single-problem convexify() at nx=24, p=64
@@ -65,6 +72,7 @@ def _handle(p, nx, mb, ng=0, nc=0, nb=1, step3=False, plain=False, exact=False):
             _HANDLES.pop(next(iter(_HANDLES))).close()
         h = HipConvexifier(p, nx, mb, chunk=want, ng=ng, nc=nc, step3=step3)
     _HANDLES[key] = h           # most recently used last
+    h.set_tuning(lowp_switch=LOWP_SWITCH_DEFAULT if LOWP_SWITCH is None else float(LOWP_SWITCH))      # (every fetch: a cached handle must not keep an earlier setting)
     return h
 
 
