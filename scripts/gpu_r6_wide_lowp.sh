@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 6: single-precision updates on the wide blocks (32 < n <= 64): large-block parity tests, then the large-block bench legs with the updates on / off
+# round 6 experiment (profiles/r6_wide_block_lowp_experiment.txt; run with a patch that is NOT in the product: O32 carved for n <= 64 at any block width, a conversion kernel behind
+# the register-staged k_cr_trsm, the nt <= TRR_NT gate of run_chunk dropped): large-block parity tests, then the large-block shapes with the updates on / off.
+# On the product the switch is ignored for these shapes and the two settings time the same.
 export TMPDIR=/tmp; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_tight.py -m gpu -q -p no:cacheprovider -x -k "large or generic or widest or n48 or wide" < /dev/null 2>&1 | tail -n 6
 timeout 900 python - <<'PY' 2>&1 | tail -n 12
